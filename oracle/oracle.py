@@ -1,0 +1,405 @@
+"""ctypes wrapper of the CPU oracle (oracle/libdvoracle.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by anything under deepvariant_amd/.
+
+Accepts proto-shaped objects (deepvariant_amd.dv_types dataclasses or real
+protobuf messages with the same attribute names) and hands them to the C++
+restatement in encoder_oracle.cpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libdvoracle.so')
+DVO_MAX_CHANNELS = 32
+
+
+def build(force: bool = False) -> str:
+  """Compiles the oracle with the committed Makefile (g++)."""
+  src = os.path.join(_HERE, 'encoder_oracle.cpp')
+  if (force or not os.path.exists(_LIB_PATH) or
+      os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+    subprocess.check_call(['make', '-C', _HERE, 'libdvoracle.so'],
+                          stdout=subprocess.DEVNULL)
+  return _LIB_PATH
+
+
+class DvoOptions(C.Structure):
+  _fields_ = [
+      ('width', C.c_int32), ('height', C.c_int32),
+      ('reference_band_height', C.c_int32), ('n_channels', C.c_int32),
+      ('channels', C.c_int32 * DVO_MAX_CHANNELS),
+      ('base_color_offset_a_and_g', C.c_int32),
+      ('base_color_offset_t_and_c', C.c_int32),
+      ('base_color_stride', C.c_int32),
+      ('allele_supporting_read_alpha', C.c_float),
+      ('allele_unsupporting_read_alpha', C.c_float),
+      ('other_allele_supporting_read_alpha', C.c_float),
+      ('reference_matching_read_alpha', C.c_float),
+      ('reference_mismatching_read_alpha', C.c_float),
+      ('indel_anchoring_base_char', C.c_int32),
+      ('reference_base_quality', C.c_int32),
+      ('positive_strand_color', C.c_int32),
+      ('negative_strand_color', C.c_int32),
+      ('base_quality_cap', C.c_int32), ('mapping_quality_cap', C.c_int32),
+      ('min_base_quality', C.c_int32), ('min_mapping_quality', C.c_int32),
+      ('random_seed', C.c_uint32),
+      ('sort_by_haplotypes', C.c_int32),
+      ('hp_tag_for_assembly_polishing', C.c_int32),
+      ('sort_by_alt_allele_support', C.c_int32),
+      ('min_non_zero_allele_frequency', C.c_float),
+  ]
+
+
+class DvoRead(C.Structure):
+  _fields_ = [
+      ('fragment_name', C.c_char_p), ('read_number', C.c_int32),
+      ('position', C.c_int64), ('mapping_quality', C.c_int32),
+      ('reverse_strand', C.c_int32), ('supplementary', C.c_int32),
+      ('fragment_length', C.c_int32),
+      ('seq', C.c_char_p), ('seq_len', C.c_int32),
+      ('qual', C.POINTER(C.c_uint8)), ('qual_len', C.c_int32),
+      ('cigar_ops', C.POINTER(C.c_int32)),
+      ('cigar_lens', C.POINTER(C.c_int64)), ('n_cigar', C.c_int32),
+      ('hp_present', C.c_int32), ('hp_n_values', C.c_int32),
+      ('hp_is_int', C.c_int32), ('hp_value', C.c_int32),
+      ('mod_5mc', C.POINTER(C.c_uint8)), ('mod_5mc_len', C.c_int32),
+      ('mod_6ma', C.POINTER(C.c_uint8)), ('mod_6ma_len', C.c_int32),
+  ]
+
+
+class DvoCall(C.Structure):
+  _fields_ = [
+      ('variant_start', C.c_int64),
+      ('n_alts', C.c_int32), ('alts', C.POINTER(C.c_char_p)),
+      ('n_support', C.c_int32), ('support_alleles', C.POINTER(C.c_char_p)),
+      ('support_offsets', C.POINTER(C.c_int32)),
+      ('support_names', C.POINTER(C.c_char_p)),
+      ('n_af', C.c_int32), ('af_alleles', C.POINTER(C.c_char_p)),
+      ('af_values', C.POINTER(C.c_float)),
+      ('n_ref_support', C.c_int32),
+  ]
+
+
+class DvoPackedBatch(C.Structure):
+  _fields_ = [
+      ('n_reads', C.c_int32),
+      ('read_pos', C.c_void_p), ('read_sort_pos', C.c_void_p),
+      ('read_seq_off', C.c_void_p), ('read_cigar_off', C.c_void_p),
+      ('read_mapq', C.c_void_p), ('read_flags', C.c_void_p),
+      ('read_frag_len', C.c_void_p), ('read_hp', C.c_void_p),
+      ('read_name_rank', C.c_void_p),
+      ('bases', C.c_void_p), ('quals', C.c_void_p),
+      ('mod_5mc', C.c_void_p), ('mod_6ma', C.c_void_p),
+      ('cigar', C.c_void_p),
+      ('n_items', C.c_int32),
+      ('item_variant_start', C.c_void_p), ('item_image_start', C.c_void_p),
+      ('item_ref_idx', C.c_void_p), ('item_list_off', C.c_void_p),
+      ('item_height', C.c_void_p), ('item_out_off', C.c_void_p),
+      ('ref_windows', C.c_void_p),
+      ('list_read', C.c_void_p), ('list_code', C.c_void_p),
+      ('list_group', C.c_void_p),
+  ]
+
+
+_lib = None
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    build()
+    _lib = C.CDLL(_LIB_PATH)
+    _lib.dvo_last_error.restype = C.c_char_p
+    _lib.dvo_channel_str_to_enum.argtypes = [C.c_char_p]
+  return _lib
+
+
+class OracleError(RuntimeError):
+  pass
+
+
+def _err():
+  return OracleError(lib().dvo_last_error().decode())
+
+
+def channel_str_to_enum(name: str) -> int:
+  v = lib().dvo_channel_str_to_enum(name.encode())
+  if v < 0:
+    raise OracleError("Channel '%s' should have a corresponding enum" % name)
+  return v
+
+
+def make_options(pic_options) -> DvoOptions:
+  """PileupImageOptions -> dvo_options (AllChannelsEnum(""))."""
+  o = DvoOptions()
+  chans = [channel_str_to_enum(c) for c in pic_options.channels]
+  chans = [c for c in chans if c != 0]
+  if len(chans) > DVO_MAX_CHANNELS:
+    raise OracleError('too many channels')
+  o.n_channels = len(chans)
+  for i, c in enumerate(chans):
+    o.channels[i] = c
+  for f in ('width', 'height', 'reference_band_height',
+            'base_color_offset_a_and_g', 'base_color_offset_t_and_c',
+            'base_color_stride', 'allele_supporting_read_alpha',
+            'allele_unsupporting_read_alpha',
+            'other_allele_supporting_read_alpha',
+            'reference_matching_read_alpha', 'reference_mismatching_read_alpha',
+            'reference_base_quality', 'positive_strand_color',
+            'negative_strand_color', 'base_quality_cap', 'mapping_quality_cap',
+            'random_seed', 'hp_tag_for_assembly_polishing',
+            'min_non_zero_allele_frequency'):
+    setattr(o, f, getattr(pic_options, f))
+  o.sort_by_haplotypes = int(bool(pic_options.sort_by_haplotypes))
+  o.sort_by_alt_allele_support = int(
+      bool(getattr(pic_options, 'sort_by_alt_allele_support', False)))
+  ch = pic_options.indel_anchoring_base_char
+  o.indel_anchoring_base_char = ord(ch[0]) if ch else 0
+  o.min_base_quality = pic_options.read_requirements.min_base_quality
+  o.min_mapping_quality = pic_options.read_requirements.min_mapping_quality
+  return o
+
+
+class _Keep:
+  """Keeps ctypes buffers alive for the duration of a call."""
+
+  def __init__(self):
+    self.refs = []
+
+  def __call__(self, x):
+    self.refs.append(x)
+    return x
+
+
+def _hp_fields(read):
+  info = read.info
+  present = 'HP' in info
+  if not present:
+    return 0, 0, 0, 0
+  values = info['HP'].values
+  n = len(values)
+  if n == 0:
+    return 1, 0, 0, 0
+  v0 = values[0]
+  is_int = v0.WhichOneof('kind') == 'int_value'
+  return 1, n, int(is_int), int(v0.int_value or 0) if is_int else 0
+
+
+def _fill_read(dst: DvoRead, read, keep: _Keep):
+  dst.fragment_name = keep(read.fragment_name.encode())
+  dst.read_number = read.read_number
+  dst.position = read.alignment.position.position
+  dst.mapping_quality = read.alignment.mapping_quality
+  dst.reverse_strand = int(bool(read.alignment.position.reverse_strand))
+  dst.supplementary = int(bool(getattr(read, 'supplementary_alignment', False)))
+  dst.fragment_length = read.fragment_length
+  seq = read.aligned_sequence
+  seq_b = keep(seq.encode() if isinstance(seq, str) else bytes(seq))
+  dst.seq = seq_b
+  dst.seq_len = len(seq_b)
+  qual = keep(np.ascontiguousarray(
+      np.frombuffer(bytes(bytearray(read.aligned_quality)), dtype=np.uint8)
+      if not isinstance(read.aligned_quality, np.ndarray)
+      else read.aligned_quality.astype(np.uint8)))
+  dst.qual = qual.ctypes.data_as(C.POINTER(C.c_uint8))
+  dst.qual_len = len(qual)
+  cig = read.alignment.cigar
+  ops = keep(np.array([int(c.operation) for c in cig], dtype=np.int32))
+  lens = keep(np.array([int(c.operation_length) for c in cig], dtype=np.int64))
+  dst.cigar_ops = ops.ctypes.data_as(C.POINTER(C.c_int32))
+  dst.cigar_lens = lens.ctypes.data_as(C.POINTER(C.c_int64))
+  dst.n_cigar = len(ops)
+  (dst.hp_present, dst.hp_n_values, dst.hp_is_int,
+   dst.hp_value) = _hp_fields(read)
+  mods = getattr(read, 'base_modifications', None) or {}
+  for key, pfield, lfield in (('5mC', 'mod_5mc', 'mod_5mc_len'),
+                              ('6mA', 'mod_6ma', 'mod_6ma_len')):
+    if key in mods:
+      arr = keep(np.frombuffer(bytes(mods[key]), dtype=np.uint8).copy())
+      setattr(dst, pfield, arr.ctypes.data_as(C.POINTER(C.c_uint8)))
+      setattr(dst, lfield, len(arr))
+    else:
+      setattr(dst, pfield, None)
+      setattr(dst, lfield, -1)
+
+
+def _str_array(strings: Sequence[str], keep: _Keep):
+  arr = (C.c_char_p * max(len(strings), 1))()
+  for i, s in enumerate(strings):
+    arr[i] = keep(s.encode())
+  return keep(arr)
+
+
+def _make_call(dv_call, keep: _Keep) -> DvoCall:
+  c = DvoCall()
+  c.variant_start = dv_call.variant.start
+  alts = list(dv_call.variant.alternate_bases)
+  c.n_alts = len(alts)
+  c.alts = _str_array(alts, keep)
+  alleles = list(dv_call.allele_support.keys())
+  names: List[str] = []
+  offs = [0]
+  for a in alleles:
+    names.extend(dv_call.allele_support[a].read_names)
+    offs.append(len(names))
+  c.n_support = len(alleles)
+  c.support_alleles = _str_array(alleles, keep)
+  offs_arr = keep(np.array(offs, dtype=np.int32))
+  c.support_offsets = offs_arr.ctypes.data_as(C.POINTER(C.c_int32))
+  c.support_names = _str_array(names, keep)
+  af = getattr(dv_call, 'allele_frequency', None) or {}
+  af_keys = list(af.keys())
+  c.n_af = len(af_keys)
+  c.af_alleles = _str_array(af_keys, keep)
+  af_vals = keep(np.array([af[k] for k in af_keys] or [0], dtype=np.float32))
+  c.af_values = af_vals.ctypes.data_as(C.POINTER(C.c_float))
+  c.n_ref_support = len(getattr(dv_call, 'ref_support', []) or [])
+  return c
+
+
+def _blank_array(channels_to_blank, keep: _Keep):
+  arr = keep(np.array(list(channels_to_blank or []) or [0], dtype=np.int32))
+  return arr.ctypes.data_as(C.POINTER(C.c_int32)), len(channels_to_blank or [])
+
+
+def encode_reference(pic_options, ref_bases: str) -> np.ndarray:
+  """-> uint8 [1, W, C] like the pybind `encode_reference`."""
+  o = make_options(pic_options)
+  w = len(ref_bases)
+  out = np.zeros((1, w, o.n_channels), dtype=np.uint8)
+  rc = lib().dvo_encode_reference(C.byref(o), ref_bases.encode(), w,
+                                  out.ctypes.data_as(C.c_void_p))
+  if rc != 0:
+    raise _err()
+  return out
+
+
+def encode_read(pic_options, dv_call, ref_bases: str, read, image_start_pos,
+                alt_alleles, channels_to_blank=None) -> Optional[np.ndarray]:
+  """-> uint8 [1, W, C] or None (rejected read)."""
+  keep = _Keep()
+  o = make_options(pic_options)
+  w = len(ref_bases)
+  out = np.zeros((1, w, o.n_channels), dtype=np.uint8)
+  r = DvoRead()
+  _fill_read(r, read, keep)
+  call = _make_call(dv_call, keep)
+  alts = _str_array(list(alt_alleles), keep)
+  blank, n_blank = _blank_array(channels_to_blank, keep)
+  rc = lib().dvo_encode_read(C.byref(o), C.byref(call), ref_bases.encode(), w,
+                             C.byref(r), C.c_int32(image_start_pos), alts,
+                             len(alt_alleles), blank, n_blank,
+                             out.ctypes.data_as(C.c_void_p))
+  if rc < 0:
+    raise _err()
+  return out if rc == 1 else None
+
+
+def build_pileup(pic_options, dv_call, ref_bases: str, reads, image_start_pos,
+                 alt_alleles, pileup_height=0, mean_coverage=0.0,
+                 alignment_positions=None, channels_to_blank=None,
+                 return_row_reads=False):
+  """BuildPileupForOneSample + FillPileupArray -> uint8 [H, W, C]."""
+  keep = _Keep()
+  o = make_options(pic_options)
+  w = len(ref_bases)
+  h = pileup_height or pic_options.height
+  out = np.zeros((h, w, o.n_channels), dtype=np.uint8)
+  row_read = np.full((h,), -1, dtype=np.int32)
+  arr = (DvoRead * max(len(reads), 1))()
+  for i, rd in enumerate(reads):
+    _fill_read(arr[i], rd, keep)
+  call = _make_call(dv_call, keep)
+  alts = _str_array(list(alt_alleles), keep)
+  blank, n_blank = _blank_array(channels_to_blank, keep)
+  ap = None
+  if alignment_positions is not None and len(alignment_positions):
+    ap_arr = keep(np.array(alignment_positions, dtype=np.int64))
+    ap = ap_arr.ctypes.data_as(C.POINTER(C.c_int64))
+  rc = lib().dvo_build_pileup(
+      C.byref(o), C.byref(call), ref_bases.encode(), w, arr, len(reads),
+      C.c_int32(image_start_pos), alts, len(alt_alleles), pileup_height,
+      C.c_float(mean_coverage), ap, blank, n_blank,
+      out.ctypes.data_as(C.c_void_p), row_read.ctypes.data_as(C.c_void_p))
+  if rc < 0:
+    raise _err()
+  if return_row_reads:
+    return out, rc, row_read
+  return out
+
+
+def downsample_indices(n: int, max_reads: int, seed: int) -> np.ndarray:
+  out = np.zeros((max(n, 1),), dtype=np.int32)
+  lib().dvo_downsample_indices(n, max_reads, C.c_uint32(seed),
+                               out.ctypes.data_as(C.c_void_p))
+  return out[:n]
+
+
+def read_overlaps(read, start: int, end: int) -> bool:
+  keep = _Keep()
+  r = DvoRead()
+  _fill_read(r, read, keep)
+  return bool(lib().dvo_read_overlaps(C.byref(r), C.c_int64(start),
+                                      C.c_int64(end)))
+
+
+def encode_packed(pic_options, batch, out_channels=None, n_threads=1):
+  """Runs the oracle over a packed batch (deepvariant_amd.packing.PackedBatch).
+
+  Returns (images uint8 [total_bytes], rows int32 [n_items]).
+  """
+  o = make_options(pic_options)
+  c_total = out_channels or o.n_channels
+  b = DvoPackedBatch()
+  keep = []
+
+  def ptr(a, dtype):
+    if a is None:
+      return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(a)
+    return a.ctypes.data
+
+  b.n_reads = batch.n_reads
+  b.read_pos = ptr(batch.read_pos, np.int32)
+  b.read_sort_pos = ptr(batch.read_sort_pos, np.int32)
+  b.read_seq_off = ptr(batch.read_seq_off, np.uint32)
+  b.read_cigar_off = ptr(batch.read_cigar_off, np.uint32)
+  b.read_mapq = ptr(batch.read_mapq, np.uint8)
+  b.read_flags = ptr(batch.read_flags, np.uint8)
+  b.read_frag_len = ptr(batch.read_frag_len, np.int32)
+  b.read_hp = ptr(batch.read_hp, np.int32)
+  b.read_name_rank = ptr(batch.read_name_rank, np.uint32)
+  b.bases = ptr(batch.bases, np.uint8)
+  b.quals = ptr(batch.quals, np.uint8)
+  b.mod_5mc = ptr(batch.mod_5mc, np.uint8)
+  b.mod_6ma = ptr(batch.mod_6ma, np.uint8)
+  b.cigar = ptr(batch.cigar, np.uint32)
+  b.n_items = batch.n_items
+  b.item_variant_start = ptr(batch.item_variant_start, np.int32)
+  b.item_image_start = ptr(batch.item_image_start, np.int32)
+  b.item_ref_idx = ptr(batch.item_ref_idx, np.uint32)
+  b.item_list_off = ptr(batch.item_list_off, np.uint32)
+  b.item_height = ptr(batch.item_height, np.uint16)
+  b.item_out_off = ptr(batch.item_out_off, np.uint64)
+  b.ref_windows = ptr(batch.ref_windows, np.uint8)
+  b.list_read = ptr(batch.list_read, np.uint32)
+  b.list_code = ptr(batch.list_code, np.uint8)
+  b.list_group = ptr(batch.list_group, np.uint8)
+  total = batch.out_bytes(c_total)
+  out = np.zeros((total,), dtype=np.uint8)
+  rows = np.zeros((max(batch.n_items, 1),), dtype=np.int32)
+  rc = lib().dvo_encode_packed(C.byref(o), C.byref(b), c_total,
+                               out.ctypes.data_as(C.c_void_p),
+                               rows.ctypes.data_as(C.c_void_p), n_threads)
+  if rc != 0:
+    raise _err()
+  return out, rows[:batch.n_items]

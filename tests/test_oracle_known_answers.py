@@ -1,0 +1,187 @@
+"""Pins the CPU oracle to the reference's own known-answer vectors (CPU only)."""
+import numpy as np
+import pytest
+
+from tests import known_answers as KA
+from tests.oracle_adapter import make
+from oracle import oracle as O
+from deepvariant_amd import dv_types as T
+
+
+def test_reference_encoding():
+  KA.check_reference_encoding(make)
+
+
+def test_encode_read_matches():
+  KA.check_encode_read_matches(make)
+
+
+@pytest.mark.parametrize('hp_value,hp_color,polishing', KA.HP_CASES)
+def test_encode_read_hp_channel(hp_value, hp_color, polishing):
+  KA.check_encode_read_hp_channel(make, hp_value, hp_color, polishing)
+
+
+def test_encode_read_allele_frequency():
+  KA.check_encode_read_allele_frequency(make)
+
+
+@pytest.mark.parametrize('s,e', KA.SPANS2_CASES)
+def test_encode_read_spans2(s, e):
+  KA.check_encode_read_spans2(make, s, e)
+
+
+def test_encode_read_deletion():
+  KA.check_encode_read_deletion(make)
+
+
+def test_encode_read_insertion():
+  KA.check_encode_read_insertion(make)
+
+
+@pytest.mark.parametrize('bq,mq', KA.QUAL_GRID)
+def test_quality_gates(bq, mq):
+  KA.check_ignores_low_quality_bases(make, bq, mq)
+  KA.check_keeps_low_quality_bases(make, bq, mq)
+  KA.check_ignores_low_mapping_quality(make, bq, mq)
+
+
+@pytest.mark.parametrize('case', KA.READ_SUPPORT_CASES)
+def test_read_support_is_respected(case):
+  KA.check_read_support_is_respected(make, *case)
+
+
+@pytest.mark.parametrize('case', KA.MULTIALLELIC_CASES)
+def test_read_support_multiallelic(case):
+  KA.check_read_support_multiallelic(make, *case)
+
+
+@pytest.mark.parametrize('case', KA.CUSTOM_CHANNEL_CASES)
+def test_custom_channels(case):
+  KA.check_custom_channel(make, *case)
+
+
+def test_custom_multi():
+  KA.check_custom_multi(make)
+
+
+@pytest.mark.parametrize('seq,exp', KA.GC_CASES)
+def test_gc_content(seq, exp):
+  KA.check_gc_content(make, seq, exp)
+
+
+@pytest.mark.parametrize('seq,exp', KA.IS_HOMOPOLYMER_CASES)
+def test_is_homopolymer(seq, exp):
+  KA.check_is_homopolymer(make, seq, exp)
+
+
+@pytest.mark.parametrize('seq,exp', KA.WEIGHTED_HOMOPOLYMER_CASES)
+def test_weighted_homopolymer(seq, exp):
+  KA.check_weighted_homopolymer(make, seq, exp)
+
+
+@pytest.mark.parametrize('name', sorted(KA.BUILD_PILEUP_CASES))
+def test_build_pileup(name):
+  KA.check_build_pileup_case(make, name)
+
+
+@pytest.mark.parametrize('blank', [
+    [], [T.DeepVariantChannelEnum.CH_READ_BASE],
+    [T.DeepVariantChannelEnum.CH_READ_BASE,
+     T.DeepVariantChannelEnum.CH_MAPPING_QUALITY]])
+def test_get_channel_data(blank):
+  def enc(options, dv_call, ref, read, start, alts, blank):
+    return O.encode_read(options, dv_call, ref, read, start, alts,
+                         [int(b) for b in blank])
+  KA.check_get_channel_data(enc, blank)
+
+
+def test_get_ref_channel_data():
+  # pileup_channel_lib_test.cc:851-930 (GetRefChannelDataTest) core values.
+  o = KA.get_channel_data_options()
+  o.reference_base_quality = 20
+  row = O.encode_reference(o, 'GGGCGCTTTTATN')[0]
+  idx = {n: i for i, n in enumerate(KA.GET_CHANNEL_DATA_CHANNELS)}
+  assert row[11, idx['read_base']] == 2 and row[1, idx['read_base']] == 3
+  assert row[1, idx['base_quality']] == 254
+  assert row[1, idx['mapping_quality']] == 254
+  assert row[1, idx['strand']] == 20
+  assert row[1, idx['read_supports_variant']] == 254
+  assert row[1, idx['base_differs_from_ref']] == 254
+  assert row[1, idx['insert_size']] == 254
+  assert row[1, idx['blank']] == 0
+  assert row[1, idx['supplementary_alignment']] == 1  # uint8(alpha=1.0)
+
+
+def test_scalar_channel_values():
+  # pileup_channel_lib_test.cc: ReadMappingPercent 5M5D -> 50, Identity
+  # 5M1I4M -> 90, GapCompressedIdentity 3M4I3M -> 85, 3=2X2I3= -> 66,
+  # AvgBaseQuality 1..10 -> 5, InsertSize 22 -> 5, 1001 -> 254, unset -> 0.
+  def pix(channel, cigar, seq='AAAAATTTTT', quals=None, frag=None):
+    o = KA.default_options([channel],
+                           read_requirements=T.ReadRequirements())
+    o.width = 21
+    read = T.make_read(seq, start=1, cigar=cigar,
+                       quals=quals or [30] * len(seq), fragment_length=frag)
+    ref = 'N' * 21
+    row = O.encode_read(o, T.DeepVariantCall(), ref, read, 0, [])
+    return int(row[0, 1, 0])
+  sc = lambda v, m: int(np.float32(254.0) * (np.float32(v) / np.float32(m)))
+  assert pix('read_mapping_percent', '5M5D') == sc(50, 100)
+  assert pix('identity', '5M1I4M') == sc(90, 100)
+  assert pix('identity', '5=1X4=') == sc(90, 100)
+  assert pix('gap_compressed_identity', '3M4I3M') == sc(85, 100)
+  assert pix('gap_compressed_identity', '3M4D3M') == sc(85, 100)
+  assert pix('gap_compressed_identity', '3=2X2I3=') == sc(66, 100)
+  assert pix('avg_base_quality', '10M', quals=list(range(1, 11))) == sc(5, 93)
+  assert pix('gc_content', '10M', seq='GGGGGCCCCC') == 254
+  assert pix('gc_content', '10M', seq='GGGGGTTTTT') == 127
+  assert pix('insert_size', '10M', frag=22) == 5
+  assert pix('insert_size', '10M', frag=-22) == 5
+  assert pix('insert_size', '10M', frag=1001) == 254
+  assert pix('insert_size', '10M') == 0
+
+
+def test_avg_base_quality_out_of_bounds_is_fatal():
+  o = KA.default_options(['avg_base_quality'],
+                         read_requirements=T.ReadRequirements())
+  o.width = 21
+  read = T.make_read('AAAAATTTTT', start=1, cigar='10M', quals=[100] * 10)
+  with pytest.raises(O.OracleError, match='outside of bounds'):
+    O.encode_read(o, T.DeepVariantCall(), 'N' * 21, read, 0, [])
+
+
+def test_supplementary_and_sample_probability():
+  # pileup_channel_lib_test.cc: SupplementaryAlignmentChannelTest,
+  # AlleleSampleProbabilityChannelTest.
+  o = T.PileupImageOptions(width=3, height=3, allele_unsupporting_read_alpha=0.0,
+                           allele_supporting_read_alpha=1.0)
+  o.channels = ['supplementary_alignment']
+  read = T.cc_make_read('chr1', 1, 'A', ['1M'], 'r')
+  read.supplementary_alignment = True
+  assert O.encode_read(o, T.DeepVariantCall(), 'AAA', read, 0, [])[0, 1, 0] == 254
+  read.supplementary_alignment = False
+  assert O.encode_read(o, T.DeepVariantCall(), 'AAA', read, 0, [])[0, 1, 0] == 0
+  o.channels = ['allele_sample_probability']
+  call = T.DeepVariantCall(
+      allele_support={'A': T.SupportingReads(['read1/0', 'read2/0'])},
+      ref_support=['read3/0'])
+  for name, exp in (('read1', 207), ('read3', 146), ('read4', 146)):
+    rd = T.cc_make_read('chr1', 1, 'A', ['1M'], name)
+    assert O.encode_read(o, call, 'AAA', rd, 0, [])[0, 1, 0] == exp
+
+
+def test_unknown_cigar_op_is_fatal():
+  o = KA.default_options()
+  o.width = 5
+  read = T.make_read('AAA', start=1, cigar='3M', quals=[30] * 3)
+  read.alignment.cigar[0].operation = 0
+  with pytest.raises(O.OracleError, match='CIGAR'):
+    O.encode_read(o, KA.make_dv_call(), 'AACAG', read, 1, ['C'])
+
+
+def test_downsample_is_identity_below_max_and_permutation_above():
+  assert O.downsample_indices(5, 95, 2101079370).tolist() == [0, 1, 2, 3, 4]
+  p = O.downsample_indices(120, 95, 2101079370)
+  assert sorted(p.tolist()) == list(range(120)) and p.tolist() != list(range(120))
+  # generator is passed by value in the reference: same stream every call
+  assert (p == O.downsample_indices(120, 95, 2101079370)).all()
