@@ -1,0 +1,176 @@
+"""Minimal BAM (BGZF) and FASTA readers feeding the hot path.
+
+htslib is not available here; zlib is.  Semantics follow the reference's
+nucleus readers for the fields the encoder consumes:
+  third_party/nucleus/io/sam_reader.cc:734-840  (ConvertToPb): aligned_quality
+  is raw phred, read_number = 0 if (unpaired or FREAD1) else 1 (:785),
+  fragment_length = isize (:774), info['HP'] from the integer HP aux tag.
+  third_party/nucleus/io/reference.cc (IndexedFastaReader, upper-cased unless
+  keep_true_case; make_examples_native.cc:128-129 sets keep_true_case=false).
+
+This is "next"-row f1 scaffolding: used by the golden-fixture
+generator and by make_examples_native when it is handed file names.
+"""
+from __future__ import annotations
+
+import gzip
+import struct
+import zlib
+from typing import Dict, Iterator, List, Optional, Tuple
+
+from deepvariant_amd import dv_types as T
+
+_SEQ_NT16 = '=ACMGRSVTWYHKDBN'
+
+
+def _bgzf_blocks(path: str) -> Iterator[bytes]:
+  with open(path, 'rb') as f:
+    data = f.read()
+  pos = 0
+  while pos < len(data):
+    # gzip header with BC extra subfield carrying the block size.
+    xlen = struct.unpack_from('<H', data, pos + 10)[0]
+    extra = data[pos + 12:pos + 12 + xlen]
+    bsize = None
+    p = 0
+    while p < xlen:
+      si1, si2, slen = extra[p], extra[p + 1], struct.unpack_from('<H', extra, p + 2)[0]
+      if si1 == 66 and si2 == 67:
+        bsize = struct.unpack_from('<H', extra, p + 4)[0] + 1
+      p += 4 + slen
+    if bsize is None:
+      raise IOError('not a BGZF file: %s' % path)
+    cdata = data[pos + 12 + xlen:pos + bsize - 8]
+    yield zlib.decompress(cdata, -15)
+    pos += bsize
+
+
+def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
+             end: int = 1 << 62) -> Tuple[List[str], List[T.Read]]:
+  """Reads a whole (small) BAM; returns (contig names, reads overlapping)."""
+  buf = b''.join(_bgzf_blocks(path))
+  if buf[:4] != b'BAM\x01':
+    raise IOError('bad BAM magic')
+  l_text = struct.unpack_from('<i', buf, 4)[0]
+  pos = 8 + l_text
+  n_ref = struct.unpack_from('<i', buf, pos)[0]
+  pos += 4
+  names = []
+  for _ in range(n_ref):
+    l_name = struct.unpack_from('<i', buf, pos)[0]
+    names.append(buf[pos + 4:pos + 4 + l_name - 1].decode())
+    pos += 4 + l_name + 4
+  reads: List[T.Read] = []
+  n = len(buf)
+  while pos < n:
+    block_size = struct.unpack_from('<i', buf, pos)[0]
+    rec = memoryview(buf)[pos + 4:pos + 4 + block_size]
+    pos += 4 + block_size
+    (ref_id, rpos, l_read_name, mapq, _bin, n_cigar, flag, l_seq, _next_ref,
+     _next_pos, tlen) = struct.unpack_from('<iiBBHHHiiii', rec, 0)
+    p = 32
+    name = bytes(rec[p:p + l_read_name - 1]).decode()
+    p += l_read_name
+    cigar = []
+    ref_len = 0
+    for k in range(n_cigar):
+      v = struct.unpack_from('<I', rec, p + 4 * k)[0]
+      op, ln = v & 0xF, v >> 4
+      cigar.append(T.CigarUnit(T.BAM_OP_TO_NUCLEUS[op], ln))
+      if op in (0, 2, 3, 7, 8):
+        ref_len += ln
+    p += 4 * n_cigar
+    seq_bytes = rec[p:p + (l_seq + 1) // 2]
+    p += (l_seq + 1) // 2
+    qual = bytes(rec[p:p + l_seq])
+    p += l_seq
+    if ref_id < 0 or (contig is not None and names[ref_id] != contig):
+      continue
+    if not (end > rpos and start < rpos + max(ref_len, 1)):
+      continue
+    seq = []
+    for i in range(l_seq):
+      b = seq_bytes[i >> 1]
+      seq.append(_SEQ_NT16[(b >> 4) if (i & 1) == 0 else (b & 0xF)])
+    info: Dict[str, T.ListValue] = {}
+    aux = rec[p:]
+    hp = _find_int_tag(aux, b'HP')
+    if hp is not None:
+      info['HP'] = T.ListValue(values=[T.Value(int_value=hp)])
+    paired = bool(flag & 0x1)
+    read_number = 0 if (not paired or (flag & 0x40)) else 1
+    reads.append(T.Read(
+        fragment_name=name,
+        read_number=read_number,
+        number_reads=2 if paired else 1,
+        proper_placement=bool(flag & 0x2),
+        duplicate_fragment=bool(flag & 0x400),
+        failed_vendor_quality_checks=bool(flag & 0x200),
+        secondary_alignment=bool(flag & 0x100),
+        supplementary_alignment=bool(flag & 0x800),
+        fragment_length=tlen,
+        aligned_sequence=''.join(seq),
+        aligned_quality=qual,
+        alignment=T.LinearAlignment(
+            position=T.Position(reference_name=names[ref_id], position=rpos,
+                                reverse_strand=bool(flag & 0x10)),
+            mapping_quality=mapq, cigar=cigar),
+        info=info))
+    reads[-1]._flag = flag  # pylint: disable=protected-access
+    reads[-1]._mate_ok = (_next_ref < 0 or _next_ref == ref_id)
+  return names, reads
+
+
+_AUX_SIZES = {b'A': 1, b'c': 1, b'C': 1, b's': 2, b'S': 2, b'i': 4, b'I': 4,
+              b'f': 4}
+_AUX_FMT = {b'c': '<b', b'C': '<B', b's': '<h', b'S': '<H', b'i': '<i',
+            b'I': '<I'}
+
+
+def _find_int_tag(aux, tag: bytes) -> Optional[int]:
+  p, n = 0, len(aux)
+  while p + 3 <= n:
+    t = bytes(aux[p:p + 2])
+    ty = bytes(aux[p + 2:p + 3])
+    p += 3
+    if ty in _AUX_SIZES:
+      if t == tag and ty in _AUX_FMT:
+        return struct.unpack_from(_AUX_FMT[ty], aux, p)[0]
+      p += _AUX_SIZES[ty]
+    elif ty in (b'Z', b'H'):
+      while aux[p] != 0:
+        p += 1
+      p += 1
+    elif ty == b'B':
+      sub = bytes(aux[p:p + 1])
+      cnt = struct.unpack_from('<i', aux, p + 1)[0]
+      p += 5 + cnt * _AUX_SIZES[sub]
+    else:
+      return None
+  return None
+
+
+class FastaReader:
+  """Whole-file FASTA (plain, gzip or bgzip) reader; bases upper-cased."""
+
+  def __init__(self, path: str):
+    opener = gzip.open if open(path, 'rb').read(2) == b'\x1f\x8b' else open
+    self._contigs: Dict[str, str] = {}
+    name, chunks = None, []
+    with opener(path, 'rt') as f:
+      for line in f:
+        if line.startswith('>'):
+          if name is not None:
+            self._contigs[name] = ''.join(chunks).upper()
+          name = line[1:].split()[0]
+          chunks = []
+        else:
+          chunks.append(line.strip())
+    if name is not None:
+      self._contigs[name] = ''.join(chunks).upper()
+
+  def n_bases(self, contig: str) -> int:
+    return len(self._contigs[contig])
+
+  def get_bases(self, contig: str, start: int, end: int) -> str:
+    return self._contigs[contig][start:end]

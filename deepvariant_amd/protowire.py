@@ -1,0 +1,342 @@
+"""Minimal protobuf wire codec for the messages that cross the hot path.
+
+protoc / generated *_pb2 modules are not available here, and the on-disk
+contract has to stay byte-compatible, so the handful of
+messages on the path are read and written at wire level:
+
+  tf.Example / Features / Feature / BytesList / Int64List   (tensorflow example.proto)
+  nucleus.genomics.v1.Variant / VariantCall                 (third_party/nucleus/protos/variants.proto:46-170)
+  DeepVariantCall                                           (deepvariant/protos/deepvariant.proto:262-317)
+  CallVariantsOutput / AltAlleleIndices                     (deepvariant/protos/deepvariant.proto:363-401)
+
+Only proto3 wire rules are used: varint (0), 64-bit (1), length-delimited (2),
+32-bit (5).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, Iterator, List, Tuple
+
+from deepvariant_amd import dv_types as T
+
+VARINT, I64, LEN, I32 = 0, 1, 2, 5
+
+
+def read_varint(buf, pos: int) -> Tuple[int, int]:
+  result = 0
+  shift = 0
+  while True:
+    b = buf[pos]
+    pos += 1
+    result |= (b & 0x7F) << shift
+    if not b & 0x80:
+      return result, pos
+    shift += 7
+
+
+def iter_fields(buf) -> Iterator[Tuple[int, int, object]]:
+  """Yields (field_number, wire_type, value) over a serialized message."""
+  pos, n = 0, len(buf)
+  mv = memoryview(buf)
+  while pos < n:
+    key, pos = read_varint(mv, pos)
+    fnum, wt = key >> 3, key & 7
+    if wt == VARINT:
+      v, pos = read_varint(mv, pos)
+    elif wt == I64:
+      v = bytes(mv[pos:pos + 8])
+      pos += 8
+    elif wt == LEN:
+      ln, pos = read_varint(mv, pos)
+      v = mv[pos:pos + ln]
+      pos += ln
+    elif wt == I32:
+      v = bytes(mv[pos:pos + 4])
+      pos += 4
+    else:
+      raise ValueError('unsupported wire type %d' % wt)
+    yield fnum, wt, v
+
+
+def to_signed64(v: int) -> int:
+  return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def enc_varint(v: int) -> bytes:
+  if v < 0:
+    v += 1 << 64
+  out = bytearray()
+  while True:
+    b = v & 0x7F
+    v >>= 7
+    if v:
+      out.append(b | 0x80)
+    else:
+      out.append(b)
+      return bytes(out)
+
+
+def enc_key(fnum: int, wt: int) -> bytes:
+  return enc_varint((fnum << 3) | wt)
+
+
+def enc_len(fnum: int, payload: bytes) -> bytes:
+  return enc_key(fnum, LEN) + enc_varint(len(payload)) + bytes(payload)
+
+
+def enc_int(fnum: int, v: int) -> bytes:
+  return enc_key(fnum, VARINT) + enc_varint(v)
+
+
+def enc_double(fnum: int, v: float) -> bytes:
+  return enc_key(fnum, I64) + struct.pack('<d', v)
+
+
+# ---------------------------------------------------------------- tf.Example
+
+def decode_example(buf) -> Dict[str, object]:
+  """tf.Example -> {name: [bytes...] | [int...] | [float...]}."""
+  out: Dict[str, object] = {}
+  for f, _, features in iter_fields(buf):
+    if f != 1:
+      continue
+    for f2, _, entry in iter_fields(features):  # map<string, Feature> feature
+      if f2 != 1:
+        continue
+      key, feat = None, None
+      for f3, _, v in iter_fields(entry):
+        if f3 == 1:
+          key = bytes(v).decode()
+        elif f3 == 2:
+          feat = v
+      vals: List[object] = []
+      if feat is not None:
+        for kind, _, lst in iter_fields(feat):
+          if kind == 1:  # BytesList
+            vals = [bytes(v) for f4, _, v in iter_fields(lst) if f4 == 1]
+          elif kind == 3:  # Int64List
+            for f4, wt, v in iter_fields(lst):
+              if f4 != 1:
+                continue
+              if wt == LEN:
+                p, mv = 0, v
+                while p < len(mv):
+                  x, p = read_varint(mv, p)
+                  vals.append(to_signed64(x))
+              else:
+                vals.append(to_signed64(v))
+          elif kind == 2:  # FloatList
+            for f4, wt, v in iter_fields(lst):
+              if f4 != 1:
+                continue
+              if wt == LEN:
+                vals.extend(struct.unpack('<%df' % (len(v) // 4), bytes(v)))
+              else:
+                vals.append(struct.unpack('<f', v)[0])
+      out[key] = vals
+  return out
+
+
+def _bytes_feature(values) -> bytes:
+  return enc_len(1, b''.join(enc_len(1, v) for v in values))
+
+
+def _int64_feature(values) -> bytes:
+  packed = b''.join(enc_varint(v) for v in values)
+  return enc_len(3, enc_len(1, packed))
+
+
+def encode_example(features: Dict[str, object]) -> bytes:
+  """{name: [bytes...] | [int...]} -> tf.Example.
+
+  Map entries are emitted in sorted key order, which is what protobuf's
+  deterministic serialization does; TF parsers accept any order.
+  """
+  entries = []
+  for key in sorted(features):
+    vals = features[key]
+    if vals and isinstance(vals[0], (bytes, bytearray, memoryview)):
+      feat = _bytes_feature(vals)
+    else:
+      feat = _int64_feature([int(v) for v in vals])
+    entries.append(enc_len(1, enc_len(1, key.encode()) + enc_len(2, feat)))
+  return enc_len(1, b''.join(entries))
+
+
+# -------------------------------------------------------------------- Variant
+
+def decode_variant(buf) -> T.Variant:
+  v = T.Variant(serialized=bytes(buf))
+  for f, wt, val in iter_fields(buf):
+    if f == 14:
+      v.reference_name = bytes(val).decode()
+    elif f == 16:
+      v.start = to_signed64(val)
+    elif f == 13:
+      v.end = to_signed64(val)
+    elif f == 6:
+      v.reference_bases = bytes(val).decode()
+    elif f == 7:
+      v.alternate_bases.append(bytes(val).decode())
+    elif f == 11:
+      call = T.VariantCall()
+      for f2, wt2, v2 in iter_fields(val):
+        if f2 == 9:
+          call.call_set_name = bytes(v2).decode()
+        elif f2 == 7:
+          if wt2 == LEN:
+            p = 0
+            while p < len(v2):
+              x, p = read_varint(v2, p)
+              call.genotype.append(to_signed64(x) if x < (1 << 63)
+                                   else to_signed64(x))
+          else:
+            call.genotype.append(to_signed64(v2))
+      v.calls.append(call)
+  return v
+
+
+def encode_variant(v: T.Variant) -> bytes:
+  """Field-number order, like the C++ serializer (used for synthetic data)."""
+  if v.serialized is not None:
+    return v.serialized
+  out = b''
+  if v.reference_bases:
+    out += enc_len(6, v.reference_bases.encode())
+  for a in v.alternate_bases:
+    out += enc_len(7, a.encode())
+  for c in v.calls:
+    body = b''
+    if c.genotype:
+      body += enc_len(7, b''.join(enc_varint(g) for g in c.genotype))
+    if c.call_set_name:
+      body += enc_len(9, c.call_set_name.encode())
+    out += enc_len(11, body)
+  if v.end:
+    out += enc_int(13, v.end)
+  if v.reference_name:
+    out += enc_len(14, v.reference_name.encode())
+  if v.start:
+    out += enc_int(16, v.start)
+  return out
+
+
+def add_call_info_string(variant_bytes: bytes, key: str, value: str) -> bytes:
+  """Sets calls[0].info[key] = [string_value] on a serialized Variant.
+
+  call_variants adds info['MID'] = 'deepvariant' to the first call
+  (deepvariant/call_variants.py:397-398,
+  third_party/nucleus/util/variantcall_utils.py:235-237).  VariantCall.info is
+  map<string, ListValue> = field 2; ListValue.values = 1; Value.string_value = 3
+  (third_party/nucleus/protos/struct.proto).
+  """
+  value_msg = enc_len(3, value.encode())              # Value{string_value}
+  list_value = enc_len(1, value_msg)                  # ListValue{values}
+  entry = enc_len(1, key.encode()) + enc_len(2, list_value)
+  info_field = enc_len(2, entry)
+  out = bytearray()
+  done = False
+  for f, wt, val in iter_fields(variant_bytes):
+    if f == 11 and not done:
+      out += enc_len(11, bytes(val) + info_field)
+      done = True
+    elif wt == VARINT:
+      out += enc_int(f, val)
+    elif wt == LEN:
+      out += enc_len(f, bytes(val))
+    else:
+      out += enc_key(f, wt) + bytes(val)
+  if not done:
+    out += enc_len(11, info_field)
+  return bytes(out)
+
+
+# ------------------------------------------------------------ DeepVariantCall
+
+def decode_deepvariant_call(buf) -> T.DeepVariantCall:
+  call = T.DeepVariantCall()
+  for f, wt, val in iter_fields(buf):
+    if f == 1:
+      call.variant = decode_variant(val)
+    elif f == 2:  # map<string, SupportingReads>
+      key, names = '', []
+      for f2, _, v2 in iter_fields(val):
+        if f2 == 1:
+          key = bytes(v2).decode()
+        elif f2 == 2:
+          names = [bytes(v3).decode() for f3, _, v3 in iter_fields(v2)
+                   if f3 == 1]
+      call.allele_support[key] = T.SupportingReads(read_names=names)
+    elif f == 3:  # map<string, float>
+      key, fv = '', 0.0
+      for f2, _, v2 in iter_fields(val):
+        if f2 == 1:
+          key = bytes(v2).decode()
+        elif f2 == 2:
+          fv = struct.unpack('<f', v2)[0]
+      call.allele_frequency[key] = fv
+    elif f == 4:
+      call.ref_support.append(bytes(val).decode())
+    elif f == 8:
+      idx = T.AltAlleleIndices()
+      for f2, wt2, v2 in iter_fields(val):
+        if f2 == 1:
+          if wt2 == LEN:
+            p = 0
+            while p < len(v2):
+              x, p = read_varint(v2, p)
+              idx.indices.append(x)
+          else:
+            idx.indices.append(v2)
+      call.make_examples_alt_allele_indices.append(idx)
+  return call
+
+
+# -------------------------------------------------------- CallVariantsOutput
+
+def encode_alt_allele_indices(indices) -> bytes:
+  """CallVariantsOutput.AltAlleleIndices{repeated int32 indices = 1 [packed]}.
+
+  make_examples_native.cc:350-374 (EncodeAltAlleles): [0] -> 0a 01 00.
+  """
+  if not indices:
+    return b''
+  return enc_len(1, b''.join(enc_varint(i) for i in indices))
+
+
+def decode_alt_allele_indices(buf) -> List[int]:
+  out: List[int] = []
+  for f, wt, v in iter_fields(buf):
+    if f == 1:
+      if wt == LEN:
+        p = 0
+        while p < len(v):
+          x, p = read_varint(v, p)
+          out.append(x)
+      else:
+        out.append(v)
+  return out
+
+
+def encode_call_variants_output(variant_bytes: bytes, alt_indices_bytes: bytes,
+                                genotype_probabilities) -> bytes:
+  """deepvariant.proto:363-401: variant=1, alt_allele_indices=2,
+  repeated double genotype_probabilities=3 (packed)."""
+  probs = b''.join(struct.pack('<d', float(p)) for p in genotype_probabilities)
+  return (enc_len(1, variant_bytes) + enc_len(2, alt_indices_bytes) +
+          enc_len(3, probs))
+
+
+def decode_call_variants_output(buf):
+  variant, alt, probs = None, [], []
+  for f, wt, v in iter_fields(buf):
+    if f == 1:
+      variant = decode_variant(v)
+    elif f == 2:
+      alt = decode_alt_allele_indices(v)
+    elif f == 3:
+      if wt == LEN:
+        probs.extend(struct.unpack('<%dd' % (len(v) // 8), bytes(v)))
+      else:
+        probs.append(struct.unpack('<d', v)[0])
+  return variant, alt, probs
