@@ -1,0 +1,164 @@
+"""ctypes binding of libdvhip.so (the C ABI in include/dvhip.h).
+
+The library is built in-tree by `deepvariant_amd/csrc/Makefile` (hipcc,
+--offload-arch=gfx950) -- see `__graft_entry__.build()`.  There is no CPU
+fallback: if the shared object is missing, loading raises, and every compute
+entry point returns DV_ERR_NO_DEVICE without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdvhip.so')
+
+DV_MAX_CHANNELS = 16
+DV_READ_AUX_STRIDE = 8
+DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
+DV_HP_NONE = -(1 << 31)
+
+DV_OK = 0
+DV_ERR_INVALID_ARGUMENT = -1
+DV_ERR_UNSUPPORTED = -2
+DV_ERR_NO_DEVICE = -3
+DV_ERR_HIP = -4
+DV_ERR_OUT_OF_MEMORY = -5
+DV_ERR_BAD_INPUT = -6
+
+# Every symbol include/dvhip.h declares (checked by tests/test_abi.py).
+ABI_SYMBOLS = [
+    'dv_last_error', 'dv_abi_version', 'dv_device_count',
+    'dv_encoder_create', 'dv_encoder_destroy', 'dv_encode_batch',
+    'dv_downsample_indices', 'dv_query_reads', 'dv_crc32c',
+    'dv_model_create', 'dv_model_destroy', 'dv_model_num_params',
+    'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
+    'dv_model_infer', 'dv_set_profiling', 'dv_profile_ms',
+    'dv_last_profile_count',
+]
+
+
+class DvError(RuntimeError):
+  """A non-zero dv_status; `.status` carries the code."""
+
+  def __init__(self, status, message):
+    super().__init__('libdvhip status %d: %s' % (status, message))
+    self.status = status
+
+
+class DvEncoderOptions(C.Structure):
+  _fields_ = [
+      ('width', C.c_int32), ('height', C.c_int32),
+      ('reference_band_height', C.c_int32), ('n_channels', C.c_int32),
+      ('channels', C.c_int32 * DV_MAX_CHANNELS),
+      ('base_color_offset_a_and_g', C.c_int32),
+      ('base_color_offset_t_and_c', C.c_int32),
+      ('base_color_stride', C.c_int32),
+      ('allele_supporting_read_alpha', C.c_float),
+      ('allele_unsupporting_read_alpha', C.c_float),
+      ('other_allele_supporting_read_alpha', C.c_float),
+      ('reference_matching_read_alpha', C.c_float),
+      ('reference_mismatching_read_alpha', C.c_float),
+      ('indel_anchoring_base_char', C.c_int32),
+      ('reference_base_quality', C.c_int32),
+      ('positive_strand_color', C.c_int32),
+      ('negative_strand_color', C.c_int32),
+      ('base_quality_cap', C.c_int32), ('mapping_quality_cap', C.c_int32),
+      ('min_base_quality', C.c_int32), ('min_mapping_quality', C.c_int32),
+      ('random_seed', C.c_uint32),
+      ('sort_by_haplotypes', C.c_int32),
+      ('hp_tag_for_assembly_polishing', C.c_int32),
+      ('sort_by_alt_allele_support', C.c_int32),
+      ('min_non_zero_allele_frequency', C.c_float),
+  ]
+
+
+class DvBatch(C.Structure):
+  _fields_ = [
+      ('memory', C.c_int32),
+      ('n_reads', C.c_int32),
+      ('read_pos', C.c_void_p), ('read_sort_pos', C.c_void_p),
+      ('read_seq_off', C.c_void_p), ('read_cigar_off', C.c_void_p),
+      ('read_mapq', C.c_void_p), ('read_flags', C.c_void_p),
+      ('read_frag_len', C.c_void_p), ('read_hp', C.c_void_p),
+      ('read_name_rank', C.c_void_p), ('read_aux', C.c_void_p),
+      ('bases', C.c_void_p), ('quals', C.c_void_p),
+      ('mod_5mc', C.c_void_p), ('mod_6ma', C.c_void_p),
+      ('cigar', C.c_void_p),
+      ('n_bases', C.c_uint32), ('n_cigar', C.c_uint32),
+      ('n_items', C.c_int32),
+      ('item_variant_start', C.c_void_p), ('item_image_start', C.c_void_p),
+      ('item_ref_idx', C.c_void_p), ('item_list_off', C.c_void_p),
+      ('item_height', C.c_void_p), ('item_out_off', C.c_void_p),
+      ('item_blank_mask', C.c_void_p), ('item_mean_coverage', C.c_void_p),
+      ('ref_windows', C.c_void_p), ('n_ref_windows', C.c_uint32),
+      ('list_read', C.c_void_p), ('list_code', C.c_void_p),
+      ('list_group', C.c_void_p), ('list_aux', C.c_void_p),
+      ('n_list', C.c_uint32), ('max_list_len', C.c_uint32),
+  ]
+
+
+class DvModelDesc(C.Structure):
+  _fields_ = [('height', C.c_int32), ('width', C.c_int32),
+              ('channels', C.c_int32), ('num_classes', C.c_int32),
+              ('max_batch', C.c_int32)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+  """Compiles libdvhip.so for gfx950 with the committed Makefile."""
+  args = ['make', '-C', os.path.join(_HERE, 'csrc')]
+  if force:
+    subprocess.check_call(args + ['clean'], stdout=subprocess.DEVNULL)
+  subprocess.check_call(args, stdout=subprocess.DEVNULL)
+  return LIB_PATH
+
+
+def lib():
+  """Loads libdvhip.so; raises if it has not been built (no fallback)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(
+          'deepvariant_amd/libdvhip.so is missing: run '
+          '`python -c "import __graft_entry__ as g; g.build()"` '
+          '(there is no CPU fallback for the HIP hot path)')
+    l = C.CDLL(LIB_PATH)
+    l.dv_last_error.restype = C.c_char_p
+    l.dv_crc32c.restype = C.c_uint32
+    l.dv_crc32c.argtypes = [C.c_void_p, C.c_size_t]
+    l.dv_profile_ms.restype = C.c_double
+    l.dv_model_num_params.restype = C.c_int64
+    l.dv_model_num_params.argtypes = [C.c_void_p]
+    l.dv_model_num_layers.argtypes = [C.c_void_p]
+    l.dv_model_destroy.argtypes = [C.c_void_p]
+    l.dv_encoder_destroy.argtypes = [C.c_void_p]
+    l.dv_encode_batch.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+        C.c_void_p]
+    l.dv_model_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p]
+    l.dv_model_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    l.dv_model_layer_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    _lib = l
+  return _lib
+
+
+def check(status: int):
+  if status != DV_OK:
+    raise DvError(status, lib().dv_last_error().decode())
+
+
+def try_crc32c(data: bytes) -> Optional[int]:
+  if not os.path.exists(LIB_PATH):
+    return None
+  buf = bytes(data)
+  return int(lib().dv_crc32c(buf, len(buf)))
+
+
+def device_count() -> int:
+  return int(lib().dv_device_count())

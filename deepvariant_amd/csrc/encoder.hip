@@ -1,0 +1,883 @@
+// encoder.hip -- pileup-image encoder for gfx950 (MI355X).
+//
+// One workgroup (4 wave64) builds one item = one
+// PileupImageEncoderNative::BuildPileupForOneSample call of the reference
+// (deepvariant/pileup_image_native.cc:297-447) and streams it out in the HWC
+// byte layout of FillPileupArray (deepvariant/pileup_image_native.h:214-275):
+//
+//   phase A  one thread per (shuffled) list entry: mapq gate
+//            (pileup_image_native.cc:485-491) and the low-base-quality-at-the-
+//            variant-start gate (pileup_channel_lib.cc:142-148) by walking the
+//            read's CIGAR (pileup_channel_lib.cc:213-260);
+//   phase B  block prefix sum over the accept flags: the first
+//            height - reference_band_height accepted entries are kept
+//            (pileup_image_native.cc:367-403);
+//   phase C  stable rank sort of <= 256 kept rows by (hap, allele group,
+//            position, name rank) (pileup_image_native.cc:75-102,405);
+//   phase D  each wave renders whole rows: every lane resolves what the read
+//            puts in its column (last CIGAR event wins, as in the reference's
+//            in-order overwrites), channel bytes come from host-built LUTs
+//            (bit-exact by construction: the fp32 truncations of
+//            channels/*.cc are evaluated once on the host), the row is staged
+//            HWC in LDS at the byte phase of its global address and leaves as
+//            fully coalesced aligned dword stores; rows below the pileup are
+//            zero-filled with 16-byte stores.
+//
+// The kernel is HBM-write bound: ~155 KB written per item
+// against ~12 KB of packed reads, most of which hit L2 because neighbouring
+// candidates share reads.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+
+#include "dv_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxKept = 256;
+constexpr int kInsertLutSize = 1008;
+
+enum ChannelKind : uint8_t {
+  kZero = 0,      // blank / mean_coverage (painted afterwards)
+  kBase,          // LUT on the read base
+  kBaseQual,      // LUT on the base quality
+  kMapq,          // LUT on the mapping quality (per read)
+  kStrand,        // per read
+  kSupport,       // LUT on list_code (per item,read)
+  kDiff,          // read base == ref base
+  kInsert,        // LUT on |fragment_length| (per read)
+  kHaplotype,     // per read
+  kSupplementary, // per read
+  kMeth5,         // LUT on the 5mC byte of the base
+  kMeth6,         // LUT on the 6mA byte of the base
+  kAuxRead0,      // host-computed per-read pixel, read_aux[k], k = kind - kAuxRead0
+  kAuxRead1,
+  kAuxRead2,
+  kAuxRead3,
+  kAuxList,       // host-computed per-(item,read) pixel, list_aux
+};
+
+// Everything the kernel needs besides the batch; copied into LDS per workgroup.
+struct alignas(16) EncConst {
+  uint8_t lut_base[256];
+  uint8_t lut_bq[256];
+  uint8_t lut_mapq[256];
+  uint8_t lut_mod[256];
+  uint8_t lut_insert[kInsertLutSize];
+  uint8_t lut_support[4];
+  uint8_t strand[2];  // [reverse]
+  uint8_t diff[2];    // [matches]
+  uint8_t supp[2];    // [is supplementary]
+  uint8_t pad0[6];
+  uint8_t kind[DV_MAX_CHANNELS];
+  uint8_t ref_const[DV_MAX_CHANNELS];
+  int32_t n_channels;
+  int32_t width;
+  int32_t band;
+  int32_t min_bq;
+  int32_t min_mapq;
+  int32_t anchor_char;
+  int32_t sort_by_haplotypes;
+  int32_t polishing;
+  int32_t sort_by_group;
+  int32_t mean_cov_channel;  // index or -1
+  int32_t pad1[2];
+};
+static_assert(sizeof(EncConst) % 16 == 0, "EncConst must be 16-byte sized");
+
+struct EncArgs {
+  const EncConst* konst;
+  const uint32_t* perm_off;
+  const uint16_t* perm;
+  // reads
+  const int32_t* read_pos;
+  const int32_t* read_sort_pos;
+  const uint32_t* read_seq_off;
+  const uint32_t* read_cigar_off;
+  const uint8_t* read_mapq;
+  const uint8_t* read_flags;
+  const int32_t* read_frag_len;
+  const int32_t* read_hp;
+  const uint32_t* read_name_rank;
+  const uint8_t* read_aux;
+  const uint8_t* bases;
+  const uint8_t* quals;
+  const uint8_t* mod_5mc;
+  const uint8_t* mod_6ma;
+  const uint32_t* cigar;
+  // items
+  const int32_t* item_variant_start;
+  const int32_t* item_image_start;
+  const uint32_t* item_ref_idx;
+  const uint32_t* item_list_off;
+  const uint16_t* item_height;
+  const uint64_t* item_out_off;
+  const uint32_t* item_blank_mask;
+  const float* item_mean_coverage;
+  const uint8_t* ref_windows;
+  const uint32_t* list_read;
+  const uint8_t* list_code;
+  const uint8_t* list_group;
+  const uint8_t* list_aux;
+  int32_t n_items;
+  int32_t out_channels;
+  int32_t row_buf_bytes;  // per-wave LDS row buffer, multiple of 16
+  uint8_t* out;
+  int32_t* out_rows;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// CalculateBaseLevelData restricted to the events that land on ref position
+// `vstart` (pileup_channel_lib.cc:126-165,213-260): true = keep the read.
+__device__ bool read_passes_site_gate(const EncArgs& a, const EncConst& c,
+                                      uint32_t r, int vstart, int istart) {
+  const int vcol = vstart - istart;
+  if (vcol < 0 || vcol >= c.width) return true;  // `col < ref_bases.size()` never holds
+  const uint32_t c0 = a.read_cigar_off[r], c1 = a.read_cigar_off[r + 1];
+  const uint32_t s0 = a.read_seq_off[r];
+  int ref_i = a.read_pos[r];
+  int read_i = 0;
+  for (uint32_t k = c0; k < c1; ++k) {
+    const uint32_t cg = a.cigar[k];
+    const int op = cg & 0xF;
+    const int len = cg >> 4;
+    switch (op) {
+      case DV_CIGAR_ALIGNMENT_MATCH:
+      case DV_CIGAR_SEQUENCE_MATCH:
+      case DV_CIGAR_SEQUENCE_MISMATCH:
+        if (vstart >= ref_i && vstart < ref_i + len) {
+          // a NUL base would not be drawn (`read_base &&`), never in practice
+          const uint32_t idx = s0 + read_i + (vstart - ref_i);
+          if (a.bases[idx] != 0 && a.quals[idx] < c.min_bq) return false;
+        }
+        ref_i += len;
+        read_i += len;
+        break;
+      case DV_CIGAR_INSERT:
+        if (ref_i > 0 && ref_i - 1 == vstart && c.anchor_char != 0) {
+          if (a.quals[s0 + read_i] < c.min_bq) return false;
+        }
+        read_i += len;
+        break;
+      case DV_CIGAR_CLIP_SOFT:
+        read_i += len;
+        break;
+      case DV_CIGAR_DELETE:
+        if (read_i > 0 && ref_i - 1 == vstart && c.anchor_char != 0) {
+          if (a.quals[s0 + read_i - 1] < c.min_bq) return false;
+        }
+        ref_i += len;
+        break;
+      case DV_CIGAR_SKIP:
+        ref_i += len;
+        break;
+      default:
+        break;
+    }
+  }
+  return true;
+}
+
+// HaplotypeTagChannel (channels/haplotype_tag_channel.cc:76-110).
+__device__ __forceinline__ uint8_t haplotype_pixel(int hp, int polishing) {
+  int v = (hp == DV_HP_NONE) ? 0 : hp;
+  if (polishing == 2) {
+    if (v == 1) v = 2;
+    else if (v == 2) v = 1;
+  }
+  if (static_cast<float>(v) > 2.0f) v = 2;
+  return static_cast<uint8_t>(
+      static_cast<int>(254.0f * (static_cast<float>(v) / 2.0f)));
+}
+
+// GetHapIndex (pileup_image_native.cc:449-475).
+__device__ __forceinline__ int hap_index(int hp, const EncConst& c) {
+  if (!c.sort_by_haplotypes || hp == DV_HP_NONE) return 0;
+  if (c.polishing > 0 && hp == c.polishing) return -1;
+  if (hp < 0) return 0;
+  return hp;
+}
+
+__global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  EncConst* c = reinterpret_cast<EncConst*>(smem);
+  uint32_t* kept_read = reinterpret_cast<uint32_t*>(smem + sizeof(EncConst));
+  uint32_t* kept_src = kept_read + kMaxKept;
+  int32_t* key_hap = reinterpret_cast<int32_t*>(kept_src + kMaxKept);
+  int32_t* key_pos = key_hap + kMaxKept;
+  uint32_t* key_rank = reinterpret_cast<uint32_t*>(key_pos + kMaxKept);
+  uint32_t* order = key_rank + kMaxKept;
+  uint32_t* wave_tot = order + kMaxKept;          // [kWaves]
+  uint8_t* pix_const = reinterpret_cast<uint8_t*>(wave_tot + 8);  // [kWaves][16]
+  uint8_t* row_bufs = pix_const + kWaves * DV_MAX_CHANNELS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int item = blockIdx.x;
+
+  {  // constants -> LDS (16-byte copies)
+    const uint4* src = reinterpret_cast<const uint4*>(a.konst);
+    uint4* dst = reinterpret_cast<uint4*>(c);
+    for (int i = tid; i < static_cast<int>(sizeof(EncConst) / 16); i += kBlock) {
+      dst[i] = src[i];
+    }
+  }
+  __syncthreads();
+
+  const int W = c->width;
+  const int C = c->n_channels;
+  const int CO = a.out_channels;
+  const int band = c->band;
+  const int H = a.item_height[item];
+  const int max_reads = H - band;
+  const uint32_t l0 = a.item_list_off[item];
+  const int n = static_cast<int>(a.item_list_off[item + 1] - l0);
+  const int vstart = a.item_variant_start[item];
+  const int istart = a.item_image_start[item];
+  const uint32_t blank_mask = a.item_blank_mask ? a.item_blank_mask[item] : 0u;
+  const bool shuffled = n > max_reads;  // DownsampleReadIndices
+  const uint16_t* perm = shuffled ? a.perm + a.perm_off[n] : nullptr;
+
+  // ---------------- phases A + B: accept flags, keep the first max_reads ----
+  int kept = 0;
+  for (int cb = 0; cb < n && kept < max_reads; cb += kBlock) {
+    const int e = cb + tid;
+    bool accept = false;
+    uint32_t src = 0, r = 0;
+    if (e < n) {
+      src = shuffled ? perm[e] : static_cast<uint32_t>(e);
+      r = a.list_read[l0 + src];
+      accept = a.read_mapq[r] >= c->min_mapq &&
+               read_passes_site_gate(a, *c, r, vstart, istart);
+    }
+    const unsigned long long ballot = __ballot(accept);
+    const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(ballot);
+    __syncthreads();
+    int prefix = before;
+    int total = 0;
+    for (int w = 0; w < kWaves; ++w) {
+      if (w < wave) prefix += wave_tot[w];
+      total += wave_tot[w];
+    }
+    const int slot = kept + prefix;
+    if (accept && slot < max_reads) {
+      kept_read[slot] = r;
+      kept_src[slot] = src;
+    }
+    kept = min(kept + total, max_reads);
+    __syncthreads();
+  }
+
+  // ---------------- phase C: stable rank sort of the kept rows --------------
+  if (tid < kept) {
+    const uint32_t r = kept_read[tid];
+    const int hap = hap_index(a.read_hp[r], *c);
+    const int group = (c->sort_by_group && a.list_group)
+                          ? a.list_group[l0 + kept_src[tid]]
+                          : 0;
+    // (hap, group) compare lexicographically; hap >= -1 and group < 256.
+    key_hap[tid] = hap * 256 + group;
+    key_pos[tid] = a.read_sort_pos ? a.read_sort_pos[r] : a.read_pos[r];
+    key_rank[tid] = a.read_name_rank[r];
+  }
+  __syncthreads();
+  if (tid < kept) {
+    const int h = key_hap[tid], p = key_pos[tid];
+    const uint32_t nr = key_rank[tid];
+    int rank = 0;
+    for (int j = 0; j < kept; ++j) {
+      const int hj = key_hap[j], pj = key_pos[j];
+      const uint32_t nj = key_rank[j];
+      const bool less = (hj != h) ? (hj < h)
+                        : (pj != p) ? (pj < p)
+                        : (nj != nr) ? (nj < nr)
+                                     : (j < tid);
+      rank += less ? 1 : 0;
+    }
+    order[rank] = tid;
+  }
+  __syncthreads();
+
+  // ---------------- phase D: render rows -------------------------------------
+  const int row_bytes = W * CO;
+  const uint64_t out0 = a.item_out_off[item];
+  int mc_limit = 0;  // rows [0, mc_limit) get the mean-coverage paint
+  if (c->mean_cov_channel >= 0) {
+    const float mc = a.item_mean_coverage ? a.item_mean_coverage[item] : 0.0f;
+    mc_limit = min(static_cast<int>(mc) + band, H);
+  }
+  const int n_render = min(max(band + kept, mc_limit), H);
+  uint8_t* rb = row_bufs + wave * a.row_buf_bytes;
+  uint8_t* pc = pix_const + wave * DV_MAX_CHANNELS;
+  const uint8_t* ref = a.ref_windows + static_cast<size_t>(a.item_ref_idx[item]) * W;
+
+  for (int row = wave; row < n_render; row += kWaves) {
+    const uint64_t g0 = out0 + static_cast<uint64_t>(row) * row_bytes;
+    const int s = static_cast<int>(g0 & 3);
+    const int ndw = (s + row_bytes + 3) >> 2;
+    uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
+    for (int k = lane; k < ndw; k += 64) rb32[k] = 0;
+    wave_sync();
+    uint8_t* px = rb + s;
+    const int mc_val = (row < mc_limit) ? (row < band ? 255 : 200) : -1;
+
+    if (row < band) {
+      // EncodeReference (pileup_channel_lib.cc:263-293)
+      for (int col = lane; col < W; col += 64) {
+        const uint8_t rbase = ref[col];
+        for (int ch = 0; ch < C; ++ch) {
+          uint8_t v = (c->kind[ch] == kBase) ? c->lut_base[rbase]
+                                             : c->ref_const[ch];
+          if (ch == c->mean_cov_channel && mc_val >= 0) v = mc_val;
+          px[col * CO + ch] = v;
+        }
+      }
+    } else if (row < band + kept) {
+      // wave-uniform: let the compiler keep the read's metadata in SGPRs
+      const int slot = __builtin_amdgcn_readfirstlane(order[row - band]);
+      const uint32_t r = __builtin_amdgcn_readfirstlane(kept_read[slot]);
+      const uint32_t le = l0 + __builtin_amdgcn_readfirstlane(kept_src[slot]);
+      const uint8_t flags = a.read_flags[r];
+      if (lane < C) {  // per-read constant pixels
+        uint8_t v = 0;
+        switch (c->kind[lane]) {
+          case kMapq: v = c->lut_mapq[a.read_mapq[r]]; break;
+          case kStrand: v = c->strand[flags & DV_READ_REVERSE ? 1 : 0]; break;
+          case kSupport: v = c->lut_support[min<int>(a.list_code[le], 3)]; break;
+          case kInsert: {
+            int f = a.read_frag_len[r];
+            f = f < 0 ? -f : f;
+            v = c->lut_insert[min(f, 1000)];
+            break;
+          }
+          case kHaplotype: v = haplotype_pixel(a.read_hp[r], c->polishing); break;
+          case kSupplementary:
+            v = c->supp[flags & DV_READ_SUPPLEMENTARY ? 1 : 0];
+            break;
+          case kAuxRead0: case kAuxRead1: case kAuxRead2: case kAuxRead3:
+            v = a.read_aux ? a.read_aux[static_cast<size_t>(r) * DV_READ_AUX_STRIDE +
+                                        (c->kind[lane] - kAuxRead0)]
+                           : 0;
+            break;
+          case kAuxList: v = a.list_aux ? a.list_aux[le] : 0; break;
+          default: break;
+        }
+        pc[lane] = v;
+      }
+      wave_sync();
+      const uint32_t c0 = a.read_cigar_off[r], c1 = a.read_cigar_off[r + 1];
+      const uint32_t s0 = a.read_seq_off[r];
+      const int rpos = a.read_pos[r];
+      for (int colb = 0; colb < W; colb += 64) {
+        const int col = colb + lane;
+        const int p = istart + col;  // reference position of this column
+        // Resolve the LAST event drawn on this column.
+        int ev = 0;  // 0 nothing, 1 aligned base, 2 indel anchor
+        int ri = 0;
+        int ref_i = rpos, read_i = 0;
+        for (uint32_t k = c0; k < c1; ++k) {
+          const uint32_t cg = a.cigar[k];
+          const int op = cg & 0xF;
+          const int len = cg >> 4;
+          switch (op) {
+            case DV_CIGAR_ALIGNMENT_MATCH:
+            case DV_CIGAR_SEQUENCE_MATCH:
+            case DV_CIGAR_SEQUENCE_MISMATCH:
+              if (p >= ref_i && p < ref_i + len) {
+                ev = 1;
+                ri = read_i + (p - ref_i);
+              }
+              ref_i += len;
+              read_i += len;
+              break;
+            case DV_CIGAR_INSERT:
+              if (ref_i > 0 && ref_i - 1 == p) {
+                ev = 2;
+                ri = read_i;
+              }
+              read_i += len;
+              break;
+            case DV_CIGAR_CLIP_SOFT:
+              read_i += len;
+              break;
+            case DV_CIGAR_DELETE:
+              if (read_i > 0 && ref_i - 1 == p) {
+                ev = 2;
+                ri = read_i - 1;
+              }
+              ref_i += len;
+              break;
+            case DV_CIGAR_SKIP:
+              ref_i += len;
+              break;
+            default:
+              break;
+          }
+        }
+        if (col < W && ev != 0) {
+          const uint8_t base = (ev == 1) ? a.bases[s0 + ri]
+                                         : static_cast<uint8_t>(c->anchor_char);
+          if (base != 0) {
+            const uint8_t q = a.quals[s0 + ri];
+            const uint8_t rbase = ref[col];
+            for (int ch = 0; ch < C; ++ch) {
+              if ((blank_mask >> ch) & 1u) continue;
+              uint8_t v;
+              switch (c->kind[ch]) {
+                case kBase: v = c->lut_base[base]; break;
+                case kBaseQual: v = c->lut_bq[q]; break;
+                case kDiff: v = c->diff[base == rbase ? 1 : 0]; break;
+                case kMeth5:
+                  if (!(flags & DV_READ_HAS_5MC) || !a.mod_5mc) continue;
+                  v = c->lut_mod[a.mod_5mc[s0 + ri]];
+                  break;
+                case kMeth6:
+                  if (!(flags & DV_READ_HAS_6MA) || !a.mod_6ma) continue;
+                  v = c->lut_mod[a.mod_6ma[s0 + ri]];
+                  break;
+                case kZero: v = 0; break;
+                default: v = pc[ch]; break;
+              }
+              px[col * CO + ch] = v;
+            }
+          }
+        }
+      }
+      if (c->mean_cov_channel >= 0 && mc_val >= 0) {
+        for (int col = lane; col < W; col += 64)
+          px[col * CO + c->mean_cov_channel] = mc_val;
+      }
+    } else {
+      // below the pileup but inside the mean-coverage paint
+      for (int col = lane; col < W; col += 64)
+        px[col * CO + c->mean_cov_channel] = mc_val;
+    }
+    wave_sync();
+    // LDS row -> HBM: aligned dwords; the (<= 3 byte) ragged ends of the row
+    // go out as byte stores so neighbouring rows never race on a dword.
+    uint8_t* gbase = a.out + (g0 - s);
+    for (int k = lane; k < ndw; k += 64) {
+      const int lo = 4 * k - s;
+      const uint32_t v = rb32[k];
+      if (lo >= 0 && lo + 4 <= row_bytes) {
+        *reinterpret_cast<uint32_t*>(gbase + 4 * k) = v;
+      } else {
+        for (int b = 0; b < 4; ++b) {
+          const int idx = lo + b;
+          if (idx >= 0 && idx < row_bytes) gbase[4 * k + b] = (v >> (8 * b)) & 0xFF;
+        }
+      }
+    }
+    wave_sync();
+  }
+
+  // ---------------- blank rows: 16-byte zero stores -------------------------
+  {
+    const uint64_t base = reinterpret_cast<uint64_t>(a.out);
+    const uint64_t z0 = base + out0 + static_cast<uint64_t>(n_render) * row_bytes;
+    const uint64_t z1 = base + out0 + static_cast<uint64_t>(H) * row_bytes;
+    if (z1 > z0) {
+      const uint64_t a0 = min((z0 + 15) & ~15ull, z1);
+      const uint64_t a1 = max(z1 & ~15ull, a0);
+      for (uint64_t b = z0 + tid; b < a0; b += kBlock)
+        *reinterpret_cast<uint8_t*>(b) = 0;
+      uint4* body = reinterpret_cast<uint4*>(a0);
+      const uint64_t nvec = (a1 - a0) >> 4;
+      const uint4 zero = make_uint4(0, 0, 0, 0);
+      for (uint64_t i = tid; i < nvec; i += kBlock) body[i] = zero;
+      for (uint64_t b = a1 + tid; b < z1; b += kBlock)
+        *reinterpret_cast<uint8_t*>(b) = 0;
+    }
+  }
+  if (tid == 0 && a.out_rows) a.out_rows[item] = kept;
+}
+
+// ------------------------------------------------------------------ host side
+
+// channels/base_quality_channel.cc:59-66 and its clones.
+inline uint8_t ScaleColor(int value, float max_val) {
+  if (static_cast<float>(value) > max_val) value = max_val;
+  return static_cast<int>(254.0f * (static_cast<float>(value) / max_val));
+}
+
+}  // namespace
+
+struct dv_encoder {
+  int device = 0;
+  dv_encoder_options opt{};
+  EncConst konst{};
+  dv::DeviceBuffer d_konst, d_perm_off, d_perm, d_out, d_rows;
+  int perm_cap = 0;
+  std::vector<dv::DeviceBuffer> staging;
+};
+
+namespace {
+
+int build_const(const dv_encoder_options& o, EncConst* k) {
+  memset(k, 0, sizeof(*k));
+  // The reference's odd-width CHECK (pileup_image_native.cc:114) belongs to the
+  // options object and is enforced by the host mirror: EncodeRead /
+  // EncodeReference take the width from ref_bases and accept any length.
+  if (o.width < 1 || o.width > 4096) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "width out of range");
+  }
+  if (o.n_channels < 1 || o.n_channels > DV_MAX_CHANNELS) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "n_channels out of range");
+  }
+  if (o.reference_band_height < 0 || o.height <= o.reference_band_height) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                    "height must exceed reference_band_height");
+  }
+  k->n_channels = o.n_channels;
+  k->width = o.width;
+  k->band = o.reference_band_height;
+  k->min_bq = o.min_base_quality;
+  k->min_mapq = o.min_mapping_quality;
+  k->anchor_char = o.indel_anchoring_base_char & 0xFF;
+  k->sort_by_haplotypes = o.sort_by_haplotypes;
+  k->polishing = o.hp_tag_for_assembly_polishing;
+  k->sort_by_group = o.sort_by_alt_allele_support;
+  k->mean_cov_channel = -1;
+  // read_base_channel.cc:56-73
+  k->lut_base['A'] = o.base_color_offset_a_and_g + o.base_color_stride * 3;
+  k->lut_base['G'] = o.base_color_offset_a_and_g + o.base_color_stride * 2;
+  k->lut_base['T'] = o.base_color_offset_t_and_c + o.base_color_stride * 1;
+  k->lut_base['C'] = o.base_color_offset_t_and_c + o.base_color_stride * 0;
+  for (int q = 0; q < 256; ++q) {
+    k->lut_bq[q] = ScaleColor(q, o.base_quality_cap);        // base_quality_channel.cc:44-50
+    k->lut_mapq[q] = ScaleColor(q, o.mapping_quality_cap);   // mapping_quality_channel.cc:43-51
+    k->lut_mod[q] = ScaleColor(q, 255);                      // base_methylation_channel.cc:88-100
+  }
+  for (int f = 0; f <= 1000; ++f) {
+    // insert_size_channel.cc:79-90
+    k->lut_insert[f] = static_cast<uint8_t>(
+        static_cast<int>(254.0f * (static_cast<float>(f) / 1000.0f)));
+  }
+  // read_supports_variant_channel.cc:105-116
+  const float alphas[3] = {o.allele_unsupporting_read_alpha,
+                           o.allele_supporting_read_alpha,
+                           o.other_allele_supporting_read_alpha};
+  for (int i = 0; i < 3; ++i) {
+    k->lut_support[i] = static_cast<uint8_t>(static_cast<int>(254.0f * alphas[i]));
+  }
+  k->lut_support[3] = k->lut_support[2];
+  k->strand[0] = static_cast<uint8_t>(o.positive_strand_color);  // strand_channel.cc:44-61
+  k->strand[1] = static_cast<uint8_t>(o.negative_strand_color);
+  // base_differs_from_ref_channel.cc:59-66
+  k->diff[0] = static_cast<uint8_t>(
+      static_cast<int>(254.0f * o.reference_mismatching_read_alpha));
+  k->diff[1] = static_cast<uint8_t>(
+      static_cast<int>(254.0f * o.reference_matching_read_alpha));
+  // supplementary_alignment_channel.cc:49-59
+  k->supp[0] = static_cast<unsigned char>(254.0f * o.allele_unsupporting_read_alpha);
+  k->supp[1] = static_cast<unsigned char>(254.0f * o.allele_supporting_read_alpha);
+
+  const uint8_t ref_bq = ScaleColor(o.reference_base_quality, o.base_quality_cap);
+  for (int c = 0; c < o.n_channels; ++c) {
+    uint8_t kind = kZero, ref = 0;
+    switch (o.channels[c]) {
+      case DV_CH_READ_BASE: kind = kBase; break;
+      case DV_CH_BASE_QUALITY: kind = kBaseQual; ref = ref_bq; break;
+      case DV_CH_MAPPING_QUALITY: kind = kMapq; ref = ref_bq; break;  // mapping_quality_channel.cc:53-58
+      case DV_CH_STRAND: kind = kStrand; ref = k->strand[0]; break;
+      case DV_CH_READ_SUPPORTS_VARIANT: kind = kSupport; ref = k->lut_support[0]; break;
+      case DV_CH_BASE_DIFFERS_FROM_REF: kind = kDiff; ref = k->diff[1]; break;
+      case DV_CH_HAPLOTYPE_TAG: kind = kHaplotype; ref = 0; break;
+      case DV_CH_ALLELE_FREQUENCY: kind = kAuxList; ref = 0; break;
+      case DV_CH_READ_MAPPING_PERCENT: kind = kAuxRead0; ref = 254; break;
+      case DV_CH_AVG_BASE_QUALITY: kind = kAuxRead1; ref = 254; break;
+      case DV_CH_IDENTITY: kind = kAuxRead2; ref = 254; break;
+      case DV_CH_GAP_COMPRESSED_IDENTITY: kind = kAuxRead3; ref = 254; break;
+      case DV_CH_BLANK: kind = kZero; break;
+      case DV_CH_INSERT_SIZE: kind = kInsert; ref = 254; break;
+      case DV_CH_MEAN_COVERAGE: kind = kZero; k->mean_cov_channel = c; break;
+      case DV_CH_BASE_METHYLATION: kind = kMeth5; break;
+      case DV_CH_BASE_6MA: kind = kMeth6; break;
+      case DV_CH_SUPPLEMENTARY_ALIGNMENT:
+        kind = kSupplementary;
+        ref = static_cast<uint8_t>(o.allele_unsupporting_read_alpha);  // sic (:61-65)
+        break;
+      case DV_CH_ALLELE_SAMPLE_PROBABILITY: kind = kAuxList; ref = 0; break;
+      default:
+        return dv::fail(DV_ERR_UNSUPPORTED,
+                        "channel enum " + std::to_string(o.channels[c]) +
+                            " is not drawn by the device encoder");
+    }
+    k->kind[c] = kind;
+    k->ref_const[c] = ref;
+  }
+  return DV_OK;
+}
+
+// Uploads pi_n for every n <= cap.  pi_n is a pure function of (n, seed)
+// because the reference passes the generator by value into
+// DownsampleReadIndices (pileup_image_native.cc:153-165,327,343).
+int ensure_perm_table(dv_encoder* enc, int need) {
+  if (need <= enc->perm_cap) return DV_OK;
+  int cap = std::max(256, enc->perm_cap);
+  while (cap < need) cap *= 2;
+  if (cap > 65535) {
+    return dv::fail(DV_ERR_UNSUPPORTED, "more than 65535 reads in one pileup");
+  }
+  std::vector<uint32_t> off(cap + 2, 0);
+  size_t total = 0;
+  for (int n = 0; n <= cap; ++n) {
+    off[n] = static_cast<uint32_t>(total);
+    total += n;
+  }
+  std::vector<uint16_t> perm(total);
+  std::vector<int> idx;
+  for (int n = 2; n <= cap; ++n) {
+    idx.resize(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::mt19937_64 gen(enc->opt.random_seed);
+    std::shuffle(idx.begin(), idx.end(), gen);
+    for (int i = 0; i < n; ++i) perm[off[n] + i] = static_cast<uint16_t>(idx[i]);
+  }
+  if (int rc = enc->d_perm_off.reserve(off.size() * 4)) return rc;
+  if (int rc = enc->d_perm.reserve(std::max<size_t>(perm.size() * 2, 16))) return rc;
+  DV_HIP_CHECK(hipMemcpy(enc->d_perm_off.ptr, off.data(), off.size() * 4,
+                         hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(enc->d_perm.ptr, perm.data(), perm.size() * 2,
+                         hipMemcpyHostToDevice));
+  enc->perm_cap = cap;
+  return DV_OK;
+}
+
+template <typename T>
+int stage(dv_encoder* enc, size_t slot, const T* host, size_t count,
+          hipStream_t stream, const T** dev) {
+  if (host == nullptr || count == 0) {
+    *dev = nullptr;
+    // keep a valid (dummy) pointer for arrays the kernel indexes with 0 items
+    if (host != nullptr) {
+      if (int rc = enc->staging[slot].reserve(16)) return rc;
+      *dev = static_cast<const T*>(enc->staging[slot].ptr);
+    }
+    return DV_OK;
+  }
+  if (int rc = enc->staging[slot].reserve(count * sizeof(T))) return rc;
+  DV_HIP_CHECK(hipMemcpyAsync(enc->staging[slot].ptr, host, count * sizeof(T),
+                              hipMemcpyHostToDevice, stream));
+  *dev = static_cast<const T*>(enc->staging[slot].ptr);
+  return DV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dv_encoder_create(const dv_encoder_options* options, int device,
+                      dv_encoder** out) {
+  if (!options || !out) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_encoder_create: null argument");
+  }
+  EncConst k;
+  if (int rc = build_const(*options, &k)) return rc;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    return dv::fail(DV_ERR_NO_DEVICE,
+                    "no HIP device: libdvhip has no CPU fallback");
+  }
+  if (device < 0 || device >= n_dev) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "bad device ordinal");
+  }
+  DV_HIP_CHECK(hipSetDevice(device));
+  auto* enc = new dv_encoder();
+  enc->device = device;
+  enc->opt = *options;
+  enc->konst = k;
+  enc->staging.resize(40);
+  int rc = enc->d_konst.reserve(sizeof(EncConst));
+  if (rc == DV_OK) {
+    hipError_t e = hipMemcpy(enc->d_konst.ptr, &k, sizeof(k), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = dv::fail(DV_ERR_HIP, hipGetErrorString(e));
+  }
+  if (rc == DV_OK) rc = ensure_perm_table(enc, 256);
+  if (rc != DV_OK) {
+    dv_encoder_destroy(enc);
+    return rc;
+  }
+  *out = enc;
+  return DV_OK;
+}
+
+void dv_encoder_destroy(dv_encoder* enc) {
+  if (!enc) return;
+  (void)hipSetDevice(enc->device);
+  enc->d_konst.release();
+  enc->d_perm_off.release();
+  enc->d_perm.release();
+  enc->d_out.release();
+  enc->d_rows.release();
+  for (auto& b : enc->staging) b.release();
+  delete enc;
+}
+
+int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
+                    uint8_t* out, int32_t* out_rows, int out_memory,
+                    void* stream_v) {
+  if (!enc || !b || !out) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_encode_batch: null argument");
+  }
+  if (out_channels < enc->opt.n_channels || out_channels > 64) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                    "out_channels must be >= n_channels");
+  }
+  if (b->n_items == 0) return DV_OK;
+  if (b->n_items < 0 || b->n_reads < 0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "negative counts");
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  DV_HIP_CHECK(hipSetDevice(enc->device));
+  if (int rc = ensure_perm_table(enc, static_cast<int>(b->max_list_len))) return rc;
+
+  const int W = enc->opt.width;
+  const size_t row_bytes = static_cast<size_t>(W) * out_channels;
+  EncArgs a{};
+  a.konst = static_cast<const EncConst*>(enc->d_konst.ptr);
+  a.perm_off = static_cast<const uint32_t*>(enc->d_perm_off.ptr);
+  a.perm = static_cast<const uint16_t*>(enc->d_perm.ptr);
+  a.n_items = b->n_items;
+  a.out_channels = out_channels;
+  a.row_buf_bytes = static_cast<int>((row_bytes + 8 + 15) & ~size_t(15));
+
+  size_t out_bytes = 0;
+  if (b->memory == DV_MEM_HOST) {
+    // Validate what the reference would LOG(FATAL)/CHECK on, then stage.
+    for (uint32_t i = 0; i < b->n_cigar; ++i) {
+      const uint32_t op = b->cigar[i] & 0xF;
+      if (op < 1 || op > 9) {
+        return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op");
+      }
+    }
+    for (int i = 0; i < b->n_items; ++i) {
+      const int h = b->item_height[i];
+      if (h <= enc->opt.reference_band_height || h - enc->opt.reference_band_height > kMaxKept) {
+        return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                        "item_height must be in (reference_band_height, "
+                        "reference_band_height + 256]");
+      }
+      if (b->item_list_off[i + 1] - b->item_list_off[i] > b->max_list_len) {
+        return dv::fail(DV_ERR_INVALID_ARGUMENT, "max_list_len too small");
+      }
+      if (b->item_ref_idx[i] >= b->n_ref_windows) {
+        return dv::fail(DV_ERR_INVALID_ARGUMENT, "item_ref_idx out of range");
+      }
+      out_bytes = std::max<size_t>(out_bytes, b->item_out_off[i] + h * row_bytes);
+    }
+    for (uint32_t i = 0; i < b->n_list; ++i) {
+      if (b->list_read[i] >= static_cast<uint32_t>(b->n_reads)) {
+        return dv::fail(DV_ERR_INVALID_ARGUMENT, "list_read out of range");
+      }
+    }
+    for (int r = 0; r < b->n_reads; ++r) {
+      // the cigar's query length must not exceed the stored sequence
+      uint64_t qlen = 0;
+      for (uint32_t c = b->read_cigar_off[r]; c < b->read_cigar_off[r + 1]; ++c) {
+        const uint32_t op = b->cigar[c] & 0xF;
+        if (op == 1 || op == 2 || op == 5 || op == 8 || op == 9) qlen += b->cigar[c] >> 4;
+      }
+      if (qlen > b->read_seq_off[r + 1] - b->read_seq_off[r]) {
+        return dv::fail(DV_ERR_BAD_INPUT,
+                        "CIGAR consumes more bases than aligned_sequence has");
+      }
+    }
+    size_t s = 0;
+    const size_t nr = b->n_reads, ni = b->n_items;
+#define DV_STAGE(field, count)                                               \
+  if (int rc = stage(enc, s++, b->field, count, stream, &a.field)) return rc;
+    DV_STAGE(read_pos, nr)
+    DV_STAGE(read_sort_pos, nr)
+    DV_STAGE(read_seq_off, nr + 1)
+    DV_STAGE(read_cigar_off, nr + 1)
+    DV_STAGE(read_mapq, nr)
+    DV_STAGE(read_flags, nr)
+    DV_STAGE(read_frag_len, nr)
+    DV_STAGE(read_hp, nr)
+    DV_STAGE(read_name_rank, nr)
+    DV_STAGE(read_aux, nr * DV_READ_AUX_STRIDE)
+    DV_STAGE(bases, b->n_bases)
+    DV_STAGE(quals, b->n_bases)
+    DV_STAGE(mod_5mc, b->n_bases)
+    DV_STAGE(mod_6ma, b->n_bases)
+    DV_STAGE(cigar, b->n_cigar)
+    DV_STAGE(item_variant_start, ni)
+    DV_STAGE(item_image_start, ni)
+    DV_STAGE(item_ref_idx, ni)
+    DV_STAGE(item_list_off, ni + 1)
+    DV_STAGE(item_height, ni)
+    DV_STAGE(item_out_off, ni)
+    DV_STAGE(item_blank_mask, ni)
+    DV_STAGE(item_mean_coverage, ni)
+    DV_STAGE(ref_windows, static_cast<size_t>(b->n_ref_windows) * W)
+    DV_STAGE(list_read, b->n_list)
+    DV_STAGE(list_code, b->n_list)
+    DV_STAGE(list_group, b->n_list)
+    DV_STAGE(list_aux, b->n_list)
+#undef DV_STAGE
+  } else {
+#define DV_PASS(field) a.field = b->field;
+    DV_PASS(read_pos) DV_PASS(read_sort_pos) DV_PASS(read_seq_off)
+    DV_PASS(read_cigar_off) DV_PASS(read_mapq) DV_PASS(read_flags)
+    DV_PASS(read_frag_len) DV_PASS(read_hp) DV_PASS(read_name_rank)
+    DV_PASS(read_aux) DV_PASS(bases) DV_PASS(quals) DV_PASS(mod_5mc)
+    DV_PASS(mod_6ma) DV_PASS(cigar) DV_PASS(item_variant_start)
+    DV_PASS(item_image_start) DV_PASS(item_ref_idx) DV_PASS(item_list_off)
+    DV_PASS(item_height) DV_PASS(item_out_off) DV_PASS(item_blank_mask)
+    DV_PASS(item_mean_coverage) DV_PASS(ref_windows) DV_PASS(list_read)
+    DV_PASS(list_code) DV_PASS(list_group) DV_PASS(list_aux)
+#undef DV_PASS
+  }
+
+  uint8_t* d_out = out;
+  int32_t* d_rows = out_rows;
+  if (out_memory == DV_MEM_HOST) {
+    if (b->memory != DV_MEM_HOST) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                      "host output requires a host batch (sizes unknown)");
+    }
+    if (int rc = enc->d_out.reserve(out_bytes)) return rc;
+    d_out = static_cast<uint8_t*>(enc->d_out.ptr);
+    if (out_rows) {
+      if (int rc = enc->d_rows.reserve(sizeof(int32_t) * b->n_items)) return rc;
+      d_rows = static_cast<int32_t*>(enc->d_rows.ptr);
+    }
+  }
+  if ((reinterpret_cast<uintptr_t>(d_out) & 3) != 0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "out must be 4-byte aligned");
+  }
+  a.out = d_out;
+  a.out_rows = d_rows;
+
+  const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
+                     kWaves * DV_MAX_CHANNELS +
+                     static_cast<size_t>(kWaves) * a.row_buf_bytes;
+  {
+    dv::ProfileScope prof(dv::kProfEncoder, stream);
+    hipLaunchKernelGGL(encode_items_kernel, dim3(b->n_items), dim3(kBlock), lds,
+                       stream, a);
+  }
+  DV_HIP_CHECK(hipGetLastError());
+  if (out_memory == DV_MEM_HOST) {
+    DV_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+    if (out_rows) {
+      DV_HIP_CHECK(hipMemcpyAsync(out_rows, d_rows, sizeof(int32_t) * b->n_items,
+                                  hipMemcpyDeviceToHost, stream));
+    }
+    DV_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return DV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+"""A `dv_batch` whose arrays live in HBM (torch tensors own the memory).
+
+PyTorch is plumbing here: it allocates device memory and provides the stream;
+the encoder is called through the C ABI with raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from deepvariant_amd import _lib
+from deepvariant_amd import packing
+
+_FIELDS = [
+    ('read_pos', np.int32), ('read_sort_pos', np.int32),
+    ('read_seq_off', np.uint32), ('read_cigar_off', np.uint32),
+    ('read_mapq', np.uint8), ('read_flags', np.uint8),
+    ('read_frag_len', np.int32), ('read_hp', np.int32),
+    ('read_name_rank', np.uint32), ('read_aux', np.uint8),
+    ('bases', np.uint8), ('quals', np.uint8), ('mod_5mc', np.uint8),
+    ('mod_6ma', np.uint8), ('cigar', np.uint32),
+    ('item_variant_start', np.int32), ('item_image_start', np.int32),
+    ('item_ref_idx', np.uint32), ('item_list_off', np.uint32),
+    ('item_height', np.uint16), ('item_out_off', np.uint64),
+    ('item_blank_mask', np.uint32), ('item_mean_coverage', np.float32),
+    ('ref_windows', np.uint8), ('list_read', np.uint32),
+    ('list_code', np.uint8), ('list_group', np.uint8), ('list_aux', np.uint8),
+]
+
+
+class DeviceBatch:
+  """Uploads a PackedBatch once; `encode` launches with device pointers."""
+
+  def __init__(self, batch: packing.PackedBatch, device: torch.device):
+    self.n_items = batch.n_items
+    self.width = batch.width
+    self.tensors = {}
+    self.c = _lib.DvBatch()
+    self.c.memory = _lib.DV_MEM_DEVICE
+    for name, dtype in _FIELDS:
+      arr = getattr(batch, name)
+      if arr is None:
+        setattr(self.c, name, None)
+        continue
+      raw = np.ascontiguousarray(arr, dtype=dtype).view(np.uint8).reshape(-1)
+      if raw.size == 0:
+        raw = np.zeros(16, np.uint8)
+      pad = (-raw.size) % 16
+      if pad:
+        raw = np.concatenate([raw, np.zeros(pad, np.uint8)])
+      t = torch.from_numpy(raw.copy()).to(device)
+      self.tensors[name] = t
+      setattr(self.c, name, t.data_ptr())
+    t = batch.table
+    self.c.n_reads = t.n_reads
+    self.c.n_bases = int(t.read_seq_off[-1])
+    self.c.n_cigar = int(t.read_cigar_off[-1])
+    self.c.n_items = batch.n_items
+    self.c.n_ref_windows = len(batch.ref_windows_list)
+    self.c.n_list = int(batch.item_list_off[-1])
+    self.c.max_list_len = batch.max_list_len
+    self.input_bytes = sum(int(x.numel()) for x in self.tensors.values())
+
+  def encode(self, encoder, out_channels: int, out: torch.Tensor,
+             rows: torch.Tensor = None, stream=None):
+    if stream is None:
+      stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().dv_encode_batch(
+        encoder.handle, C.byref(self.c), out_channels, out.data_ptr(),
+        rows.data_ptr() if rows is not None else None, _lib.DV_MEM_DEVICE,
+        C.c_void_p(stream)))

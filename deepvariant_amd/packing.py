@@ -1,0 +1,478 @@
+"""Host side of the encoder boundary: proto-shaped inputs -> packed `dv_batch`.
+
+This is where the strings of the reference's inputs stop.  The reference's
+encoder does string work per read per candidate
+(`ReadSupportsVariantChannel::ReadSupportsAlt`,
+deepvariant/channels/read_supports_variant_channel.cc:75-104; the
+(fragment_name, read_number) tie-break of `SortImageRows`,
+deepvariant/pileup_image_native.cc:97-101).  Here each is resolved ONCE on the
+host into a small integer per read / per (item, read); only integers and bytes
+cross to the device (include/dvhip.h, `dv_batch`).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from deepvariant_amd import _lib
+from deepvariant_amd import dv_types as T
+
+DV_READ_REVERSE, DV_READ_SUPPLEMENTARY, DV_READ_HAS_5MC, DV_READ_HAS_6MA = 1, 2, 4, 8
+
+# Channels whose pixel the device computes itself / which need host-computed
+# aux bytes (include/dvhip.h DV_CH_*).
+_READ_AUX_SLOT = {11: 0, 12: 1, 13: 2, 14: 3}
+_LIST_AUX_CHANNELS = (8, 27)
+
+
+def channel_enums(pic_options) -> List[int]:
+  """AllChannelsEnum("") -- pileup_image_native.cc:125-151."""
+  out = []
+  for name in pic_options.channels:
+    if name not in T.CHANNEL_STR_TO_ENUM:
+      raise ValueError(
+          "Channel '%s' should have a corresponding enum in "
+          'DeepVariantChannelEnum.' % name)
+    e = T.CHANNEL_STR_TO_ENUM[name]
+    if e != 0:
+      out.append(e)
+  return out
+
+
+def make_encoder_options(pic_options, width: Optional[int] = None
+                         ) -> _lib.DvEncoderOptions:
+  o = _lib.DvEncoderOptions()
+  chans = channel_enums(pic_options)
+  if len(chans) > _lib.DV_MAX_CHANNELS:
+    raise ValueError('at most %d channels' % _lib.DV_MAX_CHANNELS)
+  o.n_channels = len(chans)
+  for i, c in enumerate(chans):
+    o.channels[i] = c
+  for f in ('height', 'reference_band_height', 'base_color_offset_a_and_g',
+            'base_color_offset_t_and_c', 'base_color_stride',
+            'allele_supporting_read_alpha', 'allele_unsupporting_read_alpha',
+            'other_allele_supporting_read_alpha',
+            'reference_matching_read_alpha', 'reference_mismatching_read_alpha',
+            'reference_base_quality', 'positive_strand_color',
+            'negative_strand_color', 'base_quality_cap', 'mapping_quality_cap',
+            'random_seed', 'hp_tag_for_assembly_polishing',
+            'min_non_zero_allele_frequency'):
+    setattr(o, f, getattr(pic_options, f))
+  o.width = width if width is not None else pic_options.width
+  o.sort_by_haplotypes = int(bool(pic_options.sort_by_haplotypes))
+  o.sort_by_alt_allele_support = int(
+      bool(getattr(pic_options, 'sort_by_alt_allele_support', False)))
+  ch = pic_options.indel_anchoring_base_char
+  o.indel_anchoring_base_char = ord(ch[0]) if ch else 0
+  o.min_base_quality = pic_options.read_requirements.min_base_quality
+  o.min_mapping_quality = pic_options.read_requirements.min_mapping_quality
+  return o
+
+
+def _scale_color(value: int, max_val: float) -> int:
+  """ScaleColor of channels/*.cc in IEEE fp32."""
+  mv = np.float32(max_val)
+  if np.float32(value) > mv:
+    value = int(mv)
+  return int(np.float32(254.0) * (np.float32(value) / mv)) & 0xFF
+
+
+def read_key(read) -> str:
+  """read_supports_variant_channel.cc:78-79."""
+  return '%s/%d' % (read.fragment_name, read.read_number)
+
+
+def _hp_value(read) -> int:
+  """The single integer HP tag, or DV_HP_NONE.
+
+  HaplotypeTagChannel (haplotype_tag_channel.cc:76-100) and GetHapIndex
+  (pileup_image_native.cc:449-475) only disagree on reads carrying several HP
+  values or a non-integer one; direct phasing never writes those, and the
+  packer refuses them rather than guess.
+  """
+  info = read.info
+  if 'HP' not in info:
+    return _lib.DV_HP_NONE
+  values = info['HP'].values
+  if len(values) == 0:
+    return _lib.DV_HP_NONE
+  if len(values) > 1 or values[0].WhichOneof('kind') != 'int_value':
+    raise ValueError('unsupported HP tag shape on read %s' % read.fragment_name)
+  return int(values[0].int_value)
+
+
+@dataclasses.dataclass
+class ReadTable:
+  """Structure-of-arrays image of a list of Read protos (one region)."""
+  n_reads: int
+  read_pos: np.ndarray
+  read_sort_pos: Optional[np.ndarray]
+  read_seq_off: np.ndarray
+  read_cigar_off: np.ndarray
+  read_mapq: np.ndarray
+  read_flags: np.ndarray
+  read_frag_len: np.ndarray
+  read_hp: np.ndarray
+  read_name_rank: np.ndarray
+  read_aux: Optional[np.ndarray]
+  bases: np.ndarray
+  quals: np.ndarray
+  mod_5mc: Optional[np.ndarray]
+  mod_6ma: Optional[np.ndarray]
+  cigar: np.ndarray
+  keys: List[str]
+  read_end: np.ndarray
+
+  @classmethod
+  def from_reads(cls, reads: Sequence, alignment_positions=None,
+                 need_aux: bool = False) -> 'ReadTable':
+    n = len(reads)
+    pos = np.zeros(n, np.int32)
+    mapq = np.zeros(n, np.uint8)
+    flags = np.zeros(n, np.uint8)
+    frag = np.zeros(n, np.int32)
+    hp = np.full(n, _lib.DV_HP_NONE, np.int32)
+    seq_off = np.zeros(n + 1, np.uint32)
+    cig_off = np.zeros(n + 1, np.uint32)
+    read_end = np.zeros(n, np.int64)
+    seqs, quals, cig = [], [], []
+    m5, m6 = [], []
+    any5 = any6 = False
+    aux = np.zeros((n, _lib.DV_READ_AUX_STRIDE), np.uint8) if need_aux else None
+    keys, sort_keys = [], []
+    for i, r in enumerate(reads):
+      aln = r.alignment
+      p = aln.position.position
+      if not -(1 << 31) <= p < (1 << 31):
+        raise ValueError('alignment position does not fit int32')
+      pos[i] = p
+      mq = aln.mapping_quality
+      if not 0 <= mq <= 255:
+        raise ValueError('mapping_quality %d outside [0, 255]' % mq)
+      mapq[i] = mq
+      f = 0
+      if aln.position.reverse_strand:
+        f |= DV_READ_REVERSE
+      if getattr(r, 'supplementary_alignment', False):
+        f |= DV_READ_SUPPLEMENTARY
+      frag[i] = r.fragment_length
+      hp[i] = _hp_value(r)
+      seq = r.aligned_sequence
+      sb = seq.encode() if isinstance(seq, str) else bytes(seq)
+      qb = bytes(bytearray(r.aligned_quality))
+      if len(qb) != len(sb):
+        raise ValueError('aligned_quality and aligned_sequence differ in length '
+                         'for read %s' % r.fragment_name)
+      seqs.append(sb)
+      quals.append(qb)
+      seq_off[i + 1] = seq_off[i] + len(sb)
+      mods = getattr(r, 'base_modifications', None) or {}
+      for key, store, bit in ((T.K5MC, m5, DV_READ_HAS_5MC),
+                              (T.K6MA, m6, DV_READ_HAS_6MA)):
+        if key in mods:
+          mb = bytes(mods[key])
+          if len(mb) != len(sb):
+            raise ValueError('base_modifications length mismatch')
+          store.append(mb)
+          f |= bit
+          if bit == DV_READ_HAS_5MC:
+            any5 = True
+          else:
+            any6 = True
+        else:
+          store.append(b'\0' * len(sb))
+      flags[i] = f
+      e = p
+      qlen = 0
+      match_len = gap_len = 0
+      for cu in aln.cigar:
+        op, ln = int(cu.operation), int(cu.operation_length)
+        if not 1 <= op <= 9:
+          raise ValueError('Unrecognized CIGAR op')  # reference: LOG(FATAL)
+        if not 0 <= ln < (1 << 28):
+          raise ValueError('CIGAR operation_length out of range')
+        cig.append((ln << 4) | op)
+        if op in (1, 8, 9, 3, 4):
+          e += ln
+        if op in (1, 2, 5, 8, 9):
+          qlen += ln
+        if op in (1, 8):
+          match_len += ln
+          gap_len += ln
+        elif op == 9:
+          gap_len += ln
+        elif op in (2, 3):
+          gap_len += 1
+      if qlen > len(sb):
+        raise ValueError('CIGAR consumes more bases than aligned_sequence has')
+      read_end[i] = e
+      cig_off[i + 1] = cig_off[i] + len(aln.cigar)
+      if need_aux:
+        # read_mapping_percent / identity (identical arithmetic),
+        # avg_base_quality, gap_compressed_identity -- channels/*.cc.
+        f32 = np.float32
+        pct = int(f32(match_len) / f32(max(len(sb), 1)) * f32(100)) if sb else 0
+        aux[i, 0] = _scale_color(pct, 100)
+        aux[i, 2] = _scale_color(pct, 100)
+        if qb:
+          if max(qb) > 93:
+            raise ValueError('Encountered base quality outside of bounds (0,93)')
+          aux[i, 1] = _scale_color(int(f32(sum(qb)) / f32(len(qb))), 93)
+        if gap_len:
+          aux[i, 3] = _scale_color(
+              int(f32(match_len) / f32(gap_len) * f32(100)), 100)
+      keys.append(read_key(r))
+      sort_keys.append((r.fragment_name.encode(), int(r.read_number)))
+    # dense rank under the reference's tuple<string,int> ordering
+    uniq = sorted(set(sort_keys))
+    rank_of = {k: j for j, k in enumerate(uniq)}
+    ranks = np.array([rank_of[k] for k in sort_keys], np.uint32).reshape(n)
+    sort_pos = None
+    if alignment_positions is not None and len(alignment_positions):
+      if len(alignment_positions) != n:
+        raise ValueError('alignment_positions must match reads')
+      sort_pos = np.array(alignment_positions, np.int64).astype(np.int32)
+    return cls(
+        n_reads=n, read_pos=pos, read_sort_pos=sort_pos, read_seq_off=seq_off,
+        read_cigar_off=cig_off, read_mapq=mapq, read_flags=flags,
+        read_frag_len=frag, read_hp=hp, read_name_rank=ranks, read_aux=aux,
+        bases=np.frombuffer(b''.join(seqs), np.uint8),
+        quals=np.frombuffer(b''.join(quals), np.uint8),
+        mod_5mc=np.frombuffer(b''.join(m5), np.uint8) if any5 else None,
+        mod_6ma=np.frombuffer(b''.join(m6), np.uint8) if any6 else None,
+        cigar=np.array(cig, np.uint32), keys=keys, read_end=read_end)
+
+  def query(self, start: int, end: int) -> np.ndarray:
+    """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""
+    return np.nonzero((end > self.read_pos) & (start < self.read_end))[0].astype(
+        np.uint32)
+
+
+def support_codes(dv_call, alt_alleles: Sequence[str], table: ReadTable,
+                  read_idx: Sequence[int]) -> np.ndarray:
+  """ReadSupportsAlt for each listed read: 0 ref / 1 this alt / 2 other alt."""
+  first_alt: Dict[str, str] = {}
+  support = dv_call.allele_support
+  for alt in dv_call.variant.alternate_bases:
+    if alt in support:
+      for name in support[alt].read_names:
+        first_alt.setdefault(name, alt)
+  alts = set(alt_alleles)
+  out = np.zeros(len(read_idx), np.uint8)
+  for j, r in enumerate(read_idx):
+    a = first_alt.get(table.keys[r])
+    if a is not None:
+      out[j] = 1 if a in alts else 2
+  return out
+
+
+def allele_groups(dv_call, table: ReadTable, read_idx: Sequence[int]
+                  ) -> np.ndarray:
+  """Allele-support sort group (pileup_image_native.cc:346-393)."""
+  alts = list(dv_call.variant.alternate_bases)
+  group_of: Dict[str, int] = {}
+  for i, alt in enumerate(alts):
+    if alt in dv_call.allele_support:
+      for name in dv_call.allele_support[alt].read_names:
+        group_of[name] = i
+  if len(alts) > 255:
+    raise ValueError('too many alt alleles')
+  return np.array([group_of.get(table.keys[r], len(alts)) for r in read_idx],
+                  np.uint8)
+
+
+def allele_frequency_pixels(pic_options, dv_call, alt_alleles, table, read_idx
+                            ) -> np.ndarray:
+  """AlleleFrequencyChannel (channels/allele_frequency_channel.cc:53-119)."""
+  alts = set(alt_alleles)
+  out = np.zeros(len(read_idx), np.uint8)
+  support = dv_call.allele_support
+  min_af = np.float32(pic_options.min_non_zero_allele_frequency)
+  log10_min = np.float32(np.log10(np.float64(min_af)))
+  for j, r in enumerate(read_idx):
+    key = table.keys[r]
+    af = 0.0
+    done = False
+    for alt in dv_call.variant.alternate_bases:
+      if alt in support and not done:
+        for name in support[alt].read_names:
+          if name == key and alt in alts:
+            af = dv_call.allele_frequency.get(alt, 0.0)
+            done = True
+            break
+    af = np.float32(af)
+    if af > min_af:
+      log10_af = np.float32(np.log10(np.float64(af)))
+      out[j] = int(((log10_min - log10_af) / log10_min) * np.float32(254)) & 0xFF
+  return out
+
+
+@dataclasses.dataclass
+class PackedBatch:
+  """Host image of `dv_batch` (numpy arrays), plus the ctypes view."""
+  table: ReadTable
+  width: int
+  item_variant_start: List[int] = dataclasses.field(default_factory=list)
+  item_image_start: List[int] = dataclasses.field(default_factory=list)
+  item_ref_idx: List[int] = dataclasses.field(default_factory=list)
+  item_height: List[int] = dataclasses.field(default_factory=list)
+  item_out_off: List[int] = dataclasses.field(default_factory=list)
+  item_blank_mask: List[int] = dataclasses.field(default_factory=list)
+  item_mean_coverage: List[float] = dataclasses.field(default_factory=list)
+  item_list_off: List[int] = dataclasses.field(default_factory=lambda: [0])
+  ref_windows_list: List[bytes] = dataclasses.field(default_factory=list)
+  list_read_chunks: List[np.ndarray] = dataclasses.field(default_factory=list)
+  list_code_chunks: List[np.ndarray] = dataclasses.field(default_factory=list)
+  list_group_chunks: List[np.ndarray] = dataclasses.field(default_factory=list)
+  list_aux_chunks: List[np.ndarray] = dataclasses.field(default_factory=list)
+  use_groups: bool = False
+  use_list_aux: bool = False
+  _frozen: Optional[dict] = None
+
+  # ---- building -----------------------------------------------------------
+  def add_ref_window(self, ref_bases: str) -> int:
+    if len(ref_bases) != self.width:
+      raise ValueError('ref_bases.size() != width')  # pileup_image_native.cc:308
+    self.ref_windows_list.append(ref_bases.encode())
+    return len(self.ref_windows_list) - 1
+
+  def add_item(self, variant_start: int, image_start: int, ref_idx: int,
+               read_idx: np.ndarray, codes: np.ndarray, height: int,
+               out_off: int, blank_mask: int = 0, mean_coverage: float = 0.0,
+               groups: Optional[np.ndarray] = None,
+               list_aux: Optional[np.ndarray] = None):
+    self._frozen = None
+    self.item_variant_start.append(int(variant_start))
+    self.item_image_start.append(int(image_start))
+    self.item_ref_idx.append(int(ref_idx))
+    self.item_height.append(int(height))
+    self.item_out_off.append(int(out_off))
+    self.item_blank_mask.append(int(blank_mask))
+    self.item_mean_coverage.append(float(mean_coverage))
+    n = len(read_idx)
+    self.list_read_chunks.append(np.asarray(read_idx, np.uint32))
+    self.list_code_chunks.append(np.asarray(codes, np.uint8))
+    self.list_group_chunks.append(
+        np.asarray(groups, np.uint8) if groups is not None
+        else np.zeros(n, np.uint8))
+    self.list_aux_chunks.append(
+        np.asarray(list_aux, np.uint8) if list_aux is not None
+        else np.zeros(n, np.uint8))
+    self.use_groups |= groups is not None
+    self.use_list_aux |= list_aux is not None
+    self.item_list_off.append(self.item_list_off[-1] + n)
+
+  # ---- views (names = dv_batch fields; the oracle adapter reads them too) --
+  def _freeze(self) -> dict:
+    if self._frozen is None:
+      cat = lambda ch, dt: (np.concatenate(ch).astype(dt) if ch
+                            else np.zeros(0, dt))
+      self._frozen = dict(
+          item_variant_start=np.array(self.item_variant_start, np.int32),
+          item_image_start=np.array(self.item_image_start, np.int32),
+          item_ref_idx=np.array(self.item_ref_idx, np.uint32),
+          item_list_off=np.array(self.item_list_off, np.uint32),
+          item_height=np.array(self.item_height, np.uint16),
+          item_out_off=np.array(self.item_out_off, np.uint64),
+          item_blank_mask=np.array(self.item_blank_mask, np.uint32),
+          item_mean_coverage=np.array(self.item_mean_coverage, np.float32),
+          ref_windows=np.frombuffer(b''.join(self.ref_windows_list), np.uint8),
+          list_read=cat(self.list_read_chunks, np.uint32),
+          list_code=cat(self.list_code_chunks, np.uint8),
+          list_group=cat(self.list_group_chunks, np.uint8),
+          list_aux=cat(self.list_aux_chunks, np.uint8))
+    return self._frozen
+
+  def __getattr__(self, name):
+    if name.startswith('_'):
+      raise AttributeError(name)
+    fz = self._freeze()
+    if name in fz:
+      if name == 'list_group' and not self.use_groups:
+        return None
+      if name == 'list_aux' and not self.use_list_aux:
+        return None
+      return fz[name]
+    t = self.__dict__.get('table')
+    if t is not None and hasattr(t, name):
+      return getattr(t, name)
+    raise AttributeError(name)
+
+  @property
+  def n_items(self) -> int:
+    return len(self.item_height)
+
+  @property
+  def max_list_len(self) -> int:
+    off = self.item_list_off
+    return max([off[i + 1] - off[i] for i in range(self.n_items)] or [0])
+
+  def out_bytes(self, out_channels: int) -> int:
+    row = self.width * out_channels
+    return max([o + h * row for o, h in zip(self.item_out_off,
+                                            self.item_height)] or [0])
+
+  def to_ctypes(self):
+    """-> (DvBatch, keepalive list) with host pointers."""
+    fz = self._freeze()
+    t = self.table
+    b = _lib.DvBatch()
+    keep = []
+
+    def ptr(arr, dtype):
+      if arr is None:
+        return None
+      arr = np.ascontiguousarray(arr, dtype=dtype)
+      if arr.size == 0:
+        arr = np.zeros(1, dtype)
+      keep.append(arr)
+      return arr.ctypes.data
+
+    b.memory = _lib.DV_MEM_HOST
+    b.n_reads = t.n_reads
+    b.read_pos = ptr(t.read_pos, np.int32)
+    b.read_sort_pos = ptr(t.read_sort_pos, np.int32)
+    b.read_seq_off = ptr(t.read_seq_off, np.uint32)
+    b.read_cigar_off = ptr(t.read_cigar_off, np.uint32)
+    b.read_mapq = ptr(t.read_mapq, np.uint8)
+    b.read_flags = ptr(t.read_flags, np.uint8)
+    b.read_frag_len = ptr(t.read_frag_len, np.int32)
+    b.read_hp = ptr(t.read_hp, np.int32)
+    b.read_name_rank = ptr(t.read_name_rank, np.uint32)
+    b.read_aux = ptr(t.read_aux, np.uint8)
+    b.bases = ptr(t.bases, np.uint8)
+    b.quals = ptr(t.quals, np.uint8)
+    b.mod_5mc = ptr(t.mod_5mc, np.uint8)
+    b.mod_6ma = ptr(t.mod_6ma, np.uint8)
+    b.cigar = ptr(t.cigar, np.uint32)
+    b.n_bases = int(t.read_seq_off[-1])
+    b.n_cigar = int(t.read_cigar_off[-1])
+    b.n_items = self.n_items
+    b.item_variant_start = ptr(fz['item_variant_start'], np.int32)
+    b.item_image_start = ptr(fz['item_image_start'], np.int32)
+    b.item_ref_idx = ptr(fz['item_ref_idx'], np.uint32)
+    b.item_list_off = ptr(fz['item_list_off'], np.uint32)
+    b.item_height = ptr(fz['item_height'], np.uint16)
+    b.item_out_off = ptr(fz['item_out_off'], np.uint64)
+    b.item_blank_mask = ptr(fz['item_blank_mask'], np.uint32)
+    b.item_mean_coverage = ptr(fz['item_mean_coverage'], np.float32)
+    b.ref_windows = ptr(fz['ref_windows'], np.uint8)
+    b.n_ref_windows = len(self.ref_windows_list)
+    b.list_read = ptr(fz['list_read'], np.uint32)
+    b.list_code = ptr(fz['list_code'], np.uint8)
+    b.list_group = ptr(fz['list_group'], np.uint8) if self.use_groups else None
+    b.list_aux = ptr(fz['list_aux'], np.uint8) if self.use_list_aux else None
+    b.n_list = int(fz['item_list_off'][-1])
+    b.max_list_len = self.max_list_len
+    return b, keep
+
+
+def blank_mask_for(chan_enums: Sequence[int], channels_enum_to_blank) -> int:
+  mask = 0
+  blank = set(int(x) for x in (channels_enum_to_blank or []))
+  for i, e in enumerate(chan_enums):
+    if e in blank:
+      mask |= 1 << i
+  return mask

@@ -1,0 +1,299 @@
+/*
+ * dvhip.h -- C ABI of libdvhip.so, the MI355X (gfx950) implementation of
+ * DeepVariant's make_examples -> call_variants hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * pointers and sizes (no torch / protobuf / STL types), and replaces one piece
+ * of the reference's native hot path; the reference interface each one
+ * replaces is cited as file:line relative to google/deepvariant v1.10.0.
+ * INTEGRATION.md shows the pybind/ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - Return value: DV_OK (0) or a negative dv_status; dv_last_error() gives a
+ *     thread-local message.  Conditions the reference CHECK-fails on
+ *     (LOG(FATAL)) are reported as errors, never silently patched.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     device work is enqueued on it; calls that write HOST memory synchronise
+ *     the stream before returning, calls that only touch device memory do not.
+ *   - Pointers inside dv_batch are host or device pointers according to
+ *     dv_batch.memory.  Device pointers must be 4-byte aligned.
+ *   - There is NO CPU fallback: without a HIP device every compute entry
+ *     point returns DV_ERR_NO_DEVICE.
+ */
+#ifndef DVHIP_H_
+#define DVHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DV_ABI_VERSION 1
+#define DV_MAX_CHANNELS 16
+#define DV_READ_AUX_STRIDE 8
+
+typedef enum dv_status {
+  DV_OK = 0,
+  DV_ERR_INVALID_ARGUMENT = -1,
+  DV_ERR_UNSUPPORTED = -2, /* e.g. a channel the device encoder does not draw */
+  DV_ERR_NO_DEVICE = -3,
+  DV_ERR_HIP = -4,
+  DV_ERR_OUT_OF_MEMORY = -5,
+  DV_ERR_BAD_INPUT = -6, /* what the reference would CHECK-fail / LOG(FATAL) on */
+} dv_status;
+
+typedef enum dv_memory { DV_MEM_HOST = 0, DV_MEM_DEVICE = 1 } dv_memory;
+
+/* DeepVariantChannelEnum values, deepvariant/protos/deepvariant.proto:1287-1342. */
+enum {
+  DV_CH_READ_BASE = 1,
+  DV_CH_BASE_QUALITY = 2,
+  DV_CH_MAPPING_QUALITY = 3,
+  DV_CH_STRAND = 4,
+  DV_CH_READ_SUPPORTS_VARIANT = 5,
+  DV_CH_BASE_DIFFERS_FROM_REF = 6,
+  DV_CH_HAPLOTYPE_TAG = 7,
+  DV_CH_ALLELE_FREQUENCY = 8,          /* pixel supplied in list_aux */
+  DV_CH_READ_MAPPING_PERCENT = 11,     /* pixel supplied in read_aux[0] */
+  DV_CH_AVG_BASE_QUALITY = 12,         /* read_aux[1] */
+  DV_CH_IDENTITY = 13,                 /* read_aux[2] */
+  DV_CH_GAP_COMPRESSED_IDENTITY = 14,  /* read_aux[3] */
+  DV_CH_BLANK = 18,
+  DV_CH_INSERT_SIZE = 19,
+  DV_CH_MEAN_COVERAGE = 22,
+  DV_CH_BASE_METHYLATION = 23,
+  DV_CH_BASE_6MA = 24,
+  DV_CH_SUPPLEMENTARY_ALIGNMENT = 26,
+  DV_CH_ALLELE_SAMPLE_PROBABILITY = 27, /* pixel supplied in list_aux */
+};
+
+/* CIGAR op codes = nucleus CigarUnit::Operation
+ * (third_party/nucleus/protos/cigar.proto:38-82); cigar[] = (len << 4) | op. */
+enum {
+  DV_CIGAR_ALIGNMENT_MATCH = 1,
+  DV_CIGAR_INSERT = 2,
+  DV_CIGAR_DELETE = 3,
+  DV_CIGAR_SKIP = 4,
+  DV_CIGAR_CLIP_SOFT = 5,
+  DV_CIGAR_CLIP_HARD = 6,
+  DV_CIGAR_PAD = 7,
+  DV_CIGAR_SEQUENCE_MATCH = 8,
+  DV_CIGAR_SEQUENCE_MISMATCH = 9,
+};
+
+/* read_flags bits */
+enum {
+  DV_READ_REVERSE = 1,       /* alignment.position.reverse_strand */
+  DV_READ_SUPPLEMENTARY = 2, /* supplementary_alignment */
+  DV_READ_HAS_5MC = 4,       /* base_modifications has k5mC */
+  DV_READ_HAS_6MA = 8,       /* base_modifications has k6mA */
+};
+
+#define DV_HP_NONE INT32_MIN /* read has no (single, integer) HP tag */
+
+/* POD image of the PileupImageOptions fields the encoder reads
+ * (deepvariant/protos/deepvariant.proto:500-638; defaults in
+ * deepvariant/pileup_image.py:36-74).  `channels` is what
+ * PileupImageEncoderNative::AllChannelsEnum("") returns
+ * (deepvariant/pileup_image_native.cc:125-151). */
+typedef struct dv_encoder_options {
+  int32_t width;  /* = ref_bases.size(); the odd-width CHECK of pileup_image_native.cc:114 is the host mirror's */
+  int32_t height;
+  int32_t reference_band_height;
+  int32_t n_channels;
+  int32_t channels[DV_MAX_CHANNELS];
+  int32_t base_color_offset_a_and_g;
+  int32_t base_color_offset_t_and_c;
+  int32_t base_color_stride;
+  float allele_supporting_read_alpha;
+  float allele_unsupporting_read_alpha;
+  float other_allele_supporting_read_alpha;
+  float reference_matching_read_alpha;
+  float reference_mismatching_read_alpha;
+  int32_t indel_anchoring_base_char;
+  int32_t reference_base_quality;
+  int32_t positive_strand_color;
+  int32_t negative_strand_color;
+  int32_t base_quality_cap;
+  int32_t mapping_quality_cap;
+  int32_t min_base_quality;    /* read_requirements.min_base_quality */
+  int32_t min_mapping_quality; /* read_requirements.min_mapping_quality */
+  uint32_t random_seed;
+  int32_t sort_by_haplotypes;
+  int32_t hp_tag_for_assembly_polishing;
+  int32_t sort_by_alt_allele_support;
+  float min_non_zero_allele_frequency;
+} dv_encoder_options;
+
+/*
+ * A packed batch of pileup "items".  One item = one call of
+ * PileupImageEncoderNative::BuildPileupForOneSample
+ * (deepvariant/pileup_image_native.cc:297-447) followed by the kNone branch of
+ * FillPileupArray (deepvariant/pileup_image_native.h:214-275): one candidate x
+ * one alt-allele combination x one sample.  Multi-sample stacking and the
+ * `rows` / `single_row` alt-aligned layouts are several items whose
+ * item_out_off place them one below the other in the same example.
+ *
+ * Reads are a structure of arrays shared by all items of the batch (a read
+ * overlaps many candidates).  Strings never reach the device: the host
+ * resolves read names into
+ *   read_name_rank  dense rank of (fragment_name, read_number) under the
+ *                   reference's tie-break order (pileup_image_native.cc:97-101)
+ *   list_code       ReadSupportsVariantChannel::ReadSupportsAlt: 0/1/2
+ *                   (deepvariant/channels/read_supports_variant_channel.cc:75-104)
+ *   list_group      allele-support sort group (pileup_image_native.cc:346-393)
+ * per (item, read).
+ */
+typedef struct dv_batch {
+  int32_t memory; /* dv_memory: where every pointer below lives */
+
+  /* ---- reads (n_reads) ---- */
+  int32_t n_reads;
+  const int32_t* read_pos;        /* alignment.position.position */
+  const int32_t* read_sort_pos;   /* original (pre-trim) position; NULL = read_pos */
+  const uint32_t* read_seq_off;   /* [n_reads+1] into bases / quals / mods */
+  const uint32_t* read_cigar_off; /* [n_reads+1] into cigar */
+  const uint8_t* read_mapq;       /* alignment.mapping_quality (<= 255) */
+  const uint8_t* read_flags;      /* DV_READ_* */
+  const int32_t* read_frag_len;   /* fragment_length */
+  const int32_t* read_hp;         /* HP tag value or DV_HP_NONE */
+  const uint32_t* read_name_rank;
+  const uint8_t* read_aux;        /* [n_reads][DV_READ_AUX_STRIDE] or NULL */
+  const uint8_t* bases;           /* aligned_sequence, ASCII */
+  const uint8_t* quals;           /* aligned_quality, raw phred */
+  const uint8_t* mod_5mc;         /* parallel to bases, or NULL */
+  const uint8_t* mod_6ma;
+  const uint32_t* cigar;          /* (operation_length << 4) | operation */
+  uint32_t n_bases;               /* = read_seq_off[n_reads] */
+  uint32_t n_cigar;               /* = read_cigar_off[n_reads] */
+
+  /* ---- items (n_items) ---- */
+  int32_t n_items;
+  const int32_t* item_variant_start; /* dv_call.variant.start */
+  const int32_t* item_image_start;   /* image_start_pos (may be negative) */
+  const uint32_t* item_ref_idx;      /* row of ref_windows */
+  const uint32_t* item_list_off;     /* [n_items+1] into list_* */
+  const uint16_t* item_height;       /* sample pileup_height (rows of this item) */
+  const uint64_t* item_out_off;      /* byte offset of the item's row 0 in `out` */
+  const uint32_t* item_blank_mask;   /* bit c = channel index c blanked for reads; NULL = 0 */
+  const float* item_mean_coverage;   /* NULL = 0.0 */
+  const uint8_t* ref_windows;        /* [n_ref_windows][width] ASCII, N-padded */
+  uint32_t n_ref_windows;
+
+  /* ---- per (item, read) lists, in InMemoryReader::Query order
+   * (deepvariant/make_examples_native.cc:802-810); the encoder applies
+   * DownsampleReadIndices itself ---- */
+  const uint32_t* list_read;  /* read index */
+  const uint8_t* list_code;   /* 0 / 1 / 2 */
+  const uint8_t* list_group;  /* NULL = 0 */
+  const uint8_t* list_aux;    /* NULL; host-computed pixel for DV_CH_ALLELE_* */
+  uint32_t n_list;            /* = item_list_off[n_items] */
+  uint32_t max_list_len;      /* upper bound on any item's list length */
+} dv_batch;
+
+typedef struct dv_encoder dv_encoder;
+typedef struct dv_model dv_model;
+
+const char* dv_last_error(void);
+int dv_abi_version(void);
+/* Number of visible HIP devices (0 without a GPU). */
+int dv_device_count(void);
+
+/* ---------------------------------------------------------------- encoder */
+
+/* PileupImageEncoderNative::PileupImageEncoderNative
+ * (deepvariant/pileup_image_native.cc:111-123).  Builds the pixel LUTs with the
+ * reference's fp32 arithmetic on the host and uploads them. */
+int dv_encoder_create(const dv_encoder_options* options, int device,
+                      dv_encoder** out);
+void dv_encoder_destroy(dv_encoder* enc);
+
+/* BuildPileupForOneSample + FillPileupArray for every item of the batch
+ * (deepvariant/pileup_image_native.cc:297-447,
+ *  deepvariant/pileup_channel_lib.cc:91-261, deepvariant/channels/ *.cc,
+ *  deepvariant/pileup_image_native.h:214-275), one workgroup per item.
+ *   out           uint8, item i row r at out + item_out_off[i] + r*width*out_channels,
+ *                 pixels HWC with `out_channels` >= n_channels bytes each
+ *                 (extra trailing channels are zero-filled)
+ *   out_rows      int32[n_items] read rows kept per item, may be NULL
+ *   out_memory    dv_memory of out / out_rows */
+int dv_encode_batch(dv_encoder* enc, const dv_batch* batch, int out_channels,
+                    uint8_t* out, int32_t* out_rows, int out_memory,
+                    void* stream);
+
+/* DownsampleReadIndices (deepvariant/pileup_image_native.cc:153-165): iota,
+ * std::shuffle'd with std::mt19937_64(seed) iff n > max_reads.  Host only. */
+int dv_downsample_indices(int n, int max_reads, uint32_t seed, int32_t* out);
+
+/* InMemoryReader::Query + nucleus::ReadOverlapsRegion for every item
+ * (deepvariant/make_examples_native.cc:802-810,
+ *  third_party/nucleus/util/utils.cc:172-240) over packed HOST reads:
+ * item i gets the reads r (ascending index = caller order) with
+ *   query_end[i] > read_pos[r] && query_start[i] < read_end(r).
+ * Two-pass: call with list_read == NULL to get counts in list_off[n_items+1],
+ * then again with a buffer of list_off[n_items] entries. */
+int dv_query_reads(int32_t n_reads, const int32_t* read_pos,
+                   const uint32_t* read_cigar_off, const uint32_t* cigar,
+                   int32_t n_items, const int64_t* query_start,
+                   const int64_t* query_end, uint32_t* list_off,
+                   uint32_t* list_read);
+
+/* CRC32C (Castagnoli) as used by TFRecord framing
+ * (third_party/nucleus/io/example_writer.cc:88-104 via tensorflow::io::RecordWriter). */
+uint32_t dv_crc32c(const uint8_t* data, size_t n);
+
+/* ------------------------------------------------------------------ model */
+
+/* Inception-v3 classifier as instantiated by
+ * deepvariant/keras_modeling.py:246-336 (tf_keras InceptionV3,
+ * include_top=False, pooling='avg') + Dense(3, softmax) head (:46-67), for
+ * input [height, width, channels] uint8. */
+typedef struct dv_model_desc {
+  int32_t height;
+  int32_t width;
+  int32_t channels;
+  int32_t num_classes; /* 3 */
+  int32_t max_batch;   /* activations are sized for this many examples */
+} dv_model_desc;
+
+int dv_model_create(const dv_model_desc* desc, int device, dv_model** out);
+void dv_model_destroy(dv_model* m);
+
+/* Number of fp32 values dv_model_load_weights expects and, per layer i of
+ * dv_model_num_layers(), its slice: conv kernel HWIO (kh*kw*cin*cout) then BN
+ * beta, moving_mean, moving_variance (cout each); the last layer is the Dense
+ * kernel [2048, num_classes] + bias.  Layer order = tf_keras construction
+ * order, i.e. checkpoint `layer_with_weights-N` order
+ * (deepvariant/keras_modeling.py:176-184). */
+int64_t dv_model_num_params(const dv_model* m);
+int dv_model_num_layers(const dv_model* m);
+int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
+                        int32_t* cin, int32_t* cout, int64_t* param_offset);
+
+/* Folds BatchNorm (scale=False, eps=1e-3) into the conv weights, converts to
+ * fp16 in the MFMA fragment layout and uploads.  `weights` is host memory.
+ * Replaces model.load_weights (deepvariant/call_variants.py:759-762). */
+int dv_model_load_weights(dv_model* m, const float* weights, int64_t n);
+
+/* preprocess_images ((x-128)/128, deepvariant/dv_utils.py:343-366) + model
+ * forward + softmax (deepvariant/call_variants.py:904-932).
+ *   images  device uint8 [n, height, width, channels]
+ *   probs   device fp32  [n, num_classes] */
+int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
+                   void* stream);
+
+/* Average time of kernels launched by the last dv_model_infer /
+ * dv_encode_batch on `stream`, measured with HIP events around each launch
+ * when profiling is on.  kind: 0 = encoder kernel, 1 = all conv kernels,
+ * 2 = everything else.  Returns milliseconds summed over the call. */
+int dv_set_profiling(int enabled);
+double dv_profile_ms(int kind);
+/* Number of launches summed by the last dv_profile_ms call. */
+int dv_last_profile_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVHIP_H_ */

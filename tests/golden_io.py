@@ -132,5 +132,6 @@ def save(path, reads, examples, **extra):
 
 
 def load(path):
-  z = np.load(path)
+  with np.load(path) as f:
+    z = {k: f[k] for k in f.files}
   return unpack_reads(z), unpack_examples(z), z

@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/dvhip.h declares."""
+import os
+import re
+
+import pytest
+
+from deepvariant_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+  text = open(os.path.join(ROOT, 'include', 'dvhip.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(dv_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+  l = _lib.lib()
+  declared = _declared_symbols()
+  assert declared, 'no declarations parsed'
+  for sym in declared:
+    assert hasattr(l, sym), sym
+  assert sorted(_lib.ABI_SYMBOLS) == declared
+  assert l.dv_abi_version() == 1
+
+
+def test_host_helpers_need_no_gpu():
+  import ctypes as C
+  import numpy as np
+  l = _lib.lib()
+  assert _lib.try_crc32c(b'123456789') == 0xE3069283
+  out = np.zeros(120, np.int32)
+  assert l.dv_downsample_indices(120, 95, C.c_uint32(2101079370),
+                                 out.ctypes.data_as(C.c_void_p)) == 0
+  from oracle import oracle as O
+  assert (out == O.downsample_indices(120, 95, 2101079370)).all()
+
+
+def test_no_cpu_fallback_without_device():
+  import ctypes as C
+  from deepvariant_amd import packing
+  from tests.golden.make_golden import wgs_options
+  if _lib.device_count() > 0:
+    pytest.skip('GPU present')
+  o = packing.make_encoder_options(wgs_options())
+  h = C.c_void_p()
+  rc = _lib.lib().dv_encoder_create(C.byref(o), 0, C.byref(h))
+  assert rc == _lib.DV_ERR_NO_DEVICE

@@ -1,0 +1,61 @@
+"""HIP encoder vs oracle on synthetic ILLUMINA30 batches (GPU), bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('channels,n,seed', [(7, 768, 11), (6, 300, 5)])
+def test_synthetic_batch_bit_exact(channels, n, seed):
+  from deepvariant_amd import synth
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  opts = synth.illumina_options(channels)
+  batch = synth.make_illumina_batch(n, seed=seed, options=opts)
+  off = np.array(batch.item_list_off)
+  assert ((off[1:] - off[:-1]) > 95).any(), 'shuffle path not exercised'
+  out, rows = _Encoder(opts, opts.width).encode(batch, channels)
+  want, want_rows = O.encode_packed(opts, batch, channels, n_threads=8)
+  np.testing.assert_array_equal(rows, want_rows)
+  assert (rows < (off[1:] - off[:-1])).any(), 'no rejected read in the batch'
+  np.testing.assert_array_equal(out, want)
+
+
+def test_padded_output_channels_and_empty_items():
+  """out_channels > n_channels zero-fills the tail; items without reads."""
+  from deepvariant_amd import synth, packing
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  opts = synth.illumina_options(7)
+  batch = synth.make_illumina_batch(40, seed=3, options=opts, out_channels=8)
+  # an item with an empty read list
+  batch.add_item(500, 500 - 110, 0, np.zeros(0, np.uint32),
+                 np.zeros(0, np.uint8), height=100,
+                 out_off=batch.n_items * 100 * 221 * 8)
+  out, rows = _Encoder(opts, opts.width).encode(batch, 8)
+  want, want_rows = O.encode_packed(opts, batch, 8)
+  np.testing.assert_array_equal(rows, want_rows)
+  np.testing.assert_array_equal(out, want)
+  assert rows[-1] == 0
+  img = out.reshape(-1, 100, 221, 8)
+  assert not img[..., 7].any()
+
+
+def test_device_resident_batch_matches_host_batch():
+  """dv_batch.memory = DEVICE: pointers straight from torch tensors."""
+  import ctypes as C
+  import torch
+  from deepvariant_amd import synth, _lib
+  from deepvariant_amd.device_batch import DeviceBatch
+  from deepvariant_amd.pileup_image_native import _Encoder
+  opts = synth.illumina_options(7)
+  batch = synth.make_illumina_batch(128, seed=9, options=opts)
+  enc = _Encoder(opts, opts.width)
+  want, want_rows = enc.encode(batch, 7)
+  dev = DeviceBatch(batch, torch.device('cuda:0'))
+  out = torch.empty(batch.out_bytes(7), dtype=torch.uint8, device='cuda:0')
+  rows = torch.empty(batch.n_items, dtype=torch.int32, device='cuda:0')
+  dev.encode(enc, 7, out, rows)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(out.cpu().numpy(), want)
+  np.testing.assert_array_equal(rows.cpu().numpy(), want_rows)

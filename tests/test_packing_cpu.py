@@ -1,0 +1,88 @@
+"""Host packing logic (names -> codes/ranks, Query) checked on CPU.
+
+proto-shaped inputs -> oracle.build_pileup  must equal
+proto-shaped inputs -> packing.PackedBatch -> oracle.encode_packed
+(the oracle's packed adapter re-expands the integers into strings and runs the
+same reference restatement), so any slip in support codes, name ranks, list
+order or HP handling shows up without a GPU.
+"""
+import numpy as np
+import pytest
+
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import packing
+from oracle import oracle as O
+from tests import golden_io
+from tests.golden.make_golden import wgs_options
+from tests.test_oracle_golden import FIXTURE
+
+
+def test_packed_equals_proto_path_on_golden_inputs():
+  reads, examples, _ = golden_io.load(FIXTURE)
+  opts = wgs_options()
+  hw = (opts.width - 1) // 2
+  table = packing.ReadTable.from_reads(reads)
+  batch = packing.PackedBatch(table=table, width=opts.width)
+  sel = list(range(0, len(examples), 7))
+  for k, i in enumerate(sel):
+    ex = examples[i]
+    call = ex['call']
+    idx = np.array(ex['read_idx'], np.uint32)
+    # Query() parity: the fixture's read lists came from the oracle's
+    # ReadOverlapsRegion; the table must select the same reads.
+    q = table.query(call.variant.start - 5, call.variant.end + 5)
+    np.testing.assert_array_equal(q, idx)
+    batch.add_item(call.variant.start, call.variant.start - hw,
+                   batch.add_ref_window(ex['ref_window']), idx,
+                   packing.support_codes(call, ex['alt_alleles'], table, idx),
+                   height=100, out_off=k * 100 * 221 * 7)
+  out, rows = O.encode_packed(opts, batch, 7)
+  out = out.reshape(len(sel), 100, 221, 7)
+  for k, i in enumerate(sel):
+    ex = examples[i]
+    want, kept, _ = O.build_pileup(
+        opts, ex['call'], ex['ref_window'], [reads[j] for j in ex['read_idx']],
+        ex['call'].variant.start - hw, ex['alt_alleles'],
+        return_row_reads=True)
+    assert rows[k] == kept
+    np.testing.assert_array_equal(out[k], want)
+
+
+def test_support_codes_follow_reference_order():
+  call = T.DeepVariantCall(
+      variant=T.Variant('chr1', 10, 11, 'A', ['C', 'G']),
+      allele_support={'G': T.SupportingReads(['r1/1', 'r2/1']),
+                      'C': T.SupportingReads(['r1/1'])})
+  reads = [T.make_read('A', 10, quals=[30], cigar='1M', name=n)
+           for n in ('r1', 'r2', 'r3')]
+  table = packing.ReadTable.from_reads(reads)
+  idx = np.arange(3)
+  # r1 is listed under both alts; alternate_bases order (C first) decides.
+  assert packing.support_codes(call, ['C'], table, idx).tolist() == [1, 2, 0]
+  assert packing.support_codes(call, ['G'], table, idx).tolist() == [2, 1, 0]
+  assert packing.support_codes(call, ['C', 'G'], table, idx).tolist() == [1, 1, 0]
+
+
+def test_name_rank_matches_tuple_order():
+  names = [('b', 1), ('a', 2), ('a', 1), ('B', 0), ('a', 1)]
+  reads = []
+  for n, num in names:
+    r = T.make_read('A', 0, quals=[30], cigar='1M', name=n)
+    r.read_number = num
+    reads.append(r)
+  table = packing.ReadTable.from_reads(reads)
+  assert table.read_name_rank.tolist() == [3, 2, 1, 0, 1]
+
+
+def test_packer_rejects_what_the_reference_aborts_on():
+  r = T.make_read('AAA', 0, quals=[30] * 3, cigar='3M')
+  r.alignment.cigar[0].operation = 12
+  with pytest.raises(ValueError, match='CIGAR'):
+    packing.ReadTable.from_reads([r])
+  r = T.make_read('AAA', 0, quals=[30] * 3, cigar='5M')
+  with pytest.raises(ValueError, match='consumes more bases'):
+    packing.ReadTable.from_reads([r])
+  o = T.default_options()
+  o.channels = ['not_a_channel']
+  with pytest.raises(ValueError, match='corresponding enum'):
+    packing.channel_enums(o)
