@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate pileups/sec (encode + CNN) on N MI355X of one node.
+
+A "step" is one pass of the hot path over one batch of synthetic ILLUMINA30
+input that is already resident in HBM:
+    dv_encode_batch  (packed reads -> uint8 [B,100,221,7] pileup tensors)
+ -> dv_model_infer   (Inception-v3, fp16 MFMA -> fp32 softmax [B,3])
+ -> (N > 1) RCCL all-gather of the per-rank [B,3] probabilities + candidate ids
+both through the C ABI of libdvhip.so.  Every rank processes its own shard of
+candidates (weak scaling, no data-path collective besides the final gather).
+
+Prints ONE JSON line on rank 0 (see the repo task contract), including
+  roofline          conv kernels (MFMA bound): achieved TFLOP/s over the timed
+                    region, measured with HIP events around every launch
+  roofline_encoder  encoder kernel (HBM bound): algorithmic GB/s
+  cpu_baseline      the CPU oracle (C++ encoder restatement + fp32 torch
+                    Inception) on a bounded sample, on this host's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (2:1 sparsity excluded)
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch', type=int, default=2048,
+                  help='candidates per step per GPU')
+  ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-sample', type=int, default=0,
+                  help='candidates in the CPU-baseline sample (0 = auto)')
+  return ap.parse_args()
+
+
+def algorithmic_bytes_per_item(batch, out_channels):
+  """H*W*C written + per read (bases + quals + 8*n_cigar + 24)
+  + W reference bases + 1 support code per listed read."""
+  t = batch.table
+  off = np.asarray(batch.item_list_off, np.int64)
+  seq_len = (t.read_seq_off[1:].astype(np.int64) - t.read_seq_off[:-1])
+  n_cig = (t.read_cigar_off[1:].astype(np.int64) - t.read_cigar_off[:-1])
+  per_read = 2 * seq_len + 8 * n_cig + 24 + 1
+  lr = np.asarray(batch.list_read, np.int64)
+  csum = np.concatenate([[0], np.cumsum(per_read[lr])])
+  in_bytes = csum[off[1:]] - csum[off[:-1]]
+  heights = np.asarray(batch.item_height, np.int64)
+  out_bytes = heights * batch.width * out_channels
+  return float((in_bytes + out_bytes + batch.width).mean())
+
+
+def main():
+  args = parse_args()
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world != args.gpus and world > 1:
+    raise SystemExit('--gpus must equal WORLD_SIZE')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a GPU: the HIP hot path has no CPU fallback')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+    dist.init_process_group('nccl', device_id=dev)
+
+  from deepvariant_amd import _lib, synth
+  from deepvariant_amd.device_batch import DeviceBatch
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from deepvariant_amd.pileup_image_native import _Encoder
+
+  C = args.channels
+  opts = synth.illumina_options(C)
+  H, W = opts.height, opts.width
+  # Each rank owns a different shard of candidates (seeded by rank).
+  host_batch = synth.make_illumina_batch(args.batch, seed=synth.SEED + rank,
+                                         options=opts)
+  n_items = host_batch.n_items
+  dbatch = DeviceBatch(host_batch, dev)
+  enc = _Encoder(opts, W, device=local_rank)
+  model = InceptionV3((H, W, C), max_batch=min(n_items, 1024),
+                      device=local_rank)
+  model.init_random(seed=1234)          # same weights on every rank
+  images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)
+  rows = torch.empty(n_items, dtype=torch.int32, device=dev)
+  ids = (torch.arange(n_items, device=dev, dtype=torch.int64) +
+         rank * n_items)
+  if world > 1:
+    # item counts differ per rank: exchange counts once, gather padded.
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n_items], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, mine)
+    max_n = int(counts.max().item())
+    send = torch.zeros((max_n, 4), dtype=torch.float32, device=dev)
+    recv = torch.empty((world * max_n, 4), dtype=torch.float32, device=dev)
+
+  def step():
+    dbatch.encode(enc, C, images, rows)
+    probs = model(images)
+    if world > 1:
+      # CallVariantsOutput payload: 3 probabilities + the candidate id
+      # (ids < 2^24 are exact in fp32 for this bench's sizes).
+      send[:n_items, :3] = probs
+      send[:n_items, 3] = ids.to(torch.float32)
+      dist.all_gather_into_tensor(recv, send)
+    return probs
+
+  def sync_all():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  for _ in range(args.warmup):
+    step()
+  sync_all()
+  lib = _lib.lib()
+  lib.dv_set_profiling(1)
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    probs = step()
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  enc_ms = lib.dv_profile_ms(0)
+  enc_launches = lib.dv_last_profile_count()
+  conv_ms = lib.dv_profile_ms(1)
+  conv_launches = lib.dv_last_profile_count()
+  other_ms = lib.dv_profile_ms(2)
+  lib.dv_set_profiling(0)
+
+  t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  total_items = torch.tensor([n_items], dtype=torch.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(total_items, op=dist.ReduceOp.SUM)
+  elapsed = float(t.item())
+  items_per_step = float(total_items.item())
+  assert torch.isfinite(probs).all()
+
+  if rank == 0:
+    from oracle import inception_ref  # FLOP accounting + CPU baseline only
+    value = items_per_step * args.steps / elapsed
+    macs = inception_ref.macs_per_example(C, H, W)
+    conv_flops_per_item = 2.0 * (macs - 2048 * 3)
+    conv_tflops = (conv_flops_per_item * n_items * args.steps /
+                   (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0
+    bytes_per_item = algorithmic_bytes_per_item(host_batch, C)
+    enc_gbs = (bytes_per_item * n_items * args.steps / (enc_ms * 1e-3) / 1e9
+               if enc_ms > 0 else 0.0)
+    out = {
+        'metric': 'candidate pileups/sec (encode+CNN)',
+        'value': value,
+        'unit': 'candidates/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'u8 (encoder) / f16 MFMA, f32 accumulate (CNN)',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'configs[1] shape: synthetic 30x Illumina pileups, '
+                        'WGS 100x%dx%d, HIP encode + Inception-v3 MFMA on 1 '
+                        'MI355X per rank, random-init weights' % (W, C),
+            'candidates_per_step_per_gpu': n_items,
+            'reads_per_step_per_gpu': int(host_batch.table.n_reads),
+            'parallelism': 'interval shards x%d, all-gather of probs' % world,
+        },
+        'roofline': {
+            'kernel': 'conv_igemm_kernel<NB> (all 94 conv layers)',
+            'bound': 'mfma',
+            'achieved': conv_tflops,
+            'peak': MFMA_F16_PEAK_TFLOPS,
+            'unit': 'TFLOP/s',
+            'frac': conv_tflops / MFMA_F16_PEAK_TFLOPS,
+            'traffic': None,
+            'flops_per_candidate': conv_flops_per_item,
+            'avg_launch_ms': conv_ms / max(conv_launches, 1),
+            'launches': conv_launches,
+            'ms_per_step': conv_ms / args.steps,
+        },
+        'roofline_encoder': {
+            'kernel': 'encode_items_kernel',
+            'bound': 'hbm',
+            'achieved': enc_gbs,
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': enc_gbs / HBM_PEAK_GBS,
+            'traffic': None,
+            'bytes_per_candidate': bytes_per_item,
+            'avg_launch_ms': enc_ms / max(enc_launches, 1),
+            'launches': enc_launches,
+            'candidates_per_s': (n_items * args.steps / (enc_ms * 1e-3)
+                                 if enc_ms > 0 else 0.0),
+        },
+        'other_kernels_ms_per_step': other_ms / args.steps,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(host_batch, opts, C, args.cpu_sample)
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def cpu_baseline(host_batch, opts, C, sample):
+  """The oracle (a port: C++ encoder restatement + fp32 torch Inception)
+  timed on this host's cores on a bounded sample of the same workload."""
+  from oracle import inception_ref, oracle as O
+  cores = os.cpu_count() or 1
+  n_enc = sample or min(host_batch.n_items, 2048)
+  # sub-batch = the first n_enc items (lists index the shared read table)
+  t0 = time.perf_counter()
+  sub = _first_items(host_batch, n_enc)
+  imgs, _ = O.encode_packed(opts, sub, C, n_threads=cores)
+  t_enc = time.perf_counter() - t0
+  n_cnn = min(n_enc, 128)
+  ref = inception_ref.make_random_model(C, seed=1)
+  torch.set_num_threads(cores)
+  x = torch.from_numpy(imgs.reshape(-1, opts.height, opts.width, C)[:n_cnn])
+  with torch.no_grad():
+    ref(x[:8])
+    t0 = time.perf_counter()
+    ref(x)
+    t_cnn = time.perf_counter() - t0
+  per_item = t_enc / n_enc + t_cnn / n_cnn
+  return {
+      'value': 1.0 / per_item,
+      'unit': 'candidates/s',
+      'cores': cores,
+      'kind': 'port',
+      'sample': '%d candidates encoded by the C++ oracle on %d threads (%.1f s) '
+                '+ %d classified by fp32 torch-CPU Inception-v3 (%.1f s); '
+                'reference binaries cannot be built here (DESIGN.md)' %
+                (n_enc, cores, t_enc, n_cnn, t_cnn),
+      'encoder_candidates_per_s': n_enc / t_enc,
+      'cnn_candidates_per_s': n_cnn / t_cnn,
+  }
+
+
+def _first_items(batch, n):
+  from deepvariant_amd import packing
+  sub = packing.PackedBatch(table=batch.table, width=batch.width)
+  sub.ref_windows_list = batch.ref_windows_list
+  off = batch.item_list_off
+  lr, lc = np.asarray(batch.list_read), np.asarray(batch.list_code)
+  for i in range(n):
+    a, b = off[i], off[i + 1]
+    sub.add_item(batch.item_variant_start[i], batch.item_image_start[i],
+                 batch.item_ref_idx[i], lr[a:b], lc[a:b],
+                 height=batch.item_height[i], out_off=batch.item_out_off[i])
+  return sub
+
+
+if __name__ == '__main__':
+  main()

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     'dv_downsample_indices', 'dv_query_reads', 'dv_crc32c',
     'dv_model_create', 'dv_model_destroy', 'dv_model_num_params',
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
-    'dv_model_infer', 'dv_set_profiling', 'dv_profile_ms',
+    'dv_model_infer', 'dv_model_debug_tensor', 'dv_set_profiling', 'dv_profile_ms',
     'dv_last_profile_count',
 ]
 

@@ -1,22 +1,818 @@
-// model.hip -- placeholder until the Inception-v3 kernels land.
+// model.hip -- Inception-v3 call_variants classifier on gfx950 (MI355X).
+//
+// Replaces the model forward of deepvariant/call_variants.py:904-932
+// (keras_modeling.inceptionv3, deepvariant/keras_modeling.py:246-336; graph =
+// tf_keras InceptionV3(include_top=False, pooling='avg')).
+//
+// Data layout in HBM: activations are NHWC fp16, one buffer per graph tensor,
+// concat outputs are written in place (each branch's last conv stores at its
+// channel offset of the block's output buffer -- no concat kernel).  BatchNorm
+// (scale=False, eps=1e-3, moving statistics) is folded into the fp16 conv
+// weights and an fp32 per-channel shift at load time.
+//
+// Kernels
+//   preprocess_kernel      uint8 HWC -> fp16 (x-128)/128, channels padded to 16
+//   conv_igemm_kernel<NB>  implicit-GEMM conv + shift + ReLU on
+//                          v_mfma_f32_32x32x16_f16: D[cout][pixel] =
+//                          sum_k W[cout][k] X[k][pixel]; block tile 128 pixels
+//                          x NB*32 couts, K-step 32 (two 16-channel chunks of
+//                          one filter tap), LDS double buffered with one
+//                          barrier per step, epilogue transposed through LDS
+//                          so global stores are 16-byte along channels.
+//   maxpool3s2_kernel / avgpool3s1_kernel   (avg excludes padding)
+//   head_kernel            global average pool + Dense(3) + softmax in fp32
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include <hip/hip_fp16.h>
+
 #include "dv_internal.h"
 
-struct dv_model { int unused; };
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kConvBM = 128;     // pixels per block tile
+constexpr int kConvThreads = 256;
+constexpr int kChunk = 16;       // channels per K chunk
+
+struct ConvArgs {
+  const _Float16* in;
+  const _Float16* w;      // packed [cout_tile][step][2][NB*32][16]
+  const float* shift;     // [Cout] folded BN shift
+  _Float16* out;
+  int N, H, W, Cin;
+  int OH, OW, Cout;
+  int KH, KW, stride, pad_h, pad_w;
+  int out_cstride, out_coff;
+  int M;                  // N*OH*OW
+  int cpt;                // chunks per tap = Cin/16
+  int n_chunks;
+  int n_steps;
+  int relu;
+};
+
+template <int NB>
+__global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int A_STAGE = 2 * kConvBM * kChunk;  // halfs
+  constexpr int B_STAGE = 2 * BN * kChunk;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  _Float16* As = smem;                 // [2][A_STAGE]
+  _Float16* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int m0 = blockIdx.x * kConvBM;
+  const int n_tile = blockIdx.y;
+
+  // ---- A (pixels) load bookkeeping: row = tid/2, 8-channel half = tid%2 ----
+  const int a_row = tid >> 1;
+  const int a_hf = tid & 1;
+  const int m = m0 + a_row;
+  const bool valid_m = m < p.M;
+  int ih0 = 0, iw0 = 0;
+  const _Float16* in_n = p.in;
+  if (valid_m) {
+    const int ow = m % p.OW;
+    const int t = m / p.OW;
+    const int oh = t % p.OH;
+    const int n = t / p.OH;
+    ih0 = oh * p.stride - p.pad_h;
+    iw0 = ow * p.stride - p.pad_w;
+    in_n = p.in + static_cast<size_t>(n) * p.H * p.W * p.Cin + a_hf * 8;
+  }
+  const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
+                      static_cast<size_t>(n_tile) * p.n_steps * (128 * NB);
+  constexpr int B_PIECES = 128 * NB;                  // 16-byte pieces per step
+  constexpr int B_PER_THREAD = (B_PIECES + kConvThreads - 1) / kConvThreads;
+
+  uint4 ra[2];
+  uint4 rbv[B_PER_THREAD];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tiles = [&](int ks) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kc = 2 * ks + c;
+      uint4 v = zero4;
+      if (valid_m && kc < p.n_chunks) {
+        const int tap = kc / p.cpt;
+        const int cc = kc - tap * p.cpt;
+        const int kh = tap / p.KW;
+        const int kw = tap - kh * p.KW;
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+          v = *reinterpret_cast<const uint4*>(
+              in_n + (static_cast<size_t>(ih) * p.W + iw) * p.Cin + cc * kChunk);
+        }
+      }
+      ra[c] = v;
+    }
+    const uint4* ws = wsrc + static_cast<size_t>(ks) * B_PIECES;
+#pragma unroll
+    for (int j = 0; j < B_PER_THREAD; ++j) {
+      const int q = tid + j * kConvThreads;
+      rbv[j] = (q < B_PIECES) ? ws[q] : zero4;
+    }
+  };
+  auto store_tiles = [&](int stage) {
+    uint4* a_dst = reinterpret_cast<uint4*>(As + stage * A_STAGE);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) a_dst[c * (kConvBM * 2) + a_row * 2 + a_hf] = ra[c];
+    uint4* b_dst = reinterpret_cast<uint4*>(Bs + stage * B_STAGE);
+#pragma unroll
+    for (int j = 0; j < B_PER_THREAD; ++j) {
+      const int q = tid + j * kConvThreads;
+      if (q < B_PIECES) b_dst[q] = rbv[j];
+    }
+  };
+
+  float16_t acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * kChunk + (lane >> 5) * 8;  // halfs
+  for (int ks = 0; ks < p.n_steps; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < p.n_steps;
+    if (more) load_tiles(ks + 1);
+    const _Float16* a_st = As + cur * A_STAGE;
+    const _Float16* b_st = Bs + cur * B_STAGE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const half8_t xf = *reinterpret_cast<const half8_t*>(
+          a_st + c * (kConvBM * kChunk) + wave * 32 * kChunk + frag_off);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const half8_t wf = *reinterpret_cast<const half8_t*>(
+            b_st + c * (BN * kChunk) + nb * 32 * kChunk + frag_off);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[nb], 0, 0, 0);
+      }
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: shift + ReLU, transpose through LDS, 16-byte stores -------
+  constexpr int OT_STRIDE = BN + 8;  // halfs; keeps rows 16-byte aligned
+  _Float16* Ot = smem;
+  {
+    const int prow = wave * 32 + (lane & 31);
+    const int cbase = n_tile * BN;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = nb * 32 + 8 * q + 4 * (lane >> 5);
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = cbase + cl + j;
+          float v = acc[nb][4 * q + j] + (co < p.Cout ? p.shift[co] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
+          h[j] = static_cast<_Float16>(v);
+        }
+        *reinterpret_cast<half4_t*>(Ot + prow * OT_STRIDE + cl) = h;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int SEGS = BN / 8;  // 16-byte segments per pixel row
+    for (int q = tid; q < kConvBM * SEGS; q += kConvThreads) {
+      const int row = q / SEGS;
+      const int seg = q - row * SEGS;
+      const int mm = m0 + row;
+      const int co = n_tile * BN + seg * 8;
+      if (mm < p.M && co < p.Cout) {
+        const uint4 v = *reinterpret_cast<const uint4*>(Ot + row * OT_STRIDE + seg * 8);
+        *reinterpret_cast<uint4*>(p.out + static_cast<size_t>(mm) * p.out_cstride +
+                                  p.out_coff + co) = v;
+      }
+    }
+  }
+}
+
+template <int NB>
+constexpr size_t conv_lds_bytes() {
+  const size_t stages = 2 * (2 * kConvBM * kChunk + 2 * NB * 32 * kChunk) * 2;
+  const size_t epi = static_cast<size_t>(kConvBM) * (NB * 32 + 8) * 2;
+  return stages > epi ? stages : epi;
+}
+
+// uint8 [N,H,W,C] -> fp16 [N,H,W,16]: (x - 128) / 128, exact in fp16.
+__global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix,
+                                  int C) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n_pix) return;
+  const uint8_t* px = in + i * C;
+  _Float16 v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    v[c] = c < C ? static_cast<_Float16>((static_cast<float>(px[c]) - 128.0f) / 128.0f)
+                 : static_cast<_Float16>(0.f);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + i * 16);
+  dst[0] = *reinterpret_cast<uint4*>(&v[0]);
+  dst[1] = *reinterpret_cast<uint4*>(&v[8]);
+}
+
+struct PoolArgs {
+  const _Float16* in;
+  _Float16* out;
+  int N, H, W, C, OH, OW;
+  int out_cstride, out_coff;
+};
+
+// MaxPooling2D(3, strides=2, 'valid'); one thread = 8 channels of one pixel.
+__global__ void maxpool3s2_kernel(PoolArgs p) {
+  const int c8 = p.C / 8;
+  const size_t total = static_cast<size_t>(p.N) * p.OH * p.OW * c8;
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= total) return;
+  const int cg = i % c8;
+  size_t t = i / c8;
+  const int ow = t % p.OW;
+  t /= p.OW;
+  const int oh = t % p.OH;
+  const int n = t / p.OH;
+  half8_t best;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) best[j] = static_cast<_Float16>(-65504.f);
+  for (int dh = 0; dh < 3; ++dh)
+    for (int dw = 0; dw < 3; ++dw) {
+      const int ih = oh * 2 + dh, iw = ow * 2 + dw;
+      const half8_t v = *reinterpret_cast<const half8_t*>(
+          p.in + ((static_cast<size_t>(n) * p.H + ih) * p.W + iw) * p.C + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
+    }
+  *reinterpret_cast<half8_t*>(p.out + ((static_cast<size_t>(n) * p.OH + oh) * p.OW + ow) *
+                                           p.out_cstride + p.out_coff + cg * 8) = best;
+}
+
+// AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.
+__global__ void avgpool3s1_kernel(PoolArgs p) {
+  const int c8 = p.C / 8;
+  const size_t total = static_cast<size_t>(p.N) * p.H * p.W * c8;
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= total) return;
+  const int cg = i % c8;
+  size_t t = i / c8;
+  const int ow = t % p.W;
+  t /= p.W;
+  const int oh = t % p.H;
+  const int n = t / p.H;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt = 0;
+  for (int dh = -1; dh <= 1; ++dh)
+    for (int dw = -1; dw <= 1; ++dw) {
+      const int ih = oh + dh, iw = ow + dw;
+      if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
+      ++cnt;
+      const half8_t v = *reinterpret_cast<const half8_t*>(
+          p.in + ((static_cast<size_t>(n) * p.H + ih) * p.W + iw) * p.C + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
+    }
+  half8_t o;
+  const float inv = 1.0f / static_cast<float>(cnt);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
+  *reinterpret_cast<half8_t*>(p.out + ((static_cast<size_t>(n) * p.H + oh) * p.W + ow) *
+                                           p.out_cstride + p.out_coff + cg * 8) = o;
+}
+
+// GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
+__global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const float* w,
+                                                   const float* b, float* probs,
+                                                   int P, int C, int K) {
+  __shared__ float red[8][4];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const _Float16* x = in + static_cast<size_t>(n) * P * C;
+  const float invP = 1.0f / static_cast<float>(P);
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int pp = 0; pp < P; ++pp) s += static_cast<float>(x[static_cast<size_t>(pp) * C + c]);
+    s *= invP;
+    for (int k = 0; k < K; ++k) part[k] += s * w[static_cast<size_t>(c) * K + k];
+  }
+  for (int k = 0; k < K; ++k) {
+    float v = part[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((tid & 63) == 0) red[k][tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float logit[8], mx = -1e30f;
+    for (int k = 0; k < K; ++k) {
+      logit[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3] + b[k];
+      mx = fmaxf(mx, logit[k]);
+    }
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+      logit[k] = expf(logit[k] - mx);
+      sum += logit[k];
+    }
+    for (int k = 0; k < K; ++k) probs[static_cast<size_t>(n) * K + k] = logit[k] / sum;
+  }
+}
+
+// ------------------------------------------------------------------ the graph
+
+struct TensorRef {
+  int buf = -1;  // index into buffers
+  int h = 0, w = 0, c = 0;
+};
+
+struct BufferDesc {
+  int h, w, c;  // channels = full (concat) width
+};
+
+enum OpType { kOpConv, kOpMaxPool, kOpAvgPool };
+
+struct Op {
+  OpType type;
+  int in_buf, out_buf;
+  int out_coff = 0;
+  // conv
+  int layer = -1;
+  int kh = 0, kw = 0, stride = 1, pad_h = 0, pad_w = 0;
+  int cin = 0, cin_real = 0, cout = 0;
+  int ih = 0, iw = 0, oh = 0, ow = 0;
+  int nb = 4;
+  int n_steps = 0, n_chunks = 0;
+  size_t w_off = 0;      // halfs into packed weights
+  size_t shift_off = 0;  // floats into shifts
+};
+
+struct LayerInfo {
+  int kh, kw, cin, cout;
+  int64_t param_off;
+};
+
+}  // namespace
+
+struct dv_model {
+  int device = 0;
+  dv_model_desc desc{};
+  std::vector<BufferDesc> buffers;
+  std::vector<Op> ops;
+  std::vector<LayerInfo> layers;  // convs then dense
+  int64_t n_params = 0;
+  int feat_buf = -1, feat_p = 0, feat_c = 0;
+  size_t packed_halfs = 0, shift_floats = 0;
+  std::vector<dv::DeviceBuffer> dbuf;
+  dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b;
+  bool loaded = false;
+
+  // ---- builder ------------------------------------------------------------
+  int new_buffer(int h, int w, int c) {
+    buffers.push_back({h, w, c});
+    return static_cast<int>(buffers.size()) - 1;
+  }
+  static int pick_nb(int cout) {
+    // smallest waste first, then the widest tile
+    int best = 4, best_waste = 1 << 30;
+    for (int nb = 4; nb >= 1; --nb) {
+      const int bn = nb * 32;
+      const int waste = ((cout + bn - 1) / bn) * bn - cout;
+      if (waste < best_waste) {
+        best_waste = waste;
+        best = nb;
+      }
+    }
+    return best;
+  }
+  TensorRef conv(TensorRef x, int cout, int kh, int kw, int stride = 1, bool same = true,
+                 int dst_buf = -1, int dst_coff = 0, int cin_real = -1) {
+    Op op;
+    op.type = kOpConv;
+    op.kh = kh;
+    op.kw = kw;
+    op.stride = stride;
+    op.pad_h = same ? (kh - 1) / 2 : 0;
+    op.pad_w = same ? (kw - 1) / 2 : 0;
+    op.cin = x.c;
+    op.cin_real = cin_real < 0 ? x.c : cin_real;
+    op.cout = cout;
+    op.ih = x.h;
+    op.iw = x.w;
+    op.oh = (x.h + 2 * op.pad_h - kh) / stride + 1;
+    op.ow = (x.w + 2 * op.pad_w - kw) / stride + 1;
+    op.in_buf = x.buf;
+    if (dst_buf < 0) {
+      dst_buf = new_buffer(op.oh, op.ow, cout);
+      dst_coff = 0;
+    }
+    op.out_buf = dst_buf;
+    op.out_coff = dst_coff;
+    op.nb = pick_nb(cout);
+    op.n_chunks = kh * kw * (x.c / kChunk);
+    op.n_steps = (op.n_chunks + 1) / 2;
+    const int n_tiles = (cout + op.nb * 32 - 1) / (op.nb * 32);
+    op.w_off = packed_halfs;
+    packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * 2 * (op.nb * 32) * kChunk;
+    op.shift_off = shift_floats;
+    shift_floats += cout;
+    op.layer = static_cast<int>(layers.size());
+    layers.push_back({kh, kw, op.cin_real, cout, n_params});
+    n_params += static_cast<int64_t>(kh) * kw * op.cin_real * cout + 3LL * cout;
+    ops.push_back(op);
+    TensorRef out;
+    out.buf = dst_buf;
+    out.h = op.oh;
+    out.w = op.ow;
+    out.c = cout;  // view width; the consumer of a concat reads the full buffer
+    return out;
+  }
+  TensorRef full(int buf) const {
+    TensorRef t;
+    t.buf = buf;
+    t.h = buffers[buf].h;
+    t.w = buffers[buf].w;
+    t.c = buffers[buf].c;
+    return t;
+  }
+  TensorRef pool(OpType type, TensorRef x, int dst_buf = -1, int dst_coff = 0) {
+    Op op;
+    op.type = type;
+    op.in_buf = x.buf;
+    op.ih = x.h;
+    op.iw = x.w;
+    op.cin = x.c;
+    op.cout = x.c;
+    if (type == kOpMaxPool) {
+      op.oh = (x.h - 3) / 2 + 1;
+      op.ow = (x.w - 3) / 2 + 1;
+    } else {
+      op.oh = x.h;
+      op.ow = x.w;
+    }
+    if (dst_buf < 0) {
+      dst_buf = new_buffer(op.oh, op.ow, x.c);
+      dst_coff = 0;
+    }
+    op.out_buf = dst_buf;
+    op.out_coff = dst_coff;
+    ops.push_back(op);
+    TensorRef out;
+    out.buf = dst_buf;
+    out.h = op.oh;
+    out.w = op.ow;
+    out.c = x.c;
+    return out;
+  }
+
+  // tf_keras applications/inception_v3.py, construction order = layer order.
+  void build() {
+    const int in_buf = new_buffer(desc.height, desc.width, 16);
+    TensorRef x = full(in_buf);
+    x = conv(x, 32, 3, 3, 2, false, -1, 0, desc.channels);
+    x = conv(x, 32, 3, 3, 1, false);
+    x = conv(x, 64, 3, 3);
+    // (layer order: the two remaining stem convs are created before the pools run)
+    x = pool(kOpMaxPool, x);
+    x = conv(x, 80, 1, 1, 1, false);
+    x = conv(x, 192, 3, 3, 1, false);
+    x = pool(kOpMaxPool, x);
+    for (int pool_ch : {32, 64, 64}) {  // mixed0..2
+      const int out = new_buffer(x.h, x.w, 64 + 64 + 96 + pool_ch);
+      conv(x, 64, 1, 1, 1, true, out, 0);
+      TensorRef b5 = conv(x, 48, 1, 1);
+      conv(b5, 64, 5, 5, 1, true, out, 64);
+      TensorRef b3 = conv(x, 64, 1, 1);
+      b3 = conv(b3, 96, 3, 3);
+      conv(b3, 96, 3, 3, 1, true, out, 128);
+      TensorRef bp = pool(kOpAvgPool, x);
+      conv(bp, pool_ch, 1, 1, 1, true, out, 224);
+      x = full(out);
+    }
+    {  // mixed3
+      const int oh = (x.h - 3) / 2 + 1, ow = (x.w - 3) / 2 + 1;
+      const int out = new_buffer(oh, ow, 384 + 96 + x.c);
+      conv(x, 384, 3, 3, 2, false, out, 0);
+      TensorRef b = conv(x, 64, 1, 1);
+      b = conv(b, 96, 3, 3);
+      conv(b, 96, 3, 3, 2, false, out, 384);
+      pool(kOpMaxPool, x, out, 480);
+      x = full(out);
+    }
+    for (int c7 : {128, 160, 160, 192}) {  // mixed4..7
+      const int out = new_buffer(x.h, x.w, 768);
+      conv(x, 192, 1, 1, 1, true, out, 0);
+      TensorRef b = conv(x, c7, 1, 1);
+      b = conv(b, c7, 1, 7);
+      conv(b, 192, 7, 1, 1, true, out, 192);
+      TensorRef d = conv(x, c7, 1, 1);
+      d = conv(d, c7, 7, 1);
+      d = conv(d, c7, 1, 7);
+      d = conv(d, c7, 7, 1);
+      conv(d, 192, 1, 7, 1, true, out, 384);
+      TensorRef bp = pool(kOpAvgPool, x);
+      conv(bp, 192, 1, 1, 1, true, out, 576);
+      x = full(out);
+    }
+    {  // mixed8
+      const int oh = (x.h - 3) / 2 + 1, ow = (x.w - 3) / 2 + 1;
+      const int out = new_buffer(oh, ow, 320 + 192 + x.c);
+      TensorRef b = conv(x, 192, 1, 1);
+      conv(b, 320, 3, 3, 2, false, out, 0);
+      TensorRef d = conv(x, 192, 1, 1);
+      d = conv(d, 192, 1, 7);
+      d = conv(d, 192, 7, 1);
+      conv(d, 192, 3, 3, 2, false, out, 320);
+      pool(kOpMaxPool, x, out, 512);
+      x = full(out);
+    }
+    for (int i = 0; i < 2; ++i) {  // mixed9, mixed10
+      const int out = new_buffer(x.h, x.w, 2048);
+      conv(x, 320, 1, 1, 1, true, out, 0);
+      TensorRef b = conv(x, 384, 1, 1);
+      conv(b, 384, 1, 3, 1, true, out, 320);
+      conv(b, 384, 3, 1, 1, true, out, 704);
+      TensorRef d = conv(x, 448, 1, 1);
+      d = conv(d, 384, 3, 3);
+      conv(d, 384, 1, 3, 1, true, out, 1088);
+      conv(d, 384, 3, 1, 1, true, out, 1472);
+      TensorRef bp = pool(kOpAvgPool, x);
+      conv(bp, 192, 1, 1, 1, true, out, 1856);
+      x = full(out);
+    }
+    feat_buf = x.buf;
+    feat_p = x.h * x.w;
+    feat_c = x.c;
+    layers.push_back({1, 1, feat_c, desc.num_classes, n_params});
+    n_params += static_cast<int64_t>(feat_c) * desc.num_classes + desc.num_classes;
+  }
+};
+
+namespace {
+
+template <int NB>
+void launch_conv(const ConvArgs& a, hipStream_t stream) {
+  const dim3 grid((a.M + kConvBM - 1) / kConvBM, (a.Cout + NB * 32 - 1) / (NB * 32));
+  hipLaunchKernelGGL(conv_igemm_kernel<NB>, grid, dim3(kConvThreads), conv_lds_bytes<NB>(),
+                     stream, a);
+}
+
+int run_ops(dv_model* m, int n, hipStream_t stream) {
+  for (const Op& op : m->ops) {
+    const BufferDesc& ob = m->buffers[op.out_buf];
+    if (op.type == kOpConv) {
+      ConvArgs a{};
+      a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
+      a.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
+      a.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      a.N = n;
+      a.H = op.ih;
+      a.W = op.iw;
+      a.Cin = op.cin;
+      a.OH = op.oh;
+      a.OW = op.ow;
+      a.Cout = op.cout;
+      a.KH = op.kh;
+      a.KW = op.kw;
+      a.stride = op.stride;
+      a.pad_h = op.pad_h;
+      a.pad_w = op.pad_w;
+      a.out_cstride = ob.c;
+      a.out_coff = op.out_coff;
+      a.M = n * op.oh * op.ow;
+      a.cpt = op.cin / kChunk;
+      a.n_chunks = op.n_chunks;
+      a.n_steps = op.n_steps;
+      a.relu = 1;
+      dv::ProfileScope prof(dv::kProfConv, stream);
+      switch (op.nb) {
+        case 1: launch_conv<1>(a, stream); break;
+        case 2: launch_conv<2>(a, stream); break;
+        case 3: launch_conv<3>(a, stream); break;
+        default: launch_conv<4>(a, stream); break;
+      }
+    } else {
+      PoolArgs p{};
+      p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      p.N = n;
+      p.H = op.ih;
+      p.W = op.iw;
+      p.C = op.cin;
+      p.OH = op.oh;
+      p.OW = op.ow;
+      p.out_cstride = ob.c;
+      p.out_coff = op.out_coff;
+      const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
+      const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      if (op.type == kOpMaxPool) {
+        hipLaunchKernelGGL(maxpool3s2_kernel, grid, dim3(256), 0, stream, p);
+      } else {
+        hipLaunchKernelGGL(avgpool3s1_kernel, grid, dim3(256), 0, stream, p);
+      }
+    }
+  }
+  DV_HIP_CHECK(hipGetLastError());
+  return DV_OK;
+}
+
+}  // namespace
 
 extern "C" {
-int dv_model_create(const dv_model_desc*, int, dv_model**) {
-  return dv::fail(DV_ERR_UNSUPPORTED, "dv_model: not built yet");
+
+int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
+  if (!desc || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_create: null");
+  if (desc->channels < 1 || desc->channels > 16 || desc->num_classes < 1 ||
+      desc->num_classes > 8 || desc->max_batch < 1 || desc->height < 75 ||
+      desc->width < 75) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                    "dv_model_create: unsupported shape (need H,W >= 75, C <= 16)");
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    return dv::fail(DV_ERR_NO_DEVICE, "no HIP device: libdvhip has no CPU fallback");
+  }
+  if (device < 0 || device >= n_dev) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "bad device ordinal");
+  }
+  DV_HIP_CHECK(hipSetDevice(device));
+  std::unique_ptr<dv_model> m(new dv_model());
+  m->device = device;
+  m->desc = *desc;
+  m->build();
+  m->dbuf.resize(m->buffers.size());
+  for (size_t i = 0; i < m->buffers.size(); ++i) {
+    const BufferDesc& b = m->buffers[i];
+    const size_t bytes = static_cast<size_t>(desc->max_batch) * b.h * b.w * b.c * 2;
+    if (int rc = m->dbuf[i].reserve(bytes)) return rc;
+  }
+  if (int rc = m->d_w.reserve(m->packed_halfs * 2)) return rc;
+  if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
+  if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
+  if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
+  *out = m.release();
+  return DV_OK;
 }
-void dv_model_destroy(dv_model*) {}
-int64_t dv_model_num_params(const dv_model*) { return 0; }
-int dv_model_num_layers(const dv_model*) { return 0; }
-int dv_model_layer_info(const dv_model*, int, int32_t*, int32_t*, int32_t*, int32_t*, int64_t*) {
-  return dv::fail(DV_ERR_UNSUPPORTED, "dv_model: not built yet");
+
+void dv_model_destroy(dv_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  for (auto& b : m->dbuf) b.release();
+  m->d_w.release();
+  m->d_shift.release();
+  m->d_dense_w.release();
+  m->d_dense_b.release();
+  delete m;
 }
-int dv_model_load_weights(dv_model*, const float*, int64_t) {
-  return dv::fail(DV_ERR_UNSUPPORTED, "dv_model: not built yet");
+
+int64_t dv_model_num_params(const dv_model* m) { return m ? m->n_params : 0; }
+
+int dv_model_num_layers(const dv_model* m) {
+  return m ? static_cast<int>(m->layers.size()) : 0;
 }
-int dv_model_infer(dv_model*, const uint8_t*, int, float*, void*) {
-  return dv::fail(DV_ERR_UNSUPPORTED, "dv_model: not built yet");
+
+int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
+                        int32_t* cin, int32_t* cout, int64_t* param_offset) {
+  if (!m || layer < 0 || layer >= static_cast<int>(m->layers.size())) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_layer_info: bad layer");
+  }
+  const LayerInfo& l = m->layers[layer];
+  if (kh) *kh = l.kh;
+  if (kw) *kw = l.kw;
+  if (cin) *cin = l.cin;
+  if (cout) *cout = l.cout;
+  if (param_offset) *param_offset = l.param_off;
+  return DV_OK;
 }
+
+int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
+  if (!m || !weights) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_load_weights: null");
+  if (n != m->n_params) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                    "dv_model_load_weights: expected " + std::to_string(m->n_params) +
+                        " values, got " + std::to_string(n));
+  }
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  std::vector<_Float16> packed(m->packed_halfs, static_cast<_Float16>(0.f));
+  std::vector<float> shift(m->shift_floats, 0.f);
+  for (const Op& op : m->ops) {
+    if (op.type != kOpConv) continue;
+    const LayerInfo& l = m->layers[op.layer];
+    const float* w = weights + l.param_off;  // HWIO
+    const size_t wn = static_cast<size_t>(l.kh) * l.kw * l.cin * l.cout;
+    const float* beta = w + wn;
+    const float* mean = beta + l.cout;
+    const float* var = mean + l.cout;
+    std::vector<float> inv(l.cout);
+    for (int co = 0; co < l.cout; ++co) {
+      if (!(var[co] + 1e-3f > 0.f)) {
+        return dv::fail(DV_ERR_BAD_INPUT, "non-positive BatchNorm variance");
+      }
+      inv[co] = 1.0f / std::sqrt(var[co] + 1e-3f);
+      shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
+    }
+    const int bn = op.nb * 32;
+    const int cpt = op.cin / kChunk;
+    const int n_tiles = (op.cout + bn - 1) / bn;
+    for (int t = 0; t < n_tiles; ++t)
+      for (int ks = 0; ks < op.n_steps; ++ks)
+        for (int c = 0; c < 2; ++c) {
+          const int kc = 2 * ks + c;
+          if (kc >= op.n_chunks) continue;
+          const int tap = kc / cpt, cc = kc % cpt;
+          const int kh = tap / op.kw, kw = tap % op.kw;
+          for (int r = 0; r < bn; ++r) {
+            const int co = t * bn + r;
+            if (co >= op.cout) continue;
+            _Float16* dst = packed.data() + op.w_off +
+                            (((static_cast<size_t>(t) * op.n_steps + ks) * 2 + c) * bn + r) * kChunk;
+            for (int j = 0; j < kChunk; ++j) {
+              const int ci = cc * kChunk + j;
+              if (ci >= l.cin) continue;  // padded input channels
+              const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+              dst[j] = static_cast<_Float16>(v * inv[co]);
+            }
+          }
+        }
+  }
+  const LayerInfo& dl = m->layers.back();
+  const float* dw = weights + dl.param_off;
+  DV_HIP_CHECK(hipMemcpy(m->d_w.ptr, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(m->d_shift.ptr, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(m->d_dense_w.ptr, dw, static_cast<size_t>(dl.cin) * dl.cout * 4,
+                         hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dw + static_cast<size_t>(dl.cin) * dl.cout,
+                         dl.cout * 4, hipMemcpyHostToDevice));
+  m->loaded = true;
+  return DV_OK;
 }
+
+// Testing hook: copies activation buffer `index` (NHWC fp16, first n examples)
+// to host memory; returns its shape.  Buffer 0 is the preprocessed input.
+int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t* h,
+                          int32_t* w, int32_t* c) {
+  if (!m || index < 0 || index >= static_cast<int>(m->buffers.size())) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_debug_tensor: bad index");
+  }
+  const BufferDesc& b = m->buffers[index];
+  if (h) *h = b.h;
+  if (w) *w = b.w;
+  if (c) *c = b.c;
+  if (host_out) {
+    DV_HIP_CHECK(hipSetDevice(m->device));
+    DV_HIP_CHECK(hipDeviceSynchronize());
+    DV_HIP_CHECK(hipMemcpy(host_out, m->dbuf[index].ptr,
+                           static_cast<size_t>(n) * b.h * b.w * b.c * 2,
+                           hipMemcpyDeviceToHost));
+  }
+  return DV_OK;
+}
+
+int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void* stream_v) {
+  if (!m || !images || !probs || n < 0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_infer: bad argument");
+  }
+  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_infer: no weights loaded");
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  const size_t img_bytes = static_cast<size_t>(m->desc.height) * m->desc.width * m->desc.channels;
+  for (int done = 0; done < n; done += m->desc.max_batch) {
+    const int nb = std::min(m->desc.max_batch, n - done);
+    {
+      const size_t n_pix = static_cast<size_t>(nb) * m->desc.height * m->desc.width;
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
+                         dim3(256), 0, stream, images + done * img_bytes,
+                         static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels);
+    }
+    if (int rc = run_ops(m, nb, stream)) return rc;
+    {
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, stream,
+                         static_cast<const _Float16*>(m->dbuf[m->feat_buf].ptr),
+                         static_cast<const float*>(m->d_dense_w.ptr),
+                         static_cast<const float*>(m->d_dense_b.ptr),
+                         probs + static_cast<size_t>(done) * m->desc.num_classes, m->feat_p,
+                         m->feat_c, m->desc.num_classes);
+    }
+    DV_HIP_CHECK(hipGetLastError());
+  }
+  return DV_OK;
+}
+
+}  // extern "C"

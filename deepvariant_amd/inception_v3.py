@@ -1,0 +1,134 @@
+"""call_variants' classifier on MI355X: a torch.nn.Module whose forward is the
+hand-written HIP Inception-v3 of libdvhip.so (dv_model_*, include/dvhip.h).
+
+Mirrors `deepvariant/keras_modeling.py:246-336` (`inceptionv3(...)`) at the
+level call_variants uses it (deepvariant/call_variants.py:648-763,904-932):
+build for an input shape, load weights, map a uint8 image batch to softmax
+genotype probabilities.  PyTorch only owns device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from deepvariant_amd import _lib
+
+
+class InceptionV3(torch.nn.Module):
+  """`InceptionV3(input_shape=(H, W, C))`; forward(uint8 NHWC) -> probs [N,3]."""
+
+  def __init__(self, input_shape: Tuple[int, int, int], num_classes: int = 3,
+               max_batch: int = 256, device: int = 0):
+    super().__init__()
+    h, w, c = input_shape
+    self.input_shape = (h, w, c)
+    self.num_classes = num_classes
+    self.max_batch = max_batch
+    self.device_index = device
+    desc = _lib.DvModelDesc(h, w, c, num_classes, max_batch)
+    self._handle = C.c_void_p()
+    _lib.check(_lib.lib().dv_model_create(C.byref(desc), device,
+                                          C.byref(self._handle)))
+    self.num_params = int(_lib.lib().dv_model_num_params(self._handle))
+    self.flat_weights = None
+
+  # ---- weights --------------------------------------------------------------
+  def layer_table(self) -> List[Tuple[int, int, int, int, int]]:
+    """(kh, kw, cin, cout, param_offset) per layer; last = Dense."""
+    l = _lib.lib()
+    out = []
+    for i in range(l.dv_model_num_layers(self._handle)):
+      kh, kw, ci, co = (C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32())
+      off = C.c_int64()
+      _lib.check(l.dv_model_layer_info(
+          self._handle, i, C.byref(kh), C.byref(kw), C.byref(ci), C.byref(co),
+          C.byref(off)))
+      out.append((kh.value, kw.value, ci.value, co.value, off.value))
+    return out
+
+  def load_flat_weights(self, flat: np.ndarray):
+    """conv HWIO + BN beta/mean/var per conv, then Dense kernel + bias
+    (the layout documented at dv_model_load_weights)."""
+    flat = np.ascontiguousarray(flat, dtype=np.float32)
+    if flat.size != self.num_params:
+      raise ValueError('expected %d parameters, got %d' %
+                       (self.num_params, flat.size))
+    _lib.check(_lib.lib().dv_model_load_weights(self._handle, flat.ctypes.data,
+                                                flat.size))
+    self.flat_weights = flat
+
+  def init_random(self, seed: int = 0):
+    """Seeded He-normal kernels / randomised BN statistics (no checkpoint is
+    available offline; the reference's own tests do the same,
+    deepvariant/call_variants_test.py:109-127)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    flat = np.zeros(self.num_params, np.float32)
+    table = self.layer_table()
+    for kh, kw, ci, co, off in table[:-1]:
+      n = kh * kw * ci * co
+      flat[off:off + n] = rng.standard_normal(n) * np.sqrt(2.0 / (kh * kw * ci))
+      flat[off + n:off + n + co] = rng.standard_normal(co) * 0.1
+      flat[off + n + co:off + n + 2 * co] = rng.standard_normal(co) * 0.1
+      flat[off + n + 2 * co:off + n + 3 * co] = rng.random(co) + 0.5
+    kh, kw, ci, co, off = table[-1]
+    flat[off:off + ci * co] = rng.standard_normal(ci * co) * 0.3
+    flat[off + ci * co:off + ci * co + co] = rng.standard_normal(co) * 0.1
+    self.load_flat_weights(flat)
+    return flat
+
+  # ---- forward --------------------------------------------------------------
+  def forward(self, images: torch.Tensor) -> torch.Tensor:
+    if images.dtype != torch.uint8 or not images.is_cuda:
+      raise ValueError('images must be a CUDA uint8 tensor [N, H, W, C]')
+    if tuple(images.shape[1:]) != self.input_shape:
+      # call_variants.py:704-733 raises on a shape mismatch as well
+      raise ValueError('input shape %s != model shape %s' %
+                       (tuple(images.shape[1:]), self.input_shape))
+    images = images.contiguous()
+    n = images.shape[0]
+    probs = torch.empty((n, self.num_classes), dtype=torch.float32,
+                        device=images.device)
+    stream = torch.cuda.current_stream(images.device).cuda_stream
+    _lib.check(_lib.lib().dv_model_infer(
+        self._handle, images.data_ptr(), n, probs.data_ptr(),
+        C.c_void_p(stream)))
+    return probs
+
+  def debug_tensor(self, index: int, n: int) -> np.ndarray:
+    h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+    l = _lib.lib()
+    l.dv_model_debug_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p] + [C.c_void_p] * 3
+    _lib.check(l.dv_model_debug_tensor(self._handle, index, n, None,
+                                       C.byref(h), C.byref(w), C.byref(c)))
+    out = np.zeros((n, h.value, w.value, c.value), np.float16)
+    _lib.check(l.dv_model_debug_tensor(self._handle, index, n, out.ctypes.data,
+                                       C.byref(h), C.byref(w), C.byref(c)))
+    return out
+
+  def __del__(self):
+    try:
+      if self._handle:
+        _lib.lib().dv_model_destroy(self._handle)
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+def smoke(images_u8: np.ndarray):
+  """Tiny forward on cuda:0 checked against the fp32 CPU oracle (1e-3)."""
+  from oracle import inception_ref as R  # checker only
+  n = min(4, images_u8.shape[0])
+  h, w, c = images_u8.shape[1:]
+  ref = R.make_random_model(c, seed=1)
+  model = InceptionV3((h, w, c), max_batch=8)
+  model.load_flat_weights(ref.export_flat())
+  x = torch.from_numpy(np.ascontiguousarray(images_u8[:n]))
+  got = model(x.cuda()).cpu()
+  with torch.no_grad():
+    want = ref(x)
+  err = float((got - want).abs().max())
+  assert err <= 1e-3, 'softmax differs from the fp32 oracle by %g' % err
+  print('inception smoke ok: max |dp| = %.2e' % err)

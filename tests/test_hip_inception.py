@@ -1,0 +1,75 @@
+"""HIP Inception-v3 (fp16 MFMA) vs the fp32 CPU restatement (GPU).
+
+Tolerance: |softmax_hip - softmax_fp32| <= 1e-3 (BASELINE.json north_star).
+The reference pins no CNN numerics ("parity unpinned"), so the
+oracle is the fp32 torch restatement with seeded random weights, exactly like
+deepvariant/call_variants_test.py:109-127.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _pileups(n, channels, seed):
+  from deepvariant_amd import synth
+  from deepvariant_amd.pileup_image_native import _Encoder
+  opts = synth.illumina_options(channels)
+  batch = synth.make_illumina_batch(n, seed=seed, options=opts,
+                                    multi_allelic=False)
+  out, _ = _Encoder(opts, opts.width).encode(batch, channels)
+  return out.reshape(-1, 100, 221, channels)[:n]
+
+
+@pytest.mark.parametrize('channels', [7, 6])
+def test_softmax_within_1e3_of_fp32_oracle(channels):
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  ref = R.make_random_model(channels, seed=3)
+  model = InceptionV3((100, 221, channels), max_batch=8)
+  assert model.num_params == ref.num_keras_params()
+  model.load_flat_weights(ref.export_flat())
+  imgs = np.concatenate([
+      _pileups(6, channels, seed=21),
+      np.random.default_rng(0).integers(0, 256, (4, 100, 221, channels),
+                                        dtype=np.uint8)])
+  x = torch.from_numpy(imgs)
+  got = model(x.cuda()).cpu()          # 10 examples, max_batch 8 -> two chunks
+  with torch.no_grad():
+    want = ref(x)
+  assert got.shape == (10, 3)
+  assert torch.allclose(got.sum(1), torch.ones(10), atol=1e-5)
+  err = (got - want).abs().max().item()
+  assert err <= TOL, err
+  # the oracle's answers must differ between inputs for the test to mean much
+  assert (want.max(0).values - want.min(0).values).max() > 1e-2
+
+
+def test_first_layers_match_activation_by_activation():
+  """Localises errors: preprocessed input and the first conv vs torch fp32."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  ref = R.make_random_model(7, seed=5)
+  model = InceptionV3((100, 221, 7), max_batch=4)
+  model.load_flat_weights(ref.export_flat())
+  x = torch.from_numpy(_pileups(2, 7, seed=4))
+  model(x.cuda())
+  pre = model.debug_tensor(0, 2).astype(np.float32)
+  want_pre = (x.float() - 128.0) / 128.0
+  np.testing.assert_array_equal(pre[..., :7], want_pre.numpy())
+  assert not pre[..., 7:].any()
+  with torch.no_grad():
+    want = ref.stem[0](want_pre.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+  got = model.debug_tensor(1, 2).astype(np.float32)
+  assert got.shape == want.shape == (2, 49, 110, 32)
+  np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
+
+
+def test_shape_mismatch_raises():
+  from deepvariant_amd.inception_v3 import InceptionV3
+  model = InceptionV3((100, 221, 7), max_batch=2)
+  model.init_random(0)
+  with pytest.raises(ValueError, match='input shape'):
+    model(torch.zeros((1, 100, 199, 7), dtype=torch.uint8, device='cuda'))
