@@ -92,7 +92,7 @@ def main():
   n_items = host_batch.n_items
   dbatch = DeviceBatch(host_batch, dev)
   enc = _Encoder(opts, W, device=local_rank)
-  model = InceptionV3((H, W, C), max_batch=min(n_items, 1024),
+  model = InceptionV3((H, W, C), max_batch=min(n_items, 2048),
                       device=local_rank)
   model.init_random(seed=1234)          # same weights on every rank
   images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)

@@ -4,14 +4,18 @@
 // (keras_modeling.inceptionv3, deepvariant/keras_modeling.py:246-336; graph =
 // tf_keras InceptionV3(include_top=False, pooling='avg')).
 //
-// Data layout in HBM: activations are NHWC fp16, one buffer per graph tensor,
-// concat outputs are written in place (each branch's last conv stores at its
-// channel offset of the block's output buffer -- no concat kernel).  BatchNorm
+// Data layout in HBM: activations are fp16 in the channel-blocked layout
+// [N][C/8][H][W][8] ("C8"): the 8 channels an MFMA fragment needs for one pixel
+// are one 16-byte piece, and consecutive pixels of a row are consecutive
+// pieces, so every fragment load and every store of a 32-pixel tile is one
+// contiguous 512-byte run.  One buffer per graph tensor; concat outputs are
+// written in place (each branch's last conv stores at its channel-group offset
+// of the block's output buffer -- no concat kernel).  BatchNorm
 // (scale=False, eps=1e-3, moving statistics) is folded into the fp16 conv
 // weights and an fp32 per-channel shift at load time.
 //
 // Kernels
-//   preprocess_kernel      uint8 HWC -> fp16 (x-128)/128, channels padded to 16
+//   preprocess_kernel      uint8 HWC -> fp16 C8 (x-128)/128, channels padded to 16
 //   conv_igemm_kernel<NB>  implicit-GEMM conv + shift + ReLU on
 //                          v_mfma_f32_32x32x16_f16: D[cout][pixel] =
 //                          sum_k W[cout][k] X[k][pixel]; block tile 128 pixels
@@ -23,6 +27,7 @@
 //   head_kernel            global average pool + Dense(3) + softmax in fp32
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -36,170 +41,272 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
-constexpr int kConvBM = 128;     // pixels per block tile
 constexpr int kConvThreads = 256;
 constexpr int kChunk = 16;       // channels per K chunk
 
 struct ConvArgs {
   const _Float16* in;
-  const _Float16* w;      // packed [cout_tile][step][2][NB*32][16]
+  const _Float16* w;      // packed [cout_tile][slab][8 chunks][NB*32][16]
   const float* shift;     // [Cout] folded BN shift
   _Float16* out;
   int N, H, W, Cin;
   int OH, OW, Cout;
   int KH, KW, stride, pad_h, pad_w;
-  int out_cstride, out_coff;
   int M;                  // N*OH*OW
   int cpt;                // chunks per tap = Cin/16
   int n_chunks;
-  int n_steps;
+  int n_slabs;            // ceil(n_chunks / kSlabChunks)
   int relu;
+  unsigned in_bytes;      // size of the input tensor (buffer-descriptor range)
+  unsigned chunk_stride;  // bytes between consecutive K chunks of a tap = 2*H*W*16
+  int out_groups;         // channel groups (of 8) in the destination buffer
+  int out_goff;           // first destination group of this conv
 };
 
-template <int NB>
-__global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(ConvArgs p) {
+constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
+constexpr int kPrefetch = 4;     // pixel-operand prefetch depth, in chunks
+
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Implicit-GEMM convolution, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].
+//
+//  * The block's weight tile (NB*32 couts) streams through LDS in slabs of 8
+//    K-chunks (128 K values), double buffered: ONE barrier per 8*NB*PT MFMAs.
+//  * The pixel operand never touches LDS: an MFMA B fragment is 8 consecutive
+//    channels of one pixel = one 16-byte buffer_load per lane, issued
+//    kPrefetch chunks ahead straight into VGPRs.  Padding taps and the M tail
+//    are handled by the buffer descriptor's range check (offset >= 2^31 reads
+//    as zero), so there are no divergent branches in the K loop.
+//  * Each wave owns PT*32 pixels x all NB*32 couts of the tile: NB*PT
+//    independent 32x32 accumulators keep the matrix pipe busy back to back.
+//  * Epilogue: shift + ReLU in registers, per-wave transpose through LDS,
+//    16-byte stores along channels into the (possibly concatenated) output.
+// Wave-uniform walk over the K chunks (tap-major, 16 channels = 2 channel
+// groups per chunk) kept in SGPRs and advanced with selects only -- no memory,
+// no branches.  off = byte offset of (group 2*cc, kh, kw) relative to
+// (group 0, ih0, iw0) in the C8 layout.
+struct ChunkWalk {
+  int kc, cc, kh, kw;
+  unsigned off;
+  __device__ __forceinline__ void advance(const ConvArgs& p) {
+    ++kc;
+    const bool tap_end = ++cc == p.cpt;
+    cc = tap_end ? 0 : cc;
+    kw += tap_end ? 1 : 0;
+    const bool row_end = kw == p.KW;
+    kw = row_end ? 0 : kw;
+    kh += row_end ? 1 : 0;
+    off = static_cast<unsigned>(cc) * p.chunk_stride +
+          static_cast<unsigned>((kh * p.W + kw) * 16);
+  }
+};
+
+template <int PT>
+__device__ __forceinline__ void prefetch_pixels(const ConvArgs& p,
+                                                const __amdgpu_buffer_rsrc_t rsrc,
+                                                ChunkWalk& w, const int (&ih0)[PT],
+                                                const int (&iw0)[PT], const unsigned (&base)[PT],
+                                                const bool (&mvalid)[PT], uint4_t (&dst)[PT]) {
+  const bool in_range = w.kc < p.n_chunks;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const bool ok = in_range && mvalid[pt] &&
+                    static_cast<unsigned>(ih0[pt] + w.kh) < static_cast<unsigned>(p.H) &&
+                    static_cast<unsigned>(iw0[pt] + w.kw) < static_cast<unsigned>(p.W);
+    const unsigned voff = ok ? base[pt] + w.off : 0x80000000u;
+    dst[pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  }
+  w.advance(p);
+}
+
+// One weight slab of R (<= 8) K-chunks: straight-line code, no branches, so the
+// compiler's s_waitcnt insertion keeps the kPrefetch-deep load pipeline intact.
+template <int NB, int PT, int R>
+__device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
+                                          const _Float16* wslab, ChunkWalk& walk,
+                                          const int (&ih0)[PT], const int (&iw0)[PT],
+                                          const unsigned (&base)[PT], const bool (&mvalid)[PT],
+                                          uint4_t (&xf)[kPrefetch][PT],
+                                          float16_t (&acc)[NB][PT]) {
   constexpr int BN = NB * 32;
-  constexpr int A_STAGE = 2 * kConvBM * kChunk;  // halfs
-  constexpr int B_STAGE = 2 * BN * kChunk;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    half8_t xh[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[j % kPrefetch][pt]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const half8_t wf =
+          *reinterpret_cast<const half8_t*>(wslab + (j * BN + nb * 32) * kChunk);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xh[pt], acc[nb][pt], 0, 0, 0);
+      }
+    }
+    // refill the slot just consumed with chunk (current + kPrefetch)
+    prefetch_pixels<PT>(p, rsrc, walk, ih0, iw0, base, mvalid, xf[j % kPrefetch]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NB, int PT>
+__global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
+  constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
+  constexpr int W_PER_THREAD = SLAB_PIECES / kConvThreads;  // = 2 * NB
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-  _Float16* As = smem;                 // [2][A_STAGE]
-  _Float16* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int m0 = blockIdx.x * kConvBM;
   const int n_tile = blockIdx.y;
+  const int m_block = blockIdx.x * (128 * PT);
 
-  // ---- A (pixels) load bookkeeping: row = tid/2, 8-channel half = tid%2 ----
-  const int a_row = tid >> 1;
-  const int a_hf = tid & 1;
-  const int m = m0 + a_row;
-  const bool valid_m = m < p.M;
-  int ih0 = 0, iw0 = 0;
-  const _Float16* in_n = p.in;
-  if (valid_m) {
-    const int ow = m % p.OW;
-    const int t = m / p.OW;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(p.in), 0, p.in_bytes, 0x00020000);
+
+  int ih0[PT], iw0[PT];
+  unsigned base[PT];
+  unsigned obase[PT];  // piece index of (n, group 0, oh, ow) in the output
+  bool mvalid[PT];
+  const int cg_in = p.Cin / 8;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int m = m_block + (wave * PT + pt) * 32 + (lane & 31);
+    mvalid[pt] = m < p.M;
+    const int mm = mvalid[pt] ? m : 0;
+    const int ow = mm % p.OW;
+    const int t = mm / p.OW;
     const int oh = t % p.OH;
     const int n = t / p.OH;
-    ih0 = oh * p.stride - p.pad_h;
-    iw0 = ow * p.stride - p.pad_w;
-    in_n = p.in + static_cast<size_t>(n) * p.H * p.W * p.Cin + a_hf * 8;
+    ih0[pt] = oh * p.stride - p.pad_h;
+    iw0[pt] = ow * p.stride - p.pad_w;
+    // byte offset of (n, this lane's group of chunk 0, ih0, iw0); may be
+    // "negative" (wraps) for padded taps, which are masked in prefetch_pixels.
+    base[pt] = static_cast<unsigned>((((n * cg_in + (lane >> 5)) * p.H + ih0[pt]) * p.W +
+                                      iw0[pt]) * 16);
+    obase[pt] = static_cast<unsigned>((n * p.out_groups + p.out_goff) * (p.OH * p.OW) +
+                                      oh * p.OW + ow);
   }
+
+  // ---- weight slabs: global -> registers -> LDS ---------------------------
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
-                      static_cast<size_t>(n_tile) * p.n_steps * (128 * NB);
-  constexpr int B_PIECES = 128 * NB;                  // 16-byte pieces per step
-  constexpr int B_PER_THREAD = (B_PIECES + kConvThreads - 1) / kConvThreads;
+                      static_cast<size_t>(n_tile) * p.n_slabs * SLAB_PIECES;
+  uint4_t wreg[W_PER_THREAD];
+#define DV_LOAD_SLAB(s_)                                                                   \
+  {                                                                                        \
+    const uint4_t* src_ = reinterpret_cast<const uint4_t*>(wsrc) +                         \
+                          static_cast<size_t>(s_) * SLAB_PIECES + tid;                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < W_PER_THREAD; ++j_) wreg[j_] =                \
+        src_[j_ * kConvThreads];                                                           \
+  }
+#define DV_STORE_SLAB(buf_)                                                                \
+  {                                                                                        \
+    uint4_t* dst_ = reinterpret_cast<uint4_t*>(smem + (buf_) * SLAB_HALFS) + tid;          \
+    _Pragma("unroll") for (int j_ = 0; j_ < W_PER_THREAD; ++j_) dst_[j_ * kConvThreads] = \
+        wreg[j_];                                                                          \
+  }
 
-  uint4 ra[2];
-  uint4 rbv[B_PER_THREAD];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-  auto load_tiles = [&](int ks) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int kc = 2 * ks + c;
-      uint4 v = zero4;
-      if (valid_m && kc < p.n_chunks) {
-        const int tap = kc / p.cpt;
-        const int cc = kc - tap * p.cpt;
-        const int kh = tap / p.KW;
-        const int kw = tap - kh * p.KW;
-        const int ih = ih0 + kh, iw = iw0 + kw;
-        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-          v = *reinterpret_cast<const uint4*>(
-              in_n + (static_cast<size_t>(ih) * p.W + iw) * p.Cin + cc * kChunk);
-        }
-      }
-      ra[c] = v;
-    }
-    const uint4* ws = wsrc + static_cast<size_t>(ks) * B_PIECES;
-#pragma unroll
-    for (int j = 0; j < B_PER_THREAD; ++j) {
-      const int q = tid + j * kConvThreads;
-      rbv[j] = (q < B_PIECES) ? ws[q] : zero4;
-    }
-  };
-  auto store_tiles = [&](int stage) {
-    uint4* a_dst = reinterpret_cast<uint4*>(As + stage * A_STAGE);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) a_dst[c * (kConvBM * 2) + a_row * 2 + a_hf] = ra[c];
-    uint4* b_dst = reinterpret_cast<uint4*>(Bs + stage * B_STAGE);
-#pragma unroll
-    for (int j = 0; j < B_PER_THREAD; ++j) {
-      const int q = tid + j * kConvThreads;
-      if (q < B_PIECES) b_dst[q] = rbv[j];
-    }
-  };
-
-  float16_t acc[NB];
+  uint4_t xf[kPrefetch][PT];
+  float16_t acc[NB][PT];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
 
-  load_tiles(0);
-  store_tiles(0);
+  ChunkWalk walk{0, 0, 0, 0, 0u};
+  DV_LOAD_SLAB(0)
+#pragma unroll
+  for (int d = 0; d < kPrefetch; ++d) {  // chunks 0 .. kPrefetch-1
+    prefetch_pixels<PT>(p, rsrc, walk, ih0, iw0, base, mvalid, xf[d]);
+  }
+  DV_STORE_SLAB(0)
   __syncthreads();
 
   const int frag_off = (lane & 31) * kChunk + (lane >> 5) * 8;  // halfs
-  for (int ks = 0; ks < p.n_steps; ++ks) {
-    const int cur = ks & 1;
-    const bool more = ks + 1 < p.n_steps;
-    if (more) load_tiles(ks + 1);
-    const _Float16* a_st = As + cur * A_STAGE;
-    const _Float16* b_st = Bs + cur * B_STAGE;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const half8_t xf = *reinterpret_cast<const half8_t*>(
-          a_st + c * (kConvBM * kChunk) + wave * 32 * kChunk + frag_off);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const half8_t wf = *reinterpret_cast<const half8_t*>(
-            b_st + c * (BN * kChunk) + nb * 32 * kChunk + frag_off);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[nb], 0, 0, 0);
-      }
+  const int n_full = p.n_chunks / kSlabChunks;
+  const int rem = p.n_chunks - n_full * kSlabChunks;
+  for (int s = 0; s < n_full; ++s) {
+    const bool more = s + 1 < p.n_slabs;
+    if (more) DV_LOAD_SLAB(s + 1)
+    conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk,
+                                   ih0, iw0, base, mvalid, xf, acc);
+    if (more) DV_STORE_SLAB((s + 1) & 1)
+    __syncthreads();
+  }
+  if (rem) {
+    const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
+    switch (rem) {
+      case 1: conv_slab<NB, PT, 1>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 2: conv_slab<NB, PT, 2>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 3: conv_slab<NB, PT, 3>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 4: conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 5: conv_slab<NB, PT, 5>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 6: conv_slab<NB, PT, 6>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      default: conv_slab<NB, PT, 7>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
     }
-    if (more) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: shift + ReLU, transpose through LDS, 16-byte stores -------
-  constexpr int OT_STRIDE = BN + 8;  // halfs; keeps rows 16-byte aligned
-  _Float16* Ot = smem;
-  {
-    const int prow = wave * 32 + (lane & 31);
-    const int cbase = n_tile * BN;
+  // ---- epilogue: shift + ReLU, pair lanes l / l+32 into 16-byte pieces -------
+  // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
+  // A C8 piece (8 couts of one pixel) is split over lanes l and l+32: for each
+  // pair of groups (q = 2t, 2t+1) the low half-wave completes group 2t and the
+  // high half-wave group 2t+1 after one cross-half exchange, then every lane
+  // stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
+  const int cbase = n_tile * BN;
+  const int hi = lane >> 5;
+  const unsigned ohow = static_cast<unsigned>(p.OH * p.OW);
+  uint4* outp = reinterpret_cast<uint4*>(p.out);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
+    float shv[4][4];  // [q][j]: shift of cout nb*32 + 8q + 4*hi + j
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = cbase + nb * 32 + 8 * q + 4 * hi + j;
+        shv[q][j] = co < p.Cout ? p.shift[co] : 0.f;
+      }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const float16_t a = acc[nb][pt];
+      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int cl = nb * 32 + 8 * q + 4 * (lane >> 5);
-        half4_t h;
+        _Float16 h[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int co = cbase + cl + j;
-          float v = acc[nb][4 * q + j] + (co < p.Cout ? p.shift[co] : 0.f);
+          float v = a[4 * q + j] + shv[q][j];
           if (p.relu) v = fmaxf(v, 0.f);
           h[j] = static_cast<_Float16>(v);
         }
-        *reinterpret_cast<half4_t*>(Ot + prow * OT_STRIDE + cl) = h;
+        pk[q][0] = __builtin_bit_cast(unsigned short, h[0]) |
+                   (static_cast<unsigned>(__builtin_bit_cast(unsigned short, h[1])) << 16);
+        pk[q][1] = __builtin_bit_cast(unsigned short, h[2]) |
+                   (static_cast<unsigned>(__builtin_bit_cast(unsigned short, h[3])) << 16);
       }
-    }
-  }
-  __syncthreads();
-  {
-    constexpr int SEGS = BN / 8;  // 16-byte segments per pixel row
-    for (int q = tid; q < kConvBM * SEGS; q += kConvThreads) {
-      const int row = q / SEGS;
-      const int seg = q - row * SEGS;
-      const int mm = m0 + row;
-      const int co = n_tile * BN + seg * 8;
-      if (mm < p.M && co < p.Cout) {
-        const uint4 v = *reinterpret_cast<const uint4*>(Ot + row * OT_STRIDE + seg * 8);
-        *reinterpret_cast<uint4*>(p.out + static_cast<size_t>(mm) * p.out_cstride +
-                                  p.out_coff + co) = v;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // low half-wave completes group 2t (sends its half of 2t+1), high 2t+1
+        const unsigned s0 = hi ? pk[2 * t][0] : pk[2 * t + 1][0];
+        const unsigned s1 = hi ? pk[2 * t][1] : pk[2 * t + 1][1];
+        const unsigned r0 = __shfl_xor(s0, 32);
+        const unsigned r1 = __shfl_xor(s1, 32);
+        const uint4 piece = hi ? make_uint4(r0, r1, pk[2 * t + 1][0], pk[2 * t + 1][1])
+                               : make_uint4(pk[2 * t][0], pk[2 * t][1], r0, r1);
+        const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
+        if (mvalid[pt] && group * 8 < p.Cout) {
+          outp[obase[pt] + static_cast<unsigned>(group) * ohow] = piece;
+        }
       }
     }
   }
@@ -207,14 +314,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(ConvArgs p) {
 
 template <int NB>
 constexpr size_t conv_lds_bytes() {
-  const size_t stages = 2 * (2 * kConvBM * kChunk + 2 * NB * 32 * kChunk) * 2;
-  const size_t epi = static_cast<size_t>(kConvBM) * (NB * 32 + 8) * 2;
-  return stages > epi ? stages : epi;
+  return static_cast<size_t>(2) * kSlabChunks * NB * 32 * kChunk * 2;
 }
 
-// uint8 [N,H,W,C] -> fp16 [N,H,W,16]: (x - 128) / 128, exact in fp16.
+// uint8 [N,H,W,C] -> fp16 C8 [N][2][H][W][8]: (x - 128) / 128, exact in fp16.
 __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix,
-                                  int C) {
+                                  int C, int hw) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n_pix) return;
   const uint8_t* px = in + i * C;
@@ -224,57 +329,61 @@ __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix
     v[c] = c < C ? static_cast<_Float16>((static_cast<float>(px[c]) - 128.0f) / 128.0f)
                  : static_cast<_Float16>(0.f);
   }
-  uint4* dst = reinterpret_cast<uint4*>(out + i * 16);
-  dst[0] = *reinterpret_cast<uint4*>(&v[0]);
-  dst[1] = *reinterpret_cast<uint4*>(&v[8]);
+  const size_t n = i / hw;
+  const size_t pix = i - n * hw;
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  dst[(n * 2 + 0) * hw + pix] = *reinterpret_cast<uint4*>(&v[0]);
+  dst[(n * 2 + 1) * hw + pix] = *reinterpret_cast<uint4*>(&v[8]);
 }
 
 struct PoolArgs {
   const _Float16* in;
   _Float16* out;
   int N, H, W, C, OH, OW;
-  int out_cstride, out_coff;
+  int out_groups, out_goff;
 };
 
-// MaxPooling2D(3, strides=2, 'valid'); one thread = 8 channels of one pixel.
+// MaxPooling2D(3, strides=2, 'valid'), C8 layout; one thread = one 16-byte piece.
 __global__ void maxpool3s2_kernel(PoolArgs p) {
-  const int c8 = p.C / 8;
-  const size_t total = static_cast<size_t>(p.N) * p.OH * p.OW * c8;
+  const int cg = p.C / 8;
+  const size_t total = static_cast<size_t>(p.N) * cg * p.OH * p.OW;
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= total) return;
-  const int cg = i % c8;
-  size_t t = i / c8;
-  const int ow = t % p.OW;
-  t /= p.OW;
+  const int ow = i % p.OW;
+  size_t t = i / p.OW;
   const int oh = t % p.OH;
-  const int n = t / p.OH;
+  t /= p.OH;
+  const int g = t % cg;
+  const int n = t / cg;
+  const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
+                       (static_cast<size_t>(n) * cg + g) * p.H * p.W;
   half8_t best;
 #pragma unroll
   for (int j = 0; j < 8; ++j) best[j] = static_cast<_Float16>(-65504.f);
   for (int dh = 0; dh < 3; ++dh)
     for (int dw = 0; dw < 3; ++dw) {
-      const int ih = oh * 2 + dh, iw = ow * 2 + dw;
-      const half8_t v = *reinterpret_cast<const half8_t*>(
-          p.in + ((static_cast<size_t>(n) * p.H + ih) * p.W + iw) * p.C + cg * 8);
+      const half8_t v = src[(oh * 2 + dh) * p.W + ow * 2 + dw];
 #pragma unroll
       for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
     }
-  *reinterpret_cast<half8_t*>(p.out + ((static_cast<size_t>(n) * p.OH + oh) * p.OW + ow) *
-                                           p.out_cstride + p.out_coff + cg * 8) = best;
+  reinterpret_cast<half8_t*>(p.out)[(static_cast<size_t>(n) * p.out_groups + p.out_goff + g) *
+                                        p.OH * p.OW + oh * p.OW + ow] = best;
 }
 
 // AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.
 __global__ void avgpool3s1_kernel(PoolArgs p) {
-  const int c8 = p.C / 8;
-  const size_t total = static_cast<size_t>(p.N) * p.H * p.W * c8;
+  const int cg = p.C / 8;
+  const size_t total = static_cast<size_t>(p.N) * cg * p.H * p.W;
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= total) return;
-  const int cg = i % c8;
-  size_t t = i / c8;
-  const int ow = t % p.W;
-  t /= p.W;
+  const int ow = i % p.W;
+  size_t t = i / p.W;
   const int oh = t % p.H;
-  const int n = t / p.H;
+  t /= p.H;
+  const int g = t % cg;
+  const int n = t / cg;
+  const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
+                       (static_cast<size_t>(n) * cg + g) * p.H * p.W;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int cnt = 0;
   for (int dh = -1; dh <= 1; ++dh)
@@ -282,8 +391,7 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
       const int ih = oh + dh, iw = ow + dw;
       if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
       ++cnt;
-      const half8_t v = *reinterpret_cast<const half8_t*>(
-          p.in + ((static_cast<size_t>(n) * p.H + ih) * p.W + iw) * p.C + cg * 8);
+      const half8_t v = src[ih * p.W + iw];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
     }
@@ -291,8 +399,8 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
   const float inv = 1.0f / static_cast<float>(cnt);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
-  *reinterpret_cast<half8_t*>(p.out + ((static_cast<size_t>(n) * p.H + oh) * p.W + ow) *
-                                           p.out_cstride + p.out_coff + cg * 8) = o;
+  reinterpret_cast<half8_t*>(p.out)[(static_cast<size_t>(n) * p.out_groups + p.out_goff + g) *
+                                        p.H * p.W + oh * p.W + ow] = o;
 }
 
 // GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
@@ -303,11 +411,12 @@ __global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const flo
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const _Float16* x = in + static_cast<size_t>(n) * P * C;
+  const _Float16* x = in + static_cast<size_t>(n) * P * C;  // C8: [C/8][P][8]
   const float invP = 1.0f / static_cast<float>(P);
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    for (int pp = 0; pp < P; ++pp) s += static_cast<float>(x[static_cast<size_t>(pp) * C + c]);
+    const _Float16* xc = x + static_cast<size_t>(c >> 3) * P * 8 + (c & 7);
+    for (int pp = 0; pp < P; ++pp) s += static_cast<float>(xc[pp * 8]);
     s *= invP;
     for (int k = 0; k < K; ++k) part[k] += s * w[static_cast<size_t>(c) * K + k];
   }
@@ -358,6 +467,7 @@ struct Op {
   int n_steps = 0, n_chunks = 0;
   size_t w_off = 0;      // halfs into packed weights
   size_t shift_off = 0;  // floats into shifts
+  size_t tbl_off = 0;    // int2 entries into the chunk tables
 };
 
 struct LayerInfo {
@@ -375,9 +485,9 @@ struct dv_model {
   std::vector<LayerInfo> layers;  // convs then dense
   int64_t n_params = 0;
   int feat_buf = -1, feat_p = 0, feat_c = 0;
-  size_t packed_halfs = 0, shift_floats = 0;
+  size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
-  dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b;
+  dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
   bool loaded = false;
 
   // ---- builder ------------------------------------------------------------
@@ -423,12 +533,14 @@ struct dv_model {
     op.out_coff = dst_coff;
     op.nb = pick_nb(cout);
     op.n_chunks = kh * kw * (x.c / kChunk);
-    op.n_steps = (op.n_chunks + 1) / 2;
+    op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;  // weight slabs
     const int n_tiles = (cout + op.nb * 32 - 1) / (op.nb * 32);
     op.w_off = packed_halfs;
-    packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * 2 * (op.nb * 32) * kChunk;
+    packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks * (op.nb * 32) * kChunk;
     op.shift_off = shift_floats;
     shift_floats += cout;
+    op.tbl_off = tbl_entries;
+    tbl_entries += op.n_chunks;
     op.layer = static_cast<int>(layers.size());
     layers.push_back({kh, kw, op.cin_real, cout, n_params});
     n_params += static_cast<int64_t>(kh) * kw * op.cin_real * cout + 3LL * cout;
@@ -565,9 +677,20 @@ namespace {
 
 template <int NB>
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-  const dim3 grid((a.M + kConvBM - 1) / kConvBM, (a.Cout + NB * 32 - 1) / (NB * 32));
-  hipLaunchKernelGGL(conv_igemm_kernel<NB>, grid, dim3(kConvThreads), conv_lds_bytes<NB>(),
-                     stream, a);
+  const int n_tiles = (a.Cout + NB * 32 - 1) / (NB * 32);
+  // Two pixel tiles per wave halve the LDS weight traffic per MFMA; fall back
+  // to one when that would leave CUs without a block.
+  const long blocks2 = static_cast<long>((a.M + 255) / 256) * n_tiles;
+  static const int force_pt = getenv("DV_CONV_PT") ? atoi(getenv("DV_CONV_PT")) : 0;  // tuning knob
+  if (force_pt ? force_pt == 2 : blocks2 >= 512) {
+    const dim3 grid((a.M + 255) / 256, n_tiles);
+    hipLaunchKernelGGL((conv_mfma_kernel<NB, 2>), grid, dim3(kConvThreads),
+                       conv_lds_bytes<NB>(), stream, a);
+  } else {
+    const dim3 grid((a.M + 127) / 128, n_tiles);
+    hipLaunchKernelGGL((conv_mfma_kernel<NB, 1>), grid, dim3(kConvThreads),
+                       conv_lds_bytes<NB>(), stream, a);
+  }
 }
 
 int run_ops(dv_model* m, int n, hipStream_t stream) {
@@ -591,13 +714,15 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       a.stride = op.stride;
       a.pad_h = op.pad_h;
       a.pad_w = op.pad_w;
-      a.out_cstride = ob.c;
-      a.out_coff = op.out_coff;
+      a.out_groups = ob.c / 8;
+      a.out_goff = op.out_coff / 8;
+      a.chunk_stride = static_cast<unsigned>(2 * op.ih * op.iw * 16);
       a.M = n * op.oh * op.ow;
       a.cpt = op.cin / kChunk;
       a.n_chunks = op.n_chunks;
-      a.n_steps = op.n_steps;
+      a.n_slabs = op.n_steps;
       a.relu = 1;
+      a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin * 2);
       dv::ProfileScope prof(dv::kProfConv, stream);
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
@@ -615,8 +740,8 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       p.C = op.cin;
       p.OH = op.oh;
       p.OW = op.ow;
-      p.out_cstride = ob.c;
-      p.out_coff = op.out_coff;
+      p.out_groups = ob.c / 8;
+      p.out_goff = op.out_coff / 8;
       const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
       const dim3 grid(static_cast<unsigned>((total + 255) / 256));
       dv::ProfileScope prof(dv::kProfOther, stream);
@@ -638,10 +763,12 @@ extern "C" {
 int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (!desc || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_create: null");
   if (desc->channels < 1 || desc->channels > 16 || desc->num_classes < 1 ||
-      desc->num_classes > 8 || desc->max_batch < 1 || desc->height < 75 ||
+      desc->num_classes > 8 || desc->max_batch < 1 || desc->max_batch > 2048 ||
+      desc->height < 75 ||
       desc->width < 75) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT,
-                    "dv_model_create: unsupported shape (need H,W >= 75, C <= 16)");
+                    "dv_model_create: unsupported shape (need H,W >= 75, C <= 16, max_batch <= 2048: "
+                    "activation tensors are addressed through 2 GiB buffer descriptors)");
   }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -677,6 +804,7 @@ void dv_model_destroy(dv_model* m) {
   m->d_shift.release();
   m->d_dense_w.release();
   m->d_dense_b.release();
+  m->d_tbl.release();
   delete m;
 }
 
@@ -730,25 +858,24 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
     const int cpt = op.cin / kChunk;
     const int n_tiles = (op.cout + bn - 1) / bn;
     for (int t = 0; t < n_tiles; ++t)
-      for (int ks = 0; ks < op.n_steps; ++ks)
-        for (int c = 0; c < 2; ++c) {
-          const int kc = 2 * ks + c;
-          if (kc >= op.n_chunks) continue;
-          const int tap = kc / cpt, cc = kc % cpt;
-          const int kh = tap / op.kw, kw = tap % op.kw;
-          for (int r = 0; r < bn; ++r) {
-            const int co = t * bn + r;
-            if (co >= op.cout) continue;
-            _Float16* dst = packed.data() + op.w_off +
-                            (((static_cast<size_t>(t) * op.n_steps + ks) * 2 + c) * bn + r) * kChunk;
-            for (int j = 0; j < kChunk; ++j) {
-              const int ci = cc * kChunk + j;
-              if (ci >= l.cin) continue;  // padded input channels
-              const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
-              dst[j] = static_cast<_Float16>(v * inv[co]);
-            }
+      for (int kc = 0; kc < op.n_chunks; ++kc) {
+        const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
+        const int tap = kc / cpt, cc = kc % cpt;
+        const int kh = tap / op.kw, kw = tap % op.kw;
+        for (int r = 0; r < bn; ++r) {
+          const int co = t * bn + r;
+          if (co >= op.cout) continue;
+          _Float16* dst = packed.data() + op.w_off +
+                          (((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn + r) *
+                              kChunk;
+          for (int jj = 0; jj < kChunk; ++jj) {
+            const int ci = cc * kChunk + jj;
+            if (ci >= l.cin) continue;  // padded input channels
+            const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+            dst[jj] = static_cast<_Float16>(v * inv[co]);
           }
         }
+      }
   }
   const LayerInfo& dl = m->layers.back();
   const float* dw = weights + dl.param_off;
@@ -798,7 +925,8 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
       dv::ProfileScope prof(dv::kProfOther, stream);
       hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
                          dim3(256), 0, stream, images + done * img_bytes,
-                         static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels);
+                         static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels,
+                         m->desc.height * m->desc.width);
     }
     if (int rc = run_ops(m, nb, stream)) return rc;
     {

@@ -104,10 +104,12 @@ class InceptionV3(torch.nn.Module):
                                         C.c_void_p] + [C.c_void_p] * 3
     _lib.check(l.dv_model_debug_tensor(self._handle, index, n, None,
                                        C.byref(h), C.byref(w), C.byref(c)))
-    out = np.zeros((n, h.value, w.value, c.value), np.float16)
-    _lib.check(l.dv_model_debug_tensor(self._handle, index, n, out.ctypes.data,
+    # device layout is channel-blocked [N][C/8][H][W][8]; return NHWC
+    raw = np.zeros((n, c.value // 8, h.value, w.value, 8), np.float16)
+    _lib.check(l.dv_model_debug_tensor(self._handle, index, n, raw.ctypes.data,
                                        C.byref(h), C.byref(w), C.byref(c)))
-    return out
+    return np.ascontiguousarray(raw.transpose(0, 2, 3, 1, 4)).reshape(
+        n, h.value, w.value, c.value)
 
   def __del__(self):
     try:

@@ -284,8 +284,9 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n);
 int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
                    void* stream);
 
-/* Testing hook: copy activation buffer `index` (NHWC fp16, first n examples of
- * the last dv_model_infer) to host memory and report its shape. */
+/* Testing hook: copy activation buffer `index` (fp16, channel-blocked
+ * [n][c/8][h][w][8], first n examples of the last dv_model_infer) to host
+ * memory and report its shape. */
 int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out,
                           int32_t* h, int32_t* w, int32_t* c);
 
