@@ -61,6 +61,7 @@ struct ConvArgs {
   unsigned chunk_stride;  // bytes between consecutive K chunks of a tap = 2*H*W*16
   int out_groups;         // channel groups (of 8) in the destination buffer
   int out_goff;           // first destination group of this conv
+  int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
 };
 
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
@@ -86,21 +87,24 @@ __device__ __forceinline__ void wave_sync() {
 //    independent 32x32 accumulators keep the matrix pipe busy back to back.
 //  * Epilogue: shift + ReLU in registers, per-wave transpose through LDS,
 //    16-byte stores along channels into the (possibly concatenated) output.
-// Wave-uniform walk over the K chunks (tap-major, 16 channels = 2 channel
-// groups per chunk) kept in SGPRs and advanced with selects only -- no memory,
-// no branches.  off = byte offset of (group 2*cc, kh, kw) relative to
-// (group 0, ih0, iw0) in the C8 layout.
+// Wave-uniform walk over the K chunks kept in SGPRs and advanced with selects
+// only -- no memory, no branches.  K order is channel-chunk major, filter tap
+// minor: the KH*KW taps of one 16-channel chunk are consecutive, so a block
+// re-reads the same two channel-group planes (a few KB incl. halo) KH*KW times
+// back to back and the vector L1 serves all but the first pass.  (Tap-major
+// order streams the whole C8 footprint per tap and thrashes the 32 KB L1.)
+// off = byte offset of (group 2*cc, kh, kw) relative to (group 0, ih0, iw0).
 struct ChunkWalk {
   int kc, cc, kh, kw;
   unsigned off;
   __device__ __forceinline__ void advance(const ConvArgs& p) {
     ++kc;
-    const bool tap_end = ++cc == p.cpt;
-    cc = tap_end ? 0 : cc;
-    kw += tap_end ? 1 : 0;
-    const bool row_end = kw == p.KW;
+    const bool row_end = ++kw == p.KW;
     kw = row_end ? 0 : kw;
     kh += row_end ? 1 : 0;
+    const bool taps_end = kh == p.KH;
+    kh = taps_end ? 0 : kh;
+    cc += taps_end ? 1 : 0;
     off = static_cast<unsigned>(cc) * p.chunk_stride +
           static_cast<unsigned>((kh * p.W + kw) * 16);
   }
@@ -134,18 +138,33 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
                                           uint4_t (&xf)[kPrefetch][PT],
                                           float16_t (&acc)[NB][PT]) {
   constexpr int BN = NB * 32;
+  // Weight fragments are double buffered in registers: the ds_reads of chunk
+  // j+1 are issued before the MFMAs of chunk j, whose 32*NB*PT cycles cover the
+  // LDS latency.
+  half8_t wf[2][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    wf[0][nb] = *reinterpret_cast<const half8_t*>(wslab + (nb * 32) * kChunk);
+  }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
+    if (j + 1 < R) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        wf[(j + 1) & 1][nb] = *reinterpret_cast<const half8_t*>(
+            wslab + ((j + 1) * BN + nb * 32) * kChunk);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     half8_t xh[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[j % kPrefetch][pt]);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const half8_t wf =
-          *reinterpret_cast<const half8_t*>(wslab + (j * BN + nb * 32) * kChunk);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xh[pt], acc[nb][pt], 0, 0, 0);
+        acc[nb][pt] =
+            __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j & 1][nb], xh[pt], acc[nb][pt], 0, 0, 0);
       }
     }
     // refill the slot just consumed with chunk (current + kPrefetch)
@@ -165,8 +184,15 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int n_tile = blockIdx.y;
-  const int m_block = blockIdx.x * (128 * PT);
+  // 1-D grid.  Blocks are dispatched round-robin over the 8 XCDs (block b ->
+  // XCD b % 8); remap so that logically consecutive blocks -- the cout tiles of
+  // the same pixel tile, which re-read the same input -- share an XCD's L2.
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+  const int n_tile = logical % p.n_tiles;
+  const int m_block = (logical / p.n_tiles) * (128 * PT);
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<_Float16*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -682,14 +708,16 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
   // to one when that would leave CUs without a block.
   const long blocks2 = static_cast<long>((a.M + 255) / 256) * n_tiles;
   static const int force_pt = getenv("DV_CONV_PT") ? atoi(getenv("DV_CONV_PT")) : 0;  // tuning knob
+  ConvArgs b = a;
+  b.n_tiles = n_tiles;
   if (force_pt ? force_pt == 2 : blocks2 >= 512) {
-    const dim3 grid((a.M + 255) / 256, n_tiles);
+    const dim3 grid(static_cast<unsigned>(((a.M + 255) / 256) * n_tiles));
     hipLaunchKernelGGL((conv_mfma_kernel<NB, 2>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, a);
+                       conv_lds_bytes<NB>(), stream, b);
   } else {
-    const dim3 grid((a.M + 127) / 128, n_tiles);
+    const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * n_tiles));
     hipLaunchKernelGGL((conv_mfma_kernel<NB, 1>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, a);
+                       conv_lds_bytes<NB>(), stream, b);
   }
 }
 
@@ -855,12 +883,12 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
     }
     const int bn = op.nb * 32;
-    const int cpt = op.cin / kChunk;
     const int n_tiles = (op.cout + bn - 1) / bn;
     for (int t = 0; t < n_tiles; ++t)
       for (int kc = 0; kc < op.n_chunks; ++kc) {
         const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
-        const int tap = kc / cpt, cc = kc % cpt;
+        const int taps = op.kh * op.kw;
+        const int cc = kc / taps, tap = kc % taps;  // chunk-major, tap-minor (ChunkWalk)
         const int kh = tap / op.kw, kw = tap % op.kw;
         for (int r = 0; r < bn; ++r) {
           const int co = t * bn + r;

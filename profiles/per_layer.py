@@ -28,9 +28,8 @@ def main(path, n, channels=7):
     us = (e - s) / 1e3
     tot_us += us
     tot_fl += fl
-    tag = name.split('kernelI')[1].split('EEv')[0] if 'kernelI' in name else ''
     print('%3d %2d %2d %5d %4d %3d %3d %9.1f %8.1f  %s %dx%d' %
-          (i, kh, kw, ci, co, oh, ow, us, fl / (e - s) / 1e3, tag, gx // 256, gy))
+          (i, kh, kw, ci, co, oh, ow, us, fl / (e - s) / 1e3, name.split('kernelI')[1].split('EEv')[0] if 'kernelI' in name else '', gx // 256, gy))
   print('total conv: %.1f us, %.1f TFLOP/s' % (tot_us, tot_fl / tot_us / 1e6))
 
 
