@@ -37,7 +37,7 @@ def parse_args():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--batch', type=int, default=2048,
+  ap.add_argument('--batch', type=int, default=1950,
                   help='candidates per step per GPU')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
   ap.add_argument('--no-cpu-baseline', action='store_true')

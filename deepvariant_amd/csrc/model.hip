@@ -44,97 +44,92 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 constexpr int kConvThreads = 256;
 constexpr int kChunk = 16;       // channels per K chunk
 
+// Geometry of one activation tensor in HBM: fp16, channel-blocked and
+// zero-haloed, [N][C/8][H + 2*halo][W + 2*halo][8].  The halo is written once
+// (hipMemset at model creation) and never touched again: producers store the
+// interior only, so 'same'-padded convolutions read their padding as ordinary
+// in-bounds zeros and need no predicates.
+struct TensorGeom {
+  int h, w;     // interior size
+  int halo;
+  int hp, wp;   // padded size
+  int groups;   // channel groups of 8 (full concat width)
+};
+
 struct ConvArgs {
   const _Float16* in;
   const _Float16* w;      // packed [cout_tile][slab][8 chunks][NB*32][16]
   const float* shift;     // [Cout] folded BN shift
   _Float16* out;
-  int N, H, W, Cin;
-  int OH, OW, Cout;
+  TensorGeom ig, og;
+  int N, Cin, Cout;
+  int OH, OW;
   int KH, KW, stride, pad_h, pad_w;
+  int out_goff;           // first destination group of this conv
   int M;                  // N*OH*OW
-  int cpt;                // chunks per tap = Cin/16
   int n_chunks;
   int n_slabs;            // ceil(n_chunks / kSlabChunks)
   int relu;
   unsigned in_bytes;      // size of the input tensor (buffer-descriptor range)
-  unsigned chunk_stride;  // bytes between consecutive K chunks of a tap = 2*H*W*16
-  int out_groups;         // channel groups (of 8) in the destination buffer
-  int out_goff;           // first destination group of this conv
+  unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
   int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
+  float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
 };
 
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
 constexpr int kPrefetch = 4;     // pixel-operand prefetch depth, in chunks
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+// q = m / d, r = m % d for 0 <= m < 2^24 via one fp32 multiply + fix-up.
+__device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, int& r) {
+  q = static_cast<int>(static_cast<float>(m) * rcp);
+  r = m - q * d;
+  if (r < 0) {
+    r += d;
+    --q;
+  }
+  if (r >= d) {
+    r -= d;
+    ++q;
+  }
 }
 
-// Implicit-GEMM convolution, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].
-//
-//  * The block's weight tile (NB*32 couts) streams through LDS in slabs of 8
-//    K-chunks (128 K values), double buffered: ONE barrier per 8*NB*PT MFMAs.
-//  * The pixel operand never touches LDS: an MFMA B fragment is 8 consecutive
-//    channels of one pixel = one 16-byte buffer_load per lane, issued
-//    kPrefetch chunks ahead straight into VGPRs.  Padding taps and the M tail
-//    are handled by the buffer descriptor's range check (offset >= 2^31 reads
-//    as zero), so there are no divergent branches in the K loop.
-//  * Each wave owns PT*32 pixels x all NB*32 couts of the tile: NB*PT
-//    independent 32x32 accumulators keep the matrix pipe busy back to back.
-//  * Epilogue: shift + ReLU in registers, per-wave transpose through LDS,
-//    16-byte stores along channels into the (possibly concatenated) output.
 // Wave-uniform walk over the K chunks kept in SGPRs and advanced with selects
 // only -- no memory, no branches.  K order is channel-chunk major, filter tap
 // minor: the KH*KW taps of one 16-channel chunk are consecutive, so a block
 // re-reads the same two channel-group planes (a few KB incl. halo) KH*KW times
-// back to back and the vector L1 serves all but the first pass.  (Tap-major
-// order streams the whole C8 footprint per tap and thrashes the 32 KB L1.)
+// back to back and the vector L1 serves all but the first pass.
 // off = byte offset of (group 2*cc, kh, kw) relative to (group 0, ih0, iw0).
 struct ChunkWalk {
-  int kc, cc, kh, kw;
-  unsigned off;
+  int kh, kw;
+  unsigned tap_off;    // (kh*wp + kw) * 16
+  unsigned chunk_off;  // cc * chunk_stride
+  __device__ __forceinline__ unsigned off() const { return chunk_off + tap_off; }
   __device__ __forceinline__ void advance(const ConvArgs& p) {
-    ++kc;
     const bool row_end = ++kw == p.KW;
     kw = row_end ? 0 : kw;
+    tap_off += row_end ? static_cast<unsigned>((p.ig.wp - p.KW + 1) * 16) : 16u;
     kh += row_end ? 1 : 0;
     const bool taps_end = kh == p.KH;
     kh = taps_end ? 0 : kh;
-    cc += taps_end ? 1 : 0;
-    off = static_cast<unsigned>(cc) * p.chunk_stride +
-          static_cast<unsigned>((kh * p.W + kw) * 16);
+    tap_off = taps_end ? 0u : tap_off;
+    chunk_off += taps_end ? p.chunk_stride : 0u;
   }
 };
 
-template <int PT>
-__device__ __forceinline__ void prefetch_pixels(const ConvArgs& p,
-                                                const __amdgpu_buffer_rsrc_t rsrc,
-                                                ChunkWalk& w, const int (&ih0)[PT],
-                                                const int (&iw0)[PT], const unsigned (&base)[PT],
-                                                const bool (&mvalid)[PT], uint4_t (&dst)[PT]) {
-  const bool in_range = w.kc < p.n_chunks;
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const bool ok = in_range && mvalid[pt] &&
-                    static_cast<unsigned>(ih0[pt] + w.kh) < static_cast<unsigned>(p.H) &&
-                    static_cast<unsigned>(iw0[pt] + w.kw) < static_cast<unsigned>(p.W);
-    const unsigned voff = ok ? base[pt] + w.off : 0x80000000u;
-    dst[pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-  }
-  w.advance(p);
-}
-
 // One weight slab of R (<= 8) K-chunks: straight-line code, no branches, so the
 // compiler's s_waitcnt insertion keeps the kPrefetch-deep load pipeline intact.
+// Pixel fragments: voffset = per-lane base (VGPR, fixed for the whole kernel),
+// soffset = chunk offset (SGPR): ZERO vector ALU work per load.  Chunks past the
+// end of K simply read the next bytes of the (larger) input tensor or hit the
+// descriptor's range check; their values are never used.
 template <int NB, int PT, int R>
 __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
                                           const _Float16* wslab, ChunkWalk& walk,
-                                          const int (&ih0)[PT], const int (&iw0)[PT],
-                                          const unsigned (&base)[PT], const bool (&mvalid)[PT],
+                                          const unsigned (&base)[PT],
                                           uint4_t (&xf)[kPrefetch][PT],
                                           float16_t (&acc)[NB][PT]) {
   constexpr int BN = NB * 32;
@@ -168,11 +163,28 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
       }
     }
     // refill the slot just consumed with chunk (current + kPrefetch)
-    prefetch_pixels<PT>(p, rsrc, walk, ih0, iw0, base, mvalid, xf[j % kPrefetch]);
+    const unsigned soff = walk.off();
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      xf[j % kPrefetch][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+    }
+    walk.advance(p);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
+// Implicit-GEMM convolution, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].
+//
+//  * The block's weight tile (NB*32 couts) streams through LDS in slabs of 8
+//    K-chunks (128 K values), double buffered: ONE barrier per 8*NB*PT MFMAs.
+//  * The pixel operand never touches LDS: an MFMA B fragment is 8 consecutive
+//    channels of one pixel = one 16-byte piece of the C8 layout, loaded
+//    kPrefetch chunks ahead straight into VGPRs; 32 consecutive pixels are one
+//    contiguous 512-byte run.
+//  * Each wave owns PT*32 pixels x all NB*32 couts of the tile: NB*PT
+//    independent 32x32 accumulators keep the matrix pipe busy back to back.
+//  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
+//    pieces, stored as contiguous 512-byte runs (no LDS).
 template <int NB, int PT>
 __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
@@ -197,28 +209,25 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<_Float16*>(p.in), 0, p.in_bytes, 0x00020000);
 
-  int ih0[PT], iw0[PT];
-  unsigned base[PT];
-  unsigned obase[PT];  // piece index of (n, group 0, oh, ow) in the output
+  unsigned base[PT];   // byte offset of (n, group lane>>5, ih0, iw0) in the input
+  unsigned obase[PT];  // piece index of (n, group out_goff, oh, ow) in the output
   bool mvalid[PT];
-  const int cg_in = p.Cin / 8;
+  const int ohow = p.OH * p.OW;
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int m = m_block + (wave * PT + pt) * 32 + (lane & 31);
     mvalid[pt] = m < p.M;
-    const int mm = mvalid[pt] ? m : 0;
-    const int ow = mm % p.OW;
-    const int t = mm / p.OW;
-    const int oh = t % p.OH;
-    const int n = t / p.OH;
-    ih0[pt] = oh * p.stride - p.pad_h;
-    iw0[pt] = ow * p.stride - p.pad_w;
-    // byte offset of (n, this lane's group of chunk 0, ih0, iw0); may be
-    // "negative" (wraps) for padded taps, which are masked in prefetch_pixels.
-    base[pt] = static_cast<unsigned>((((n * cg_in + (lane >> 5)) * p.H + ih0[pt]) * p.W +
-                                      iw0[pt]) * 16);
-    obase[pt] = static_cast<unsigned>((n * p.out_groups + p.out_goff) * (p.OH * p.OW) +
-                                      oh * p.OW + ow);
+    int n, pix, oh, ow;
+    divmod_small(mvalid[pt] ? m : 0, ohow, p.rcp_ohow, n, pix);
+    divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
+    const int iy = oh * p.stride - p.pad_h + p.ig.halo;
+    const int ix = ow * p.stride - p.pad_w + p.ig.halo;
+    base[pt] = mvalid[pt]
+                   ? static_cast<unsigned>((((n * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
+                                                p.ig.wp + ix) * 16)
+                   : 0x80000000u;  // beyond the descriptor's range: reads as zero
+    obase[pt] = static_cast<unsigned>(((n * p.og.groups + p.out_goff) * p.og.hp + oh +
+                                       p.og.halo) * p.og.wp + ow + p.og.halo);
   }
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
@@ -248,11 +257,16 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
 
-  ChunkWalk walk{0, 0, 0, 0, 0u};
+  ChunkWalk walk{0, 0, 0u, 0u};
   DV_LOAD_SLAB(0)
 #pragma unroll
   for (int d = 0; d < kPrefetch; ++d) {  // chunks 0 .. kPrefetch-1
-    prefetch_pixels<PT>(p, rsrc, walk, ih0, iw0, base, mvalid, xf[d]);
+    const unsigned soff = walk.off();
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      xf[d][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+    }
+    walk.advance(p);
   }
   DV_STORE_SLAB(0)
   __syncthreads();
@@ -263,24 +277,25 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   for (int s = 0; s < n_full; ++s) {
     const bool more = s + 1 < p.n_slabs;
     if (more) DV_LOAD_SLAB(s + 1)
-    conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk,
-                                   ih0, iw0, base, mvalid, xf, acc);
+    conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base,
+                                   xf, acc);
     if (more) DV_STORE_SLAB((s + 1) & 1)
     __syncthreads();
   }
   if (rem) {
     const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
     switch (rem) {
-      case 1: conv_slab<NB, PT, 1>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      case 2: conv_slab<NB, PT, 2>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      case 3: conv_slab<NB, PT, 3>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      case 4: conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      case 5: conv_slab<NB, PT, 5>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      case 6: conv_slab<NB, PT, 6>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
-      default: conv_slab<NB, PT, 7>(p, rsrc, wslab, walk, ih0, iw0, base, mvalid, xf, acc); break;
+      case 1: conv_slab<NB, PT, 1>(p, rsrc, wslab, walk, base, xf, acc); break;
+      case 2: conv_slab<NB, PT, 2>(p, rsrc, wslab, walk, base, xf, acc); break;
+      case 3: conv_slab<NB, PT, 3>(p, rsrc, wslab, walk, base, xf, acc); break;
+      case 4: conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc); break;
+      case 5: conv_slab<NB, PT, 5>(p, rsrc, wslab, walk, base, xf, acc); break;
+      case 6: conv_slab<NB, PT, 6>(p, rsrc, wslab, walk, base, xf, acc); break;
+      default: conv_slab<NB, PT, 7>(p, rsrc, wslab, walk, base, xf, acc); break;
     }
-    __syncthreads();
   }
+#undef DV_LOAD_SLAB
+#undef DV_STORE_SLAB
 
   // ---- epilogue: shift + ReLU, pair lanes l / l+32 into 16-byte pieces -------
   // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
@@ -290,35 +305,34 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   // stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
   const int cbase = n_tile * BN;
   const int hi = lane >> 5;
-  const unsigned ohow = static_cast<unsigned>(p.OH * p.OW);
-  uint4* outp = reinterpret_cast<uint4*>(p.out);
+  const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
+  uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    float shv[4][4];  // [q][j]: shift of cout nb*32 + 8q + 4*hi + j
+    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int co = cbase + nb * 32 + 8 * q + 4 * hi + j;
-        shv[q][j] = co < p.Cout ? p.shift[co] : 0.f;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int co = cbase + nb * 32 + 8 * q + 4 * hi;
+      const bool ok = co < p.Cout;  // Cout is a multiple of 8: all four or none
+      const float4 s4 = ok ? *reinterpret_cast<const float4*>(p.shift + co)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      shv[q][0] = float2_t{s4.x, s4.y};
+      shv[q][1] = float2_t{s4.z, s4.w};
+    }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const float16_t a = acc[nb][pt];
       unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        _Float16 h[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = a[4 * q + j] + shv[q][j];
-          if (p.relu) v = fmaxf(v, 0.f);
-          h[j] = static_cast<_Float16>(v);
+        for (int hq = 0; hq < 2; ++hq) {
+          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
+          half2_t h = __builtin_convertvector(v, half2_t);
+          if (p.relu) h = __builtin_elementwise_max(h, zero2);
+          pk[q][hq] = __builtin_bit_cast(unsigned, h);
         }
-        pk[q][0] = __builtin_bit_cast(unsigned short, h[0]) |
-                   (static_cast<unsigned>(__builtin_bit_cast(unsigned short, h[1])) << 16);
-        pk[q][1] = __builtin_bit_cast(unsigned short, h[2]) |
-                   (static_cast<unsigned>(__builtin_bit_cast(unsigned short, h[3])) << 16);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -327,11 +341,11 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
         const unsigned s1 = hi ? pk[2 * t][1] : pk[2 * t + 1][1];
         const unsigned r0 = __shfl_xor(s0, 32);
         const unsigned r1 = __shfl_xor(s1, 32);
-        const uint4 piece = hi ? make_uint4(r0, r1, pk[2 * t + 1][0], pk[2 * t + 1][1])
-                               : make_uint4(pk[2 * t][0], pk[2 * t][1], r0, r1);
+        const uint4_t piece = hi ? uint4_t{r0, r1, pk[2 * t + 1][0], pk[2 * t + 1][1]}
+                                 : uint4_t{pk[2 * t][0], pk[2 * t][1], r0, r1};
         const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
         if (mvalid[pt] && group * 8 < p.Cout) {
-          outp[obase[pt] + static_cast<unsigned>(group) * ohow] = piece;
+          outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
         }
       }
     }
@@ -343,9 +357,9 @@ constexpr size_t conv_lds_bytes() {
   return static_cast<size_t>(2) * kSlabChunks * NB * 32 * kChunk * 2;
 }
 
-// uint8 [N,H,W,C] -> fp16 C8 [N][2][H][W][8]: (x - 128) / 128, exact in fp16.
-__global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix,
-                                  int C, int hw) {
+// uint8 [N,H,W,C] -> fp16 C8 [N][2][hp][wp][8]: (x - 128) / 128, exact in fp16.
+__global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix, int C,
+                                  int H, int W, TensorGeom og) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n_pix) return;
   const uint8_t* px = in + i * C;
@@ -355,18 +369,22 @@ __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix
     v[c] = c < C ? static_cast<_Float16>((static_cast<float>(px[c]) - 128.0f) / 128.0f)
                  : static_cast<_Float16>(0.f);
   }
-  const size_t n = i / hw;
-  const size_t pix = i - n * hw;
+  const size_t n = i / (static_cast<size_t>(H) * W);
+  const int pix = static_cast<int>(i - n * (static_cast<size_t>(H) * W));
+  const int y = pix / W, x = pix - y * W;
   uint4* dst = reinterpret_cast<uint4*>(out);
-  dst[(n * 2 + 0) * hw + pix] = *reinterpret_cast<uint4*>(&v[0]);
-  dst[(n * 2 + 1) * hw + pix] = *reinterpret_cast<uint4*>(&v[8]);
+  const size_t plane = static_cast<size_t>(og.hp) * og.wp;
+  const size_t at = (n * 2) * plane + static_cast<size_t>(y + og.halo) * og.wp + x + og.halo;
+  dst[at] = *reinterpret_cast<uint4*>(&v[0]);
+  dst[at + plane] = *reinterpret_cast<uint4*>(&v[8]);
 }
 
 struct PoolArgs {
   const _Float16* in;
   _Float16* out;
-  int N, H, W, C, OH, OW;
-  int out_groups, out_goff;
+  TensorGeom ig, og;
+  int N, C, OH, OW;
+  int out_goff;
 };
 
 // MaxPooling2D(3, strides=2, 'valid'), C8 layout; one thread = one 16-byte piece.
@@ -382,42 +400,44 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
   const int g = t % cg;
   const int n = t / cg;
   const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
-                       (static_cast<size_t>(n) * cg + g) * p.H * p.W;
+                       (static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp * p.ig.wp;
   half8_t best;
 #pragma unroll
   for (int j = 0; j < 8; ++j) best[j] = static_cast<_Float16>(-65504.f);
   for (int dh = 0; dh < 3; ++dh)
     for (int dw = 0; dw < 3; ++dw) {
-      const half8_t v = src[(oh * 2 + dh) * p.W + ow * 2 + dw];
+      const half8_t v = src[(oh * 2 + dh + p.ig.halo) * p.ig.wp + ow * 2 + dw + p.ig.halo];
 #pragma unroll
       for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
     }
-  reinterpret_cast<half8_t*>(p.out)[(static_cast<size_t>(n) * p.out_groups + p.out_goff + g) *
-                                        p.OH * p.OW + oh * p.OW + ow] = best;
+  reinterpret_cast<half8_t*>(p.out)[((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) *
+                                         p.og.hp + oh + p.og.halo) * p.og.wp + ow + p.og.halo] =
+      best;
 }
 
 // AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.
 __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int cg = p.C / 8;
-  const size_t total = static_cast<size_t>(p.N) * cg * p.H * p.W;
+  const int H = p.ig.h, W = p.ig.w;
+  const size_t total = static_cast<size_t>(p.N) * cg * H * W;
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= total) return;
-  const int ow = i % p.W;
-  size_t t = i / p.W;
-  const int oh = t % p.H;
-  t /= p.H;
+  const int ow = i % W;
+  size_t t = i / W;
+  const int oh = t % H;
+  t /= H;
   const int g = t % cg;
   const int n = t / cg;
   const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
-                       (static_cast<size_t>(n) * cg + g) * p.H * p.W;
+                       (static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp * p.ig.wp;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int cnt = 0;
   for (int dh = -1; dh <= 1; ++dh)
     for (int dw = -1; dw <= 1; ++dw) {
       const int ih = oh + dh, iw = ow + dw;
-      if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
+      if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
       ++cnt;
-      const half8_t v = src[ih * p.W + iw];
+      const half8_t v = src[(ih + p.ig.halo) * p.ig.wp + iw + p.ig.halo];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
     }
@@ -425,24 +445,28 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
   const float inv = 1.0f / static_cast<float>(cnt);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
-  reinterpret_cast<half8_t*>(p.out)[(static_cast<size_t>(n) * p.out_groups + p.out_goff + g) *
-                                        p.H * p.W + oh * p.W + ow] = o;
+  reinterpret_cast<half8_t*>(p.out)[((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) *
+                                         p.og.hp + oh + p.og.halo) * p.og.wp + ow + p.og.halo] = o;
 }
 
 // GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
 __global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const float* w,
                                                    const float* b, float* probs,
-                                                   int P, int C, int K) {
+                                                   TensorGeom g, int K) {
   __shared__ float red[8][4];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
+  const int C = g.groups * 8;
+  const size_t plane = static_cast<size_t>(g.hp) * g.wp * 8;
   float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const _Float16* x = in + static_cast<size_t>(n) * P * C;  // C8: [C/8][P][8]
-  const float invP = 1.0f / static_cast<float>(P);
+  const _Float16* x = in + static_cast<size_t>(n) * g.groups * plane;
+  const float invP = 1.0f / static_cast<float>(g.h * g.w);
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    const _Float16* xc = x + static_cast<size_t>(c >> 3) * P * 8 + (c & 7);
-    for (int pp = 0; pp < P; ++pp) s += static_cast<float>(xc[pp * 8]);
+    const _Float16* xc = x + static_cast<size_t>(c >> 3) * plane + (c & 7);
+    for (int y = 0; y < g.h; ++y)
+      for (int xx = 0; xx < g.w; ++xx)
+        s += static_cast<float>(xc[((y + g.halo) * g.wp + xx + g.halo) * 8]);
     s *= invP;
     for (int k = 0; k < K; ++k) part[k] += s * w[static_cast<size_t>(c) * K + k];
   }
@@ -476,6 +500,13 @@ struct TensorRef {
 
 struct BufferDesc {
   int h, w, c;  // channels = full (concat) width
+  int halo = 0; // max padding any consumer needs (zero border kept in HBM)
+  TensorGeom geom() const {
+    return TensorGeom{h, w, halo, h + 2 * halo, w + 2 * halo, c / 8};
+  }
+  size_t bytes_per_example() const {
+    return static_cast<size_t>(h + 2 * halo) * (w + 2 * halo) * c * 2;
+  }
 };
 
 enum OpType { kOpConv, kOpMaxPool, kOpAvgPool };
@@ -518,7 +549,7 @@ struct dv_model {
 
   // ---- builder ------------------------------------------------------------
   int new_buffer(int h, int w, int c) {
-    buffers.push_back({h, w, c});
+    buffers.push_back({h, w, c, 0});
     return static_cast<int>(buffers.size()) - 1;
   }
   static int pick_nb(int cout) {
@@ -694,6 +725,11 @@ struct dv_model {
     feat_buf = x.buf;
     feat_p = x.h * x.w;
     feat_c = x.c;
+    for (const Op& op : ops) {  // zero halo wide enough for every consumer
+      int need = 0;
+      if (op.type == kOpConv) need = std::max(op.pad_h, op.pad_w);
+      buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
+    }
     layers.push_back({1, 1, feat_c, desc.num_classes, n_params});
     n_params += static_cast<int64_t>(feat_c) * desc.num_classes + desc.num_classes;
   }
@@ -730,27 +766,28 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       a.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
       a.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      const BufferDesc& ib = m->buffers[op.in_buf];
+      a.ig = ib.geom();
+      a.og = ob.geom();
       a.N = n;
-      a.H = op.ih;
-      a.W = op.iw;
       a.Cin = op.cin;
+      a.Cout = op.cout;
       a.OH = op.oh;
       a.OW = op.ow;
-      a.Cout = op.cout;
       a.KH = op.kh;
       a.KW = op.kw;
       a.stride = op.stride;
       a.pad_h = op.pad_h;
       a.pad_w = op.pad_w;
-      a.out_groups = ob.c / 8;
       a.out_goff = op.out_coff / 8;
-      a.chunk_stride = static_cast<unsigned>(2 * op.ih * op.iw * 16);
+      a.chunk_stride = static_cast<unsigned>(2 * a.ig.hp * a.ig.wp * 16);
       a.M = n * op.oh * op.ow;
-      a.cpt = op.cin / kChunk;
       a.n_chunks = op.n_chunks;
       a.n_slabs = op.n_steps;
       a.relu = 1;
-      a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin * 2);
+      a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * ib.bytes_per_example());
+      a.rcp_ow = 1.0f / static_cast<float>(op.ow);
+      a.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
       dv::ProfileScope prof(dv::kProfConv, stream);
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
@@ -762,13 +799,12 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       PoolArgs p{};
       p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
       p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      p.ig = m->buffers[op.in_buf].geom();
+      p.og = ob.geom();
       p.N = n;
-      p.H = op.ih;
-      p.W = op.iw;
       p.C = op.cin;
       p.OH = op.oh;
       p.OW = op.ow;
-      p.out_groups = ob.c / 8;
       p.out_goff = op.out_coff / 8;
       const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
       const dim3 grid(static_cast<unsigned>((total + 255) / 256));
@@ -813,8 +849,9 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->dbuf.resize(m->buffers.size());
   for (size_t i = 0; i < m->buffers.size(); ++i) {
     const BufferDesc& b = m->buffers[i];
-    const size_t bytes = static_cast<size_t>(desc->max_batch) * b.h * b.w * b.c * 2;
+    const size_t bytes = static_cast<size_t>(desc->max_batch) * b.bytes_per_example();
     if (int rc = m->dbuf[i].reserve(bytes)) return rc;
+    DV_HIP_CHECK(hipMemset(m->dbuf[i].ptr, 0, bytes));  // halos stay zero forever
   }
   if (int rc = m->d_w.reserve(m->packed_halfs * 2)) return rc;
   if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
@@ -925,14 +962,15 @@ int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_debug_tensor: bad index");
   }
   const BufferDesc& b = m->buffers[index];
-  if (h) *h = b.h;
-  if (w) *w = b.w;
+  // reports the PADDED plane size (interior + 2*halo on each axis)
+  if (h) *h = b.h + 2 * b.halo;
+  if (w) *w = b.w + 2 * b.halo;
   if (c) *c = b.c;
   if (host_out) {
     DV_HIP_CHECK(hipSetDevice(m->device));
     DV_HIP_CHECK(hipDeviceSynchronize());
     DV_HIP_CHECK(hipMemcpy(host_out, m->dbuf[index].ptr,
-                           static_cast<size_t>(n) * b.h * b.w * b.c * 2,
+                           static_cast<size_t>(n) * b.bytes_per_example(),
                            hipMemcpyDeviceToHost));
   }
   return DV_OK;
@@ -946,15 +984,18 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   DV_HIP_CHECK(hipSetDevice(m->device));
   const size_t img_bytes = static_cast<size_t>(m->desc.height) * m->desc.width * m->desc.channels;
-  for (int done = 0; done < n; done += m->desc.max_batch) {
-    const int nb = std::min(m->desc.max_batch, n - done);
+  // split evenly so that no launch is left with a sliver of a batch
+  const int n_parts = (n + m->desc.max_batch - 1) / m->desc.max_batch;
+  const int part = n_parts ? (n + n_parts - 1) / n_parts : 0;
+  for (int done = 0; done < n; done += part) {
+    const int nb = std::min(part, n - done);
     {
       const size_t n_pix = static_cast<size_t>(nb) * m->desc.height * m->desc.width;
       dv::ProfileScope prof(dv::kProfOther, stream);
       hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
                          dim3(256), 0, stream, images + done * img_bytes,
                          static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels,
-                         m->desc.height * m->desc.width);
+                         m->desc.height, m->desc.width, m->buffers[0].geom());
     }
     if (int rc = run_ops(m, nb, stream)) return rc;
     {
@@ -963,8 +1004,8 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
                          static_cast<const _Float16*>(m->dbuf[m->feat_buf].ptr),
                          static_cast<const float*>(m->d_dense_w.ptr),
                          static_cast<const float*>(m->d_dense_b.ptr),
-                         probs + static_cast<size_t>(done) * m->desc.num_classes, m->feat_p,
-                         m->feat_c, m->desc.num_classes);
+                         probs + static_cast<size_t>(done) * m->desc.num_classes,
+                         m->buffers[m->feat_buf].geom(), m->desc.num_classes);
     }
     DV_HIP_CHECK(hipGetLastError());
   }

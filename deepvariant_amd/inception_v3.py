@@ -108,8 +108,9 @@ class InceptionV3(torch.nn.Module):
     raw = np.zeros((n, c.value // 8, h.value, w.value, 8), np.float16)
     _lib.check(l.dv_model_debug_tensor(self._handle, index, n, raw.ctypes.data,
                                        C.byref(h), C.byref(w), C.byref(c)))
-    return np.ascontiguousarray(raw.transpose(0, 2, 3, 1, 4)).reshape(
+    out = np.ascontiguousarray(raw.transpose(0, 2, 3, 1, 4)).reshape(
         n, h.value, w.value, c.value)
+    return out  # padded plane: interior is out[:, halo:-halo, halo:-halo]
 
   def __del__(self):
     try:

@@ -63,6 +63,7 @@ def test_first_layers_match_activation_by_activation():
   with torch.no_grad():
     want = ref.stem[0](want_pre.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
   got = model.debug_tensor(1, 2).astype(np.float32)
+  # buffer 1 feeds a 'valid' conv: no halo, so the padded plane is the tensor
   assert got.shape == want.shape == (2, 49, 110, 32)
   np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
 
