@@ -37,7 +37,7 @@ def parse_args():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--batch', type=int, default=1950,
+  ap.add_argument('--batch', type=int, default=1900,
                   help='candidates per step per GPU')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -182,7 +182,7 @@ def main():
             'parallelism': 'interval shards x%d, all-gather of probs' % world,
         },
         'roofline': {
-            'kernel': 'conv_igemm_kernel<NB> (all 94 conv layers)',
+            'kernel': 'conv_mfma_kernel<NB,PT> (all 94 conv layers)',
             'bound': 'mfma',
             'achieved': conv_tflops,
             'peak': MFMA_F16_PEAK_TFLOPS,

@@ -1,0 +1,54 @@
+"""Multi-GPU plumbing: one process per GPU, shards by genomic interval, one
+final all-gather of the call outputs (RCCL over xGMI on MI355X; `gloo` in the
+CPU tests).
+
+The reference's only real parallelism is the same sharding rule
+(`deepvariant/make_examples_core.py:879-888`: region i belongs to task
+`i % num_shards`), realised there as N independent processes plus files
+(`scripts/run_deepvariant.py:457-462`).  Here rank r of an N-GPU node takes the
+regions of task r, encodes and classifies them on its own GPU with no
+inter-GPU traffic, and the per-candidate results (3 probabilities + a
+candidate id, ~20 bytes) are exchanged once.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def regions_for_rank(regions: Sequence, rank: int, world_size: int) -> List:
+  """make_examples_core.py:879-888: `i % num_shards == task_id`."""
+  return [r for i, r in enumerate(regions) if i % world_size == rank]
+
+
+def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+  """All ranks receive every rank's (probabilities [n_i, 3], ids [n_i]).
+
+  Counts differ per rank, so they are exchanged first and the payload is padded
+  to the maximum; two collectives in total, no reduction.
+  """
+  world = dist.get_world_size(group)
+  n = torch.tensor([probs.shape[0]], dtype=torch.int64, device=probs.device)
+  counts = torch.zeros(world, dtype=torch.int64, device=probs.device)
+  dist.all_gather_into_tensor(counts, n, group=group)
+  max_n = int(counts.max().item())
+  k = probs.shape[1]
+  send = torch.zeros((max_n, k + 2), dtype=torch.float32, device=probs.device)
+  send[:probs.shape[0], :k] = probs
+  # int64 ids travel as two fp32-exact 24-bit halves (ids < 2^48)
+  send[:probs.shape[0], k] = (ids & 0xFFFFFF).to(torch.float32)
+  send[:probs.shape[0], k + 1] = (ids >> 24).to(torch.float32)
+  recv = torch.empty((world * max_n, k + 2), dtype=torch.float32,
+                     device=probs.device)
+  dist.all_gather_into_tensor(recv, send, group=group)
+  recv = recv.view(world, max_n, k + 2)
+  out_p, out_i = [], []
+  for r in range(world):
+    c = int(counts[r].item())
+    out_p.append(recv[r, :c, :k])
+    out_i.append(recv[r, :c, k].to(torch.int64) +
+                 (recv[r, :c, k + 1].to(torch.int64) << 24))
+  return torch.cat(out_p), torch.cat(out_i)

@@ -1,0 +1,376 @@
+"""Drop-in for `deepvariant.python.make_examples_native` on MI355X.
+
+Same class / method names, argument meaning, return values and error behaviour
+as the reference's pybind module
+(`deepvariant/python/make_examples_native_pybind.cc:56-108`), i.e. the
+`ExamplesGenerator` that `RegionProcessor.writes_examples_in_region` drives
+(`deepvariant/make_examples_core.py:1893-2013`).  What the reference does per
+candidate on one CPU thread (`deepvariant/make_examples_native.cc:632-736`) is
+done here for a whole region in ONE `dv_encode_batch` launch: every
+(candidate x alt-allele combination x sample) is one item of a packed batch.
+
+Written in Python because the reference's callers hand over Python protobuf
+objects and protoc is unavailable here; everything below the packed batch is
+the C ABI (include/dvhip.h).  Not reproduced (explicit errors, never silent):
+alt-aligned pileups (`diff_channels` / `base_channels` / `rows` / `single_row`
+need the FastPassAligner), `trim_reads_for_pileup`,
+`stream_examples`.
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import genomics_io
+from deepvariant_amd import packing
+from deepvariant_amd import protowire as pw
+from deepvariant_amd import tfrecord
+from deepvariant_amd.pileup_image_native import PileupImageEncoderNative, _Encoder
+
+DEEP_VARIANT_VERSION = '1.10.0'  # deepvariant/dv_vcf_constants.py:36
+
+# EncodedVariantType, deepvariant/make_examples_native.h
+K_UNKNOWN, K_SNP, K_INDEL = 0, 1, 2
+
+
+@dataclasses.dataclass
+class VariantLabel:
+  """make_examples_native.h VariantLabel (is_confident, variant, genotype, is_denovo)."""
+  is_confident: bool
+  variant: T.Variant
+  genotype: List[int]
+  is_denovo: bool = False
+
+  def label_for_alt_alleles(self, alt_indices_set) -> int:
+    # VariantLabel::LabelForAltAlleles, make_examples_native.cc:814-828
+    v = sum(1 for g in self.genotype if g != 0 and (g - 1) in alt_indices_set)
+    if not 0 <= v <= 2:
+      raise ValueError('label_value out of range')
+    return v
+
+
+def encoded_variant_type(variant) -> int:
+  """EncodedVariantType, make_examples_native.cc:301-321."""
+  alts = list(variant.alternate_bases)
+  if len(variant.reference_bases) == 1 and len(alts) >= 1:
+    if all(len(a) == 1 for a in alts):
+      return K_SNP
+  if len(variant.reference_bases) > 1:
+    return K_INDEL
+  if any(len(a) > 1 for a in alts):
+    return K_INDEL
+  return K_UNKNOWN
+
+
+def alt_allele_combinations(candidate, multi_allelic_mode: int
+                            ) -> List[List[str]]:
+  """AltAlleleCombinations[FromIndices], make_examples_native.cc:191-267."""
+  variant = candidate.variant
+  alts = list(variant.alternate_bases)
+  explicit = list(getattr(candidate, 'make_examples_alt_allele_indices', []))
+  if multi_allelic_mode == T.MultiAllelicMode.UNSPECIFIED:
+    raise ValueError('multi_allelic_mode cannot be UNSPECIFIED')
+  if explicit:
+    out = []
+    for idx in explicit:
+      indices = list(idx.indices)
+      if multi_allelic_mode == T.MultiAllelicMode.NO_HET_ALT_IMAGES:
+        if len(indices) == 1:
+          out.append([alts[indices[0]]])
+      else:
+        out.append([alts[i] for i in indices])
+    return out
+  if multi_allelic_mode == T.MultiAllelicMode.NO_HET_ALT_IMAGES:
+    return [[a] for a in alts]
+  if multi_allelic_mode != T.MultiAllelicMode.ADD_HET_ALT_IMAGES:
+    raise ValueError('Unknown value is specified for PileupImageOptions')
+  alleles = [variant.reference_bases] + alts
+  out = []
+  for i in range(len(alleles)):
+    for j in range(i + 1, len(alleles)):
+      combo = []
+      if i > 0:  # the ref allele is not used in combinations
+        combo.append(alleles[i])
+      combo.append(alleles[j])
+      out.append(combo)
+  return out
+
+
+def encode_alt_alleles(variant, alt_combination) -> Tuple[bytes, set]:
+  """EncodeAltAlleles, make_examples_native.cc:350-374."""
+  index_of = {}
+  for i, alt in enumerate(variant.alternate_bases):
+    index_of[alt] = i  # later duplicates overwrite, like the flat_hash_map
+  indices = [index_of.get(a, 0) for a in alt_combination]
+  return pw.encode_alt_allele_indices(indices), set(indices)
+
+
+def get_reference_bases_for_pileup(ref_reader, variant, width: int) -> str:
+  """GetReferenceBasesForPileup, make_examples_native.cc:514-538: N-padded."""
+  half = (width - 1) // 2
+  n_bases = ref_reader.n_bases(variant.reference_name)
+  start = variant.start - half
+  end = start + width
+  bases = ref_reader.get_bases(variant.reference_name, max(0, start),
+                               min(n_bases, end))
+  if start < 0:
+    bases = 'N' * (-start) + bases
+  if end > n_bases:
+    bases = bases + 'N' * (end - n_bases)
+  return bases
+
+
+def calculate_pileup_image_height(options) -> int:
+  """CalculatePileupImageHeight, pileup_image_native.cc:220-240."""
+  total = 0
+  for so in options.sample_options:
+    mode = so.alt_aligned_pileup or options.pic_options.alt_aligned_pileup
+    mult = 3 if mode == 'rows' else 2 if mode == 'single_row' else 1
+    total += so.pileup_height * mult
+  return total
+
+
+class ExamplesGenerator:
+  """`ExamplesGenerator(options: MakeExamplesOptions, example_filenames:
+  dict[role, path], test_mode=False)` -- make_examples_native.h:154-278."""
+
+  def __init__(self, options, example_filenames: Dict[str, str],
+               test_mode: bool = False, device: int = 0, ref_reader=None):
+    self._options = options
+    pic = options.pic_options
+    if pic.alt_aligned_pileup not in ('', 'none'):
+      raise NotImplementedError(
+          "alt_aligned_pileup=%r needs the FastPassAligner (not built yet)" %
+          pic.alt_aligned_pileup)
+    if getattr(options, 'trim_reads_for_pileup', False):
+      raise NotImplementedError('trim_reads_for_pileup is not supported yet')
+    if getattr(options, 'stream_examples', False):
+      raise NotImplementedError('stream_examples is not supported yet')
+    self._encoder_api = PileupImageEncoderNative(pic, device=device)
+    self._chan_enums = packing.channel_enums(pic)
+    self._half_width = (pic.width - 1) // 2
+    self._samples = {so.role: so for so in options.sample_options}
+    for so in options.sample_options:
+      if so.alt_aligned_pileup not in ('', 'none'):
+        raise NotImplementedError('per-sample alt_aligned_pileup')
+      if so.keep_only_window_spanning_reads:
+        raise NotImplementedError('keep_only_window_spanning_reads')
+      if so.use_non_uniform_downsampling:
+        raise NotImplementedError('use_non_uniform_downsampling')
+    self._height = calculate_pileup_image_height(options)
+    self._labels: List[Optional[VariantLabel]] = []
+    self._writers: Dict[str, tfrecord.Writer] = {}
+    self._ref = ref_reader
+    self._device_encoder: Optional[_Encoder] = None
+    self._device = device
+    if test_mode:
+      return
+    if self._ref is None:
+      # keep_true_case=false -> upper case (make_examples_native.cc:126-132)
+      self._ref = genomics_io.FastaReader(options.reference_filename)
+    for role, path in example_filenames.items():
+      self._writers[role] = tfrecord.Writer(path)
+
+  # ---------------------------------------------------------------- pybind API
+  def append_label(self, label: VariantLabel):
+    self._labels.append(label)
+
+  def signal_shard_finished(self):
+    for w in self._writers.values():
+      w.close()
+    self._writers = {}
+
+  def write_examples_in_region(self, candidates: Sequence,
+                               reads_per_sample: Sequence[Sequence],
+                               sample_order: Sequence[int], role: str,
+                               mean_coverage_per_sample: Sequence[float]
+                               ) -> Tuple[Dict[str, int], List[int]]:
+    """-> (stats, image_shape); make_examples_native.cc:742-793."""
+    if self._labels and len(self._labels) != len(candidates):
+      raise ValueError('labels_.size() != candidates.size()')  # CHECK, :751
+    if role not in self._samples:
+      raise ValueError('Role %s not found.' % role)
+    if role not in self._writers:
+      raise ValueError('Role %s does not have a writer.' % role)
+    stats: Dict[str, int] = {}
+    examples, image_shape = self.encode_region(
+        candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
+        stats)
+    writer = self._writers[role]
+    for ex in examples:
+      writer.write(ex)
+    self._labels = []
+    return stats, image_shape
+
+  # --------------------------------------------------------------- internals
+  def encode_region(self, candidates, reads_per_sample, sample_order,
+                    mean_coverage_per_sample, stats) -> Tuple[List[bytes], List[int]]:
+    """All examples of one region: one packed batch, one kernel launch."""
+    pic = self._options.pic_options
+    width = pic.width
+    n_chan_total = len(pic.channels)  # image_shape[2], make_examples_native.cc:399
+    c_enc = len(self._chan_enums)
+    image_shape = [self._height, width, n_chan_total]
+    row_bytes = width * n_chan_total
+    example_bytes = self._height * row_bytes
+
+    # One ReadTable per sample; the encoder batch concatenates them.
+    tables = [packing.ReadTable.from_reads(reads,
+                                           need_aux=self._encoder_api._need_aux)
+              for reads in reads_per_sample]
+    merged, sample_base = _concat_tables(tables)
+    batch = packing.PackedBatch(table=merged, width=width)
+    plan = []  # (candidate index, alt_combination)
+    for ci, cand in enumerate(candidates):
+      variant = cand.variant
+      ref_bases = get_reference_bases_for_pileup(self._ref, variant, width)
+      if not ref_bases:
+        continue  # edge of the contig (make_examples_native.cc:650-653)
+      ref_idx = batch.add_ref_window(ref_bases)
+      q0 = variant.start - pic.read_overlap_buffer_bp
+      q1 = variant.end + pic.read_overlap_buffer_bp
+      vtype = encoded_variant_type(variant)
+      for combo in alt_allele_combinations(cand, pic.multi_allelic_mode):
+        out_off = len(plan) * example_bytes
+        for s in sample_order:
+          so = self._options.sample_options[s]
+          table = tables[s]
+          idx_local = table.query(q0, q1)
+          blank = list(so.channels_enum_to_blank)
+          if vtype in _types_to_blank(so):
+            blank = list(T.DeepVariantChannelEnum)
+          batch.add_item(
+              variant.start, variant.start - self._half_width, ref_idx,
+              idx_local + sample_base[s],
+              packing.support_codes(cand, combo, table, idx_local),
+              height=so.pileup_height, out_off=out_off,
+              blank_mask=packing.blank_mask_for(self._chan_enums, blank),
+              mean_coverage=float(mean_coverage_per_sample[s]),
+              groups=(packing.allele_groups(cand, table, idx_local)
+                      if pic.sort_by_alt_allele_support else None),
+              list_aux=self._encoder_api._list_aux(cand, combo, table, idx_local))
+          out_off += so.pileup_height * row_bytes
+        plan.append((ci, combo))
+    if not plan:
+      return [], image_shape
+    if self._device_encoder is None:
+      self._device_encoder = _Encoder(pic, width, self._device)
+    if n_chan_total < c_enc:
+      raise ValueError('num_channels smaller than the encoder channel list')
+    images, _ = self._device_encoder.encode(batch, n_chan_total)
+    examples = []
+    for k, (ci, combo) in enumerate(plan):
+      label = self._labels[ci] if self._labels else None
+      image = images[k * example_bytes:(k + 1) * example_bytes]
+      examples.append(self._encode_example(
+          candidates[ci].variant, combo, image, image_shape, label, stats))
+    return examples, image_shape
+
+  def _encode_example(self, variant, alt_combination, image: np.ndarray,
+                      image_shape, label, stats) -> bytes:
+    """EncodeExample, make_examples_native.cc:388-474."""
+    alt_encoded, alt_set = encode_alt_alleles(variant, alt_combination)
+    vtype = encoded_variant_type(variant)
+    locus = '%s:%d-%d' % (variant.reference_name, variant.start + 1, variant.end)
+    src_variant = label.variant if label is not None else variant
+    features = {
+        'locus': [locus.encode()],
+        'variant/encoded': [pw.encode_variant(src_variant)],
+        'variant_type': [vtype],
+        'alt_allele_indices/encoded': [alt_encoded],
+        'image/encoded': [image.tobytes()],
+        'image/shape': list(image_shape),
+        'sequencing_type': [int(self._options.pic_options.sequencing_type)],
+    }
+    label_value = 0
+    if label is not None:
+      label_value = label.label_for_alt_alleles(alt_set)
+      features['label'] = [label_value]
+      if getattr(self._options, 'denovo_regions_filename', ''):
+        features['denovo_label'] = [int(label.is_denovo)]
+    _update_stats(vtype, label, label_value, stats)
+    return pw.encode_example(features)
+
+
+def _types_to_blank(so) -> set:
+  out = set()
+  for v in so.variant_types_to_blank:
+    if v == 1:  # SampleOptions.VARIANT_TYPE_SNP
+      out.add(K_SNP)
+    elif v == 2:  # VARIANT_TYPE_INDEL
+      out.add(K_INDEL)
+  return out
+
+
+def _update_stats(vtype, label, label_value, stats):
+  """UpdateStats, make_examples_native.cc:331-348."""
+  stats['n_examples'] = stats.get('n_examples', 0) + 1
+  key = 'n_indels' if vtype == K_INDEL else 'n_snps'
+  stats[key] = stats.get(key, 0) + 1
+  if label is not None:
+    for c in (0, 1, 2):
+      stats['n_class_%d' % c] = stats.get('n_class_%d' % c, 0) + int(label_value == c)
+    stats['n_non_denovo'] = stats.get('n_non_denovo', 0) + int(not label.is_denovo)
+    stats['n_denovo'] = stats.get('n_denovo', 0) + int(label.is_denovo)
+
+
+def _concat_tables(tables: List[packing.ReadTable]):
+  """Concatenates per-sample read tables (read indices shift by sample_base)."""
+  if len(tables) == 1:
+    return tables[0], [0]
+  base, n = [], 0
+  for t in tables:
+    base.append(n)
+    n += t.n_reads
+  cat = lambda name, dt: np.concatenate([getattr(t, name) for t in tables]).astype(dt)
+  seq_off = [np.zeros(1, np.uint32)]
+  cig_off = [np.zeros(1, np.uint32)]
+  so = co = 0
+  for t in tables:
+    seq_off.append(t.read_seq_off[1:] + so)
+    cig_off.append(t.read_cigar_off[1:] + co)
+    so += int(t.read_seq_off[-1])
+    co += int(t.read_cigar_off[-1])
+  # name ranks must stay comparable across samples: re-rank the union
+  keys = [k for t in tables for k in _rank_keys(t)]
+  uniq = {k: i for i, k in enumerate(sorted(set(keys)))}
+  ranks = np.array([uniq[k] for k in keys], np.uint32)
+  opt = lambda name: (np.concatenate([getattr(t, name) for t in tables])
+                      if all(getattr(t, name) is not None for t in tables) else None)
+  merged = packing.ReadTable(
+      n_reads=n, read_pos=cat('read_pos', np.int32), read_sort_pos=opt('read_sort_pos'),
+      read_seq_off=np.concatenate(seq_off).astype(np.uint32),
+      read_cigar_off=np.concatenate(cig_off).astype(np.uint32),
+      read_mapq=cat('read_mapq', np.uint8), read_flags=cat('read_flags', np.uint8),
+      read_frag_len=cat('read_frag_len', np.int32), read_hp=cat('read_hp', np.int32),
+      read_name_rank=ranks, read_aux=opt('read_aux'),
+      bases=cat('bases', np.uint8), quals=cat('quals', np.uint8),
+      mod_5mc=opt('mod_5mc'), mod_6ma=opt('mod_6ma'), cigar=cat('cigar', np.uint32),
+      keys=[k for t in tables for k in t.keys],
+      read_end=cat('read_end', np.int64))
+  return merged, base
+
+
+def _rank_keys(table: packing.ReadTable):
+  out = []
+  for k in table.keys:
+    name, num = k.rsplit('/', 1)
+    out.append((name.encode(), int(num)))
+  return out
+
+
+def write_example_info_json(examples_path: str, image_shape, channel_names):
+  """`<examples>.example_info.json` (make_examples_core.py:3755-3774)."""
+  info = {
+      'version': DEEP_VARIANT_VERSION,
+      'shape': list(image_shape),
+      'channels': [T.CHANNEL_NAME_TO_INFO_ENUM[c] for c in channel_names],
+  }
+  with open(examples_path + '.example_info.json', 'w') as f:
+    json.dump(info, f)
+  return info

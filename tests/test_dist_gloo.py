@@ -1,0 +1,55 @@
+"""N > 1 path on CPU: world_size-2 gloo (no GPU needed)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from deepvariant_amd import dist as dvd
+  regions = list(range(11))
+  mine = dvd.regions_for_rank(regions, rank, world)
+  # each rank "classifies" its regions: 2 candidates per region
+  ids = torch.tensor([r * 10 + k for r in mine for k in range(2)], dtype=torch.int64)
+  probs = torch.stack([torch.tensor([0.1, 0.2, 0.7]) * 0 + (i % 7) / 10.0
+                       for i in ids.tolist()]).float()
+  all_p, all_i = dvd.gather_call_outputs(probs, ids)
+  q.put((rank, mine, all_i.tolist(), all_p[:, 0].tolist()))
+  dist.destroy_process_group()
+
+
+def test_shards_and_all_gather_world2():
+  world = 2
+  port = _free_port()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = [q.get(timeout=120) for _ in range(world)]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  results.sort()
+  # the reference's round-robin rule
+  assert results[0][1] == [0, 2, 4, 6, 8, 10] and results[1][1] == [1, 3, 5, 7, 9]
+  # every rank holds every candidate exactly once, with the right payload
+  for _, _, ids, p0 in results:
+    assert sorted(ids) == sorted(r * 10 + k for r in range(11) for k in range(2))
+    for i, v in zip(ids, p0):
+      assert abs(v - (i % 7) / 10.0) < 1e-6
+  assert results[0][2] == results[1][2]
