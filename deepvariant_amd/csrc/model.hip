@@ -282,16 +282,35 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
     if (more) DV_STORE_SLAB((s + 1) & 1)
     __syncthreads();
   }
+  // Tail slab (n_chunks % 8 chunks): a rolled loop, one chunk per iteration,
+  // that always consumes prefetch slot 0 and rotates the slots.  (Unrolled
+  // per-count variants behind a switch made the register allocator clone the
+  // whole accumulator file: 2x AGPRs, half the occupancy.)
   if (rem) {
     const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
-    switch (rem) {
-      case 1: conv_slab<NB, PT, 1>(p, rsrc, wslab, walk, base, xf, acc); break;
-      case 2: conv_slab<NB, PT, 2>(p, rsrc, wslab, walk, base, xf, acc); break;
-      case 3: conv_slab<NB, PT, 3>(p, rsrc, wslab, walk, base, xf, acc); break;
-      case 4: conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc); break;
-      case 5: conv_slab<NB, PT, 5>(p, rsrc, wslab, walk, base, xf, acc); break;
-      case 6: conv_slab<NB, PT, 6>(p, rsrc, wslab, walk, base, xf, acc); break;
-      default: conv_slab<NB, PT, 7>(p, rsrc, wslab, walk, base, xf, acc); break;
+    for (int j = 0; j < rem; ++j) {
+      half8_t xh[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[0][pt]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const half8_t wf =
+            *reinterpret_cast<const half8_t*>(wslab + (j * BN + nb * 32) * kChunk);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xh[pt], acc[nb][pt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d + 1 < kPrefetch; ++d)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xf[d][pt] = xf[d + 1][pt];
+      const unsigned soff = walk.off();
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        xf[kPrefetch - 1][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+      }
+      walk.advance(p);
     }
   }
 #undef DV_LOAD_SLAB
