@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co = cbase + nb * 32 + 8 * q + 4 * hi;
-      const bool ok = co < p.Cout;  // Cout is a multiple of 8: all four or none
+      const bool ok = p.shift != nullptr && co < p.Cout;  // Cout % 8 == 0: all four or none
       const float4 s4 = ok ? *reinterpret_cast<const float4*>(p.shift + co)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
       shv[q][0] = float2_t{s4.x, s4.y};
@@ -404,6 +404,7 @@ struct PoolArgs {
   TensorGeom ig, og;
   int N, C, OH, OW;
   int out_goff;
+  const float* shift;  // avgpool only: per-channel shift + ReLU after the average, or NULL
 };
 
 // MaxPooling2D(3, strides=2, 'valid'), C8 layout; one thread = one 16-byte piece.
@@ -462,8 +463,15 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
     }
   half8_t o;
   const float inv = 1.0f / static_cast<float>(cnt);
+  if (p.shift != nullptr) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
+    for (int j = 0; j < 8; ++j) {
+      o[j] = static_cast<_Float16>(fmaxf(s[j] * inv + p.shift[g * 8 + j], 0.f));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
+  }
   reinterpret_cast<half8_t*>(p.out)[((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) *
                                          p.og.hp + oh + p.og.halo) * p.og.wp + ow + p.og.halo] = o;
 }
@@ -544,6 +552,8 @@ struct Op {
   size_t w_off = 0;      // halfs into packed weights
   size_t shift_off = 0;  // floats into shifts
   size_t tbl_off = 0;    // int2 entries into the chunk tables
+  bool raw = false;              // conv: skip shift + ReLU (applied by a later pool)
+  bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
 };
 
 struct LayerInfo {
@@ -636,6 +646,19 @@ struct dv_model {
     t.c = buffers[buf].c;
     return t;
   }
+  // AveragePooling2D(3,1,'same') -> conv 1x1 -> BN -> ReLU, evaluated as
+  // conv 1x1 (raw) -> average pool -> +shift -> ReLU.  A 1x1 convolution is a
+  // per-pixel linear map, so it commutes with the (per-pixel-normalised)
+  // average; pooling the Cout (32..192) projected channels instead of the Cin
+  // (192..2048) input channels moves 4-10x fewer bytes.
+  void pooled_projection(TensorRef x, int cout, int dst_buf, int dst_coff) {
+    TensorRef raw = conv(x, cout, 1, 1);
+    ops.back().raw = true;                   // no shift, no ReLU in the conv epilogue
+    const size_t shift_off = ops.back().shift_off;
+    pool(kOpAvgPool, raw, dst_buf, dst_coff);
+    ops.back().shift_off = shift_off;        // applied after the pool
+    ops.back().pool_shift_relu = true;
+  }
   TensorRef pool(OpType type, TensorRef x, int dst_buf = -1, int dst_coff = 0) {
     Op op;
     op.type = type;
@@ -686,8 +709,7 @@ struct dv_model {
       TensorRef b3 = conv(x, 64, 1, 1);
       b3 = conv(b3, 96, 3, 3);
       conv(b3, 96, 3, 3, 1, true, out, 128);
-      TensorRef bp = pool(kOpAvgPool, x);
-      conv(bp, pool_ch, 1, 1, 1, true, out, 224);
+      pooled_projection(x, pool_ch, out, 224);
       x = full(out);
     }
     {  // mixed3
@@ -711,8 +733,7 @@ struct dv_model {
       d = conv(d, c7, 1, 7);
       d = conv(d, c7, 7, 1);
       conv(d, 192, 1, 7, 1, true, out, 384);
-      TensorRef bp = pool(kOpAvgPool, x);
-      conv(bp, 192, 1, 1, 1, true, out, 576);
+      pooled_projection(x, 192, out, 576);
       x = full(out);
     }
     {  // mixed8
@@ -737,8 +758,7 @@ struct dv_model {
       d = conv(d, 384, 3, 3);
       conv(d, 384, 1, 3, 1, true, out, 1088);
       conv(d, 384, 3, 1, 1, true, out, 1472);
-      TensorRef bp = pool(kOpAvgPool, x);
-      conv(bp, 192, 1, 1, 1, true, out, 1856);
+      pooled_projection(x, 192, out, 1856);
       x = full(out);
     }
     feat_buf = x.buf;
@@ -803,7 +823,8 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       a.M = n * op.oh * op.ow;
       a.n_chunks = op.n_chunks;
       a.n_slabs = op.n_steps;
-      a.relu = 1;
+      a.relu = op.raw ? 0 : 1;
+      if (op.raw) a.shift = nullptr;
       a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * ib.bytes_per_example());
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
       a.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
@@ -825,6 +846,9 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
       p.OH = op.oh;
       p.OW = op.ow;
       p.out_goff = op.out_coff / 8;
+      p.shift = op.pool_shift_relu
+                    ? static_cast<const float*>(m->d_shift.ptr) + op.shift_off
+                    : nullptr;
       const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
       const dim3 grid(static_cast<unsigned>((total + 255) / 256));
       dv::ProfileScope prof(dv::kProfOther, stream);
