@@ -76,6 +76,14 @@ struct ConvArgs {
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
 };
 
+// Examples per stem pass.  Measured on MI355X (round 1): sub-batching the stem to
+// keep its hand-offs in the 256 MB Infinity Cache (64/128/256) LOSES 5-19 % at
+// 2 K examples per launch -- the stem is not HBM-bound and the extra launches
+// cost ~5 us each -- so it is off by default; DV_STEM_SB enables it for tuning.
+static int stem_sub_batch() {
+  static const int v = getenv("DV_STEM_SB") ? std::max(1, atoi(getenv("DV_STEM_SB"))) : (1 << 30);
+  return v;
+}
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
 constexpr int kPrefetch = 4;     // pixel-operand prefetch depth, in chunks
 
@@ -571,6 +579,7 @@ struct dv_model {
   std::vector<LayerInfo> layers;  // convs then dense
   int64_t n_params = 0;
   int feat_buf = -1, feat_p = 0, feat_c = 0;
+  int stem_ops_end = 0, stem_out_buf = -1;
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
@@ -701,6 +710,13 @@ struct dv_model {
     x = conv(x, 80, 1, 1, 1, false);
     x = conv(x, 192, 3, 3, 1, false);
     x = pool(kOpMaxPool, x);
+    // Everything up to here is the "stem": big feature maps (0.2-0.7 MB per
+    // example each).  It runs in sub-batches of stem_sub_batch() examples over
+    // small, reused buffers so that every producer->consumer hand-off stays in
+    // the 256 MB Infinity Cache instead of streaming through HBM; only the
+    // 96 KB/example stem output is written at full-batch width.
+    stem_ops_end = static_cast<int>(ops.size());
+    stem_out_buf = x.buf;
     for (int pool_ch : {32, 64, 64}) {  // mixed0..2
       const int out = new_buffer(x.h, x.w, 64 + 64 + 96 + pool_ch);
       conv(x, 64, 1, 1, 1, true, out, 0);
@@ -796,15 +812,22 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
   }
 }
 
-int run_ops(dv_model* m, int n, hipStream_t stream) {
-  for (const Op& op : m->ops) {
+// Runs ops [first, last) on `n` examples.  `out_example_off` shifts the output
+// pointer of ops that write `shifted_buf` (the stem's full-batch output).
+int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
+            int shifted_buf = -1, int out_example_off = 0) {
+  for (int oi = first; oi < last; ++oi) {
+    const Op& op = m->ops[oi];
     const BufferDesc& ob = m->buffers[op.out_buf];
+    const size_t out_shift_halfs =
+        op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
+                                  : 0;
     if (op.type == kOpConv) {
       ConvArgs a{};
       a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
       a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       a.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
-      a.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      a.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
       const BufferDesc& ib = m->buffers[op.in_buf];
       a.ig = ib.geom();
       a.og = ob.geom();
@@ -838,7 +861,7 @@ int run_ops(dv_model* m, int n, hipStream_t stream) {
     } else {
       PoolArgs p{};
       p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
-      p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr);
+      p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
       p.ig = m->buffers[op.in_buf].geom();
       p.og = ob.geom();
       p.N = n;
@@ -892,7 +915,10 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->dbuf.resize(m->buffers.size());
   for (size_t i = 0; i < m->buffers.size(); ++i) {
     const BufferDesc& b = m->buffers[i];
-    const size_t bytes = static_cast<size_t>(desc->max_batch) * b.bytes_per_example();
+    const bool stem_buf = static_cast<int>(i) < m->stem_out_buf;
+    const size_t bytes = static_cast<size_t>(stem_buf ? std::min(desc->max_batch, stem_sub_batch())
+                                                      : desc->max_batch) *
+                         b.bytes_per_example();
     if (int rc = m->dbuf[i].reserve(bytes)) return rc;
     DV_HIP_CHECK(hipMemset(m->dbuf[i].ptr, 0, bytes));  // halos stay zero forever
   }
@@ -1032,15 +1058,21 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   const int part = n_parts ? (n + n_parts - 1) / n_parts : 0;
   for (int done = 0; done < n; done += part) {
     const int nb = std::min(part, n - done);
-    {
-      const size_t n_pix = static_cast<size_t>(nb) * m->desc.height * m->desc.width;
-      dv::ProfileScope prof(dv::kProfOther, stream);
-      hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
-                         dim3(256), 0, stream, images + done * img_bytes,
-                         static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels,
-                         m->desc.height, m->desc.width, m->buffers[0].geom());
+    for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
+      const int sb = std::min(stem_sub_batch(), nb - sb0);
+      {
+        const size_t n_pix = static_cast<size_t>(sb) * m->desc.height * m->desc.width;
+        dv::ProfileScope prof(dv::kProfOther, stream);
+        hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
+                           dim3(256), 0, stream, images + (done + sb0) * img_bytes,
+                           static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels,
+                           m->desc.height, m->desc.width, m->buffers[0].geom());
+      }
+      if (int rc = run_ops(m, 0, m->stem_ops_end, sb, stream, m->stem_out_buf, sb0)) return rc;
     }
-    if (int rc = run_ops(m, nb, stream)) return rc;
+    if (int rc = run_ops(m, m->stem_ops_end, static_cast<int>(m->ops.size()), nb, stream)) {
+      return rc;
+    }
     {
       dv::ProfileScope prof(dv::kProfOther, stream);
       hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, stream,
