@@ -58,7 +58,7 @@ struct TensorGeom {
 
 struct ConvArgs {
   const _Float16* in;
-  const _Float16* w;      // packed [cout_tile][slab][8 chunks][NB*32][16]
+  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
   const float* shift;     // [Cout] folded BN shift
   _Float16* out;
   TensorGeom ig, og;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
   half8_t wf[2][NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    wf[0][nb] = *reinterpret_cast<const half8_t*>(wslab + (nb * 32) * kChunk);
+    wf[0][nb] = *reinterpret_cast<const half8_t*>(wslab + (nb * 32) * 8);
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         wf[(j + 1) & 1][nb] = *reinterpret_cast<const half8_t*>(
-            wslab + ((j + 1) * BN + nb * 32) * kChunk);
+            wslab + (j + 1) * BN * kChunk + (nb * 32) * 8);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -279,7 +279,10 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   DV_STORE_SLAB(0)
   __syncthreads();
 
-  const int frag_off = (lane & 31) * kChunk + (lane >> 5) * 8;  // halfs
+  // LDS image of a chunk: [k-group g = lane>>5][cout][8 halfs] -> each half-wave
+  // reads 512 contiguous bytes: conflict-free for ds_read_b128 (a [cout][16]
+  // image is 2-way conflicted: measured SQ_LDS_BANK_CONFLICT ~ LDS active).
+  const int frag_off = (lane >> 5) * (BN * 8) + (lane & 31) * 8;  // halfs
   const int n_full = p.n_chunks / kSlabChunks;
   const int rem = p.n_chunks - n_full * kSlabChunks;
   for (int s = 0; s < n_full; ++s) {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const half8_t wf =
-            *reinterpret_cast<const half8_t*>(wslab + (j * BN + nb * 32) * kChunk);
+            *reinterpret_cast<const half8_t*>(wslab + j * BN * kChunk + (nb * 32) * 8);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xh[pt], acc[nb][pt], 0, 0, 0);
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
   // A C8 piece (8 couts of one pixel) is split over lanes l and l+32: for each
   // pair of groups (q = 2t, 2t+1) the low half-wave completes group 2t and the
-  // high half-wave group 2t+1 after one cross-half exchange, then every lane
-  // stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
+  // high half-wave group 2t+1 after one v_permlane32_swap per dword, then every
+  // lane stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
   const int cbase = n_tile * BN;
   const int hi = lane >> 5;
   const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
@@ -363,13 +366,12 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        // low half-wave completes group 2t (sends its half of 2t+1), high 2t+1
-        const unsigned s0 = hi ? pk[2 * t][0] : pk[2 * t + 1][0];
-        const unsigned s1 = hi ? pk[2 * t][1] : pk[2 * t + 1][1];
-        const unsigned r0 = __shfl_xor(s0, 32);
-        const unsigned r1 = __shfl_xor(s1, 32);
-        const uint4_t piece = hi ? uint4_t{r0, r1, pk[2 * t + 1][0], pk[2 * t + 1][1]}
-                                 : uint4_t{pk[2 * t][0], pk[2 * t][1], r0, r1};
+        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
+        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
+        // group 2t in the low half-wave and of group 2t+1 in the high one.
+        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
         const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
         if (mvalid[pt] && group * 8 < p.Cout) {
           outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
@@ -999,14 +1001,16 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         for (int r = 0; r < bn; ++r) {
           const int co = t * bn + r;
           if (co >= op.cout) continue;
-          _Float16* dst = packed.data() + op.w_off +
-                          (((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn + r) *
-                              kChunk;
+          // chunk image [k-group g][cout r][8]: matches conv_mfma_kernel's frag_off
+          _Float16* chunk = packed.data() + op.w_off +
+                            ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn *
+                                kChunk;
           for (int jj = 0; jj < kChunk; ++jj) {
             const int ci = cc * kChunk + jj;
             if (ci >= l.cin) continue;  // padded input channels
             const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
-            dst[jj] = static_cast<_Float16>(v * inv[co]);
+            chunk[(static_cast<size_t>(jj / 8) * bn + r) * 8 + (jj % 8)] =
+                static_cast<_Float16>(v * inv[co]);
           }
         }
       }
