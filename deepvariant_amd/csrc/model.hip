@@ -194,7 +194,7 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
 template <int NB, int PT>
-__global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
@@ -293,35 +293,17 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
     if (more) DV_STORE_SLAB((s + 1) & 1)
     __syncthreads();
   }
-  // Tail slab (n_chunks % 8 chunks): a rolled loop, one chunk per iteration,
-  // that always consumes prefetch slot 0 and rotates the slots.  (Unrolled
-  // per-count variants behind a switch made the register allocator clone the
-  // whole accumulator file: 2x AGPRs, half the occupancy.)
+  // Tail slab (n_chunks % 8 chunks), in straight-line groups of 4: K is padded
+  // to a multiple of 4 chunks with zero weights (the slab image is zero there),
+  // so no chunk count ever needs a branch or a register rotation inside the
+  // load pipeline.  (A rolled one-chunk loop had to rotate the prefetch slots and
+  // drained vmcnt(0) every chunk; per-count unrolled variants behind a switch
+  // made the register allocator clone the accumulators.)
   if (rem) {
     const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
-    for (int j = 0; j < rem; ++j) {
-      half8_t xh[PT];
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[0][pt]);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const half8_t wf =
-            *reinterpret_cast<const half8_t*>(wslab + j * BN * kChunk + (nb * 32) * 8);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xh[pt], acc[nb][pt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int d = 0; d + 1 < kPrefetch; ++d)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) xf[d][pt] = xf[d + 1][pt];
-      const unsigned soff = walk.off();
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        xf[kPrefetch - 1][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
-      }
-      walk.advance(p);
+    conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
+    if (rem > 4) {
+      conv_slab<NB, PT, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
     }
   }
 #undef DV_LOAD_SLAB
@@ -340,15 +322,23 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 6 ? 1 : 2)) void conv_mfm
   const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
+    // Shifts come through the SCALAR cache (constant address space, wave-uniform
+    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
     float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int co = cbase + nb * 32 + 8 * q + 4 * hi;
-      const bool ok = p.shift != nullptr && co < p.Cout;  // Cout % 8 == 0: all four or none
-      const float4 s4 = ok ? *reinterpret_cast<const float4*>(p.shift + co)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-      shv[q][0] = float2_t{s4.x, s4.y};
-      shv[q][1] = float2_t{s4.z, s4.w};
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+      if (p.shift != nullptr) {  // uniform; the shift array is padded past Cout
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
+            p.shift + (cbase + nb * 32 + 8 * q)));
+        const f4_t l4 = sp[0], u4 = sp[1];
+        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
+      }
+      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
+      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -635,7 +625,7 @@ struct dv_model {
     op.w_off = packed_halfs;
     packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks * (op.nb * 32) * kChunk;
     op.shift_off = shift_floats;
-    shift_floats += cout;
+    shift_floats += cout + 128;  // padded: the epilogue reads whole 32-cout tiles
     op.tbl_off = tbl_entries;
     tbl_entries += op.n_chunks;
     op.layer = static_cast<int>(layers.size());
