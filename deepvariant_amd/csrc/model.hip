@@ -56,20 +56,35 @@ struct TensorGeom {
   int groups;   // channel groups of 8 (full concat width)
 };
 
+// One output branch of a (possibly grouped) convolution launch.
+struct ConvBranch {
+  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
+  const float* shift;     // [Cout (+pad)] folded BN shift, or NULL (raw output)
+  _Float16* out;
+  TensorGeom og;
+  int out_goff;           // first destination group of this branch
+  int Cout;
+  int relu;
+  int tile0;              // first cout tile of this branch in the launch
+};
+
+constexpr int kMaxBranches = 4;
+
 struct ConvArgs {
   const _Float16* in;
-  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
-  const float* shift;     // [Cout] folded BN shift
-  _Float16* out;
-  TensorGeom ig, og;
-  int N, Cin, Cout;
+  // Sibling convolutions that read the SAME input with the same geometry (the
+  // 1x1 heads of an Inception block) run as one launch: consecutive cout tiles
+  // of one pixel tile belong to different branches but re-read the same pixels,
+  // which then come from L2 instead of HBM once per branch.
+  ConvBranch br[kMaxBranches];
+  int n_branches;
+  TensorGeom ig;
+  int N, Cin;
   int OH, OW;
   int KH, KW, stride, pad_h, pad_w;
-  int out_goff;           // first destination group of this conv
   int M;                  // N*OH*OW
   int n_chunks;
   int n_slabs;            // ceil(n_chunks / kSlabChunks)
-  int relu;
   unsigned in_bytes;      // size of the input tensor (buffer-descriptor range)
   unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
   int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
@@ -211,8 +226,15 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   const int xq = nwg >> 3, xr = nwg & 7;
   const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-  const int n_tile = logical % p.n_tiles;
+  const int n_tile_all = logical % p.n_tiles;
   const int m_block = (logical / p.n_tiles) * (128 * PT);
+  // branch of this cout tile (wave-uniform selects, no memory indexing)
+  ConvBranch b = p.br[0];
+#pragma unroll
+  for (int i = 1; i < kMaxBranches; ++i) {
+    if (i < p.n_branches && n_tile_all >= p.br[i].tile0) b = p.br[i];
+  }
+  const int n_tile = n_tile_all - b.tile0;
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<_Float16*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -234,12 +256,12 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
                    ? static_cast<unsigned>((((n * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
                                                 p.ig.wp + ix) * 16)
                    : 0x80000000u;  // beyond the descriptor's range: reads as zero
-    obase[pt] = static_cast<unsigned>(((n * p.og.groups + p.out_goff) * p.og.hp + oh +
-                                       p.og.halo) * p.og.wp + ow + p.og.halo);
+    obase[pt] = static_cast<unsigned>(((n * b.og.groups + b.out_goff) * b.og.hp + oh +
+                                       b.og.halo) * b.og.wp + ow + b.og.halo);
   }
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
-  const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
+  const uint4* wsrc = reinterpret_cast<const uint4*>(b.w) +
                       static_cast<size_t>(n_tile) * p.n_slabs * SLAB_PIECES;
   uint4_t wreg[W_PER_THREAD];
 #define DV_LOAD_SLAB(s_)                                                                   \
@@ -317,8 +339,8 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   // lane stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
   const int cbase = n_tile * BN;
   const int hi = lane >> 5;
-  const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
-  uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
+  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
   const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -328,11 +350,11 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
-      if (p.shift != nullptr) {  // uniform; the shift array is padded past Cout
+      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
         typedef float f4_t __attribute__((ext_vector_type(4)));
         typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
         const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
-            p.shift + (cbase + nb * 32 + 8 * q)));
+            b.shift + (cbase + nb * 32 + 8 * q)));
         const f4_t l4 = sp[0], u4 = sp[1];
         lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
         up = make_float4(u4[0], u4[1], u4[2], u4[3]);
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
         for (int hq = 0; hq < 2; ++hq) {
           const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
           half2_t h = __builtin_convertvector(v, half2_t);
-          if (p.relu) h = __builtin_elementwise_max(h, zero2);
+          if (b.relu) h = __builtin_elementwise_max(h, zero2);
           pk[q][hq] = __builtin_bit_cast(unsigned, h);
         }
       }
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
         const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
         const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
         const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
-        if (mvalid[pt] && group * 8 < p.Cout) {
+        if (mvalid[pt] && group * 8 < b.Cout) {
           outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
         }
       }
@@ -553,6 +575,7 @@ struct Op {
   size_t shift_off = 0;  // floats into shifts
   size_t tbl_off = 0;    // int2 entries into the chunk tables
   bool raw = false;              // conv: skip shift + ReLU (applied by a later pool)
+  int group_followers = 0;       // conv: the next k ops are siblings sharing this launch
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
 };
 
@@ -621,9 +644,6 @@ struct dv_model {
     op.nb = pick_nb(cout);
     op.n_chunks = kh * kw * (x.c / kChunk);
     op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;  // weight slabs
-    const int n_tiles = (cout + op.nb * 32 - 1) / (op.nb * 32);
-    op.w_off = packed_halfs;
-    packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks * (op.nb * 32) * kChunk;
     op.shift_off = shift_floats;
     shift_floats += cout + 128;  // padded: the epilogue reads whole 32-cout tiles
     op.tbl_off = tbl_entries;
@@ -688,6 +708,40 @@ struct dv_model {
     out.w = op.ow;
     out.c = x.c;
     return out;
+  }
+
+  // Sibling 1x1 convolutions of an Inception block read the same tensor.  Hoist
+  // them next to the first one and mark them as ONE launch (ConvArgs::br): the
+  // input is then fetched from HBM once and re-read from L2 by the siblings.
+  // Layer (= weight) order is untouched -- only the execution order changes,
+  // which is legal because every hoisted op depends on the shared input only.
+  void group_siblings() {
+    static const bool off = getenv("DV_NO_GROUPING") != nullptr;  // tuning knob
+    if (off) return;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      Op& lead = ops[i];
+      if (lead.type != kOpConv || lead.kh != 1 || lead.kw != 1 || lead.stride != 1) continue;
+      std::vector<size_t> sib;
+      for (size_t j = i + 1; j < ops.size() && j < i + 16 && sib.size() + 1 < kMaxBranches; ++j) {
+        const Op& o = ops[j];
+        if (o.type == kOpConv && o.kh == 1 && o.kw == 1 && o.stride == 1 &&
+            o.in_buf == lead.in_buf) {
+          sib.push_back(j);
+        }
+      }
+      if (sib.empty()) continue;
+      // common tile width: 64 couts (NB = 2) wastes the least over {32..448}
+      int total = lead.cout;
+      for (size_t j : sib) total += ops[j].cout;
+      const int nb = total >= 512 ? 4 : 2;
+      std::vector<Op> moved;
+      for (size_t j : sib) moved.push_back(ops[j]);
+      for (size_t k = sib.size(); k-- > 0;) ops.erase(ops.begin() + sib[k]);
+      ops.insert(ops.begin() + i + 1, moved.begin(), moved.end());
+      ops[i].group_followers = static_cast<int>(moved.size());
+      for (size_t k = 0; k <= moved.size(); ++k) ops[i + k].nb = nb;
+      i += moved.size();
+    }
   }
 
   // tf_keras applications/inception_v3.py, construction order = layer order.
@@ -772,6 +826,13 @@ struct dv_model {
     feat_buf = x.buf;
     feat_p = x.h * x.w;
     feat_c = x.c;
+    group_siblings();
+    for (Op& op : ops) {  // packed-weight offsets (after grouping fixed every nb)
+      if (op.type != kOpConv) continue;
+      const int n_tiles = (op.cout + op.nb * 32 - 1) / (op.nb * 32);
+      op.w_off = packed_halfs;
+      packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks * (op.nb * 32) * kChunk;
+    }
     for (const Op& op : ops) {  // zero halo wide enough for every consumer
       int need = 0;
       if (op.type == kOpConv) need = std::max(op.pad_h, op.pad_w);
@@ -786,21 +847,19 @@ namespace {
 
 template <int NB>
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-  const int n_tiles = (a.Cout + NB * 32 - 1) / (NB * 32);
+  const int n_tiles = a.n_tiles;
   // Two pixel tiles per wave halve the LDS weight traffic per MFMA; fall back
   // to one when that would leave CUs without a block.
   const long blocks2 = static_cast<long>((a.M + 255) / 256) * n_tiles;
   static const int force_pt = getenv("DV_CONV_PT") ? atoi(getenv("DV_CONV_PT")) : 0;  // tuning knob
-  ConvArgs b = a;
-  b.n_tiles = n_tiles;
   if (force_pt ? force_pt == 2 : blocks2 >= 512) {
     const dim3 grid(static_cast<unsigned>(((a.M + 255) / 256) * n_tiles));
     hipLaunchKernelGGL((conv_mfma_kernel<NB, 2>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, b);
+                       conv_lds_bytes<NB>(), stream, a);
   } else {
     const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * n_tiles));
     hipLaunchKernelGGL((conv_mfma_kernel<NB, 1>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, b);
+                       conv_lds_bytes<NB>(), stream, a);
   }
 }
 
@@ -817,15 +876,10 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
     if (op.type == kOpConv) {
       ConvArgs a{};
       a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
-      a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
-      a.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
-      a.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
       const BufferDesc& ib = m->buffers[op.in_buf];
       a.ig = ib.geom();
-      a.og = ob.geom();
       a.N = n;
       a.Cin = op.cin;
-      a.Cout = op.cout;
       a.OH = op.oh;
       a.OW = op.ow;
       a.KH = op.kh;
@@ -833,16 +887,36 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.stride = op.stride;
       a.pad_h = op.pad_h;
       a.pad_w = op.pad_w;
-      a.out_goff = op.out_coff / 8;
       a.chunk_stride = static_cast<unsigned>(2 * a.ig.hp * a.ig.wp * 16);
       a.M = n * op.oh * op.ow;
       a.n_chunks = op.n_chunks;
       a.n_slabs = op.n_steps;
-      a.relu = op.raw ? 0 : 1;
-      if (op.raw) a.shift = nullptr;
       a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * ib.bytes_per_example());
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
       a.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
+      // this op + the sibling convs grouped behind it (same input, same geometry)
+      int tiles = 0;
+      a.n_branches = 0;
+      for (int gi = 0; gi <= op.group_followers; ++gi) {
+        const Op& bo = m->ops[oi + gi];
+        const BufferDesc& bob = m->buffers[bo.out_buf];
+        ConvBranch& br = a.br[a.n_branches++];
+        br.w = static_cast<const _Float16*>(m->d_w.ptr) + bo.w_off;
+        br.shift = bo.raw ? nullptr
+                          : static_cast<const float*>(m->d_shift.ptr) + bo.shift_off;
+        br.out = static_cast<_Float16*>(m->dbuf[bo.out_buf].ptr) +
+                 (bo.out_buf == shifted_buf
+                      ? static_cast<size_t>(out_example_off) * bob.bytes_per_example() / 2
+                      : 0);
+        br.og = bob.geom();
+        br.out_goff = bo.out_coff / 8;
+        br.Cout = bo.cout;
+        br.relu = bo.raw ? 0 : 1;
+        br.tile0 = tiles;
+        tiles += (bo.cout + bo.nb * 32 - 1) / (bo.nb * 32);
+      }
+      a.n_tiles = tiles;
+      oi += op.group_followers;  // the followers ran in this launch
       dv::ProfileScope prof(dv::kProfConv, stream);
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
