@@ -398,6 +398,132 @@ constexpr size_t conv_lds_bytes() {
   return static_cast<size_t>(2) * kSlabChunks * NB * 32 * kChunk * 2;
 }
 
+// First convolution fused with preprocess_images: reads the uint8 HWC pileup
+// tensor the encoder wrote (C <= 8 channels), normalises (x-128)/128 in
+// registers and multiplies on MFMA.  K layout: one 16-wide chunk = two filter
+// taps x 8 "channels" (C real + zero-weight padding), so a 3x3x7 filter is 5
+// chunks instead of the 9 half-empty ones of a 16-channel padded fp16 image,
+// and the 0.7 MB/example fp16 staging tensor disappears (HBM: 155 KB read
+// instead of 155 KB read + 707 KB written + 707 KB read).
+// A lane's fragment = the 8 bytes at (pixel, tap) -- unaligned, fetched as the
+// 3 aligned dwords around it and funnel-shifted; byte C..7 belong to the next
+// pixel and meet zero weights.  'valid' convolutions only, Cout <= 32.
+struct FirstConvArgs {
+  const uint8_t* in;        // [N][H][W][C]
+  const _Float16* w;        // packed [chunk][2 k-groups = taps][32][8]
+  const float* shift;
+  _Float16* out;
+  TensorGeom og;
+  int N, H, W, C, Cout;
+  int OH, OW, KH, KW, stride;
+  int M, n_chunks;
+  unsigned in_bytes;
+  float rcp_ow, rcp_ohow;
+};
+
+constexpr int kFirstMaxChunks = 13;  // up to 5x5 taps
+
+template <int PT>
+__global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvArgs p) {
+  __shared__ __attribute__((aligned(16))) _Float16 wl[kFirstMaxChunks * 32 * kChunk];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+  const int m_block = blockIdx.x * (128 * PT);
+
+  {  // all weights (<= 13 KB) -> LDS
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(p.w);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(wl);
+    for (int i = tid; i < p.n_chunks * 64; i += kConvThreads) dst[i] = src[i];
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.in), 0, p.in_bytes, 0x00020000);
+
+  unsigned base[PT], obase[PT];
+  bool mvalid[PT];
+  const int ohow = p.OH * p.OW;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int m = m_block + (wave * PT + pt) * 32 + (lane & 31);
+    mvalid[pt] = m < p.M;
+    int n, pix, oh, ow;
+    divmod_small(mvalid[pt] ? m : 0, ohow, p.rcp_ohow, n, pix);
+    divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
+    base[pt] = mvalid[pt] ? static_cast<unsigned>(((n * p.H + oh * p.stride) * p.W +
+                                                   ow * p.stride) * p.C)
+                          : 0x80000000u;
+    obase[pt] = static_cast<unsigned>((n * p.og.groups * p.og.hp + oh + p.og.halo) * p.og.wp +
+                                      ow + p.og.halo);
+  }
+  const int taps = p.KH * p.KW;
+  float16_t acc[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[pt][i] = 0.f;
+  __syncthreads();
+
+  for (int kc = 0; kc < p.n_chunks; ++kc) {
+    // this lane-half's tap; past the last tap the weights are zero
+    const int t = min(2 * kc + hi, taps - 1);
+    const int kh = t / p.KW, kw = t - kh * p.KW;
+    const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
+    const half8_t wf = *reinterpret_cast<const half8_t*>(
+        wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const unsigned a = base[pt] + toff;
+      typedef unsigned uint3_t __attribute__((ext_vector_type(3)));
+      const uint3_t d = __builtin_amdgcn_raw_buffer_load_b96(rsrc, a & ~3u, 0, 0);
+      const unsigned sh = (a & 3u) * 8u;
+      const unsigned lo = __builtin_amdgcn_alignbit(d[1], d[0], sh);
+      const unsigned up = __builtin_amdgcn_alignbit(d[2], d[1], sh);
+      half8_t x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = static_cast<_Float16>((static_cast<float>((lo >> (8 * j)) & 0xFF) - 128.0f) *
+                                     (1.0f / 128.0f));
+        x[4 + j] = static_cast<_Float16>((static_cast<float>((up >> (8 * j)) & 0xFF) - 128.0f) *
+                                         (1.0f / 128.0f));
+      }
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, x, acc[pt], 0, 0, 0);
+    }
+  }
+
+  // epilogue (same piece pairing as conv_mfma_kernel, one 32-cout tile)
+  const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
+  uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    unsigned pk[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 8 * q + 4 * hi;
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        const float2_t sv = {co + 2 * hq < p.Cout ? p.shift[co + 2 * hq] : 0.f,
+                             co + 2 * hq + 1 < p.Cout ? p.shift[co + 2 * hq + 1] : 0.f};
+        const float2_t v = float2_t{acc[pt][4 * q + 2 * hq], acc[pt][4 * q + 2 * hq + 1]} + sv;
+        half2_t h = __builtin_convertvector(v, half2_t);
+        h = __builtin_elementwise_max(h, zero2);
+        pk[q][hq] = __builtin_bit_cast(unsigned, h);
+      }
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t2][0], pk[2 * t2 + 1][0], false, false);
+      const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t2][1], pk[2 * t2 + 1][1], false, false);
+      const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+      const int group = 2 * t2 + hi;
+      if (mvalid[pt] && group * 8 < p.Cout) {
+        outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
+      }
+    }
+  }
+}
+
 // uint8 [N,H,W,C] -> fp16 C8 [N][2][hp][wp][8]: (x - 128) / 128, exact in fp16.
 __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix, int C,
                                   int H, int W, TensorGeom og) {
@@ -576,6 +702,7 @@ struct Op {
   size_t tbl_off = 0;    // int2 entries into the chunk tables
   bool raw = false;              // conv: skip shift + ReLU (applied by a later pool)
   int group_followers = 0;       // conv: the next k ops are siblings sharing this launch
+  bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
 };
 
@@ -749,6 +876,14 @@ struct dv_model {
     const int in_buf = new_buffer(desc.height, desc.width, 16);
     TensorRef x = full(in_buf);
     x = conv(x, 32, 3, 3, 2, false, -1, 0, desc.channels);
+    if (desc.channels <= 8 && getenv("DV_NO_U8_CONV1") == nullptr) {
+      Op& f = ops.back();
+      f.first_u8 = true;  // conv_first_u8_kernel: K chunk = 2 taps x 8 channels
+      f.nb = 1;
+      f.n_chunks = (f.kh * f.kw + 1) / 2;
+      f.n_steps = 1;
+      buffers[in_buf] = {1, 1, 16, 0};  // the fp16 staging image is never materialised
+    }
     x = conv(x, 32, 3, 3, 1, false);
     x = conv(x, 64, 3, 3);
     // (layer order: the two remaining stem convs are created before the pools run)
@@ -831,7 +966,10 @@ struct dv_model {
       if (op.type != kOpConv) continue;
       const int n_tiles = (op.cout + op.nb * 32 - 1) / (op.nb * 32);
       op.w_off = packed_halfs;
-      packed_halfs += static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks * (op.nb * 32) * kChunk;
+      packed_halfs += op.first_u8
+                          ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
+                          : static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks *
+                                (op.nb * 32) * kChunk;
     }
     for (const Op& op : ops) {  // zero halo wide enough for every consumer
       int need = 0;
@@ -866,14 +1004,39 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
 // Runs ops [first, last) on `n` examples.  `out_example_off` shifts the output
 // pointer of ops that write `shifted_buf` (the stem's full-batch output).
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
-            int shifted_buf = -1, int out_example_off = 0) {
+            int shifted_buf = -1, int out_example_off = 0, const uint8_t* images = nullptr) {
   for (int oi = first; oi < last; ++oi) {
     const Op& op = m->ops[oi];
     const BufferDesc& ob = m->buffers[op.out_buf];
     const size_t out_shift_halfs =
         op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
                                   : 0;
-    if (op.type == kOpConv) {
+    if (op.type == kOpConv && op.first_u8) {
+      FirstConvArgs f{};
+      f.in = images;
+      f.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
+      f.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
+      f.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
+      f.og = ob.geom();
+      f.N = n;
+      f.H = op.ih;
+      f.W = op.iw;
+      f.C = op.cin_real;
+      f.Cout = op.cout;
+      f.OH = op.oh;
+      f.OW = op.ow;
+      f.KH = op.kh;
+      f.KW = op.kw;
+      f.stride = op.stride;
+      f.M = n * op.oh * op.ow;
+      f.n_chunks = op.n_chunks;
+      f.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin_real);
+      f.rcp_ow = 1.0f / static_cast<float>(op.ow);
+      f.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
+      dv::ProfileScope prof(dv::kProfConv, stream);
+      hipLaunchKernelGGL((conv_first_u8_kernel<2>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
+                         stream, f);
+    } else if (op.type == kOpConv) {
       ConvArgs a{};
       a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
       const BufferDesc& ib = m->buffers[op.in_buf];
@@ -1054,6 +1217,22 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       inv[co] = 1.0f / std::sqrt(var[co] + 1e-3f);
       shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
     }
+    if (op.first_u8) {
+      // [chunk kc][k-group g = tap 2kc+g][cout][8]: channel c < cin_real, else zero
+      for (int kc = 0; kc < op.n_chunks; ++kc)
+        for (int g = 0; g < 2; ++g) {
+          const int tap = 2 * kc + g;
+          if (tap >= op.kh * op.kw) continue;
+          const int kh = tap / op.kw, kw = tap % op.kw;
+          for (int co = 0; co < op.cout; ++co)
+            for (int ci = 0; ci < l.cin; ++ci) {
+              const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+              packed[op.w_off + ((static_cast<size_t>(kc) * 2 + g) * 32 + co) * 8 + ci] =
+                  static_cast<_Float16>(v * inv[co]);
+            }
+        }
+      continue;
+    }
     const int bn = op.nb * 32;
     const int n_tiles = (op.cout + bn - 1) / bn;
     for (int t = 0; t < n_tiles; ++t)
@@ -1128,15 +1307,16 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
     const int nb = std::min(part, n - done);
     for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
       const int sb = std::min(stem_sub_batch(), nb - sb0);
-      {
+      const uint8_t* img = images + (done + sb0) * img_bytes;
+      if (!m->ops[0].first_u8) {
         const size_t n_pix = static_cast<size_t>(sb) * m->desc.height * m->desc.width;
         dv::ProfileScope prof(dv::kProfOther, stream);
         hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
-                           dim3(256), 0, stream, images + (done + sb0) * img_bytes,
-                           static_cast<_Float16*>(m->dbuf[0].ptr), n_pix, m->desc.channels,
-                           m->desc.height, m->desc.width, m->buffers[0].geom());
+                           dim3(256), 0, stream, img, static_cast<_Float16*>(m->dbuf[0].ptr),
+                           n_pix, m->desc.channels, m->desc.height, m->desc.width,
+                           m->buffers[0].geom());
       }
-      if (int rc = run_ops(m, 0, m->stem_ops_end, sb, stream, m->stem_out_buf, sb0)) return rc;
+      if (int rc = run_ops(m, 0, m->stem_ops_end, sb, stream, m->stem_out_buf, sb0, img)) return rc;
     }
     if (int rc = run_ops(m, m->stem_ops_end, static_cast<int>(m->ops.size()), nb, stream)) {
       return rc;
