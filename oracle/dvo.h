@@ -221,6 +221,8 @@ typedef struct dvo_packed_batch {
   const uint32_t* list_read; /* read index, in Query() order (NOT shuffled) */
   const uint8_t* list_code;  /* ReadSupportsAlt: 0 / 1 / 2 */
   const uint8_t* list_group; /* allele support group (sort_by_alt_allele_support), may be NULL */
+  const uint32_t* item_blank_mask;  /* bit i = blank channel i of opt->channels; may be NULL */
+  const float* item_mean_coverage;  /* may be NULL (0) */
 } dvo_packed_batch;
 
 int dvo_encode_packed(const dvo_options* opt, const dvo_packed_batch* b,

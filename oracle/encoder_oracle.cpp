@@ -1078,9 +1078,17 @@ static int EncodePackedItem(const dvo_options& opt, const dvo_packed_batch& b,
   std::string ref(reinterpret_cast<const char*>(b.ref_windows) +
                       static_cast<size_t>(b.item_ref_idx[item]) * opt.width,
                   opt.width);
+  std::vector<int32_t> blank;
+  if (b.item_blank_mask != nullptr) {
+    for (int c = 0; c < opt.n_channels; ++c) {
+      if ((b.item_blank_mask[item] >> c) & 1u) blank.push_back(opt.channels[c]);
+    }
+  }
+  const float mean_cov = b.item_mean_coverage ? b.item_mean_coverage[item] : 0.0f;
   int kept = BuildPileup(opt, call, ref, reads.data(), n,
-                         b.item_image_start[item], alt_alleles, 1, h, 0.0f,
-                         sort_pos.data(), nullptr, 0, &rows, &row_read);
+                         b.item_image_start[item], alt_alleles, 1, h, mean_cov,
+                         sort_pos.data(), blank.data(),
+                         static_cast<int>(blank.size()), &rows, &row_read);
   if (kept < 0) return -1;
   FillPileupArray(rows, out_channels, out + b.item_out_off[item]);
   if (out_rows) out_rows[item] = kept;

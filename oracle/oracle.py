@@ -106,6 +106,7 @@ class DvoPackedBatch(C.Structure):
       ('ref_windows', C.c_void_p),
       ('list_read', C.c_void_p), ('list_code', C.c_void_p),
       ('list_group', C.c_void_p),
+      ('item_blank_mask', C.c_void_p), ('item_mean_coverage', C.c_void_p),
   ]
 
 
@@ -394,6 +395,8 @@ def encode_packed(pic_options, batch, out_channels=None, n_threads=1):
   b.list_read = ptr(batch.list_read, np.uint32)
   b.list_code = ptr(batch.list_code, np.uint8)
   b.list_group = ptr(batch.list_group, np.uint8)
+  b.item_blank_mask = ptr(batch.item_blank_mask, np.uint32)
+  b.item_mean_coverage = ptr(batch.item_mean_coverage, np.float32)
   total = batch.out_bytes(c_total)
   out = np.zeros((total,), dtype=np.uint8)
   rows = np.zeros((max(batch.n_items, 1),), dtype=np.int32)

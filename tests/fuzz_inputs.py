@@ -1,0 +1,96 @@
+"""Seeded random proto-shaped pileup inputs exercising every CIGAR op, window
+overlap, HP tags, strands, support lists, deep pile-ups (shuffle path)."""
+import numpy as np
+
+from deepvariant_amd import dv_types as T
+
+_OPS = {'M': 1, 'I': 2, 'D': 3, 'N': 4, 'S': 5, 'H': 6, 'P': 7, '=': 8, 'X': 9}
+
+
+def random_cigar(rng, min_ops=1, max_ops=7):
+  ops = []
+  n = int(rng.integers(min_ops, max_ops + 1))
+  for k in range(n):
+    choices = 'MMM=XIDNSHP' if 0 < k < n - 1 else 'MM=XSHIDN'
+    op = choices[int(rng.integers(0, len(choices)))]
+    ln = int(rng.integers(1, 40 if op in 'M=X' else 8))
+    ops.append(T.CigarUnit(_OPS[op], ln))
+  return ops
+
+
+def query_len(cigar):
+  return sum(c.operation_length for c in cigar if c.operation in (1, 2, 5, 8, 9))
+
+
+def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
+              with_mods=False, n_alts=2):
+  hw = (width - 1) // 2
+  ref_window = ''.join('ACGTN'[int(i)] for i in rng.choice(5, size=width,
+                                                           p=[.24, .24, .24, .24, .04]))
+  alts = ['C', 'G', 'T'][:n_alts]
+  reads = []
+  for i in range(n_reads):
+    cigar = random_cigar(rng)
+    qlen = max(query_len(cigar), 1)
+    if query_len(cigar) == 0:
+      cigar.append(T.CigarUnit(1, 1))
+    start = variant_start - int(rng.integers(-10, hw + 40))
+    seq = ''.join('ACGT'[int(j)] for j in rng.integers(0, 4, size=qlen))
+    quals = rng.integers(0, 60, size=qlen).astype(np.uint8)
+    r = T.Read(
+        fragment_name='frag%d' % int(rng.integers(0, max(n_reads // 2, 1))),
+        read_number=int(rng.integers(0, 2)), number_reads=2,
+        fragment_length=int(rng.integers(-1500, 1500)),
+        aligned_sequence=seq, aligned_quality=bytes(quals),
+        supplementary_alignment=bool(rng.integers(0, 2)),
+        alignment=T.LinearAlignment(
+            position=T.Position('chr1', start, bool(rng.integers(0, 2))),
+            mapping_quality=int(rng.integers(0, 70)), cigar=cigar))
+    if with_hp and rng.random() < 0.7:
+      r.info['HP'] = T.ListValue(values=[T.Value(int_value=int(rng.integers(0, 4)))])
+    if with_mods and rng.random() < 0.5:
+      r.base_modifications[T.K5MC] = bytes(rng.integers(0, 256, size=qlen).astype(np.uint8))
+    if with_mods and rng.random() < 0.5:
+      r.base_modifications[T.K6MA] = bytes(rng.integers(0, 256, size=qlen).astype(np.uint8))
+    reads.append(r)
+  keys = ['%s/%d' % (r.fragment_name, r.read_number) for r in reads]
+  support = {}
+  for a in alts:
+    k = int(rng.integers(0, max(n_reads // 2, 1) + 1))
+    if n_reads:
+      support[a] = T.SupportingReads(
+          [keys[int(j)] for j in rng.integers(0, n_reads, size=k)])
+  call = T.DeepVariantCall(
+      variant=T.Variant('chr1', variant_start, variant_start + 1, 'A', alts),
+      allele_support=support)
+  combo = [alts[int(j)] for j in sorted(set(rng.integers(0, n_alts, size=int(rng.integers(1, 3))).tolist()))]
+  return call, ref_window, reads, variant_start - hw, combo
+
+
+from tests import known_answers as KA  # noqa: E402
+
+
+def options(channels, width, height, **kw):
+  rr = T.ReadRequirements(min_mapping_quality=kw.pop('min_mapq', 5),
+                          min_base_quality=kw.pop('min_bq', 10))
+  o = KA.default_options(channels, read_requirements=rr, **kw)
+  o.width, o.height = width, height
+  return o
+
+
+CONFIGS = [
+    # (name, channels, width, height, options, case kwargs)
+    ('wgs7', T.PILEUP_CHANNELS_WITH_INSERT_SIZE, 221, 100, {}, {}),
+    ('narrow_even_band2', T.PILEUP_DEFAULT_CHANNELS, 31, 20,
+     dict(reference_band_height=2), {}),
+    ('pacbio_like', T.PILEUP_DEFAULT_CHANNELS + ['haplotype', 'base_methylation',
+                                                 'base_6ma', 'supplementary_alignment'],
+     147, 60, dict(sort_by_haplotypes=True, min_mapq=1), dict(with_hp=True, with_mods=True)),
+    ('polishing_hp', T.PILEUP_DEFAULT_CHANNELS + ['haplotype'], 75, 40,
+     dict(sort_by_haplotypes=True, hp_tag_for_assembly_polishing=2), dict(with_hp=True)),
+    ('aux_channels', ['read_base', 'read_mapping_percent', 'avg_base_quality', 'identity',
+                      'gap_compressed_identity', 'blank', 'mean_coverage', 'insert_size'],
+     51, 30, {}, {}),
+    ('sort_by_support', T.PILEUP_DEFAULT_CHANNELS, 41, 24,
+     dict(sort_by_alt_allele_support=True), {}),
+]
