@@ -741,12 +741,16 @@ struct dv_model {
     return static_cast<int>(buffers.size()) - 1;
   }
   static int pick_nb(int cout) {
-    // smallest waste first, then the widest tile
-    int best = 4, best_waste = 1 << 30;
+    // Cost of a cout tiling ~ tiles x (nb MFMA columns + 1 pixel-fragment stream): a
+    // 160-wide layer is cheaper as 2 x 96 (one sixth padding) than as 5 x 32, whose
+    // blocks re-load every pixel fragment five times.  Ties -> less padding.
+    int best = 4, best_cost = 1 << 30, best_waste = 1 << 30;
     for (int nb = 4; nb >= 1; --nb) {
       const int bn = nb * 32;
-      const int waste = ((cout + bn - 1) / bn) * bn - cout;
-      if (waste < best_waste) {
+      const int tiles = (cout + bn - 1) / bn;
+      const int cost = tiles * (nb + 1), waste = tiles * bn - cout;
+      if (cost < best_cost || (cost == best_cost && waste < best_waste)) {
+        best_cost = cost;
         best_waste = waste;
         best = nb;
       }
@@ -1011,6 +1015,47 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 // Runs ops [first, last) on `n` examples.  `out_example_off` shifts the output
 // pointer of ops that write `shifted_buf` (the stem's full-batch output).
+// DV_OP_TRACE=1: per-launch table (ms, TFLOP/s, activation GB/s) on stderr after
+// every eager forward -- the per-layer view rocprofv3's per-kernel-name stats cannot give.
+struct OpTrace {
+  hipEvent_t a, b;
+  std::string label;
+  double flops, bytes;
+};
+std::vector<OpTrace>* g_trace = nullptr;
+
+struct TraceScope {
+  hipStream_t stream;
+  bool on;
+  TraceScope(hipStream_t s, std::string label, double flops, double bytes) : stream(s), on(g_trace != nullptr) {
+    if (!on) return;
+    OpTrace t{nullptr, nullptr, std::move(label), flops, bytes};
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, stream);
+    g_trace->push_back(std::move(t));
+  }
+  ~TraceScope() {
+    if (on) (void)hipEventRecord(g_trace->back().b, stream);
+  }
+};
+
+void dump_trace(hipStream_t stream) {
+  (void)hipStreamSynchronize(stream);
+  double tot = 0;
+  for (OpTrace& t : *g_trace) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t.a, t.b);
+    tot += ms;
+    fprintf(stderr, "[dv-op] %-58s %8.1f us %7.1f TF/s %7.0f GB/s\n", t.label.c_str(), ms * 1e3,
+            t.flops / (ms * 1e-3) / 1e12, t.bytes / (ms * 1e-3) / 1e9);
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  fprintf(stderr, "[dv-op] total %.1f us\n", tot * 1e3);
+  g_trace->clear();
+}
+
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
             int shifted_buf = -1, int out_example_off = 0, const uint8_t* images = nullptr) {
   for (int oi = first; oi < last; ++oi) {
@@ -1041,6 +1086,9 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       f.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin_real);
       f.rcp_ow = 1.0f / static_cast<float>(op.ow);
       f.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
+      TraceScope tr(stream, "conv_first_u8 3x3 s2 " + std::to_string(op.cin_real) + "->" + std::to_string(op.cout),
+                    2.0 * f.M * op.kh * op.kw * op.cin_real * op.cout,
+                    static_cast<double>(n) * (op.ih * op.iw * op.cin_real + 2.0 * op.oh * op.ow * op.cout));
       dv::ProfileScope prof(dv::kProfConv, stream);
       hipLaunchKernelGGL((conv_first_u8_kernel<2>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
                          stream, f);
@@ -1068,8 +1116,14 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       // this op + the sibling convs grouped behind it (same input, same geometry)
       int tiles = 0;
       a.n_branches = 0;
+      double tr_flops = 0, tr_bytes = static_cast<double>(n) * op.ih * op.iw * op.cin * 2.0;
+      std::string tr_label = "conv " + std::to_string(op.kh) + "x" + std::to_string(op.kw) + " s" +
+                             std::to_string(op.stride) + " " + std::to_string(op.cin) + "->";
       for (int gi = 0; gi <= op.group_followers; ++gi) {
         const Op& bo = m->ops[oi + gi];
+        tr_flops += 2.0 * n * op.oh * op.ow * op.kh * op.kw * op.cin * bo.cout;
+        tr_bytes += 2.0 * n * op.oh * op.ow * bo.cout;
+        tr_label += (gi ? "+" : "") + std::to_string(bo.cout);
         const BufferDesc& bob = m->buffers[bo.out_buf];
         ConvBranch& br = a.br[a.n_branches++];
         br.w = static_cast<const _Float16*>(m->d_w.ptr) + bo.w_off;
@@ -1088,6 +1142,9 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       }
       a.n_tiles = tiles;
       oi += op.group_followers;  // the followers ran in this launch
+      tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
+                  " tiles" + std::to_string(tiles);
+      TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
@@ -1111,6 +1168,9 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                     : nullptr;
       const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
       const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+      TraceScope tr(stream, std::string(op.type == kOpMaxPool ? "maxpool3s2 " : "avgpool3s1 ") +
+                                std::to_string(op.cin) + " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow),
+                    0.0, 2.0 * n * op.cin * (static_cast<double>(op.ih) * op.iw + op.oh * op.ow));
       dv::ProfileScope prof(dv::kProfOther, stream);
       if (op.type == kOpMaxPool) {
         hipLaunchKernelGGL(maxpool3s2_kernel, grid, dim3(256), 0, stream, p);
@@ -1352,8 +1412,12 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   // by (n, images, probs, stream); per-launch event profiling needs eager mode.
   static const bool no_graph = getenv("DV_NO_GRAPH") != nullptr;
   if (no_graph || dv::profiling_enabled() || stream == nullptr) {
+    static const bool op_trace = getenv("DV_OP_TRACE") != nullptr;
+    static std::vector<OpTrace> trace_store;
+    g_trace = op_trace ? &trace_store : nullptr;
     if (int rc = enqueue_forward(m, images, n, probs, stream)) return rc;
     DV_HIP_CHECK(hipGetLastError());
+    if (op_trace) dump_trace(stream);
     return DV_OK;
   }
   for (const dv_model::GraphEntry& g : m->graphs) {

@@ -201,3 +201,144 @@ def make_illumina_batch(n_candidates: int, seed: int = SEED, options=None,
                      height=H, out_off=k * img_bytes)
       k += 1
   return batch
+
+
+# --------------------------------------------------------------------------
+# Long-read shapes (SURVEY.md 8d "HIFI35" / "ONT50"; BASELINE.json configs 4, 5)
+# --------------------------------------------------------------------------
+HIFI_CHANNELS = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype', 'base_methylation']
+ONT_CHANNELS = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype']
+
+
+def longread_options(kind: str = 'hifi') -> T.PileupImageOptions:
+  """PACBIO (W=147, 6+haplotype+methylation) / ONT_R104 (W=199, 6+haplotype) encoder
+  options: min_mapping_quality 1, sort_by_haplotypes (make_examples_options.py long-read
+  model defaults).  The two alt-aligned diff channels of the released models come from
+  the realigner and are not generated here."""
+  rr = T.ReadRequirements(min_mapping_quality=1, min_base_quality=10,
+                          min_base_quality_mode=1)
+  o = T.default_options(rr)
+  o.height = 100
+  o.width = 147 if kind == 'hifi' else 199
+  o.channels = list(HIFI_CHANNELS if kind == 'hifi' else ONT_CHANNELS)
+  o.num_channels = len(o.channels)
+  o.sort_by_haplotypes = True
+  return o
+
+
+def make_longread_batch(n_candidates: int, kind: str = 'hifi', seed: int = SEED,
+                        options=None) -> packing.PackedBatch:
+  """HIFI35: depth~Poisson(35), BQ 20-93, MAPQ 60, HP {0,1,2} w.p. {.2,.4,.4}, 5mC byte
+  per base, sparse indels, '='/'X' CIGARs.  ONT50: depth~Poisson(50) plus 10 % sites
+  with 96-160 reads (shuffle path), ~3 % indel events per base (dozens of CIGAR ops
+  per read), BQ 5-40.  Reads are window-trimmed (TrimReads) to <= W+40 bases."""
+  opts = options or longread_options(kind)
+  W, H = opts.width, opts.height
+  hw = (W - 1) // 2
+  C = len(packing.channel_enums(opts))
+  rng = np.random.Generator(np.random.PCG64(seed ^ (0x9e37 if kind == 'hifi' else 0x79b9)))
+  hifi = kind == 'hifi'
+  indel_rate = 0.002 if hifi else 0.03
+  n = n_candidates
+  pos = 5000 + 2000 * np.arange(n, dtype=np.int64)
+  seg = _ACGT[rng.integers(0, 4, size=(n, 2 * W + 200))]
+  seg0 = pos - hw - W // 2 - 50                      # genomic coordinate of seg[:, 0]
+  depth = np.clip(rng.poisson(35 if hifi else 50, size=n), 2, 95 if hifi else 94)
+  if not hifi:
+    deep = rng.random(n) < 0.10
+    depth = np.where(deep, rng.integers(96, 161, size=n), depth)
+  p_pos, p_mapq, p_flags, p_hp, p_rank = [], [], [], [], []
+  seq_chunks, qual_chunks, mod_chunks, cig_all = [], [], [], []
+  seq_off, cig_off, read_end = [0], [0], []
+  first = [0]
+  allele_of = []
+  for i in range(n):
+    d = int(depth[i])
+    alt = _ACGT[(np.searchsorted(_ACGT, seg[i, pos[i] - seg0[i]]) + 1) % 4]
+    for _ in range(d):
+      start = int(pos[i]) - hw - int(rng.integers(-20, 21))
+      span = W + int(rng.integers(0, 41))            # reference bases covered
+      g = start - int(seg0[i])
+      ref = seg[i, g:g + span]
+      carries = rng.random() < 0.5
+      ops, bases = [], []
+      j = 0
+      while j < span:
+        run = int(rng.geometric(indel_rate)) if indel_rate > 0 else span
+        run = min(run, span - j)
+        chunk = ref[j:j + run].copy()
+        site = int(pos[i]) - start
+        if carries and j <= site < j + run:
+          chunk[site - j] = alt
+        if hifi:                                     # '=' / 'X' ops
+          k0 = 0
+          mism = np.nonzero(chunk != ref[j:j + run])[0]
+          for m in mism:
+            if m > k0:
+              ops.append((int(m - k0), 8))
+            ops.append((1, 9))
+            k0 = int(m) + 1
+          if run > k0:
+            ops.append((run - k0, 8))
+        else:
+          ops.append((run, 1))
+        bases.append(chunk)
+        j += run
+        if j >= span:
+          break
+        ln = int(rng.integers(1, 4))
+        if rng.random() < 0.5:                       # deletion
+          ln = min(ln, span - j - 1)
+          if ln > 0:
+            ops.append((ln, 3))
+            j += ln
+        else:
+          ops.append((ln, 2))
+          bases.append(_ACGT[rng.integers(0, 4, size=ln)])
+      merged = []
+      for ln, op in ops:                             # merge neighbours of one kind
+        if merged and merged[-1][1] == op:
+          merged[-1] = (merged[-1][0] + ln, op)
+        else:
+          merged.append((ln, op))
+      b = np.concatenate(bases)
+      q = (rng.integers(20, 94, size=b.size) if hifi
+           else rng.integers(5, 41, size=b.size)).astype(np.uint8)
+      seq_chunks.append(b)
+      qual_chunks.append(q)
+      mod_chunks.append(np.where(rng.random(b.size) < 0.1,
+                                 rng.integers(0, 256, size=b.size), 0).astype(np.uint8))
+      seq_off.append(seq_off[-1] + b.size)
+      cig_all.extend((ln << 4) | op for ln, op in merged)
+      cig_off.append(cig_off[-1] + len(merged))
+      p_pos.append(start)
+      read_end.append(start + sum(ln for ln, op in merged if op in (1, 3, 8, 9)))
+      p_mapq.append(60 if rng.random() < 0.95 else int(rng.integers(0, 60)))
+      fl = packing.DV_READ_REVERSE if rng.random() < 0.5 else 0
+      if hifi:
+        fl |= packing.DV_READ_HAS_5MC
+      p_flags.append(fl)
+      u = rng.random()
+      p_hp.append(0 if u < 0.2 else (1 if u < 0.6 else 2))
+      allele_of.append(1 if carries else 0)
+    first.append(first[-1] + d)
+  R = len(p_pos)
+  table = packing.ReadTable(
+      n_reads=R, read_pos=np.array(p_pos, np.int32), read_sort_pos=None,
+      read_seq_off=np.array(seq_off, np.uint32), read_cigar_off=np.array(cig_off, np.uint32),
+      read_mapq=np.array(p_mapq, np.uint8), read_flags=np.array(p_flags, np.uint8),
+      read_frag_len=np.zeros(R, np.int32), read_hp=np.array(p_hp, np.int32),
+      read_name_rank=rng.permutation(R).astype(np.uint32), read_aux=None,
+      bases=np.concatenate(seq_chunks), quals=np.concatenate(qual_chunks),
+      mod_5mc=np.concatenate(mod_chunks) if hifi else None, mod_6ma=None,
+      cigar=np.array(cig_all, np.uint32), keys=[], read_end=np.array(read_end, np.int64))
+  batch = packing.PackedBatch(table=table, width=W)
+  allele_of = np.array(allele_of, np.uint8)
+  for i in range(n):
+    w0 = int(pos[i]) - hw - int(seg0[i])
+    ref_idx = batch.add_ref_window(bytes(seg[i, w0:w0 + W]).decode())
+    lo, hi = first[i], first[i + 1]
+    batch.add_item(int(pos[i]), int(pos[i]) - hw, ref_idx,
+                   np.arange(lo, hi, dtype=np.uint32), allele_of[lo:hi], height=H,
+                   out_off=i * H * W * C)
+  return batch

@@ -47,6 +47,24 @@ def test_softmax_within_1e3_of_fp32_oracle(channels):
   assert (want.max(0).values - want.min(0).values).max() > 1e-2
 
 
+@pytest.mark.parametrize('shape', [(100, 147, 10), (100, 199, 9), (75, 75, 1), (120, 301, 16)])
+def test_other_model_shapes_within_1e3(shape):
+  """PACBIO (100x147x10), ONT (100x199x9) and the extremes dv_model_create accepts."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  h, w, c = shape
+  ref = R.make_random_model(c, seed=5)
+  model = InceptionV3(shape, max_batch=4)
+  assert model.num_params == ref.num_keras_params()
+  model.load_flat_weights(ref.export_flat())
+  x = torch.from_numpy(np.random.default_rng(c).integers(0, 256, (5, h, w, c), dtype=np.uint8))
+  got = model(x.cuda()).cpu()
+  with torch.no_grad():
+    want = ref(x)
+  err = (got - want).abs().max().item()
+  assert err <= TOL, (shape, err)
+
+
 def test_first_conv_matches_activation_by_activation():
   """Localises errors: the first conv (fused with the uint8 preprocessing,
   (x-128)/128, deepvariant/dv_utils.py:343-366) vs torch fp32."""

@@ -59,3 +59,22 @@ def test_device_resident_batch_matches_host_batch():
   torch.cuda.synchronize()
   np.testing.assert_array_equal(out.cpu().numpy(), want)
   np.testing.assert_array_equal(rows.cpu().numpy(), want_rows)
+
+
+@pytest.mark.parametrize('kind,n', [('hifi', 160), ('ont', 160)])
+def test_longread_shapes_bit_exact(kind, n):
+  """BASELINE.json configs 4/5 shapes: W=147 (8 ch: haplotype + methylation, '='/'X'
+  CIGARs) and W=199 (7 ch, ~14 CIGAR ops/read, 10 % of sites deeper than the image)."""
+  from deepvariant_amd import synth
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  opts = synth.longread_options(kind)
+  c = len(opts.channels)
+  batch = synth.make_longread_batch(n, kind, seed=77)
+  got, got_rows = _Encoder(opts, opts.width).encode(batch, c)
+  want, want_rows = O.encode_packed(opts, batch, c, n_threads=8)
+  np.testing.assert_array_equal(got_rows, want_rows)
+  np.testing.assert_array_equal(got, want)
+  if kind == 'ont':
+    off = np.asarray(batch.item_list_off)
+    assert (np.diff(off) > 95).any()      # the shuffle-and-truncate path ran
