@@ -85,7 +85,8 @@ struct ConvArgs {
   int M;                  // N*OH*OW
   int n_chunks;
   int n_slabs;            // ceil(n_chunks / kSlabChunks)
-  unsigned in_bytes;      // size of the input tensor (buffer-descriptor range)
+  size_t in_bytes;        // size of the input tensor
+  unsigned img_bytes;     // bytes of one example of the input tensor (all groups, with halo)
   unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
   int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
@@ -100,13 +101,27 @@ static int stem_sub_batch() {
   return v;
 }
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
-constexpr int kPrefetch = 4;     // pixel-operand prefetch depth, in chunks
+// Pixel-operand prefetch depth, in chunks.  A chunk is only NB*PT MFMAs (32 cycles
+// each) of cover, so thin tiles need a deeper queue to ride out L2/HBM latency.
+#ifndef DV_PF_THIN
+#define DV_PF_THIN 4
+#endif
+#ifndef DV_PF_MID
+#define DV_PF_MID 4
+#endif
+#ifndef DV_PF_BIG
+#define DV_PF_BIG 4
+#endif
+constexpr int prefetch_depth(int nb, int pt) {
+  return nb * pt <= 2 ? DV_PF_THIN : (nb * pt <= 4 ? DV_PF_MID : DV_PF_BIG);
+}
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-// q = m / d, r = m % d for 0 <= m < 2^24 via one fp32 multiply + fix-up.
+// q = m / d, r = m % d for 0 <= m < 2^26, d >= 5 via one fp32 multiply + fix-up: float(m)
+// is off by <= 2 and the product by a few ulp, so q is off by at most one.
 __device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, int& r) {
   q = static_cast<int>(static_cast<float>(m) * rcp);
   r = m - q * d;
@@ -149,13 +164,14 @@ struct ChunkWalk {
 // soffset = chunk offset (SGPR): ZERO vector ALU work per load.  Chunks past the
 // end of K simply read the next bytes of the (larger) input tensor or hit the
 // descriptor's range check; their values are never used.
-template <int NB, int PT, int R>
+template <int NB, int PT, int R, int S0 = 0>
 __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
                                           const _Float16* wslab, ChunkWalk& walk,
                                           const unsigned (&base)[PT],
-                                          uint4_t (&xf)[kPrefetch][PT],
+                                          uint4_t (&xf)[prefetch_depth(NB, PT)][PT],
                                           float16_t (&acc)[NB][PT]) {
   constexpr int BN = NB * 32;
+  constexpr int kPrefetch = prefetch_depth(NB, PT);
   // Weight fragments are double buffered in registers: the ds_reads of chunk
   // j+1 are issued before the MFMAs of chunk j, whose 32*NB*PT cycles cover the
   // LDS latency.
@@ -176,7 +192,7 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
     __builtin_amdgcn_sched_barrier(0);
     half8_t xh[PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[j % kPrefetch][pt]);
+    for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[(S0 + j) % kPrefetch][pt]);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -189,7 +205,7 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
     const unsigned soff = walk.off();
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      xf[j % kPrefetch][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+      xf[(S0 + j) % kPrefetch][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
     }
     walk.advance(p);
     __builtin_amdgcn_sched_barrier(0);
@@ -214,6 +230,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
   constexpr int W_PER_THREAD = SLAB_PIECES / kConvThreads;  // = 2 * NB
+  constexpr int kPrefetch = prefetch_depth(NB, PT);
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 
   const int tid = threadIdx.x;
@@ -236,10 +253,11 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   }
   const int n_tile = n_tile_all - b.tile0;
 
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16*>(p.in), 0, p.in_bytes, 0x00020000);
-
-  unsigned base[PT];   // byte offset of (n, group lane>>5, ih0, iw0) in the input
+  // Buffer offsets are 32 bit, tensors are not (8 K examples x 1.4 MB): every wave
+  // addresses the input relative to the first example it touches (n0), through its
+  // own descriptor -- a wave's 64 pixels never span more than a few hundred KB.
+  int n0 = 0;
+  unsigned base[PT];   // byte offset of (n - n0, group lane>>5, ih0, iw0) in the input
   unsigned obase[PT];  // piece index of (n, group out_goff, oh, ow) in the output
   bool mvalid[PT];
   const int ohow = p.OH * p.OW;
@@ -252,13 +270,20 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
     divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
     const int iy = oh * p.stride - p.pad_h + p.ig.halo;
     const int ix = ow * p.stride - p.pad_w + p.ig.halo;
+    if (pt == 0) n0 = __builtin_amdgcn_readfirstlane(n);  // lane 0 holds the wave's first pixel
     base[pt] = mvalid[pt]
-                   ? static_cast<unsigned>((((n * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
+                   ? static_cast<unsigned>(((((n - n0) * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
                                                 p.ig.wp + ix) * 16)
                    : 0x80000000u;  // beyond the descriptor's range: reads as zero
     obase[pt] = static_cast<unsigned>(((n * b.og.groups + b.out_goff) * b.og.hp + oh +
                                        b.og.halo) * b.og.wp + ow + b.og.halo);
   }
+
+  const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
+  const size_t in_left = p.in_bytes - in_off;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.in) + in_off), 0,
+      static_cast<unsigned>(in_left < 0x7fffffffu ? in_left : 0x7fffffffu), 0x00020000);
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
   const uint4* wsrc = reinterpret_cast<const uint4*>(b.w) +
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
     const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
     conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
     if (rem > 4) {
-      conv_slab<NB, PT, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+      conv_slab<NB, PT, 4, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
     }
   }
 #undef DV_LOAD_SLAB
@@ -386,7 +411,11 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
         const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
         const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
         if (mvalid[pt] && group * 8 < b.Cout) {
+#ifdef DV_NT_STORE
+          __builtin_nontemporal_store(piece, &outp[obase[pt] + static_cast<unsigned>(group) * gstride]);
+#else
           outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
+#endif
         }
       }
     }
@@ -1170,7 +1199,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t main_stream,
       a.M = n * op.oh * op.ow;
       a.n_chunks = op.n_chunks;
       a.n_slabs = op.n_steps;
-      a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * ib.bytes_per_example());
+      a.in_bytes = static_cast<size_t>(n) * ib.bytes_per_example();
+      a.img_bytes = static_cast<unsigned>(ib.bytes_per_example());
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
       a.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
       // this op + the sibling convs grouped behind it (same input, same geometry)
@@ -1257,12 +1287,11 @@ extern "C" {
 int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (!desc || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_create: null");
   if (desc->channels < 1 || desc->channels > 16 || desc->num_classes < 1 ||
-      desc->num_classes > 8 || desc->max_batch < 1 || desc->max_batch > 2048 ||
+      desc->num_classes > 8 || desc->max_batch < 1 || desc->max_batch > 8192 ||
       desc->height < 75 ||
       desc->width < 75) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT,
-                    "dv_model_create: unsupported shape (need H,W >= 75, C <= 16, max_batch <= 2048: "
-                    "activation tensors are addressed through 2 GiB buffer descriptors)");
+                    "dv_model_create: unsupported shape (need H,W >= 75, C <= 16, max_batch <= 8192)");
   }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -1276,6 +1305,21 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->device = device;
   m->desc = *desc;
   m->build();
+  // 32-bit index ranges of the kernels at max_batch (see conv_mfma_kernel's prologue)
+  for (const Op& op : m->ops) {
+    const BufferDesc& ob = m->buffers[op.out_buf];
+    const double pieces = static_cast<double>(desc->max_batch) * ob.bytes_per_example() / 16.0;
+    const double pixels = static_cast<double>(desc->max_batch) * op.oh * op.ow;
+    if (pieces >= 2147483648.0 || pixels >= 67108864.0) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                      "dv_model_create: max_batch too large for this image size (N*OH*OW must stay "
+                      "below 2^26 and every activation tensor below 2^31 16-byte pieces)");
+    }
+  }
+  if (static_cast<double>(desc->max_batch) * desc->height * desc->width * desc->channels >=
+      2147483648.0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_create: max_batch * H * W * C must be < 2^31");
+  }
   m->dbuf.resize(m->buffers.size());
   for (size_t i = 0; i < m->buffers.size(); ++i) {
     const BufferDesc& b = m->buffers[i];

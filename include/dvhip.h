@@ -255,7 +255,7 @@ typedef struct dv_model_desc {
   int32_t width;
   int32_t channels;
   int32_t num_classes; /* 3 */
-  int32_t max_batch;   /* activations are sized for this many examples */
+  int32_t max_batch;   /* activations are sized for this many examples (<= 8192; ~6 MB of HBM each at 100x221) */
 } dv_model_desc;
 
 int dv_model_create(const dv_model_desc* desc, int device, dv_model** out);

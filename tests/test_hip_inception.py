@@ -90,3 +90,19 @@ def test_shape_mismatch_raises():
   model.init_random(0)
   with pytest.raises(ValueError, match='input shape'):
     model(torch.zeros((1, 100, 199, 7), dtype=torch.uint8, device='cuda'))
+
+
+def test_large_batch_addresses_past_4gib():
+  """3000 examples put the stem tensors past 2^32 bytes: per-wave relative
+  addressing must give the same answers as a small batch of the same images."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  model = InceptionV3((100, 221, 7), max_batch=3000)
+  model.init_random(seed=7)
+  rng = np.random.default_rng(5)
+  base = torch.from_numpy(rng.integers(0, 256, (8, 100, 221, 7), dtype=np.uint8)).cuda()
+  big = base.repeat(375, 1, 1, 1)                  # 3000 examples, known period 8
+  got = model(big).cpu().reshape(375, 8, 3)
+  small = InceptionV3((100, 221, 7), max_batch=8)
+  small.init_random(seed=7)
+  want = small(base).cpu()
+  assert (got - want[None]).abs().max().item() <= 1e-6
