@@ -212,6 +212,78 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
   }
 }
 
+// Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
+// 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run.
+template <int NB, int PT>
+__device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvBranch& b,
+                                              int n_tile, const unsigned (&obase)[PT],
+                                              const bool (&mvalid)[PT], int lane) {
+  constexpr int BN = NB * 32;
+  // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
+  // A C8 piece (8 couts of one pixel) is split over lanes l and l+32: for each
+  // pair of groups (q = 2t, 2t+1) the low half-wave completes group 2t and the
+  // high half-wave group 2t+1 after one v_permlane32_swap per dword, then every
+  // lane stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
+  const int cbase = n_tile * BN;
+  const int hi = lane >> 5;
+  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    // Shifts come through the SCALAR cache (constant address space, wave-uniform
+    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
+    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
+            b.shift + (cbase + nb * 32 + 8 * q)));
+        const f4_t l4 = sp[0], u4 = sp[1];
+        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
+      }
+      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
+      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const float16_t a = acc[nb][pt];
+      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
+          half2_t h = __builtin_convertvector(v, half2_t);
+          if (b.relu) h = __builtin_elementwise_max(h, zero2);
+          pk[q][hq] = __builtin_bit_cast(unsigned, h);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
+        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
+        // group 2t in the low half-wave and of group 2t+1 in the high one.
+        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+        const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
+        if (mvalid[pt] && group * 8 < b.Cout) {
+#ifdef DV_NT_STORE
+          __builtin_nontemporal_store(piece, &outp[obase[pt] + static_cast<unsigned>(group) * gstride]);
+#else
+          outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
+#endif
+        }
+      }
+    }
+  }
+}
+
 // Implicit-GEMM convolution, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].
 //
 //  * The block's weight tile (NB*32 couts) streams through LDS in slabs of 8
@@ -356,70 +428,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
 #undef DV_LOAD_SLAB
 #undef DV_STORE_SLAB
 
-  // ---- epilogue: shift + ReLU, pair lanes l / l+32 into 16-byte pieces -------
-  // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
-  // A C8 piece (8 couts of one pixel) is split over lanes l and l+32: for each
-  // pair of groups (q = 2t, 2t+1) the low half-wave completes group 2t and the
-  // high half-wave group 2t+1 after one v_permlane32_swap per dword, then every
-  // lane stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
-  const int cbase = n_tile * BN;
-  const int hi = lane >> 5;
-  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
-  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    // Shifts come through the SCALAR cache (constant address space, wave-uniform
-    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
-    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
-      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
-        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
-            b.shift + (cbase + nb * 32 + 8 * q)));
-        const f4_t l4 = sp[0], u4 = sp[1];
-        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
-        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
-      }
-      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
-      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
-    }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const float16_t a = acc[nb][pt];
-      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
-          half2_t h = __builtin_convertvector(v, half2_t);
-          if (b.relu) h = __builtin_elementwise_max(h, zero2);
-          pk[q][hq] = __builtin_bit_cast(unsigned, h);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
-        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
-        // group 2t in the low half-wave and of group 2t+1 in the high one.
-        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
-        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
-        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
-        const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
-        if (mvalid[pt] && group * 8 < b.Cout) {
-#ifdef DV_NT_STORE
-          __builtin_nontemporal_store(piece, &outp[obase[pt] + static_cast<unsigned>(group) * gstride]);
-#else
-          outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
-#endif
-        }
-      }
-    }
-  }
+  conv_epilogue<NB, PT>(acc, b, n_tile, obase, mvalid, lane);
 }
 
 template <int NB>
