@@ -621,7 +621,9 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
       best;
 }
 
-// AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.
+// AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.  The input
+// buffer carries a zero halo of >= 1 (build() asks for it), so the nine taps are
+// unconditional 16-byte loads and only the divisor depends on the position.
 __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int cg = p.C / 8;
   const int H = p.ig.h, W = p.ig.w;
@@ -635,25 +637,30 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int g = t % cg;
   const int n = t / cg;
   const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
-                       (static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp * p.ig.wp;
-  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int cnt = 0;
-  for (int dh = -1; dh <= 1; ++dh)
-    for (int dw = -1; dw <= 1; ++dw) {
-      const int ih = oh + dh, iw = ow + dw;
-      if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
-      ++cnt;
-      const half8_t v = src[(ih + p.ig.halo) * p.ig.wp + iw + p.ig.halo];
+                       ((static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp + oh + p.ig.halo - 1) *
+                           p.ig.wp + ow + p.ig.halo - 1;
+  half8_t v[9];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
-    }
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) v[dh * 3 + dw] = src[dh * p.ig.wp + dw];
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a += static_cast<float>(v[k][j]);
+    s[j] = a;
+  }
+  const int cnt = ((oh > 0) + (oh < H - 1) + 1) * ((ow > 0) + (ow < W - 1) + 1);
   half8_t o;
   const float inv = 1.0f / static_cast<float>(cnt);
   if (p.shift != nullptr) {
+    const float4 s0 = *reinterpret_cast<const float4*>(p.shift + g * 8);
+    const float4 s1 = *reinterpret_cast<const float4*>(p.shift + g * 8 + 4);
+    const float sh[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o[j] = static_cast<_Float16>(fmaxf(s[j] * inv + p.shift[g * 8 + j], 0.f));
-    }
+    for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(fmaxf(s[j] * inv + sh[j], 0.f));
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
@@ -1075,6 +1082,7 @@ struct dv_model {
     for (const Op& op : ops) {  // zero halo wide enough for every consumer
       int need = 0;
       if (op.type == kOpConv) need = std::max(op.pad_h, op.pad_w);
+      if (op.type == kOpAvgPool) need = 1;  // avgpool3s1_kernel reads its taps unconditionally
       buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
     }
     layers.push_back({1, 1, feat_c, desc.num_classes, n_params});
