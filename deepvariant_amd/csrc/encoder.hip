@@ -38,7 +38,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr int kColsPerLane = 4;  // a row is rendered in passes of 256 columns, 4 per lane
 constexpr int kMaxKept = 256;
+constexpr int kPixDw = DV_MAX_CHANNELS / 4;  // dwords of one pixel's channel bytes
 constexpr int kInsertLutSize = 1008;
 
 enum ChannelKind : uint8_t {
@@ -124,6 +126,7 @@ struct EncArgs {
   const uint8_t* list_group;
   const uint8_t* list_aux;
   int32_t n_items;
+  int32_t n_channels;     // = EncConst::n_channels (sizes the LDS layout)
   int32_t out_channels;
   int32_t row_buf_bytes;  // per-wave LDS row buffer, multiple of 16
   uint8_t* out;
@@ -216,8 +219,18 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   uint32_t* key_rank = reinterpret_cast<uint32_t*>(key_pos + kMaxKept);
   uint32_t* order = key_rank + kMaxKept;
   uint32_t* wave_tot = order + kMaxKept;          // [kWaves]
-  uint8_t* pix_const = reinterpret_cast<uint8_t*>(wave_tot + 8);  // [kWaves][16]
-  uint8_t* row_bufs = pix_const + kWaves * DV_MAX_CHANNELS;
+  // per kept read: pixel program = constant bytes + v_perm selectors, 4 channels per dword
+  const int pdw = (a.n_channels + 3) >> 2;         // dwords per pixel program entry
+  uint32_t* m_const = wave_tot + 8;                // [kMaxKept][pdw]
+  uint32_t* m_sel_a = m_const + kMaxKept * pdw;    // dynamic bytes {base, qual, diff, 5mC}
+  uint32_t* m_sel_b = m_sel_a + kMaxKept * pdw;    // dynamic byte  {6mA}
+  uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_sel_b + kMaxKept * pdw);
+  // after the sort the key arrays are dead: they become the per-read metadata
+  uint32_t* m_c0 = reinterpret_cast<uint32_t*>(key_hap);
+  uint32_t* m_s0 = reinterpret_cast<uint32_t*>(key_pos);
+  int32_t* m_rpos = reinterpret_cast<int32_t*>(key_rank);
+  uint32_t* m_c1 = kept_src;
+  uint32_t* m_flags = kept_read;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -308,6 +321,76 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   }
   __syncthreads();
 
+  // ---------------- phase C': per-read metadata + pixel program ---------------
+  // One thread per kept read fetches everything phase D needs about it (one memory
+  // round trip for all rows instead of one per row) and compiles its pixel: the bytes
+  // that are constant along the read (mapq, strand, support, insert size, ...) and, per
+  // channel, a v_perm_b32 selector that either keeps that constant or picks one of the
+  // per-base bytes {base, quality, differs-from-ref, 5mC | 6mA}.
+  if (tid < kept) {
+    const uint32_t r = kept_read[tid];
+    const uint32_t le = l0 + kept_src[tid];
+    const uint8_t flags = a.read_flags[r];
+    uint32_t konst[kPixDw], sel_a[kPixDw], sel_b[kPixDw];
+#pragma unroll
+    for (int d = 0; d < kPixDw; ++d) {
+      konst[d] = 0;
+      sel_a[d] = 0x03020100u;  // identity: keep the bytes of the second operand
+      sel_b[d] = 0x03020100u;
+    }
+    for (int ch = 0; ch < C; ++ch) {
+      if ((blank_mask >> ch) & 1u) continue;
+      const int d = ch >> 2, sh = (ch & 3) * 8;
+      uint32_t v = 0;
+      int dyn_a = -1, dyn_b = -1;
+      switch (c->kind[ch]) {
+        case kBase: dyn_a = 0; break;
+        case kBaseQual: dyn_a = 1; break;
+        case kDiff: dyn_a = 2; break;
+        case kMeth5: if ((flags & DV_READ_HAS_5MC) && a.mod_5mc) dyn_a = 3; break;
+        case kMeth6: if ((flags & DV_READ_HAS_6MA) && a.mod_6ma) dyn_b = 0; break;
+        case kMapq: v = c->lut_mapq[a.read_mapq[r]]; break;
+        case kStrand: v = c->strand[flags & DV_READ_REVERSE ? 1 : 0]; break;
+        case kSupport: v = c->lut_support[min<int>(a.list_code[le], 3)]; break;
+        case kInsert: {
+          int f = a.read_frag_len[r];
+          f = f < 0 ? -f : f;
+          v = c->lut_insert[min(f, 1000)];
+          break;
+        }
+        case kHaplotype: v = haplotype_pixel(a.read_hp[r], c->polishing); break;
+        case kSupplementary: v = c->supp[flags & DV_READ_SUPPLEMENTARY ? 1 : 0]; break;
+        case kAuxRead0: case kAuxRead1: case kAuxRead2: case kAuxRead3:
+          v = a.read_aux ? a.read_aux[static_cast<size_t>(r) * DV_READ_AUX_STRIDE +
+                                      (c->kind[ch] - kAuxRead0)]
+                         : 0;
+          break;
+        case kAuxList: v = a.list_aux ? a.list_aux[le] : 0; break;
+        default: break;  // kZero
+      }
+      konst[d] |= v << sh;
+      if (dyn_a >= 0) sel_a[d] = (sel_a[d] & ~(0xFFu << sh)) | (static_cast<uint32_t>(4 + dyn_a) << sh);
+      if (dyn_b >= 0) sel_b[d] = (sel_b[d] & ~(0xFFu << sh)) | (static_cast<uint32_t>(4 + dyn_b) << sh);
+    }
+    const uint32_t rc0 = a.read_cigar_off[r], rc1 = a.read_cigar_off[r + 1];
+    const uint32_t rs0 = a.read_seq_off[r];
+    const int rp = a.read_pos[r];
+#pragma unroll
+    for (int d = 0; d < kPixDw; ++d) {
+      if (d < pdw) {
+        m_const[tid * pdw + d] = konst[d];
+        m_sel_a[tid * pdw + d] = sel_a[d];
+        m_sel_b[tid * pdw + d] = sel_b[d];
+      }
+    }
+    m_c0[tid] = rc0;   // (key_* / kept_* of this slot are dead from here on)
+    m_s0[tid] = rs0;
+    m_rpos[tid] = rp;
+    m_c1[tid] = rc1;
+    m_flags[tid] = flags;
+  }
+  __syncthreads();
+
   // ---------------- phase D: render rows -------------------------------------
   const int row_bytes = W * CO;
   const uint64_t out0 = a.item_out_off[item];
@@ -318,7 +401,6 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   }
   const int n_render = min(max(band + kept, mc_limit), H);
   uint8_t* rb = row_bufs + wave * a.row_buf_bytes;
-  uint8_t* pc = pix_const + wave * DV_MAX_CHANNELS;
   const uint8_t* ref = a.ref_windows + static_cast<size_t>(a.item_ref_idx[item]) * W;
 
   for (int row = wave; row < n_render; row += kWaves) {
@@ -326,7 +408,10 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
     const int s = static_cast<int>(g0 & 3);
     const int ndw = (s + row_bytes + 3) >> 2;
     uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
-    for (int k = lane; k < ndw; k += 64) rb32[k] = 0;
+    const bool read_row = row >= band && row < band + kept;
+    if (!read_row) {  // read rows write every pixel themselves
+      for (int k = lane; k < ndw; k += 64) rb32[k] = 0;
+    }
     wave_sync();
     uint8_t* px = rb + s;
     const int mc_val = (row < mc_limit) ? (row < band ? 255 : 200) : -1;
@@ -336,74 +421,78 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
       for (int col = lane; col < W; col += 64) {
         const uint8_t rbase = ref[col];
         for (int ch = 0; ch < C; ++ch) {
-          uint8_t v = (c->kind[ch] == kBase) ? c->lut_base[rbase]
-                                             : c->ref_const[ch];
+          uint8_t v = (__builtin_amdgcn_readfirstlane(c->kind[ch]) == kBase) ? c->lut_base[rbase]
+                                                                             : c->ref_const[ch];
           if (ch == c->mean_cov_channel && mc_val >= 0) v = mc_val;
           px[col * CO + ch] = v;
         }
       }
-    } else if (row < band + kept) {
-      // wave-uniform: let the compiler keep the read's metadata in SGPRs
+    } else if (read_row) {
+      // wave-uniform metadata of this row's read, precomputed in phase C'
       const int slot = __builtin_amdgcn_readfirstlane(order[row - band]);
-      const uint32_t r = __builtin_amdgcn_readfirstlane(kept_read[slot]);
-      const uint32_t le = l0 + __builtin_amdgcn_readfirstlane(kept_src[slot]);
-      const uint8_t flags = a.read_flags[r];
-      if (lane < C) {  // per-read constant pixels
-        uint8_t v = 0;
-        switch (c->kind[lane]) {
-          case kMapq: v = c->lut_mapq[a.read_mapq[r]]; break;
-          case kStrand: v = c->strand[flags & DV_READ_REVERSE ? 1 : 0]; break;
-          case kSupport: v = c->lut_support[min<int>(a.list_code[le], 3)]; break;
-          case kInsert: {
-            int f = a.read_frag_len[r];
-            f = f < 0 ? -f : f;
-            v = c->lut_insert[min(f, 1000)];
-            break;
-          }
-          case kHaplotype: v = haplotype_pixel(a.read_hp[r], c->polishing); break;
-          case kSupplementary:
-            v = c->supp[flags & DV_READ_SUPPLEMENTARY ? 1 : 0];
-            break;
-          case kAuxRead0: case kAuxRead1: case kAuxRead2: case kAuxRead3:
-            v = a.read_aux ? a.read_aux[static_cast<size_t>(r) * DV_READ_AUX_STRIDE +
-                                        (c->kind[lane] - kAuxRead0)]
-                           : 0;
-            break;
-          case kAuxList: v = a.list_aux ? a.list_aux[le] : 0; break;
-          default: break;
+      const uint32_t flags = __builtin_amdgcn_readfirstlane(m_flags[slot]);
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(m_c0[slot]);
+      const uint32_t c1 = __builtin_amdgcn_readfirstlane(m_c1[slot]);
+      const uint32_t s0 = __builtin_amdgcn_readfirstlane(m_s0[slot]);
+      const int rpos = __builtin_amdgcn_readfirstlane(m_rpos[slot]);
+      uint32_t konst[kPixDw], sel_a[kPixDw], sel_b[kPixDw];
+      bool any_b = false;
+#pragma unroll
+      for (int d = 0; d < kPixDw; ++d) {
+        konst[d] = 0;
+        sel_a[d] = sel_b[d] = 0x03020100u;
+        if (d < pdw) {
+          konst[d] = __builtin_amdgcn_readfirstlane(m_const[slot * pdw + d]);
+          sel_a[d] = __builtin_amdgcn_readfirstlane(m_sel_a[slot * pdw + d]);
+          sel_b[d] = __builtin_amdgcn_readfirstlane(m_sel_b[slot * pdw + d]);
         }
-        pc[lane] = v;
+        any_b |= sel_b[d] != 0x03020100u;
       }
-      wave_sync();
-      const uint32_t c0 = a.read_cigar_off[r], c1 = a.read_cigar_off[r + 1];
-      const uint32_t s0 = a.read_seq_off[r];
-      const int rpos = a.read_pos[r];
-      for (int colb = 0; colb < W; colb += 64) {
-        const int col = colb + lane;
-        const int p = istart + col;  // reference position of this column
-        // Resolve the LAST event drawn on this column.
-        int ev = 0;  // 0 nothing, 1 aligned base, 2 indel anchor
-        int ri = 0;
-        int ref_i = rpos, read_i = 0;
-        for (uint32_t k = c0; k < c1; ++k) {
-          const uint32_t cg = a.cigar[k];
+      const int n_pix_dw = pdw;
+      for (int cb0 = 0; cb0 < W; cb0 += 64 * kColsPerLane) {
+      // One CIGAR walk per pass (one pass for W <= 256): the ops come in with one coalesced vector load and are
+      // broadcast with v_readlane, the running (ref_i, read_i) are wave-uniform (SGPRs),
+      // and every lane resolves the LAST event on each of its kColsPerLane columns
+      // (lane, lane+64, ...) in registers -- the reference overwrites in op order.
+      int ev[kColsPerLane], ri[kColsPerLane];  // ev: 0 nothing, 1 aligned base, 2 indel anchor
+#pragma unroll
+      for (int q = 0; q < kColsPerLane; ++q) {
+        ev[q] = 0;
+        ri[q] = 0;
+      }
+      int ref_i = rpos, read_i = 0;
+      const int n_ops = static_cast<int>(c1 - c0);
+      for (int kb = 0; kb < n_ops; kb += 64) {
+        const uint32_t cg_v = (kb + lane < n_ops) ? a.cigar[c0 + kb + lane] : 0u;
+        const int nk = min(64, n_ops - kb);
+        for (int k = 0; k < nk; ++k) {
+          const uint32_t cg = __builtin_amdgcn_readlane(cg_v, k);
           const int op = cg & 0xF;
           const int len = cg >> 4;
           switch (op) {
             case DV_CIGAR_ALIGNMENT_MATCH:
             case DV_CIGAR_SEQUENCE_MATCH:
             case DV_CIGAR_SEQUENCE_MISMATCH:
-              if (p >= ref_i && p < ref_i + len) {
-                ev = 1;
-                ri = read_i + (p - ref_i);
+#pragma unroll
+              for (int q = 0; q < kColsPerLane; ++q) {
+                const int d = istart + cb0 + q * 64 + lane - ref_i;
+                if (d >= 0 && d < len) {
+                  ev[q] = 1;
+                  ri[q] = read_i + d;
+                }
               }
               ref_i += len;
               read_i += len;
               break;
             case DV_CIGAR_INSERT:
-              if (ref_i > 0 && ref_i - 1 == p) {
-                ev = 2;
-                ri = read_i;
+              if (ref_i > 0) {
+#pragma unroll
+                for (int q = 0; q < kColsPerLane; ++q) {
+                  if (istart + cb0 + q * 64 + lane == ref_i - 1) {
+                    ev[q] = 2;
+                    ri[q] = read_i;
+                  }
+                }
               }
               read_i += len;
               break;
@@ -411,9 +500,14 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
               read_i += len;
               break;
             case DV_CIGAR_DELETE:
-              if (read_i > 0 && ref_i - 1 == p) {
-                ev = 2;
-                ri = read_i - 1;
+              if (read_i > 0) {
+#pragma unroll
+                for (int q = 0; q < kColsPerLane; ++q) {
+                  if (istart + cb0 + q * 64 + lane == ref_i - 1) {
+                    ev[q] = 2;
+                    ri[q] = read_i - 1;
+                  }
+                }
               }
               ref_i += len;
               break;
@@ -424,35 +518,60 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
               break;
           }
         }
-        if (col < W && ev != 0) {
-          const uint8_t base = (ev == 1) ? a.bases[s0 + ri]
-                                         : static_cast<uint8_t>(c->anchor_char);
-          if (base != 0) {
-            const uint8_t q = a.quals[s0 + ri];
-            const uint8_t rbase = ref[col];
-            for (int ch = 0; ch < C; ++ch) {
-              if ((blank_mask >> ch) & 1u) continue;
-              uint8_t v;
-              switch (c->kind[ch]) {
-                case kBase: v = c->lut_base[base]; break;
-                case kBaseQual: v = c->lut_bq[q]; break;
-                case kDiff: v = c->diff[base == rbase ? 1 : 0]; break;
-                case kMeth5:
-                  if (!(flags & DV_READ_HAS_5MC) || !a.mod_5mc) continue;
-                  v = c->lut_mod[a.mod_5mc[s0 + ri]];
-                  break;
-                case kMeth6:
-                  if (!(flags & DV_READ_HAS_6MA) || !a.mod_6ma) continue;
-                  v = c->lut_mod[a.mod_6ma[s0 + ri]];
-                  break;
-                case kZero: v = 0; break;
-                default: v = pc[ch]; break;
-              }
-              px[col * CO + ch] = v;
+      }
+      // bases / quals of all columns first (independent loads in flight), then the pixels
+      uint8_t bb[kColsPerLane], qq[kColsPerLane], rr[kColsPerLane];
+#pragma unroll
+      for (int q = 0; q < kColsPerLane; ++q) {
+        const int col = cb0 + q * 64 + lane;
+        const bool on = col < W && ev[q] != 0;
+        bb[q] = on ? (ev[q] == 1 ? a.bases[s0 + ri[q]] : static_cast<uint8_t>(c->anchor_char)) : 0;
+        qq[q] = on ? a.quals[s0 + ri[q]] : 0;
+        rr[q] = on ? ref[col] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < kColsPerLane; ++q) {
+        const int col = cb0 + q * 64 + lane;
+        if (col >= W) continue;
+        const uint8_t base = bb[q];
+        uint32_t o[kPixDw];
+#pragma unroll
+        for (int d = 0; d < kPixDw; ++d) o[d] = 0;
+        if (base != 0) {  // `read_base &&` (pileup_channel_lib.cc:139): a NUL base draws nothing
+          uint32_t dyn_a = c->lut_base[base] | (static_cast<uint32_t>(c->lut_bq[qq[q]]) << 8) |
+                           (static_cast<uint32_t>(c->diff[base == rr[q] ? 1 : 0]) << 16);
+          if ((flags & DV_READ_HAS_5MC) && a.mod_5mc) {
+            dyn_a |= static_cast<uint32_t>(c->lut_mod[a.mod_5mc[s0 + ri[q]]]) << 24;
+          }
+#pragma unroll
+          for (int d = 0; d < kPixDw; ++d) {
+            if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_a, konst[d], sel_a[d]);
+          }
+          if (any_b) {
+            const uint32_t dyn_b = c->lut_mod[a.mod_6ma[s0 + ri[q]]];
+#pragma unroll
+            for (int d = 0; d < kPixDw; ++d) {
+              if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_b, o[d], sel_b[d]);
             }
           }
         }
+        // every lane writes its whole pixel (zeros where the read draws nothing), so the
+        // row buffer needs no clearing pass
+        uint8_t* dst = px + col * CO;
+        if (CO == 7) {
+          __builtin_memcpy(dst, &o[0], 4);
+          const uint16_t m = static_cast<uint16_t>(o[1]);
+          __builtin_memcpy(dst + 4, &m, 2);
+          dst[6] = static_cast<uint8_t>(o[1] >> 16);
+        } else if (CO == 6) {
+          __builtin_memcpy(dst, &o[0], 4);
+          const uint16_t m = static_cast<uint16_t>(o[1]);
+          __builtin_memcpy(dst + 4, &m, 2);
+        } else {
+          for (int ch = 0; ch < CO; ++ch) dst[ch] = static_cast<uint8_t>(o[ch >> 2] >> ((ch & 3) * 8));
+        }
       }
+      }  // column pass
       if (c->mean_cov_channel >= 0 && mc_val >= 0) {
         for (int col = lane; col < W; col += 64)
           px[col * CO + c->mean_cov_channel] = mc_val;
@@ -750,6 +869,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   a.perm = static_cast<const uint16_t*>(enc->d_perm.ptr);
   a.n_items = b->n_items;
   a.out_channels = out_channels;
+  a.n_channels = enc->konst.n_channels;
   a.row_buf_bytes = static_cast<int>((row_bytes + 8 + 15) & ~size_t(15));
 
   size_t out_bytes = 0;
@@ -861,7 +981,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   a.out_rows = d_rows;
 
   const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
-                     kWaves * DV_MAX_CHANNELS +
+                     3 * static_cast<size_t>(kMaxKept) * ((a.n_channels + 3) / 4) * 4 +
                      static_cast<size_t>(kWaves) * a.row_buf_bytes;
   {
     dv::ProfileScope prof(dv::kProfEncoder, stream);
