@@ -77,6 +77,8 @@ struct alignas(16) EncConst {
   uint8_t pad0[6];
   uint8_t kind[DV_MAX_CHANNELS];
   uint8_t ref_const[DV_MAX_CHANNELS];
+  uint32_t ref_konst[DV_MAX_CHANNELS / 4];  // reference-row pixel: constants, 4 channels per dword
+  uint32_t ref_sel[DV_MAX_CHANNELS / 4];    // v_perm selectors: 4 = base colour, i = constant i
   int32_t n_channels;
   int32_t width;
   int32_t band;
@@ -187,6 +189,23 @@ __device__ bool read_passes_site_gate(const EncArgs& a, const EncConst& c,
     }
   }
   return true;
+}
+
+// Writes one pixel's CO channel bytes (packed 4 per dword in o[]) at an arbitrary byte
+// address of the LDS row buffer.
+__device__ __forceinline__ void store_pixel(uint8_t* dst, const uint32_t (&o)[kPixDw], int CO) {
+  if (CO == 7) {
+    __builtin_memcpy(dst, &o[0], 4);
+    const uint16_t m = static_cast<uint16_t>(o[1]);
+    __builtin_memcpy(dst + 4, &m, 2);
+    dst[6] = static_cast<uint8_t>(o[1] >> 16);
+  } else if (CO == 6) {
+    __builtin_memcpy(dst, &o[0], 4);
+    const uint16_t m = static_cast<uint16_t>(o[1]);
+    __builtin_memcpy(dst + 4, &m, 2);
+  } else {
+    for (int ch = 0; ch < CO; ++ch) dst[ch] = static_cast<uint8_t>(o[ch >> 2] >> ((ch & 3) * 8));
+  }
 }
 
 // HaplotypeTagChannel (channels/haplotype_tag_channel.cc:76-110).
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
     const int ndw = (s + row_bytes + 3) >> 2;
     uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
     const bool read_row = row >= band && row < band + kept;
-    if (!read_row) {  // read rows write every pixel themselves
+    if (!read_row && row >= band) {  // reference and read rows write every pixel themselves
       for (int k = lane; k < ndw; k += 64) rb32[k] = 0;
     }
     wave_sync();
@@ -418,14 +437,23 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
 
     if (row < band) {
       // EncodeReference (pileup_channel_lib.cc:263-293)
+      // pixel = per-channel constants, with the base-colour byte spliced in by v_perm
+      uint32_t rk[kPixDw], rs[kPixDw];
+#pragma unroll
+      for (int d = 0; d < kPixDw; ++d) {
+        rk[d] = __builtin_amdgcn_readfirstlane(c->ref_konst[d]);
+        rs[d] = __builtin_amdgcn_readfirstlane(c->ref_sel[d]);
+      }
       for (int col = lane; col < W; col += 64) {
-        const uint8_t rbase = ref[col];
-        for (int ch = 0; ch < C; ++ch) {
-          uint8_t v = (__builtin_amdgcn_readfirstlane(c->kind[ch]) == kBase) ? c->lut_base[rbase]
-                                                                             : c->ref_const[ch];
-          if (ch == c->mean_cov_channel && mc_val >= 0) v = mc_val;
-          px[col * CO + ch] = v;
-        }
+        const uint32_t bv = c->lut_base[ref[col]];
+        uint32_t o[kPixDw];
+#pragma unroll
+        for (int d = 0; d < kPixDw; ++d) o[d] = __builtin_amdgcn_perm(bv, rk[d], rs[d]);
+        store_pixel(px + col * CO, o, CO);
+      }
+      if (c->mean_cov_channel >= 0 && mc_val >= 0) {
+        for (int col = lane; col < W; col += 64)
+          px[col * CO + c->mean_cov_channel] = mc_val;
       }
     } else if (read_row) {
       // wave-uniform metadata of this row's read, precomputed in phase C'
@@ -557,19 +585,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         }
         // every lane writes its whole pixel (zeros where the read draws nothing), so the
         // row buffer needs no clearing pass
-        uint8_t* dst = px + col * CO;
-        if (CO == 7) {
-          __builtin_memcpy(dst, &o[0], 4);
-          const uint16_t m = static_cast<uint16_t>(o[1]);
-          __builtin_memcpy(dst + 4, &m, 2);
-          dst[6] = static_cast<uint8_t>(o[1] >> 16);
-        } else if (CO == 6) {
-          __builtin_memcpy(dst, &o[0], 4);
-          const uint16_t m = static_cast<uint16_t>(o[1]);
-          __builtin_memcpy(dst + 4, &m, 2);
-        } else {
-          for (int ch = 0; ch < CO; ++ch) dst[ch] = static_cast<uint8_t>(o[ch >> 2] >> ((ch & 3) * 8));
-        }
+        store_pixel(px + col * CO, o, CO);
       }
       }  // column pass
       if (c->mean_cov_channel >= 0 && mc_val >= 0) {
@@ -734,6 +750,18 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
     }
     k->kind[c] = kind;
     k->ref_const[c] = ref;
+  }
+  for (int d = 0; d < DV_MAX_CHANNELS / 4; ++d) {
+    k->ref_konst[d] = 0;
+    k->ref_sel[d] = 0x03020100u;
+  }
+  for (int c = 0; c < o.n_channels; ++c) {
+    const int d = c >> 2, sh = (c & 3) * 8;
+    if (k->kind[c] == kBase) {
+      k->ref_sel[d] = (k->ref_sel[d] & ~(0xFFu << sh)) | (4u << sh);
+    } else {
+      k->ref_konst[d] |= static_cast<uint32_t>(k->ref_const[c]) << sh;
+    }
   }
   return DV_OK;
 }
