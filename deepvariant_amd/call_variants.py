@@ -84,7 +84,7 @@ def example_info_shape(examples_path: str) -> Optional[List[int]]:
   return None
 
 
-def call_variants(examples: str, outfile: str, model, batch_size: int = _DEFAULT_BATCH,
+def call_variants(examples, outfile: str, model, batch_size: int = _DEFAULT_BATCH,
                   max_batches: Optional[int] = None, writer_shards: int = 1,
                   allow_empty_examples: bool = False) -> int:
   """Runs `model` (deepvariant_amd.inception_v3.InceptionV3 with weights
@@ -95,7 +95,7 @@ def call_variants(examples: str, outfile: str, model, batch_size: int = _DEFAULT
   number of records written.
   """
   import torch  # device memory + stream only
-  paths = sharded_paths(examples)
+  paths = list(examples) if isinstance(examples, (list, tuple)) else sharded_paths(examples)
   stem, ext = outfile, ''
   for e in ('.tfrecord.gz', '.tfrecord'):
     if outfile.endswith(e):
@@ -140,3 +140,102 @@ def call_variants(examples: str, outfile: str, model, batch_size: int = _DEFAULT
     # call_variants.py:793-808
     raise ValueError('No examples found in %s' % examples)
   return n_written
+
+
+# ---------------------------------------------------------------------------
+# Command line: the reference's flag names (deepvariant/call_variants.py:88-224).
+# Flags whose machinery is not part of this hot path are accepted when they are
+# no-ops here and rejected -- never silently ignored -- when they would change
+# the output.
+# ---------------------------------------------------------------------------
+def build_arg_parser():
+  import argparse
+  ap = argparse.ArgumentParser(
+      prog='call_variants', allow_abbrev=False,
+      description='MI355X call_variants: tf.Example TFRecords -> CallVariantsOutput TFRecords')
+  boolean = dict(nargs='?', const='true', default='false')
+  ap.add_argument('--examples', required=True)
+  ap.add_argument('--outfile', required=True)
+  ap.add_argument('--checkpoint', required=True,
+                  help='flat fp32 weights (.npy / .bin, layout of dv_model_load_weights) or '
+                       '"random:<seed>"; TensorFlow checkpoint bundles are not read')
+  ap.add_argument('--batch_size', type=int, default=_DEFAULT_BATCH)
+  ap.add_argument('--max_batches', type=int, default=None)
+  ap.add_argument('--num_readers', type=int, default=8)          # tf.data knob: no-op
+  ap.add_argument('--include_debug_info', **boolean)
+  ap.add_argument('--activation_layers', default='')
+  ap.add_argument('--debugging_true_label_mode', **boolean)
+  ap.add_argument('--execution_hardware', default='auto')
+  ap.add_argument('--config_string', default=None)               # XLA/TPU knob: no-op
+  ap.add_argument('--kmp_blocktime', default='0')                # MKL knob: no-op
+  ap.add_argument('--writer_threads', type=int, default=0)
+  ap.add_argument('--limit', type=int, default=0)
+  ap.add_argument('--num_input_shards', type=int, default=0)
+  ap.add_argument('--shm_prefix', default='')
+  ap.add_argument('--stream_examples', **boolean)
+  ap.add_argument('--allow_empty_examples', **boolean)
+  ap.add_argument('--device', type=int, default=0)
+  return ap
+
+
+def _flag_true(v) -> bool:
+  return str(v).lower() in ('1', 'true', 't', 'yes')
+
+
+def check_flags(args):
+  """Raises ValueError for flag values this implementation cannot honour."""
+  if args.execution_hardware not in ('auto', 'accelerator'):
+    # call_variants.py:66-77: 'cpu' would run the TF graph on host cores
+    raise ValueError('--execution_hardware=%s: this build has no CPU path '
+                     '(use auto or accelerator)' % args.execution_hardware)
+  for name in ('include_debug_info', 'debugging_true_label_mode', 'stream_examples'):
+    if _flag_true(getattr(args, name)):
+      raise ValueError('--%s is not supported by the MI355X call_variants' % name)
+  if args.activation_layers:
+    raise ValueError('--activation_layers is not supported')
+  if args.shm_prefix:
+    raise ValueError('--shm_prefix (stream_examples) is not supported')
+  if args.batch_size < 1:
+    raise ValueError('--batch_size must be positive')
+
+
+def load_flat_checkpoint(spec: str, model):
+  """--checkpoint: `random:<seed>` or a flat fp32 array in dv_model_load_weights order."""
+  if spec.startswith('random:'):
+    model.init_random(seed=int(spec.split(':', 1)[1]))
+    return
+  if os.path.isdir(spec) or os.path.exists(spec + '.index'):
+    raise ValueError('TensorFlow checkpoint bundles are not read here; export the weights '
+                     'to the flat layout documented in include/dvhip.h')
+  flat = np.load(spec) if spec.endswith('.npy') else np.fromfile(spec, np.float32)
+  model.load_flat_weights(np.ascontiguousarray(flat, np.float32))
+
+
+def main(argv=None) -> int:
+  args = build_arg_parser().parse_args(argv)
+  check_flags(args)
+  paths = sharded_paths(args.examples)
+  if args.num_input_shards:
+    paths = paths[:args.num_input_shards]        # call_variants.py:115-120
+  shape = example_info_shape(paths[0]) if paths else None
+  if shape is None:
+    raise ValueError('%s.example_info.json is missing: the model shape comes from it '
+                     '(call_variants.py:704-733)' % (paths[0] if paths else args.examples))
+  from deepvariant_amd.inception_v3 import InceptionV3
+  model = InceptionV3(tuple(shape), max_batch=min(args.batch_size, 8192), device=args.device)
+  load_flat_checkpoint(args.checkpoint, model)
+  max_batches = args.max_batches
+  if args.limit:                                  # --limit N examples (call_variants.py:112)
+    lim = (args.limit + args.batch_size - 1) // args.batch_size
+    max_batches = lim if max_batches is None else min(max_batches, lim)
+  n = call_variants(paths, args.outfile, model,
+                    batch_size=args.batch_size, max_batches=max_batches,
+                    writer_shards=max(1, min(args.writer_threads or 1, 16)),
+                    allow_empty_examples=_flag_true(args.allow_empty_examples))
+  print('call_variants: wrote %d CallVariantsOutput records' % n)
+  return 0
+
+
+if __name__ == '__main__':
+  import sys
+  sys.exit(main())

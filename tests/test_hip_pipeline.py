@@ -109,3 +109,14 @@ def test_make_examples_then_call_variants(tmp_path):
     assert abs(sum(probs) - 1.0) < 1e-6 and len(probs) == 3
     assert max(abs(p - w) for p, w in zip(probs, want_p[k])) <= 1e-3 + 1e-9
     assert variant.start == examples[k]['call'].variant.start
+
+  # the command line (reference flag names) writes the same records
+  flat = str(tmp_path / 'weights.npy')
+  np.save(flat, ref.export_flat())
+  out2 = str(tmp_path / 'cli.tfrecord.gz')
+  assert cv.main(['--examples', ex_path, '--outfile', out2, '--checkpoint', flat,
+                  '--batch_size', '32', '--writer_threads', '2', '--num_readers', '4']) == 0
+  for i in range(2):
+    a = list(tfrecord.read_tfrecords(shards[i]))
+    b = list(tfrecord.read_tfrecords(str(tmp_path / ('cli-%05d-of-00002.tfrecord.gz' % i))))
+    assert a == b
