@@ -424,7 +424,10 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
 
   for (int row = wave; row < n_render; row += kWaves) {
     const uint64_t g0 = out0 + static_cast<uint64_t>(row) * row_bytes;
-    const int s = static_cast<int>(g0 & 3);
+    // the row is staged at the byte phase of its global address so that it leaves as
+    // aligned 16-byte pieces
+    const uint64_t gaddr = reinterpret_cast<uint64_t>(a.out) + g0;
+    const int s = static_cast<int>(gaddr & 15);
     const int ndw = (s + row_bytes + 3) >> 2;
     uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
     const bool read_row = row >= band && row < band + kept;
@@ -598,20 +601,24 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         px[col * CO + c->mean_cov_channel] = mc_val;
     }
     wave_sync();
-    // LDS row -> HBM: aligned dwords; the (<= 3 byte) ragged ends of the row
-    // go out as byte stores so neighbouring rows never race on a dword.
-    uint8_t* gbase = a.out + (g0 - s);
-    for (int k = lane; k < ndw; k += 64) {
-      const int lo = 4 * k - s;
-      const uint32_t v = rb32[k];
-      if (lo >= 0 && lo + 4 <= row_bytes) {
-        *reinterpret_cast<uint32_t*>(gbase + 4 * k) = v;
-      } else {
-        for (int b = 0; b < 4; ++b) {
-          const int idx = lo + b;
-          if (idx >= 0 && idx < row_bytes) gbase[4 * k + b] = (v >> (8 * b)) & 0xFF;
+    // LDS row -> HBM: aligned 16-byte pieces; the (<= 15 byte) ragged ends of the row
+    // go out as byte stores so neighbouring rows never race on a piece.
+    {
+      uint8_t* gbase = reinterpret_cast<uint8_t*>(gaddr - s);
+      const int npc = (s + row_bytes + 15) >> 4;
+      const uint4* rb128 = reinterpret_cast<const uint4*>(rb);
+      for (int k = lane; k < npc; k += 64) {
+        const int lo = 16 * k - s;
+        if (lo >= 0 && lo + 16 <= row_bytes) {
+          *reinterpret_cast<uint4*>(gbase + 16 * k) = rb128[k];
         }
       }
+      // head: bytes [0, head) of the row; tail: bytes [tail0, row_bytes)
+      const int head = min((16 - s) & 15, row_bytes);
+      const int tail0 = max(head, ((s + row_bytes) & ~15) - s);
+      if (lane < head) gbase[s + lane] = rb[s + lane];
+      const int t = tail0 + lane - 16;  // lanes 16..31 take the tail
+      if (lane >= 16 && lane < 32 && t < row_bytes) gbase[s + t] = rb[s + t];
     }
     wave_sync();
   }
@@ -898,7 +905,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   a.n_items = b->n_items;
   a.out_channels = out_channels;
   a.n_channels = enc->konst.n_channels;
-  a.row_buf_bytes = static_cast<int>((row_bytes + 8 + 15) & ~size_t(15));
+  a.row_buf_bytes = static_cast<int>((row_bytes + 16 + 15) & ~size_t(15));
 
   size_t out_bytes = 0;
   if (b->memory == DV_MEM_HOST) {
