@@ -170,6 +170,7 @@ def main():
     bytes_per_item = algorithmic_bytes_per_item(host_batch, C)
     enc_gbs = (bytes_per_item * n_items * args.steps / (enc_ms * 1e-3) / 1e9
                if enc_ms > 0 else 0.0)
+    conv_traffic, enc_traffic, traffic_note = pmc_traffic(n_items)
     out = {
         'metric': 'candidate pileups/sec (encode+CNN)',
         'value': value,
@@ -198,7 +199,8 @@ def main():
             'peak': MFMA_F16_PEAK_TFLOPS,
             'unit': 'TFLOP/s',
             'frac': conv_tflops / MFMA_F16_PEAK_TFLOPS,
-            'traffic': None,
+            'traffic': conv_traffic,
+            'traffic_note': traffic_note,
             'flops_per_candidate': conv_flops_per_item,
             'avg_launch_ms': conv_ms / max(conv_launches, 1),
             'launches': conv_launches,
@@ -212,7 +214,7 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': enc_gbs / HBM_PEAK_GBS,
-            'traffic': None,
+            'traffic': enc_traffic,
             'bytes_per_candidate': bytes_per_item,
             'avg_launch_ms': enc_ms / max(enc_launches, 1),
             'launches': enc_launches,
@@ -226,6 +228,25 @@ def main():
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def pmc_traffic(n_items):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
+  gfx950 x2 correction + WRITE_SIZE; profiles/r01p_pmc_hbm_traffic.txt).  bench.py cannot
+  run the counter passes itself, so this is only reported for the batch they were taken at."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                      'r01p_pmc_traffic.json')
+  try:
+    with open(path) as f:
+      t = json.load(f)
+  except (OSError, ValueError):
+    return None, None, None
+  if t.get('candidates_per_step') != n_items:
+    return None, None, 'PMC passes were taken at %s candidates/step' % t.get('candidates_per_step')
+  c, e = t['conv'], t['encoder']
+  conv = (c['fetch_bytes_per_pass_x2'] + c['write_bytes_per_pass']) / c['launches_per_pass']
+  enc = e['fetch_bytes_per_launch_x2'] + e['write_bytes_per_launch']
+  return conv, enc, 'bytes per launch, separate rocprofv3 --pmc passes: ' + t['source']
 
 
 def cpu_baseline(host_batch, opts, C, sample):
