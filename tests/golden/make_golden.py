@@ -128,5 +128,145 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'pacbio' not in sys.argv[1:]:
   main()
+
+
+# ---------------------------------------------------------------------------
+# PacBio golden (BASELINE.json configs[3] shape)
+#   deepvariant/testdata/golden.pacbio_examples.tfrecord.gz     401 x [100,147,10]
+#   deepvariant/testdata/input/test_pacbio.chr20_100kbp_at_9mb.bam  (285 HiFi reads)
+#   deepvariant/testdata/input/grch38.chr20_and_21_10M.fa.gz
+#   flags: deepvariant/make_examples_test.py:794-818 (8 encoder channels = default 6 +
+#   haplotype + base_methylation, + 2 alt-aligned diff channels; realigner OFF,
+#   min_mapping_quality 1, width 147, trim_reads_for_pileup, direct phasing).
+# The candidates (allele_support) and the phasing (HP) are not in the testdata, so the
+# fixture pins what the raw BAM + FASTA determine: all 8 encoder channels of the
+# reference-band rows, and channels {read_base, base_quality, mapping_quality, strand,
+# base_differs_from_ref} of every read row.  Reads are clipped to the window +-20 bp here
+# (the reference trims them too; in-window pixels do not change), which keeps the fixture
+# small.
+# ---------------------------------------------------------------------------
+PACBIO_CHANNELS = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype', 'base_methylation']
+PACBIO_CHECKED = [0, 1, 2, 3, 5]   # indices of the pinned read-row channels
+
+
+def pacbio_options():
+  rr = T.ReadRequirements(min_mapping_quality=1, min_base_quality=10, min_base_quality_mode=1)
+  o = T.default_options(rr)
+  o.channels = list(PACBIO_CHANNELS)
+  o.num_channels = len(o.channels)
+  o.width = 147
+  o.sort_by_haplotypes = True
+  return o
+
+
+def clip_read(read, lo, hi):
+  """The part of `read` aligned to reference [lo, hi): new position, CIGAR, bases, quals.
+  Indels are kept when they start inside the interval (their anchor pixel is drawn at the
+  base before them, whatever follows)."""
+  ref_i = read.alignment.position.position
+  read_i = 0
+  new_pos = None
+  cigar, s_lo, s_hi = [], None, None
+
+  def take(op, ln, r0, n_read):
+    nonlocal s_lo, s_hi
+    if n_read:
+      s_lo = r0 if s_lo is None else s_lo
+      s_hi = r0 + n_read
+    if cigar and cigar[-1].operation == op:
+      cigar[-1] = T.CigarUnit(op, cigar[-1].operation_length + ln)
+    else:
+      cigar.append(T.CigarUnit(op, ln))
+
+  for cu in read.alignment.cigar:
+    op, ln = cu.operation, cu.operation_length
+    if op in (1, 8, 9):
+      a, b = max(ref_i, lo), min(ref_i + ln, hi)
+      if b > a:
+        if new_pos is None:
+          new_pos = a
+        take(op, b - a, read_i + (a - ref_i), b - a)
+      ref_i += ln
+      read_i += ln
+    elif op == 2:
+      if new_pos is not None and lo < ref_i < hi:
+        take(op, ln, read_i, ln)
+      read_i += ln
+    elif op in (3, 4):
+      if new_pos is not None and lo < ref_i < hi:   # its anchor pixel sits at ref_i - 1
+        take(op, ln, read_i, 0)
+      ref_i += ln
+    elif op == 5:
+      read_i += ln
+  if new_pos is None:
+    return None
+  out = T.Read(
+      fragment_name=read.fragment_name, read_number=read.read_number,
+      number_reads=read.number_reads, fragment_length=read.fragment_length,
+      aligned_sequence=read.aligned_sequence[s_lo:s_hi],
+      aligned_quality=bytes(bytearray(read.aligned_quality))[s_lo:s_hi],
+      alignment=T.LinearAlignment(
+          position=T.Position(read.alignment.position.reference_name, new_pos,
+                              read.alignment.position.reverse_strand),
+          mapping_quality=read.alignment.mapping_quality, cigar=cigar))
+  return out
+
+
+def main_pacbio(n_keep=120):
+  opts = pacbio_options()
+  hw = (opts.width - 1) // 2
+  band = opts.reference_band_height
+  fasta = genomics_io.FastaReader(os.path.join(REF, 'input/grch38.chr20_and_21_10M.fa.gz'))
+  _, reads = genomics_io.read_bam(
+      os.path.join(REF, 'input/test_pacbio.chr20_100kbp_at_9mb.bam'), 'chr20',
+      8_900_000, 9_200_000)
+  reads = [r for r in reads if not (r.duplicate_fragment or r.failed_vendor_quality_checks or
+                                    r.secondary_alignment or r.supplementary_alignment)
+           and r.alignment.mapping_quality >= 1]
+  examples_all = list(tfrecord.read_tfrecords(
+      os.path.join(REF, 'golden.pacbio_examples.tfrecord.gz'), verify_crc=True))
+  n_rows = n_match = n_ref_ok = 0
+  kept_examples, kept_reads = [], []
+  step = max(1, len(examples_all) // n_keep)
+  for k, rec in enumerate(examples_all):
+    ex = pw.decode_example(rec)
+    shape = ex['image/shape']
+    img = np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(shape)
+    v = pw.decode_variant(ex['variant/encoded'][0])
+    start = v.start - hw
+    window = fasta.get_bases(v.reference_name, start, start + opts.width)
+    call = T.DeepVariantCall(variant=v)
+    q0, q1 = v.start - opts.read_overlap_buffer_bp, v.end + opts.read_overlap_buffer_bp
+    clipped = []
+    for r in reads:
+      if O.read_overlaps(r, q0, q1):
+        c = clip_read(r, start - 20, start + opts.width + 20)
+        if c is not None:
+          clipped.append(c)
+    ref_row = O.encode_reference(opts, window)
+    n_ref_ok += int(all((img[r, :, :8] == ref_row[0]).all() for r in range(band)))
+    ours = set()
+    for r in clipped:
+      row = O.encode_read(opts, call, window, r, start, [])
+      if row is not None:
+        ours.add(row[0][:, PACBIO_CHECKED].tobytes())
+    gold = [r for r in range(band, shape[0]) if img[r, :, PACBIO_CHECKED].any()]
+    n_rows += len(gold)
+    n_match += sum(np.ascontiguousarray(img[r][:, PACBIO_CHECKED]).tobytes() in ours for r in gold)
+    if k % step == 0:
+      kept_examples.append(dict(call=call, alt_alleles=[], ref_window=window,
+                                read_idx=list(range(len(kept_reads), len(kept_reads) + len(clipped))),
+                                image=img, full=False))
+      kept_reads.extend(clipped)
+  print('pacbio images', len(examples_all), 'ref-band exact', n_ref_ok, 'read rows', n_rows,
+        'matched', n_match, '(%.2f%%)' % (100.0 * n_match / max(n_rows, 1)),
+        'kept', len(kept_examples), 'examples /', len(kept_reads), 'clipped reads')
+  golden_io.save(
+      os.path.join(ROOT, 'tests/golden/pacbio_chr20.npz'), kept_reads, kept_examples,
+      stats=np.array([len(examples_all), n_ref_ok, n_rows, n_match], np.int64))
+
+
+if __name__ == '__main__' and 'pacbio' in sys.argv[1:]:
+  main_pacbio()

@@ -48,3 +48,47 @@ def test_golden_batch_bit_exact():
       np.testing.assert_array_equal(got[i], ex['image'])
       n_full += 1
   assert n_full == 7
+
+
+def test_pacbio_golden_rows_hip():
+  """Real HiFi reads ('=' / 'X' / I / D CIGARs, W = 147, 8 channels): every read of the
+  134 fixture examples goes through ONE dv_encode_batch call as an EncodeRead item; the
+  rows must equal the oracle's bit for bit and contain every golden read row."""
+  from deepvariant_amd import packing
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  from tests.golden.make_golden import pacbio_options
+  from tests.test_oracle_golden import PACBIO_FIXTURE, check_pacbio_example
+  from tests.golden.make_golden import PACBIO_CHECKED
+  reads, examples, _ = golden_io.load(PACBIO_FIXTURE)
+  opts = pacbio_options()
+  band, w, c = opts.reference_band_height, opts.width, 8
+  hw = (w - 1) // 2
+  table = packing.ReadTable.from_reads(reads)
+  batch = packing.PackedBatch(table=table, width=w)
+  item_bytes = (band + 1) * w * c
+  owner = []
+  for e, ex in enumerate(examples):
+    call = ex['call']
+    ref_idx = batch.add_ref_window(ex['ref_window'])
+    for k in ex['read_idx']:
+      idx = np.array([k], np.uint32)
+      batch.add_item(call.variant.start, call.variant.start - hw, ref_idx, idx,
+                     np.zeros(1, np.uint8), height=band + 1, out_off=len(owner) * item_bytes)
+      owner.append(e)
+  out, rows = _Encoder(opts, w).encode(batch, c)
+  want, want_rows = O.encode_packed(opts, batch, c, n_threads=8)
+  np.testing.assert_array_equal(rows, want_rows)
+  np.testing.assert_array_equal(out, want)
+  got = out.reshape(len(owner), band + 1, w, c)
+  per_example = [set() for _ in examples]
+  for i, e in enumerate(owner):
+    if rows[i]:
+      per_example[e].add(np.ascontiguousarray(got[i, band][:, PACBIO_CHECKED]).tobytes())
+  n_rows = n_hit = 0
+  for e, ex in enumerate(examples):
+    a, b = check_pacbio_example(opts, ex, per_example[e], got[[o for o in range(len(owner)) if owner[o] == e][0], 0:1]
+                                if ex['read_idx'] else O.encode_reference(opts, ex['ref_window']))
+    n_rows += a
+    n_hit += b
+  assert n_hit == n_rows and n_rows > 4000

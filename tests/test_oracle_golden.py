@@ -54,3 +54,56 @@ def test_golden_illumina_images(golden):
   # of rows are untouched by the (not yet restated) realigner.
   assert n_match == 3467
   assert n_full == 7
+
+
+# ---------------------------------------------------------------------------
+# PacBio golden (BASELINE.json configs[3] shape: 100x147x10, realigner OFF).
+# Fixture: tests/golden/pacbio_chr20.npz from golden.pacbio_examples.tfrecord.gz +
+# test_pacbio.chr20_100kbp_at_9mb.bam + grch38.chr20_and_21_10M.fa.gz
+# (tests/golden/make_golden.py pacbio).  Pinned: all 8 encoder channels of the reference
+# band, and {read_base, base_quality, mapping_quality, strand, base_differs_from_ref} of
+# every read row ('=' / 'X' / I / D CIGARs of real HiFi reads); haplotype / support /
+# methylation / the two alt-aligned channels need inputs the testdata does not carry.
+# ---------------------------------------------------------------------------
+PACBIO_FIXTURE = os.path.join(os.path.dirname(__file__), 'golden', 'pacbio_chr20.npz')
+
+
+def pacbio_rows(opts, reads, ex, encode_read):
+  from tests.golden.make_golden import PACBIO_CHECKED
+  call = ex['call']
+  start = call.variant.start - (opts.width - 1) // 2
+  ours = set()
+  for k in ex['read_idx']:
+    row = encode_read(call, ex['ref_window'], reads[k], start)
+    if row is not None:
+      ours.add(np.ascontiguousarray(row[0][:, PACBIO_CHECKED]).tobytes())
+  return ours
+
+
+def check_pacbio_example(opts, ex, ours, ref_row):
+  from tests.golden.make_golden import PACBIO_CHECKED
+  img = ex['image']
+  assert img.shape == (100, 147, 10)
+  band = opts.reference_band_height
+  for r in range(band):
+    np.testing.assert_array_equal(img[r, :, :8], ref_row[0])
+  gold = [r for r in range(band, 100) if img[r][:, PACBIO_CHECKED].any()]
+  hits = sum(np.ascontiguousarray(img[r][:, PACBIO_CHECKED]).tobytes() in ours for r in gold)
+  return len(gold), hits
+
+
+def test_golden_pacbio_rows():
+  from tests.golden.make_golden import pacbio_options
+  reads, examples, z = golden_io.load(PACBIO_FIXTURE)
+  # what make_golden.py measured over ALL 401 golden images (= SURVEY 8c's numbers)
+  assert z['stats'].tolist() == [401, 401, 13689, 13689]
+  opts = pacbio_options()
+  n_rows = n_hit = 0
+  for ex in examples:
+    ours = pacbio_rows(opts, reads, ex,
+                       lambda call, win, rd, start: O.encode_read(opts, call, win, rd, start, []))
+    a, b = check_pacbio_example(opts, ex, ours, O.encode_reference(opts, ex['ref_window']))
+    n_rows += a
+    n_hit += b
+  assert len(examples) == 134 and n_rows > 4000
+  assert n_hit == n_rows
