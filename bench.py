@@ -109,6 +109,11 @@ def main():
     send = torch.zeros((max_n, 4), dtype=torch.float32, device=dev)
     recv = torch.empty((world * max_n, 4), dtype=torch.float32, device=dev)
 
+  # A real (non-default) HIP stream: dv_model_infer replays the forward as one hipGraph
+  # on it (the legacy default stream cannot be captured and runs eagerly).
+  work = torch.cuda.Stream(device=dev)
+  torch.cuda.set_stream(work)
+
   def step():
     dbatch.encode(enc, C, images, rows)
     probs = model(images)

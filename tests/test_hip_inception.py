@@ -106,3 +106,25 @@ def test_large_batch_addresses_past_4gib():
   small.init_random(seed=7)
   want = small(base).cpu()
   assert (got - want[None]).abs().max().item() <= 1e-6
+
+
+def test_graph_replay_on_a_side_stream_matches_eager():
+  """On a non-default stream dv_model_infer captures the forward once and replays it as a
+  hipGraph; on the legacy default stream it launches eagerly.  Same bytes either way."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  model = InceptionV3((100, 221, 7), max_batch=16)
+  model.init_random(seed=3)
+  rng = np.random.default_rng(9)
+  x1 = torch.from_numpy(rng.integers(0, 256, (16, 100, 221, 7), dtype=np.uint8)).cuda()
+  eager = model(x1).clone()
+  s = torch.cuda.Stream()
+  with torch.cuda.stream(s):
+    first = model(x1).clone()       # capture + first launch
+    x1.copy_(torch.from_numpy(rng.integers(0, 256, (16, 100, 221, 7), dtype=np.uint8)))
+    second = model(x1).clone()      # replay of the same graph on new pixels
+  s.synchronize()
+  eager2 = model(x1).clone()
+  torch.cuda.synchronize()
+  assert torch.equal(first.cpu(), eager.cpu())
+  assert torch.equal(second.cpu(), eager2.cpu())
+  assert not torch.equal(first.cpu(), second.cpu())
