@@ -749,7 +749,6 @@ struct Op {
   int group_followers = 0;       // conv: the next k ops are siblings sharing this launch
   bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
-  int lane = 0;                  // stream lane: independent Inception branches run concurrently
 };
 
 struct LayerInfo {
@@ -780,25 +779,6 @@ struct dv_model {
     hipGraphExec_t exec;
   };
   std::vector<GraphEntry> graphs;  // captured forwards, see dv_model_infer
-  // Branch lanes: the branches of an Inception block are independent once the grouped
-  // 1x1 launch is done.  Lane 0 is the caller's stream; lanes 1..3 are side streams
-  // forked/joined with events, so the tail of one branch's launch (a half-empty last
-  // round of workgroups) is filled by another branch's blocks.
-  static constexpr int kLanes = 4;
-  int cur_lane = 0;                        // builder state
-  hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> events;          // reused every forward
-  size_t next_event = 0;
-  bool lanes_active = false;
-  std::vector<std::vector<std::pair<int, hipEvent_t>>> writers;  // per buffer: (lane, done event)
-  hipEvent_t take_event() {
-    if (next_event == events.size()) {
-      hipEvent_t e = nullptr;
-      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-      events.push_back(e);
-    }
-    return events[next_event++];
-  }
 
   // ---- builder ------------------------------------------------------------
   int new_buffer(int h, int w, int c) {
@@ -846,7 +826,6 @@ struct dv_model {
     op.out_buf = dst_buf;
     op.out_coff = dst_coff;
     op.nb = pick_nb(cout);
-    op.lane = cur_lane;
     op.n_chunks = kh * kw * (x.c / kChunk);
     op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;  // weight slabs
     op.shift_off = shift_floats;
@@ -880,7 +859,6 @@ struct dv_model {
   void pooled_projection(TensorRef x, int cout, int dst_buf, int dst_coff) {
     TensorRef raw = conv(x, cout, 1, 1);
     ops.back().raw = true;                   // no shift, no ReLU in the conv epilogue
-    ops.back().lane = 0;                     // rides in the block's grouped 1x1 launch
     const size_t shift_off = ops.back().shift_off;
     pool(kOpAvgPool, raw, dst_buf, dst_coff);
     ops.back().shift_off = shift_off;        // applied after the pool
@@ -907,7 +885,6 @@ struct dv_model {
     }
     op.out_buf = dst_buf;
     op.out_coff = dst_coff;
-    op.lane = cur_lane;
     ops.push_back(op);
     TensorRef out;
     out.buf = dst_buf;
@@ -980,90 +957,62 @@ struct dv_model {
     stem_out_buf = x.buf;
     for (int pool_ch : {32, 64, 64}) {  // mixed0..2
       const int out = new_buffer(x.h, x.w, 64 + 64 + 96 + pool_ch);
-      cur_lane = 0;
       conv(x, 64, 1, 1, 1, true, out, 0);
       TensorRef b5 = conv(x, 48, 1, 1);
-      cur_lane = 1;
       conv(b5, 64, 5, 5, 1, true, out, 64);
-      cur_lane = 0;
       TensorRef b3 = conv(x, 64, 1, 1);
-      cur_lane = 2;
       b3 = conv(b3, 96, 3, 3);
       conv(b3, 96, 3, 3, 1, true, out, 128);
-      cur_lane = 3;
       pooled_projection(x, pool_ch, out, 224);
-      cur_lane = 0;
       x = full(out);
     }
     {  // mixed3
       const int oh = (x.h - 3) / 2 + 1, ow = (x.w - 3) / 2 + 1;
       const int out = new_buffer(oh, ow, 384 + 96 + x.c);
-      cur_lane = 0;
       conv(x, 384, 3, 3, 2, false, out, 0);
-      cur_lane = 1;
       TensorRef b = conv(x, 64, 1, 1);
       b = conv(b, 96, 3, 3);
       conv(b, 96, 3, 3, 2, false, out, 384);
-      cur_lane = 2;
       pool(kOpMaxPool, x, out, 480);
-      cur_lane = 0;
       x = full(out);
     }
     for (int c7 : {128, 160, 160, 192}) {  // mixed4..7
       const int out = new_buffer(x.h, x.w, 768);
-      cur_lane = 0;
       conv(x, 192, 1, 1, 1, true, out, 0);
       TensorRef b = conv(x, c7, 1, 1);
-      cur_lane = 1;
       b = conv(b, c7, 1, 7);
       conv(b, 192, 7, 1, 1, true, out, 192);
-      cur_lane = 0;
       TensorRef d = conv(x, c7, 1, 1);
-      cur_lane = 2;
       d = conv(d, c7, 7, 1);
       d = conv(d, c7, 1, 7);
       d = conv(d, c7, 7, 1);
       conv(d, 192, 1, 7, 1, true, out, 384);
-      cur_lane = 3;
       pooled_projection(x, 192, out, 576);
-      cur_lane = 0;
       x = full(out);
     }
     {  // mixed8
       const int oh = (x.h - 3) / 2 + 1, ow = (x.w - 3) / 2 + 1;
       const int out = new_buffer(oh, ow, 320 + 192 + x.c);
-      cur_lane = 0;
       TensorRef b = conv(x, 192, 1, 1);
       conv(b, 320, 3, 3, 2, false, out, 0);
       TensorRef d = conv(x, 192, 1, 1);
-      cur_lane = 1;
       d = conv(d, 192, 1, 7);
       d = conv(d, 192, 7, 1);
       conv(d, 192, 3, 3, 2, false, out, 320);
-      cur_lane = 2;
       pool(kOpMaxPool, x, out, 512);
-      cur_lane = 0;
       x = full(out);
     }
     for (int i = 0; i < 2; ++i) {  // mixed9, mixed10
       const int out = new_buffer(x.h, x.w, 2048);
-      cur_lane = 0;
       conv(x, 320, 1, 1, 1, true, out, 0);
       TensorRef b = conv(x, 384, 1, 1);
-      cur_lane = 1;
       conv(b, 384, 1, 3, 1, true, out, 320);
-      cur_lane = 2;
       conv(b, 384, 3, 1, 1, true, out, 704);
-      cur_lane = 0;
       TensorRef d = conv(x, 448, 1, 1);
-      cur_lane = 3;
       d = conv(d, 384, 3, 3);
       conv(d, 384, 1, 3, 1, true, out, 1088);
-      cur_lane = 1;
       conv(d, 384, 3, 1, 1, true, out, 1472);
-      cur_lane = 2;
       pooled_projection(x, 192, out, 1856);
-      cur_lane = 0;
       x = full(out);
     }
     feat_buf = x.buf;
@@ -1153,19 +1102,10 @@ void dump_trace(hipStream_t stream) {
   g_trace->clear();
 }
 
-int run_ops(dv_model* m, int first, int last, int n, hipStream_t main_stream,
+int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
             int shifted_buf = -1, int out_example_off = 0, const uint8_t* images = nullptr) {
   for (int oi = first; oi < last; ++oi) {
     const Op& op = m->ops[oi];
-    // lane stream + cross-lane dependencies (see dv_model::lanes_active)
-    const int lane = m->lanes_active ? op.lane : 0;
-    hipStream_t stream = lane == 0 ? main_stream : m->side[lane - 1];
-    if (m->lanes_active) {
-      for (const auto& w : m->writers[op.in_buf]) {
-        if (w.first != lane) DV_HIP_CHECK(hipStreamWaitEvent(stream, w.second, 0));
-      }
-    }
-    const int launch_first = oi;
     const BufferDesc& ob = m->buffers[op.out_buf];
     const size_t out_shift_halfs =
         op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
@@ -1285,13 +1225,6 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t main_stream,
         hipLaunchKernelGGL(avgpool3s1_kernel, grid, dim3(256), 0, stream, p);
       }
     }
-    if (m->lanes_active) {
-      hipEvent_t done = m->take_event();
-      DV_HIP_CHECK(hipEventRecord(done, stream));
-      for (int k = launch_first; k <= oi; ++k) {  // oi was advanced past grouped followers
-        m->writers[m->ops[k].out_buf].push_back({lane, done});
-      }
-    }
   }
   DV_HIP_CHECK(hipGetLastError());
   return DV_OK;
@@ -1347,10 +1280,6 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
     if (int rc = m->dbuf[i].reserve(bytes)) return rc;
     DV_HIP_CHECK(hipMemset(m->dbuf[i].ptr, 0, bytes));  // halos stay zero forever
   }
-  // side streams + events are made here, never inside a stream capture
-  for (hipStream_t& s : m->side) DV_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  for (size_t i = 0; i < m->ops.size() + 16; ++i) (void)m->take_event();
-  m->next_event = 0;
   if (int rc = m->d_w.reserve(m->packed_halfs * 2)) return rc;
   if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
@@ -1369,10 +1298,6 @@ void dv_model_destroy(dv_model* m) {
   m->d_dense_b.release();
   m->d_tbl.release();
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-  for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
-  for (hipStream_t s : m->side) {
-    if (s) (void)hipStreamDestroy(s);
-  }
   delete m;
 }
 
@@ -1504,19 +1429,8 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
   // split evenly so that no launch is left with a sliver of a batch
   const int n_parts = (n + m->desc.max_batch - 1) / m->desc.max_batch;
   const int part = n_parts ? (n + n_parts - 1) / n_parts : 0;
-  // Opt-in (DV_LANES=1): measured 3 % SLOWER on MI355X at 2 K candidates/step -- launches
-  // from different lanes do overlap, but they evict each other's L2 working set.
-  static const bool lanes = getenv("DV_LANES") != nullptr;
-  m->lanes_active = lanes && !dv::profiling_enabled() && g_trace == nullptr;
   for (int done = 0; done < n; done += part) {
     const int nb = std::min(part, n - done);
-    if (m->lanes_active) {  // fork: side lanes start after everything already on `stream`
-      m->next_event = 0;
-      m->writers.assign(m->buffers.size(), {});
-      hipEvent_t fork = m->take_event();
-      DV_HIP_CHECK(hipEventRecord(fork, stream));
-      for (hipStream_t s : m->side) DV_HIP_CHECK(hipStreamWaitEvent(s, fork, 0));
-    }
     for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
       const int sb = std::min(stem_sub_batch(), nb - sb0);
       const uint8_t* img = images + (done + sb0) * img_bytes;
@@ -1532,13 +1446,6 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
     }
     if (int rc = run_ops(m, m->stem_ops_end, static_cast<int>(m->ops.size()), nb, stream)) {
       return rc;
-    }
-    if (m->lanes_active) {  // join
-      for (hipStream_t s : m->side) {
-        hipEvent_t e = m->take_event();
-        DV_HIP_CHECK(hipEventRecord(e, s));
-        DV_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-      }
     }
     {
       dv::ProfileScope prof(dv::kProfOther, stream);
