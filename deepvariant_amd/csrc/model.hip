@@ -100,6 +100,7 @@ static int stem_sub_batch() {
   static const int v = getenv("DV_STEM_SB") ? std::max(1, atoi(getenv("DV_STEM_SB"))) : (1 << 30);
   return v;
 }
+constexpr int kFirstUnroll = 5;  // conv_first_u8_kernel: chunks of a 3x3 filter (2 taps per chunk)
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
 // Pixel-operand prefetch depth, in chunks.  A chunk is only NB*PT MFMAs (32 cycles
 // each) of cover, so thin tiles need a deeper queue to ride out L2/HBM latency.
@@ -502,30 +503,69 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
     for (int i = 0; i < 16; ++i) acc[pt][i] = 0.f;
   __syncthreads();
 
-  for (int kc = 0; kc < p.n_chunks; ++kc) {
-    // this lane-half's tap; past the last tap the weights are zero
-    const int t = min(2 * kc + hi, taps - 1);
-    const int kh = t / p.KW, kw = t - kh * p.KW;
-    const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
-    const half8_t wf = *reinterpret_cast<const half8_t*>(
-        wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
+  // uint8 -> fp16 without per-byte converts: 0x6400 | b is the fp16 number 1024 + b, and
+  // (1024 + b) * 2^-7 - 9 = (b - 128) / 128 exactly -- one v_perm_b32 and one packed FMA
+  // per two channels.
+  auto normalise = [](unsigned lo, unsigned up) {
+    const half2_t scale = {static_cast<_Float16>(0.0078125f), static_cast<_Float16>(0.0078125f)};
+    const half2_t bias = {static_cast<_Float16>(-9.0f), static_cast<_Float16>(-9.0f)};
+    const unsigned k = 0x64646464u;
+    const half2_t h01 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(lo, k, 0x00050004u));
+    const half2_t h23 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(lo, k, 0x00070006u));
+    const half2_t h45 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(up, k, 0x00050004u));
+    const half2_t h67 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(up, k, 0x00070006u));
+    const half2_t a = h01 * scale + bias, b = h23 * scale + bias;
+    const half2_t c = h45 * scale + bias, d = h67 * scale + bias;
+    return half8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+  };
+  typedef unsigned uint3_t __attribute__((ext_vector_type(3)));
+  if (p.n_chunks <= kFirstUnroll) {
+    // every fragment of the tile is requested before the first one is used
+    uint3_t d[kFirstUnroll][PT];
+    unsigned sh[kFirstUnroll][PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const unsigned a = base[pt] + toff;
-      typedef unsigned uint3_t __attribute__((ext_vector_type(3)));
-      const uint3_t d = __builtin_amdgcn_raw_buffer_load_b96(rsrc, a & ~3u, 0, 0);
-      const unsigned sh = (a & 3u) * 8u;
-      const unsigned lo = __builtin_amdgcn_alignbit(d[1], d[0], sh);
-      const unsigned up = __builtin_amdgcn_alignbit(d[2], d[1], sh);
-      half8_t x;
+    for (int kc = 0; kc < kFirstUnroll; ++kc) {
+      const int t = min(2 * kc + hi, taps - 1);
+      const int kh = t / p.KW, kw = t - kh * p.KW;
+      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = static_cast<_Float16>((static_cast<float>((lo >> (8 * j)) & 0xFF) - 128.0f) *
-                                     (1.0f / 128.0f));
-        x[4 + j] = static_cast<_Float16>((static_cast<float>((up >> (8 * j)) & 0xFF) - 128.0f) *
-                                         (1.0f / 128.0f));
+      for (int pt = 0; pt < PT; ++pt) {
+        const unsigned a = base[pt] + toff;
+        sh[kc][pt] = (a & 3u) * 8u;
+        d[kc][pt] = kc < p.n_chunks ? __builtin_amdgcn_raw_buffer_load_b96(rsrc, a & ~3u, 0, 0)
+                                    : uint3_t{0u, 0u, 0u};
       }
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, x, acc[pt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kc = 0; kc < kFirstUnroll; ++kc) {
+      if (kc < p.n_chunks) {
+        const half8_t wf = *reinterpret_cast<const half8_t*>(
+            wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const unsigned lo = __builtin_amdgcn_alignbit(d[kc][pt][1], d[kc][pt][0], sh[kc][pt]);
+          const unsigned up = __builtin_amdgcn_alignbit(d[kc][pt][2], d[kc][pt][1], sh[kc][pt]);
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, normalise(lo, up), acc[pt], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    for (int kc = 0; kc < p.n_chunks; ++kc) {
+      // this lane-half's tap; past the last tap the weights are zero
+      const int t = min(2 * kc + hi, taps - 1);
+      const int kh = t / p.KW, kw = t - kh * p.KW;
+      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
+      const half8_t wf = *reinterpret_cast<const half8_t*>(
+          wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const unsigned a = base[pt] + toff;
+        const uint3_t dd = __builtin_amdgcn_raw_buffer_load_b96(rsrc, a & ~3u, 0, 0);
+        const unsigned s8 = (a & 3u) * 8u;
+        const unsigned lo = __builtin_amdgcn_alignbit(dd[1], dd[0], s8);
+        const unsigned up = __builtin_amdgcn_alignbit(dd[2], dd[1], s8);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, normalise(lo, up), acc[pt], 0, 0, 0);
+      }
     }
   }
 
