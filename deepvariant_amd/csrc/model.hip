@@ -58,14 +58,13 @@ struct TensorGeom {
 
 // One output branch of a (possibly grouped) convolution launch.
 struct ConvBranch {
-  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
   const float* shift;     // [Cout (+pad)] folded BN shift, or NULL (raw output)
   _Float16* out;
   TensorGeom og;
   int out_goff;           // first destination group of this branch
   int Cout;
   int relu;
-  int tile0;              // first cout tile of this branch in the launch
+  int sub0;               // first 32-cout subtile of this branch in the launch's cout space
 };
 
 constexpr int kMaxBranches = 4;
@@ -73,9 +72,13 @@ constexpr int kMaxBranches = 4;
 struct ConvArgs {
   const _Float16* in;
   // Sibling convolutions that read the SAME input with the same geometry (the
-  // 1x1 heads of an Inception block) run as one launch: consecutive cout tiles
-  // of one pixel tile belong to different branches but re-read the same pixels,
-  // which then come from L2 instead of HBM once per branch.
+  // 1x1 heads of an Inception block) run as one launch over the CONCATENATION of their
+  // output channels (each branch padded to whole 32-cout subtiles): one packed weight
+  // image, cout tiles of NB*32 that may straddle two branches, and an epilogue that
+  // routes every 32-cout subtile to its branch's tensor.  The input is fetched from HBM
+  // once and re-read from L2 by ceil(sum couts / (NB*32)) tiles instead of once per
+  // branch tile.
+  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
   ConvBranch br[kMaxBranches];
   int n_branches;
   TensorGeom ig;
@@ -216,22 +219,25 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 // Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
 // 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run.
 template <int NB, int PT>
-__device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvBranch& b,
-                                              int n_tile, const unsigned (&obase)[PT],
-                                              const bool (&mvalid)[PT], int lane) {
-  constexpr int BN = NB * 32;
-  // acc[nb][pt][4q + j] = cout nb*32 + 8q + 4*(lane>>5) + j at pixel lane&31.
-  // A C8 piece (8 couts of one pixel) is split over lanes l and l+32: for each
-  // pair of groups (q = 2t, 2t+1) the low half-wave completes group 2t and the
-  // high half-wave group 2t+1 after one v_permlane32_swap per dword, then every
-  // lane stores 16 bytes and 32 consecutive pixels form a contiguous 512-byte run.
-  const int cbase = n_tile * BN;
+__device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvArgs& p,
+                                              int n_tile, const int (&pn)[PT], const int (&poh)[PT],
+                                              const int (&pow_)[PT], const bool (&mvalid)[PT],
+                                              int lane) {
   const int hi = lane >> 5;
-  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
   const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
+    // branch of this 32-cout subtile (wave-uniform; the branch table sits in the kernarg
+    // segment and is indexed with scalar loads)
+    const int sub = n_tile * NB + nb;
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
+    const ConvBranch& b = p.br[bi];
+    const int cbase = (sub - b.sub0) * 32;  // first cout of the subtile within its branch
+    if (cbase >= b.Cout) continue;           // padding subtile past the last branch
+    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
     // Shifts come through the SCALAR cache (constant address space, wave-uniform
     // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
     float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
@@ -242,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], co
         typedef float f4_t __attribute__((ext_vector_type(4)));
         typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
         const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
-            b.shift + (cbase + nb * 32 + 8 * q)));
+            b.shift + (cbase + 8 * q)));
         const f4_t l4 = sp[0], u4 = sp[1];
         lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
         up = make_float4(u4[0], u4[1], u4[2], u4[3]);
@@ -253,6 +259,10 @@ __device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const float16_t a = acc[nb][pt];
+      // piece index of (n, group out_goff, oh, ow) in this branch's output tensor
+      const unsigned obase = static_cast<unsigned>(
+          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
+          pow_[pt] + b.og.halo);
       unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -272,13 +282,9 @@ __device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], co
         const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
         const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
         const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
-        const int group = (cbase + nb * 32) / 8 + 2 * t + hi;
+        const int group = cbase / 8 + 2 * t + hi;
         if (mvalid[pt] && group * 8 < b.Cout) {
-#ifdef DV_NT_STORE
-          __builtin_nontemporal_store(piece, &outp[obase[pt] + static_cast<unsigned>(group) * gstride]);
-#else
-          outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece;
-#endif
+          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
         }
       }
     }
@@ -316,22 +322,15 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   const int xq = nwg >> 3, xr = nwg & 7;
   const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-  const int n_tile_all = logical % p.n_tiles;
+  const int n_tile = logical % p.n_tiles;
   const int m_block = (logical / p.n_tiles) * (128 * PT);
-  // branch of this cout tile (wave-uniform selects, no memory indexing)
-  ConvBranch b = p.br[0];
-#pragma unroll
-  for (int i = 1; i < kMaxBranches; ++i) {
-    if (i < p.n_branches && n_tile_all >= p.br[i].tile0) b = p.br[i];
-  }
-  const int n_tile = n_tile_all - b.tile0;
 
   // Buffer offsets are 32 bit, tensors are not (8 K examples x 1.4 MB): every wave
   // addresses the input relative to the first example it touches (n0), through its
   // own descriptor -- a wave's 64 pixels never span more than a few hundred KB.
   int n0 = 0;
   unsigned base[PT];   // byte offset of (n - n0, group lane>>5, ih0, iw0) in the input
-  unsigned obase[PT];  // piece index of (n, group out_goff, oh, ow) in the output
+  int pn[PT], poh[PT], pow_[PT];  // output coordinates, turned into addresses per branch
   bool mvalid[PT];
   const int ohow = p.OH * p.OW;
 #pragma unroll
@@ -348,8 +347,9 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
                    ? static_cast<unsigned>(((((n - n0) * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
                                                 p.ig.wp + ix) * 16)
                    : 0x80000000u;  // beyond the descriptor's range: reads as zero
-    obase[pt] = static_cast<unsigned>(((n * b.og.groups + b.out_goff) * b.og.hp + oh +
-                                       b.og.halo) * b.og.wp + ow + b.og.halo);
+    pn[pt] = n;
+    poh[pt] = oh;
+    pow_[pt] = ow;
   }
 
   const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
       static_cast<unsigned>(in_left < 0x7fffffffu ? in_left : 0x7fffffffu), 0x00020000);
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
-  const uint4* wsrc = reinterpret_cast<const uint4*>(b.w) +
+  const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
                       static_cast<size_t>(n_tile) * p.n_slabs * SLAB_PIECES;
   uint4_t wreg[W_PER_THREAD];
 #define DV_LOAD_SLAB(s_)                                                                   \
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
 #undef DV_LOAD_SLAB
 #undef DV_STORE_SLAB
 
-  conv_epilogue<NB, PT>(acc, b, n_tile, obase, mvalid, lane);
+  conv_epilogue<NB, PT>(acc, p, n_tile, pn, poh, pow_, mvalid, lane);
 }
 
 template <int NB>
@@ -954,10 +954,14 @@ struct dv_model {
         }
       }
       if (sib.empty()) continue;
-      // common tile width: 64 couts (NB = 2) wastes the least over {32..448}
-      int total = lead.cout;
-      for (size_t j : sib) total += ops[j].cout;
-      const int nb = total >= 512 ? 4 : 2;
+      // tile width over the concatenated cout space (32-cout subtiles), same cost model
+      // as pick_nb: tiles x (nb MFMA columns + 1 pixel-fragment stream)
+      int subs = (lead.cout + 31) / 32;
+      for (size_t j : sib) subs += (ops[j].cout + 31) / 32;
+      // measured (8 K examples): 128-cout tiles win from 16 subtiles up (17x17 and 8x8 heads,
+      // -20..-26 %); the 7-subtile 35x35 heads and the 12-subtile 768->192+192 head are
+      // faster as 64-cout tiles at three blocks per CU.
+      const int nb = subs >= 16 ? 4 : 2;
       std::vector<Op> moved;
       for (size_t j : sib) moved.push_back(ops[j]);
       for (size_t k = sib.size(); k-- > 0;) ops.erase(ops.begin() + sib[k]);
@@ -1059,14 +1063,18 @@ struct dv_model {
     feat_p = x.h * x.w;
     feat_c = x.c;
     group_siblings();
-    for (Op& op : ops) {  // packed-weight offsets (after grouping fixed every nb)
+    for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
+      Op& op = ops[i];
       if (op.type != kOpConv) continue;
-      const int n_tiles = (op.cout + op.nb * 32 - 1) / (op.nb * 32);
-      op.w_off = packed_halfs;
+      int subs = 0;
+      for (int gi = 0; gi <= op.group_followers; ++gi) subs += (ops[i + gi].cout + 31) / 32;
+      const int n_tiles = (subs + op.nb - 1) / op.nb;
+      for (int gi = 0; gi <= op.group_followers; ++gi) ops[i + gi].w_off = packed_halfs;
       packed_halfs += op.first_u8
                           ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
                           : static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks *
                                 (op.nb * 32) * kChunk;
+      i += op.group_followers;
     }
     for (const Op& op : ops) {  // zero halo wide enough for every consumer
       int need = 0;
@@ -1213,7 +1221,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
       a.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
       // this op + the sibling convs grouped behind it (same input, same geometry)
-      int tiles = 0;
+      int subs = 0;
       a.n_branches = 0;
       double tr_flops = 0, tr_bytes = static_cast<double>(n) * op.ih * op.iw * op.cin * 2.0;
       std::string tr_label = "conv " + std::to_string(op.kh) + "x" + std::to_string(op.kw) + " s" +
@@ -1225,7 +1233,6 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         tr_label += (gi ? "+" : "") + std::to_string(bo.cout);
         const BufferDesc& bob = m->buffers[bo.out_buf];
         ConvBranch& br = a.br[a.n_branches++];
-        br.w = static_cast<const _Float16*>(m->d_w.ptr) + bo.w_off;
         br.shift = bo.raw ? nullptr
                           : static_cast<const float*>(m->d_shift.ptr) + bo.shift_off;
         br.out = static_cast<_Float16*>(m->dbuf[bo.out_buf].ptr) +
@@ -1236,9 +1243,11 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         br.out_goff = bo.out_coff / 8;
         br.Cout = bo.cout;
         br.relu = bo.raw ? 0 : 1;
-        br.tile0 = tiles;
-        tiles += (bo.cout + bo.nb * 32 - 1) / (bo.nb * 32);
+        br.sub0 = subs;
+        subs += (bo.cout + 31) / 32;
       }
+      a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
+      const int tiles = (subs + op.nb - 1) / op.nb;
       a.n_tiles = tiles;
       oi += op.group_followers;  // the followers ran in this launch
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
@@ -1383,7 +1392,8 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
   DV_HIP_CHECK(hipSetDevice(m->device));
   std::vector<_Float16> packed(m->packed_halfs, static_cast<_Float16>(0.f));
   std::vector<float> shift(m->shift_floats, 0.f);
-  for (const Op& op : m->ops) {
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const Op& op = m->ops[oi];
     if (op.type != kOpConv) continue;
     const LayerInfo& l = m->layers[op.layer];
     const float* w = weights + l.param_off;  // HWIO
@@ -1415,30 +1425,38 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         }
       continue;
     }
+    // Row of this op's cout `co` in the launch's concatenated cout space: the siblings
+    // grouped before it (leader first) each occupy whole 32-cout subtiles.
+    int sub0 = 0;
+    {
+      size_t lead = oi;
+      while (lead > 0 && m->ops[lead].group_followers == 0 && m->ops[lead - 1].type == kOpConv &&
+             m->ops[lead - 1].w_off == op.w_off) {
+        --lead;  // walk back to the leader (all ops of a launch share w_off)
+      }
+      for (size_t j = lead; j < oi; ++j) sub0 += (m->ops[j].cout + 31) / 32;
+    }
     const int bn = op.nb * 32;
-    const int n_tiles = (op.cout + bn - 1) / bn;
-    for (int t = 0; t < n_tiles; ++t)
-      for (int kc = 0; kc < op.n_chunks; ++kc) {
-        const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
-        const int taps = op.kh * op.kw;
-        const int cc = kc / taps, tap = kc % taps;  // chunk-major, tap-minor (ChunkWalk)
-        const int kh = tap / op.kw, kw = tap % op.kw;
-        for (int r = 0; r < bn; ++r) {
-          const int co = t * bn + r;
-          if (co >= op.cout) continue;
-          // chunk image [k-group g][cout r][8]: matches conv_mfma_kernel's frag_off
-          _Float16* chunk = packed.data() + op.w_off +
-                            ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn *
-                                kChunk;
-          for (int jj = 0; jj < kChunk; ++jj) {
-            const int ci = cc * kChunk + jj;
-            if (ci >= l.cin) continue;  // padded input channels
-            const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
-            chunk[(static_cast<size_t>(jj / 8) * bn + r) * 8 + (jj % 8)] =
-                static_cast<_Float16>(v * inv[co]);
-          }
+    const int taps = op.kh * op.kw;
+    for (int kc = 0; kc < op.n_chunks; ++kc) {
+      const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
+      const int cc = kc / taps, tap = kc % taps;  // chunk-major, tap-minor (ChunkWalk)
+      const int kh = tap / op.kw, kw = tap % op.kw;
+      for (int co = 0; co < op.cout; ++co) {
+        const int row = sub0 * 32 + co;
+        const int t = row / bn, r = row % bn;
+        // chunk image [k-group g][cout r][8]: matches conv_mfma_kernel's frag_off
+        _Float16* chunk = packed.data() + op.w_off +
+                          ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn * kChunk;
+        for (int jj = 0; jj < kChunk; ++jj) {
+          const int ci = cc * kChunk + jj;
+          if (ci >= l.cin) continue;  // padded input channels
+          const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+          chunk[(static_cast<size_t>(jj / 8) * bn + r) * 8 + (jj % 8)] =
+              static_cast<_Float16>(v * inv[co]);
         }
       }
+    }
   }
   const LayerInfo& dl = m->layers.back();
   const float* dw = weights + dl.param_off;
