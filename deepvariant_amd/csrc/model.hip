@@ -432,6 +432,97 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   conv_epilogue<NB, PT>(acc, p, n_tile, pn, poh, pow_, mvalid, lane);
 }
 
+// MaxPooling2D(3, strides 2) fused into the 1x1 convolution that consumes it (stem:
+// maxpool -> 64->80): the pooled tensor (0.16 MB / example written and read back) never
+// exists.  A pixel fragment is the element-wise maximum of the nine 16-byte pieces of its
+// window, taken in registers (v_pk_max_f16) -- exact, so results are bit-identical to the
+// separate max-pool kernel.  K is short (Cin/16 chunks): the whole weight tile sits in LDS,
+// fragments of chunk c+1 are in flight while chunk c multiplies.  One 32-pixel fragment
+// per wave (PT = 1) keeps the 2 x 9 outstanding loads within the register budget.
+template <int NB>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_pool1x1_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int PT = 1;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nwg = gridDim.x;
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+  const int n_tile = logical % p.n_tiles;
+  const int m_block = (logical / p.n_tiles) * 128;
+
+  {  // whole weight tile -> LDS
+    const int pieces = p.n_slabs * kSlabChunks * BN * 2;
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(p.w) + static_cast<size_t>(n_tile) * pieces;
+    uint4_t* dst = reinterpret_cast<uint4_t*>(smem);
+    for (int i = tid; i < pieces; i += kConvThreads) dst[i] = src[i];
+  }
+  int pn[PT], poh[PT], pow_[PT];
+  bool mvalid[PT];
+  const int m = m_block + wave * 32 + (lane & 31);
+  mvalid[0] = m < p.M;
+  int n, pix, oh, ow;
+  divmod_small(mvalid[0] ? m : 0, p.OH * p.OW, p.rcp_ohow, n, pix);
+  divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
+  pn[0] = n;
+  poh[0] = oh;
+  pow_[0] = ow;
+  const int n0 = __builtin_amdgcn_readfirstlane(n);
+  // window origin: pooled pixel (oh, ow) covers input rows 2oh..2oh+2, cols 2ow..2ow+2
+  const unsigned base =
+      mvalid[0] ? static_cast<unsigned>(((((n - n0) * p.ig.groups + (lane >> 5)) * p.ig.hp + 2 * oh +
+                                          p.ig.halo) * p.ig.wp + 2 * ow + p.ig.halo) * 16)
+                : 0x80000000u;
+  const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
+  const size_t in_left = p.in_bytes - in_off;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.in) + in_off), 0,
+      static_cast<unsigned>(in_left < 0x7fffffffu ? in_left : 0x7fffffffu), 0x00020000);
+  const unsigned row_b = static_cast<unsigned>(p.ig.wp) * 16u;
+
+  float16_t acc[NB][PT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][0][i] = 0.f;
+
+  half8_t win[2][9];
+#define DV_LOAD_WINDOW(slot_, cc_)                                                          \
+  {                                                                                         \
+    const unsigned so_ = static_cast<unsigned>(cc_) * p.chunk_stride;                       \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) win[slot_][t_] = __builtin_bit_cast(  \
+        half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base,                          \
+                                                       so_ + (t_ / 3) * row_b + (t_ % 3) * 16, 0)); \
+  }
+  DV_LOAD_WINDOW(0, 0)
+  __syncthreads();
+  const _Float16* wfrag = smem + (lane >> 5) * (BN * 8) + (lane & 31) * 8;
+  for (int cc = 0; cc < p.n_chunks; cc += 2) {   // two chunks per trip: static window slots
+    if (cc + 1 < p.n_chunks) DV_LOAD_WINDOW(1, cc + 1)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+        if (cc + 1 >= p.n_chunks) break;
+        if (cc + 2 < p.n_chunks) DV_LOAD_WINDOW(0, cc + 2)
+      }
+      half8_t x = win[half][0];
+#pragma unroll
+      for (int t = 1; t < 9; ++t) x = __builtin_elementwise_max(x, win[half][t]);
+      const _Float16* wc = wfrag + (cc + half) * (BN * kChunk);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const half8_t wf = *reinterpret_cast<const half8_t*>(wc + nb * 32 * 8);
+        acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, x, acc[nb][0], 0, 0, 0);
+      }
+    }
+  }
+#undef DV_LOAD_WINDOW
+  conv_epilogue<NB, PT>(acc, p, n_tile, pn, poh, pow_, mvalid, lane);
+}
+
 template <int NB>
 constexpr size_t conv_lds_bytes() {
   return static_cast<size_t>(2) * kSlabChunks * NB * 32 * kChunk * 2;
@@ -789,6 +880,7 @@ struct Op {
   int group_followers = 0;       // conv: the next k ops are siblings sharing this launch
   bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
+  bool pool_in = false;          // 1x1 conv that max-pools (3x3, stride 2) its input on the fly
 };
 
 struct LayerInfo {
@@ -988,8 +1080,20 @@ struct dv_model {
     x = conv(x, 32, 3, 3, 1, false);
     x = conv(x, 64, 3, 3);
     // (layer order: the two remaining stem convs are created before the pools run)
-    x = pool(kOpMaxPool, x);
-    x = conv(x, 80, 1, 1, 1, false);
+    if (getenv("DV_NO_POOL_FUSE") == nullptr) {  // tuning knob
+      // max-pool fused into the 1x1 that consumes it (conv_pool1x1_kernel)
+      TensorRef pooled = x;
+      pooled.h = (x.h - 3) / 2 + 1;
+      pooled.w = (x.w - 3) / 2 + 1;
+      const int ih = x.h, iw = x.w;
+      x = conv(pooled, 80, 1, 1, 1, false);
+      ops.back().pool_in = true;
+      ops.back().ih = ih;
+      ops.back().iw = iw;
+    } else {
+      x = pool(kOpMaxPool, x);
+      x = conv(x, 80, 1, 1, 1, false);
+    }
     x = conv(x, 192, 3, 3, 1, false);
     x = pool(kOpMaxPool, x);
     // Everything up to here is the "stem": big feature maps (0.2-0.7 MB per
@@ -1252,8 +1356,20 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       oi += op.group_followers;  // the followers ran in this launch
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
                   " tiles" + std::to_string(tiles);
+      if (op.pool_in) tr_label += " <- maxpool3s2";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
+      if (op.pool_in) {
+        a.stride = 2;  // documentary: the window origin is (2 oh, 2 ow)
+        const size_t lds = static_cast<size_t>(op.n_steps) * kSlabChunks * op.nb * 32 * kChunk * 2;
+        const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * a.n_tiles));
+        switch (op.nb) {
+          case 1: hipLaunchKernelGGL((conv_pool1x1_kernel<1>), grid, dim3(kConvThreads), lds, stream, a); break;
+          case 2: hipLaunchKernelGGL((conv_pool1x1_kernel<2>), grid, dim3(kConvThreads), lds, stream, a); break;
+          case 3: hipLaunchKernelGGL((conv_pool1x1_kernel<3>), grid, dim3(kConvThreads), lds, stream, a); break;
+          default: hipLaunchKernelGGL((conv_pool1x1_kernel<4>), grid, dim3(kConvThreads), lds, stream, a); break;
+        }
+      } else
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
         case 2: launch_conv<2>(a, stream); break;
