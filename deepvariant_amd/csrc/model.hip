@@ -1052,8 +1052,8 @@ struct dv_model {
       for (size_t j : sib) subs += (ops[j].cout + 31) / 32;
       // measured (8 K examples): 128-cout tiles win from 16 subtiles up (17x17 and 8x8 heads,
       // -20..-26 %); the 7-subtile 35x35 heads and the 12-subtile 768->192+192 head are
-      // faster as 64-cout tiles at three blocks per CU.
-      const int nb = subs >= 16 ? 4 : 2;
+      // faster as 96-cout tiles (two blocks per CU) than as 128 (one block per CU).
+      const int nb = subs >= 16 ? 4 : 3;
       std::vector<Op> moved;
       for (size_t j : sib) moved.push_back(ops[j]);
       for (size_t k = sib.size(); k-- > 0;) ops.erase(ops.begin() + sib[k]);
@@ -1300,8 +1300,16 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                     2.0 * f.M * op.kh * op.kw * op.cin_real * op.cout,
                     static_cast<double>(n) * (op.ih * op.iw * op.cin_real + 2.0 * op.oh * op.ow * op.cout));
       dv::ProfileScope prof(dv::kProfConv, stream);
-      hipLaunchKernelGGL((conv_first_u8_kernel<2>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
-                         stream, f);
+      // four pixel fragments per wave: 20 outstanding 12-byte loads per lane (+1.7 % end to end
+      // over two on MI355X); DV_FIRST_PT2 restores the smaller tile for tuning.
+      static const bool first4 = getenv("DV_FIRST_PT2") == nullptr;
+      if (first4) {
+        hipLaunchKernelGGL((conv_first_u8_kernel<4>), dim3((f.M + 511) / 512), dim3(kConvThreads), 0,
+                           stream, f);
+      } else {
+        hipLaunchKernelGGL((conv_first_u8_kernel<2>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
+                           stream, f);
+      }
     } else if (op.type == kOpConv) {
       ConvArgs a{};
       a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
