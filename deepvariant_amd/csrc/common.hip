@@ -45,7 +45,7 @@ struct EventPair {
 static bool g_profiling = false;
 static std::vector<EventPair> g_events[kProfKinds];
 static std::vector<EventPair> g_pool;
-static hipEvent_t g_open[kProfKinds];
+
 
 bool profiling_enabled() { return g_profiling; }
 

@@ -4,8 +4,8 @@
 // (keras_modeling.inceptionv3, deepvariant/keras_modeling.py:246-336; graph =
 // tf_keras InceptionV3(include_top=False, pooling='avg')).
 //
-// Data layout in HBM: activations are fp16 in the channel-blocked layout
-// [N][C/8][H][W][8] ("C8"): the 8 channels an MFMA fragment needs for one pixel
+// Data layout in HBM: activations are fp16 in the channel-blocked, zero-haloed layout
+// [N][C/8][H+2h][W+2h][8] ("C8"): the 8 channels an MFMA fragment needs for one pixel
 // are one 16-byte piece, and consecutive pixels of a row are consecutive
 // pieces, so every fragment load and every store of a 32-pixel tile is one
 // contiguous 512-byte run.  One buffer per graph tensor; concat outputs are
@@ -14,17 +14,19 @@
 // (scale=False, eps=1e-3, moving statistics) is folded into the fp16 conv
 // weights and an fp32 per-channel shift at load time.
 //
-// Kernels
-//   preprocess_kernel      uint8 HWC -> fp16 C8 (x-128)/128, channels padded to 16
-//   conv_igemm_kernel<NB>  implicit-GEMM conv + shift + ReLU on
-//                          v_mfma_f32_32x32x16_f16: D[cout][pixel] =
-//                          sum_k W[cout][k] X[k][pixel]; block tile 128 pixels
-//                          x NB*32 couts, K-step 32 (two 16-channel chunks of
-//                          one filter tap), LDS double buffered with one
-//                          barrier per step, epilogue transposed through LDS
-//                          so global stores are 16-byte along channels.
-//   maxpool3s2_kernel / avgpool3s1_kernel   (avg excludes padding)
-//   head_kernel            global average pool + Dense(3) + softmax in fp32
+// Kernels (DESIGN.md 4.2 has the measurements behind each choice)
+//   conv_mfma_kernel<NB,PT>   implicit-GEMM conv + shift + ReLU on v_mfma_f32_32x32x16_f16:
+//                             D[cout][pixel] = sum_k W[cout][k] X[k][pixel]; a wave owns
+//                             PT*32 pixels x NB*32 couts; weights stream through LDS in
+//                             slabs of 8 K-chunks, pixel fragments go global -> VGPR;
+//                             sibling 1x1 heads share one launch over their concatenated
+//                             couts
+//   conv_first_u8_kernel<PT>  first 3x3/2 conv straight from the uint8 pileup tensor
+//                             ((x-128)/128 in registers)
+//   conv_pool1x1_kernel<NB>   1x1 conv whose input is max-pooled (3x3/2) on the fly
+//   preprocess_kernel         uint8 HWC -> fp16 C8, only for inputs with > 8 channels
+//   maxpool3s2_kernel / avgpool3s1_kernel   (avg excludes padding, optional shift + ReLU)
+//   head_kernel               global average pool + Dense(3) + softmax in fp32
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

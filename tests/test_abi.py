@@ -47,3 +47,18 @@ def test_no_cpu_fallback_without_device():
   h = C.c_void_p()
   rc = _lib.lib().dv_encoder_create(C.byref(o), 0, C.byref(h))
   assert rc == _lib.DV_ERR_NO_DEVICE
+
+
+def test_model_create_rejects_oversized_batch_before_touching_a_device():
+  """Argument validation comes first: max_batch > 8192 is DV_ERR_INVALID_ARGUMENT with or
+  without a GPU (include/dvhip.h dv_model_desc)."""
+  import ctypes as C
+  from deepvariant_amd import _lib
+  lib = _lib.lib()
+  desc = _lib.DvModelDesc(100, 221, 7, 3, 8193)
+  handle = C.c_void_p()
+  rc = lib.dv_model_create(C.byref(desc), 0, C.byref(handle))
+  assert rc == _lib.DV_ERR_INVALID_ARGUMENT
+  assert b'max_batch' in lib.dv_last_error()
+  desc = _lib.DvModelDesc(64, 221, 7, 3, 16)        # H < 75: Inception-v3's minimum
+  assert lib.dv_model_create(C.byref(desc), 0, C.byref(handle)) == _lib.DV_ERR_INVALID_ARGUMENT
