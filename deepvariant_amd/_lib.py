@@ -127,6 +127,14 @@ def lib():
           'deepvariant_amd/libdvhip.so is missing: run '
           '`python -c "import __graft_entry__ as g; g.build()"` '
           '(there is no CPU fallback for the HIP hot path)')
+    try:
+      # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If /opt/rocm's
+      # copies (libdvhip.so's DT_NEEDED) get into the process first, torch later finds
+      # "No HIP GPUs"; loaded after torch, libdvhip.so binds to torch's runtime by SONAME
+      # and both share one device context.  Without torch this is a plain ROCm library.
+      import torch  # noqa: F401  pylint: disable=unused-import,g-import-not-at-top
+    except ImportError:
+      pass
     l = C.CDLL(LIB_PATH)
     l.dv_last_error.restype = C.c_char_p
     l.dv_crc32c.restype = C.c_uint32
