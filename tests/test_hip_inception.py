@@ -128,3 +128,50 @@ def test_graph_replay_on_a_side_stream_matches_eager():
   assert torch.equal(first.cpu(), eager.cpu())
   assert torch.equal(second.cpu(), eager2.cpu())
   assert not torch.equal(first.cpu(), second.cpu())
+
+
+def test_preprocess_known_answer_all_byte_values():
+  """deepvariant/dv_utils_test.py:177-200: preprocess_images([0, 128, 255]) ==
+  [-1, 0, 0.9921875] exactly.  Both device paths are checked on all 256 byte values:
+  the staging kernel (inputs with > 8 channels; buffer 0 is the preprocessed image) and
+  the conversion fused into conv_first_u8_kernel (a one-hot 3x3 filter copies the centre
+  pixel's channel 0 to output channel 0)."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  want = ((np.arange(256, dtype=np.float32) - 128.0) / 128.0)
+  assert want[0] == -1.0 and want[128] == 0.0 and want[255] == 0.9921875
+  # (a) staging kernel
+  model = InceptionV3((75, 75, 9), max_batch=1)
+  model.init_random(seed=1)
+  x = np.zeros((1, 75, 75, 9), np.uint8)
+  x[0, 0, :, 0] = np.arange(75)
+  x[0, 1, :, 0] = np.arange(75, 150)
+  x[0, 2, :, 0] = np.arange(150, 225)
+  x[0, 3, :31, 0] = np.arange(225, 256)
+  model(torch.from_numpy(x).cuda())
+  got = model.debug_tensor(0, 1).astype(np.float32)[0, :, :, 0]
+  flat = np.concatenate([got[0], got[1], got[2], got[3, :31]])
+  np.testing.assert_array_equal(flat, want)
+  # (b) fused uint8 first conv: relu((x-128)/128 * 1 + 2) - 2 recovers every value exactly
+  from oracle import inception_ref as R
+  ref = R.make_random_model(1, seed=2)
+  flat_w = ref.export_flat()
+  k = np.zeros((3, 3, 1, 32), np.float32)
+  k[1, 1, 0, 0] = 1.0
+  n_w = k.size
+  # BN with beta=2, mean=0, var=1-eps: scale 1, shift 2
+  flat_w[:n_w] = k.reshape(-1)
+  flat_w[n_w:n_w + 32] = 2.0
+  flat_w[n_w + 32:n_w + 64] = 0.0
+  flat_w[n_w + 64:n_w + 96] = 1.0 - 1e-3
+  model1 = InceptionV3((75, 75, 1), max_batch=1)
+  model1.load_flat_weights(flat_w)
+  x1 = np.zeros((1, 75, 75, 1), np.uint8)
+  vals = np.arange(256, dtype=np.uint8)
+  # centre pixels of the stride-2 windows: (2*oh+1, 2*ow+1)
+  for i, v in enumerate(vals):
+    x1[0, 2 * (i // 37) + 1, 2 * (i % 37) + 1, 0] = v
+  model1(torch.from_numpy(x1).cuda())
+  out = model1.debug_tensor(1, 1).astype(np.float32)[0, :, :, 0]
+  got1 = np.array([out[i // 37, i % 37] for i in range(256)]) - 2.0
+  np.testing.assert_allclose(got1, want, atol=2e-3)   # fp16 output grid near 2.0 is 2^-9
+  assert got1[128] == 0.0 and got1[0] == -1.0
