@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
     'dv_model_infer', 'dv_model_debug_tensor', 'dv_set_profiling', 'dv_profile_ms',
     'dv_last_profile_count',
+    'dv_bam_read_region', 'dv_read_table_fill_batch', 'dv_read_table_name',
+    'dv_read_table_names', 'dv_read_table_ends', 'dv_read_table_free',
 ]
 
 
@@ -100,6 +102,15 @@ class DvBatch(C.Structure):
   ]
 
 
+class DvReadRequirements(C.Structure):
+  _fields_ = [('keep_duplicates', C.c_int32),
+              ('keep_failed_vendor_quality_checks', C.c_int32),
+              ('keep_secondary_alignments', C.c_int32),
+              ('keep_supplementary_alignments', C.c_int32),
+              ('keep_improperly_placed', C.c_int32),
+              ('min_mapping_quality', C.c_int32)]
+
+
 class DvModelDesc(C.Structure):
   _fields_ = [('height', C.c_int32), ('width', C.c_int32),
               ('channels', C.c_int32), ('num_classes', C.c_int32),
@@ -152,6 +163,15 @@ def lib():
                                  C.c_void_p]
     l.dv_model_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     l.dv_model_layer_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    l.dv_bam_read_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_int, C.c_void_p]
+    l.dv_read_table_fill_batch.argtypes = [C.c_void_p, C.c_void_p]
+    l.dv_read_table_name.restype = C.c_char_p
+    l.dv_read_table_name.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    l.dv_read_table_names.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    l.dv_read_table_ends.restype = C.c_void_p
+    l.dv_read_table_ends.argtypes = [C.c_void_p]
+    l.dv_read_table_free.argtypes = [C.c_void_p]
     _lib = l
   return _lib
 

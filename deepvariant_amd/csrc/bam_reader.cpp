@@ -1,0 +1,349 @@
+// bam_reader.cpp -- BAM (BGZF) -> the packed read table of dv_batch, on the host.
+//
+// SURVEY.md 8f row f1 ("BAM -> packed read SoA"): the step in front of the hot path.
+// The reference reads through htslib + nucleus::SamReader into Read protos
+// (third_party/nucleus/io/sam_reader.cc:734-840 ConvertToPb, :217-247 read
+// requirements, third_party/nucleus/util/utils.cc:261-266 IsReadProperlyPlaced) and the
+// per-region InMemoryReader is then built from those protos.  htslib is not in this
+// image; zlib is.  This file inflates the BGZF blocks (in parallel), decodes the records
+// of one region and writes them straight into the structure-of-arrays layout
+// encode_items_kernel reads: no per-read objects, no strings except the name blob the
+// host keeps for allele_support matching.
+//
+// Field semantics (all from ConvertToPb): qualities are raw phred bytes; read_number =
+// 0 if FREAD1 or unpaired else 1; fragment_length = isize; HP = the integer HP aux tag;
+// CIGAR ops are mapped to nucleus' CigarUnit enum (htslib op + 1).
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dv_internal.h"
+
+struct dv_read_table {
+  std::vector<int32_t> pos, frag_len, hp;
+  std::vector<uint32_t> seq_off, cigar_off, cigar, name_rank, name_off;
+  std::vector<uint8_t> mapq, flags, read_number, bases, quals;
+  std::vector<int64_t> end;
+  std::vector<char> names;  // NUL-terminated, concatenated
+};
+
+namespace {
+
+inline uint32_t le32(const uint8_t* p) {
+  return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+}
+inline uint16_t le16(const uint8_t* p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
+
+struct Block {
+  size_t in_off, in_len;  // deflate payload
+  size_t out_off, out_len;
+};
+
+// Whole file -> one inflated buffer.  Block boundaries come from the BC extra field
+// (SAMv1 4.1), sizes from ISIZE, so blocks inflate independently.
+int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<uint8_t>* out) {
+  std::vector<Block> blocks;
+  size_t pos = 0, total = 0;
+  while (pos < file.size()) {
+    if (pos + 18 > file.size() || file[pos] != 31 || file[pos + 1] != 139) {
+      return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF file (bad gzip member header)");
+    }
+    const unsigned xlen = le16(&file[pos + 10]);
+    size_t p = pos + 12;
+    const size_t xend = p + xlen;
+    long bsize = -1;
+    while (p + 4 <= xend && xend <= file.size()) {
+      const unsigned slen = le16(&file[p + 2]);
+      if (file[p] == 66 && file[p + 1] == 67 && slen == 2) bsize = le16(&file[p + 4]) + 1L;
+      p += 4 + slen;
+    }
+    if (bsize < 0 || pos + bsize > file.size() || static_cast<size_t>(bsize) < 12u + xlen + 8u) {
+      return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF file (no BC subfield / truncated block)");
+    }
+    Block b;
+    b.in_off = xend;
+    b.in_len = pos + bsize - 8 - xend;
+    b.out_len = le32(&file[pos + bsize - 4]);
+    b.out_off = total;
+    total += b.out_len;
+    blocks.push_back(b);
+    pos += bsize;
+  }
+  out->resize(total);
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  auto work = [&]() {
+    z_stream zs;
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= blocks.size() || failed.load()) return;
+      const Block& b = blocks[i];
+      if (b.out_len == 0) continue;  // EOF marker block
+      std::memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) {
+        failed = 1;
+        return;
+      }
+      zs.next_in = const_cast<Bytef*>(&file[b.in_off]);
+      zs.avail_in = static_cast<uInt>(b.in_len);
+      zs.next_out = out->data() + b.out_off;
+      zs.avail_out = static_cast<uInt>(b.out_len);
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) failed = 1;
+    }
+  };
+  const int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(blocks.size())));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  if (failed.load()) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block failed to inflate");
+  return DV_OK;
+}
+
+// Integer value of a 2-letter aux tag (c C s S i I), or false.
+bool find_int_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1, int32_t* value) {
+  const uint8_t* p = aux;
+  auto size_of = [](uint8_t ty) -> int {
+    switch (ty) {
+      case 'A': case 'c': case 'C': return 1;
+      case 's': case 'S': return 2;
+      case 'i': case 'I': case 'f': return 4;
+      default: return 0;
+    }
+  };
+  while (p + 3 <= end) {
+    const bool hit = p[0] == static_cast<uint8_t>(t0) && p[1] == static_cast<uint8_t>(t1);
+    const uint8_t ty = p[2];
+    p += 3;
+    const int sz = size_of(ty);
+    if (sz) {
+      if (p + sz > end) return false;
+      if (hit) {
+        switch (ty) {
+          case 'c': *value = static_cast<int8_t>(p[0]); return true;
+          case 'C': *value = p[0]; return true;
+          case 's': *value = static_cast<int16_t>(le16(p)); return true;
+          case 'S': *value = le16(p); return true;
+          case 'i': case 'I': *value = static_cast<int32_t>(le32(p)); return true;
+          default: return false;
+        }
+      }
+      p += sz;
+    } else if (ty == 'Z' || ty == 'H') {
+      while (p < end && *p) ++p;
+      ++p;
+    } else if (ty == 'B') {
+      if (p + 5 > end) return false;
+      const int sub = size_of(p[0]);
+      if (!sub) return false;
+      p += 5 + static_cast<size_t>(le32(p + 1)) * sub;
+    } else {
+      return false;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dv_bam_read_region(const char* path, const char* contig, int64_t start, int64_t end,
+                       const dv_read_requirements* req, int n_threads, dv_read_table** out) {
+  if (!path || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_bam_read_region: null");
+  dv_read_requirements rq{};
+  if (req) rq = *req;
+  std::vector<uint8_t> file;
+  {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return dv::fail(DV_ERR_BAD_INPUT, std::string("cannot open ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    file.resize(n > 0 ? static_cast<size_t>(n) : 0);
+    const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), f);
+    std::fclose(f);
+    if (got != file.size()) return dv::fail(DV_ERR_BAD_INPUT, std::string("short read on ") + path);
+  }
+  std::vector<uint8_t> buf;
+  if (int rc = inflate_bgzf(file, n_threads, &buf)) return rc;
+  file.clear();
+  file.shrink_to_fit();
+  if (buf.size() < 12 || std::memcmp(buf.data(), "BAM\1", 4) != 0) {
+    return dv::fail(DV_ERR_BAD_INPUT, "bad BAM magic");
+  }
+  size_t p = 8 + static_cast<size_t>(le32(&buf[4]));
+  if (p + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
+  const int32_t n_ref = static_cast<int32_t>(le32(&buf[p]));
+  p += 4;
+  int32_t want_ref = -1;
+  for (int32_t i = 0; i < n_ref; ++i) {
+    if (p + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
+    const uint32_t l_name = le32(&buf[p]);
+    if (p + 4 + l_name + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
+    if (contig && std::strlen(contig) + 1 == l_name &&
+        std::memcmp(&buf[p + 4], contig, l_name - 1) == 0) {
+      want_ref = i;
+    }
+    p += 4 + l_name + 4;
+  }
+  if (contig && want_ref < 0) {
+    return dv::fail(DV_ERR_BAD_INPUT, std::string("contig not in the BAM header: ") + contig);
+  }
+  static const char kNt16[] = "=ACMGRSVTWYHKDBN";  // htslib seq_nt16_str
+  std::unique_ptr<dv_read_table> t(new dv_read_table());
+  t->seq_off.push_back(0);
+  t->cigar_off.push_back(0);
+  while (p + 4 <= buf.size()) {
+    const uint32_t block_size = le32(&buf[p]);
+    const uint8_t* r = &buf[p + 4];
+    if (block_size < 32 || p + 4 + block_size > buf.size()) {
+      return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM record");
+    }
+    p += 4 + block_size;
+    const int32_t ref_id = static_cast<int32_t>(le32(r));
+    const int32_t rpos = static_cast<int32_t>(le32(r + 4));
+    const unsigned l_read_name = r[8];
+    const unsigned mapq = r[9];
+    const unsigned n_cigar = le16(r + 12);
+    const unsigned flag = le16(r + 14);
+    const uint32_t l_seq = le32(r + 16);
+    const int32_t next_ref = static_cast<int32_t>(le32(r + 20));
+    const int32_t tlen = static_cast<int32_t>(le32(r + 28));
+    const size_t need = 32u + l_read_name + 4u * n_cigar + (l_seq + 1) / 2 + l_seq;
+    if (need > block_size || l_read_name == 0) return dv::fail(DV_ERR_BAD_INPUT, "corrupt BAM record");
+    if (ref_id < 0 || (flag & 0x4)) continue;                    // unmapped: no position
+    if (contig && ref_id != want_ref) continue;
+    // PartialReadSatisfiesRequirements (sam_reader.cc:217-234)
+    if ((!rq.keep_duplicates && (flag & 0x400)) ||
+        (!rq.keep_failed_vendor_quality_checks && (flag & 0x200)) ||
+        (!rq.keep_secondary_alignments && (flag & 0x100)) ||
+        (!rq.keep_supplementary_alignments && (flag & 0x800))) {
+      continue;
+    }
+    // IsReadProperlyPlaced (utils.cc:261-266): the mate position only exists for a
+    // paired read whose mate is mapped with a valid reference id (sam_reader.cc:829-837)
+    const bool paired = flag & 0x1;
+    const bool has_mate_pos = paired && !(flag & 0x8) && next_ref >= 0;
+    const bool properly_placed = !paired || (flag & 0x2) || !has_mate_pos || next_ref == ref_id;
+    if (!rq.keep_improperly_placed && !properly_placed) continue;
+    if (static_cast<int32_t>(mapq) < rq.min_mapping_quality) continue;
+    const uint8_t* name = r + 32;
+    const uint8_t* cig = name + l_read_name;
+    int64_t ref_len = 0;
+    for (unsigned k = 0; k < n_cigar; ++k) {
+      const uint32_t v = le32(cig + 4 * k);
+      const unsigned op = v & 0xF;
+      if (op > 8) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op in BAM record");
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+    }
+    // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
+    if (!(end > rpos && start < rpos + std::max<int64_t>(ref_len, 1))) continue;
+    const uint8_t* seq = cig + 4 * n_cigar;
+    const uint8_t* qual = seq + (l_seq + 1) / 2;
+    if (l_seq && qual[0] == 0xff) {
+      return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
+    }
+    t->pos.push_back(rpos);
+    t->end.push_back(rpos + ref_len);
+    t->mapq.push_back(static_cast<uint8_t>(mapq));
+    t->flags.push_back(static_cast<uint8_t>(((flag & 0x10) ? DV_READ_REVERSE : 0) |
+                                            ((flag & 0x800) ? DV_READ_SUPPLEMENTARY : 0)));
+    t->read_number.push_back((flag & 0x40) || !paired ? 0 : 1);
+    t->frag_len.push_back(tlen);
+    int32_t hp = 0;
+    t->hp.push_back(find_int_tag(qual + l_seq, r + block_size, 'H', 'P', &hp) ? hp : DV_HP_NONE);
+    for (unsigned k = 0; k < n_cigar; ++k) {
+      const uint32_t v = le32(cig + 4 * k);
+      t->cigar.push_back(((v >> 4) << 4) | ((v & 0xF) + 1));  // kHtslibCigarToProto
+    }
+    t->cigar_off.push_back(static_cast<uint32_t>(t->cigar.size()));
+    const size_t b0 = t->bases.size();
+    t->bases.resize(b0 + l_seq);
+    for (uint32_t i = 0; i < l_seq; ++i) {
+      const uint8_t byte = seq[i >> 1];
+      t->bases[b0 + i] = static_cast<uint8_t>(kNt16[(i & 1) ? (byte & 0xF) : (byte >> 4)]);
+    }
+    t->quals.insert(t->quals.end(), qual, qual + l_seq);
+    t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
+    t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
+    t->names.insert(t->names.end(), name, name + l_read_name);  // includes the NUL
+    if (t->names.back() != '\0') t->names.back() = '\0';
+  }
+  if (t->bases.size() >= (1ull << 32) || t->cigar.size() >= (1ull << 32)) {
+    return dv::fail(DV_ERR_UNSUPPORTED, "region too large: offsets are 32 bit");
+  }
+  // dense rank under the reference's tuple<string, int> ordering (fragment_name, read_number)
+  const size_t n = t->pos.size();
+  std::vector<uint32_t> order(n);
+  std::iota(order.begin(), order.end(), 0u);
+  auto key_less = [&](uint32_t a, uint32_t b) {
+    const int c = std::strcmp(&t->names[t->name_off[a]], &t->names[t->name_off[b]]);
+    return c != 0 ? c < 0 : t->read_number[a] < t->read_number[b];
+  };
+  std::sort(order.begin(), order.end(), key_less);
+  t->name_rank.assign(n, 0);
+  uint32_t rank = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (i && key_less(order[i - 1], order[i])) ++rank;
+    t->name_rank[order[i]] = rank;
+  }
+  *out = t.release();
+  return DV_OK;
+}
+
+int dv_read_table_fill_batch(const dv_read_table* t, dv_batch* b) {
+  if (!t || !b) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_read_table_fill_batch: null");
+  b->memory = DV_MEM_HOST;
+  b->n_reads = static_cast<int32_t>(t->pos.size());
+  b->read_pos = t->pos.data();
+  b->read_sort_pos = nullptr;
+  b->read_seq_off = t->seq_off.data();
+  b->read_cigar_off = t->cigar_off.data();
+  b->read_mapq = t->mapq.data();
+  b->read_flags = t->flags.data();
+  b->read_frag_len = t->frag_len.data();
+  b->read_hp = t->hp.data();
+  b->read_name_rank = t->name_rank.data();
+  b->read_aux = nullptr;
+  b->bases = t->bases.data();
+  b->quals = t->quals.data();
+  b->mod_5mc = nullptr;
+  b->mod_6ma = nullptr;
+  b->cigar = t->cigar.data();
+  b->n_bases = static_cast<uint32_t>(t->bases.size());
+  b->n_cigar = static_cast<uint32_t>(t->cigar.size());
+  return DV_OK;
+}
+
+const char* dv_read_table_name(const dv_read_table* t, int32_t i, int32_t* read_number) {
+  if (!t || i < 0 || static_cast<size_t>(i) >= t->pos.size()) return nullptr;
+  if (read_number) *read_number = t->read_number[i];
+  return &t->names[t->name_off[i]];
+}
+
+const int64_t* dv_read_table_ends(const dv_read_table* t) { return t ? t->end.data() : nullptr; }
+
+int dv_read_table_names(const dv_read_table* t, const char** blob, const uint32_t** offsets,
+                        const uint8_t** read_numbers, uint64_t* blob_bytes) {
+  if (!t) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_read_table_names: null");
+  if (blob) *blob = t->names.data();
+  if (offsets) *offsets = t->name_off.data();
+  if (read_numbers) *read_numbers = t->read_number.data();
+  if (blob_bytes) *blob_bytes = t->names.size();
+  return DV_OK;
+}
+
+void dv_read_table_free(dv_read_table* t) { delete t; }
+
+}  // extern "C"

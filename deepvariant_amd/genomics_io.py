@@ -84,7 +84,7 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
     p += (l_seq + 1) // 2
     qual = bytes(rec[p:p + l_seq])
     p += l_seq
-    if ref_id < 0 or (contig is not None and names[ref_id] != contig):
+    if ref_id < 0 or (flag & 0x4) or (contig is not None and names[ref_id] != contig):
       continue
     if not (end > rpos and start < rpos + max(ref_len, 1)):
       continue
@@ -117,7 +117,10 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
             mapping_quality=mapq, cigar=cigar),
         info=info))
     reads[-1]._flag = flag  # pylint: disable=protected-access
-    reads[-1]._mate_ok = (_next_ref < 0 or _next_ref == ref_id)
+    # next_mate_position exists only for a paired read whose mate is mapped with a valid
+    # reference id (sam_reader.cc:829-837); without it the read counts as properly placed
+    has_mate_pos = paired and not (flag & 0x8) and _next_ref >= 0
+    reads[-1]._mate_ok = (not has_mate_pos) or _next_ref == ref_id
   return names, reads
 
 
@@ -174,3 +177,27 @@ class FastaReader:
 
   def get_bases(self, contig: str, start: int, end: int) -> str:
     return self._contigs[contig][start:end]
+
+
+def read_satisfies_requirements(read, min_mapping_quality: int = 0,
+                                keep_duplicates: bool = False,
+                                keep_failed_qc: bool = False,
+                                keep_secondary: bool = False,
+                                keep_supplementary: bool = False,
+                                keep_improperly_placed: bool = False) -> bool:
+  """sam_reader_internal::ReadSatisfiesRequirements
+  (third_party/nucleus/io/sam_reader.cc:217-247) for aligned reads, with
+  IsReadProperlyPlaced (third_party/nucleus/util/utils.cc:261-266)."""
+  if read.duplicate_fragment and not keep_duplicates:
+    return False
+  if read.failed_vendor_quality_checks and not keep_failed_qc:
+    return False
+  if read.secondary_alignment and not keep_secondary:
+    return False
+  if read.supplementary_alignment and not keep_supplementary:
+    return False
+  properly_placed = (read.number_reads < 2 or read.proper_placement or
+                     getattr(read, '_mate_ok', True))
+  if not properly_placed and not keep_improperly_placed:
+    return False
+  return read.alignment.mapping_quality >= min_mapping_quality

@@ -244,6 +244,54 @@ class ReadTable:
         mod_6ma=np.frombuffer(b''.join(m6), np.uint8) if any6 else None,
         cigar=np.array(cig, np.uint32), keys=keys, read_end=read_end)
 
+  @classmethod
+  def from_bam(cls, path: str, contig: Optional[str] = None, start: int = 0,
+               end: int = 1 << 62, min_mapping_quality: int = 0,
+               keep_duplicates: bool = False, keep_supplementary: bool = False,
+               keep_secondary: bool = False, keep_failed_qc: bool = False,
+               keep_improperly_placed: bool = False, n_threads: int = 4) -> 'ReadTable':
+    """Native BAM -> packed table (dv_bam_read_region, include/dvhip.h): the reads of
+    `contig` overlapping [start, end) that pass nucleus' ReadRequirements, in file order."""
+    import ctypes as C
+    lib = _lib.lib()
+    req = _lib.DvReadRequirements(int(keep_duplicates), int(keep_failed_qc), int(keep_secondary),
+                                  int(keep_supplementary), int(keep_improperly_placed),
+                                  int(min_mapping_quality))
+    handle = C.c_void_p()
+    _lib.check(lib.dv_bam_read_region(
+        path.encode(), contig.encode() if contig is not None else None, int(start),
+        int(min(end, (1 << 62))), C.byref(req), int(n_threads), C.byref(handle)))
+    try:
+      b = _lib.DvBatch()
+      _lib.check(lib.dv_read_table_fill_batch(handle, C.byref(b)))
+      n = b.n_reads
+
+      def arr(ptr, dtype, count):
+        if not count:
+          return np.zeros(0, dtype)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+      ends = arr(lib.dv_read_table_ends(handle), np.int64, n)
+      blob, offs, rns, nbytes = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+      _lib.check(lib.dv_read_table_names(handle, C.byref(blob), C.byref(offs), C.byref(rns),
+                                         C.byref(nbytes)))
+      names = bytes(arr(blob.value, np.uint8, nbytes.value)).decode().split('\0')[:n]
+      read_numbers = arr(rns.value, np.uint8, n)
+      keys = ['%s/%d' % (nm, rn) for nm, rn in zip(names, read_numbers.tolist())]
+      return cls(
+          n_reads=n, read_pos=arr(b.read_pos, np.int32, n), read_sort_pos=None,
+          read_seq_off=arr(b.read_seq_off, np.uint32, n + 1),
+          read_cigar_off=arr(b.read_cigar_off, np.uint32, n + 1),
+          read_mapq=arr(b.read_mapq, np.uint8, n), read_flags=arr(b.read_flags, np.uint8, n),
+          read_frag_len=arr(b.read_frag_len, np.int32, n), read_hp=arr(b.read_hp, np.int32, n),
+          read_name_rank=arr(b.read_name_rank, np.uint32, n), read_aux=None,
+          bases=arr(b.bases, np.uint8, b.n_bases), quals=arr(b.quals, np.uint8, b.n_bases),
+          mod_5mc=None, mod_6ma=None, cigar=arr(b.cigar, np.uint32, b.n_cigar), keys=keys,
+          read_end=ends)
+    finally:
+      lib.dv_read_table_free(handle)
+
   def query(self, start: int, end: int) -> np.ndarray:
     """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""
     return np.nonzero((end > self.read_pos) & (start < self.read_end))[0].astype(

@@ -240,6 +240,46 @@ int dv_query_reads(int32_t n_reads, const int32_t* read_pos,
                    const int64_t* query_end, uint32_t* list_off,
                    uint32_t* list_read);
 
+/* ---- BAM -> packed read table (host only) --------------
+ * Replaces SamReader::Query + ConvertToPb + InMemoryReader construction
+ * (third_party/nucleus/io/sam_reader.cc:734-840, deepvariant/make_examples_core.py:
+ * region_reads_norealign) for the fields the encoder consumes.  dv_read_requirements
+ * mirrors nucleus.genomics.v1.ReadRequirements
+ * (third_party/nucleus/protos/reads.proto:421-445; sam_reader.cc:217-247,
+ *  third_party/nucleus/util/utils.cc:261-266); make_examples' defaults are all zero
+ * except min_mapping_quality (deepvariant/make_examples_options.py:954-990). */
+typedef struct dv_read_requirements {
+  int32_t keep_duplicates;
+  int32_t keep_failed_vendor_quality_checks;
+  int32_t keep_secondary_alignments;
+  int32_t keep_supplementary_alignments;
+  int32_t keep_improperly_placed;
+  int32_t min_mapping_quality;
+} dv_read_requirements;
+
+typedef struct dv_read_table dv_read_table; /* owns host arrays in dv_batch's read layout */
+
+/* Reads `path` (BGZF BAM; the whole file is inflated on `n_threads` threads, no index
+ * is used) and keeps the mapped reads of `contig` (NULL = all) that overlap
+ * [start, end) (nucleus::ReadOverlapsRegion) and satisfy `req` (NULL = keep nothing
+ * optional, mapq >= 0), in file order. */
+int dv_bam_read_region(const char* path, const char* contig, int64_t start, int64_t end,
+                       const dv_read_requirements* req, int n_threads, dv_read_table** out);
+/* Points the read-table fields of `b` (n_reads, read_*, bases, quals, cigar, n_bases,
+ * n_cigar; memory = DV_MEM_HOST) at the table's arrays; item / list fields are left
+ * alone.  The table must outlive the batch. */
+int dv_read_table_fill_batch(const dv_read_table* t, dv_batch* b);
+/* fragment_name (NUL-terminated) and read_number of read i: the key
+ * "<fragment_name>/<read_number>" DeepVariantCall.allele_support refers to. */
+const char* dv_read_table_name(const dv_read_table* t, int32_t i, int32_t* read_number);
+/* All names at once: NUL-terminated strings in `blob` (blob_bytes long), name i at
+ * blob + offsets[i], read_numbers[i] in {0, 1}. */
+int dv_read_table_names(const dv_read_table* t, const char** blob, const uint32_t** offsets,
+                        const uint8_t** read_numbers, uint64_t* blob_bytes);
+/* exclusive reference end of every read (alignment start + reference span) */
+const int64_t* dv_read_table_ends(const dv_read_table* t);
+void dv_read_table_free(dv_read_table* t);
+
 /* CRC32C (Castagnoli) as used by TFRecord framing
  * (third_party/nucleus/io/example_writer.cc:88-104 via tensorflow::io::RecordWriter). */
 uint32_t dv_crc32c(const uint8_t* data, size_t n);

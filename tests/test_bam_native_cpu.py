@@ -1,0 +1,127 @@
+"""Native BAM -> packed read table (dv_bam_read_region) vs the Python
+restatement of nucleus' SamReader semantics, on a synthetic BGZF BAM written here (every
+flag combination the read requirements look at, every CIGAR op, HP tags of all integer
+types behind Z / B / f tags, records straddling BGZF blocks), and on the reference's own
+test BAMs when they are present in the container."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from deepvariant_amd import _lib, genomics_io, packing
+
+NT16 = '=ACMGRSVTWYHKDBN'
+BAM_OPS = 'MIDNSHP=X'
+
+
+def _bgzf(data: bytes, block: int) -> bytes:
+  out = b''
+  for i in list(range(0, len(data), block)) + [None]:
+    chunk = b'' if i is None else data[i:i + block]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = c.compress(chunk) + c.flush()
+    bsize = 12 + 6 + len(payload) + 8
+    out += (b'\x1f\x8b\x08\x04' + b'\0' * 4 + b'\0\xff' + struct.pack('<H', 6) +
+            b'BC' + struct.pack('<HH', 2, bsize - 1) + payload +
+            struct.pack('<II', zlib.crc32(chunk), len(chunk)))
+  return out
+
+
+def _record(rng, ref_id, pos, name, flag, mapq, cigar, next_ref, tlen, aux=b''):
+  l_seq = sum(n for n, op in cigar if op in 'MIS=X')
+  seq = rng.integers(1, 16, size=l_seq)
+  packed = bytearray((l_seq + 1) // 2)
+  for i, v in enumerate(seq):
+    packed[i >> 1] |= int(v) << (4 if i % 2 == 0 else 0)
+  qual = bytes(rng.integers(0, 60, size=l_seq).astype(np.uint8))
+  cig = b''.join(struct.pack('<I', (n << 4) | BAM_OPS.index(op)) for n, op in cigar)
+  body = (struct.pack('<iiBBHHHiiii', ref_id, pos, len(name) + 1, mapq, 0, len(cigar), flag,
+                      l_seq, next_ref, 0, tlen) + name.encode() + b'\0' + cig + bytes(packed) +
+          qual + aux)
+  return struct.pack('<i', len(body)) + body
+
+
+def _write_bam(path, rng, n=400):
+  refs = [('chrA', 100000), ('chrB', 50000)]
+  hdr = b'BAM\x01' + struct.pack('<i', 0) + struct.pack('<i', len(refs))
+  for name, ln in refs:
+    hdr += struct.pack('<i', len(name) + 1) + name.encode() + b'\0' + struct.pack('<i', ln)
+  recs = []
+  flags = [0x0, 0x10, 0x1 | 0x2 | 0x40, 0x1 | 0x2 | 0x80 | 0x10, 0x1 | 0x40, 0x1 | 0x80 | 0x8,
+           0x400, 0x200, 0x100, 0x800, 0x4, 0x1 | 0x2 | 0x40 | 0x400]
+  hp_tags = [b'', b'HPc\x02', b'HPC\x01', b'HPs\x02\x00', b'HPS\x01\x00', b'HPi\x02\0\0\0',
+             b'XAZabc\0HPC\x02', b'XBBs\x02\0\0\0\x01\0\x02\0XFf\0\0\x80?HPc\x01', b'HPZ1\0']
+  pos = 100
+  for i in range(n):
+    flag = flags[int(rng.integers(0, len(flags)))]
+    ref_id = -1 if flag & 0x4 else int(rng.integers(0, 2))
+    n_ops = int(rng.integers(1, 6))
+    cigar = []
+    for k in range(n_ops):
+      op = 'MMM=XIDNSHP'[int(rng.integers(0, 11))] if 0 < k < n_ops - 1 else 'MM=XSH'[int(rng.integers(0, 6))]
+      cigar.append((int(rng.integers(1, 50)), op))
+    if not any(op in 'M=X' for _, op in cigar):
+      cigar.append((20, 'M'))
+    next_ref = [ref_id, ref_id, 1 - ref_id if ref_id >= 0 else -1, -1][int(rng.integers(0, 4))]
+    pos += int(rng.integers(0, 120))
+    name = 'frag%03d' % int(rng.integers(0, n // 2))
+    recs.append(_record(rng, ref_id, pos % 40000, name, flag, int(rng.integers(0, 61)), cigar,
+                        next_ref, int(rng.integers(-900, 900)),
+                        hp_tags[int(rng.integers(0, len(hp_tags)))]))
+  with open(path, 'wb') as f:
+    f.write(_bgzf(hdr + b''.join(recs), block=3000))   # records straddle blocks
+
+
+def _python_table(path, contig, start, end, **req):
+  _, reads = genomics_io.read_bam(path, contig, start, end)
+  reads = [r for r in reads if genomics_io.read_satisfies_requirements(r, **req)]
+  return packing.ReadTable.from_reads(reads)
+
+
+def _assert_same(nat, py):
+  assert nat.n_reads == py.n_reads
+  for f in ('read_pos', 'read_seq_off', 'read_cigar_off', 'read_mapq', 'read_flags',
+            'read_frag_len', 'read_hp', 'read_name_rank', 'bases', 'quals', 'cigar', 'read_end'):
+    np.testing.assert_array_equal(np.asarray(getattr(nat, f)), np.asarray(getattr(py, f)), err_msg=f)
+  assert nat.keys == py.keys
+
+
+@pytest.mark.parametrize('req', [
+    dict(), dict(min_mapping_quality=20), dict(keep_duplicates=True, keep_supplementary=True),
+    dict(keep_secondary=True, keep_failed_qc=True, keep_improperly_placed=True)])
+def test_native_equals_python_reader_on_synthetic_bam(tmp_path, req):
+  path = str(tmp_path / 'synthetic.bam')
+  _write_bam(path, np.random.default_rng(11))
+  for contig, start, end in (('chrA', 0, 1 << 40), ('chrB', 5000, 20000), ('chrA', 39990, 39995)):
+    nat = packing.ReadTable.from_bam(path, contig, start, end, n_threads=3, **req)
+    _assert_same(nat, _python_table(path, contig, start, end, **req))
+  assert packing.ReadTable.from_bam(path, 'chrA', 0, 1 << 40, **req).n_reads > 20
+
+
+def test_errors_are_reported(tmp_path):
+  bad = tmp_path / 'not_a.bam'
+  bad.write_bytes(b'hello world, definitely not BGZF')
+  with pytest.raises(_lib.DvError, match='BGZF'):
+    packing.ReadTable.from_bam(str(bad))
+  with pytest.raises(_lib.DvError, match='cannot open'):
+    packing.ReadTable.from_bam(str(tmp_path / 'missing.bam'))
+  path = str(tmp_path / 's.bam')
+  _write_bam(path, np.random.default_rng(1), n=20)
+  with pytest.raises(_lib.DvError, match='contig'):
+    packing.ReadTable.from_bam(path, 'chrZ')
+
+
+REF_INPUT = '/root/reference/deepvariant/testdata/input'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INPUT), reason='reference testdata not in this container')
+@pytest.mark.parametrize('bam,contig,start,end,mapq', [
+    ('NA12878_S1.chr20.10_10p1mb.bam', 'chr20', 9_999_000, 10_012_000, 5),
+    ('test_pacbio.chr20_100kbp_at_9mb.bam', 'chr20', 8_900_000, 9_200_000, 1)])
+def test_native_equals_python_reader_on_reference_bams(bam, contig, start, end, mapq):
+  path = os.path.join(REF_INPUT, bam)
+  nat = packing.ReadTable.from_bam(path, contig, start, end, min_mapping_quality=mapq)
+  _assert_same(nat, _python_table(path, contig, start, end, min_mapping_quality=mapq))
+  assert nat.n_reads in (6014, 281)
