@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -175,8 +176,10 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
     std::fclose(f);
     if (got != file.size()) return dv::fail(DV_ERR_BAD_INPUT, std::string("short read on ") + path);
   }
+  const auto t0 = std::chrono::steady_clock::now();
   std::vector<uint8_t> buf;
   if (int rc = inflate_bgzf(file, n_threads, &buf)) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
   file.clear();
   file.shrink_to_fit();
   if (buf.size() < 12 || std::memcmp(buf.data(), "BAM\1", 4) != 0) {
@@ -283,6 +286,7 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   if (t->bases.size() >= (1ull << 32) || t->cigar.size() >= (1ull << 32)) {
     return dv::fail(DV_ERR_UNSUPPORTED, "region too large: offsets are 32 bit");
   }
+  const auto t2 = std::chrono::steady_clock::now();
   // dense rank under the reference's tuple<string, int> ordering (fragment_name, read_number)
   const size_t n = t->pos.size();
   std::vector<uint32_t> order(n);
@@ -297,6 +301,12 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   for (size_t i = 0; i < n; ++i) {
     if (i && key_less(order[i - 1], order[i])) ++rank;
     t->name_rank[order[i]] = rank;
+  }
+  if (getenv("DV_BAM_TIMING")) {
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[dv-bam] inflate %.1f ms (%zu MB), decode %.1f ms (%zu reads), rank %.1f ms\n",
+            ms(t0, t1), buf.size() >> 20, ms(t1, t2), n, ms(t2, t3));
   }
   *out = t.release();
   return DV_OK;
