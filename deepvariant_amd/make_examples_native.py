@@ -220,9 +220,17 @@ class ExamplesGenerator:
     example_bytes = self._height * row_bytes
 
     # One ReadTable per sample; the encoder batch concatenates them.
-    tables = [packing.ReadTable.from_reads(reads,
-                                           need_aux=self._encoder_api._need_aux)
-              for reads in reads_per_sample]
+    # (a sample may also arrive already packed -- packing.ReadTable.from_bam -- instead of
+    # as a list of Read protos)
+    tables = []
+    for reads in reads_per_sample:
+      if isinstance(reads, packing.ReadTable):
+        if self._encoder_api._need_aux and reads.read_aux is None:
+          raise ValueError('this channel set needs per-read aux pixels; pack the reads with '
+                           'ReadTable.from_reads(need_aux=True)')
+        tables.append(reads)
+      else:
+        tables.append(packing.ReadTable.from_reads(reads, need_aux=self._encoder_api._need_aux))
     merged, sample_base = _concat_tables(tables)
     batch = packing.PackedBatch(table=merged, width=width)
     plan = []  # (candidate index, alt_combination)

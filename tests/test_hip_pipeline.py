@@ -120,3 +120,49 @@ def test_make_examples_then_call_variants(tmp_path):
     a = list(tfrecord.read_tfrecords(shards[i]))
     b = list(tfrecord.read_tfrecords(str(tmp_path / ('cli-%05d-of-00002.tfrecord.gz' % i))))
     assert a == b
+
+
+def test_region_from_native_bam_table_equals_region_from_read_protos(tmp_path):
+  """f1 plumbing: reads packed natively from a BAM (packing.ReadTable.from_bam) give
+  byte-identical examples to the same reads handed over as Read protos."""
+  from deepvariant_amd import genomics_io, packing
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import tfrecord
+  from tests.test_bam_native_cpu import _write_bam
+  bam = str(tmp_path / 's.bam')
+  _write_bam(bam, np.random.default_rng(3), n=600)
+  _, reads = genomics_io.read_bam(bam, 'chrA', 0, 1 << 40)
+  reads = [r for r in reads if genomics_io.read_satisfies_requirements(r, min_mapping_quality=5)]
+  table = packing.ReadTable.from_bam(bam, 'chrA', 0, 1 << 40, min_mapping_quality=5)
+  assert table.n_reads == len(reads) > 50
+  rng = np.random.default_rng(8)
+  cands = []
+  for k in range(12):
+    r = reads[int(rng.integers(0, len(reads)))]
+    pos = r.alignment.position.position + 3
+    names = ['%s/%d' % (q.fragment_name, q.read_number) for q in reads
+             if q.alignment.position.position <= pos < q.alignment.position.position + 30][:5]
+    cands.append(T.DeepVariantCall(
+        variant=T.Variant('chrA', pos, pos + 1, 'A', ['C', 'G'][:1 + k % 2]),
+        allele_support={'C': T.SupportingReads(names)}))
+  cands.sort(key=lambda c: c.variant.start)
+  pic = wgs_options()
+  options = T.MakeExamplesOptions(
+      pic_options=pic, sample_options=[T.SampleOptions(role='main', name='s', pileup_height=100)])
+
+  class _Ref:
+    def n_bases(self, contig):
+      return 100000
+
+    def get_bases(self, contig, start, end):
+      return ''.join('ACGT'[(p * 7 + p // 3) % 4] for p in range(start, end))
+
+  outs = []
+  for tag, sample in (('protos', reads), ('table', table)):
+    path = str(tmp_path / ('%s.tfrecord.gz' % tag))
+    gen = men.ExamplesGenerator(options, {'main': path}, ref_reader=_Ref())
+    stats, shape = gen.write_examples_in_region(cands, [sample], [0], 'main', [0.0])
+    gen.signal_shard_finished()
+    outs.append(list(tfrecord.read_tfrecords(path)))
+    assert stats['n_examples'] == len(outs[-1]) >= 12
+  assert outs[0] == outs[1]
