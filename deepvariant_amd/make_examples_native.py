@@ -208,9 +208,9 @@ class ExamplesGenerator:
     return stats, image_shape
 
   # --------------------------------------------------------------- internals
-  def encode_region(self, candidates, reads_per_sample, sample_order,
-                    mean_coverage_per_sample, stats) -> Tuple[List[bytes], List[int]]:
-    """All examples of one region: one packed batch, one kernel launch."""
+  def _plan_region(self, candidates, reads_per_sample, sample_order, mean_coverage_per_sample):
+    """-> (PackedBatch, [(candidate index, alt combination)], image_shape): everything
+    CreateAndWriteExamplesForCandidate decides before pixels are drawn."""
     pic = self._options.pic_options
     width = pic.width
     n_chan_total = len(pic.channels)  # image_shape[2], make_examples_native.cc:399
@@ -264,11 +264,21 @@ class ExamplesGenerator:
               list_aux=self._encoder_api._list_aux(cand, combo, table, idx_local))
           out_off += so.pileup_height * row_bytes
         plan.append((ci, combo))
+    return batch, plan, image_shape
+
+  def encode_region(self, candidates, reads_per_sample, sample_order,
+                    mean_coverage_per_sample, stats) -> Tuple[List[bytes], List[int]]:
+    """All examples of one region: one packed batch, one kernel launch."""
+    batch, plan, image_shape = self._plan_region(candidates, reads_per_sample, sample_order,
+                                                 mean_coverage_per_sample)
+    pic = self._options.pic_options
+    n_chan_total = len(pic.channels)
+    example_bytes = self._height * pic.width * n_chan_total
     if not plan:
       return [], image_shape
     if self._device_encoder is None:
-      self._device_encoder = _Encoder(pic, width, self._device)
-    if n_chan_total < c_enc:
+      self._device_encoder = _Encoder(pic, pic.width, self._device)
+    if n_chan_total < len(self._chan_enums):
       raise ValueError('num_channels smaller than the encoder channel list')
     images, _ = self._device_encoder.encode(batch, n_chan_total)
     examples = []
@@ -278,6 +288,39 @@ class ExamplesGenerator:
       examples.append(self._encode_example(
           candidates[ci].variant, combo, image, image_shape, label, stats))
     return examples, image_shape
+
+  def call_variants_in_region(self, candidates, reads_per_sample, sample_order,
+                              mean_coverage_per_sample, model) -> List[bytes]:
+    """Fused make_examples -> call_variants for one region (the
+    reference's precedent is fast_pipeline / stream_examples.cc:117-176): the pileup
+    tensors are encoded straight into device memory and classified there -- no
+    tf.Example, no GZIP, no host copy of the images.  Returns serialised
+    CallVariantsOutput protos identical to what call_variants writes for the examples
+    write_examples_in_region would have produced (same order)."""
+    import torch  # device memory + stream only
+    from deepvariant_amd import call_variants as cv
+    from deepvariant_amd.device_batch import DeviceBatch
+    batch, plan, image_shape = self._plan_region(candidates, reads_per_sample, sample_order,
+                                                 mean_coverage_per_sample)
+    if not plan:
+      return []
+    if list(image_shape) != list(model.input_shape):
+      raise ValueError('example shape %s != model shape %s' % (image_shape, list(model.input_shape)))
+    pic = self._options.pic_options
+    if self._device_encoder is None:
+      self._device_encoder = _Encoder(pic, pic.width, self._device)
+    dev = torch.device('cuda', self._device)
+    dbatch = DeviceBatch(batch, dev)
+    images = torch.empty([len(plan)] + list(image_shape), dtype=torch.uint8, device=dev)
+    dbatch.encode(self._device_encoder, image_shape[2], images)
+    probs = model(images).cpu().numpy().astype(np.float64)
+    out = []
+    for (ci, combo), p in zip(plan, probs):
+      variant = candidates[ci].variant
+      alt_encoded, _ = encode_alt_alleles(variant, combo)
+      gls = cv.round_gls([float(v) for v in p], precision=10)
+      out.append(cv.create_cvo(pw.encode_variant(variant), gls, alt_encoded))
+    return out
 
   def _encode_example(self, variant, alt_combination, image: np.ndarray,
                       image_shape, label, stats) -> bytes:

@@ -110,6 +110,15 @@ def test_make_examples_then_call_variants(tmp_path):
     assert max(abs(p - w) for p, w in zip(probs, want_p[k])) <= 1e-3 + 1e-9
     assert variant.start == examples[k]['call'].variant.start
 
+  # fused region path (no tf.Example / GZIP hop): same CallVariantsOutput bytes, same order
+  gen2 = men.ExamplesGenerator(options, {}, test_mode=True,
+                               ref_reader=_WindowRef(examples, pic.width))
+  fused = gen2.call_variants_in_region(cands, [reads], [0], [0.0], model)
+  two_step = [list(tfrecord.read_tfrecords(s)) for s in shards]
+  assert len(fused) == 84
+  for k, rec in enumerate(fused):
+    assert rec == two_step[k % 2][k // 2]
+
   # the command line (reference flag names) writes the same records
   flat = str(tmp_path / 'weights.npy')
   np.save(flat, ref.export_flat())
