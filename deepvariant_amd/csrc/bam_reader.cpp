@@ -155,6 +155,301 @@ bool find_int_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1, int3
   return false;
 }
 
+// ---- record decoding ------------------------------------------------------------
+struct RegionFilter {
+  dv_read_requirements rq{};
+  bool any_contig = true;
+  int32_t want_ref = -1;
+  int64_t start = 0, end = 0;
+};
+
+// Decodes one BAM record (r = first byte after block_size) into the table if it passes.
+// Returns DV_OK (kept or skipped) or an error; *past_end is set when the record starts at
+// or beyond the region end on the wanted contig (coordinate-sorted files can stop there).
+int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, dv_read_table* t,
+                  bool* past_end) {
+  static const char kNt16[] = "=ACMGRSVTWYHKDBN";  // htslib seq_nt16_str
+  const dv_read_requirements& rq = f.rq;
+  const int32_t ref_id = static_cast<int32_t>(le32(r));
+  const int32_t rpos = static_cast<int32_t>(le32(r + 4));
+  const unsigned l_read_name = r[8];
+  const unsigned mapq = r[9];
+  const unsigned n_cigar = le16(r + 12);
+  const unsigned flag = le16(r + 14);
+  const uint32_t l_seq = le32(r + 16);
+  const int32_t next_ref = static_cast<int32_t>(le32(r + 20));
+  const int32_t tlen = static_cast<int32_t>(le32(r + 28));
+  const size_t need = 32u + l_read_name + 4u * n_cigar + (l_seq + 1) / 2 + l_seq;
+  if (need > block_size || l_read_name == 0) return dv::fail(DV_ERR_BAD_INPUT, "corrupt BAM record");
+  if (past_end && !f.any_contig && (ref_id > f.want_ref || (ref_id == f.want_ref && rpos >= f.end))) {
+    *past_end = true;
+  }
+  if (ref_id < 0 || (flag & 0x4)) return DV_OK;                    // unmapped: no position
+  if (!f.any_contig && ref_id != f.want_ref) return DV_OK;
+  // PartialReadSatisfiesRequirements (sam_reader.cc:217-234)
+  if ((!rq.keep_duplicates && (flag & 0x400)) ||
+      (!rq.keep_failed_vendor_quality_checks && (flag & 0x200)) ||
+      (!rq.keep_secondary_alignments && (flag & 0x100)) ||
+      (!rq.keep_supplementary_alignments && (flag & 0x800))) {
+    return DV_OK;
+  }
+  // IsReadProperlyPlaced (utils.cc:261-266): the mate position only exists for a
+  // paired read whose mate is mapped with a valid reference id (sam_reader.cc:829-837)
+  const bool paired = flag & 0x1;
+  const bool has_mate_pos = paired && !(flag & 0x8) && next_ref >= 0;
+  const bool properly_placed = !paired || (flag & 0x2) || !has_mate_pos || next_ref == ref_id;
+  if (!rq.keep_improperly_placed && !properly_placed) return DV_OK;
+  if (static_cast<int32_t>(mapq) < rq.min_mapping_quality) return DV_OK;
+  const uint8_t* name = r + 32;
+  const uint8_t* cig = name + l_read_name;
+  int64_t ref_len = 0;
+  for (unsigned k = 0; k < n_cigar; ++k) {
+    const uint32_t v = le32(cig + 4 * k);
+    const unsigned op = v & 0xF;
+    if (op > 8) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op in BAM record");
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+  }
+  // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
+  if (!(f.end > rpos && f.start < rpos + std::max<int64_t>(ref_len, 1))) return DV_OK;
+  const uint8_t* seq = cig + 4 * n_cigar;
+  const uint8_t* qual = seq + (l_seq + 1) / 2;
+  if (l_seq && qual[0] == 0xff) {
+    return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
+  }
+  t->pos.push_back(rpos);
+  t->end.push_back(rpos + ref_len);
+  t->mapq.push_back(static_cast<uint8_t>(mapq));
+  t->flags.push_back(static_cast<uint8_t>(((flag & 0x10) ? DV_READ_REVERSE : 0) |
+                                          ((flag & 0x800) ? DV_READ_SUPPLEMENTARY : 0)));
+  t->read_number.push_back((flag & 0x40) || !paired ? 0 : 1);
+  t->frag_len.push_back(tlen);
+  int32_t hp = 0;
+  t->hp.push_back(find_int_tag(qual + l_seq, r + block_size, 'H', 'P', &hp) ? hp : DV_HP_NONE);
+  for (unsigned k = 0; k < n_cigar; ++k) {
+    const uint32_t v = le32(cig + 4 * k);
+    t->cigar.push_back(((v >> 4) << 4) | ((v & 0xF) + 1));  // kHtslibCigarToProto
+  }
+  t->cigar_off.push_back(static_cast<uint32_t>(t->cigar.size()));
+  const size_t b0 = t->bases.size();
+  t->bases.resize(b0 + l_seq);
+  for (uint32_t i = 0; i < l_seq; ++i) {
+    const uint8_t byte = seq[i >> 1];
+    t->bases[b0 + i] = static_cast<uint8_t>(kNt16[(i & 1) ? (byte & 0xF) : (byte >> 4)]);
+  }
+  t->quals.insert(t->quals.end(), qual, qual + l_seq);
+  t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
+  t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
+  t->names.insert(t->names.end(), name, name + l_read_name);  // includes the NUL
+  if (t->names.back() != '\0') t->names.back() = '\0';
+  return DV_OK;
+}
+
+// Header: magic, text, reference names.  Returns the offset of the first record in `buf`,
+// or 0 when `buf` does not hold the whole header yet (indexed path inflates more blocks).
+int parse_header(const std::vector<uint8_t>& buf, const char* contig, size_t* first_record,
+                 int32_t* want_ref, bool* complete) {
+  *complete = false;
+  if (buf.size() < 12) return DV_OK;
+  if (std::memcmp(buf.data(), "BAM\1", 4) != 0) return dv::fail(DV_ERR_BAD_INPUT, "bad BAM magic");
+  size_t p = 8 + static_cast<size_t>(le32(&buf[4]));
+  if (p + 4 > buf.size()) return DV_OK;
+  const int32_t n_ref = static_cast<int32_t>(le32(&buf[p]));
+  p += 4;
+  *want_ref = -1;
+  for (int32_t i = 0; i < n_ref; ++i) {
+    if (p + 4 > buf.size()) return DV_OK;
+    const uint32_t l_name = le32(&buf[p]);
+    if (p + 4 + l_name + 4 > buf.size()) return DV_OK;
+    if (contig && std::strlen(contig) + 1 == l_name &&
+        std::memcmp(&buf[p + 4], contig, l_name - 1) == 0) {
+      *want_ref = i;
+    }
+    p += 4 + l_name + 4;
+  }
+  *first_record = p;
+  *complete = true;
+  return DV_OK;
+}
+
+// ---- .bai index (SAMv1 5.2) ---------------------------------------------------------
+struct Chunk {
+  uint64_t beg, end;  // virtual offsets: (compressed offset << 16) | offset in the block
+};
+
+// Chunks of reference `ref` that may hold records overlapping [start, end): the bins of
+// reg2bins, cut by the 16 kb linear index, merged.
+int bai_chunks(const std::string& bai_path, int32_t ref, int64_t start, int64_t end,
+               std::vector<Chunk>* chunks) {
+  FILE* f = std::fopen(bai_path.c_str(), "rb");
+  if (!f) return dv::fail(DV_ERR_BAD_INPUT, "cannot open " + bai_path);
+  std::vector<uint8_t> d;
+  std::fseek(f, 0, SEEK_END);
+  const long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  d.resize(n > 0 ? n : 0);
+  const size_t got = d.empty() ? 0 : std::fread(d.data(), 1, d.size(), f);
+  std::fclose(f);
+  if (got != d.size() || d.size() < 8 || std::memcmp(d.data(), "BAI\1", 4) != 0) {
+    return dv::fail(DV_ERR_BAD_INPUT, "bad BAI file: " + bai_path);
+  }
+  auto le64 = [&](size_t p) { return static_cast<uint64_t>(le32(&d[p])) | (static_cast<uint64_t>(le32(&d[p + 4])) << 32); };
+  if (end > (1ll << 29)) end = 1ll << 29;
+  if (start < 0) start = 0;
+  std::vector<uint32_t> bins;
+  {
+    const int64_t b = start, e = end - 1;
+    bins.push_back(0);
+    for (int k = 1 + (b >> 26); k <= 1 + (e >> 26); ++k) bins.push_back(k);
+    for (int k = 9 + (b >> 23); k <= 9 + (e >> 23); ++k) bins.push_back(k);
+    for (int k = 73 + (b >> 20); k <= 73 + (e >> 20); ++k) bins.push_back(k);
+    for (int k = 585 + (b >> 17); k <= 585 + (e >> 17); ++k) bins.push_back(k);
+    for (int k = 4681 + (b >> 14); k <= 4681 + (e >> 14); ++k) bins.push_back(k);
+  }
+  size_t p = 8;
+  const int32_t n_ref = static_cast<int32_t>(le32(&d[4]));
+  if (ref >= n_ref) return dv::fail(DV_ERR_BAD_INPUT, "BAI has fewer references than the BAM");
+  std::vector<Chunk> found;
+  uint64_t min_off = 0;
+  for (int32_t r = 0; r <= ref; ++r) {
+    if (p + 4 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAI");
+    const int32_t n_bin = static_cast<int32_t>(le32(&d[p]));
+    p += 4;
+    for (int32_t b = 0; b < n_bin; ++b) {
+      if (p + 8 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAI");
+      const uint32_t bin = le32(&d[p]);
+      const int32_t n_chunk = static_cast<int32_t>(le32(&d[p + 4]));
+      p += 8;
+      if (p + 16ull * n_chunk > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAI");
+      if (r == ref && bin != 37450 && std::find(bins.begin(), bins.end(), bin) != bins.end()) {
+        for (int32_t c = 0; c < n_chunk; ++c) found.push_back({le64(p + 16 * c), le64(p + 16 * c + 8)});
+      }
+      p += 16ull * n_chunk;
+    }
+    if (p + 4 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAI");
+    const int32_t n_intv = static_cast<int32_t>(le32(&d[p]));
+    p += 4;
+    if (p + 8ull * n_intv > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAI");
+    if (r == ref && n_intv > 0) {
+      const int64_t w = std::min<int64_t>(start >> 14, n_intv - 1);
+      min_off = le64(p + 8 * w);
+    }
+    p += 8ull * n_intv;
+  }
+  std::sort(found.begin(), found.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+  for (const Chunk& c : found) {
+    if (c.end <= min_off) continue;
+    if (!chunks->empty() && c.beg <= chunks->back().end) {
+      chunks->back().end = std::max(chunks->back().end, c.end);
+    } else {
+      chunks->push_back(c);
+    }
+  }
+  return DV_OK;
+}
+
+// Inflates the BGZF member at file offset `coff` and appends it to `out`; *csize = its
+// compressed size (0 at end of file).
+int inflate_member(FILE* f, uint64_t coff, std::vector<uint8_t>* out, size_t* csize) {
+  uint8_t hdr[18];
+  *csize = 0;
+  if (fseeko(f, static_cast<off_t>(coff), SEEK_SET) != 0) return dv::fail(DV_ERR_BAD_INPUT, "seek failed");
+  const size_t got = std::fread(hdr, 1, 18, f);
+  if (got == 0) return DV_OK;
+  if (got < 18 || hdr[0] != 31 || hdr[1] != 139) return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF member");
+  const unsigned xlen = le16(hdr + 10);
+  std::vector<uint8_t> extra(xlen);
+  std::memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+  if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) {
+    return dv::fail(DV_ERR_BAD_INPUT, "truncated BGZF member");
+  }
+  long bsize = -1;
+  for (size_t p = 0; p + 4 <= xlen;) {
+    const unsigned slen = le16(&extra[p + 2]);
+    if (extra[p] == 66 && extra[p + 1] == 67 && slen == 2 && p + 6 <= xlen) bsize = le16(&extra[p + 4]) + 1L;
+    p += 4 + slen;
+  }
+  if (bsize < static_cast<long>(12 + xlen + 8)) return dv::fail(DV_ERR_BAD_INPUT, "bad BGZF block size");
+  const size_t payload = static_cast<size_t>(bsize) - 12 - xlen;  // deflate data + crc32 + isize
+  std::vector<uint8_t> comp(payload);
+  if (fseeko(f, static_cast<off_t>(coff + 12 + xlen), SEEK_SET) != 0 ||
+      std::fread(comp.data(), 1, payload, f) != payload) {
+    return dv::fail(DV_ERR_BAD_INPUT, "truncated BGZF member");
+  }
+  const uint32_t isize = le32(&comp[payload - 4]);
+  const size_t o0 = out->size();
+  out->resize(o0 + isize);
+  if (isize) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return dv::fail(DV_ERR_BAD_INPUT, "zlib init failed");
+    zs.next_in = comp.data();
+    zs.avail_in = static_cast<uInt>(payload - 8);
+    zs.next_out = out->data() + o0;
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block failed to inflate");
+  }
+  *csize = static_cast<size_t>(bsize);
+  return DV_OK;
+}
+
+// Indexed read: only the BGZF members the .bai points at are read and inflated.
+int read_indexed(const char* path, const std::string& bai, const char* contig, RegionFilter f,
+                 dv_read_table* t) {
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) return dv::fail(DV_ERR_BAD_INPUT, std::string("cannot open ") + path);
+  struct Closer {
+    FILE* f;
+    ~Closer() { std::fclose(f); }
+  } closer{fp};
+  // header (may span several members)
+  std::vector<uint8_t> buf;
+  uint64_t coff = 0;
+  size_t first_record = 0;
+  bool complete = false;
+  while (!complete) {
+    size_t csize = 0;
+    if (int rc = inflate_member(fp, coff, &buf, &csize)) return rc;
+    if (csize == 0) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
+    coff += csize;
+    if (int rc = parse_header(buf, contig, &first_record, &f.want_ref, &complete)) return rc;
+  }
+  if (f.want_ref < 0) return dv::fail(DV_ERR_BAD_INPUT, std::string("contig not in the BAM header: ") + contig);
+  std::vector<Chunk> chunks;
+  if (int rc = bai_chunks(bai, f.want_ref, f.start, f.end, &chunks)) return rc;
+  for (const Chunk& c : chunks) {
+    buf.clear();
+    uint64_t next = c.beg >> 16;                 // file offset of the next member to inflate
+    const uint64_t end_coff = c.end >> 16;
+    size_t end_limit = static_cast<size_t>(-1);  // buffer offset matching the chunk's end
+    size_t p = c.beg & 0xFFFF;
+    bool past = false, eof = false;
+    for (;;) {
+      // make sure the record at p is complete in buf
+      while (!eof && (buf.size() < p + 4 || buf.size() < p + 4 + le32(&buf[p]))) {
+        if (next == end_coff && end_limit == static_cast<size_t>(-1)) end_limit = buf.size() + (c.end & 0xFFFF);
+        size_t csize = 0;
+        if (int rc = inflate_member(fp, next, &buf, &csize)) return rc;
+        if (csize == 0) eof = true;
+        next += csize;
+      }
+      if (next > end_coff && end_limit == static_cast<size_t>(-1)) {
+        // the end member was inflated without passing through the branch above
+        end_limit = buf.size();
+      }
+      if (buf.size() < p + 4 || p >= end_limit) break;
+      const uint32_t block_size = le32(&buf[p]);
+      if (block_size < 32) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM record");
+      if (buf.size() < p + 4 + block_size) break;  // ran off the file
+      if (int rc = decode_record(&buf[p + 4], block_size, f, t, &past)) return rc;
+      if (past) break;
+      p += 4 + block_size;
+    }
+  }
+  return DV_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -162,126 +457,66 @@ extern "C" {
 int dv_bam_read_region(const char* path, const char* contig, int64_t start, int64_t end,
                        const dv_read_requirements* req, int n_threads, dv_read_table** out) {
   if (!path || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_bam_read_region: null");
-  dv_read_requirements rq{};
-  if (req) rq = *req;
-  std::vector<uint8_t> file;
-  {
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return dv::fail(DV_ERR_BAD_INPUT, std::string("cannot open ") + path);
-    std::fseek(f, 0, SEEK_END);
-    const long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    file.resize(n > 0 ? static_cast<size_t>(n) : 0);
-    const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), f);
-    std::fclose(f);
-    if (got != file.size()) return dv::fail(DV_ERR_BAD_INPUT, std::string("short read on ") + path);
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  std::vector<uint8_t> buf;
-  if (int rc = inflate_bgzf(file, n_threads, &buf)) return rc;
-  const auto t1 = std::chrono::steady_clock::now();
-  file.clear();
-  file.shrink_to_fit();
-  if (buf.size() < 12 || std::memcmp(buf.data(), "BAM\1", 4) != 0) {
-    return dv::fail(DV_ERR_BAD_INPUT, "bad BAM magic");
-  }
-  size_t p = 8 + static_cast<size_t>(le32(&buf[4]));
-  if (p + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
-  const int32_t n_ref = static_cast<int32_t>(le32(&buf[p]));
-  p += 4;
-  int32_t want_ref = -1;
-  for (int32_t i = 0; i < n_ref; ++i) {
-    if (p + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
-    const uint32_t l_name = le32(&buf[p]);
-    if (p + 4 + l_name + 4 > buf.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
-    if (contig && std::strlen(contig) + 1 == l_name &&
-        std::memcmp(&buf[p + 4], contig, l_name - 1) == 0) {
-      want_ref = i;
-    }
-    p += 4 + l_name + 4;
-  }
-  if (contig && want_ref < 0) {
-    return dv::fail(DV_ERR_BAD_INPUT, std::string("contig not in the BAM header: ") + contig);
-  }
-  static const char kNt16[] = "=ACMGRSVTWYHKDBN";  // htslib seq_nt16_str
+  RegionFilter flt;
+  if (req) flt.rq = *req;
+  flt.any_contig = contig == nullptr;
+  flt.start = start;
+  flt.end = end;
   std::unique_ptr<dv_read_table> t(new dv_read_table());
   t->seq_off.push_back(0);
   t->cigar_off.push_back(0);
-  while (p + 4 <= buf.size()) {
-    const uint32_t block_size = le32(&buf[p]);
-    const uint8_t* r = &buf[p + 4];
-    if (block_size < 32 || p + 4 + block_size > buf.size()) {
-      return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM record");
+  const auto t0 = std::chrono::steady_clock::now();
+  auto t1 = t0;
+  size_t inflated = 0;
+  // <path>.bai or <path minus .bam>.bai: seek + inflate only what the region needs
+  std::string bai;
+  if (contig && getenv("DV_BAM_NO_INDEX") == nullptr) {
+    for (const std::string& cand : {std::string(path) + ".bai",
+                                    std::string(path).substr(0, std::strlen(path) > 4 ? std::strlen(path) - 4 : 0) + ".bai"}) {
+      if (FILE* f = std::fopen(cand.c_str(), "rb")) {
+        std::fclose(f);
+        bai = cand;
+        break;
+      }
     }
-    p += 4 + block_size;
-    const int32_t ref_id = static_cast<int32_t>(le32(r));
-    const int32_t rpos = static_cast<int32_t>(le32(r + 4));
-    const unsigned l_read_name = r[8];
-    const unsigned mapq = r[9];
-    const unsigned n_cigar = le16(r + 12);
-    const unsigned flag = le16(r + 14);
-    const uint32_t l_seq = le32(r + 16);
-    const int32_t next_ref = static_cast<int32_t>(le32(r + 20));
-    const int32_t tlen = static_cast<int32_t>(le32(r + 28));
-    const size_t need = 32u + l_read_name + 4u * n_cigar + (l_seq + 1) / 2 + l_seq;
-    if (need > block_size || l_read_name == 0) return dv::fail(DV_ERR_BAD_INPUT, "corrupt BAM record");
-    if (ref_id < 0 || (flag & 0x4)) continue;                    // unmapped: no position
-    if (contig && ref_id != want_ref) continue;
-    // PartialReadSatisfiesRequirements (sam_reader.cc:217-234)
-    if ((!rq.keep_duplicates && (flag & 0x400)) ||
-        (!rq.keep_failed_vendor_quality_checks && (flag & 0x200)) ||
-        (!rq.keep_secondary_alignments && (flag & 0x100)) ||
-        (!rq.keep_supplementary_alignments && (flag & 0x800))) {
-      continue;
+  }
+  if (!bai.empty()) {
+    if (int rc = read_indexed(path, bai, contig, flt, t.get())) return rc;
+    t1 = std::chrono::steady_clock::now();
+  } else {
+    std::vector<uint8_t> file;
+    {
+      FILE* f = std::fopen(path, "rb");
+      if (!f) return dv::fail(DV_ERR_BAD_INPUT, std::string("cannot open ") + path);
+      std::fseek(f, 0, SEEK_END);
+      const long n = std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      file.resize(n > 0 ? static_cast<size_t>(n) : 0);
+      const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), f);
+      std::fclose(f);
+      if (got != file.size()) return dv::fail(DV_ERR_BAD_INPUT, std::string("short read on ") + path);
     }
-    // IsReadProperlyPlaced (utils.cc:261-266): the mate position only exists for a
-    // paired read whose mate is mapped with a valid reference id (sam_reader.cc:829-837)
-    const bool paired = flag & 0x1;
-    const bool has_mate_pos = paired && !(flag & 0x8) && next_ref >= 0;
-    const bool properly_placed = !paired || (flag & 0x2) || !has_mate_pos || next_ref == ref_id;
-    if (!rq.keep_improperly_placed && !properly_placed) continue;
-    if (static_cast<int32_t>(mapq) < rq.min_mapping_quality) continue;
-    const uint8_t* name = r + 32;
-    const uint8_t* cig = name + l_read_name;
-    int64_t ref_len = 0;
-    for (unsigned k = 0; k < n_cigar; ++k) {
-      const uint32_t v = le32(cig + 4 * k);
-      const unsigned op = v & 0xF;
-      if (op > 8) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op in BAM record");
-      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+    std::vector<uint8_t> buf;
+    if (int rc = inflate_bgzf(file, n_threads, &buf)) return rc;
+    t1 = std::chrono::steady_clock::now();
+    inflated = buf.size();
+    file.clear();
+    file.shrink_to_fit();
+    size_t p = 0;
+    bool complete = false;
+    if (int rc = parse_header(buf, contig, &p, &flt.want_ref, &complete)) return rc;
+    if (!complete) return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM header");
+    if (contig && flt.want_ref < 0) {
+      return dv::fail(DV_ERR_BAD_INPUT, std::string("contig not in the BAM header: ") + contig);
     }
-    // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
-    if (!(end > rpos && start < rpos + std::max<int64_t>(ref_len, 1))) continue;
-    const uint8_t* seq = cig + 4 * n_cigar;
-    const uint8_t* qual = seq + (l_seq + 1) / 2;
-    if (l_seq && qual[0] == 0xff) {
-      return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
+    while (p + 4 <= buf.size()) {
+      const uint32_t block_size = le32(&buf[p]);
+      if (block_size < 32 || p + 4 + block_size > buf.size()) {
+        return dv::fail(DV_ERR_BAD_INPUT, "truncated BAM record");
+      }
+      if (int rc = decode_record(&buf[p + 4], block_size, flt, t.get(), nullptr)) return rc;
+      p += 4 + block_size;
     }
-    t->pos.push_back(rpos);
-    t->end.push_back(rpos + ref_len);
-    t->mapq.push_back(static_cast<uint8_t>(mapq));
-    t->flags.push_back(static_cast<uint8_t>(((flag & 0x10) ? DV_READ_REVERSE : 0) |
-                                            ((flag & 0x800) ? DV_READ_SUPPLEMENTARY : 0)));
-    t->read_number.push_back((flag & 0x40) || !paired ? 0 : 1);
-    t->frag_len.push_back(tlen);
-    int32_t hp = 0;
-    t->hp.push_back(find_int_tag(qual + l_seq, r + block_size, 'H', 'P', &hp) ? hp : DV_HP_NONE);
-    for (unsigned k = 0; k < n_cigar; ++k) {
-      const uint32_t v = le32(cig + 4 * k);
-      t->cigar.push_back(((v >> 4) << 4) | ((v & 0xF) + 1));  // kHtslibCigarToProto
-    }
-    t->cigar_off.push_back(static_cast<uint32_t>(t->cigar.size()));
-    const size_t b0 = t->bases.size();
-    t->bases.resize(b0 + l_seq);
-    for (uint32_t i = 0; i < l_seq; ++i) {
-      const uint8_t byte = seq[i >> 1];
-      t->bases[b0 + i] = static_cast<uint8_t>(kNt16[(i & 1) ? (byte & 0xF) : (byte >> 4)]);
-    }
-    t->quals.insert(t->quals.end(), qual, qual + l_seq);
-    t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
-    t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
-    t->names.insert(t->names.end(), name, name + l_read_name);  // includes the NUL
-    if (t->names.back() != '\0') t->names.back() = '\0';
   }
   if (t->bases.size() >= (1ull << 32) || t->cigar.size() >= (1ull << 32)) {
     return dv::fail(DV_ERR_UNSUPPORTED, "region too large: offsets are 32 bit");
@@ -305,8 +540,9 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   if (getenv("DV_BAM_TIMING")) {
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "[dv-bam] inflate %.1f ms (%zu MB), decode %.1f ms (%zu reads), rank %.1f ms\n",
-            ms(t0, t1), buf.size() >> 20, ms(t1, t2), n, ms(t2, t3));
+    fprintf(stderr, "[dv-bam] %s: inflate%s %.1f ms (%zu MB), decode %.1f ms (%zu reads), rank %.1f ms\n",
+            bai.empty() ? "full scan" : "indexed", bai.empty() ? "" : "+decode", ms(t0, t1),
+            inflated >> 20, ms(t1, t2), n, ms(t2, t3));
   }
   *out = t.release();
   return DV_OK;

@@ -259,8 +259,9 @@ typedef struct dv_read_requirements {
 
 typedef struct dv_read_table dv_read_table; /* owns host arrays in dv_batch's read layout */
 
-/* Reads `path` (BGZF BAM; the whole file is inflated on `n_threads` threads, no index
- * is used) and keeps the mapped reads of `contig` (NULL = all) that overlap
+/* Reads `path` (BGZF BAM).  With `<path>.bai` present and a contig given, only the BGZF
+ * members the index points at are read; otherwise the whole file is inflated on
+ * `n_threads` threads.  Keeps the mapped reads of `contig` (NULL = all) that overlap
  * [start, end) (nucleus::ReadOverlapsRegion) and satisfy `req` (NULL = keep nothing
  * optional, mapq >= 0), in file order. */
 int dv_bam_read_region(const char* path, const char* contig, int64_t start, int64_t end,

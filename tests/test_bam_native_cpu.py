@@ -125,3 +125,23 @@ def test_native_equals_python_reader_on_reference_bams(bam, contig, start, end, 
   nat = packing.ReadTable.from_bam(path, contig, start, end, min_mapping_quality=mapq)
   _assert_same(nat, _python_table(path, contig, start, end, min_mapping_quality=mapq))
   assert nat.n_reads in (6014, 281)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INPUT), reason='reference testdata not in this container')
+@pytest.mark.parametrize('bam,regions,mapq', [
+    ('NA12878_S1.chr20.10_10p1mb.bam',
+     [(9_999_000, 10_012_000), (10_050_000, 10_051_000), (0, 1 << 40), (10_099_900, 10_200_000),
+      (5, 10)], 5),
+    ('test_pacbio.chr20_100kbp_at_9mb.bam',
+     [(8_900_000, 9_200_000), (9_050_000, 9_050_100), (9_099_000, 9_099_500)], 1)])
+def test_bai_indexed_read_equals_full_scan(bam, regions, mapq, monkeypatch):
+  """With <bam>.bai next to the file only the BGZF members the index points at are read
+  (reg2bins + linear index, SAMv1 5.2); the result must be the full scan's, read for read."""
+  path = os.path.join(REF_INPUT, bam)
+  assert os.path.exists(path + '.bai')
+  for start, end in regions:
+    monkeypatch.delenv('DV_BAM_NO_INDEX', raising=False)
+    indexed = packing.ReadTable.from_bam(path, 'chr20', start, end, min_mapping_quality=mapq)
+    monkeypatch.setenv('DV_BAM_NO_INDEX', '1')
+    full = packing.ReadTable.from_bam(path, 'chr20', start, end, min_mapping_quality=mapq)
+    _assert_same(indexed, full)
