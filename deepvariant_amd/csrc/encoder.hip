@@ -270,7 +270,9 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   const int CO = a.out_channels;
   const int band = c->band;
   const int H = a.item_height[item];
-  const int max_reads = H - band;
+  // host batches are validated (height - band <= kMaxKept); device batches are clamped so
+  // that a bad height can never run past the LDS tables
+  const int max_reads = min(H - band, kMaxKept);
   const uint32_t l0 = a.item_list_off[item];
   const int n = static_cast<int>(a.item_list_off[item + 1] - l0);
   const int vstart = a.item_variant_start[item];

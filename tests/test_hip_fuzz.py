@@ -63,3 +63,24 @@ def test_empty_batch_and_bad_arguments():
   bad._frozen = None
   with pytest.raises(_lib.DvError):
     enc.encode(bad, 7)
+
+
+def test_maximum_pileup_height_and_depth():
+  """The tallest image the encoder accepts (reference band + 256 read rows), with more
+  reads than rows (shuffle-and-truncate over 700 reads), and one row too many."""
+  from deepvariant_amd import _lib
+  from deepvariant_amd.pileup_image_native import PileupImageEncoderNative
+  from oracle import oracle as O
+  rng = np.random.default_rng(99)
+  width, height = 61, 5 + 256
+  opts = _options(T.PILEUP_CHANNELS_WITH_INSERT_SIZE, width, height)
+  enc = PileupImageEncoderNative(opts)
+  for n_reads in (256, 257, 700):
+    call, ref, reads, start, combo = F.make_case(rng, width, n_reads)
+    got = enc.build_pileup_for_one_sample(call, ref, reads, start, combo,
+                                          T.SampleOptions(pileup_height=height))
+    want = O.build_pileup(opts, call, ref, reads, start, combo, pileup_height=height)
+    np.testing.assert_array_equal(got, want)
+  with pytest.raises(_lib.DvError, match='item_height'):
+    enc.build_pileup_for_one_sample(call, ref, reads, start, combo,
+                                    T.SampleOptions(pileup_height=height + 1))
