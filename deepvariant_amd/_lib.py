@@ -99,6 +99,8 @@ class DvBatch(C.Structure):
       ('list_read', C.c_void_p), ('list_code', C.c_void_p),
       ('list_group', C.c_void_p), ('list_aux', C.c_void_p),
       ('n_list', C.c_uint32), ('max_list_len', C.c_uint32),
+      ('base_aux0', C.c_void_p), ('base_aux1', C.c_void_p),
+      ('ref_aux0', C.c_void_p), ('ref_aux1', C.c_void_p), ('ref_aux2', C.c_void_p),
   ]
 
 

@@ -60,7 +60,10 @@ enum ChannelKind : uint8_t {
   kAuxRead1,
   kAuxRead2,
   kAuxRead3,
+  kAuxRead4,      // gc_content of the read (read_aux[4]); reference row: ref_aux2
   kAuxList,       // host-computed per-(item,read) pixel, list_aux
+  kBaseAux0,      // host-computed per-base pixel (is_homopolymer); reference row: ref_aux0
+  kBaseAux1,      // host-computed per-base pixel (homopolymer_weighted); reference row: ref_aux1
 };
 
 // Everything the kernel needs besides the batch; copied into LDS per workgroup.
@@ -127,6 +130,11 @@ struct EncArgs {
   const uint8_t* list_code;
   const uint8_t* list_group;
   const uint8_t* list_aux;
+  const uint8_t* base_aux0;
+  const uint8_t* base_aux1;
+  const uint8_t* ref_aux0;
+  const uint8_t* ref_aux1;
+  const uint8_t* ref_aux2;
   int32_t n_items;
   int32_t n_channels;     // = EncConst::n_channels (sizes the LDS layout)
   int32_t out_channels;
@@ -381,12 +389,14 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         }
         case kHaplotype: v = haplotype_pixel(a.read_hp[r], c->polishing); break;
         case kSupplementary: v = c->supp[flags & DV_READ_SUPPLEMENTARY ? 1 : 0]; break;
-        case kAuxRead0: case kAuxRead1: case kAuxRead2: case kAuxRead3:
+        case kAuxRead0: case kAuxRead1: case kAuxRead2: case kAuxRead3: case kAuxRead4:
           v = a.read_aux ? a.read_aux[static_cast<size_t>(r) * DV_READ_AUX_STRIDE +
                                       (c->kind[ch] - kAuxRead0)]
                          : 0;
           break;
         case kAuxList: v = a.list_aux ? a.list_aux[le] : 0; break;
+        case kBaseAux0: if (a.base_aux0) dyn_b = 1; break;
+        case kBaseAux1: if (a.base_aux1) dyn_b = 2; break;
         default: break;  // kZero
       }
       konst[d] |= v << sh;
@@ -449,8 +459,12 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         rk[d] = __builtin_amdgcn_readfirstlane(c->ref_konst[d]);
         rs[d] = __builtin_amdgcn_readfirstlane(c->ref_sel[d]);
       }
+      const size_t ref_row = static_cast<size_t>(a.item_ref_idx[item]) * W;
       for (int col = lane; col < W; col += 64) {
-        const uint32_t bv = c->lut_base[ref[col]];
+        uint32_t bv = c->lut_base[ref[col]];
+        if (a.ref_aux0) bv |= static_cast<uint32_t>(a.ref_aux0[ref_row + col]) << 8;
+        if (a.ref_aux1) bv |= static_cast<uint32_t>(a.ref_aux1[ref_row + col]) << 16;
+        if (a.ref_aux2) bv |= static_cast<uint32_t>(a.ref_aux2[ref_row + col]) << 24;
         uint32_t o[kPixDw];
 #pragma unroll
         for (int d = 0; d < kPixDw; ++d) o[d] = __builtin_amdgcn_perm(bv, rk[d], rs[d]);
@@ -581,7 +595,10 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
             if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_a, konst[d], sel_a[d]);
           }
           if (any_b) {
-            const uint32_t dyn_b = c->lut_mod[a.mod_6ma[s0 + ri[q]]];
+            uint32_t dyn_b = 0;  // {6mA, is_homopolymer, homopolymer_weighted} pixels of this base
+            if ((flags & DV_READ_HAS_6MA) && a.mod_6ma) dyn_b = c->lut_mod[a.mod_6ma[s0 + ri[q]]];
+            if (a.base_aux0) dyn_b |= static_cast<uint32_t>(a.base_aux0[s0 + ri[q]]) << 8;
+            if (a.base_aux1) dyn_b |= static_cast<uint32_t>(a.base_aux1[s0 + ri[q]]) << 16;
 #pragma unroll
             for (int d = 0; d < kPixDw; ++d) {
               if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_b, o[d], sel_b[d]);
@@ -742,6 +759,9 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
       case DV_CH_AVG_BASE_QUALITY: kind = kAuxRead1; ref = 254; break;
       case DV_CH_IDENTITY: kind = kAuxRead2; ref = 254; break;
       case DV_CH_GAP_COMPRESSED_IDENTITY: kind = kAuxRead3; ref = 254; break;
+      case DV_CH_GC_CONTENT: kind = kAuxRead4; break;
+      case DV_CH_IS_HOMOPOLYMER: kind = kBaseAux0; break;
+      case DV_CH_HOMOPOLYMER_WEIGHTED: kind = kBaseAux1; break;
       case DV_CH_BLANK: kind = kZero; break;
       case DV_CH_INSERT_SIZE: kind = kInsert; ref = 254; break;
       case DV_CH_MEAN_COVERAGE: kind = kZero; k->mean_cov_channel = c; break;
@@ -766,8 +786,10 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
   }
   for (int c = 0; c < o.n_channels; ++c) {
     const int d = c >> 2, sh = (c & 3) * 8;
-    if (k->kind[c] == kBase) {
-      k->ref_sel[d] = (k->ref_sel[d] & ~(0xFFu << sh)) | (4u << sh);
+    const int dyn = k->kind[c] == kBase ? 4 : k->kind[c] == kBaseAux0 ? 5
+                    : k->kind[c] == kBaseAux1 ? 6 : k->kind[c] == kAuxRead4 ? 7 : -1;
+    if (dyn >= 0) {  // reference-row byte taken from {base colour, ref_aux0, ref_aux1, ref_aux2}
+      k->ref_sel[d] = (k->ref_sel[d] & ~(0xFFu << sh)) | (static_cast<uint32_t>(dyn) << sh);
     } else {
       k->ref_konst[d] |= static_cast<uint32_t>(k->ref_const[c]) << sh;
     }
@@ -982,6 +1004,11 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     DV_STAGE(list_code, b->n_list)
     DV_STAGE(list_group, b->n_list)
     DV_STAGE(list_aux, b->n_list)
+    DV_STAGE(base_aux0, b->n_bases)
+    DV_STAGE(base_aux1, b->n_bases)
+    DV_STAGE(ref_aux0, static_cast<size_t>(b->n_ref_windows) * W)
+    DV_STAGE(ref_aux1, static_cast<size_t>(b->n_ref_windows) * W)
+    DV_STAGE(ref_aux2, static_cast<size_t>(b->n_ref_windows) * W)
 #undef DV_STAGE
   } else {
 #define DV_PASS(field) a.field = b->field;
@@ -994,6 +1021,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     DV_PASS(item_height) DV_PASS(item_out_off) DV_PASS(item_blank_mask)
     DV_PASS(item_mean_coverage) DV_PASS(ref_windows) DV_PASS(list_read)
     DV_PASS(list_code) DV_PASS(list_group) DV_PASS(list_aux)
+    DV_PASS(base_aux0) DV_PASS(base_aux1) DV_PASS(ref_aux0) DV_PASS(ref_aux1) DV_PASS(ref_aux2)
 #undef DV_PASS
   }
 

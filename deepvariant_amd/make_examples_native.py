@@ -225,14 +225,17 @@ class ExamplesGenerator:
     tables = []
     for reads in reads_per_sample:
       if isinstance(reads, packing.ReadTable):
-        if self._encoder_api._need_aux and reads.read_aux is None:
+        if ((self._encoder_api._need_aux and reads.read_aux is None) or
+            (self._encoder_api._need_seq_aux and reads.base_aux0 is None)):
           raise ValueError('this channel set needs per-read aux pixels; pack the reads with '
                            'ReadTable.from_reads(need_aux=True)')
         tables.append(reads)
       else:
-        tables.append(packing.ReadTable.from_reads(reads, need_aux=self._encoder_api._need_aux))
+        tables.append(packing.ReadTable.from_reads(reads, need_aux=self._encoder_api._need_aux,
+                                                   need_seq_aux=self._encoder_api._need_seq_aux))
     merged, sample_base = _concat_tables(tables)
-    batch = packing.PackedBatch(table=merged, width=width)
+    batch = packing.PackedBatch(table=merged, width=width,
+                                use_ref_aux=self._encoder_api._need_ref_aux)
     plan = []  # (candidate index, alt_combination)
     for ci, cand in enumerate(candidates):
       variant = cand.variant
@@ -403,7 +406,8 @@ def _concat_tables(tables: List[packing.ReadTable]):
       bases=cat('bases', np.uint8), quals=cat('quals', np.uint8),
       mod_5mc=opt('mod_5mc'), mod_6ma=opt('mod_6ma'), cigar=cat('cigar', np.uint32),
       keys=[k for t in tables for k in t.keys],
-      read_end=cat('read_end', np.int64))
+      read_end=cat('read_end', np.int64),
+      base_aux0=opt('base_aux0'), base_aux1=opt('base_aux1'))
   return merged, base
 
 

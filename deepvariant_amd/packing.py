@@ -23,7 +23,9 @@ DV_READ_REVERSE, DV_READ_SUPPLEMENTARY, DV_READ_HAS_5MC, DV_READ_HAS_6MA = 1, 2,
 
 # Channels whose pixel the device computes itself / which need host-computed
 # aux bytes (include/dvhip.h DV_CH_*).
-_READ_AUX_SLOT = {11: 0, 12: 1, 13: 2, 14: 3}
+_READ_AUX_SLOT = {11: 0, 12: 1, 13: 2, 14: 3, 15: 4}
+_SEQ_AUX_CHANNELS = (16, 17)        # is_homopolymer, homopolymer_weighted: per-base pixels
+_REF_AUX_CHANNELS = (15, 16, 17)    # ... and gc_content: per-window reference-row pixels
 _LIST_AUX_CHANNELS = (8, 27)
 
 
@@ -79,6 +81,48 @@ def _scale_color(value: int, max_val: float) -> int:
   return int(np.float32(254.0) * (np.float32(value) / mv)) & 0xFF
 
 
+def is_homopolymer_pixels(seq: bytes) -> np.ndarray:
+  """IsHomopolymerChannel::IsHomopolymer + ScaleColorVector(.., 1)
+  (channels/is_homopolymer_channel.cc:83-113): runs of >= 3 equal bases -> 254."""
+  b = np.frombuffer(seq, np.uint8)
+  out = np.zeros(b.size, np.uint8)
+  if b.size >= 3:
+    trip = (b[2:] == b[1:-1]) & (b[1:-1] == b[:-2])
+    out[2:][trip] = 254
+    out[1:-1][trip] = 254
+    out[:-2][trip] = 254
+  return out
+
+
+_HW_LUT = None
+
+
+def homopolymer_weighted_pixels(seq: bytes) -> np.ndarray:
+  """HomopolymerWeightedChannel::HomopolymerWeighted + ScaleColorVector(.., 30)
+  (channels/homopolymer_weighted_channel.cc:85-122).  The reference keeps run lengths
+  in a vector<uint8_t>, so runs wrap modulo 256 before the cap at 30."""
+  global _HW_LUT
+  if _HW_LUT is None:
+    _HW_LUT = np.array([_scale_color(v, 30.0) for v in range(256)], np.uint8)
+  b = np.frombuffer(seq, np.uint8)
+  if b.size == 0:
+    return np.zeros(0, np.uint8)
+  change = np.flatnonzero(b[1:] != b[:-1]) + 1
+  starts = np.concatenate([[0], change])
+  lens = np.diff(np.concatenate([starts, [b.size]]))
+  return _HW_LUT[np.repeat(lens, lens) & 0xFF]
+
+
+def gc_content_pixel(seq: bytes) -> int:
+  """GcContentChannel::GcContent + ScaleColor(.., 100) (channels/gc_content_channel.cc:78-101)."""
+  if not seq:
+    return 0
+  b = np.frombuffer(seq, np.uint8)
+  gc = int(((b == ord('G')) | (b == ord('C'))).sum())
+  pct = int(np.float32(gc) / np.float32(len(seq)) * np.float32(100))
+  return _scale_color(pct, 100.0)
+
+
 def read_key(read) -> str:
   """read_supports_variant_channel.cc:78-79."""
   return '%s/%d' % (read.fragment_name, read.read_number)
@@ -124,10 +168,12 @@ class ReadTable:
   cigar: np.ndarray
   keys: List[str]
   read_end: np.ndarray
+  base_aux0: Optional[np.ndarray] = None  # is_homopolymer pixel per base
+  base_aux1: Optional[np.ndarray] = None  # homopolymer_weighted pixel per base
 
   @classmethod
   def from_reads(cls, reads: Sequence, alignment_positions=None,
-                 need_aux: bool = False) -> 'ReadTable':
+                 need_aux: bool = False, need_seq_aux: bool = False) -> 'ReadTable':
     n = len(reads)
     pos = np.zeros(n, np.int32)
     mapq = np.zeros(n, np.uint8)
@@ -223,6 +269,7 @@ class ReadTable:
         if gap_len:
           aux[i, 3] = _scale_color(
               int(f32(match_len) / f32(gap_len) * f32(100)), 100)
+        aux[i, 4] = gc_content_pixel(sb)
       keys.append(read_key(r))
       sort_keys.append((r.fragment_name.encode(), int(r.read_number)))
     # dense rank under the reference's tuple<string,int> ordering
@@ -242,7 +289,11 @@ class ReadTable:
         quals=np.frombuffer(b''.join(quals), np.uint8),
         mod_5mc=np.frombuffer(b''.join(m5), np.uint8) if any5 else None,
         mod_6ma=np.frombuffer(b''.join(m6), np.uint8) if any6 else None,
-        cigar=np.array(cig, np.uint32), keys=keys, read_end=read_end)
+        cigar=np.array(cig, np.uint32), keys=keys, read_end=read_end,
+        base_aux0=(np.concatenate([is_homopolymer_pixels(x) for x in seqs] or
+                                  [np.zeros(0, np.uint8)]) if need_seq_aux else None),
+        base_aux1=(np.concatenate([homopolymer_weighted_pixels(x) for x in seqs] or
+                                  [np.zeros(0, np.uint8)]) if need_seq_aux else None))
 
   @classmethod
   def from_bam(cls, path: str, contig: Optional[str] = None, start: int = 0,
@@ -377,6 +428,7 @@ class PackedBatch:
   list_aux_chunks: List[np.ndarray] = dataclasses.field(default_factory=list)
   use_groups: bool = False
   use_list_aux: bool = False
+  use_ref_aux: bool = False   # build ref_aux0..2 (sequence-context channels' reference rows)
   _frozen: Optional[dict] = None
 
   # ---- building -----------------------------------------------------------
@@ -431,6 +483,14 @@ class PackedBatch:
           list_code=cat(self.list_code_chunks, np.uint8),
           list_group=cat(self.list_group_chunks, np.uint8),
           list_aux=cat(self.list_aux_chunks, np.uint8))
+      if self.use_ref_aux:
+        wins = self.ref_windows_list
+        plane = lambda fn: (np.concatenate([fn(w) for w in wins]) if wins
+                            else np.zeros(0, np.uint8))
+        self._frozen['ref_aux0'] = plane(is_homopolymer_pixels)
+        self._frozen['ref_aux1'] = plane(homopolymer_weighted_pixels)
+        self._frozen['ref_aux2'] = plane(
+            lambda w: np.full(len(w), gc_content_pixel(w), np.uint8))
     return self._frozen
 
   def __getattr__(self, name):
@@ -443,6 +503,8 @@ class PackedBatch:
       if name == 'list_aux' and not self.use_list_aux:
         return None
       return fz[name]
+    if name in ('ref_aux0', 'ref_aux1', 'ref_aux2'):
+      return None
     t = self.__dict__.get('table')
     if t is not None and hasattr(t, name):
       return getattr(t, name)
@@ -512,6 +574,10 @@ class PackedBatch:
     b.list_code = ptr(fz['list_code'], np.uint8)
     b.list_group = ptr(fz['list_group'], np.uint8) if self.use_groups else None
     b.list_aux = ptr(fz['list_aux'], np.uint8) if self.use_list_aux else None
+    b.base_aux0 = ptr(t.base_aux0, np.uint8)
+    b.base_aux1 = ptr(t.base_aux1, np.uint8)
+    for name in ('ref_aux0', 'ref_aux1', 'ref_aux2'):
+      setattr(b, name, ptr(fz.get(name), np.uint8))
     b.n_list = int(fz['item_list_off'][-1])
     b.max_list_len = self.max_list_len
     return b, keep

@@ -67,6 +67,8 @@ class PileupImageEncoderNative:
                          for e in self._channel_enums)
     self._need_list_aux = any(e in packing._LIST_AUX_CHANNELS
                               for e in self._channel_enums)
+    self._need_seq_aux = any(e in packing._SEQ_AUX_CHANNELS for e in self._channel_enums)
+    self._need_ref_aux = any(e in packing._REF_AUX_CHANNELS for e in self._channel_enums)
     if 27 in self._channel_enums:
       raise NotImplementedError(
           'allele_sample_probability iterates a proto map in hash order in the '
@@ -105,8 +107,8 @@ class PileupImageEncoderNative:
     width = len(ref_bases)
     table = packing.ReadTable.from_reads(
         reads, alignment_positions=alignment_positions,
-        need_aux=self._need_aux)
-    batch = packing.PackedBatch(table=table, width=width)
+        need_aux=self._need_aux, need_seq_aux=self._need_seq_aux)
+    batch = packing.PackedBatch(table=table, width=width, use_ref_aux=self._need_ref_aux)
     ref_idx = batch.add_ref_window(ref_bases)
     idx = np.arange(len(reads), dtype=np.uint32)
     codes = packing.support_codes(dv_call, alt_alleles, table, idx)

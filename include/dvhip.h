@@ -60,6 +60,9 @@ enum {
   DV_CH_AVG_BASE_QUALITY = 12,         /* read_aux[1] */
   DV_CH_IDENTITY = 13,                 /* read_aux[2] */
   DV_CH_GAP_COMPRESSED_IDENTITY = 14,  /* read_aux[3] */
+  DV_CH_GC_CONTENT = 15,               /* read: read_aux[4]; reference row: ref_aux2 */
+  DV_CH_IS_HOMOPOLYMER = 16,           /* per base: base_aux0; reference row: ref_aux0 */
+  DV_CH_HOMOPOLYMER_WEIGHTED = 17,     /* per base: base_aux1; reference row: ref_aux1 */
   DV_CH_BLANK = 18,
   DV_CH_INSERT_SIZE = 19,
   DV_CH_MEAN_COVERAGE = 22,
@@ -191,6 +194,15 @@ typedef struct dv_batch {
   const uint8_t* list_aux;    /* NULL; host-computed pixel for DV_CH_ALLELE_* */
   uint32_t n_list;            /* = item_list_off[n_items] */
   uint32_t max_list_len;      /* upper bound on any item's list length */
+
+  /* ---- sequence-context channels (channels/{is_homopolymer,homopolymer_weighted,
+   * gc_content}_channel.cc): host-computed PIXELS, all optional (NULL unless the channel
+   * list asks for them) ---- */
+  const uint8_t* base_aux0; /* parallel to bases: is_homopolymer pixel of every read base */
+  const uint8_t* base_aux1; /* parallel to bases: homopolymer_weighted pixel */
+  const uint8_t* ref_aux0;  /* [n_ref_windows][width]: is_homopolymer pixel of the window */
+  const uint8_t* ref_aux1;  /* [n_ref_windows][width]: homopolymer_weighted pixel */
+  const uint8_t* ref_aux2;  /* [n_ref_windows][width]: gc_content pixel of the window, repeated */
 } dv_batch;
 
 typedef struct dv_encoder dv_encoder;

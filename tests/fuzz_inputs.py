@@ -91,6 +91,8 @@ CONFIGS = [
     ('aux_channels', ['read_base', 'read_mapping_percent', 'avg_base_quality', 'identity',
                       'gap_compressed_identity', 'blank', 'mean_coverage', 'insert_size'],
      51, 30, {}, {}),
+    ('seq_context', T.PILEUP_DEFAULT_CHANNELS + ['gc_content', 'is_homopolymer',
+                                                 'homopolymer_weighted'], 45, 26, {}, {}),
     ('sort_by_support', T.PILEUP_DEFAULT_CHANNELS, 41, 24,
      dict(sort_by_alt_allele_support=True), {}),
 ]

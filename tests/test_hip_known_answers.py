@@ -4,6 +4,7 @@ Same vectors as tests/test_oracle_known_answers.py, but `make` is the product:
 deepvariant_amd.pileup_image_native.PileupImageEncoderNative ->
 packing -> dv_encode_batch (libdvhip.so) on the GPU.
 """
+import numpy as np
 import pytest
 
 from tests import known_answers as KA
@@ -81,8 +82,22 @@ def test_build_pileup(name):
 def test_unsupported_channel_fails_loudly():
   from deepvariant_amd import _lib
   with pytest.raises(_lib.DvError) as e:
-    make(KA.default_options(['is_homopolymer'])).encode_reference('ACGTA')
+    make(KA.default_options(['read_supports_variant_fuzzy'])).encode_reference('ACGTA')
   assert e.value.status == _lib.DV_ERR_UNSUPPORTED
+
+
+def test_sequence_context_channels_reference_rows():
+  """gc_content / is_homopolymer / homopolymer_weighted reference rows
+  (channels/*_channel.cc FillRefBase; vectors of pileup_channel_lib_test.cc:487-560:
+  ATCGGGAG -> 00011100, ATCGGGAA -> 11133322)."""
+  from oracle import oracle as O
+  opts = KA.default_options(['gc_content', 'is_homopolymer', 'homopolymer_weighted'])
+  ref = 'ATCGGGAAT'
+  got = make(opts).encode_reference(ref)
+  np.testing.assert_array_equal(got, O.encode_reference(opts, ref))
+  assert got[0, :, 1].tolist() == [0, 0, 0, 254, 254, 254, 0, 0, 0]
+  assert got[0, :, 2].tolist() == [8, 8, 8, 25, 25, 25, 16, 16, 8]
+  assert set(got[0, :, 0].tolist()) == {int(254.0 * (44 / 100.0))}   # 4 of 9 bases are G/C
 
 
 def test_unknown_cigar_op_is_an_error():
