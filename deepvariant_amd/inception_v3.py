@@ -118,20 +118,3 @@ class InceptionV3(torch.nn.Module):
         _lib.lib().dv_model_destroy(self._handle)
     except Exception:  # pylint: disable=broad-except
       pass
-
-
-def smoke(images_u8: np.ndarray):
-  """Tiny forward on cuda:0 checked against the fp32 CPU oracle (1e-3)."""
-  from oracle import inception_ref as R  # checker only
-  n = min(4, images_u8.shape[0])
-  h, w, c = images_u8.shape[1:]
-  ref = R.make_random_model(c, seed=1)
-  model = InceptionV3((h, w, c), max_batch=8)
-  model.load_flat_weights(ref.export_flat())
-  x = torch.from_numpy(np.ascontiguousarray(images_u8[:n]))
-  got = model(x.cuda()).cpu()
-  with torch.no_grad():
-    want = ref(x)
-  err = float((got - want).abs().max())
-  assert err <= 1e-3, 'softmax differs from the fp32 oracle by %g' % err
-  print('inception smoke ok: max |dp| = %.2e' % err)

@@ -62,3 +62,16 @@ def test_model_create_rejects_oversized_batch_before_touching_a_device():
   assert b'max_batch' in lib.dv_last_error()
   desc = _lib.DvModelDesc(64, 221, 7, 3, 16)        # H < 75: Inception-v3's minimum
   assert lib.dv_model_create(C.byref(desc), 0, C.byref(handle)) == _lib.DV_ERR_INVALID_ARGUMENT
+
+
+def test_product_package_never_imports_the_oracle():
+  """oracle/ is test infrastructure: nothing under deepvariant_amd/ may import it."""
+  import os
+  import re
+  root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'deepvariant_amd')
+  for dirpath, _, files in os.walk(root):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.cpp', '.h')):
+        text = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+        assert 'libdvoracle' not in text, f
