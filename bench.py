@@ -166,10 +166,8 @@ def main():
   assert torch.isfinite(probs).all()
 
   if rank == 0:
-    from oracle import inception_ref  # FLOP accounting + CPU baseline only
     value = items_per_step * args.steps / elapsed
-    macs = inception_ref.macs_per_example(C, H, W)
-    conv_flops_per_item = 2.0 * (macs - 2048 * 3)
+    conv_flops_per_item = 2.0 * model.conv_macs_per_example
     conv_tflops = (conv_flops_per_item * n_items * args.steps /
                    (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0
     bytes_per_item = algorithmic_bytes_per_item(host_batch, C)

@@ -1490,6 +1490,17 @@ void dv_model_destroy(dv_model* m) {
 
 int64_t dv_model_num_params(const dv_model* m) { return m ? m->n_params : 0; }
 
+int64_t dv_model_conv_macs(const dv_model* m) {
+  if (!m) return 0;
+  int64_t macs = 0;
+  for (const Op& op : m->ops) {
+    if (op.type == kOpConv) {
+      macs += static_cast<int64_t>(op.kh) * op.kw * op.cin_real * op.cout * op.oh * op.ow;
+    }
+  }
+  return macs;
+}
+
 int dv_model_num_layers(const dv_model* m) {
   return m ? static_cast<int>(m->layers.size()) : 0;
 }

@@ -97,6 +97,10 @@ class InceptionV3(torch.nn.Module):
         C.c_void_p(stream)))
     return probs
 
+  @property
+  def conv_macs_per_example(self) -> int:
+    return int(_lib.lib().dv_model_conv_macs(self._handle))
+
   def debug_tensor(self, index: int, n: int) -> np.ndarray:
     h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
     l = _lib.lib()

@@ -321,6 +321,10 @@ void dv_model_destroy(dv_model* m);
  * order, i.e. checkpoint `layer_with_weights-N` order
  * (deepvariant/keras_modeling.py:176-184). */
 int64_t dv_model_num_params(const dv_model* m);
+/* Multiply-accumulates of the 94 convolutions for ONE example of the model's input
+ * shape (padding taps included, as in every FLOP count of this architecture): the
+ * algorithmic work bench.py prices the conv kernels with. */
+int64_t dv_model_conv_macs(const dv_model* m);
 int dv_model_num_layers(const dv_model* m);
 int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
                         int32_t* cin, int32_t* cout, int64_t* param_offset);

@@ -175,3 +175,14 @@ def test_preprocess_known_answer_all_byte_values():
   got1 = np.array([out[i // 37, i % 37] for i in range(256)]) - 2.0
   np.testing.assert_allclose(got1, want, atol=2e-3)   # fp16 output grid near 2.0 is 2^-9
   assert got1[128] == 0.0 and got1[0] == -1.0
+
+
+def test_conv_macs_match_the_architecture_count():
+  """dv_model_conv_macs (what bench.py prices the conv kernels with) equals the count of
+  the fp32 restatement: 1.005 GMAC at 100x221x7 (2.011 GFLOP per example)."""
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  for shape in ((100, 221, 7), (100, 147, 10)):
+    model = InceptionV3(shape, max_batch=1)
+    assert model.conv_macs_per_example == R.macs_per_example(shape[2], shape[0], shape[1]) - 2048 * 3
+  assert abs(2 * InceptionV3((100, 221, 7), max_batch=1).conv_macs_per_example - 2.0105e9) < 1e6
