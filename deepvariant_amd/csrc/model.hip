@@ -745,51 +745,62 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
 }
 
 // AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.  The input
-// buffer carries a zero halo of >= 1 (build() asks for it), so the nine taps are
-// unconditional 16-byte loads and only the divisor depends on the position.
+// buffer carries a zero halo of >= 1 (build() asks for it), so the taps are unconditional
+// 16-byte loads and only the divisor depends on the position.  One thread produces TWO
+// horizontally adjacent outputs from a 3x4 window (12 loads instead of 18): the three
+// column sums in the middle are shared.
 __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int cg = p.C / 8;
   const int H = p.ig.h, W = p.ig.w;
-  const size_t total = static_cast<size_t>(p.N) * cg * H * W;
+  const int W2 = (W + 1) >> 1;
+  const size_t total = static_cast<size_t>(p.N) * cg * H * W2;
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= total) return;
-  const int ow = i % W;
-  size_t t = i / W;
+  const int ow = 2 * static_cast<int>(i % W2);
+  size_t t = i / W2;
   const int oh = t % H;
   t /= H;
   const int g = t % cg;
   const int n = t / cg;
+  const bool two = ow + 1 < W;
   const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
                        ((static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp + oh + p.ig.halo - 1) *
                            p.ig.wp + ow + p.ig.halo - 1;
-  half8_t v[9];
+  const int last = two ? 3 : 2;  // never read past the row's halo
+  float col[4][8];
 #pragma unroll
-  for (int dh = 0; dh < 3; ++dh)
+  for (int dw = 0; dw < 4; ++dw) {
+    const int c = dw < 3 ? dw : last;
+    const half8_t a = src[c], b = src[p.ig.wp + c], d = src[2 * p.ig.wp + c];
 #pragma unroll
-    for (int dw = 0; dw < 3; ++dw) v[dh * 3 + dw] = src[dh * p.ig.wp + dw];
-  float s[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a += static_cast<float>(v[k][j]);
-    s[j] = a;
+    for (int j = 0; j < 8; ++j) {
+      col[dw][j] = static_cast<float>(a[j]) + static_cast<float>(b[j]) + static_cast<float>(d[j]);
+    }
   }
-  const int cnt = ((oh > 0) + (oh < H - 1) + 1) * ((ow > 0) + (ow < W - 1) + 1);
-  half8_t o;
-  const float inv = 1.0f / static_cast<float>(cnt);
+  const int rows = (oh > 0) + (oh < H - 1) + 1;
+  float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (p.shift != nullptr) {
     const float4 s0 = *reinterpret_cast<const float4*>(p.shift + g * 8);
     const float4 s1 = *reinterpret_cast<const float4*>(p.shift + g * 8 + 4);
-    const float sh[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(fmaxf(s[j] * inv + sh[j], 0.f));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = static_cast<_Float16>(s[j] * inv);
+    sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
+    sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
   }
-  reinterpret_cast<half8_t*>(p.out)[((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) *
-                                         p.og.hp + oh + p.og.halo) * p.og.wp + ow + p.og.halo] = o;
+  half8_t* dst = reinterpret_cast<half8_t*>(p.out) +
+                 ((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) * p.og.hp + oh +
+                  p.og.halo) * p.og.wp + ow + p.og.halo;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1 && !two) break;
+    const int x = ow + k;
+    const float inv = 1.0f / static_cast<float>(rows * ((x > 0) + (x < W - 1) + 1));
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (col[k][j] + col[k + 1][j] + col[k + 2][j]) * inv;
+      o[j] = static_cast<_Float16>(p.shift != nullptr ? fmaxf(v + sh[j], 0.f) : v);
+    }
+    dst[k] = o;
+  }
 }
 
 // GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
@@ -1390,7 +1401,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       p.shift = op.pool_shift_relu
                     ? static_cast<const float*>(m->d_shift.ptr) + op.shift_off
                     : nullptr;
-      const size_t total = static_cast<size_t>(n) * op.oh * op.ow * (op.cin / 8);
+      const size_t total = static_cast<size_t>(n) * op.oh *
+                           (op.type == kOpAvgPool ? (op.ow + 1) / 2 : op.ow) * (op.cin / 8);
       const dim3 grid(static_cast<unsigned>((total + 255) / 256));
       TraceScope tr(stream, std::string(op.type == kOpMaxPool ? "maxpool3s2 " : "avgpool3s1 ") +
                                 std::to_string(op.cin) + " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow),
