@@ -36,6 +36,7 @@
 #include <hip/hip_fp16.h>
 
 #include "dv_internal.h"
+#include "stem_fused.h"
 
 namespace {
 
@@ -884,6 +885,10 @@ struct Op {
   bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
   bool pool_in = false;          // 1x1 conv that max-pools (3x3, stride 2) its input on the fly
+  // Fused stem (stem.hip): the op marked stem_a / stem_b runs together with the op that
+  // follows it as ONE launch; the tensor between them is never materialised.
+  bool stem_a = false;           // first conv (uint8 input) + conv 3x3 32->32
+  bool stem_b = false;           // conv 3x3 32->64 + maxpool 3x3/2 + conv 1x1 64->80
 };
 
 struct LayerInfo {
@@ -902,6 +907,7 @@ struct dv_model {
   int64_t n_params = 0;
   int feat_buf = -1, feat_p = 0, feat_c = 0;
   int stem_ops_end = 0, stem_out_buf = -1;
+  int stem_a_grid = 512, stem_b_grid = 256;  // persistent grids of the fused stem kernels
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
@@ -1097,6 +1103,16 @@ struct dv_model {
       x = pool(kOpMaxPool, x);
       x = conv(x, 80, 1, 1, 1, false);
     }
+    // Fused stem kernels (stem.hip): conv1+conv2 and conv3+maxpool+1x1 as two persistent
+    // launches whose intermediates stay in LDS.  DV_NO_STEM_FUSE keeps the per-layer path
+    // (also used for inputs with more than 8 channels).
+    if (ops[0].first_u8 && ops[3].pool_in && getenv("DV_NO_STEM_FUSE") == nullptr &&
+        ops[3].cout <= 96) {
+      ops[0].stem_a = true;
+      ops[2].stem_b = true;
+      buffers[ops[0].out_buf] = {1, 1, 32, 0};  // conv1 output: LDS only
+      buffers[ops[2].out_buf] = {1, 1, 64, 0};  // conv3 output: LDS only
+    }
     x = conv(x, 192, 3, 3, 1, false);
     x = pool(kOpMaxPool, x);
     // Everything up to here is the "stem": big feature maps (0.2-0.7 MB per
@@ -1277,7 +1293,70 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
     const size_t out_shift_halfs =
         op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
                                   : 0;
-    if (op.type == kOpConv && op.first_u8) {
+    if (op.type == kOpConv && op.stem_a) {
+      const Op& c2 = m->ops[oi + 1];
+      const BufferDesc& o2 = m->buffers[c2.out_buf];
+      dv::StemAArgs a{};
+      a.in = images;
+      a.w1 = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
+      a.w2 = static_cast<const _Float16*>(m->d_w.ptr) + c2.w_off;
+      a.shift1 = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
+      a.shift2 = static_cast<const float*>(m->d_shift.ptr) + c2.shift_off;
+      a.out = static_cast<_Float16*>(m->dbuf[c2.out_buf].ptr);
+      const TensorGeom g = o2.geom();
+      a.og = dv::C8Geom{g.h, g.w, g.halo, g.hp, g.wp, g.groups};
+      a.N = n;
+      a.H = op.ih;
+      a.W = op.iw;
+      a.C = op.cin_real;
+      a.OH1 = op.oh;
+      a.OW1 = op.ow;
+      a.OH2 = c2.oh;
+      a.OW2 = c2.ow;
+      a.tiles_y = (c2.oh + dv::kStemA_TH - 1) / dv::kStemA_TH;
+      a.tiles_x = (c2.ow + dv::kStemA_TW - 1) / dv::kStemA_TW;
+      a.total_tiles = n * a.tiles_y * a.tiles_x;
+      a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin_real);
+      TraceScope tr(stream, "stem_a conv3x3s2 " + std::to_string(op.cin_real) + "->32 + conv3x3 32->32 (fused)",
+                    2.0 * n * (static_cast<double>(op.oh) * op.ow * op.kh * op.kw * op.cin_real * op.cout +
+                               static_cast<double>(c2.oh) * c2.ow * 9 * 32 * 32),
+                    static_cast<double>(n) * (op.ih * op.iw * op.cin_real + 2.0 * c2.oh * c2.ow * 32));
+      dv::ProfileScope prof(dv::kProfConv, stream);
+      dv::launch_stem_a(a, m->stem_a_grid, stream);
+      oi += 1;
+    } else if (op.type == kOpConv && op.stem_b) {
+      const Op& c4 = m->ops[oi + 1];
+      const BufferDesc& ib = m->buffers[op.in_buf];
+      const BufferDesc& o4 = m->buffers[c4.out_buf];
+      dv::StemBArgs a{};
+      a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      a.w3 = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
+      a.w4 = static_cast<const _Float16*>(m->d_w.ptr) + c4.w_off;
+      a.shift3 = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
+      a.shift4 = static_cast<const float*>(m->d_shift.ptr) + c4.shift_off;
+      a.out = static_cast<_Float16*>(m->dbuf[c4.out_buf].ptr);
+      const TensorGeom gi = ib.geom(), go = o4.geom();
+      a.ig = dv::C8Geom{gi.h, gi.w, gi.halo, gi.hp, gi.wp, gi.groups};
+      a.og = dv::C8Geom{go.h, go.w, go.halo, go.hp, go.wp, go.groups};
+      a.N = n;
+      a.OH3 = op.oh;
+      a.OW3 = op.ow;
+      a.PH = c4.oh;
+      a.PW = c4.ow;
+      a.Cout4 = c4.cout;
+      a.tiles_y = (c4.oh + dv::kStemB_PH - 1) / dv::kStemB_PH;
+      a.tiles_x = (c4.ow + dv::kStemB_PW - 1) / dv::kStemB_PW;
+      a.total_tiles = n * a.tiles_y * a.tiles_x;
+      a.in_bytes = static_cast<size_t>(n) * ib.bytes_per_example();
+      a.in_img_bytes = static_cast<unsigned>(ib.bytes_per_example());
+      TraceScope tr(stream, "stem_b conv3x3 32->64 + maxpool3s2 + conv1x1 64->" + std::to_string(c4.cout) + " (fused)",
+                    2.0 * n * (static_cast<double>(op.oh) * op.ow * 9 * 32 * 64 +
+                               static_cast<double>(c4.oh) * c4.ow * 64 * c4.cout),
+                    2.0 * n * (static_cast<double>(op.ih) * op.iw * 32 + static_cast<double>(c4.oh) * c4.ow * c4.cout));
+      dv::ProfileScope prof(dv::kProfConv, stream);
+      dv::launch_stem_b(a, m->stem_b_grid, stream);
+      oi += 1;
+    } else if (op.type == kOpConv && op.first_u8) {
       FirstConvArgs f{};
       f.in = images;
       f.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
@@ -1444,6 +1523,8 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->device = device;
   m->desc = *desc;
   m->build();
+  m->stem_a_grid = dv::stem_a_blocks(device);
+  m->stem_b_grid = dv::stem_b_blocks(device);
   // 32-bit index ranges of the kernels at max_batch (see conv_mfma_kernel's prologue)
   for (const Op& op : m->ops) {
     const BufferDesc& ob = m->buffers[op.out_buf];
@@ -1547,6 +1628,14 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       }
       inv[co] = 1.0f / std::sqrt(var[co] + 1e-3f);
       shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
+    }
+    if (m->ops[0].stem_a && oi < 4) {  // fused stem: stem.hip's own fragment images
+      _Float16* dst = packed.data() + op.w_off;
+      if (oi == 0) dv::pack_stem_a_w1(w, inv.data(), l.cin, dst);
+      if (oi == 1) dv::pack_stem_a_w2(w, inv.data(), dst);
+      if (oi == 2) dv::pack_stem_b_w3(w, inv.data(), dst);
+      if (oi == 3) dv::pack_stem_b_w4(w, inv.data(), l.cout, dst);
+      continue;
     }
     if (op.first_u8) {
       // [chunk kc][k-group g = tap 2kc+g][cout][8]: channel c < cin_real, else zero

@@ -1,0 +1,80 @@
+// Interface between model.hip (graph, weights) and stem.hip (the fused stem kernels).
+#ifndef DV_STEM_FUSED_H_
+#define DV_STEM_FUSED_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace dv {
+
+// Geometry of an fp16 activation tensor in the channel-blocked, zero-haloed
+// layout [N][C/8][h + 2 halo][w + 2 halo][8] (model.hip).
+struct C8Geom {
+  int h, w, halo, hp, wp, groups;
+};
+
+// ---- stem A: conv 3x3/2 (uint8 pileup, C <= 8 channels -> 32) + conv 3x3 32 -> 32 --------
+// tf_keras InceptionV3 stem layers 1-2 (deepvariant/keras_modeling.py:268-274 builds the
+// backbone); both 'valid'.  One workgroup produces a TH x TW tile of the SECOND conv: the
+// (TH+2) x (TW+2) tile of the first conv's output lives in LDS only.
+constexpr int kStemA_TH = 7, kStemA_TW = 54;
+constexpr int kStemA_W1Halfs = 5 * 2 * 32 * 8;    // conv1: 5 chunks (2 taps x 8 channels each)
+constexpr int kStemA_W2Halfs = 18 * 2 * 32 * 8;   // conv2: 9 taps x 2 channel chunks
+
+struct StemAArgs {
+  const uint8_t* in;      // [N][H][W][C]
+  const _Float16* w1;     // pack_stem_a_w1
+  const _Float16* w2;     // pack_stem_a_w2
+  const float* shift1;    // [32]
+  const float* shift2;    // [32]
+  _Float16* out;          // conv2 output, C8 layout, 4 groups
+  C8Geom og;
+  int N, H, W, C;
+  int OH1, OW1, OH2, OW2;
+  int tiles_y, tiles_x;
+  int total_tiles;        // N * tiles_y * tiles_x
+  unsigned in_bytes;      // N*H*W*C (< 2^31)
+};
+
+// ---- stem B: conv 3x3 'same' 32 -> 64, max-pool 3x3/2, conv 1x1 64 -> 80 -----------------
+// One workgroup produces a PH x PW tile of the 1x1's output; the conv3 tile
+// ((2PH+1) x (2PW+1) x 64) and its pooled image live in LDS only.
+constexpr int kStemB_PH = 12, kStemB_PW = 9;
+constexpr int kStemB_W3Halfs = 2 * 18 * 2 * 32 * 8;  // [cout half][9 taps x 2 chunks]
+constexpr int kStemB_W4Halfs = 3 * 4 * 2 * 32 * 8;   // [cout subtile][4 chunks]
+
+struct StemBArgs {
+  const _Float16* in;     // conv2 output (C8, 4 groups, halo >= 1)
+  const _Float16* w3;
+  const _Float16* w4;
+  const float* shift3;    // [64]
+  const float* shift4;    // [80] (+ padding to 96 readable)
+  _Float16* out;          // 1x1 output, C8 layout, 10 groups
+  C8Geom ig, og;
+  int N;
+  int OH3, OW3;           // conv3 output size (= its input size)
+  int PH, PW;             // pooled size
+  int Cout4;              // 80
+  int tiles_y, tiles_x;
+  int total_tiles;
+  size_t in_bytes;
+  unsigned in_img_bytes;
+};
+
+void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream);
+void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream);
+int stem_a_blocks(int device);
+int stem_b_blocks(int device);
+
+// Host-side weight packing.  `w` is the layer's HWIO kernel, `inv` the folded BatchNorm
+// scale 1/sqrt(var + eps) per output channel.
+void pack_stem_a_w1(const float* w, const float* inv, int cin, _Float16* dst);
+void pack_stem_a_w2(const float* w, const float* inv, _Float16* dst);
+void pack_stem_b_w3(const float* w, const float* inv, _Float16* dst);
+void pack_stem_b_w4(const float* w, const float* inv, int cout, _Float16* dst);
+
+}  // namespace dv
+
+#endif  // DV_STEM_FUSED_H_

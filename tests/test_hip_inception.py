@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
+def _per_layer_model(shape, max_batch):
+  """A model built with DV_NO_STEM_FUSE: one launch (and one HBM tensor) per stem layer."""
+  import os
+  from deepvariant_amd.inception_v3 import InceptionV3
+  os.environ['DV_NO_STEM_FUSE'] = '1'
+  try:
+    return InceptionV3(shape, max_batch=max_batch)
+  finally:
+    del os.environ['DV_NO_STEM_FUSE']
+
+
 def _pileups(n, channels, seed):
   from deepvariant_amd import synth
   from deepvariant_amd.pileup_image_native import _Encoder
@@ -71,7 +82,7 @@ def test_first_conv_matches_activation_by_activation():
   from deepvariant_amd.inception_v3 import InceptionV3
   from oracle import inception_ref as R
   ref = R.make_random_model(7, seed=5)
-  model = InceptionV3((100, 221, 7), max_batch=4)
+  model = _per_layer_model((100, 221, 7), 4)   # the fused stem never materialises this tensor
   model.load_flat_weights(ref.export_flat())
   x = torch.from_numpy(_pileups(2, 7, seed=4))
   model(x.cuda())
@@ -163,7 +174,7 @@ def test_preprocess_known_answer_all_byte_values():
   flat_w[n_w:n_w + 32] = 2.0
   flat_w[n_w + 32:n_w + 64] = 0.0
   flat_w[n_w + 64:n_w + 96] = 1.0 - 1e-3
-  model1 = InceptionV3((75, 75, 1), max_batch=1)
+  model1 = _per_layer_model((75, 75, 1), 1)
   model1.load_flat_weights(flat_w)
   x1 = np.zeros((1, 75, 75, 1), np.uint8)
   vals = np.arange(256, dtype=np.uint8)
@@ -175,6 +186,25 @@ def test_preprocess_known_answer_all_byte_values():
   got1 = np.array([out[i // 37, i % 37] for i in range(256)]) - 2.0
   np.testing.assert_allclose(got1, want, atol=2e-3)   # fp16 output grid near 2.0 is 2^-9
   assert got1[128] == 0.0 and got1[0] == -1.0
+  # (c) the conversion inside the fused stem kernel (stem.hip): the second conv copies the
+  # first conv's channel 0 (one-hot centre tap, BN shift 0), so conv2[oy, ox, 0] =
+  # conv1[oy+1, ox+1, 0] = (x - 128)/128 + 2 on the 2^-7 grid -- exact in fp16
+  k2 = np.zeros((3, 3, 32, 32), np.float32)
+  k2[1, 1, 0, 0] = 1.0
+  o2 = n_w + 96
+  flat_w[o2:o2 + k2.size] = k2.reshape(-1)
+  flat_w[o2 + k2.size:o2 + k2.size + 32] = 0.0           # beta
+  flat_w[o2 + k2.size + 32:o2 + k2.size + 64] = 0.0      # mean
+  flat_w[o2 + k2.size + 64:o2 + k2.size + 96] = 1.0 - 1e-3
+  model2 = InceptionV3((75, 75, 1), max_batch=1)
+  model2.load_flat_weights(flat_w)
+  model2(torch.from_numpy(x1).cuda())
+  out2 = model2.debug_tensor(2, 1).astype(np.float32)[0, :, :, 0]
+  halo = (out2.shape[0] - 35) // 2
+  got2 = np.array([out2[halo + i // 37 - 1, halo + i % 37 - 1]
+                   for i in range(256) if i // 37 >= 1 and 1 <= i % 37 <= 35]) - 2.0
+  want2 = np.array([want[i] for i in range(256) if i // 37 >= 1 and 1 <= i % 37 <= 35])
+  np.testing.assert_array_equal(got2, want2)
 
 
 def test_conv_macs_match_the_architecture_count():

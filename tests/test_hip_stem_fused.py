@@ -1,0 +1,139 @@
+"""Fused stem kernels (deepvariant_amd/csrc/stem.hip) vs the fp32 oracle and vs the
+per-layer HIP path (GPU).
+
+The fused launches compute the same chain as the first five layers of
+`oracle/inception_ref.InceptionV3.stem` (tf_keras InceptionV3 as built by
+deepvariant/keras_modeling.py:268-274): fp16 operands, fp32 accumulation, fp16
+hand-offs -- so against the per-layer path only the accumulation order differs
+(an fp16 ulp now and then), and against the fp32 oracle the tolerance is the fp16
+grid of the activations.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(n, channels, seed):
+  from deepvariant_amd import synth
+  from deepvariant_amd.pileup_image_native import _Encoder
+  opts = synth.illumina_options(channels)
+  k = max(1, (2 * n) // 3)
+  batch = synth.make_illumina_batch(k, seed=seed, options=opts, multi_allelic=False)
+  out, _ = _Encoder(opts, opts.width).encode(batch, channels)
+  real = out.reshape(-1, 100, 221, channels)[:k]
+  noise = np.random.default_rng(seed).integers(0, 256, (n - k, 100, 221, channels), dtype=np.uint8)
+  return np.concatenate([real, noise])
+
+
+def _model(shape, weights, max_batch, fused):
+  from deepvariant_amd.inception_v3 import InceptionV3
+  old = os.environ.pop('DV_NO_STEM_FUSE', None)
+  if not fused:
+    os.environ['DV_NO_STEM_FUSE'] = '1'
+  try:
+    m = InceptionV3(shape, max_batch=max_batch)
+  finally:
+    os.environ.pop('DV_NO_STEM_FUSE', None)
+    if old is not None:
+      os.environ['DV_NO_STEM_FUSE'] = old
+  m.load_flat_weights(weights)
+  return m
+
+
+def _interior(t, halo):
+  return t[:, halo:t.shape[1] - halo, halo:t.shape[2] - halo] if halo else t
+
+
+def _report(name, got, want, atol, rtol):
+  diff = np.abs(got - want)
+  bad = diff > atol + rtol * np.abs(want)
+  if bad.any():
+    idx = np.argwhere(bad)
+    lines = ['%s: %d / %d elements differ (max |d| = %g)' % (name, bad.sum(), bad.size, diff.max())]
+    for axis, label in enumerate(('example', 'row', 'col', 'channel')):
+      vals, counts = np.unique(idx[:, axis], return_counts=True)
+      lines.append('  bad %ss: %s' % (label, ', '.join(
+          '%d(x%d)' % (v, c) for v, c in list(zip(vals, counts))[:24])))
+    for i in idx[:8]:
+      lines.append('  at %s got %g want %g' % (tuple(i), got[tuple(i)], want[tuple(i)]))
+    pytest.fail('\n'.join(lines))
+
+
+@pytest.mark.parametrize('channels', [7, 6])
+def test_fused_stem_stage_by_stage(channels):
+  """conv2's and the 1x1's outputs (the two tensors the fused launches write) against
+  the fp32 oracle and against the per-layer HIP kernels, on more tiles than the persistent
+  grids have workgroups (every block walks 2-3 tiles)."""
+  from oracle import inception_ref as R
+  n = 80
+  ref = R.make_random_model(channels, seed=11)
+  w = ref.export_flat()
+  x = torch.from_numpy(_images(n, channels, seed=31))
+  fused = _model((100, 221, channels), w, n, fused=True)
+  plain = _model((100, 221, channels), w, n, fused=False)
+  fused(x.cuda())
+  plain(x.cuda())
+  pre = ((x.float() - 128.0) / 128.0).permute(0, 3, 1, 2)
+  with torch.no_grad():
+    c2 = ref.stem[1](ref.stem[0](pre))
+    c4 = ref.stem[3](R._maxpool(ref.stem[2](c2)))
+  want2 = c2.permute(0, 2, 3, 1).numpy()
+  want4 = c4.permute(0, 2, 3, 1).numpy()
+  # buffer 2 = conv2 output (halo 1: conv3 is 'same'), buffer 4 = 1x1 output (no halo)
+  got2 = _interior(fused.debug_tensor(2, n).astype(np.float32), 1)
+  got4 = fused.debug_tensor(4, n).astype(np.float32)
+  old2 = _interior(plain.debug_tensor(2, n).astype(np.float32), 1)
+  old4 = plain.debug_tensor(4, n).astype(np.float32)
+  assert got2.shape == want2.shape == (n, 47, 108, 32)
+  assert got4.shape == want4.shape == (n, 23, 53, 80)
+  _report('conv2 vs per-layer HIP', got2, old2, 4e-3, 4e-3)
+  _report('conv2 vs fp32 oracle', got2, want2, 2e-2, 2e-2)
+  _report('1x1 vs per-layer HIP', got4, old4, 8e-3, 8e-3)
+  _report('1x1 vs fp32 oracle', got4, want4, 3e-2, 3e-2)
+  # the halo ring of the conv2 buffer must still be zero (conv3 reads it as padding)
+  full2 = fused.debug_tensor(2, n)
+  assert not full2[:, 0].any() and not full2[:, -1].any()
+  assert not full2[:, :, 0].any() and not full2[:, :, -1].any()
+
+
+@pytest.mark.parametrize('shape', [(100, 147, 8), (75, 75, 1), (120, 301, 5)])
+def test_fused_stem_other_shapes(shape):
+  """Tile edges at other image sizes (partial tiles in both directions)."""
+  from oracle import inception_ref as R
+  h, w_, c = shape
+  n = 6
+  ref = R.make_random_model(c, seed=13)
+  x = torch.from_numpy(np.random.default_rng(c).integers(0, 256, (n, h, w_, c), dtype=np.uint8))
+  fused = _model(shape, ref.export_flat(), n, fused=True)
+  plain = _model(shape, ref.export_flat(), n, fused=False)
+  got = fused(x.cuda()).cpu()
+  old = plain(x.cuda()).cpu()
+  with torch.no_grad():
+    want = ref(x)
+  got4 = fused.debug_tensor(4, n).astype(np.float32)
+  old4 = plain.debug_tensor(4, n).astype(np.float32)
+  _report('1x1 vs per-layer HIP %s' % (shape,), got4, old4, 8e-3, 8e-3)
+  assert (got - want).abs().max().item() <= 1e-3
+  assert (got - old).abs().max().item() <= 5e-4
+
+
+def test_benchmark_configuration_against_the_oracle():
+  """600 ILLUMINA30 pileups in ONE forward: every kernel variant the bench batch uses
+  (fused stem, <NB,2>, <NB,4>, pooled 1x1) meets the fp32 oracle directly: softmax within
+  1e-3 (BASELINE.json), logits within a relative tolerance."""
+  from oracle import inception_ref as R
+  n = 600
+  ref = R.make_random_model(7, seed=17)
+  x = torch.from_numpy(_images(n, 7, seed=41))
+  model = _model((100, 221, 7), ref.export_flat(), n, fused=True)
+  got = model(x.cuda()).cpu()
+  torch.set_num_threads(min(32, os.cpu_count() or 1))
+  with torch.no_grad():
+    want = torch.cat([ref(x[i:i + 50]) for i in range(0, n, 50)])
+  err = (got - want).abs().max().item()
+  assert err <= 1e-3, err
+  assert (want.max(0).values - want.min(0).values).max() > 1e-2
