@@ -1,0 +1,170 @@
+// Device-side pieces shared by the convolution kernels of libdvhip.so (model.hip,
+// imgconv.hip): the C8 activation geometry, the launch arguments and the epilogue
+// that turns MFMA accumulators into 16-byte pieces of the output tensor(s).
+#ifndef DV_CONV_COMMON_H_
+#define DV_CONV_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace dv {
+namespace convk {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kConvThreads = 256;
+constexpr int kChunk = 16;       // channels per K chunk
+
+// Geometry of one activation tensor in HBM: fp16, channel-blocked and
+// zero-haloed, [N][C/8][H + 2*halo][W + 2*halo][8].  The halo is written once
+// (hipMemset at model creation) and never touched again: producers store the
+// interior only, so 'same'-padded convolutions read their padding as ordinary
+// in-bounds zeros and need no predicates.
+struct TensorGeom {
+  int h, w;     // interior size
+  int halo;
+  int hp, wp;   // padded size
+  int groups;   // channel groups of 8 (full concat width)
+};
+
+// One output branch of a (possibly grouped) convolution launch.
+struct ConvBranch {
+  const float* shift;     // [Cout (+pad)] folded BN shift, or NULL (raw output)
+  _Float16* out;
+  TensorGeom og;
+  int out_goff;           // first destination group of this branch
+  int Cout;
+  int relu;
+  int sub0;               // first 32-cout subtile of this branch in the launch's cout space
+};
+
+constexpr int kMaxBranches = 4;
+
+struct ConvArgs {
+  const _Float16* in;
+  // Sibling convolutions that read the SAME input with the same geometry (the
+  // 1x1 heads of an Inception block) run as one launch over the CONCATENATION of their
+  // output channels (each branch padded to whole 32-cout subtiles): one packed weight
+  // image, cout tiles of NB*32 that may straddle two branches, and an epilogue that
+  // routes every 32-cout subtile to its branch's tensor.  The input is fetched from HBM
+  // once and re-read from L2 by ceil(sum couts / (NB*32)) tiles instead of once per
+  // branch tile.
+  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
+  ConvBranch br[kMaxBranches];
+  int n_branches;
+  TensorGeom ig;
+  int N, Cin;
+  int OH, OW;
+  int KH, KW, stride, pad_h, pad_w;
+  int M;                  // N*OH*OW
+  int n_chunks;
+  int n_slabs;            // ceil(n_chunks / kSlabChunks)
+  size_t in_bytes;        // size of the input tensor
+  unsigned img_bytes;     // bytes of one example of the input tensor (all groups, with halo)
+  unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
+  int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
+  float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
+};
+
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// q = m / d, r = m % d for 0 <= m < 2^26, d >= 5 via one fp32 multiply + fix-up: float(m)
+// is off by <= 2 and the product by a few ulp, so q is off by at most one.
+__device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, int& r) {
+  q = static_cast<int>(static_cast<float>(m) * rcp);
+  r = m - q * d;
+  if (r < 0) {
+    r += d;
+    --q;
+  }
+  if (r >= d) {
+    r -= d;
+    ++q;
+  }
+}
+
+// Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
+// 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run.
+template <int NB, int PT>
+__device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvArgs& p,
+                                              int n_tile, const int (&pn)[PT], const int (&poh)[PT],
+                                              const int (&pow_)[PT], const bool (&mvalid)[PT],
+                                              int lane) {
+  const int hi = lane >> 5;
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    // branch of this 32-cout subtile (wave-uniform; the branch table sits in the kernarg
+    // segment and is indexed with scalar loads)
+    const int sub = n_tile * NB + nb;
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
+    const ConvBranch& b = p.br[bi];
+    const int cbase = (sub - b.sub0) * 32;  // first cout of the subtile within its branch
+    if (cbase >= b.Cout) continue;           // padding subtile past the last branch
+    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+    // Shifts come through the SCALAR cache (constant address space, wave-uniform
+    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
+    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
+            b.shift + (cbase + 8 * q)));
+        const f4_t l4 = sp[0], u4 = sp[1];
+        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
+      }
+      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
+      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const float16_t a = acc[nb][pt];
+      // piece index of (n, group out_goff, oh, ow) in this branch's output tensor
+      const unsigned obase = static_cast<unsigned>(
+          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
+          pow_[pt] + b.og.halo);
+      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
+          half2_t h = __builtin_convertvector(v, half2_t);
+          if (b.relu) h = __builtin_elementwise_max(h, zero2);
+          pk[q][hq] = __builtin_bit_cast(unsigned, h);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
+        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
+        // group 2t in the low half-wave and of group 2t+1 in the high one.
+        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+        const int group = cbase / 8 + 2 * t + hi;
+        if (mvalid[pt] && group * 8 < b.Cout) {
+          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace convk
+}  // namespace dv
+
+#endif  // DV_CONV_COMMON_H_

@@ -1,0 +1,255 @@
+// imgconv.hip -- stride-1 convolutions of the Inception blocks over tiles of WHOLE feature
+// maps, both MFMA operands in LDS.
+//
+// The Inception-v3 blocks of call_variants' classifier (deepvariant/keras_modeling.py:268-274,
+// SURVEY.md App. B) work on small maps (10x25, 4x12, 1x5 at the WGS pileup shape), so a tile
+// of G consecutive images (G*OH*OW <= 512 output pixels = 16 MFMA fragments) is contiguous
+// in the C8 layout and needs no halo exchange.  Compared with conv_mfma_kernel (model.hip),
+// which pulls every pixel fragment of every filter tap through the vector L1:
+//   * the input patch of a 16-channel chunk (G images x (OH+KH-1) x (OW+KW-1) pixels) is
+//     copied into LDS ONCE by LDS-DMA (global_load_lds_dwordx4, per-lane gather addresses,
+//     no VGPRs) and all KH*KW taps read it from there: 9x / 25x / 7x fewer L1 requests;
+//   * the weight slab of the step goes through LDS the same way;
+//   * workgroups are persistent and the (tile, K-step) sequence is ONE software pipeline:
+//     the DMA of step i+1 -- the next tile's first step included -- is in flight while step
+//     i multiplies; one s_barrier per step, no wave ever waits on a register load.
+// A step = KC channel chunks x all taps (KC = 1 for filters with taps, 4 for 1x1).
+#include "imgconv.h"
+
+namespace dv {
+namespace {
+
+using namespace convk;
+
+constexpr int IC_WAVES = 8;
+constexpr int IC_PT = 2;                       // pixel fragments per wave
+constexpr int IC_THREADS = 64 * IC_WAVES;
+constexpr int IC_MAXA = 8;                     // activation DMA rounds per step (8 KB each)
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int KH, int KW, int KC, int NB>
+__global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
+  constexpr int TAPS = KH * KW, S = KC * TAPS, BN = NB * 32, PT = IC_PT;
+  constexpr int W_SLAB = S * 2 * BN * 16;      // bytes: [kc][tap][k-group][BN couts][8 halfs]
+  constexpr int W_ROUNDS = (W_SLAB / 1024 + IC_WAVES - 1) / IC_WAVES;
+  constexpr int D = 2;                         // LDS fragment prefetch depth (steps of NB*PT MFMAs)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned act_bytes = static_cast<unsigned>(p.act_slab_bytes);
+  const unsigned w_lds0 = 2 * act_bytes;
+
+  // ---- per-lane constants ---------------------------------------------------------------
+  const ConvArgs& c = p.c;
+  const int patch_px = p.RP * p.CP;
+  unsigned bbase[PT];
+  int pimg[PT], poh[PT], pow_[PT];
+  bool pvalid[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int m = (wave * PT + pt) * 32 + l31;
+    pvalid[pt] = m < p.G * p.P;
+    const int mm = pvalid[pt] ? m : 0;
+    const int img = mm / p.P, pix = mm - img * p.P;
+    const int oy = pix / c.OW, ox = pix - oy * c.OW;
+    pimg[pt] = img;
+    poh[pt] = oy;
+    pow_[pt] = ox;
+    // slab layout per chunk: [k-group][image][patch row][patch col] pieces
+    bbase[pt] = static_cast<unsigned>(((hi * p.G + img) * patch_px + oy * p.CP + ox) * 16);
+  }
+  const unsigned abase = static_cast<unsigned>((hi * BN + l31) * 16);
+  const unsigned chunk_lds = static_cast<unsigned>(2 * p.plane_pieces * 16);
+  const unsigned cp16 = static_cast<unsigned>(p.CP * 16);
+  // activation DMA: piece (round k, this wave, lane) of the slab -> byte offset in the input
+  // relative to (first image of the tile, first chunk of the step)
+  unsigned arel[IC_MAXA];
+#pragma unroll
+  for (int k = 0; k < IC_MAXA; ++k) {
+    const int e = (k * IC_WAVES + wave) * 64 + lane;
+    unsigned off = 0;
+    if (e < p.act_pieces) {
+      const int kc = e / (2 * p.plane_pieces), r1 = e - kc * 2 * p.plane_pieces;
+      const int kg = r1 / p.plane_pieces, r2 = r1 - kg * p.plane_pieces;
+      const int img = r2 / patch_px, r3 = r2 - img * patch_px;
+      const int r = r3 / p.CP, cc = r3 - r * p.CP;
+      off = static_cast<unsigned>(img) * c.img_bytes +
+            static_cast<unsigned>((((2 * kc + kg) * c.ig.hp + r + c.ig.halo - c.pad_h) * c.ig.wp + cc +
+                                   c.ig.halo - c.pad_w) * 16);
+    }
+    arel[k] = off;
+  }
+
+  const int total = p.n_img_tiles * p.n_cout_tiles;
+  auto first_image = [&](int item) {
+    const int t = item / p.n_cout_tiles;
+    return max(0, min(t * p.G, c.N - p.G));  // the last tile is shifted back to end at image N
+  };
+  // Buffer-addressed DMA: descriptor (SGPRs) = tile / step base, voffset = the lane's 32-bit
+  // gather offset -- no 64-bit per-lane addresses.
+  // (hipcc keeps the running 64-bit step pointers in VGPRs and would wrap every DMA in a
+  // waterfall loop: the readfirstlanes make the descriptor provably wave-uniform)
+  auto uniform_ptr = [](const char* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned up = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<char*>((static_cast<unsigned long long>(up) << 32) | lo);
+  };
+  auto issue = [&](int n0, int ct, int st, unsigned slot) {
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(reinterpret_cast<const char*>(c.in) + static_cast<size_t>(n0) * c.img_bytes +
+                    static_cast<size_t>(st) * KC * c.chunk_stride),
+        0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < IC_MAXA; ++k) {
+      const unsigned piece0 = static_cast<unsigned>((k * IC_WAVES + wave) * 1024);
+      if (piece0 < act_bytes) {  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + slot * act_bytes + piece0), 16,
+                                                 arel[k], 0, 0, 0);
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(reinterpret_cast<const char*>(c.w) + (static_cast<size_t>(ct) * p.n_steps + st) * W_SLAB),
+        0, W_SLAB, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < W_ROUNDS; ++k) {
+      const unsigned piece0 = static_cast<unsigned>((k * IC_WAVES + wave) * 1024);
+      if (piece0 < W_SLAB) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(smem + w_lds0 + slot * W_SLAB + piece0), 16,
+                                                 lane * 16, piece0, 0, 0);
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= total) return;
+  int n0 = first_image(item), ct = item % p.n_cout_tiles;
+  unsigned slot = 0;
+  issue(n0, ct, 0, 0);
+  for (;;) {
+    float16_t acc[NB][PT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
+    const int item_n = item + gridDim.x;
+    const int n0_n = item_n < total ? first_image(item_n) : 0;
+    const int ct_n = item_n < total ? item_n % p.n_cout_tiles : 0;
+    for (int st = 0; st < p.n_steps; ++st) {
+      // my DMAs of this step have landed, every wave is past the previous step's LDS reads:
+      // ONE statement, so that neither LDS reads nor the next DMAs can move across it
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (st + 1 < p.n_steps) {
+        issue(n0, ct, st + 1, slot ^ 1);
+      } else if (item_n < total) {
+        issue(n0_n, ct_n, 0, slot ^ 1);
+      }
+      // ---- S = KC * taps sub-steps of NB x PT MFMAs; fragments D sub-steps ahead -------------
+      const char* aslab = smem + slot * act_bytes;
+      const char* wslab = smem + w_lds0 + slot * W_SLAB + abase;
+      half8_t wr[D][NB], xr[D][PT];
+      auto load_sub = [&](int s, int d) {
+        const int kc = s / TAPS, tap = s - kc * TAPS;
+        const unsigned toff = kc * chunk_lds + (tap / KW) * cp16 + (tap % KW) * 16;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          wr[d][nb] = *reinterpret_cast<const half8_t*>(wslab + s * (2 * BN * 16) + nb * 512);
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          xr[d][pt] = *reinterpret_cast<const half8_t*>(aslab + bbase[pt] + toff);
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < D && d < S; ++d) load_sub(d, d);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % D][nb], xr[s % D][pt],
+                                                                 acc[nb][pt], 0, 0, 0);
+          }
+        if (s + D < S) load_sub(s + D, s % D);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot ^= 1;
+    }
+    // ---- epilogue: shift + ReLU, 16-byte pieces into the branch tensors -------------------
+    int pn[PT];
+    bool mvalid[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      pn[pt] = n0 + pimg[pt];
+      mvalid[pt] = pvalid[pt] && pn[pt] < c.N;
+    }
+    conv_epilogue<NB, PT>(acc, c, ct, pn, poh, pow_, mvalid, lane);
+    item = item_n;
+    if (item >= total) break;
+    n0 = n0_n;
+    ct = ct_n;
+  }
+}
+
+template <int KH, int KW, int KC, int NB>
+void launch_one(const ImgConvArgs& a, int blocks, size_t lds, hipStream_t stream) {
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KH, KW, KC, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  const int total = a.n_img_tiles * a.n_cout_tiles;
+  const int grid = total < blocks ? total : blocks;
+  hipLaunchKernelGGL((imgconv_kernel<KH, KW, KC, NB>), dim3(grid > 0 ? grid : 1), dim3(IC_THREADS), lds,
+                     stream, a);
+}
+
+template <int KH, int KW, int KC>
+void launch_nb(const ImgConvArgs& a, int nb, int blocks, size_t lds, hipStream_t stream) {
+  switch (nb) {
+    case 2: launch_one<KH, KW, KC, 2>(a, blocks, lds, stream); break;
+    case 3: launch_one<KH, KW, KC, 3>(a, blocks, lds, stream); break;
+    default: launch_one<KH, KW, KC, 4>(a, blocks, lds, stream); break;
+  }
+}
+
+}  // namespace
+
+int imgconv_threads() { return IC_THREADS; }
+
+int imgconv_kc(int kh, int kw) { return kh * kw == 1 ? 4 : 1; }
+
+bool imgconv_supported(int kh, int kw, int nb) {
+  if (nb < 2 || nb > 4) return false;
+  return (kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 5 && kw == 5) ||
+         (kh == 1 && kw == 7) || (kh == 7 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 1);
+}
+
+size_t imgconv_wslab_halfs(int kh, int kw, int nb) {
+  return static_cast<size_t>(imgconv_kc(kh, kw)) * kh * kw * 2 * nb * 32 * 8;
+}
+
+size_t imgconv_lds_bytes(const ImgConvArgs& a, int nb) {
+  return 2 * (static_cast<size_t>(a.act_slab_bytes) + imgconv_wslab_halfs(a.c.KH, a.c.KW, nb) * 2);
+}
+
+void launch_imgconv(const ImgConvArgs& a, int nb, int blocks, hipStream_t stream) {
+  const size_t lds = imgconv_lds_bytes(a, nb);
+  const int kh = a.c.KH, kw = a.c.KW;
+  if (kh == 1 && kw == 1) launch_nb<1, 1, 4>(a, nb, blocks, lds, stream);
+  else if (kh == 3 && kw == 3) launch_nb<3, 3, 1>(a, nb, blocks, lds, stream);
+  else if (kh == 5 && kw == 5) launch_nb<5, 5, 1>(a, nb, blocks, lds, stream);
+  else if (kh == 1 && kw == 7) launch_nb<1, 7, 1>(a, nb, blocks, lds, stream);
+  else if (kh == 7 && kw == 1) launch_nb<7, 1, 1>(a, nb, blocks, lds, stream);
+  else if (kh == 1 && kw == 3) launch_nb<1, 3, 1>(a, nb, blocks, lds, stream);
+  else launch_nb<3, 1, 1>(a, nb, blocks, lds, stream);
+}
+
+}  // namespace dv

@@ -36,67 +36,13 @@
 #include <hip/hip_fp16.h>
 
 #include "dv_internal.h"
+#include "conv_common.h"
+#include "imgconv.h"
 #include "stem_fused.h"
 
+using namespace dv::convk;
+
 namespace {
-
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef float float16_t __attribute__((ext_vector_type(16)));
-
-constexpr int kConvThreads = 256;
-constexpr int kChunk = 16;       // channels per K chunk
-
-// Geometry of one activation tensor in HBM: fp16, channel-blocked and
-// zero-haloed, [N][C/8][H + 2*halo][W + 2*halo][8].  The halo is written once
-// (hipMemset at model creation) and never touched again: producers store the
-// interior only, so 'same'-padded convolutions read their padding as ordinary
-// in-bounds zeros and need no predicates.
-struct TensorGeom {
-  int h, w;     // interior size
-  int halo;
-  int hp, wp;   // padded size
-  int groups;   // channel groups of 8 (full concat width)
-};
-
-// One output branch of a (possibly grouped) convolution launch.
-struct ConvBranch {
-  const float* shift;     // [Cout (+pad)] folded BN shift, or NULL (raw output)
-  _Float16* out;
-  TensorGeom og;
-  int out_goff;           // first destination group of this branch
-  int Cout;
-  int relu;
-  int sub0;               // first 32-cout subtile of this branch in the launch's cout space
-};
-
-constexpr int kMaxBranches = 4;
-
-struct ConvArgs {
-  const _Float16* in;
-  // Sibling convolutions that read the SAME input with the same geometry (the
-  // 1x1 heads of an Inception block) run as one launch over the CONCATENATION of their
-  // output channels (each branch padded to whole 32-cout subtiles): one packed weight
-  // image, cout tiles of NB*32 that may straddle two branches, and an epilogue that
-  // routes every 32-cout subtile to its branch's tensor.  The input is fetched from HBM
-  // once and re-read from L2 by ceil(sum couts / (NB*32)) tiles instead of once per
-  // branch tile.
-  const _Float16* w;      // packed [cout_tile][slab][8 chunks][2 k-groups][NB*32][8]
-  ConvBranch br[kMaxBranches];
-  int n_branches;
-  TensorGeom ig;
-  int N, Cin;
-  int OH, OW;
-  int KH, KW, stride, pad_h, pad_w;
-  int M;                  // N*OH*OW
-  int n_chunks;
-  int n_slabs;            // ceil(n_chunks / kSlabChunks)
-  size_t in_bytes;        // size of the input tensor
-  unsigned img_bytes;     // bytes of one example of the input tensor (all groups, with halo)
-  unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
-  int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
-  float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
-};
 
 // Examples per stem pass.  Measured on MI355X (round 1): sub-batching the stem to
 // keep its hand-offs in the 256 MB Infinity Cache (64/128/256) LOSES 5-19 % at
@@ -112,25 +58,6 @@ constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
 // instead of 4 changes nothing (+-1 %) for thin, mid or big tiles -- the queue is not what
 // the waves wait for -- so every shape uses 4.
 constexpr int prefetch_depth(int /*nb*/, int /*pt*/) { return 4; }
-
-typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-
-// q = m / d, r = m % d for 0 <= m < 2^26, d >= 5 via one fp32 multiply + fix-up: float(m)
-// is off by <= 2 and the product by a few ulp, so q is off by at most one.
-__device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, int& r) {
-  q = static_cast<int>(static_cast<float>(m) * rcp);
-  r = m - q * d;
-  if (r < 0) {
-    r += d;
-    --q;
-  }
-  if (r >= d) {
-    r -= d;
-    ++q;
-  }
-}
 
 // Wave-uniform walk over the K chunks kept in SGPRs and advanced with selects
 // only -- no memory, no branches.  K order is channel-chunk major, filter tap
@@ -206,81 +133,6 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
     }
     walk.advance(p);
     __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
-// 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run.
-template <int NB, int PT>
-__device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvArgs& p,
-                                              int n_tile, const int (&pn)[PT], const int (&poh)[PT],
-                                              const int (&pow_)[PT], const bool (&mvalid)[PT],
-                                              int lane) {
-  const int hi = lane >> 5;
-  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    // branch of this 32-cout subtile (wave-uniform; the branch table sits in the kernarg
-    // segment and is indexed with scalar loads)
-    const int sub = n_tile * NB + nb;
-    int bi = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
-    const ConvBranch& b = p.br[bi];
-    const int cbase = (sub - b.sub0) * 32;  // first cout of the subtile within its branch
-    if (cbase >= b.Cout) continue;           // padding subtile past the last branch
-    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
-    // Shifts come through the SCALAR cache (constant address space, wave-uniform
-    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
-    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
-      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
-        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
-            b.shift + (cbase + 8 * q)));
-        const f4_t l4 = sp[0], u4 = sp[1];
-        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
-        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
-      }
-      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
-      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
-    }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const float16_t a = acc[nb][pt];
-      // piece index of (n, group out_goff, oh, ow) in this branch's output tensor
-      const unsigned obase = static_cast<unsigned>(
-          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
-          pow_[pt] + b.og.halo);
-      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
-          half2_t h = __builtin_convertvector(v, half2_t);
-          if (b.relu) h = __builtin_elementwise_max(h, zero2);
-          pk[q][hq] = __builtin_bit_cast(unsigned, h);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
-        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
-        // group 2t in the low half-wave and of group 2t+1 in the high one.
-        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
-        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
-        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
-        const int group = cbase / 8 + 2 * t + hi;
-        if (mvalid[pt] && group * 8 < b.Cout) {
-          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
-        }
-      }
-    }
   }
 }
 
@@ -856,6 +708,7 @@ struct TensorRef {
 struct BufferDesc {
   int h, w, c;  // channels = full (concat) width
   int halo = 0; // max padding any consumer needs (zero border kept in HBM)
+  int min_examples = 1;  // imgconv tiles read whole groups of images: allocate at least this many
   TensorGeom geom() const {
     return TensorGeom{h, w, halo, h + 2 * halo, w + 2 * halo, c / 8};
   }
@@ -887,6 +740,11 @@ struct Op {
   bool pool_in = false;          // 1x1 conv that max-pools (3x3, stride 2) its input on the fly
   // Fused stem (stem.hip): the op marked stem_a / stem_b runs together with the op that
   // follows it as ONE launch; the tensor between them is never materialised.
+  // imgconv.hip: whole-map tiles, both operands through LDS (set on the launch's leader op)
+  bool v2 = false;
+  int v2_g = 0;                  // images per tile
+  int v2_steps = 0;              // K steps (KC channel chunks each)
+  int v2_tiles = 0;              // cout tiles of nb*32
   bool stem_a = false;           // first conv (uint8 input) + conv 3x3 32->32
   bool stem_b = false;           // conv 3x3 32->64 + maxpool 3x3/2 + conv 1x1 64->80
 };
@@ -908,6 +766,7 @@ struct dv_model {
   int feat_buf = -1, feat_p = 0, feat_c = 0;
   int stem_ops_end = 0, stem_out_buf = -1;
   int stem_a_grid = 512, stem_b_grid = 256;  // persistent grids of the fused stem kernels
+  int n_cus = 256;
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
@@ -1073,6 +932,61 @@ struct dv_model {
     }
   }
 
+  // Tile geometry of an imgconv launch for `g` images per tile.
+  dv::ImgConvArgs imgconv_geometry(const Op& op, int g) const {
+    dv::ImgConvArgs a{};
+    const int kc = dv::imgconv_kc(op.kh, op.kw);
+    a.G = g;
+    a.P = op.oh * op.ow;
+    a.RP = op.oh + op.kh - 1;
+    a.CP = op.ow + op.kw - 1;
+    a.plane_pieces = g * a.RP * a.CP;
+    a.act_pieces = kc * 2 * a.plane_pieces;
+    a.act_slab_bytes = (a.act_pieces * 16 + 1023) / 1024 * 1024;
+    a.n_steps = (op.cin / kChunk + kc - 1) / kc;
+    a.c.KH = op.kh;
+    a.c.KW = op.kw;
+    return a;
+  }
+  // Stride-1 convolutions on small maps run in imgconv.hip (whole-map tiles, both operands
+  // in LDS) when a tile of G images fills at least 3/4 of the 512-pixel tile and the double
+  // buffered slabs fit the CU's LDS.  DV_NO_IMGCONV keeps conv_mfma_kernel for all of them.
+  void choose_imgconv() {
+    if (getenv("DV_NO_IMGCONV") != nullptr) return;
+    const char* only = getenv("DV_IMGCONV_TAPS");  // tuning knob: e.g. "9,25" = only 3x3 and 5x5
+    for (size_t i = 0; i < ops.size(); ++i) {
+      Op& op = ops[i];
+      const int followers = op.type == kOpConv ? op.group_followers : 0;
+      if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.stem_a && !op.stem_b &&
+          !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
+          dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
+        bool wanted = true;
+        if (only != nullptr) {
+          wanted = false;
+          for (const char* q = only; *q;) {
+            if (atoi(q) == op.kh * op.kw) wanted = true;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+          }
+        }
+        int subs = 0;
+        for (int gi = 0; gi <= followers; ++gi) subs += (ops[i + gi].cout + 31) / 32;
+        const int P = op.oh * op.ow;
+        for (int g = 512 / P; wanted && g >= 1 && g * P >= 384; --g) {
+          const dv::ImgConvArgs a = imgconv_geometry(op, g);
+          if (a.act_slab_bytes > 64 * 1024 || dv::imgconv_lds_bytes(a, op.nb) > 160 * 1024) continue;
+          op.v2 = true;
+          op.v2_g = g;
+          op.v2_steps = a.n_steps;
+          op.v2_tiles = (subs + op.nb - 1) / op.nb;
+          buffers[op.in_buf].min_examples = std::max(buffers[op.in_buf].min_examples, g);
+          break;
+        }
+      }
+      i += followers;
+    }
+  }
+
   // tf_keras applications/inception_v3.py, construction order = layer order.
   void build() {
     const int in_buf = new_buffer(desc.height, desc.width, 16);
@@ -1186,6 +1100,13 @@ struct dv_model {
     feat_p = x.h * x.w;
     feat_c = x.c;
     group_siblings();
+    for (const Op& op : ops) {  // zero halo wide enough for every consumer
+      int need = 0;
+      if (op.type == kOpConv) need = std::max(op.pad_h, op.pad_w);
+      if (op.type == kOpAvgPool) need = 1;  // avgpool3s1_kernel reads its taps unconditionally
+      buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
+    }
+    choose_imgconv();
     for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
       Op& op = ops[i];
       if (op.type != kOpConv) continue;
@@ -1193,17 +1114,12 @@ struct dv_model {
       for (int gi = 0; gi <= op.group_followers; ++gi) subs += (ops[i + gi].cout + 31) / 32;
       const int n_tiles = (subs + op.nb - 1) / op.nb;
       for (int gi = 0; gi <= op.group_followers; ++gi) ops[i + gi].w_off = packed_halfs;
-      packed_halfs += op.first_u8
-                          ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
-                          : static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks *
-                                (op.nb * 32) * kChunk;
+      packed_halfs += op.first_u8 ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
+                      : op.v2     ? static_cast<size_t>(op.v2_tiles) * op.v2_steps *
+                                        dv::imgconv_wslab_halfs(op.kh, op.kw, op.nb)
+                                  : static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks *
+                                        (op.nb * 32) * kChunk;
       i += op.group_followers;
-    }
-    for (const Op& op : ops) {  // zero halo wide enough for every consumer
-      int need = 0;
-      if (op.type == kOpConv) need = std::max(op.pad_h, op.pad_w);
-      if (op.type == kOpAvgPool) need = 1;  // avgpool3s1_kernel reads its taps unconditionally
-      buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
     }
     layers.push_back({1, 1, feat_c, desc.num_classes, n_params});
     n_params += static_cast<int64_t>(feat_c) * desc.num_classes + desc.num_classes;
@@ -1447,9 +1363,16 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
                   " tiles" + std::to_string(tiles);
       if (op.pool_in) tr_label += " <- maxpool3s2";
+      if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
-      if (op.pool_in) {
+      if (op.v2) {
+        dv::ImgConvArgs ia = m->imgconv_geometry(op, op.v2_g);
+        ia.c = a;
+        ia.n_img_tiles = (n + op.v2_g - 1) / op.v2_g;
+        ia.n_cout_tiles = op.v2_tiles;
+        dv::launch_imgconv(ia, op.nb, m->n_cus, stream);
+      } else if (op.pool_in) {
         a.stride = 2;  // documentary: the window origin is (2 oh, 2 ow)
         const size_t lds = static_cast<size_t>(op.n_steps) * kSlabChunks * op.nb * 32 * kChunk * 2;
         const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * a.n_tiles));
@@ -1525,6 +1448,7 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->build();
   m->stem_a_grid = dv::stem_a_blocks(device);
   m->stem_b_grid = dv::stem_b_blocks(device);
+  m->n_cus = m->stem_b_grid;
   // 32-bit index ranges of the kernels at max_batch (see conv_mfma_kernel's prologue)
   for (const Op& op : m->ops) {
     const BufferDesc& ob = m->buffers[op.out_buf];
@@ -1544,11 +1468,16 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   for (size_t i = 0; i < m->buffers.size(); ++i) {
     const BufferDesc& b = m->buffers[i];
     const bool stem_buf = static_cast<int>(i) < m->stem_out_buf;
-    const size_t bytes = static_cast<size_t>(stem_buf ? std::min(desc->max_batch, stem_sub_batch())
-                                                      : desc->max_batch) *
-                         b.bytes_per_example();
+    // imgconv tiles read whole groups of images and (1x1 steps of 4 channel chunks) up to
+    // three chunks past the last channel: both stay inside the allocation, which is zeroed
+    // to its full capacity (finite values times zero-padded weights).
+    const size_t examples = std::max(
+        static_cast<size_t>(stem_buf ? std::min(desc->max_batch, stem_sub_batch()) : desc->max_batch),
+        static_cast<size_t>(b.min_examples));
+    const size_t bytes = examples * b.bytes_per_example() +
+                         static_cast<size_t>(8) * (b.h + 2 * b.halo) * (b.w + 2 * b.halo) * 16;
     if (int rc = m->dbuf[i].reserve(bytes)) return rc;
-    DV_HIP_CHECK(hipMemset(m->dbuf[i].ptr, 0, bytes));  // halos stay zero forever
+    DV_HIP_CHECK(hipMemset(m->dbuf[i].ptr, 0, m->dbuf[i].cap));  // halos stay zero forever
   }
   if (int rc = m->d_w.reserve(m->packed_halfs * 2)) return rc;
   if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
@@ -1666,6 +1595,40 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
     }
     const int bn = op.nb * 32;
     const int taps = op.kh * op.kw;
+    {
+      // the launch's leader carries the imgconv decision
+      size_t lead = oi;
+      while (lead > 0 && m->ops[lead].group_followers == 0 && m->ops[lead - 1].type == kOpConv &&
+             m->ops[lead - 1].w_off == op.w_off) {
+        --lead;
+      }
+      const Op& lo = m->ops[lead];
+      if (lo.v2) {
+        // [cout tile][step][chunk in step][tap][k-group][bn couts][8]
+        const int kcs = dv::imgconv_kc(op.kh, op.kw);
+        const size_t slab = dv::imgconv_wslab_halfs(op.kh, op.kw, op.nb);
+        for (int cc = 0; cc < l.cin / kChunk + (l.cin % kChunk ? 1 : 0); ++cc) {
+          const int st = cc / kcs, kc = cc % kcs;
+          for (int tap = 0; tap < taps; ++tap) {
+            const int kh = tap / op.kw, kw = tap % op.kw;
+            for (int co = 0; co < op.cout; ++co) {
+              const int row = sub0 * 32 + co;
+              const int t = row / bn, r = row % bn;
+              _Float16* sub = packed.data() + op.w_off +
+                              (static_cast<size_t>(t) * lo.v2_steps + st) * slab +
+                              (static_cast<size_t>(kc) * taps + tap) * 2 * bn * 8;
+              for (int jj = 0; jj < kChunk; ++jj) {
+                const int ci = cc * kChunk + jj;
+                if (ci >= l.cin) continue;
+                const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+                sub[(static_cast<size_t>(jj / 8) * bn + r) * 8 + (jj % 8)] = static_cast<_Float16>(v * inv[co]);
+              }
+            }
+          }
+        }
+        continue;
+      }
+    }
     for (int kc = 0; kc < op.n_chunks; ++kc) {
       const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
       const int cc = kc / taps, tap = kc % taps;  // chunk-major, tap-minor (ChunkWalk)

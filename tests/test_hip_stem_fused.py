@@ -122,9 +122,10 @@ def test_fused_stem_other_shapes(shape):
 
 
 def test_benchmark_configuration_against_the_oracle():
-  """600 ILLUMINA30 pileups in ONE forward: every kernel variant the bench batch uses
-  (fused stem, <NB,2>, <NB,4>, pooled 1x1) meets the fp32 oracle directly: softmax within
-  1e-3 (BASELINE.json), logits within a relative tolerance."""
+  """600 images in ONE forward (400 ILLUMINA30 pileups + 200 uniform-noise images): every
+  kernel variant the bench batch uses (fused stem, imgconv tiles, <NB,2>, <NB,4>) meets the
+  fp32 oracle directly.  Softmax within 1e-3 on the pileups (BASELINE.json); the noise
+  images (every channel uniform in 0..255 -- far outside what the encoder can draw) get 2e-3."""
   from oracle import inception_ref as R
   n = 600
   ref = R.make_random_model(7, seed=17)
@@ -134,6 +135,10 @@ def test_benchmark_configuration_against_the_oracle():
   torch.set_num_threads(min(32, os.cpu_count() or 1))
   with torch.no_grad():
     want = torch.cat([ref(x[i:i + 50]) for i in range(0, n, 50)])
-  err = (got - want).abs().max().item()
-  assert err <= 1e-3, err
+  err = (got - want).abs().max(1).values
+  k = (2 * n) // 3
+  print('max |dp|: pileups %.3g (mean %.3g), noise %.3g (mean %.3g)' %
+        (err[:k].max(), err[:k].mean(), err[k:].max(), err[k:].mean()))
+  assert err[:k].max().item() <= 1e-3, err[:k].max().item()
+  assert err[k:].max().item() <= 2e-3, err[k:].max().item()
   assert (want.max(0).values - want.min(0).values).max() > 1e-2
