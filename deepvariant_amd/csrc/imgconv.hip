@@ -97,25 +97,32 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
     const unsigned up = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
     return reinterpret_cast<char*>((static_cast<unsigned long long>(up) << 32) | lo);
   };
-  auto issue = [&](int n0, int ct, int st, unsigned slot) {
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+  // The DMAs of one step, as a list of J = IC_MAXA + W_ROUNDS wave-instructions: issued one
+  // or two at a time BETWEEN the sub-steps of the running step, so that a wave's DMA issue
+  // slots (tens of cycles each) fall under its SIMD partner's MFMAs instead of after a barrier
+  // where every wave of the CU would issue them at once.
+  constexpr int J = IC_MAXA + W_ROUNDS;
+  auto act_desc = [&](int n0, int st) {
+    return __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(reinterpret_cast<const char*>(c.in) + static_cast<size_t>(n0) * c.img_bytes +
                     static_cast<size_t>(st) * KC * c.chunk_stride),
         0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < IC_MAXA; ++k) {
-      const unsigned piece0 = static_cast<unsigned>((k * IC_WAVES + wave) * 1024);
-      if (piece0 < act_bytes) {  // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + slot * act_bytes + piece0), 16,
-                                                 arel[k], 0, 0, 0);
-      }
-    }
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+  };
+  auto w_desc = [&](int ct, int st) {
+    return __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(reinterpret_cast<const char*>(c.w) + (static_cast<size_t>(ct) * p.n_steps + st) * W_SLAB),
         0, W_SLAB, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < W_ROUNDS; ++k) {
-      const unsigned piece0 = static_cast<unsigned>((k * IC_WAVES + wave) * 1024);
+  };
+  auto issue_one = [&](int j, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rw,
+                       unsigned slot) {
+    if (j < IC_MAXA) {
+      const unsigned piece0 = static_cast<unsigned>((j * IC_WAVES + wave) * 1024);
+      if (piece0 < act_bytes) {  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + slot * act_bytes + piece0), 16,
+                                                 arel[j < IC_MAXA ? j : 0], 0, 0, 0);
+      }
+    } else {
+      const unsigned piece0 = static_cast<unsigned>(((j - IC_MAXA) * IC_WAVES + wave) * 1024);
       if (piece0 < W_SLAB) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(smem + w_lds0 + slot * W_SLAB + piece0), 16,
                                                  lane * 16, piece0, 0, 0);
@@ -127,7 +134,11 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
   if (item >= total) return;
   int n0 = first_image(item), ct = item % p.n_cout_tiles;
   unsigned slot = 0;
-  issue(n0, ct, 0, 0);
+  {
+    const __amdgpu_buffer_rsrc_t ra = act_desc(n0, 0), rw = w_desc(ct, 0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) issue_one(j, ra, rw, 0);
+  }
   for (;;) {
     float16_t acc[NB][PT];
 #pragma unroll
@@ -143,11 +154,10 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
       // my DMAs of this step have landed, every wave is past the previous step's LDS reads:
       // ONE statement, so that neither LDS reads nor the next DMAs can move across it
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (st + 1 < p.n_steps) {
-        issue(n0, ct, st + 1, slot ^ 1);
-      } else if (item_n < total) {
-        issue(n0_n, ct_n, 0, slot ^ 1);
-      }
+      const bool same = st + 1 < p.n_steps;
+      const bool more = same || item_n < total;
+      const __amdgpu_buffer_rsrc_t ra = act_desc(same ? n0 : n0_n, same ? st + 1 : 0);
+      const __amdgpu_buffer_rsrc_t rw = w_desc(same ? ct : ct_n, same ? st + 1 : 0);
       // ---- S = KC * taps sub-steps of NB x PT MFMAs; fragments D sub-steps ahead -------------
       const char* aslab = smem + slot * act_bytes;
       const char* wslab = smem + w_lds0 + slot * W_SLAB + abase;
@@ -177,6 +187,11 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
                                                                  acc[nb][pt], 0, 0, 0);
           }
         if (s + D < S) load_sub(s + D, s % D);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {  // this sub-step's share of the next step's DMAs
+#pragma unroll
+          for (int j = s * J / S; j < (s + 1) * J / S; ++j) issue_one(j, ra, rw, slot ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       slot ^= 1;

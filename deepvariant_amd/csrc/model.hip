@@ -960,7 +960,15 @@ struct dv_model {
       if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.stem_a && !op.stem_b &&
           !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
           dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
-        bool wanted = true;
+        // 1x1 layers have no taps to share a patch between: the DMA count equals
+        // conv_mfma_kernel's fragment loads and the LDS round trip only costs (measured
+        // 0.75x); they stay on conv_mfma_kernel unless DV_IMGCONV_1X1 is set.
+        bool wanted = op.kh * op.kw > 1 || getenv("DV_IMGCONV_1X1") != nullptr;
+        // Measured at 8 K examples: +10..30 % on the 10x25 maps (3x3, 5x5), no gain on the
+        // 4x12 maps (7-tap filters) and a loss on 1x5 (the patch is mostly halo): only maps
+        // of at least DV_IMGCONV_MINP pixels (default 100) take this path.
+        static const int min_p = getenv("DV_IMGCONV_MINP") ? atoi(getenv("DV_IMGCONV_MINP")) : 100;
+        if (op.oh * op.ow < min_p) wanted = false;
         if (only != nullptr) {
           wanted = false;
           for (const char* q = only; *q;) {
@@ -1270,7 +1278,31 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                                static_cast<double>(c4.oh) * c4.ow * 64 * c4.cout),
                     2.0 * n * (static_cast<double>(op.ih) * op.iw * 32 + static_cast<double>(c4.oh) * c4.ow * c4.cout));
       dv::ProfileScope prof(dv::kProfConv, stream);
-      dv::launch_stem_b(a, m->stem_b_grid, stream);
+      static const bool stem_prof = getenv("DV_STEM_PROF") != nullptr;  // tuning aid, eager only
+      if (stem_prof && g_trace != nullptr) {
+        const size_t words = static_cast<size_t>(m->stem_b_grid) * 16;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, words * 8) == hipSuccess) {
+          (void)hipMemsetAsync(d, 0, words * 8, stream);
+          a.prof = d;
+          dv::launch_stem_b(a, m->stem_b_grid, stream);
+          std::vector<unsigned long long> h(words);
+          (void)hipStreamSynchronize(stream);
+          (void)hipMemcpy(h.data(), d, words * 8, hipMemcpyDeviceToHost);
+          (void)hipFree(d);
+          for (int w = 0; w < 2; ++w) {
+            double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < m->stem_b_grid; ++b)
+              for (int i = 0; i < 7; ++i) sum[i] += static_cast<double>(h[(b * 2 + w) * 8 + i]);
+            const double tiles = static_cast<double>(a.total_tiles);
+            fprintf(stderr, "[dv-stem-b wave %d] cycles/tile: issue %.0f conv3 %.0f dma-wait %.0f barrierA %.0f pool %.0f "
+                            "barrierB %.0f conv1x1+store %.0f\n", w ? 7 : 0, sum[0] / tiles, sum[1] / tiles,
+                    sum[6] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles);
+          }
+        }
+      } else {
+        dv::launch_stem_b(a, m->stem_b_grid, stream);
+      }
       oi += 1;
     } else if (op.type == kOpConv && op.first_u8) {
       FirstConvArgs f{};

@@ -113,6 +113,26 @@ __device__ __forceinline__ void mfma_sweep(const half8_t (&a)[S], const char* sm
   }
 }
 
+// The same sweep for TWO output-channel subtiles that share every pixel piece (one LDS read
+// per two MFMAs).
+template <int S, int D, class Addr, class Filler>
+__device__ __forceinline__ void mfma_sweep_pair(const half8_t (&a0)[S], const half8_t (&a1)[S],
+                                                const char* smem, Addr addr, float16_t& acc0,
+                                                float16_t& acc1, Filler filler) {
+  half8_t ring[D];
+#pragma unroll
+  for (int d = 0; d < D && d < S; ++d) ring[d] = lds_piece(smem, addr(d));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], ring[s % D], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], ring[s % D], acc1, 0, 0, 0);
+    if (s + D < S) ring[s % D] = lds_piece(smem, addr(s + D));
+    filler(s);  // a slice of unrelated work (DMA issue) that rides under the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // =========================================================================== stem A
 constexpr int A_TH = kStemA_TH, A_TW = kStemA_TW;
 constexpr int A_C1H = A_TH + 2, A_C1W = A_TW + 2;             // conv1 tile 9 x 56
@@ -337,11 +357,13 @@ constexpr int B_PH = kStemB_PH, B_PW = kStemB_PW;             // pooled tile 12 
 constexpr int B_C3H = 2 * B_PH + 1, B_C3W = 2 * B_PW + 1;     // conv3 tile 25 x 19
 constexpr int B_C3PX = B_C3H * B_C3W;                         // 475
 constexpr int B_C3FR = (B_C3PX + 31) / 32;                    // 15 fragments
-constexpr int B_C3PLANE = B_C3FR * 32 * 16;                   // 7680
+// conv3 tile in LDS: 8 planes of 8 channels; the plane stride is an ODD number of pieces so
+// that the max-pool's stride-2 reads of two adjacent planes interleave on the LDS banks
+constexpr int B_C3PLANE = (B_C3FR * 32 + 1) * 16;             // 7696
 constexpr int B_PTH = B_C3H + 2, B_PTW = B_C3W + 2;           // input patch 27 x 21
 constexpr int B_PTPX = B_PTH * B_PTW;                         // 567
 constexpr int B_PTPLANE = B_PTPX * 16;                        // 9072
-constexpr int B_PT_BYTES = 4 * B_PTPLANE;                     // 36288 (32 channels)
+constexpr int B_PT_BYTES = (4 * B_PTPLANE + 1023) / 1024 * 1024;  // 32 channels, padded to the 1 KB DMA granule
 constexpr int B_PT_PIECES = 4 * B_PTPX;                       // 2268
 constexpr int B_PPX = B_PH * B_PW;                            // 108 pooled pixels
 constexpr int B_PFR = (B_PPX + 31) / 32;                      // 4 fragments
@@ -360,30 +382,25 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int ch = wave >> 2;  // conv3: which 32 of the 64 output channels this wave computes
-  const int wg = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-  // ---- weights -> registers --------------------------------------------------------------
-  half8_t a3[18], a4[8];
+  // ---- conv3 weights -> registers: BOTH 32-channel halves (144 VGPRs), so that a pixel
+  // piece read from LDS feeds two MFMAs ---------------------------------------------------
+  half8_t a3lo[18], a3up[18];
 #pragma unroll
   for (int kc = 0; kc < 18; ++kc) {
-    a3[kc] = *reinterpret_cast<const half8_t*>(p.w3 + (((ch * 18 + kc) * 2 + hi) * 32 + l31) * 8);
+    a3lo[kc] = *reinterpret_cast<const half8_t*>(p.w3 + (((0 * 18 + kc) * 2 + hi) * 32 + l31) * 8);
+    a3up[kc] = *reinterpret_cast<const half8_t*>(p.w3 + (((1 * 18 + kc) * 2 + hi) * 32 + l31) * 8);
   }
-  // 1x1: waves 0-3 own output subtiles 0 and 1 of pooled fragment `wave`, waves 4-7 subtile 2
+  // 1x1: waves 0-3 own output subtiles 0 and 1 of pooled fragment `wave`, waves 4-7 subtile 2;
+  // its weights (12 fragments, L2 resident) are fetched per tile, not held
   const int s0 = wave < 4 ? 0 : 2;
   const int nsub = wave < 4 ? 2 : 1;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int sub = min(s0 + s, 2);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a4[s * 4 + c] = *reinterpret_cast<const half8_t*>(p.w4 + (((sub * 4 + c) * 2 + hi) * 32 + l31) * 8);
-    }
+  for (int kc = 0; kc < 18; ++kc) {  // loads retire here (see stem A)
+    asm volatile("" : "+v"(a3lo[kc]));
+    asm volatile("" : "+v"(a3up[kc]));
   }
-#pragma unroll
-  for (int kc = 0; kc < 18; ++kc) asm volatile("" : "+v"(a3[kc]));  // loads retire here (see stem A)
-#pragma unroll
-  for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(a4[k]));
   float* lsh = reinterpret_cast<float*>(smem + B_OFF_SH);
   if (tid < 160) {  // [0,64): conv3 [cout half][hi][r]; [64,160): 1x1 [subtile][hi][r]
     const int r = tid & 15, h = (tid >> 4) & 1;
@@ -407,16 +424,16 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
                    ? static_cast<unsigned>(((g * p.ig.hp + row) * p.ig.wp + col) * 16)
                    : 0x80000000u;
   }
-  // conv3: fragments wg, wg+4, wg+8, wg+12 of the 25 x 19 tile
-  unsigned b3[4], c3dst[4];
+  // conv3: fragments wave and wave + 8 of the 25 x 19 tile
+  unsigned b3[2], c3dst[2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int i = (wg + 4 * m) * 32 + l31;
+  for (int m = 0; m < 2; ++m) {
+    const int i = (wave + 8 * m) * 32 + l31;
     const int ii = min(i, B_C3PX - 1);
     const int cy = ii / B_C3W, cx = ii - cy * B_C3W;
     b3[m] = static_cast<unsigned>(hi * B_PTPLANE + (cy * B_PTW + cx) * 16);
-    // conv3 output channel 32ch + 16rh + {0-3, 8-11} + 4hi  ->  plane (2ch + rh)*2 + hi
-    c3dst[m] = static_cast<unsigned>(B_OFF_C3 + ((2 * ch) * 2 + hi) * B_C3PLANE + i * 16);
+    // conv3 output channel 32h + 16rh + {0-3, 8-11} + 4hi  ->  plane (2h + rh)*2 + hi
+    c3dst[m] = static_cast<unsigned>(B_OFF_C3 + hi * B_C3PLANE + i * 16);
   }
   // 1x1: pooled fragment wave & 3
   const int pp = (wave & 3) * 32 + l31;
@@ -427,7 +444,6 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   const int tiles_img = p.tiles_y * p.tiles_x;
   const unsigned ogstride = static_cast<unsigned>(p.og.hp * p.og.wp);
 
-  uint4_t pre[B_PASSES];
   auto tile_coords = [&](int t, int& n, int& py0, int& px0) {
     n = t / tiles_img;
     const int r = t - n * tiles_img;
@@ -435,25 +451,28 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     py0 = ty * B_PH;
     px0 = (r - ty * p.tiles_x) * B_PW;
   };
-  auto issue_loads = [&](int n, int py0, int px0) {
+  // The patch goes HBM -> LDS by LDS-DMA (no VGPRs: the 144 weight registers leave none to
+  // spare): wave w moves the 1 KB granules w, w+8, ...; lane = piece within the granule.
+  auto patch_desc = [&](int n) {
     const size_t off = static_cast<size_t>(n) * p.in_img_bytes;
     const size_t left = p.in_bytes - off;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.in) + off), 0,
+    const unsigned long long base = reinterpret_cast<unsigned long long>(p.in) + off;
+    // provably wave-uniform descriptor (no waterfall loop around the DMA)
+    const unsigned blo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base));
+    const unsigned bup = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>((static_cast<unsigned long long>(bup) << 32) | blo), 0,
         static_cast<unsigned>(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
-    // conv3 is 'same': output (oy, ox) reads rows oy-1..oy+1 = padded rows oy-1+halo..
-    const unsigned soff = static_cast<unsigned>(
-        ((2 * py0 - 1 + p.ig.halo) * p.ig.wp + 2 * px0 - 1 + p.ig.halo) * 16);
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-      pre[ps] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, prel[ps], soff, 0);
-    }
   };
-  auto store_patch = [&](unsigned buf_off) {
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-      const int e = ps * B_THREADS + tid;
-      if (e < B_PT_PIECES) *reinterpret_cast<uint4_t*>(smem + buf_off + e * 16) = pre[ps];
+  // conv3 is 'same': output (oy, ox) reads rows oy-1..oy+1 = padded rows oy-1+halo..
+  auto patch_soff = [&](int py0, int px0) {
+    return static_cast<unsigned>(((2 * py0 - 1 + p.ig.halo) * p.ig.wp + 2 * px0 - 1 + p.ig.halo) * 16);
+  };
+  auto dma_round = [&](int ps, const __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned buf_off) {
+    const unsigned g0 = static_cast<unsigned>((ps * 8 + wave_u) * 1024);
+    if (g0 < static_cast<unsigned>(B_PT_BYTES)) {  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(smem + buf_off + g0), 16, prel[ps], soff, 0, 0);
     }
   };
 
@@ -462,61 +481,110 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   unsigned buf = 0;  // byte offset of the current patch buffer
   if (t < p.total_tiles) {
     tile_coords(t, n, py0, px0);
-    issue_loads(n, py0, px0);
-    store_patch(0);
+    const __amdgpu_buffer_rsrc_t r0 = patch_desc(n);
+    const unsigned so0 = patch_soff(py0, px0);
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) dma_round(ps, r0, so0, 0);
   }
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tm = p.prof ? __builtin_amdgcn_s_memtime() : 0;
+#define DV_PHASE(i_)                                          \
+  if (p.prof) {                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    ph[i_] += now_ - tm;                                      \
+    tm = now_;                                                \
+  }
   while (t < p.total_tiles) {
     const int tn = t + gridDim.x;
     int nn = 0, pyn = 0, pxn = 0;
-    if (tn < p.total_tiles) {
-      tile_coords(tn, nn, pyn, pxn);
-      issue_loads(nn, pyn, pxn);
-    }
+    const bool more = tn < p.total_tiles;
+    if (more) tile_coords(tn, nn, pyn, pxn);
+    // Next patch: one DMA per three sub-steps of the first fragment's sweep (a DMA's issue
+    // slot then falls under the SIMD partner's MFMAs), waited for at barrier A.  Measured
+    // alternatives: all five at the top of the tile +0.3 k cycles per tile; right after
+    // barrier A of the previous tile (a whole tile of lead, HBM wait 1.4 k -> 0.3 k cycles)
+    // +1.2 k cycles per tile -- the issue slots then sit in the MFMA-free pool phase.
+    const __amdgpu_buffer_rsrc_t rn = patch_desc(more ? nn : n);
+    const unsigned son = patch_soff(pyn, pxn);
+    DV_PHASE(0)
 
-    // ---- conv3 (3x3 'same', 32 -> this wave's 32 of 64 channels) -> LDS ---------------------
+    // ---- conv3 (3x3 'same', 32 -> 64) on this wave's two fragments -> LDS ---------------------
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      float16_t acc[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) acc[f] = acc_init(lsh + ch * 32 + hi * 16);
-      mfma_sweep<18, 2, 4>(
-          a3, smem,
-          [&](int s, int f) {
-            const int tap = s >> 1, c = s & 1;
-            return buf + b3[round * 2 + f] + c * 2 * B_PTPLANE + ((tap / 3) * B_PTW + tap % 3) * 16;
-          },
-          acc);
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const int m = round * 2 + f;
-        if (wg + 4 * m < B_C3FR) {  // wave-uniform: fragment 15 does not exist
-          *reinterpret_cast<uint4_t*>(smem + c3dst[m]) = relu_piece(acc[f], 0);
-          *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 2 * B_C3PLANE) = relu_piece(acc[f], 1);
-        }
+    for (int m = 0; m < 2; ++m) {
+      if (wave + 8 * m < B_C3FR) {  // wave-uniform: fragment 15 does not exist
+        float16_t acc_lo = acc_init(lsh + hi * 16), acc_up = acc_init(lsh + 32 + hi * 16);
+        mfma_sweep_pair<18, 4>(
+            a3lo, a3up, smem,
+            [&](int s) {
+              const int tap = s >> 1, c = s & 1;
+              return buf + b3[m] + c * 2 * B_PTPLANE + ((tap / 3) * B_PTW + tap % 3) * 16;
+            },
+            acc_lo, acc_up,
+            [&](int sI) {
+              if (m == 0 && more && sI % 3 == 0 && sI / 3 < B_PASSES) {
+                dma_round(sI / 3, rn, son, buf ^ B_PT_BYTES);
+              }
+            });
+        *reinterpret_cast<uint4_t*>(smem + c3dst[m]) = relu_piece(acc_lo, 0);
+        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 2 * B_C3PLANE) = relu_piece(acc_lo, 1);
+        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 4 * B_C3PLANE) = relu_piece(acc_up, 0);
+        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 6 * B_C3PLANE) = relu_piece(acc_up, 1);
       }
     }
-    if (tn < p.total_tiles) store_patch(buf ^ B_PT_BYTES);
-    __syncthreads();  // conv3 tile and the next patch are complete
+    // this wave's 1x1 weight fragments start their trip now (used after the pool)
+    half8_t a4[8];
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      const int sub = min(s0 + sI, 2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a4[sI * 4 + c] = *reinterpret_cast<const half8_t*>(p.w4 + (((sub * 4 + c) * 2 + hi) * 32 + l31) * 8);
+      }
+    }
+    DV_PHASE(1)
+    if (p.prof) {  // tuning aid: how much of barrier A is the DMA wait
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DV_PHASE(6)
+    }
+    // conv3 tile (LDS writes) and the next patch (my DMAs) are complete: one statement, so that
+    // no LDS access moves across it
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DV_PHASE(2)
 
     // ---- max-pool 3x3 / 2 on the LDS tile (per 8-channel plane) -------------------------------
+    // lane -> (plane parity = lane & 1, pooled pixel): with the odd plane stride a half-wave's
+    // 16-byte reads fall on 32 consecutive even/odd LDS slots -- no bank conflicts (they cost
+    // 2x on 124 KB of reads per tile when a wave walked one plane with stride 2)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = k * B_THREADS + tid;
       if (e < 8 * B_PPX) {
-        const int q = e / B_PPX, pq = e - q * B_PPX;
+        const int j = e >> 1;
+        const int q = 2 * (j / B_PPX) + (e & 1), pq = j % B_PPX;
         const int qy = pq / B_PW, qx = pq - qy * B_PW;
         const char* src = smem + B_OFF_C3 + q * B_C3PLANE + (2 * qy * B_C3W + 2 * qx) * 16;
-        half8_t best = *reinterpret_cast<const half8_t*>(src);
+        // all nine pieces in flight before the first max (hipcc otherwise serialises
+        // read -> wait -> max: nine exposed LDS latencies per pooled pixel)
+        half8_t win[9];
 #pragma unroll
-        for (int w9 = 1; w9 < 9; ++w9) {
-          best = __builtin_elementwise_max(
-              best, *reinterpret_cast<const half8_t*>(src + ((w9 / 3) * B_C3W + w9 % 3) * 16));
+        for (int w9 = 0; w9 < 9; ++w9) {
+          win[w9] = *reinterpret_cast<const half8_t*>(src + ((w9 / 3) * B_C3W + w9 % 3) * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const half8_t m01 = __builtin_elementwise_max(win[0], win[1]);
+        const half8_t m23 = __builtin_elementwise_max(win[2], win[3]);
+        const half8_t m45 = __builtin_elementwise_max(win[4], win[5]);
+        const half8_t m67 = __builtin_elementwise_max(win[6], win[7]);
+        const half8_t best = __builtin_elementwise_max(
+            __builtin_elementwise_max(__builtin_elementwise_max(m01, m23), __builtin_elementwise_max(m45, m67)),
+            win[8]);
         *reinterpret_cast<half8_t*>(smem + B_OFF_P + q * B_PPLANE + pq * 16) = best;
       }
     }
+    DV_PHASE(3)
     __syncthreads();  // pooled tile complete
+    DV_PHASE(4)
 
     // ---- conv 1x1 (64 -> 80) on the pooled tile -> HBM ----------------------------------------
     {
@@ -547,11 +615,17 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
         }
       }
     }
+    DV_PHASE(5)
     t = tn;
     n = nn;
     py0 = pyn;
     px0 = pxn;
     buf ^= B_PT_BYTES;
+  }
+#undef DV_PHASE
+  if (p.prof && lane == 0 && (wave == 0 || wave == 7)) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) p.prof[(blockIdx.x * 2 + (wave == 7)) * 8 + i] = ph[i];
   }
 }
 

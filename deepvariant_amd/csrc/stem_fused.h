@@ -61,6 +61,8 @@ struct StemBArgs {
   int total_tiles;
   size_t in_bytes;
   unsigned in_img_bytes;
+  // tuning aid (DV_STEM_PROF): per-phase shader-clock sums [block][8], or NULL
+  unsigned long long* prof;
 };
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream);
