@@ -65,9 +65,79 @@ def algorithmic_bytes_per_item(batch, out_channels):
 
 def main():
   args = parse_args()
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if 'WORLD_SIZE' in os.environ:       # launched by torch.distributed.run: one rank per process
+    run_rank(args, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+             int(os.environ['WORLD_SIZE']))
+    return
+  if args.gpus <= 1:
+    run_rank(args, 0, 0, 1)
+    return
+  # --gpus N without a launcher: spawn the N ranks here, one process per GPU
+  # (scripts/run_deepvariant.py:457-462 starts its N make_examples shards the same way).
+  import socket
+  import torch.multiprocessing as mp
+  if torch.cuda.device_count() < args.gpus:
+    raise SystemExit('--gpus %d but only %d GPU(s) are visible' %
+                     (args.gpus, torch.cuda.device_count()))
+  sock = socket.socket()
+  sock.bind(('127.0.0.1', 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  mp.spawn(_spawned_rank, args=(args, port), nprocs=args.gpus, join=True)
+
+
+def _spawned_rank(rank, args, port):
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  run_rank(args, rank, rank, args.gpus)
+
+
+def timed_steps(step, sync_all, warmup, steps):
+  """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by
+  barrier + synchronize on both sides.  Returns (seconds, last step's result)."""
+  for _ in range(warmup):
+    step()
+  sync_all()
+  t0 = time.perf_counter()
+  out = None
+  for _ in range(steps):
+    out = step()
+  sync_all()
+  return time.perf_counter() - t0, out
+
+
+def make_gather_step(local_step, ids, world, device):
+  """local_step() -> probs [n, 3] of this rank's shard.  For world > 1 the returned step
+  also runs the product's gather (deepvariant_amd/dist.gather_call_outputs: every rank
+  receives every rank's probabilities + candidate ids) inside the timed step."""
+  if world == 1:
+    return local_step, None
+  import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+  from deepvariant_amd import dist as dvd
+  counts = dvd.exchange_counts(int(ids.shape[0]), device)   # shard sizes are fixed: once
+  state = {}
+
+  def step():
+    probs = local_step()
+    state['all'] = dvd.gather_call_outputs(probs, ids, counts=counts)
+    return probs
+  return step, state
+
+
+def reduce_elapsed(elapsed, n_items, world, device):
+  """MAX over ranks of the elapsed time, SUM of the per-rank items."""
+  if world == 1:
+    return elapsed, float(n_items)
+  import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+  t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+  total = torch.tensor([n_items], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  dist.all_reduce(total, op=dist.ReduceOp.SUM)
+  return float(t.item()), float(total.item())
+
+
+def run_rank(args, rank, local_rank, world):
   if world != args.gpus and world > 1:
     raise SystemExit('--gpus must equal WORLD_SIZE')
   if not torch.cuda.is_available():
@@ -99,47 +169,27 @@ def main():
   images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)
   rows = torch.empty(n_items, dtype=torch.int32, device=dev)
   ids = (torch.arange(n_items, device=dev, dtype=torch.int64) +
-         rank * n_items)
-  if world > 1:
-    # item counts differ per rank: exchange counts once, gather padded.
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([n_items], dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine)
-    max_n = int(counts.max().item())
-    send = torch.zeros((max_n, 4), dtype=torch.float32, device=dev)
-    recv = torch.empty((world * max_n, 4), dtype=torch.float32, device=dev)
+         rank * (1 << 24))
 
   # A real (non-default) HIP stream: dv_model_infer replays the forward as one hipGraph
   # on it (the legacy default stream cannot be captured and runs eagerly).
   work = torch.cuda.Stream(device=dev)
   torch.cuda.set_stream(work)
 
-  def step():
+  def local_step():
     dbatch.encode(enc, C, images, rows)
-    probs = model(images)
-    if world > 1:
-      # CallVariantsOutput payload: 3 probabilities + the candidate id
-      # (ids < 2^24 are exact in fp32 for this bench's sizes).
-      send[:n_items, :3] = probs
-      send[:n_items, 3] = ids.to(torch.float32)
-      dist.all_gather_into_tensor(recv, send)
-    return probs
+    return model(images)
+
+  step, gathered = make_gather_step(local_step, ids, world, dev)
 
   def sync_all():
     if world > 1:
       dist.barrier()
     torch.cuda.synchronize(dev)
 
-  for _ in range(args.warmup):
-    step()
-  sync_all()
   lib = _lib.lib()
   # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    probs = step()
-  sync_all()
-  elapsed = time.perf_counter() - t0
+  elapsed, probs = timed_steps(step, sync_all, args.warmup, args.steps)
   # ---- instrumented pass: the SAME K steps again with a HIP event pair around
   # every kernel launch, on the launch stream.  Event profiling forces eager
   # launches (the timed region replays the forward as one hipGraph), so it is
@@ -156,14 +206,11 @@ def main():
   other_ms = lib.dv_profile_ms(2)
   lib.dv_set_profiling(0)
 
-  t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-  total_items = torch.tensor([n_items], dtype=torch.float64, device=dev)
-  if world > 1:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(total_items, op=dist.ReduceOp.SUM)
-  elapsed = float(t.item())
-  items_per_step = float(total_items.item())
+  elapsed, items_per_step = reduce_elapsed(elapsed, n_items, world, dev)
   assert torch.isfinite(probs).all()
+  if gathered is not None:   # every rank holds every rank's results
+    all_p, all_i = gathered['all']
+    assert all_p.shape[0] == int(items_per_step) and all_i.unique().numel() == all_p.shape[0]
 
   if rank == 0:
     value = items_per_step * args.steps / elapsed
@@ -194,9 +241,12 @@ def main():
             'candidates_per_step_per_gpu': n_items,
             'reads_per_step_per_gpu': int(host_batch.table.n_reads),
             'parallelism': 'interval shards x%d, all-gather of probs' % world,
+            'collective_world_size': (dist.get_world_size() if world > 1 else 1),
+            'collective_backend': (dist.get_backend() if world > 1 else None),
         },
         'roofline': {
-            'kernel': 'conv_mfma_kernel<NB,PT> (all 94 conv layers)',
+            'kernel': 'conv kernels: stem_a/stem_b (fused stem), imgconv_kernel, '
+                      'conv_mfma_kernel<NB,PT> (all 94 conv layers)',
             'bound': 'mfma',
             'achieved': conv_tflops,
             'peak': MFMA_F16_PEAK_TFLOPS,
@@ -228,9 +278,33 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(host_batch, opts, C, args.cpu_sample)
+      out['parity'] = parity_sample(host_batch, opts, C, model, images, probs)
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def parity_sample(host_batch, opts, C, model, images, probs, n=64):
+  """The first `n` candidates of the TIMED batch against the oracle, after the timed
+  region: pileup tensors bit-exact vs the C++ encoder restatement, softmax vs the fp32
+  torch restatement loaded with the same weights (bar: 1e-3, BASELINE.json)."""
+  from oracle import inception_ref, oracle as O
+  n = min(n, host_batch.n_items)
+  want_img, _ = O.encode_packed(opts, _first_items(host_batch, n), C,
+                                n_threads=os.cpu_count() or 1)
+  got_img = images[:n].cpu().numpy().reshape(n, -1)
+  ref = inception_ref.InceptionV3(C)
+  ref.load_flat(model.flat_weights)
+  with torch.no_grad():
+    want = ref(torch.from_numpy(got_img.reshape(n, opts.height, opts.width, C)))
+  err = float((probs[:n].cpu() - want).abs().max())
+  return {
+      'candidates': n,
+      'pileup_tensors_bit_exact': bool((got_img == want_img.reshape(n, -1)).all()),
+      'max_abs_dp': err,
+      'tolerance': 1e-3,
+      'ok': bool(err <= 1e-3),
+  }
 
 
 def pmc_traffic(n_items):

@@ -32,7 +32,7 @@ DV_ERR_BAD_INPUT = -6
 ABI_SYMBOLS = [
     'dv_last_error', 'dv_abi_version', 'dv_device_count',
     'dv_encoder_create', 'dv_encoder_destroy', 'dv_encode_batch',
-    'dv_downsample_indices', 'dv_query_reads', 'dv_crc32c',
+    'dv_downsample_indices', 'dv_validate_batch', 'dv_query_reads', 'dv_crc32c',
     'dv_model_create', 'dv_model_destroy', 'dv_model_num_params', 'dv_model_conv_macs',
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
     'dv_model_infer', 'dv_model_debug_tensor', 'dv_set_profiling', 'dv_profile_ms',
@@ -160,6 +160,7 @@ def lib():
     l.dv_model_num_layers.argtypes = [C.c_void_p]
     l.dv_model_destroy.argtypes = [C.c_void_p]
     l.dv_encoder_destroy.argtypes = [C.c_void_p]
+    l.dv_validate_batch.argtypes = [C.c_void_p, C.c_int32]
     l.dv_encode_batch.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
         C.c_void_p]

@@ -26,24 +26,52 @@ _DEFAULT_BATCH = 1024  # --batch_size default, call_variants.py:104
 
 
 def round_gls(gls, precision=None):
-  """call_variants.py:248-285, verbatim semantics."""
-  if abs(sum(gls) - 1) > 1e-6:
+  """One candidate's genotype likelihoods rounded to `precision` decimals such that they
+  still sum to one: the smallest entry (first on ties) absorbs the rounding residual,
+  clamped at zero.  Same results as the reference's `round_gls`
+  (deepvariant/call_variants.py:248-285; its pinned vectors are in
+  tests/test_host_io_cpu.py).  np.float32 input is rounded in float32 like the reference,
+  which feeds the model's float32 outputs through Python's `round`."""
+  values = list(gls)
+  total = sum(values)
+  if abs(total - 1) > 1e-6:
     raise ValueError(
-        'Invalid genotype likelihoods do not sum to one: sum({}) = {}'.format(
-            gls, sum(gls)))
+        'Invalid genotype likelihoods do not sum to one: sum({}) = {}'.format(gls, total))
   if precision is None:
     return gls
-  min_ix = 0
-  min_gl = gls[0]
-  for ix, gl in enumerate(gls):
-    if gl < min_gl:
-      min_gl = gl
-      min_ix = ix
-  rounded_gls = [round(gl, precision) for gl in gls]
-  rounded_gls[min_ix] = max(
-      0.0,
-      round(1 - sum(rounded_gls[:min_ix] + rounded_gls[min_ix + 1:]), precision))
-  return rounded_gls
+  lowest = min(range(len(values)), key=values.__getitem__)   # first index of the minimum
+  out = [round(v, precision) for v in values]
+  rest = sum(v for i, v in enumerate(out) if i != lowest)
+  out[lowest] = max(0.0, round(1 - rest, precision))
+  return out
+
+
+def round_gls_batch(probs: np.ndarray, precision: int = _GL_PRECISION) -> np.ndarray:
+  """`round_gls` for a whole batch [N, K] at once (the per-candidate Python loop costs more
+  than the classifier at MI355X rates).  float32 probabilities stay float32 through the
+  rounding -- NumPy's float32 `round` is what the reference applies to its float32
+  predictions -- and are widened to the proto's doubles afterwards."""
+  p = np.asarray(probs)
+  if p.ndim != 2:
+    raise ValueError('expected [N, K] probabilities')
+  total = np.zeros(p.shape[0], p.dtype)
+  for k in range(p.shape[1]):          # the reference's left-to-right sum
+    total = total + p[:, k]
+  bad = np.nonzero(np.abs(total - 1) > 1e-6)[0]
+  if bad.size:
+    row = p[bad[0]]
+    raise ValueError('Invalid genotype likelihoods do not sum to one: sum({}) = {}'.format(
+        list(row), total[bad[0]]))
+  rows = np.arange(p.shape[0])
+  lowest = np.argmin(p, axis=1)        # first minimum, like the reference's strict '<' scan
+  out = np.round(p, precision)
+  masked = out.copy()
+  masked[rows, lowest] = 0
+  rest = np.zeros(p.shape[0], p.dtype)
+  for k in range(p.shape[1]):          # x + 0 is exact: same sum as skipping the entry
+    rest = rest + masked[:, k]
+  out[rows, lowest] = np.maximum(0.0, np.round(1 - rest, precision)).astype(p.dtype)
+  return out.astype(np.float64)
 
 
 def create_cvo(encoded_variant: bytes, gls: Sequence[float],
@@ -84,45 +112,63 @@ def example_info_shape(examples_path: str) -> Optional[List[int]]:
   return None
 
 
+def is_sharded_filename(path: str) -> bool:
+  """third_party/nucleus/io/sharded_file_utils.py:59,181-184 (`name-00003-of-00016[.ext]`)."""
+  return re.match(r'(.*)-(\d+)-of-(\d*[1-9]\d*)([^/]+)?$', path) is not None
+
+
 def call_variants(examples, outfile: str, model, batch_size: int = _DEFAULT_BATCH,
                   max_batches: Optional[int] = None, writer_shards: int = 1,
-                  allow_empty_examples: bool = False) -> int:
+                  allow_empty_examples: bool = False, limit: int = 0) -> int:
   """Runs `model` (deepvariant_amd.inception_v3.InceptionV3 with weights
   loaded) over every example and writes CallVariantsOutput TFRecords.
 
   `outfile` follows the reference's naming: `x.tfrecord.gz` becomes
-  `x-0000i-of-0000K.tfrecord.gz` (call_variants.py:813-826).  Returns the
+  `x-0000i-of-0000K.tfrecord.gz`; a name that is already one shard is written as is
+  (call_variants.py:813-826).  `limit` > 0 stops after that many examples.  Returns the
   number of records written.
   """
   import torch  # device memory + stream only
   paths = list(examples) if isinstance(examples, (list, tuple)) else sharded_paths(examples)
-  stem, ext = outfile, ''
-  for e in ('.tfrecord.gz', '.tfrecord'):
-    if outfile.endswith(e):
-      stem, ext = outfile[:-len(e)], e
-      break
-  out_paths = ['%s-%05d-of-%05d%s' % (stem, i, writer_shards, ext)
-               for i in range(writer_shards)]
+  if is_sharded_filename(outfile):
+    # "Output is already sharded, so dynamic sharding is disabled" (call_variants.py:813-817)
+    out_paths = [outfile]
+  else:
+    stem, ext = outfile, ''
+    for e in ('.tfrecord.gz', '.tfrecord'):
+      if outfile.endswith(e):
+        stem, ext = outfile[:-len(e)], e
+        break
+    out_paths = ['%s-%05d-of-%05d%s' % (stem, i, writer_shards, ext)
+                 for i in range(writer_shards)]
   writers = [tfrecord.Writer(p) for p in out_paths]
   h, w, c = model.input_shape
   n_written = 0
   n_batches = 0
   buf_imgs, buf_meta = [], []
+  staged = torch.empty((batch_size, h, w, c), dtype=torch.uint8,
+                       device='cuda:%d' % model.device_index)
 
   def flush():
     nonlocal n_written
     if not buf_imgs:
       return
-    x = torch.from_numpy(np.stack(buf_imgs)).to('cuda:%d' % model.device_index)
-    probs = model(x).cpu().numpy().astype(np.float64)
-    for p, (var, alt) in zip(probs, buf_meta):
-      gls = round_gls([float(v) for v in p], precision=_GL_PRECISION)
-      writers[n_written % writer_shards].write(create_cvo(var, gls, alt))
+    # one device input buffer for the whole run: full batches then hit the model's captured
+    # hipGraph (keyed by the buffer address) instead of re-capturing per batch
+    k = len(buf_imgs)
+    staged[:k].copy_(torch.from_numpy(np.stack(buf_imgs)))
+    gls = round_gls_batch(model(staged[:k]).cpu().numpy(), _GL_PRECISION)
+    for row, (var, alt) in zip(gls, buf_meta):
+      writers[n_written % len(writers)].write(create_cvo(var, row.tolist(), alt))
       n_written += 1
     buf_imgs.clear()
     buf_meta.clear()
 
+  n_read = 0
   for image, variant, alt, shape in read_examples(paths):
+    if limit and n_read >= limit:      # --limit: "<= limit examples" (call_variants.py:199-201)
+      break
+    n_read += 1
     if shape is not None and list(shape) != [h, w, c]:
       # call_variants.py:704-733: input shape must match the model's
       raise ValueError('example shape %s != model shape %s' % (shape, [h, w, c]))
@@ -224,14 +270,11 @@ def main(argv=None) -> int:
   from deepvariant_amd.inception_v3 import InceptionV3
   model = InceptionV3(tuple(shape), max_batch=min(args.batch_size, 8192), device=args.device)
   load_flat_checkpoint(args.checkpoint, model)
-  max_batches = args.max_batches
-  if args.limit:                                  # --limit N examples (call_variants.py:112)
-    lim = (args.limit + args.batch_size - 1) // args.batch_size
-    max_batches = lim if max_batches is None else min(max_batches, lim)
   n = call_variants(paths, args.outfile, model,
-                    batch_size=args.batch_size, max_batches=max_batches,
+                    batch_size=args.batch_size, max_batches=args.max_batches,
                     writer_shards=max(1, min(args.writer_threads or 1, 16)),
-                    allow_empty_examples=_flag_true(args.allow_empty_examples))
+                    allow_empty_examples=_flag_true(args.allow_empty_examples),
+                    limit=max(0, args.limit))
   print('call_variants: wrote %d CallVariantsOutput records' % n)
   return 0
 

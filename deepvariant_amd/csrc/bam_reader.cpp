@@ -73,6 +73,7 @@ int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<ui
     b.in_off = xend;
     b.in_len = pos + bsize - 8 - xend;
     b.out_len = le32(&file[pos + bsize - 4]);
+    if (b.out_len > 65536) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block larger than 64 KiB (ISIZE)");
     b.out_off = total;
     total += b.out_len;
     blocks.push_back(b);
@@ -179,8 +180,13 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   const uint32_t l_seq = le32(r + 16);
   const int32_t next_ref = static_cast<int32_t>(le32(r + 20));
   const int32_t tlen = static_cast<int32_t>(le32(r + 28));
-  const size_t need = 32u + l_read_name + 4u * n_cigar + (l_seq + 1) / 2 + l_seq;
-  if (need > block_size || l_read_name == 0) return dv::fail(DV_ERR_BAD_INPUT, "corrupt BAM record");
+  // 64-bit sum: l_seq comes from an untrusted file, and 32-bit arithmetic wraps (an l_seq of
+  // 0xAAAAAAAB made `need` ~33 and the decoder read gigabytes past the record)
+  const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (static_cast<uint64_t>(l_seq) + 1) / 2 +
+                        static_cast<uint64_t>(l_seq);
+  if (need > block_size || l_seq > block_size || l_read_name == 0) {
+    return dv::fail(DV_ERR_BAD_INPUT, "corrupt BAM record");
+  }
   if (past_end && !f.any_contig && (ref_id > f.want_ref || (ref_id == f.want_ref && rpos >= f.end))) {
     *past_end = true;
   }
@@ -202,12 +208,13 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   if (static_cast<int32_t>(mapq) < rq.min_mapping_quality) return DV_OK;
   const uint8_t* name = r + 32;
   const uint8_t* cig = name + l_read_name;
-  int64_t ref_len = 0;
+  int64_t ref_len = 0, query_len = 0;
   for (unsigned k = 0; k < n_cigar; ++k) {
     const uint32_t v = le32(cig + 4 * k);
     const unsigned op = v & 0xF;
     if (op > 8) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op in BAM record");
     if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) query_len += v >> 4;  // M I S = X
   }
   // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
   if (!(f.end > rpos && f.start < rpos + std::max<int64_t>(ref_len, 1))) return DV_OK;
@@ -215,6 +222,12 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   const uint8_t* qual = seq + (l_seq + 1) / 2;
   if (l_seq && qual[0] == 0xff) {
     return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
+  }
+  // The encoder indexes bases / qualities by CIGAR query offsets without bounds checks (like
+  // the reference, whose SAM parser rejects such records: "CIGAR and query sequence are of
+  // different length"); SEQ '*' (l_seq = 0) with a query-consuming CIGAR is the common case.
+  if (n_cigar && query_len != static_cast<int64_t>(l_seq)) {
+    return dv::fail(DV_ERR_BAD_INPUT, "CIGAR and query sequence are of different length");
   }
   t->pos.push_back(rpos);
   t->end.push_back(rpos + ref_len);
@@ -376,6 +389,7 @@ int inflate_member(FILE* f, uint64_t coff, std::vector<uint8_t>* out, size_t* cs
     return dv::fail(DV_ERR_BAD_INPUT, "truncated BGZF member");
   }
   const uint32_t isize = le32(&comp[payload - 4]);
+  if (isize > 65536) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block larger than 64 KiB (ISIZE)");
   const size_t o0 = out->size();
   out->resize(o0 + isize);
   if (isize) {

@@ -902,6 +902,61 @@ void dv_encoder_destroy(dv_encoder* enc) {
   delete enc;
 }
 
+// What the reference would LOG(FATAL)/CHECK on, plus the index ranges the kernel trusts.
+// Host-resident batches only (dv_encode_batch runs it on them itself); a caller that
+// uploads its own DV_MEM_DEVICE batch runs it on the host image before the upload.
+int dv_validate_batch(const dv_batch* b, int32_t reference_band_height) {
+  if (!b) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_validate_batch: null");
+  if (b->memory != DV_MEM_HOST) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_validate_batch needs a host-resident batch");
+  }
+  if (b->n_items < 0 || b->n_reads < 0) return dv::fail(DV_ERR_INVALID_ARGUMENT, "negative counts");
+  for (uint32_t i = 0; i < b->n_cigar; ++i) {
+    const uint32_t op = b->cigar[i] & 0xF;
+    if (op < 1 || op > 9) {
+      return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op");  // pileup_channel_lib.cc:252
+    }
+  }
+  for (int i = 0; i < b->n_items; ++i) {
+    const int h = b->item_height[i];
+    if (h <= reference_band_height || h - reference_band_height > kMaxKept) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT,
+                      "item_height must be in (reference_band_height, "
+                      "reference_band_height + 256]");
+    }
+    if (b->item_list_off[i + 1] < b->item_list_off[i] || b->item_list_off[i + 1] > b->n_list) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "item_list_off is not a prefix sum within n_list");
+    }
+    if (b->item_list_off[i + 1] - b->item_list_off[i] > b->max_list_len) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "max_list_len too small");
+    }
+    if (b->item_ref_idx[i] >= b->n_ref_windows) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "item_ref_idx out of range");
+    }
+  }
+  for (uint32_t i = 0; i < b->n_list; ++i) {
+    if (b->list_read[i] >= static_cast<uint32_t>(b->n_reads)) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "list_read out of range");
+    }
+  }
+  for (int r = 0; r < b->n_reads; ++r) {
+    if (b->read_cigar_off[r + 1] < b->read_cigar_off[r] || b->read_cigar_off[r + 1] > b->n_cigar ||
+        b->read_seq_off[r + 1] < b->read_seq_off[r] || b->read_seq_off[r + 1] > b->n_bases) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "read offsets are not prefix sums within the arrays");
+    }
+    // the cigar's query length must not exceed the stored sequence
+    uint64_t qlen = 0;
+    for (uint32_t c = b->read_cigar_off[r]; c < b->read_cigar_off[r + 1]; ++c) {
+      const uint32_t op = b->cigar[c] & 0xF;
+      if (op == 1 || op == 2 || op == 5 || op == 8 || op == 9) qlen += b->cigar[c] >> 4;
+    }
+    if (qlen > b->read_seq_off[r + 1] - b->read_seq_off[r]) {
+      return dv::fail(DV_ERR_BAD_INPUT, "CIGAR consumes more bases than aligned_sequence has");
+    }
+  }
+  return DV_OK;
+}
+
 int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
                     uint8_t* out, int32_t* out_rows, int out_memory,
                     void* stream_v) {
@@ -934,43 +989,9 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   size_t out_bytes = 0;
   if (b->memory == DV_MEM_HOST) {
     // Validate what the reference would LOG(FATAL)/CHECK on, then stage.
-    for (uint32_t i = 0; i < b->n_cigar; ++i) {
-      const uint32_t op = b->cigar[i] & 0xF;
-      if (op < 1 || op > 9) {
-        return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op");
-      }
-    }
+    if (int rc = dv_validate_batch(b, enc->opt.reference_band_height)) return rc;
     for (int i = 0; i < b->n_items; ++i) {
-      const int h = b->item_height[i];
-      if (h <= enc->opt.reference_band_height || h - enc->opt.reference_band_height > kMaxKept) {
-        return dv::fail(DV_ERR_INVALID_ARGUMENT,
-                        "item_height must be in (reference_band_height, "
-                        "reference_band_height + 256]");
-      }
-      if (b->item_list_off[i + 1] - b->item_list_off[i] > b->max_list_len) {
-        return dv::fail(DV_ERR_INVALID_ARGUMENT, "max_list_len too small");
-      }
-      if (b->item_ref_idx[i] >= b->n_ref_windows) {
-        return dv::fail(DV_ERR_INVALID_ARGUMENT, "item_ref_idx out of range");
-      }
-      out_bytes = std::max<size_t>(out_bytes, b->item_out_off[i] + h * row_bytes);
-    }
-    for (uint32_t i = 0; i < b->n_list; ++i) {
-      if (b->list_read[i] >= static_cast<uint32_t>(b->n_reads)) {
-        return dv::fail(DV_ERR_INVALID_ARGUMENT, "list_read out of range");
-      }
-    }
-    for (int r = 0; r < b->n_reads; ++r) {
-      // the cigar's query length must not exceed the stored sequence
-      uint64_t qlen = 0;
-      for (uint32_t c = b->read_cigar_off[r]; c < b->read_cigar_off[r + 1]; ++c) {
-        const uint32_t op = b->cigar[c] & 0xF;
-        if (op == 1 || op == 2 || op == 5 || op == 8 || op == 9) qlen += b->cigar[c] >> 4;
-      }
-      if (qlen > b->read_seq_off[r + 1] - b->read_seq_off[r]) {
-        return dv::fail(DV_ERR_BAD_INPUT,
-                        "CIGAR consumes more bases than aligned_sequence has");
-      }
+      out_bytes = std::max<size_t>(out_bytes, b->item_out_off[i] + b->item_height[i] * row_bytes);
     }
     size_t s = 0;
     const size_t nr = b->n_reads, ni = b->n_items;

@@ -1697,6 +1697,8 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
 // to host memory; returns its shape.  Buffer 0 is the preprocessed input.
 int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t* h,
                           int32_t* w, int32_t* c) {
+  if (m && index == -1) index = m->feat_buf;      // the last block's output (input of the head)
+  if (m && index == -2) index = m->stem_out_buf;  // the stem's output (input of mixed0)
   if (!m || index < 0 || index >= static_cast<int>(m->buffers.size())) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_debug_tensor: bad index");
   }
@@ -1802,7 +1804,8 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   if (ie != hipSuccess) {
     return dv::fail(DV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
   }
-  if (m->graphs.size() >= 8) {  // bounded cache
+  if (m->graphs.size() >= 8) {  // bounded cache; the evicted replay may still be in flight
+    (void)hipStreamSynchronize(m->graphs.front().stream);
     (void)hipGraphExecDestroy(m->graphs.front().exec);
     m->graphs.erase(m->graphs.begin());
   }

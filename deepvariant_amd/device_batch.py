@@ -35,7 +35,14 @@ _FIELDS = [
 class DeviceBatch:
   """Uploads a PackedBatch once; `encode` launches with device pointers."""
 
-  def __init__(self, batch: packing.PackedBatch, device: torch.device):
+  def __init__(self, batch: packing.PackedBatch, device: torch.device,
+               reference_band_height: int = 5):
+    # dv_encode_batch cannot inspect a device-resident batch: run its host-side checks
+    # (CIGAR ops, CIGAR vs sequence length, index ranges) on the host image before the
+    # upload, so that a malformed read fails here instead of reading out of bounds on the GPU
+    host_c, keep = batch.to_ctypes()
+    _lib.check(_lib.lib().dv_validate_batch(C.byref(host_c), int(reference_band_height)))
+    del keep
     self.n_items = batch.n_items
     self.width = batch.width
     self.tensors = {}

@@ -23,18 +23,30 @@ def regions_for_rank(regions: Sequence, rank: int, world_size: int) -> List:
   return [r for i, r in enumerate(regions) if i % world_size == rank]
 
 
-def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None
+def exchange_counts(n: int, device, group=None) -> List[int]:
+  """Every rank's candidate count (one small all-gather)."""
+  world = dist.get_world_size(group)
+  mine = torch.tensor([n], dtype=torch.int64, device=device)
+  counts = torch.zeros(world, dtype=torch.int64, device=device)
+  dist.all_gather_into_tensor(counts, mine, group=group)
+  return [int(c) for c in counts.tolist()]
+
+
+def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None,
+                        counts: Sequence[int] = None
                         ) -> Tuple[torch.Tensor, torch.Tensor]:
   """All ranks receive every rank's (probabilities [n_i, 3], ids [n_i]).
 
   Counts differ per rank, so they are exchanged first and the payload is padded
-  to the maximum; two collectives in total, no reduction.
+  to the maximum; two collectives in total, no reduction.  A caller that
+  repeats the gather with fixed shard sizes passes `counts` (from
+  `exchange_counts`) and pays for the payload collective only -- no host
+  synchronisation inside the step.
   """
   world = dist.get_world_size(group)
-  n = torch.tensor([probs.shape[0]], dtype=torch.int64, device=probs.device)
-  counts = torch.zeros(world, dtype=torch.int64, device=probs.device)
-  dist.all_gather_into_tensor(counts, n, group=group)
-  max_n = int(counts.max().item())
+  if counts is None:
+    counts = exchange_counts(probs.shape[0], probs.device, group)
+  max_n = max(counts)
   k = probs.shape[1]
   send = torch.zeros((max_n, k + 2), dtype=torch.float32, device=probs.device)
   send[:probs.shape[0], :k] = probs
@@ -47,7 +59,7 @@ def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None
   recv = recv.view(world, max_n, k + 2)
   out_p, out_i = [], []
   for r in range(world):
-    c = int(counts[r].item())
+    c = counts[r]
     out_p.append(recv[r, :c, :k])
     out_i.append(recv[r, :c, k].to(torch.int64) +
                  (recv[r, :c, k + 1].to(torch.int64) << 24))

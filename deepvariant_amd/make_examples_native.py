@@ -313,16 +313,15 @@ class ExamplesGenerator:
     if self._device_encoder is None:
       self._device_encoder = _Encoder(pic, pic.width, self._device)
     dev = torch.device('cuda', self._device)
-    dbatch = DeviceBatch(batch, dev)
+    dbatch = DeviceBatch(batch, dev, pic.reference_band_height)
     images = torch.empty([len(plan)] + list(image_shape), dtype=torch.uint8, device=dev)
     dbatch.encode(self._device_encoder, image_shape[2], images)
-    probs = model(images).cpu().numpy().astype(np.float64)
+    gls = cv.round_gls_batch(model(images).cpu().numpy(), 10)
     out = []
-    for (ci, combo), p in zip(plan, probs):
+    for (ci, combo), row in zip(plan, gls):
       variant = candidates[ci].variant
       alt_encoded, _ = encode_alt_alleles(variant, combo)
-      gls = cv.round_gls([float(v) for v in p], precision=10)
-      out.append(cv.create_cvo(pw.encode_variant(variant), gls, alt_encoded))
+      out.append(cv.create_cvo(pw.encode_variant(variant), row.tolist(), alt_encoded))
     return out
 
   def _encode_example(self, variant, alt_combination, image: np.ndarray,

@@ -235,6 +235,13 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* batch, int out_channels,
                     uint8_t* out, int32_t* out_rows, int out_memory,
                     void* stream);
 
+/* The checks dv_encode_batch applies to a HOST batch before staging it: what the
+ * reference LOG(FATAL)s / CHECKs on (unknown CIGAR op, pileup_channel_lib.cc:252; a CIGAR
+ * that consumes more bases than aligned_sequence holds) and every index range the kernel
+ * trusts.  A caller that uploads its own DV_MEM_DEVICE batch (device batches are not
+ * readable from the host) runs this on the host image first.  Host only, no device work. */
+int dv_validate_batch(const dv_batch* batch, int32_t reference_band_height);
+
 /* DownsampleReadIndices (deepvariant/pileup_image_native.cc:153-165): iota,
  * std::shuffle'd with std::mt19937_64(seed) iff n > max_reads.  Host only. */
 int dv_downsample_indices(int n, int max_reads, uint32_t seed, int32_t* out);
@@ -343,7 +350,8 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
 
 /* Testing hook: copy activation buffer `index` (fp16, channel-blocked
  * [n][c/8][h][w][8], first n examples of the last dv_model_infer) to host
- * memory and report its shape. */
+ * memory and report its (padded) shape.  index -1 = the last Inception block's
+ * output (what GlobalAveragePooling reads), -2 = the stem's output. */
 int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out,
                           int32_t* h, int32_t* w, int32_t* c);
 

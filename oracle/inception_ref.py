@@ -173,6 +173,28 @@ class InceptionV3(nn.Module):
               self.classification.bias.detach()]
     return torch.cat([p.reshape(-1).float() for p in parts]).numpy()
 
+  def load_flat(self, flat: np.ndarray) -> None:
+    """Inverse of export_flat (same layout as dv_model_load_weights)."""
+    flat = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32))
+    off = 0
+    with torch.no_grad():
+      for m in self.convs:
+        co, ci, kh, kw = m.conv.weight.shape
+        n = co * ci * kh * kw
+        m.conv.weight.copy_(flat[off:off + n].reshape(kh, kw, ci, co).permute(3, 2, 0, 1))
+        off += n
+        m.bn.bias.copy_(flat[off:off + co])
+        m.bn.running_mean.copy_(flat[off + co:off + 2 * co])
+        m.bn.running_var.copy_(flat[off + 2 * co:off + 3 * co])
+        off += 3 * co
+      k, c = self.classification.weight.shape
+      self.classification.weight.copy_(flat[off:off + k * c].reshape(c, k).t())
+      off += k * c
+      self.classification.bias.copy_(flat[off:off + k])
+      off += k
+    assert off == flat.numel(), (off, flat.numel())
+    self.eval()
+
   def num_keras_params(self) -> int:
     n = 0
     for m in self.convs:

@@ -145,3 +145,50 @@ def test_bai_indexed_read_equals_full_scan(bam, regions, mapq, monkeypatch):
     monkeypatch.setenv('DV_BAM_NO_INDEX', '1')
     full = packing.ReadTable.from_bam(path, 'chr20', start, end, min_mapping_quality=mapq)
     _assert_same(indexed, full)
+
+
+def _one_record_bam(path, body):
+  hdr = (b'BAM\x01' + struct.pack('<i', 0) + struct.pack('<i', 1) + struct.pack('<i', 5) +
+         b'chrA\0' + struct.pack('<i', 100000))
+  with open(path, 'wb') as f:
+    f.write(_bgzf(hdr + struct.pack('<i', len(body)) + body, block=60000))
+
+
+def test_untrusted_record_sizes_are_rejected_not_followed(tmp_path):
+  """A BAM is untrusted input: a 32-bit wrap in the record-size sum (l_seq = 0xAAAAAAAB makes
+  32 + l_read_name + 4 n_cigar + (l_seq+1)/2 + l_seq come out as ~33) must be an error, not a
+  multi-gigabyte read; so must a record whose SEQ is '*' (l_seq = 0) or shorter than what its
+  CIGAR consumes -- the encoder indexes bases by CIGAR offsets without bounds checks."""
+  cig = struct.pack('<I', (50 << 4) | 0)   # 50M
+  def body(l_seq, seq_bytes):
+    return (struct.pack('<iiBBHHHiiii', 0, 100, 2, 60, 0, 1, 0, l_seq, -1, 0, 0) + b'r\0' + cig +
+            seq_bytes)
+  cases = {
+      'wrap': (body(0xAAAAAAAB - (1 << 32), b'\x11' * 40), 'corrupt BAM record'),
+      'star': (body(0, b''), 'different length'),
+      'short': (body(10, b'\x11' * 5 + b'\x20' * 10), 'different length'),
+  }
+  for name, (rec, msg) in cases.items():
+    path = str(tmp_path / (name + '.bam'))
+    _one_record_bam(path, rec)
+    with pytest.raises(_lib.DvError, match=msg):
+      packing.ReadTable.from_bam(path, 'chrA', 0, 1000)
+  # the well-formed twin of 'short' is accepted
+  ok = str(tmp_path / 'ok.bam')
+  _one_record_bam(ok, body(50, b'\x11' * 25 + b'\x20' * 50))
+  assert packing.ReadTable.from_bam(ok, 'chrA', 0, 1000).n_reads == 1
+
+
+def test_bgzf_isize_is_capped(tmp_path):
+  """BGZF blocks inflate to at most 64 KiB; a larger ISIZE is a corrupt file, not a 4 GB resize."""
+  chunk = b'BAM\x01' + b'\0' * 8
+  c = zlib.compressobj(6, zlib.DEFLATED, -15)
+  payload = c.compress(chunk) + c.flush()
+  bsize = 12 + 6 + len(payload) + 8
+  blk = (b'\x1f\x8b\x08\x04' + b'\0' * 4 + b'\0\xff' + struct.pack('<H', 6) + b'BC' +
+         struct.pack('<HH', 2, bsize - 1) + payload + struct.pack('<II', zlib.crc32(chunk), 0xF0000000))
+  path = str(tmp_path / 'big.bam')
+  with open(path, 'wb') as f:
+    f.write(blk)
+  with pytest.raises(_lib.DvError, match='64 KiB'):
+    packing.ReadTable.from_bam(path, 'chrA', 0, 1000)

@@ -1,0 +1,123 @@
+"""Region-scale parity through the reference-shaped interfaces (GPU): many candidates
+sharing one region's reads, two samples stacked per example (DeepTrio-style), one of
+them deeper than the image (DownsampleReadIndices' shuffle-and-truncate on every item).
+
+The HIP side is the product end to end -- ExamplesGenerator.encode_region: packing.py
+(read table, per-candidate query, support codes, name ranks) + ONE dv_encode_batch launch.
+The oracle side gets the PROTO-SHAPED inputs per (candidate, alt combination, sample):
+the test restates the reference's own per-candidate steps -- InMemoryReader::Query
+(make_examples_native.cc:802-810, nucleus/util/utils.cc:172-188), the window
+(`:645-648`), AltAlleleCombinations (`:191-267`) -- and never touches the product's
+packed batch, so packing errors cannot cancel out.
+"""
+import numpy as np
+import pytest
+
+from deepvariant_amd import dv_types as T
+from tests import fuzz_inputs as F
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ref:
+  def __init__(self, seq):
+    self.seq = seq
+
+  def n_bases(self, contig):
+    return len(self.seq)
+
+  def get_bases(self, contig, start, end):
+    return self.seq[start:end]
+
+
+def _read_end(read):
+  """ReadEnd: start + reference-consuming CIGAR ops (M, D, N, =, X)."""
+  return read.alignment.position.position + sum(
+      c.operation_length for c in read.alignment.cigar if c.operation in (1, 3, 4, 8, 9))
+
+
+def _query(reads, start, end):
+  """utils.cc:172-188 ReadOverlapsRegion, in input order (InMemoryReader::Query)."""
+  return [r for r in reads if end > r.alignment.position.position and start < _read_end(r)]
+
+
+def _region_reads(rng, n, lo, hi, tag):
+  reads = []
+  for i in range(n):
+    cigar = F.random_cigar(rng, 1, 5)
+    if F.query_len(cigar) == 0:
+      cigar.append(T.CigarUnit(1, 1))
+    qlen = F.query_len(cigar)
+    quals = rng.integers(0, 60, size=qlen).astype(np.uint8)
+    reads.append(T.Read(
+        fragment_name='%s%d' % (tag, int(rng.integers(0, max(n // 2, 1)))),
+        read_number=int(rng.integers(0, 2)), number_reads=2,
+        fragment_length=int(rng.integers(-900, 900)),
+        aligned_sequence=''.join('ACGT'[int(j)] for j in rng.integers(0, 4, size=qlen)),
+        aligned_quality=bytes(quals),
+        alignment=T.LinearAlignment(
+            position=T.Position('chr1', int(rng.integers(lo, hi)), bool(rng.integers(0, 2))),
+            mapping_quality=int(rng.integers(0, 70)), cigar=cigar)))
+  # the reference's readers hand reads over sorted by position
+  reads.sort(key=lambda r: r.alignment.position.position)
+  return reads
+
+
+@pytest.mark.parametrize('sort_by_support', [False, True])
+def test_two_samples_many_candidates_one_launch(sort_by_support):
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from oracle import oracle as O
+  rng = np.random.default_rng(20260921)
+  width = 81
+  hw = (width - 1) // 2
+  pic = F.options(T.PILEUP_CHANNELS_WITH_INSERT_SIZE, width, 0,
+                  sort_by_alt_allele_support=sort_by_support)
+  pic.num_channels = len(pic.channels)
+  heights = (40, 60)
+  pic.height = sum(heights)
+  options = T.MakeExamplesOptions(
+      pic_options=pic,
+      sample_options=[T.SampleOptions(role='child', name='c', pileup_height=heights[0]),
+                      T.SampleOptions(role='parent', name='p', pileup_height=heights[1])])
+  ref = _Ref(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=4000)))
+  # sample 0: ~25x, sample 1: ~110 reads over every site (more than its 55 read rows)
+  reads = [_region_reads(rng, 420, 900, 2100, 'c'), _region_reads(rng, 2600, 900, 2100, 'p')]
+  cands = []
+  for pos in sorted(set(rng.integers(1000, 2000, size=34).tolist())):
+    refb = ref.seq[pos]
+    alts = [b for b in 'ACGT' if b != refb][:int(rng.integers(1, 3))]
+    near = [r for s in reads for r in _query(s, pos - 5, pos + 6)]
+    support = {}
+    for a in alts:
+      k = int(rng.integers(0, 12))
+      pick = rng.integers(0, len(near), size=k)
+      support[a] = T.SupportingReads(['%s/%d' % (near[int(j)].fragment_name,
+                                                 near[int(j)].read_number) for j in pick])
+    cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + 1, refb, alts),
+                                   allele_support=support))
+  gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=ref)
+  stats = {}
+  examples, shape = gen.encode_region(cands, reads, [0, 1], [0.0, 0.0], stats)
+  assert shape == [100, width, len(pic.channels)]
+  # the reference's example order: candidates in order, alt combinations in order
+  k = 0
+  deep_items = 0
+  for cand in cands:
+    v = cand.variant
+    window = men.get_reference_bases_for_pileup(ref, v, width)
+    for combo in men.alt_allele_combinations(cand, pic.multi_allelic_mode):
+      rec = pw.decode_example(examples[k])
+      k += 1
+      img = np.frombuffer(rec['image/encoded'][0], np.uint8).reshape(100, width, len(pic.channels))
+      parts = []
+      for s, h in enumerate(heights):
+        overlapping = _query(reads[s], v.start - pic.read_overlap_buffer_bp,
+                             v.end + pic.read_overlap_buffer_bp)
+        deep_items += len(overlapping) > h - pic.reference_band_height
+        parts.append(O.build_pileup(pic, cand, window, overlapping, v.start - hw, list(combo),
+                                    pileup_height=h))
+      np.testing.assert_array_equal(img, np.concatenate(parts, axis=0),
+                                    err_msg='candidate at %d, alts %s' % (v.start, combo))
+  assert k == len(examples) == stats['n_examples'] and k >= len(cands)
+  assert deep_items >= len(cands)      # the shuffle path ran for (at least) every parent image

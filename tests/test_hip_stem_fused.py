@@ -142,3 +142,45 @@ def test_benchmark_configuration_against_the_oracle():
   assert err[:k].max().item() <= 1e-3, err[:k].max().item()
   assert err[k:].max().item() <= 2e-3, err[k:].max().item()
   assert (want.max(0).values - want.min(0).values).max() > 1e-2
+
+
+def test_features_and_logits_stage_by_stage():
+  """Beyond the softmax: the stem's output, the 2048 pooled features and the logits of
+  the HIP forward against the fp32 oracle with RELATIVE tolerances (a softmax of random
+  weights can hide a wrong feature map behind a saturated class)."""
+  from oracle import inception_ref as R
+  n = 24
+  ref = R.make_random_model(7, seed=23)
+  w = ref.export_flat()
+  x = torch.from_numpy(_images(n, 7, seed=5))
+  model = _model((100, 221, 7), w, n, fused=True)
+  probs = model(x.cuda()).cpu()
+  pre = ((x.float() - 128.0) / 128.0).permute(0, 3, 1, 2)
+  with torch.no_grad():
+    s = ref.stem
+    stem_out = R._maxpool(s[4](s[3](R._maxpool(s[2](s[1](s[0](pre)))))))
+    feats = ref.features(pre)
+    logits = ref.classification(feats)
+  got_stem = model.debug_tensor(-2, n).astype(np.float32)
+  halo = (got_stem.shape[1] - 10) // 2
+  got_stem = _interior(got_stem, halo)
+  want_stem = stem_out.permute(0, 2, 3, 1).numpy()
+  assert got_stem.shape == want_stem.shape == (n, 10, 25, 192)
+  rel = np.abs(got_stem - want_stem).max() / np.abs(want_stem).max()
+  assert rel <= 1e-2, rel
+  fmap = model.debug_tensor(-1, n).astype(np.float32)
+  fh = (fmap.shape[1] - 1) // 2
+  got_feats = _interior(fmap, fh).reshape(n, 5, 2048).mean(axis=1)
+  want_feats = feats.numpy()
+  rms = float(np.sqrt((want_feats ** 2).mean()))
+  err = np.abs(got_feats - want_feats)
+  assert err.max() <= 0.05 * rms and np.sqrt((err ** 2).mean()) <= 0.005 * rms, (err.max(), rms)
+  # logits from the HIP features through the fp32 head vs the oracle's logits
+  wd = ref.classification.weight.detach().numpy()
+  bd = ref.classification.bias.detach().numpy()
+  got_logits = got_feats @ wd.T + bd
+  scale = np.abs(logits.numpy()).max()
+  assert np.abs(got_logits - logits.numpy()).max() <= 5e-3 * max(scale, 1.0)
+  # and the device head agrees with that host-side head
+  e = np.exp(got_logits - got_logits.max(1, keepdims=True))
+  np.testing.assert_allclose(probs.numpy(), e / e.sum(1, keepdims=True), atol=2e-5)

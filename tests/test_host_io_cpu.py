@@ -115,3 +115,33 @@ def test_golden_examples_decode_with_our_reader():
                            'alt_allele_indices/encoded': [b'\n\x01\x00']})
   d = pw.decode_example(rec)
   assert np.array_equal(np.frombuffer(d['image/encoded'][0], np.uint8).reshape(img.shape), img)
+
+
+def test_round_gls_batch_equals_the_scalar_path_on_float32():
+  """The batched rounding used by call_variants == the per-candidate function applied to
+  np.float32 scalars (what the reference's loop sees: float32 predictions through Python's
+  round), bit for bit, on softmax-like rows incl. ties, tiny minima and exact halves."""
+  from deepvariant_amd import call_variants as cv
+  rng = np.random.default_rng(7)
+  logits = rng.normal(0, 4, size=(5000, 3)).astype(np.float32)
+  e = np.exp(logits - logits.max(1, keepdims=True))
+  p = (e / e.sum(1, keepdims=True)).astype(np.float32)
+  p[:3] = np.array([[0.25, 0.25, 0.5], [1.0, 0.0, 0.0], [0.33333334, 0.33333334, 0.3333333]],
+                   np.float32)
+  got = cv.round_gls_batch(p, 10)
+  assert got.dtype == np.float64
+  for row, want_in in zip(got, p):
+    want = cv.round_gls(list(want_in), 10)          # np.float32 scalars
+    assert [float(v) for v in want] == row.tolist()
+  # doubles are float32-granular, like the reference's CVO bytes
+  assert (got == got.astype(np.float32).astype(np.float64)).all()
+  with pytest.raises(ValueError, match='do not sum to one'):
+    cv.round_gls_batch(np.array([[0.5, 0.5, 0.5]], np.float32))
+
+
+def test_sharded_output_name_detection():
+  from deepvariant_amd import call_variants as cv
+  assert cv.is_sharded_filename('/x/cvo-00000-of-00001.tfrecord.gz')
+  assert cv.is_sharded_filename('cvo-3-of-16')
+  assert not cv.is_sharded_filename('/x/cvo.tfrecord.gz')
+  assert not cv.is_sharded_filename('/x/cvo-00000-of-00000.tfrecord.gz')

@@ -86,3 +86,36 @@ def test_packer_rejects_what_the_reference_aborts_on():
   o.channels = ['not_a_channel']
   with pytest.raises(ValueError, match='corresponding enum'):
     packing.channel_enums(o)
+
+
+def test_validate_batch_rejects_what_the_device_path_cannot_check():
+  """dv_validate_batch = dv_encode_batch's host-side checks, exported so that callers who
+  upload their own device batch (DeviceBatch) run them first: a CIGAR that consumes more bases
+  than the read stores, an unknown CIGAR op, a list entry past the read table."""
+  import ctypes as C
+  from deepvariant_amd import _lib, synth
+  opts = synth.illumina_options(7)
+  lib = _lib.lib()
+
+  def rc_of(batch):
+    c, keep = batch.to_ctypes()
+    return lib.dv_validate_batch(C.byref(c), opts.reference_band_height)
+
+  good = synth.make_illumina_batch(6, seed=3, options=opts)
+  assert rc_of(good) == 0
+  bad = synth.make_illumina_batch(6, seed=3, options=opts)
+  bad.table.cigar = bad.table.cigar.copy()
+  bad.table.cigar[0] = (10000 << 4) | 1          # 10000M on a 150-base read
+  bad._frozen = None
+  assert rc_of(bad) == _lib.DV_ERR_BAD_INPUT
+  assert b'CIGAR consumes more bases' in lib.dv_last_error()
+  bad2 = synth.make_illumina_batch(6, seed=3, options=opts)
+  bad2.table.cigar = bad2.table.cigar.copy()
+  bad2.table.cigar[0] = (5 << 4) | 12            # op 12 does not exist
+  bad2._frozen = None
+  assert rc_of(bad2) == _lib.DV_ERR_BAD_INPUT
+  bad3 = synth.make_illumina_batch(6, seed=3, options=opts)
+  bad3.list_read_chunks[0] = bad3.list_read_chunks[0].copy()
+  bad3.list_read_chunks[0][0] = 10 ** 7
+  bad3._frozen = None
+  assert rc_of(bad3) == _lib.DV_ERR_INVALID_ARGUMENT
