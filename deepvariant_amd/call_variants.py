@@ -203,8 +203,9 @@ def build_arg_parser():
   ap.add_argument('--examples', required=True)
   ap.add_argument('--outfile', required=True)
   ap.add_argument('--checkpoint', required=True,
-                  help='flat fp32 weights (.npy / .bin, layout of dv_model_load_weights) or '
-                       '"random:<seed>"; TensorFlow checkpoint bundles are not read')
+                  help='TensorFlow checkpoint prefix / SavedModel directory of the Keras '
+                       'InceptionV3 (call_variants.py:759-762), flat fp32 weights (.npy / .bin, '
+                       'layout of dv_model_load_weights) or "random:<seed>"')
   ap.add_argument('--batch_size', type=int, default=_DEFAULT_BATCH)
   ap.add_argument('--max_batches', type=int, default=None)
   ap.add_argument('--num_readers', type=int, default=8)          # tf.data knob: no-op
@@ -245,14 +246,83 @@ def check_flags(args):
     raise ValueError('--batch_size must be positive')
 
 
-def load_flat_checkpoint(spec: str, model):
-  """--checkpoint: `random:<seed>` or a flat fp32 array in dv_model_load_weights order."""
+def checkpoint_prefix(spec: str) -> Optional[str]:
+  """The tensor-bundle prefix behind a `--checkpoint` value, or None: a TF checkpoint prefix
+  (`.../ckpt-123`), its `.index` file, or a SavedModel directory (`variables/variables`)."""
+  if spec.endswith('.index'):
+    spec = spec[:-len('.index')]
+  if os.path.exists(spec + '.index'):
+    return spec
+  if os.path.isdir(spec):
+    for cand in (os.path.join(spec, 'variables', 'variables'), os.path.join(spec, 'variables')):
+      if os.path.exists(cand + '.index'):
+        return cand
+  return None
+
+
+def import_keras_checkpoint(prefix: str, in_channels: int, num_classes: int = 3,
+                            allow_channel_mismatch: bool = False) -> np.ndarray:
+  """A checkpoint written by the reference's Keras model (`model.save_weights` /
+  `model.load_weights`, deepvariant/keras_modeling.py:304-335) -> the flat fp32 layout of
+  `dv_model_load_weights`.  Variables are matched BY NAME (`layer_with_weights-N/...`, N in
+  tf_keras' depth-sorted layer order -- deepvariant_amd/keras_layout.py) and every shape is
+  checked, so a layout mistake is an error, never silently permuted weights.
+
+  When the checkpoint was trained with a different number of input channels the reference
+  copies the first kernel's common channels and leaves the rest at their random
+  initialisation (`load_weights_to_model_with_different_channels`, :113-168); inference on
+  that is meaningless, so it is an error here unless `allow_channel_mismatch`, in which case
+  the missing channels are ZERO."""
+  from deepvariant_amd import keras_layout, tf_checkpoint
+  reader = tf_checkpoint.CheckpointReader(prefix)
+  first = 'layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE'
+  names = reader.get_variable_to_shape_map()
+  if any(k.startswith('layer_with_weights-0/layer_with_weights-0/kernel') for k in names):
+    raise ValueError('You are using an older DeepVariant Keras model architecture. '
+                     'Please use a new model.')              # keras_modeling.py:186-192
+  if first not in names or len(names[first]) != 4:
+    raise ValueError('Unexpected model format.')              # keras_modeling.py:193
+  ckpt_channels = names[first][2]
+  if ckpt_channels != in_channels and not allow_channel_mismatch:
+    raise ValueError('checkpoint has %d input channels, the examples have %d' %
+                     (ckpt_channels, in_channels))
+  src_entries, n_src = keras_layout.variable_layout(ckpt_channels, num_classes)
+  src = np.zeros(n_src, np.float32)
+  for name, shape, off in src_entries:
+    if name not in names:
+      raise ValueError('checkpoint lacks %s' % name)
+    if tuple(names[name]) != tuple(shape):
+      raise ValueError('%s has shape %s in the checkpoint, the InceptionV3 layout expects %s'
+                       % (name, names[name], list(shape)))
+    t = reader.get_tensor(name).astype(np.float32, copy=False)
+    src[off:off + t.size] = t.reshape(-1)
+  if ckpt_channels == in_channels:
+    return src
+  # first-conv channel surgery; everything behind the first kernel keeps its place
+  k_src = 3 * 3 * ckpt_channels * 32
+  k_dst = 3 * 3 * in_channels * 32
+  dst = np.zeros(n_src - k_src + k_dst, np.float32)
+  common = min(ckpt_channels, in_channels)
+  dst[:k_dst].reshape(3, 3, in_channels, 32)[:, :, :common, :] = \
+      src[:k_src].reshape(3, 3, ckpt_channels, 32)[:, :, :common, :]
+  dst[k_dst:] = src[k_src:]
+  return dst
+
+
+def load_flat_checkpoint(spec: str, model, allow_channel_mismatch: bool = False):
+  """--checkpoint: a TensorFlow checkpoint / SavedModel directory of the reference's Keras
+  model, `random:<seed>`, or a flat fp32 array in dv_model_load_weights order."""
   if spec.startswith('random:'):
     model.init_random(seed=int(spec.split(':', 1)[1]))
     return
-  if os.path.isdir(spec) or os.path.exists(spec + '.index'):
-    raise ValueError('TensorFlow checkpoint bundles are not read here; export the weights '
-                     'to the flat layout documented in include/dvhip.h')
+  prefix = checkpoint_prefix(spec)
+  if prefix is not None:
+    flat = import_keras_checkpoint(prefix, model.input_shape[2], model.num_classes,
+                                   allow_channel_mismatch)
+    model.load_flat_weights(flat)
+    return
+  if os.path.isdir(spec):
+    raise ValueError('%s holds no checkpoint (no variables.index)' % spec)
   flat = np.load(spec) if spec.endswith('.npy') else np.fromfile(spec, np.float32)
   model.load_flat_weights(np.ascontiguousarray(flat, np.float32))
 

@@ -75,7 +75,9 @@ class InceptionV3(torch.nn.Module):
       flat[off + n + co:off + n + 2 * co] = rng.standard_normal(co) * 0.1
       flat[off + n + 2 * co:off + n + 3 * co] = rng.random(co) + 0.5
     kh, kw, ci, co, off = table[-1]
-    flat[off:off + ci * co] = rng.standard_normal(ci * co) * 0.3
+    # small head weights: the softmax must not saturate, or a parity check on these
+    # weights could not see anything
+    flat[off:off + ci * co] = rng.standard_normal(ci * co) * 0.05
     flat[off + ci * co:off + ci * co + co] = rng.standard_normal(co) * 0.1
     self.load_flat_weights(flat)
     return flat

@@ -324,9 +324,12 @@ void dv_model_destroy(dv_model* m);
 /* Number of fp32 values dv_model_load_weights expects and, per layer i of
  * dv_model_num_layers(), its slice: conv kernel HWIO (kh*kw*cin*cout) then BN
  * beta, moving_mean, moving_variance (cout each); the last layer is the Dense
- * kernel [2048, num_classes] + bias.  Layer order = tf_keras construction
- * order, i.e. checkpoint `layer_with_weights-N` order
- * (deepvariant/keras_modeling.py:176-184). */
+ * kernel [2048, num_classes] + bias.  Layer order = tf_keras CONSTRUCTION
+ * order (applications/inception_v3.py).  That is NOT the
+ * checkpoint's `layer_with_weights-N` numbering, which follows Keras'
+ * depth-sorted `model.layers`: a TensorFlow checkpoint is mapped by variable
+ * name and shape by the host importer (deepvariant_amd/keras_layout.py,
+ * call_variants.import_keras_checkpoint), never by position. */
 int64_t dv_model_num_params(const dv_model* m);
 /* Multiply-accumulates of the 94 convolutions for ONE example of the model's input
  * shape (padding taps included, as in every FLOP count of this architecture): the

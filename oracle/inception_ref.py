@@ -152,11 +152,13 @@ class InceptionV3(nn.Module):
                      self._seq(blk['bp'], _avgpool(x))], 1)
     return x.mean(dim=(2, 3))  # GlobalAveragePooling2D
 
-  def forward(self, images_u8_nhwc: torch.Tensor) -> torch.Tensor:
-    """uint8 [N,H,W,C] -> softmax probabilities fp32 [N,3]."""
+  def forward(self, images_u8_nhwc: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
+    """uint8 [N,H,W,C] -> softmax probabilities fp32 [N,3].  `channels_last` only changes
+    the memory format torch's CPU kernels work in (a speed knob of the cpu_baseline leg)."""
     x = images_u8_nhwc.to(torch.float32)
     x = (x - 128.0) / 128.0  # dv_utils.preprocess_images
-    x = x.permute(0, 3, 1, 2).contiguous()
+    x = x.permute(0, 3, 1, 2)
+    x = x.contiguous(memory_format=torch.channels_last) if channels_last else x.contiguous()
     logits = self.classification(self.features(x))  # Dropout = identity
     return torch.softmax(logits, dim=1)
 

@@ -31,7 +31,20 @@ def test_unsupported_flags_are_rejected(flags):
     cv.check_flags(_parse(*flags))
 
 
-def test_tensorflow_checkpoint_bundle_is_rejected(tmp_path):
+def test_checkpoint_argument_forms(tmp_path):
+  """--checkpoint accepts what the reference's does (a TF checkpoint prefix or a SavedModel
+  directory, call_variants.py:759-762); a directory without one and a corrupt index are
+  errors, never a silent fallback."""
+  class _Model:
+    input_shape = (100, 221, 7)
+    num_classes = 3
   (tmp_path / 'model.ckpt.index').write_bytes(b'')
-  with pytest.raises(ValueError, match='flat layout'):
-    cv.load_flat_checkpoint(str(tmp_path / 'model.ckpt'), model=None)
+  assert cv.checkpoint_prefix(str(tmp_path / 'model.ckpt')) == str(tmp_path / 'model.ckpt')
+  with pytest.raises(ValueError, match='not a checkpoint index'):
+    cv.load_flat_checkpoint(str(tmp_path / 'model.ckpt'), _Model())
+  (tmp_path / 'saved' / 'variables').mkdir(parents=True)
+  (tmp_path / 'saved' / 'variables' / 'variables.index').write_bytes(b'')
+  assert cv.checkpoint_prefix(str(tmp_path / 'saved')).endswith('variables/variables')
+  (tmp_path / 'empty').mkdir()
+  with pytest.raises(ValueError, match='holds no checkpoint'):
+    cv.load_flat_checkpoint(str(tmp_path / 'empty'), _Model())
