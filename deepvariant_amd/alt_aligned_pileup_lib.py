@@ -1,0 +1,227 @@
+"""Host side of the long-read / alt-aligned pileup path: window trimming of reads, the
+alt haplotype, and the layouts that merge a reference-aligned image with its (up to two)
+alt-aligned images.
+
+Mirrors, function by function,
+  deepvariant/alt_aligned_pileup_lib.cc:91-266   TrimCigar, TrimRead, TrimReads,
+                                                 CalculateAlignmentRegion, CalculateCigarLength
+  deepvariant/make_examples_native.cc:269-297    CreateHaplotype
+  deepvariant/make_examples_native.cc:500-512    NeedAltAlignment
+  deepvariant/pileup_image_native.cc:167-218     GetAltAlignedPileup, GetAltImageRowIndices, ...
+  deepvariant/pileup_image_native.h:214-335      FillPileupArray, FillPileupArrayBySample
+with the reference's own test vectors in tests/test_alt_aligned_pileup_lib_cpu.py.
+
+Not here (not built): RealignReadsToHaplotype -- the FastPassAligner
+(deepvariant/realigner/fast_pass_aligner.cc) that produces the alt-aligned reads.  Everything
+on both sides of it is: the trimmed reads it consumes and the image layouts its results
+are drawn into.
+
+Images are numpy uint8 [rows, width, channels] (the HWC bytes of `image/encoded`); an
+"empty" alt image is None.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from deepvariant_amd import dv_types as T
+
+K_DEFAULT_MINIMUM_READ_OVERLAP = 15   # alt_aligned_pileup_lib.h kDefaultMinimumReadOverlap
+K_REF_ALIGN_MARGIN = 20               # alt_aligned_pileup_lib.cc kRefAlignMargin
+
+# nucleus CigarUnit::Operation values (third_party/nucleus/protos/cigar.proto:38-82)
+_REF_ADVANCING = frozenset((1, 3, 4, 8, 9))    # M D N = X
+_READ_ADVANCING = frozenset((1, 2, 5, 8, 9))   # M I S = X
+
+
+def trim_cigar(cigar: Sequence, ref_start: int, ref_length: int) -> Tuple[List, int, int]:
+  """TrimCigar (alt_aligned_pileup_lib.cc:91-148) -> (new_cigar, read_start, new_read_length).
+
+  `ref_start` reference bases are skipped from the read's alignment start, then at most
+  `ref_length` reference bases are covered."""
+  trim_remaining = ref_start
+  cover_remaining = ref_length
+  read_start = 0
+  new_read_length = 0
+  out = []
+  for unit in cigar:
+    length = unit.operation_length
+    advances_ref = unit.operation in _REF_ADVANCING
+    advances_read = unit.operation in _READ_ADVANCING
+    ref_step = length if advances_ref else 0
+    if trim_remaining > 0:
+      if ref_step <= trim_remaining:       # the whole op falls into the trimmed prefix
+        trim_remaining -= ref_step
+        read_start += length if advances_read else 0
+        continue
+      ref_step -= trim_remaining           # the trim ends inside this op
+      read_start += trim_remaining if advances_read else 0
+      length = ref_step
+      trim_remaining = 0
+    if ref_step <= cover_remaining:        # the op (or what is left of it) fits the window
+      out.append(T.CigarUnit(unit.operation, length))
+      cover_remaining -= ref_step
+      new_read_length += length if advances_read else 0
+    else:                                  # the window ends inside this op
+      length = cover_remaining
+      out.append(T.CigarUnit(unit.operation, length))
+      new_read_length += length if advances_read else 0
+      break
+  return out, read_start, new_read_length
+
+
+def calculate_cigar_length(cigar: Sequence) -> int:
+  """CalculateCigarLength (:216-224): reference bases the alignment spans."""
+  return sum(u.operation_length for u in cigar if u.operation in _REF_ADVANCING)
+
+
+def trim_read(read, region_start: int, region_end: int):
+  """TrimRead (:150-216): the part of `read` aligned inside [region_start, region_end)."""
+  pos = read.alignment.position.position
+  trim_left = max(region_start - pos, 0)
+  ref_length = region_end - max(region_start, pos)
+  if ref_length <= 0:
+    raise ValueError('Check failed: ref_length > 0')                  # CHECK_GT, :156
+  cigar, read_trim, new_len = trim_cigar(read.alignment.cigar, trim_left, ref_length)
+  if read_trim + new_len > len(read.aligned_sequence) or read_trim + new_len > len(read.aligned_quality):
+    raise ValueError('Check failed: read_trim + new_read_length <= aligned_sequence.size()')
+  mods = {}
+  for spec, values in read.base_modifications.items():
+    if len(values) < read_trim + new_len:
+      raise ValueError('Check failed: base_mods.size() >= read_trim + new_read_length')
+    mods[spec] = values[read_trim:read_trim + new_len]
+  position = T.Position(read.alignment.position.reference_name,
+                        region_start if trim_left != 0 else pos,
+                        read.alignment.position.reverse_strand)
+  return T.Read(
+      fragment_name=read.fragment_name, read_number=read.read_number,
+      number_reads=read.number_reads, fragment_length=read.fragment_length,
+      proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
+      failed_vendor_quality_checks=read.failed_vendor_quality_checks,
+      secondary_alignment=read.secondary_alignment,
+      aligned_sequence=read.aligned_sequence[read_trim:read_trim + new_len],
+      aligned_quality=read.aligned_quality[read_trim:read_trim + new_len],
+      supplementary_alignment=read.supplementary_alignment,
+      alignment=T.LinearAlignment(position=position,
+                                  mapping_quality=read.alignment.mapping_quality, cigar=cigar),
+      info=dict(read.info), base_modifications=mods)
+
+
+def trim_reads(reads: Sequence, region_start: int, region_end: int,
+               min_overlap: int = K_DEFAULT_MINIMUM_READ_OVERLAP) -> Tuple[List, List[int]]:
+  """TrimReads (:231-248) -> (trimmed reads, their alignment starts BEFORE trimming: the
+  reference sorts image rows by those, pileup_image_native.cc:75-102)."""
+  out, original = [], []
+  for read in reads:
+    t = trim_read(read, region_start, region_end)
+    if calculate_cigar_length(t.alignment.cigar) >= min_overlap and t.aligned_sequence:
+      original.append(read.alignment.position.position)
+      out.append(t)
+  return out, original
+
+
+def calculate_alignment_region(variant, half_width: int, contig_n_bases: int) -> Tuple[int, int]:
+  """CalculateAlignmentRegion (:218-231): the pileup window clipped to the contig."""
+  ref_end = variant.start + len(variant.reference_bases)
+  return max(variant.start - half_width, 0), min(contig_n_bases, ref_end + half_width)
+
+
+def create_haplotype(ref_reader, variant, alt: str, half_width: int) -> Tuple[str, int, int]:
+  """CreateHaplotype (make_examples_native.cc:269-297) -> (haplotype, ref_start, ref_end):
+  reference prefix + alt + reference suffix around the variant."""
+  contig = variant.reference_name
+  var_start = variant.start
+  var_end = var_start + len(variant.reference_bases)
+  ref_start = max(var_start - half_width, 0)
+  prefix = ref_reader.get_bases(contig, ref_start, var_start) if ref_start < var_start else ''
+  ref_end = min(ref_reader.n_bases(contig), var_end + half_width)
+  suffix = ref_reader.get_bases(contig, var_end, ref_end) if ref_end > var_end else ''
+  return prefix + alt + suffix, ref_start, ref_end
+
+
+def need_alt_alignment(pic_options, variant) -> bool:
+  """NeedAltAlignment (make_examples_native.cc:500-512)."""
+  if pic_options.alt_aligned_pileup in ('none', ''):
+    return False
+  kinds = pic_options.types_to_alt_align
+  if kinds == 'all':
+    return True
+  if kinds == 'indels':
+    return len(variant.reference_bases) > 1 or any(len(a) > 1 for a in variant.alternate_bases)
+  return False
+
+
+# ------------------------------------------------------------------ image layouts
+NONE, BASE_CHANNELS, DIFF_CHANNELS, ROWS, SINGLE_ROW = 'none', 'base_channels', 'diff_channels', 'rows', 'single_row'
+_MODES = (NONE, BASE_CHANNELS, DIFF_CHANNELS, ROWS, SINGLE_ROW)
+
+
+def get_alt_aligned_pileup(name: str) -> str:
+  """GetAltAlignedPileup (pileup_image_native.cc:167-181); unknown names are fatal there."""
+  if name not in _MODES:
+    raise ValueError('Unknown value is specified for alt_aligned_pileup')
+  return name
+
+
+def get_sample_alt_aligned_pileup(global_mode: str, sample_name: str) -> str:
+  return get_alt_aligned_pileup(sample_name) if sample_name else global_mode
+
+
+def get_alt_image_row_indices(mode: str, alt_combination: Sequence[str]) -> List[int]:
+  """GetAltImageRowIndices (:193-209): which alt images become extra row blocks."""
+  if mode == ROWS:
+    return [0, 1]
+  if mode == SINGLE_ROW:
+    if len(alt_combination) == 2 and len(alt_combination[1]) > len(alt_combination[0]):
+      return [1]
+    return [0]
+  return []
+
+
+def fill_pileup_array(image: np.ndarray, alt_images: Sequence[Optional[np.ndarray]], mode: str,
+                      alt_image_row_indices: Sequence[int] = ()) -> np.ndarray:
+  """FillPileupArray (pileup_image_native.h:214-307) for one sample.
+
+  `image` is [H, W, C].  base_channels / diff_channels append two channels: channel 0
+  (read base) resp. channel 5 (base differs from ref) of alt image 1 and of alt image 2,
+  zero when alt 1 is missing and alt 1's value again when alt 2 is missing.  The alt images
+  are zipped to the reference image purely by row index.  rows / single_row append whole
+  alt images (zero blocks for missing ones) as extra rows."""
+  h, w, c = image.shape
+  if mode in (BASE_CHANNELS, DIFF_CHANNELS):
+    if len(alt_images) != 2:
+      raise ValueError('Check failed: alt_image.size() == 2')
+    ch = 5 if mode == DIFF_CHANNELS else 0
+    out = np.zeros((h, w, c + 2), np.uint8)
+    out[:, :, :c] = image
+    a1 = alt_images[0]
+    if a1 is not None and a1.size:
+      out[:, :, c] = a1[:h, :, ch]
+    a2 = alt_images[1]
+    out[:, :, c + 1] = a2[:h, :, ch] if a2 is not None and a2.size else out[:, :, c]
+    blocks = [out]
+  else:
+    blocks = [image]
+  for k in alt_image_row_indices:
+    alt = alt_images[k]
+    blocks.append(np.zeros_like(image) if alt is None or not alt.size else alt)
+  if len(blocks) == 1:
+    return blocks[0]
+  if any(b.shape[1:] != blocks[0].shape[1:] for b in blocks):
+    raise ValueError('alt-aligned row blocks need the reference image\'s width and channels')
+  return np.concatenate(blocks, axis=0)
+
+
+def fill_pileup_array_by_sample(images: Sequence[np.ndarray],
+                                alt_images: Sequence[Sequence[Optional[np.ndarray]]],
+                                options, alt_combination: Sequence[str]) -> np.ndarray:
+  """FillPileupArrayBySample (:311-335): samples stacked top to bottom, each with its own
+  (or the global) alt-aligned representation."""
+  mode = get_alt_aligned_pileup(options.pic_options.alt_aligned_pileup or NONE)
+  parts = []
+  for s, so in enumerate(options.sample_options):
+    rows = get_alt_image_row_indices(
+        get_sample_alt_aligned_pileup(mode, so.alt_aligned_pileup), alt_combination)
+    parts.append(fill_pileup_array(images[s], alt_images[s], mode, rows))
+  return np.concatenate(parts, axis=0)

@@ -75,9 +75,12 @@ class InceptionV3(torch.nn.Module):
       flat[off + n + co:off + n + 2 * co] = rng.standard_normal(co) * 0.1
       flat[off + n + 2 * co:off + n + 3 * co] = rng.random(co) + 0.5
     kh, kw, ci, co, off = table[-1]
-    # small head weights: the softmax must not saturate, or a parity check on these
-    # weights could not see anything
-    flat[off:off + ci * co] = rng.standard_normal(ci * co) * 0.05
+    # small, column-centred head weights: post-ReLU features are all positive, so random
+    # columns would put class-dependent offsets of several units on the logits and the
+    # softmax would saturate -- a parity check on saturated outputs sees nothing
+    dense = rng.standard_normal((ci, co)) * 0.02
+    dense -= dense.mean(axis=0, keepdims=True)
+    flat[off:off + ci * co] = dense.reshape(-1)
     flat[off + ci * co:off + ci * co + co] = rng.standard_normal(co) * 0.1
     self.load_flat_weights(flat)
     return flat

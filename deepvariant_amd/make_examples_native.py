@@ -147,8 +147,6 @@ class ExamplesGenerator:
       raise NotImplementedError(
           "alt_aligned_pileup=%r needs the FastPassAligner (not built yet)" %
           pic.alt_aligned_pileup)
-    if getattr(options, 'trim_reads_for_pileup', False):
-      raise NotImplementedError('trim_reads_for_pileup is not supported yet')
     if getattr(options, 'stream_examples', False):
       raise NotImplementedError('stream_examples is not supported yet')
     self._encoder_api = PileupImageEncoderNative(pic, device=device)
@@ -158,8 +156,6 @@ class ExamplesGenerator:
     for so in options.sample_options:
       if so.alt_aligned_pileup not in ('', 'none'):
         raise NotImplementedError('per-sample alt_aligned_pileup')
-      if so.keep_only_window_spanning_reads:
-        raise NotImplementedError('keep_only_window_spanning_reads')
       if so.use_non_uniform_downsampling:
         raise NotImplementedError('use_non_uniform_downsampling')
     self._height = calculate_pileup_image_height(options)
@@ -200,7 +196,7 @@ class ExamplesGenerator:
     stats: Dict[str, int] = {}
     examples, image_shape = self.encode_region(
         candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
-        stats)
+        stats, role=role)
     writer = self._writers[role]
     for ex in examples:
       writer.write(ex)
@@ -208,7 +204,44 @@ class ExamplesGenerator:
     return stats, image_shape
 
   # --------------------------------------------------------------- internals
-  def _plan_region(self, candidates, reads_per_sample, sample_order, mean_coverage_per_sample):
+  def _trim_region_reads(self, candidates, reads_per_sample, sample_order, tables):
+    """trim_reads_for_pileup / keep_only_window_spanning_reads
+    (make_examples_native.cc:655-685): every candidate gets ITS OWN copies of the reads it
+    overlaps, cut to the pileup window (TrimReads), rows still sorted by the untrimmed
+    starts.  -> (per-sample read tables of the trimmed copies, {(candidate, sample): index
+    range})."""
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    pic = self._options.pic_options
+    trimmed = [[] for _ in reads_per_sample]
+    starts = [[] for _ in reads_per_sample]
+    ranges = {}
+    for ci, cand in enumerate(candidates):
+      variant = cand.variant
+      if not get_reference_bases_for_pileup(self._ref, variant, pic.width):
+        continue
+      q0 = variant.start - pic.read_overlap_buffer_bp
+      q1 = variant.end + pic.read_overlap_buffer_bp
+      r0, r1 = aap.calculate_alignment_region(variant, self._half_width,
+                                              self._ref.n_bases(variant.reference_name))
+      for s in sample_order:
+        so = self._options.sample_options[s]
+        if isinstance(reads_per_sample[s], packing.ReadTable):
+          raise NotImplementedError('trim_reads_for_pileup needs Read objects, not a packed table')
+        min_overlap = pic.width if so.keep_only_window_spanning_reads \
+            else aap.K_DEFAULT_MINIMUM_READ_OVERLAP
+        overlapping = [reads_per_sample[s][int(k)] for k in tables[s].query(q0, q1)]
+        kept, original = aap.trim_reads(overlapping, r0, r1, min_overlap)
+        lo = len(trimmed[s])
+        trimmed[s].extend(kept)
+        starts[s].extend(original)
+        ranges[(ci, s)] = (lo, lo + len(kept))
+    new_tables = [packing.ReadTable.from_reads(
+        trimmed[s], alignment_positions=starts[s] or None, need_aux=self._encoder_api._need_aux,
+        need_seq_aux=self._encoder_api._need_seq_aux) for s in range(len(reads_per_sample))]
+    return new_tables, ranges
+
+  def _plan_region(self, candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
+                   role=None):
     """-> (PackedBatch, [(candidate index, alt combination)], image_shape): everything
     CreateAndWriteExamplesForCandidate decides before pixels are drawn."""
     pic = self._options.pic_options
@@ -233,6 +266,18 @@ class ExamplesGenerator:
       else:
         tables.append(packing.ReadTable.from_reads(reads, need_aux=self._encoder_api._need_aux,
                                                    need_seq_aux=self._encoder_api._need_seq_aux))
+    role_sample = self._samples.get(role) if role is not None else \
+        self._options.sample_options[sample_order[0]]
+    use_trimmed = bool(getattr(self._options, 'trim_reads_for_pileup', False) or
+                       role_sample.keep_only_window_spanning_reads)
+    trim_ranges = None
+    if use_trimmed:
+      tables, trim_ranges = self._trim_region_reads(candidates, reads_per_sample, sample_order,
+                                                    tables)
+      if any(t.read_sort_pos is None for t in tables):   # a sample without reads at all
+        for t in tables:
+          if t.read_sort_pos is None:
+            t.read_sort_pos = t.read_pos.copy()
     merged, sample_base = _concat_tables(tables)
     batch = packing.PackedBatch(table=merged, width=width,
                                 use_ref_aux=self._encoder_api._need_ref_aux)
@@ -251,7 +296,10 @@ class ExamplesGenerator:
         for s in sample_order:
           so = self._options.sample_options[s]
           table = tables[s]
-          idx_local = table.query(q0, q1)
+          if trim_ranges is not None:
+            idx_local = np.arange(*trim_ranges[(ci, s)], dtype=np.int64)
+          else:
+            idx_local = table.query(q0, q1)
           blank = list(so.channels_enum_to_blank)
           if vtype in _types_to_blank(so):
             blank = list(T.DeepVariantChannelEnum)
@@ -270,10 +318,10 @@ class ExamplesGenerator:
     return batch, plan, image_shape
 
   def encode_region(self, candidates, reads_per_sample, sample_order,
-                    mean_coverage_per_sample, stats) -> Tuple[List[bytes], List[int]]:
+                    mean_coverage_per_sample, stats, role=None) -> Tuple[List[bytes], List[int]]:
     """All examples of one region: one packed batch, one kernel launch."""
     batch, plan, image_shape = self._plan_region(candidates, reads_per_sample, sample_order,
-                                                 mean_coverage_per_sample)
+                                                 mean_coverage_per_sample, role)
     pic = self._options.pic_options
     n_chan_total = len(pic.channels)
     example_bytes = self._height * pic.width * n_chan_total

@@ -41,10 +41,10 @@ def _query(reads, start, end):
   return [r for r in reads if end > r.alignment.position.position and start < _read_end(r)]
 
 
-def _region_reads(rng, n, lo, hi, tag):
+def _region_reads(rng, n, lo, hi, tag, max_ops=5):
   reads = []
   for i in range(n):
-    cigar = F.random_cigar(rng, 1, 5)
+    cigar = F.random_cigar(rng, 1, max_ops)
     if F.query_len(cigar) == 0:
       cigar.append(T.CigarUnit(1, 1))
     qlen = F.query_len(cigar)
@@ -121,3 +121,54 @@ def test_two_samples_many_candidates_one_launch(sort_by_support):
                                     err_msg='candidate at %d, alts %s' % (v.start, combo))
   assert k == len(examples) == stats['n_examples'] and k >= len(cands)
   assert deep_items >= len(cands)      # the shuffle path ran for (at least) every parent image
+
+
+def test_trim_reads_for_pileup_long_reads():
+  """trim_reads_for_pileup (the long-read configs: deepvariant/json/deepvariant.pacbio.*
+  `trim_reads_for_pileup: true`): every candidate draws window-trimmed copies of its reads
+  (TrimReads, deepvariant/alt_aligned_pileup_lib.cc:231-248), reads overlapping the window
+  by less than 15 bp vanish, rows stay sorted by the UNTRIMMED starts
+  (make_examples_native.cc:672-697).  The oracle is fed the trimmed proto-shaped reads per
+  candidate; the trimming itself is pinned by the reference's vectors in
+  tests/test_alt_aligned_pileup_lib_cpu.py."""
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from oracle import oracle as O
+  rng = np.random.default_rng(77)
+  width = 61
+  hw = (width - 1) // 2
+  pic = F.options(T.PILEUP_DEFAULT_CHANNELS + ['haplotype'], width, 50, sort_by_haplotypes=True,
+                  min_mapq=1)
+  options = T.MakeExamplesOptions(
+      pic_options=pic, trim_reads_for_pileup=True,
+      sample_options=[T.SampleOptions(role='main', name='m', pileup_height=50)])
+  ref = _Ref(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000)))
+  reads = _region_reads(rng, 260, 500, 2600, 'r', max_ops=40)       # up to ~1 kb alignments
+  for r in reads:
+    if rng.random() < 0.6:
+      r.info['HP'] = T.ListValue(values=[T.Value(int_value=int(rng.integers(0, 3)))])
+  cands = []
+  for pos in sorted(set(rng.integers(1200, 2400, size=22).tolist())):
+    refb = ref.seq[pos]
+    alts = [b for b in 'ACGT' if b != refb][:1]
+    cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + 1, refb, alts),
+                                   allele_support={}))
+  gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=ref)
+  stats = {}
+  examples, shape = gen.encode_region(cands, [reads], [0], [0.0], stats, role='main')
+  assert len(examples) == len(cands)
+  dropped = moved = 0
+  for cand, ex in zip(cands, examples):
+    v = cand.variant
+    img = np.frombuffer(pw.decode_example(ex)['image/encoded'][0], np.uint8).reshape(shape)
+    overlapping = _query(reads, v.start - 5, v.end + 5)
+    r0, r1 = A.calculate_alignment_region(v, hw, len(ref.seq))
+    kept, original = A.trim_reads(overlapping, r0, r1)
+    dropped += len(overlapping) - len(kept)
+    moved += sum(1 for k, o in zip(kept, original) if k.alignment.position.position != o)
+    want = O.build_pileup(pic, cand, men.get_reference_bases_for_pileup(ref, v, width), kept,
+                          v.start - hw, list(v.alternate_bases), pileup_height=50,
+                          alignment_positions=original)
+    np.testing.assert_array_equal(img, want, err_msg='candidate at %d' % v.start)
+  assert moved > 50          # the trimming did cut reads (their starts moved to the window)
