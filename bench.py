@@ -41,6 +41,11 @@ def parse_args():
                   help='candidate sites per step per GPU; ~5 % more pileups (multi-allelic '
                        'sites give 3) -- 7700 sites fill one 8192-example forward')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
+  ap.add_argument('--mode', choices=['resident', 'host'], default='resident',
+                  help="'resident' (default, the contract's metric): inputs already in HBM. "
+                       "'host': host-inclusive -- every step packs the region's candidates and "
+                       'reads natively (dv_pack_region), uploads them over PCIe and runs the GPU '
+                       'path, double buffered (deepvariant_amd/host_pipeline.py); 1 GPU only')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample', type=int, default=0,
                   help='candidates in the CPU-baseline sample (0 = auto)')
@@ -176,6 +181,12 @@ def run_rank(args, rank, local_rank, world):
   work = torch.cuda.Stream(device=dev)
   torch.cuda.set_stream(work)
 
+  if args.mode == 'host':
+    if world != 1:
+      raise SystemExit('--mode host runs on one GPU')
+    host_inclusive(args, host_batch, opts, C, enc, model, dev)
+    return
+
   def local_step():
     dbatch.encode(enc, C, images, rows)
     return model(images)
@@ -282,6 +293,51 @@ def run_rank(args, rank, local_rank, world):
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def host_inclusive(args, host_batch, opts, C, enc, model, dev):
+  """Candidates/s INCLUDING the host: per step the region's candidates + read table are
+  packed natively (dv_pack_region: per-candidate read query, support codes from read-name
+  lists), staged into pinned memory, uploaded over PCIe (reads included -- a new region
+  brings new reads) and encoded + classified on the GPU; packing/upload of step k+1 overlap
+  the GPU work of step k.  Not the contract's `value` (inputs resident in HBM)."""
+  from deepvariant_amd import host_pipeline as hp, synth
+  H, W = opts.height, opts.width
+  table, cands, combos, windows = synth.region_inputs_from_batch(host_batch, opts)
+  inputs = hp.RegionInputs(table, cands, combos, windows, W, opts.read_overlap_buffer_bp, H, H * W * C)
+  pipe = hp.HostPipeline(inputs, enc, model, C, dev, (H, W, C))
+  pipe.run(max(args.warmup, 2))
+  torch.cuda.synchronize(dev)
+  pipe.pack_seconds = pipe.stage_seconds = 0.0
+  t0 = time.perf_counter()
+  probs = pipe.run(args.steps)
+  torch.cuda.synchronize(dev)
+  elapsed = time.perf_counter() - t0
+  n_items = pipe.slots[0].n_items
+  assert torch.isfinite(probs).all() and probs.shape[0] == n_items
+  upload_bytes = sum(int(x.numel()) for x in pipe.slots[0].pinned.values())
+  print(json.dumps({
+      'metric': 'candidate pileups/sec (host packing + PCIe + encode + CNN)',
+      'value': n_items * args.steps / elapsed,
+      'unit': 'candidates/s',
+      'n_gpus': 1,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': 1e3 * elapsed / args.steps,
+      'higher_is_better': True,
+      'data': 'synthetic',
+      'config': {
+          'workload': 'the resident-mode workload (synthetic 30x Illumina, 100x%dx%d) handed over '
+                      'in region form: read table with names + candidates with allele_support '
+                      'read-name lists' % (W, C),
+          'candidates_per_step': n_items,
+          'reads_per_step': int(table.n_reads),
+          'host_threads': 'one packer thread + the launching thread',
+      },
+      'pack_ms_per_step': 1e3 * pipe.pack_seconds / args.steps,
+      'staging_ms_per_step': 1e3 * pipe.stage_seconds / args.steps,
+      'upload_bytes_per_step': upload_bytes,
+  }))
 
 
 def parity_sample(host_batch, opts, C, model, images, probs, n=64):

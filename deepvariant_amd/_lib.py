@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     'dv_last_profile_count',
     'dv_bam_read_region', 'dv_read_table_fill_batch', 'dv_read_table_name',
     'dv_read_table_names', 'dv_read_table_ends', 'dv_read_table_free',
+    'dv_pack_region', 'dv_packed_region_fill_batch', 'dv_packed_region_items',
+    'dv_packed_region_free',
 ]
 
 
@@ -113,6 +115,22 @@ class DvReadRequirements(C.Structure):
               ('min_mapping_quality', C.c_int32)]
 
 
+class DvPackReads(C.Structure):
+  _fields_ = [('n_reads', C.c_int32), ('read_pos', C.c_void_p), ('read_end', C.c_void_p),
+              ('names', C.c_void_p), ('name_off', C.c_void_p), ('read_number', C.c_void_p)]
+
+
+class DvPackOptions(C.Structure):
+  _fields_ = [('width', C.c_int32), ('read_overlap_buffer_bp', C.c_int32),
+              ('pileup_height', C.c_int32), ('example_bytes', C.c_uint64)]
+
+
+class DvPackCandidate(C.Structure):
+  _fields_ = [('start', C.c_int64), ('end', C.c_int64), ('n_alts', C.c_int32),
+              ('ref_idx', C.c_int32), ('first_combo', C.c_uint32), ('n_combos', C.c_uint32),
+              ('first_support', C.c_uint32), ('n_support', C.c_uint32)]
+
+
 class DvModelDesc(C.Structure):
   _fields_ = [('height', C.c_int32), ('width', C.c_int32),
               ('channels', C.c_int32), ('num_classes', C.c_int32),
@@ -174,6 +192,10 @@ def lib():
     l.dv_read_table_name.restype = C.c_char_p
     l.dv_read_table_name.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     l.dv_read_table_names.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    l.dv_pack_region.argtypes = [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+    l.dv_packed_region_fill_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    l.dv_packed_region_items.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_packed_region_free.argtypes = [C.c_void_p]
     l.dv_read_table_ends.restype = C.c_void_p
     l.dv_read_table_ends.argtypes = [C.c_void_p]
     l.dv_read_table_free.argtypes = [C.c_void_p]

@@ -278,6 +278,23 @@ class ExamplesGenerator:
         for t in tables:
           if t.read_sort_pos is None:
             t.read_sort_pos = t.read_pos.copy()
+    # Fast path: one sample, nothing per-item beyond the read list -- the whole region is
+    # packed by libdvhip's dv_pack_region (region_packer.cpp) instead of the per-candidate
+    # Python below (DV_PY_PACKER=1 keeps the Python path; tests compare the two).
+    if (trim_ranges is None and len(sample_order) == 1 and len(tables) == 1 and
+        not self._encoder_api._need_list_aux and os.environ.get('DV_PY_PACKER') is None):
+      so = self._options.sample_options[sample_order[0]]
+      if not so.channels_enum_to_blank and not so.variant_types_to_blank:
+        windows = [get_reference_bases_for_pileup(self._ref, c.variant, width) for c in candidates]
+        combos = [list(alt_allele_combinations(c, pic.multi_allelic_mode)) if w else []
+                  for c, w in zip(candidates, windows)]
+        batch, plan = packing.pack_region_native(
+            tables[0], candidates, combos, windows, width, pic.read_overlap_buffer_bp,
+            so.pileup_height, example_bytes, use_groups=bool(pic.sort_by_alt_allele_support))
+        batch.use_ref_aux = self._encoder_api._need_ref_aux
+        mc = float(mean_coverage_per_sample[sample_order[0]])
+        batch.item_mean_coverage = [mc] * batch.n_items
+        return batch, plan, image_shape
     merged, sample_base = _concat_tables(tables)
     batch = packing.PackedBatch(table=merged, width=width,
                                 use_ref_aux=self._encoder_api._need_ref_aux)

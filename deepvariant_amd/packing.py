@@ -408,6 +408,119 @@ def allele_frequency_pixels(pic_options, dv_call, alt_alleles, table, read_idx
   return out
 
 
+def _native_names(table: 'ReadTable'):
+  """(names blob, offsets, read numbers) of a table's keys, cached on the table."""
+  cached = table.__dict__.get('_names_cache')
+  if cached is None:
+    names, nums = [], np.zeros(table.n_reads, np.uint8)
+    for i, k in enumerate(table.keys):
+      name, num = k.rsplit('/', 1)
+      names.append(name.encode())
+      nums[i] = int(num)
+    lens = np.array([len(x) + 1 for x in names], np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32) if names \
+        else np.zeros(0, np.uint32)
+    blob = np.frombuffer(b'\0'.join(names) + b'\0', np.uint8).copy() if names \
+        else np.zeros(1, np.uint8)
+    cached = (blob, offs, nums)
+    table.__dict__['_names_cache'] = cached
+  return cached
+
+
+def pack_region_native(table: 'ReadTable', candidates: Sequence, combos: Sequence[Sequence[Sequence[str]]],
+                       ref_windows: Sequence[Optional[str]], width: int,
+                       read_overlap_buffer_bp: int, pileup_height: int, example_bytes: int,
+                       use_groups: bool = False):
+  """dv_pack_region (include/dvhip.h): the per-candidate Query, the item per alt
+  combination and the support codes / allele groups of a whole region in one native call.
+
+  candidates[i] is a DeepVariantCall, combos[i] its alt combinations (lists of alleles,
+  make_examples_native.alt_allele_combinations), ref_windows[i] its reference bases for the
+  pileup ('' / None = contig edge, candidate skipped).  -> (PackedBatch, [(candidate index,
+  alt combination)]) exactly like ExamplesGenerator._plan_region's Python path."""
+  import ctypes as C
+  lib = _lib.lib()
+  blob, offs, nums = _native_names(table)
+  read_pos = np.ascontiguousarray(table.read_pos, np.int32)
+  read_end = np.ascontiguousarray(table.read_end, np.int64)
+  reads = _lib.DvPackReads(table.n_reads, read_pos.ctypes.data, read_end.ctypes.data,
+                           blob.ctypes.data, offs.ctypes.data if offs.size else None,
+                           nums.ctypes.data if nums.size else None)
+  opt = _lib.DvPackOptions(int(width), int(read_overlap_buffer_bp), int(pileup_height),
+                           int(example_bytes))
+  n = len(candidates)
+  cands = (_lib.DvPackCandidate * max(n, 1))()
+  masks: List[int] = []
+  keys: List[bytes] = []
+  alts_of: List[int] = []
+  batch = PackedBatch(table=table, width=width)
+  for i, cand in enumerate(candidates):
+    v = cand.variant
+    alts = list(v.alternate_bases)
+    c = cands[i]
+    c.start, c.end, c.n_alts = int(v.start), int(v.end), len(alts)
+    c.ref_idx = batch.add_ref_window(ref_windows[i]) if ref_windows[i] else -1
+    c.first_combo, c.n_combos = len(masks), len(combos[i])
+    for combo in combos[i]:
+      m = 0
+      for a in combo:
+        m |= 1 << alts.index(a)
+      masks.append(m)
+    c.first_support = len(keys)
+    for ai, alt in enumerate(alts):
+      if alt in cand.allele_support:
+        for name in cand.allele_support[alt].read_names:
+          keys.append(name.encode())
+          alts_of.append(ai)
+    c.n_support = len(keys) - c.first_support
+  mask_arr = np.array(masks or [0], np.uint32)
+  key_lens = np.array([len(k) + 1 for k in keys], np.int64)
+  key_off = (np.concatenate([[0], np.cumsum(key_lens)[:-1]]).astype(np.uint32) if keys
+             else np.zeros(1, np.uint32))
+  key_blob = np.frombuffer(b'\0'.join(keys) + b'\0', np.uint8).copy()
+  alt_arr = np.array(alts_of or [0], np.uint8)
+  handle = C.c_void_p()
+  _lib.check(lib.dv_pack_region(C.byref(reads), C.byref(opt), n, cands, mask_arr.ctypes.data,
+                                key_blob.ctypes.data, key_off.ctypes.data, alt_arr.ctypes.data,
+                                C.byref(handle)))
+  try:
+    b = _lib.DvBatch()
+    _lib.check(lib.dv_packed_region_fill_batch(handle, int(use_groups), C.byref(b)))
+    ic, im = C.c_void_p(), C.c_void_p()
+    n_items = lib.dv_packed_region_items(handle, C.byref(ic), C.byref(im))
+
+    def arr(ptr, dtype, count):
+      if not count:
+        return np.zeros(0, dtype)
+      buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+      return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+    off = arr(b.item_list_off, np.uint32, n_items + 1)
+    batch.item_variant_start = arr(b.item_variant_start, np.int32, n_items).tolist()
+    batch.item_image_start = arr(b.item_image_start, np.int32, n_items).tolist()
+    batch.item_ref_idx = arr(b.item_ref_idx, np.uint32, n_items).tolist()
+    batch.item_height = arr(b.item_height, np.uint16, n_items).tolist()
+    batch.item_out_off = arr(b.item_out_off, np.uint64, n_items).tolist()
+    batch.item_blank_mask = [0] * n_items
+    batch.item_mean_coverage = [0.0] * n_items
+    batch.item_list_off = off.tolist() if n_items else [0]
+    batch.list_read_chunks = [arr(b.list_read, np.uint32, b.n_list)]
+    batch.list_code_chunks = [arr(b.list_code, np.uint8, b.n_list)]
+    batch.list_group_chunks = [arr(b.list_group, np.uint8, b.n_list) if use_groups
+                               else np.zeros(b.n_list, np.uint8)]
+    batch.list_aux_chunks = [np.zeros(b.n_list, np.uint8)]
+    batch.use_groups = bool(use_groups)
+    item_cand = arr(ic.value, np.int32, n_items)
+    item_mask = arr(im.value, np.uint32, n_items)
+  finally:
+    lib.dv_packed_region_free(handle)
+  plan = []
+  for ci, m in zip(item_cand.tolist(), item_mask.tolist()):
+    alts = list(candidates[ci].variant.alternate_bases)
+    plan.append((ci, [a for k, a in enumerate(alts) if (m >> k) & 1]))
+  return batch, plan
+
+
 @dataclasses.dataclass
 class PackedBatch:
   """Host image of `dv_batch` (numpy arrays), plus the ctypes view."""
@@ -435,7 +548,7 @@ class PackedBatch:
   def add_ref_window(self, ref_bases: str) -> int:
     if len(ref_bases) != self.width:
       raise ValueError('ref_bases.size() != width')  # pileup_image_native.cc:308
-    self.ref_windows_list.append(ref_bases.encode())
+    self.ref_windows_list.append(ref_bases.encode() if isinstance(ref_bases, str) else bytes(ref_bases))
     return len(self.ref_windows_list) - 1
 
   def add_item(self, variant_start: int, image_start: int, ref_idx: int,

@@ -342,3 +342,39 @@ def make_longread_batch(n_candidates: int, kind: str = 'hifi', seed: int = SEED,
                    np.arange(lo, hi, dtype=np.uint32), allele_of[lo:hi], height=H,
                    out_off=i * H * W * C)
   return batch
+
+
+def region_inputs_from_batch(batch: packing.PackedBatch, options):
+  """The same synthetic workload in REGION form -- a read table with read names plus
+  DeepVariantCall-shaped candidates with `allele_support` read-name lists -- i.e. what
+  make_examples hands to ExamplesGenerator before any packing.  Used by the host-inclusive
+  bench mode and the native packer's tests.  (Reads the generator tagged "other alt" at
+  bi-allelic sites become plain non-supporting reads: one alt allele cannot list them.)
+  -> (table, candidates, alt combinations per candidate, reference windows per candidate)"""
+  t = batch.table
+  table = packing.ReadTable(**{f.name: getattr(t, f.name) for f in
+                               __import__('dataclasses').fields(packing.ReadTable)})
+  table.keys = ['r%d/0' % i for i in range(t.n_reads)]
+  starts = np.asarray(batch.item_variant_start)
+  off = np.asarray(batch.item_list_off)
+  lr, lc = np.asarray(batch.list_read), np.asarray(batch.list_code)
+  wins = batch.ref_windows_list
+  cands, combos, windows = [], [], []
+  i, n = 0, batch.n_items
+  while i < n:
+    k = 1
+    while i + k < n and starts[i + k] == starts[i]:
+      k += 1
+    reads = lr[off[i]:off[i + 1]]
+    codes = lc[off[i]:off[i + 1]]
+    alts = ['C', 'G'] if k == 3 else ['C']
+    support = {'C': T.SupportingReads([table.keys[int(r)] for r in reads[codes == 1]])}
+    if k == 3:
+      support['G'] = T.SupportingReads([table.keys[int(r)] for r in reads[codes == 2]])
+    pos = int(starts[i])
+    cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + 1, 'A', alts),
+                                   allele_support=support))
+    combos.append([['C'], ['G'], ['C', 'G']] if k == 3 else [['C']])
+    windows.append(wins[batch.item_ref_idx[i]])
+    i += k
+  return table, cands, combos, windows

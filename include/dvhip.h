@@ -300,6 +300,58 @@ int dv_read_table_names(const dv_read_table* t, const char** blob, const uint32_
 const int64_t* dv_read_table_ends(const dv_read_table* t);
 void dv_read_table_free(dv_read_table* t);
 
+/* ---- candidates + region reads -> item / list arrays (host only) -------------
+ * Replaces the per-candidate decisions of ExamplesGenerator::
+ * CreateAndWriteExamplesForCandidate that precede the pixels
+ * (deepvariant/make_examples_native.cc:632-736): InMemoryReader::Query per
+ * candidate (:645-648,802-810), one item per alt-allele combination (:191-267),
+ * and per (item, read) the ReadSupportsAlt code
+ * (deepvariant/channels/read_supports_variant_channel.cc:54-116) and allele group
+ * (deepvariant/pileup_image_native.cc:346-393) from DeepVariantCall.allele_support.
+ * Single sample; multi-sample stacking stays with the host mirror. */
+typedef struct dv_pack_reads {
+  int32_t n_reads;
+  const int32_t* read_pos;     /* alignment start */
+  const int64_t* read_end;     /* exclusive reference end (dv_read_table_ends) */
+  const char* names;           /* NUL-terminated fragment names, concatenated */
+  const uint32_t* name_off;    /* [n_reads] offset of each name in `names` */
+  const uint8_t* read_number;  /* [n_reads] 0 / 1: the key is "<name>/<read_number>" */
+} dv_pack_reads;
+
+typedef struct dv_pack_options {
+  int32_t width;                   /* pic_options.width: image_start = variant.start - (width-1)/2 */
+  int32_t read_overlap_buffer_bp;  /* pic_options.read_overlap_buffer_bp (5) */
+  int32_t pileup_height;           /* sample_options.pileup_height */
+  uint64_t example_bytes;          /* bytes of one example: item k is written at k * example_bytes */
+} dv_pack_options;
+
+typedef struct dv_pack_candidate {
+  int64_t start, end;       /* variant.start, variant.end */
+  int32_t n_alts;           /* variant.alternate_bases_size (<= 32) */
+  int32_t ref_idx;          /* index of its reference window in the batch's ref_windows; < 0 = none
+                               (contig edge): the candidate is skipped like the reference does */
+  uint32_t first_combo, n_combos;      /* slice of combo_masks: bit i = alternate_bases[i] is in the combination */
+  uint32_t first_support, n_support;   /* slice of the support arrays */
+} dv_pack_candidate;
+
+typedef struct dv_packed_region dv_packed_region; /* owns the item / list arrays */
+
+/* support_keys: NUL-terminated "<fragment_name>/<read_number>" strings (allele_support
+ * read_names), support_key_off[j] the offset of entry j, support_alt[j] the index in
+ * alternate_bases of the allele that lists it. */
+int dv_pack_region(const dv_pack_reads* reads, const dv_pack_options* opt, int32_t n_candidates,
+                   const dv_pack_candidate* cands, const uint32_t* combo_masks,
+                   const char* support_keys, const uint32_t* support_key_off,
+                   const uint8_t* support_alt, dv_packed_region** out);
+/* Points the item / list fields of `b` (n_items, n_list, max_list_len, item_*, list_read,
+ * list_code, list_group iff use_groups) at the packed arrays; read-table, reference-window
+ * and per-item option fields (blank mask, mean coverage) are the caller's. */
+int dv_packed_region_fill_batch(const dv_packed_region* p, int use_groups, dv_batch* b);
+/* Which (candidate, combination mask) each item is; returns the item count. */
+int dv_packed_region_items(const dv_packed_region* p, const int32_t** item_candidate,
+                           const uint32_t** item_combo);
+void dv_packed_region_free(dv_packed_region* p);
+
 /* CRC32C (Castagnoli) as used by TFRecord framing
  * (third_party/nucleus/io/example_writer.cc:88-104 via tensorflow::io::RecordWriter). */
 uint32_t dv_crc32c(const uint8_t* data, size_t n);
