@@ -14,6 +14,8 @@
 //     the DMA of step i+1 -- the next tile's first step included -- is in flight while step
 //     i multiplies; one s_barrier per step, no wave ever waits on a register load.
 // A step = KC channel chunks x all taps (KC = 1 for filters with taps, 4 for 1x1).
+#include <cstdlib>
+
 #include "imgconv.h"
 
 namespace dv {
@@ -28,7 +30,23 @@ constexpr int IC_MAXA = 8;                     // activation DMA rounds per step
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int KH, int KW, int KC, int NB>
+// s_waitcnt needs an immediate: at most `n` of this wave's vector-memory operations may still
+// be in flight (they complete in issue order), then the workgroup barrier -- one statement, so
+// that neither LDS reads nor later DMAs can move across it.
+__device__ __forceinline__ void wait_dma_and_barrier(int n) {
+#define DV_CASE(k_) case k_: asm volatile("s_waitcnt vmcnt(" #k_ ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  switch (n) {
+    DV_CASE(1) DV_CASE(2) DV_CASE(3) DV_CASE(4) DV_CASE(5) DV_CASE(6) DV_CASE(7) DV_CASE(8)
+    DV_CASE(9) DV_CASE(10) DV_CASE(11) DV_CASE(12) DV_CASE(13) DV_CASE(14) DV_CASE(15) DV_CASE(16)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+#undef DV_CASE
+}
+
+// R = LDS ring depth: the DMA of step i + R - 1 is issued while step i multiplies.  R = 2
+// gives a DMA one step (~3.5 k cycles) of lead, less than an HBM round trip under load
+// (measured ~5 k cycles): every step then waits.  R = 3 is used wherever three slabs fit.
+template <int KH, int KW, int KC, int NB, int R>
 __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
   constexpr int TAPS = KH * KW, S = KC * TAPS, BN = NB * 32, PT = IC_PT;
   constexpr int W_SLAB = S * 2 * BN * 16;      // bytes: [kc][tap][k-group][BN couts][8 halfs]
@@ -39,7 +57,7 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned act_bytes = static_cast<unsigned>(p.act_slab_bytes);
-  const unsigned w_lds0 = 2 * act_bytes;
+  const unsigned w_lds0 = R * act_bytes;
 
   // ---- per-lane constants ---------------------------------------------------------------
   const ConvArgs& c = p.c;
@@ -130,100 +148,148 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
     }
   };
 
-  int item = blockIdx.x;
-  if (item >= total) return;
-  int n0 = first_image(item), ct = item % p.n_cout_tiles;
-  unsigned slot = 0;
-  {
-    const __amdgpu_buffer_rsrc_t ra = act_desc(n0, 0), rw = w_desc(ct, 0);
+  // the (item, K step) sequence of this workgroup as ONE stream of steps
+  struct Pos {
+    int item, st, n0, ct;
+  };
+  auto advance = [&](Pos q) {
+    if (q.st + 1 < p.n_steps) {
+      ++q.st;
+      return q;
+    }
+    q.item += gridDim.x;
+    q.st = 0;
+    if (q.item < total) {
+      q.n0 = first_image(q.item);
+      q.ct = q.item % p.n_cout_tiles;
+    }
+    return q;
+  };
+  auto issue_all = [&](const Pos& q, unsigned slot) {
+    const __amdgpu_buffer_rsrc_t ra = act_desc(q.n0, q.st), rw = w_desc(q.ct, q.st);
 #pragma unroll
-    for (int j = 0; j < J; ++j) issue_one(j, ra, rw, 0);
+    for (int j = 0; j < J; ++j) issue_one(j, ra, rw, slot);
+  };
+  int my_dmas = 0;  // DMA instructions this wave issues per step (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const unsigned piece0 = static_cast<unsigned>(((j < IC_MAXA ? j : j - IC_MAXA) * IC_WAVES + wave) * 1024);
+    my_dmas += (j < IC_MAXA ? piece0 < act_bytes : piece0 < static_cast<unsigned>(W_SLAB)) ? 1 : 0;
   }
+
+  my_dmas = __builtin_amdgcn_readfirstlane(my_dmas);
+
+  Pos cur{static_cast<int>(blockIdx.x), 0, 0, 0};
+  if (cur.item >= total) return;
+  cur.n0 = first_image(cur.item);
+  cur.ct = cur.item % p.n_cout_tiles;
+  Pos ahead = cur;
+  unsigned slot = 0;
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k) {  // steps 0 .. R-2 start their trip before the loop
+    if (ahead.item < total) issue_all(ahead, k);
+    ahead = advance(ahead);
+  }
+  float16_t acc[NB][PT];
   for (;;) {
-    float16_t acc[NB][PT];
+    if (cur.st == 0) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
-    const int item_n = item + gridDim.x;
-    const int n0_n = item_n < total ? first_image(item_n) : 0;
-    const int ct_n = item_n < total ? item_n % p.n_cout_tiles : 0;
-    for (int st = 0; st < p.n_steps; ++st) {
-      // my DMAs of this step have landed, every wave is past the previous step's LDS reads:
-      // ONE statement, so that neither LDS reads nor the next DMAs can move across it
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const bool same = st + 1 < p.n_steps;
-      const bool more = same || item_n < total;
-      const __amdgpu_buffer_rsrc_t ra = act_desc(same ? n0 : n0_n, same ? st + 1 : 0);
-      const __amdgpu_buffer_rsrc_t rw = w_desc(same ? ct : ct_n, same ? st + 1 : 0);
-      // ---- S = KC * taps sub-steps of NB x PT MFMAs; fragments D sub-steps ahead -------------
-      const char* aslab = smem + slot * act_bytes;
-      const char* wslab = smem + w_lds0 + slot * W_SLAB + abase;
-      half8_t wr[D][NB], xr[D][PT];
-      auto load_sub = [&](int s, int d) {
-        const int kc = s / TAPS, tap = s - kc * TAPS;
-        const unsigned toff = kc * chunk_lds + (tap / KW) * cp16 + (tap % KW) * 16;
+          for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
+    }
+    // this step's DMAs have landed (the R - 2 younger steps' may still fly), every wave is
+    // past the LDS reads of the slot the next DMAs will overwrite
+    if (R == 2) {
+      wait_dma_and_barrier(0);
+    } else {
+      const Pos nx = advance(cur);
+      wait_dma_and_barrier(nx.item < total ? my_dmas : 0);
+    }
+    const bool more = ahead.item < total;
+    const __amdgpu_buffer_rsrc_t ra = act_desc(more ? ahead.n0 : cur.n0, more ? ahead.st : 0);
+    const __amdgpu_buffer_rsrc_t rw = w_desc(more ? ahead.ct : cur.ct, more ? ahead.st : 0);
+    const unsigned slot_ahead = (slot + R - 1) % R;
+    // ---- S = KC * taps sub-steps of NB x PT MFMAs; fragments D sub-steps ahead -------------
+    const char* aslab = smem + slot * act_bytes;
+    const char* wslab = smem + w_lds0 + slot * W_SLAB + abase;
+    half8_t wr[D][NB], xr[D][PT];
+    auto load_sub = [&](int s, int d) {
+      const int kc = s / TAPS, tap = s - kc * TAPS;
+      const unsigned toff = kc * chunk_lds + (tap / KW) * cp16 + (tap % KW) * 16;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          wr[d][nb] = *reinterpret_cast<const half8_t*>(wslab + s * (2 * BN * 16) + nb * 512);
-        }
+      for (int nb = 0; nb < NB; ++nb) {
+        wr[d][nb] = *reinterpret_cast<const half8_t*>(wslab + s * (2 * BN * 16) + nb * 512);
+      }
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        xr[d][pt] = *reinterpret_cast<const half8_t*>(aslab + bbase[pt] + toff);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < D && d < S; ++d) load_sub(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-          xr[d][pt] = *reinterpret_cast<const half8_t*>(aslab + bbase[pt] + toff);
+          acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % D][nb], xr[s % D][pt],
+                                                               acc[nb][pt], 0, 0, 0);
         }
-      };
-#pragma unroll
-      for (int d = 0; d < D && d < S; ++d) load_sub(d, d);
+      if (s + D < S) load_sub(s + D, s % D);
       __builtin_amdgcn_sched_barrier(0);
+      if (more) {  // this sub-step's share of the DMAs of step i + R - 1
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int pt = 0; pt < PT; ++pt) {
-            acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % D][nb], xr[s % D][pt],
-                                                                 acc[nb][pt], 0, 0, 0);
-          }
-        if (s + D < S) load_sub(s + D, s % D);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {  // this sub-step's share of the next step's DMAs
-#pragma unroll
-          for (int j = s * J / S; j < (s + 1) * J / S; ++j) issue_one(j, ra, rw, slot ^ 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = s * J / S; j < (s + 1) * J / S; ++j) issue_one(j, ra, rw, slot_ahead);
       }
-      slot ^= 1;
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- epilogue: shift + ReLU, 16-byte pieces into the branch tensors -------------------
-    int pn[PT];
-    bool mvalid[PT];
+    if (cur.st == p.n_steps - 1) {
+      // ---- epilogue: shift + ReLU, 16-byte pieces into the branch tensors -------------------
+      int pn[PT];
+      bool mvalid[PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      pn[pt] = n0 + pimg[pt];
-      mvalid[pt] = pvalid[pt] && pn[pt] < c.N;
+      for (int pt = 0; pt < PT; ++pt) {
+        pn[pt] = cur.n0 + pimg[pt];
+        mvalid[pt] = pvalid[pt] && pn[pt] < c.N;
+      }
+      conv_epilogue<NB, PT>(acc, c, cur.ct, pn, poh, pow_, mvalid, lane);
     }
-    conv_epilogue<NB, PT>(acc, c, ct, pn, poh, pow_, mvalid, lane);
-    item = item_n;
-    if (item >= total) break;
-    n0 = n0_n;
-    ct = ct_n;
+    cur = advance(cur);
+    if (cur.item >= total) break;
+    ahead = advance(ahead);
+    slot = (slot + 1) % R;
   }
 }
 
-template <int KH, int KW, int KC, int NB>
-void launch_one(const ImgConvArgs& a, int blocks, size_t lds, hipStream_t stream) {
+template <int KH, int KW, int KC, int NB, int R>
+void launch_ring(const ImgConvArgs& a, int blocks, size_t lds, hipStream_t stream) {
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KH, KW, KC, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imgconv_kernel<KH, KW, KC, NB, R>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr;
   const int total = a.n_img_tiles * a.n_cout_tiles;
   const int grid = total < blocks ? total : blocks;
-  hipLaunchKernelGGL((imgconv_kernel<KH, KW, KC, NB>), dim3(grid > 0 ? grid : 1), dim3(IC_THREADS), lds,
+  hipLaunchKernelGGL((imgconv_kernel<KH, KW, KC, NB, R>), dim3(grid > 0 ? grid : 1), dim3(IC_THREADS), lds,
                      stream, a);
+}
+
+template <int KH, int KW, int KC, int NB>
+void launch_one(const ImgConvArgs& a, int blocks, size_t /*lds2*/, hipStream_t stream) {
+  // three slabs in flight where the CU's LDS holds them (DV_IMGCONV_RING=2 forces two)
+  static const bool force2 = getenv("DV_IMGCONV_RING") != nullptr && atoi(getenv("DV_IMGCONV_RING")) == 2;
+  const size_t slab = static_cast<size_t>(a.act_slab_bytes) + imgconv_wslab_halfs(KH, KW, NB) * 2;
+  if (!force2 && 3 * slab <= 160 * 1024) {
+    launch_ring<KH, KW, KC, NB, 3>(a, blocks, 3 * slab, stream);
+  } else {
+    launch_ring<KH, KW, KC, NB, 2>(a, blocks, 2 * slab, stream);
+  }
 }
 
 template <int KH, int KW, int KC>
