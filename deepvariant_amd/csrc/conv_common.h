@@ -67,6 +67,14 @@ struct ConvArgs {
   unsigned img_bytes;     // bytes of one example of the input tensor (all groups, with halo)
   unsigned chunk_stride;  // bytes between consecutive 16-channel chunks = 2*hp*wp*16
   int n_tiles;            // cout tiles (grid = m_blocks * n_tiles)
+  // Row-band mode (band = H > 0): 'same'-padded, stride-1 filters TALLER than the map
+  // (7x1 on 4 rows, 3x3 / 3x1 on 1 row).  A block's pixels all lie in ONE output row r, so
+  // the taps that fall into the zero halo above / below the map are the same for the whole
+  // block and are skipped: KH here is the number of map rows (taps kh = pad_h - r + 0..H-1
+  // hit input rows 0..H-1), `w` holds one packed image per output row, and the grid is
+  // band * ceil(N*OW / block pixels) * n_tiles.  Skipped products are exact zeros, so the
+  // result is bit-identical to the full filter.
+  int band;
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
 };
 

@@ -148,8 +148,8 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 //    independent 32x32 accumulators keep the matrix pipe busy back to back.
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
-template <int NB, int PT>
-__global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
+template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2)>
+__global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
@@ -168,7 +168,13 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
   const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int n_tile = logical % p.n_tiles;
-  const int m_block = (logical / p.n_tiles) * (128 * PT);
+  int pix_block = logical / p.n_tiles;
+  int band_r = 0;  // row-band mode: the output row of every pixel of this block
+  if (p.band) {
+    band_r = pix_block % p.band;   // rows minor: the H blocks reading the same images are neighbours
+    pix_block /= p.band;
+  }
+  const int m_block = pix_block * (128 * PT);
 
   // Buffer offsets are 32 bit, tensors are not (8 K examples x 1.4 MB): every wave
   // addresses the input relative to the first example it touches (n0), through its
@@ -181,11 +187,18 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int m = m_block + (wave * PT + pt) * 32 + (lane & 31);
-    mvalid[pt] = m < p.M;
-    int n, pix, oh, ow;
-    divmod_small(mvalid[pt] ? m : 0, ohow, p.rcp_ohow, n, pix);
-    divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
-    const int iy = oh * p.stride - p.pad_h + p.ig.halo;
+    int n, pix, oh, ow, iy;
+    if (p.band) {  // m runs over (example, column) of row band_r; taps start at map row 0
+      mvalid[pt] = m < p.N * p.OW;
+      divmod_small(mvalid[pt] ? m : 0, p.OW, p.rcp_ow, n, ow);
+      oh = band_r;
+      iy = p.ig.halo;
+    } else {
+      mvalid[pt] = m < p.M;
+      divmod_small(mvalid[pt] ? m : 0, ohow, p.rcp_ohow, n, pix);
+      divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
+      iy = oh * p.stride - p.pad_h + p.ig.halo;
+    }
     const int ix = ow * p.stride - p.pad_w + p.ig.halo;
     if (pt == 0) n0 = __builtin_amdgcn_readfirstlane(n);  // lane 0 holds the wave's first pixel
     base[pt] = mvalid[pt]
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(kConvThreads, (NB * PT >= 8 ? 1 : 2)) void conv_mfm
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
-                      static_cast<size_t>(n_tile) * p.n_slabs * SLAB_PIECES;
+                      static_cast<size_t>(band_r * p.n_tiles + n_tile) * p.n_slabs * SLAB_PIECES;
   uint4_t wreg[W_PER_THREAD];
 #define DV_LOAD_SLAB(s_)                                                                   \
   {                                                                                        \
@@ -741,6 +754,7 @@ struct Op {
   // Fused stem (stem.hip): the op marked stem_a / stem_b runs together with the op that
   // follows it as ONE launch; the tensor between them is never materialised.
   // imgconv.hip: whole-map tiles, both operands through LDS (set on the launch's leader op)
+  int band = 0;                  // conv_mfma_kernel's row-band mode: map rows (= taps kept), 0 = off
   bool v2 = false;
   int v2_g = 0;                  // images per tile
   int v2_steps = 0;              // K steps (KC channel chunks each)
@@ -995,6 +1009,34 @@ struct dv_model {
     }
   }
 
+  // Filters taller than the map: conv_mfma_kernel's row-band mode (ConvArgs::band) skips the
+  // taps that only ever see the zero halo.  At 100 x 221 inputs these are the 7x1 layers of
+  // the 4 x 12 maps (4 of 7 taps remain) and the 3x3 / 3x1 layers of the 1 x 5 maps (the
+  // middle row only).  Needs every output row to see ALL map rows (so each row keeps exactly
+  // H taps): H <= min(pad, KH - 1 - pad) + 1.  DV_NO_BAND keeps the full filters.
+  void choose_band() {
+    if (getenv("DV_NO_BAND") != nullptr) return;
+    for (Op& op : ops) {
+      if (op.type != kOpConv || op.first_u8 || op.pool_in || op.stem_a || op.stem_b || op.v2 ||
+          op.group_followers != 0 || op.stride != 1 || op.kh <= 1 || op.oh != op.ih) {
+        continue;
+      }
+      const int h = op.ih;
+      if (h >= op.kh || h > std::min(op.pad_h, op.kh - 1 - op.pad_h) + 1 || op.ow < 5) continue;
+      bool follower = false;  // a sibling inside another op's launch keeps that launch's geometry
+      for (const Op& lead : ops) {
+        if (lead.type == kOpConv && lead.group_followers > 0 && &op > &lead &&
+            &op <= &lead + lead.group_followers) {
+          follower = true;
+        }
+      }
+      if (follower) continue;
+      op.band = h;
+      op.n_chunks = h * op.kw * (op.cin / kChunk);
+      op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;
+    }
+  }
+
   // tf_keras applications/inception_v3.py, construction order = layer order.
   void build() {
     const int in_buf = new_buffer(desc.height, desc.width, 16);
@@ -1115,6 +1157,7 @@ struct dv_model {
       buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
     }
     choose_imgconv();
+    choose_band();
     for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
       Op& op = ops[i];
       if (op.type != kOpConv) continue;
@@ -1125,8 +1168,8 @@ struct dv_model {
       packed_halfs += op.first_u8 ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
                       : op.v2     ? static_cast<size_t>(op.v2_tiles) * op.v2_steps *
                                         dv::imgconv_wslab_halfs(op.kh, op.kw, op.nb)
-                                  : static_cast<size_t>(n_tiles) * op.n_steps * kSlabChunks *
-                                        (op.nb * 32) * kChunk;
+                                  : static_cast<size_t>(op.band ? op.band : 1) * n_tiles * op.n_steps *
+                                        kSlabChunks * (op.nb * 32) * kChunk;
       i += op.group_followers;
     }
     layers.push_back({1, 1, feat_c, desc.num_classes, n_params});
@@ -1139,9 +1182,13 @@ namespace {
 template <int NB>
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int n_tiles = a.n_tiles;
+  // pixel blocks of `px` pixels: over all N*OH*OW pixels, or per output row in row-band mode
+  const long rows = a.band ? a.band : 1;
+  const long row_px = a.band ? static_cast<long>(a.N) * a.OW : a.M;
+  auto blocks = [&](int px) { return rows * ((row_px + px - 1) / px) * n_tiles; };
   // Two pixel tiles per wave halve the LDS weight traffic per MFMA; fall back
   // to one when that would leave CUs without a block.
-  const long blocks2 = static_cast<long>((a.M + 255) / 256) * n_tiles;
+  const long blocks2 = blocks(256);
   static const int force_pt = getenv("DV_CONV_PT") ? atoi(getenv("DV_CONV_PT")) : 0;  // tuning knob
   // Four pixel tiles per wave where the accumulators still leave two blocks per CU and
   // K is long enough to amortise the wider prologue: measured -6 % on the 32-cout stem
@@ -1149,20 +1196,28 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
   static const bool no_pt4 = getenv("DV_NO_PT4") != nullptr;  // tuning knob
   if constexpr (NB <= 2) {
     if (!no_pt4 && !force_pt && blocks2 >= 4096 && (NB == 1 || a.KH * a.KW >= 25)) {
-      const dim3 grid(static_cast<unsigned>(((a.M + 511) / 512) * n_tiles));
-      hipLaunchKernelGGL((conv_mfma_kernel<NB, 4>), grid, dim3(kConvThreads),
-                         conv_lds_bytes<NB>(), stream, a);
+      hipLaunchKernelGGL((conv_mfma_kernel<NB, 4>), dim3(static_cast<unsigned>(blocks(512))),
+                         dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
       return;
     }
   }
   if (force_pt ? force_pt == 2 : blocks2 >= 512) {
-    const dim3 grid(static_cast<unsigned>(((a.M + 255) / 256) * n_tiles));
-    hipLaunchKernelGGL((conv_mfma_kernel<NB, 2>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, a);
+    if constexpr (NB == 4) {
+      // <4,2> compiled for two blocks per CU (249 VGPRs, no spills) instead of one with
+      // accumulators in AGPRs (284): a second wave per SIMD covers the other's waits --
+      // measured -12...-26 % on every nb4 layer (DV_CONV42_BLOCKS=1 restores one block).
+      static const bool two = getenv("DV_CONV42_BLOCKS") == nullptr || atoi(getenv("DV_CONV42_BLOCKS")) != 1;
+      if (two) {
+        hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2>), dim3(static_cast<unsigned>(blocks2)),
+                           dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<NB, 2>), dim3(static_cast<unsigned>(blocks2)),
+                       dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
   } else {
-    const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * n_tiles));
-    hipLaunchKernelGGL((conv_mfma_kernel<NB, 1>), grid, dim3(kConvThreads),
-                       conv_lds_bytes<NB>(), stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<NB, 1>), dim3(static_cast<unsigned>(blocks(128))),
+                       dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
   }
 }
 
@@ -1349,7 +1404,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.Cin = op.cin;
       a.OH = op.oh;
       a.OW = op.ow;
-      a.KH = op.kh;
+      a.band = op.band;
+      a.KH = op.band ? op.band : op.kh;
       a.KW = op.kw;
       a.stride = op.stride;
       a.pad_h = op.pad_h;
@@ -1396,6 +1452,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                   " tiles" + std::to_string(tiles);
       if (op.pool_in) tr_label += " <- maxpool3s2";
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
+      if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
       if (op.v2) {
@@ -1661,13 +1718,18 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         continue;
       }
     }
+    // row-band mode: one image per output row `band_r`, holding the op.band tap rows
+    // kh = pad_h - band_r + 0..band-1 that meet map rows 0..band-1
+    const int eff_taps = op.band ? op.band * op.kw : taps;
+    const int n_tiles_op = ((op.cout + 31) / 32 + op.nb - 1) / op.nb;   // band ops are never grouped
+    for (int band_r = 0; band_r < (op.band ? op.band : 1); ++band_r)
     for (int kc = 0; kc < op.n_chunks; ++kc) {
       const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
-      const int cc = kc / taps, tap = kc % taps;  // chunk-major, tap-minor (ChunkWalk)
-      const int kh = tap / op.kw, kw = tap % op.kw;
+      const int cc = kc / eff_taps, tap = kc % eff_taps;  // chunk-major, tap-minor (ChunkWalk)
+      const int kh = tap / op.kw + (op.band ? op.pad_h - band_r : 0), kw = tap % op.kw;
       for (int co = 0; co < op.cout; ++co) {
         const int row = sub0 * 32 + co;
-        const int t = row / bn, r = row % bn;
+        const int t = row / bn + band_r * n_tiles_op, r = row % bn;
         // chunk image [k-group g][cout r][8]: matches conv_mfma_kernel's frag_off
         _Float16* chunk = packed.data() + op.w_off +
                           ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn * kChunk;

@@ -216,3 +216,30 @@ def test_conv_macs_match_the_architecture_count():
     model = InceptionV3(shape, max_batch=1)
     assert model.conv_macs_per_example == R.macs_per_example(shape[2], shape[0], shape[1]) - 2048 * 3
   assert abs(2 * InceptionV3((100, 221, 7), max_batch=1).conv_macs_per_example - 2.0105e9) < 1e6
+
+
+@pytest.mark.parametrize('shape,n', [((100, 221, 7), 70), ((100, 147, 10), 9), ((140, 221, 7), 5)])
+def test_row_band_mode_is_bit_identical_to_the_full_filters(shape, n):
+  """Filters taller than the map (7x1 on the 4-row maps, 3x3 / 3x1 on the 1-row maps) skip
+  the tap rows that only meet the zero halo (ConvArgs::band).  Dropping exact-zero products
+  from an fp32 accumulation changes nothing: logits must be IDENTICAL with DV_NO_BAND.
+  (140 rows: the last maps are 3 rows high -- 3x3 no longer qualifies, 7x1 on 6 rows neither.)"""
+  import os
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  ref = R.make_random_model(shape[2], seed=11)
+  flat = ref.export_flat()
+  x = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+  banded = InceptionV3(shape, max_batch=64)
+  banded.load_flat_weights(flat)
+  os.environ['DV_NO_BAND'] = '1'
+  try:
+    full = InceptionV3(shape, max_batch=64)
+  finally:
+    del os.environ['DV_NO_BAND']
+  full.load_flat_weights(flat)
+  pa, pb = banded(x).clone(), full(x).clone()
+  a, b = banded.debug_tensor(-1, n), full.debug_tensor(-1, n)   # the head's input: [n, h, w, 2048]
+  assert np.array_equal(a, b)
+  assert torch.equal(pa, pb)
+  assert np.abs(a.astype(np.float32)).max() > 0
