@@ -297,10 +297,11 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
 // separate max-pool kernel.  K is short (Cin/16 chunks): the whole weight tile sits in LDS,
 // fragments of chunk c+1 are in flight while chunk c multiplies.  One 32-pixel fragment
 // per wave (PT = 1) keeps the 2 x 9 outstanding loads within the register budget.
-template <int NB>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_pool1x1_kernel(ConvArgs p) {
+template <int NB, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_pool1x1_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   constexpr int PT = 1;
+  constexpr int kThreads = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -310,13 +311,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_pool1x1_kernel(ConvArgs 
   const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int n_tile = logical % p.n_tiles;
-  const int m_block = (logical / p.n_tiles) * 128;
+  const int m_block = (logical / p.n_tiles) * (WAVES * 32);
 
   {  // whole weight tile -> LDS
     const int pieces = p.n_slabs * kSlabChunks * BN * 2;
     const uint4_t* src = reinterpret_cast<const uint4_t*>(p.w) + static_cast<size_t>(n_tile) * pieces;
     uint4_t* dst = reinterpret_cast<uint4_t*>(smem);
-    for (int i = tid; i < pieces; i += kConvThreads) dst[i] = src[i];
+    for (int i = tid; i < pieces; i += kThreads) dst[i] = src[i];
   }
   int pn[PT], poh[PT], pow_[PT];
   bool mvalid[PT];
@@ -935,7 +936,10 @@ struct dv_model {
       // measured (8 K examples): 128-cout tiles win from 16 subtiles up (17x17 and 8x8 heads,
       // -20..-26 %); the 7-subtile 35x35 heads and the 12-subtile 768->192+192 head are
       // faster as 96-cout tiles (two blocks per CU) than as 128 (one block per CU).
-      const int nb = subs >= 16 ? 4 : 3;
+      // heads that max-pool their input on the fly (mixed0): ONE tile of all 7 subtiles, so
+      // that every 3x3 window is fetched and reduced once (three 96-cout tiles: 1.55 ms
+      // against 0.84 + 0.47 ms for the separate pool + heads)
+      const int nb = lead.pool_in && subs == 7 && getenv("DV_POOL2_NB3") == nullptr ? 7 : subs >= 16 ? 4 : 3;
       std::vector<Op> moved;
       for (size_t j : sib) moved.push_back(ops[j]);
       for (size_t k = sib.size(); k-- > 0;) ops.erase(ops.begin() + sib[k]);
@@ -1078,7 +1082,19 @@ struct dv_model {
       buffers[ops[2].out_buf] = {1, 1, 64, 0};  // conv3 output: LDS only
     }
     x = conv(x, 192, 3, 3, 1, false);
-    x = pool(kOpMaxPool, x);
+    // The stem's second max-pool has ONE consumer launch -- mixed0's four 1x1 heads, grouped
+    // (the pooled branch projects before it averages) -- so it is taken on the fly there
+    // (conv_pool1x1_kernel) and the pooled tensor is never written.  DV_NO_POOL2_FUSE keeps
+    // the separate max-pool kernel.
+    const bool fuse_pool2 = getenv("DV_NO_POOL2_FUSE") == nullptr && getenv("DV_NO_POOL_FUSE") == nullptr &&
+                            getenv("DV_NO_GROUPING") == nullptr;
+    const int pool2_ih = x.h, pool2_iw = x.w;
+    if (fuse_pool2) {
+      x.h = (x.h - 3) / 2 + 1;
+      x.w = (x.w - 3) / 2 + 1;
+    } else {
+      x = pool(kOpMaxPool, x);
+    }
     // Everything up to here is the "stem": big feature maps (0.2-0.7 MB per
     // example each).  It runs in sub-batches of stem_sub_batch() examples over
     // small, reused buffers so that every producer->consumer hand-off stays in
@@ -1095,6 +1111,15 @@ struct dv_model {
       b3 = conv(b3, 96, 3, 3);
       conv(b3, 96, 3, 3, 1, true, out, 128);
       pooled_projection(x, pool_ch, out, 224);
+      if (fuse_pool2 && x.buf == stem_out_buf) {  // mixed0: its 1x1 heads pool their input
+        for (size_t k = stem_ops_end; k < ops.size(); ++k) {
+          if (ops[k].type == kOpConv && ops[k].in_buf == x.buf) {
+            ops[k].pool_in = true;
+            ops[k].ih = pool2_ih;
+            ops[k].iw = pool2_iw;
+          }
+        }
+      }
       x = full(out);
     }
     {  // mixed3
@@ -1465,6 +1490,16 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         a.stride = 2;  // documentary: the window origin is (2 oh, 2 ow)
         const size_t lds = static_cast<size_t>(op.n_steps) * kSlabChunks * op.nb * 32 * kChunk * 2;
         const dim3 grid(static_cast<unsigned>(((a.M + 127) / 128) * a.n_tiles));
+        if (op.nb == 7) {  // mixed0's heads: all 7 subtiles in one tile, every window pooled once
+          static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pool1x1_kernel<7, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+          }();
+          (void)attr;
+          hipLaunchKernelGGL((conv_pool1x1_kernel<7, 8>), dim3(static_cast<unsigned>((a.M + 255) / 256)),
+                             dim3(512), lds, stream, a);
+        } else
         switch (op.nb) {
           case 1: hipLaunchKernelGGL((conv_pool1x1_kernel<1>), grid, dim3(kConvThreads), lds, stream, a); break;
           case 2: hipLaunchKernelGGL((conv_pool1x1_kernel<2>), grid, dim3(kConvThreads), lds, stream, a); break;

@@ -243,3 +243,25 @@ def test_row_band_mode_is_bit_identical_to_the_full_filters(shape, n):
   assert np.array_equal(a, b)
   assert torch.equal(pa, pb)
   assert np.abs(a.astype(np.float32)).max() > 0
+
+
+def test_second_stem_pool_fused_into_mixed0_is_bit_identical():
+  """The stem's second max-pool runs inside mixed0's grouped 1x1 launch (max of the nine
+  pieces in registers -- exact) instead of as its own kernel (DV_NO_POOL2_FUSE)."""
+  import os
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import inception_ref as R
+  shape, n = (100, 221, 7), 37
+  flat = R.make_random_model(7, seed=13).export_flat()
+  x = torch.from_numpy(np.random.default_rng(6).integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+  fused = InceptionV3(shape, max_batch=64)
+  fused.load_flat_weights(flat)
+  os.environ['DV_NO_POOL2_FUSE'] = '1'
+  try:
+    plain = InceptionV3(shape, max_batch=64)
+  finally:
+    del os.environ['DV_NO_POOL2_FUSE']
+  plain.load_flat_weights(flat)
+  pa, pb = fused(x).clone(), plain(x).clone()
+  assert np.array_equal(fused.debug_tensor(-1, n), plain.debug_tensor(-1, n))
+  assert torch.equal(pa, pb)

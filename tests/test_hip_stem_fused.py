@@ -162,8 +162,13 @@ def test_features_and_logits_stage_by_stage():
     feats = ref.features(pre)
     logits = ref.classification(feats)
   got_stem = model.debug_tensor(-2, n).astype(np.float32)
-  halo = (got_stem.shape[1] - 10) // 2
-  got_stem = _interior(got_stem, halo)
+  if got_stem.shape[1] >= 21:
+    # the stem's last max-pool is taken on the fly by mixed0's heads: the stem's last TENSOR
+    # is the 21 x 51 output of the 3x3 80->192 (no halo); pool it here (max is exact)
+    t = torch.from_numpy(got_stem).permute(0, 3, 1, 2)
+    got_stem = R._maxpool(t).permute(0, 2, 3, 1).numpy()
+  else:
+    got_stem = _interior(got_stem, (got_stem.shape[1] - 10) // 2)
   want_stem = stem_out.permute(0, 2, 3, 1).numpy()
   assert got_stem.shape == want_stem.shape == (n, 10, 25, 192)
   rel = np.abs(got_stem - want_stem).max() / np.abs(want_stem).max()
