@@ -41,6 +41,12 @@ ABI_SYMBOLS = [
     'dv_read_table_names', 'dv_read_table_ends', 'dv_read_table_free',
     'dv_pack_region', 'dv_packed_region_fill_batch', 'dv_packed_region_items',
     'dv_packed_region_free',
+    'dv_aligner_create', 'dv_aligner_destroy', 'dv_aligner_set_reference',
+    'dv_aligner_set_haplotypes', 'dv_aligner_set_reads', 'dv_aligner_align_reads',
+    'dv_aligner_stage', 'dv_aligner_fast_align', 'dv_aligner_haplotype_info',
+    'dv_aligner_read_alignment', 'dv_aligner_merge_alignment', 'dv_aligner_is_normalized',
+    'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
+    'dv_merge_cigar_op', 'dv_local_align',
 ]
 
 
@@ -131,6 +137,30 @@ class DvPackCandidate(C.Structure):
               ('first_support', C.c_uint32), ('n_support', C.c_uint32)]
 
 
+class DvAlignerOptions(C.Structure):
+  _fields_ = [('match', C.c_int32), ('mismatch', C.c_int32), ('gap_open', C.c_int32),
+              ('gap_extend', C.c_int32), ('kmer_size', C.c_int32), ('read_size', C.c_int32),
+              ('max_num_of_mismatches', C.c_int32),
+              ('realignment_similarity_threshold', C.c_double),
+              ('force_alignment', C.c_int32), ('normalize_reads', C.c_int32),
+              ('ref_prefix_len', C.c_int32), ('ref_suffix_len', C.c_int32)]
+
+
+class DvRealignedRead(C.Structure):
+  _fields_ = [('status', C.c_int32), ('n_cigar', C.c_int32), ('position', C.c_int64),
+              ('cigar_off', C.c_uint32), ('reserved', C.c_uint32)]
+
+
+class DvReadAlignment(C.Structure):
+  _fields_ = [('position', C.c_int32), ('score', C.c_int32), ('cigar', C.c_char * 120)]
+
+
+class DvLocalAlignment(C.Structure):
+  _fields_ = [('score', C.c_int32), ('ref_begin', C.c_int32), ('ref_end', C.c_int32),
+              ('query_begin', C.c_int32), ('query_end', C.c_int32), ('mismatches', C.c_int32),
+              ('cigar', C.c_char * 512)]
+
+
 class DvModelDesc(C.Structure):
   _fields_ = [('height', C.c_int32), ('width', C.c_int32),
               ('channels', C.c_int32), ('num_classes', C.c_int32),
@@ -199,6 +229,25 @@ def lib():
     l.dv_read_table_ends.restype = C.c_void_p
     l.dv_read_table_ends.argtypes = [C.c_void_p]
     l.dv_read_table_free.argtypes = [C.c_void_p]
+    l.dv_aligner_create.argtypes = [C.c_void_p, C.c_void_p]
+    l.dv_aligner_destroy.argtypes = [C.c_void_p]
+    l.dv_aligner_destroy.restype = None
+    l.dv_aligner_set_reference.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    l.dv_aligner_set_haplotypes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    l.dv_aligner_set_reads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    l.dv_aligner_align_reads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_aligner_stage.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    l.dv_aligner_fast_align.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
+    l.dv_aligner_haplotype_info.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32]
+    l.dv_aligner_read_alignment.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    l.dv_aligner_merge_alignment.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p,
+                                             C.c_void_p, C.c_int32]
+    l.dv_aligner_is_normalized.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p]
+    l.dv_aligner_score_threshold.argtypes = [C.c_void_p]
+    l.dv_aligner_kmer_occurrences.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
+    l.dv_positions_map.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
+    l.dv_merge_cigar_op.argtypes = [C.c_void_p, C.c_int32, C.c_char, C.c_int32, C.c_int32]
+    l.dv_local_align.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int32] * 4 + [C.c_void_p]
     _lib = l
   return _lib
 

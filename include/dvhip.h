@@ -352,6 +352,83 @@ int dv_packed_region_items(const dv_packed_region* p, const int32_t** item_candi
                            const uint32_t** item_combo);
 void dv_packed_region_free(dv_packed_region* p);
 
+/* ---- read realigner (host only) ----------------------------------------------
+ * Replaces deepvariant/realigner/fast_pass_aligner.{h,cc} (class FastPassAligner) and the
+ * local aligner it links (libssw v1.2.5 through deepvariant/realigner/ssw.{h,cc}); used by
+ * RealignReadsToHaplotype for alt-aligned pileups (deepvariant/alt_aligned_pileup_lib.cc:
+ * 278-313).  Options follow AlignerOptions (deepvariant/protos/realigner.proto:178-228):
+ * 0 keeps the class default. */
+typedef struct dv_aligner dv_aligner;
+
+typedef struct dv_aligner_options {
+  int32_t match, mismatch, gap_open, gap_extend;          /* defaults 4, 6, 8, 1 */
+  int32_t kmer_size, read_size, max_num_of_mismatches;    /* defaults 32, 100, 2 */
+  double realignment_similarity_threshold;                /* default 0.85 */
+  int32_t force_alignment;   /* never return the original alignment (alt-aligned pileups) */
+  int32_t normalize_reads;   /* --normalize_reads: keep alignments that could shift left */
+  int32_t ref_prefix_len, ref_suffix_len;   /* reference padding around the haplotype */
+} dv_aligner_options;
+
+typedef struct dv_realigned_read {
+  int32_t status;      /* 0 = original alignment kept, 1 = new alignment, 2 = read dropped
+                          (force_alignment and no alignment found: the reference returns an empty Read) */
+  int32_t n_cigar;
+  int64_t position;    /* new alignment start (reference coordinates), status 1 only */
+  uint32_t cigar_off;  /* first word of its CIGAR in the array dv_aligner_align_reads returns */
+  uint32_t reserved;
+} dv_realigned_read;
+
+typedef struct dv_read_alignment {   /* ReadAlignment (fast_pass_aligner.h:104-128) */
+  int32_t position;    /* offset in the haplotype; -1 = kNotAligned */
+  int32_t score;
+  char cigar[120];     /* text, as the reference keeps it ("15=", "3S3=2I13=") */
+} dv_read_alignment;
+
+typedef struct dv_local_alignment {  /* StripedSmithWaterman::Alignment, the fields used */
+  int32_t score, ref_begin, ref_end, query_begin, query_end, mismatches;
+  char cigar[512];
+} dv_local_alignment;
+
+int dv_aligner_create(const dv_aligner_options* options, dv_aligner** out);   /* set_options */
+void dv_aligner_destroy(dv_aligner* a);
+int dv_aligner_set_reference(dv_aligner* a, const char* reference, int64_t ref_start); /* set_reference + set_ref_start */
+int dv_aligner_set_haplotypes(dv_aligner* a, int32_t n, const char* const* haplotypes);
+int dv_aligner_set_reads(dv_aligner* a, int32_t n, const char* const* reads);
+/* FastPassAligner::AlignReads.  `cigar` receives (length << 4 | op) words -- nucleus op
+ * codes, dv_batch's CIGAR encoding -- owned by the aligner until its next call. */
+int dv_aligner_align_reads(dv_aligner* a, int32_t n, const char* const* sequences,
+                           dv_realigned_read* out, const uint32_t** cigar);
+/* Individual stages, for tests that follow fast_pass_aligner_test.cc. */
+enum {
+  DV_ALIGNER_BUILD_INDEX = 0,        /* BuildIndex */
+  DV_ALIGNER_INIT_LOCAL_ALIGNER = 1, /* InitSswLib */
+  DV_ALIGNER_ALIGN_HAPLOTYPES = 2,   /* AlignHaplotypesToReference */
+  DV_ALIGNER_POSITION_MAPS = 3,      /* CalculatePositionMaps */
+  DV_ALIGNER_LOCAL_ALIGN_READS = 4,  /* SswAlignReadsToHaplotypes(arg = score threshold) */
+  DV_ALIGNER_SCORE_THRESHOLD = 5     /* CalculateSswAlignmentScoreThreshold */
+};
+int dv_aligner_stage(dv_aligner* a, int32_t stage, int32_t arg);
+int dv_aligner_fast_align(dv_aligner* a, const char* haplotype, int32_t* haplotype_score,
+                          dv_read_alignment* out /* [n reads] */);   /* FastAlignReadsToHaplotype */
+int dv_aligner_haplotype_info(const dv_aligner* a, int32_t k, int32_t* haplotype_index,
+                              int32_t* haplotype_score, int64_t* ref_pos, int32_t* is_reference,
+                              char* cigar, int32_t cigar_cap);
+int dv_aligner_read_alignment(const dv_aligner* a, int32_t k, int32_t read, dv_read_alignment* out);
+/* CalculateReadToRefAlignment; the merged CIGAR as text with M / I / D / S. */
+int dv_aligner_merge_alignment(const dv_aligner* a, int32_t read, int32_t position,
+                               const char* read_cigar, const char* haplotype_cigar, char* out, int32_t cap);
+int dv_aligner_is_normalized(const dv_aligner* a, const char* cigar, int32_t ref_offset,
+                             const char* read);                          /* 1 / 0 */
+int dv_aligner_score_threshold(const dv_aligner* a);
+/* Occurrences of a k-mer in the read index (count returned); "" returns the number of k-mers. */
+int dv_aligner_kmer_occurrences(const dv_aligner* a, const char* kmer, int32_t cap, int32_t* reads,
+                                int32_t* offsets);
+int dv_positions_map(const char* cigar, int32_t haplotype_size, int32_t* out);        /* SetPositionsMap */
+int dv_merge_cigar_op(char* cigar, int32_t cap, char op, int32_t length, int32_t read_len); /* MergeCigarOp */
+/* One local alignment (Aligner::SetReferenceSequence + Align). */
+int dv_local_align(const char* reference, const char* query, int32_t match, int32_t mismatch,
+                   int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
+
 /* CRC32C (Castagnoli) as used by TFRecord framing
  * (third_party/nucleus/io/example_writer.cc:88-104 via tensorflow::io::RecordWriter). */
 uint32_t dv_crc32c(const uint8_t* data, size_t n);
