@@ -135,6 +135,12 @@ def calculate_pileup_image_height(options) -> int:
   return total
 
 
+# realigner flags' defaults (deepvariant/realigner/realigner.py:168-240), which
+# RealignReadsToHaplotype inherits through options.realigner_options.aln_config
+DEFAULT_ALN_CONFIG = dict(match=4, mismatch=6, gap_open=8, gap_extend=2, kmer_size=32,
+                          max_num_of_mismatches=2, realignment_similarity_threshold=0.16934)
+
+
 class ExamplesGenerator:
   """`ExamplesGenerator(options: MakeExamplesOptions, example_filenames:
   dict[role, path], test_mode=False)` -- make_examples_native.h:154-278."""
@@ -143,10 +149,8 @@ class ExamplesGenerator:
                test_mode: bool = False, device: int = 0, ref_reader=None):
     self._options = options
     pic = options.pic_options
-    if pic.alt_aligned_pileup not in ('', 'none'):
-      raise NotImplementedError(
-          "alt_aligned_pileup=%r needs the FastPassAligner (not built yet)" %
-          pic.alt_aligned_pileup)
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    self._alt_mode = aap.get_alt_aligned_pileup(pic.alt_aligned_pileup or aap.NONE)
     if getattr(options, 'stream_examples', False):
       raise NotImplementedError('stream_examples is not supported yet')
     self._encoder_api = PileupImageEncoderNative(pic, device=device)
@@ -154,8 +158,7 @@ class ExamplesGenerator:
     self._half_width = (pic.width - 1) // 2
     self._samples = {so.role: so for so in options.sample_options}
     for so in options.sample_options:
-      if so.alt_aligned_pileup not in ('', 'none'):
-        raise NotImplementedError('per-sample alt_aligned_pileup')
+      aap.get_alt_aligned_pileup(so.alt_aligned_pileup or aap.NONE)   # unknown names are fatal
       if so.use_non_uniform_downsampling:
         raise NotImplementedError('use_non_uniform_downsampling')
     self._height = calculate_pileup_image_height(options)
@@ -204,7 +207,7 @@ class ExamplesGenerator:
     return stats, image_shape
 
   # --------------------------------------------------------------- internals
-  def _trim_region_reads(self, candidates, reads_per_sample, sample_order, tables):
+  def _trim_region_reads(self, candidates, reads_per_sample, sample_order, tables, wanted=None):
     """trim_reads_for_pileup / keep_only_window_spanning_reads
     (make_examples_native.cc:655-685): every candidate gets ITS OWN copies of the reads it
     overlaps, cut to the pileup window (TrimReads), rows still sorted by the untrimmed
@@ -217,6 +220,8 @@ class ExamplesGenerator:
     ranges = {}
     for ci, cand in enumerate(candidates):
       variant = cand.variant
+      if wanted is not None and not wanted[ci]:
+        continue
       if not get_reference_bases_for_pileup(self._ref, variant, pic.width):
         continue
       q0 = variant.start - pic.read_overlap_buffer_bp
@@ -235,10 +240,60 @@ class ExamplesGenerator:
         trimmed[s].extend(kept)
         starts[s].extend(original)
         ranges[(ci, s)] = (lo, lo + len(kept))
-    new_tables = [packing.ReadTable.from_reads(
-        trimmed[s], alignment_positions=starts[s] or None, need_aux=self._encoder_api._need_aux,
-        need_seq_aux=self._encoder_api._need_seq_aux) for s in range(len(reads_per_sample))]
+    new_tables = [self._table_of(trimmed[s], starts[s]) for s in range(len(reads_per_sample))]
+    self._trimmed_reads, self._trimmed_starts = trimmed, starts
     return new_tables, ranges
+
+  def _table_of(self, reads, sort_positions):
+    t = packing.ReadTable.from_reads(
+        reads, alignment_positions=sort_positions or None, need_aux=self._encoder_api._need_aux,
+        need_seq_aux=self._encoder_api._need_seq_aux)
+    if t.read_sort_pos is None:
+      t.read_sort_pos = t.read_pos.copy()
+    return t
+
+  def _realign_for_alt_images(self, candidates, need_alt, sample_order, trim_ranges):
+    """CreateAltAlignedImages' host part (make_examples_native.cc:553-600): per candidate,
+    sample and alt allele, the haplotype (reference prefix + alt + suffix) and the trimmed
+    reads realigned to it.  -> (per-sample tables of the realigned reads,
+    {(candidate, sample, alt): (lo, hi, haplotype window)})."""
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    from deepvariant_amd import fast_pass_aligner as fpa
+    pic = self._options.pic_options
+    cfg = dict(getattr(self._options, 'aln_config', None) or DEFAULT_ALN_CONFIG)
+    n_samples = len(self._trimmed_reads)
+    reads_out = [[] for _ in range(n_samples)]
+    starts_out = [[] for _ in range(n_samples)]
+    ranges = {}
+    for ci, cand in enumerate(candidates):
+      if not need_alt[ci]:
+        continue
+      variant = cand.variant
+      for s in sample_order:
+        if (ci, s) not in trim_ranges or not self._sample_needs_alt(self._options.sample_options[s]):
+          continue
+        lo, hi = trim_ranges[(ci, s)]
+        trimmed = self._trimmed_reads[s][lo:hi]
+        starts = self._trimmed_starts[s][lo:hi]
+        for alt in variant.alternate_bases:
+          haplotype, ref_start, ref_end = aap.create_haplotype(self._ref, variant, alt, self._half_width)
+          if len(haplotype) < pic.width:
+            continue          # too close to the contig start: no alt-aligned pixels (:575-581)
+          realigned = fpa.realign_reads_to_haplotype(haplotype, trimmed, variant.reference_name,
+                                                     ref_start, ref_end, self._ref, cfg)
+          a = len(reads_out[s])
+          for read, start in zip(realigned, starts):
+            if read is not None and read.aligned_sequence:
+              reads_out[s].append(read)
+              starts_out[s].append(start)
+          ranges[(ci, s, alt)] = (a, len(reads_out[s]), haplotype[:pic.width])
+    return [self._table_of(reads_out[s], starts_out[s]) for s in range(n_samples)], ranges
+
+  @staticmethod
+  def _sample_needs_alt(so) -> bool:
+    """SampleNeedsAltAlignment (make_examples_native.cc:476-498): a sample that blanks any
+    alt-aligned channel gets no alt alignment."""
+    return not any(e in (9, 10, 20, 21) for e in so.channels_enum_to_blank)
 
   def _plan_region(self, candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
                    role=None):
@@ -266,18 +321,30 @@ class ExamplesGenerator:
       else:
         tables.append(packing.ReadTable.from_reads(reads, need_aux=self._encoder_api._need_aux,
                                                    need_seq_aux=self._encoder_api._need_seq_aux))
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
     role_sample = self._samples.get(role) if role is not None else \
         self._options.sample_options[sample_order[0]]
-    use_trimmed = bool(getattr(self._options, 'trim_reads_for_pileup', False) or
-                       role_sample.keep_only_window_spanning_reads)
-    trim_ranges = None
-    if use_trimmed:
-      tables, trim_ranges = self._trim_region_reads(candidates, reads_per_sample, sample_order,
-                                                    tables)
-      if any(t.read_sort_pos is None for t in tables):   # a sample without reads at all
-        for t in tables:
-          if t.read_sort_pos is None:
-            t.read_sort_pos = t.read_pos.copy()
+    # Per candidate (make_examples_native.cc:654-657): trimmed copies of its reads when
+    # trim_reads_for_pileup / keep_only_window_spanning_reads is set or the variant gets
+    # alt-aligned images.
+    need_alt = [self._alt_mode != aap.NONE and aap.need_alt_alignment(pic, c.variant) for c in candidates]
+    trim_all = bool(getattr(self._options, 'trim_reads_for_pileup', False) or
+                    role_sample.keep_only_window_spanning_reads)
+    use_trimmed = [trim_all or na for na in need_alt]
+    trim_ranges, alt_ranges = None, {}
+    n_samples = len(tables)
+    all_tables = list(tables)
+    if any(use_trimmed):
+      trim_tables, trim_ranges = self._trim_region_reads(candidates, reads_per_sample, sample_order,
+                                                         tables, use_trimmed)
+      all_tables += trim_tables
+      if any(need_alt):
+        alt_tables, alt_ranges = self._realign_for_alt_images(candidates, need_alt, sample_order,
+                                                              trim_ranges)
+        all_tables += alt_tables
+      for t in all_tables:
+        if t.read_sort_pos is None:
+          t.read_sort_pos = t.read_pos.copy()
     # Fast path: one sample, nothing per-item beyond the read list -- the whole region is
     # packed by libdvhip's dv_pack_region (region_packer.cpp) instead of the per-candidate
     # Python below (DV_PY_PACKER=1 keeps the Python path; tests compare the two).
@@ -294,11 +361,17 @@ class ExamplesGenerator:
         batch.use_ref_aux = self._encoder_api._need_ref_aux
         mc = float(mean_coverage_per_sample[sample_order[0]])
         batch.item_mean_coverage = [mc] * batch.n_items
+        self._alt_plan = []
         return batch, plan, image_shape
-    merged, sample_base = _concat_tables(tables)
+    merged, sample_base = _concat_tables(all_tables)
     batch = packing.PackedBatch(table=merged, width=width,
                                 use_ref_aux=self._encoder_api._need_ref_aux)
     plan = []  # (candidate index, alt_combination)
+    # alt-aligned images that end up in CHANNELS are drawn into scratch rows behind the
+    # examples and copied over afterwards (_merge_alt_channels); images that end up as extra
+    # ROWS are drawn in place.  alt_plan: (example, first row, rows, [scratch slot of alt 1, of alt 2])
+    alt_plan = []
+    pending = []   # alt items: (table, idx_local, base, cand, combo, haplotype window, so, mc, vtype, target)
     for ci, cand in enumerate(candidates):
       variant = cand.variant
       ref_bases = get_reference_bases_for_pileup(self._ref, variant, width)
@@ -310,29 +383,104 @@ class ExamplesGenerator:
       vtype = encoded_variant_type(variant)
       for combo in alt_allele_combinations(cand, pic.multi_allelic_mode):
         out_off = len(plan) * example_bytes
+        row0 = 0
         for s in sample_order:
           so = self._options.sample_options[s]
-          table = tables[s]
-          if trim_ranges is not None:
+          if use_trimmed[ci]:
+            table, base = all_tables[n_samples + s], sample_base[n_samples + s]
             idx_local = np.arange(*trim_ranges[(ci, s)], dtype=np.int64)
           else:
+            table, base = tables[s], sample_base[s]
             idx_local = table.query(q0, q1)
           blank = list(so.channels_enum_to_blank)
           if vtype in _types_to_blank(so):
             blank = list(T.DeepVariantChannelEnum)
+          mask = packing.blank_mask_for(self._chan_enums, blank)
+          mc = float(mean_coverage_per_sample[s])
           batch.add_item(
               variant.start, variant.start - self._half_width, ref_idx,
-              idx_local + sample_base[s],
+              idx_local + base,
               packing.support_codes(cand, combo, table, idx_local),
               height=so.pileup_height, out_off=out_off,
-              blank_mask=packing.blank_mask_for(self._chan_enums, blank),
-              mean_coverage=float(mean_coverage_per_sample[s]),
+              blank_mask=mask, mean_coverage=mc,
               groups=(packing.allele_groups(cand, table, idx_local)
                       if pic.sort_by_alt_allele_support else None),
               list_aux=self._encoder_api._list_aux(cand, combo, table, idx_local))
-          out_off += so.pileup_height * row_bytes
+          sample_mode = aap.get_sample_alt_aligned_pileup(self._alt_mode, so.alt_aligned_pileup or '')
+          row_slots = aap.get_alt_image_row_indices(sample_mode, combo)
+          if need_alt[ci] and self._sample_needs_alt(so):
+            slots = [None, None]
+            for k, alt in enumerate(combo[:2]):   # CHECK_LE(alt_combination.size(), 2)
+              if (ci, s, alt) not in alt_ranges:
+                break                              # haplotype shorter than the window: stop (:575-581)
+              lo, hi, hap_window = alt_ranges[(ci, s, alt)]
+              slots[k] = len(pending)
+              pending.append(dict(
+                  table=all_tables[2 * n_samples + s], base=sample_base[2 * n_samples + s],
+                  idx=np.arange(lo, hi, dtype=np.int64), cand=cand, combo=combo, window=hap_window,
+                  so=so, mc=mc, mask=mask, variant=variant,
+                  # rows / single_row: drawn in place, (1 + position) blocks below the reference image
+                  in_place=(out_off + (1 + row_slots.index(k)) * so.pileup_height * row_bytes
+                            if k in row_slots else None)))
+            if self._alt_mode in (aap.BASE_CHANNELS, aap.DIFF_CHANNELS):
+              alt_plan.append((len(plan), row0, so.pileup_height, slots))
+          block_rows = so.pileup_height * (1 + len(row_slots))
+          out_off += block_rows * row_bytes
+          row0 += block_rows
         plan.append((ci, combo))
+    scratch0 = len(plan) * example_bytes
+    n_scratch = 0
+    for item in pending:
+      so = item['so']
+      if item['in_place'] is not None and self._alt_mode not in (aap.BASE_CHANNELS, aap.DIFF_CHANNELS):
+        out_off = item['in_place']
+        item['scratch'] = None
+      else:
+        # channel modes read the alt image from scratch; an image that is ALSO a row block
+        # (sample-level rows under a global channel mode) is drawn twice, once per place
+        out_off = scratch0 + n_scratch * self._max_sample_height() * row_bytes
+        item['scratch'] = n_scratch
+        n_scratch += 1
+      for target in ([out_off] + ([item['in_place']] if item['scratch'] is not None and
+                                  item['in_place'] is not None else [])):
+        idx_local, table = item['idx'], item['table']
+        batch.add_item(
+            item['variant'].start, item['variant'].start - self._half_width,
+            batch.add_ref_window(item['window']), idx_local + item['base'],
+            packing.support_codes(item['cand'], item['combo'], table, idx_local),
+            height=so.pileup_height, out_off=target, blank_mask=item['mask'], mean_coverage=item['mc'],
+            groups=(packing.allele_groups(item['cand'], table, idx_local)
+                    if pic.sort_by_alt_allele_support else None),
+            list_aux=self._encoder_api._list_aux(item['cand'], item['combo'], table, idx_local))
+    self._alt_plan = [(ex, row0, rows, [None if k is None else pending[k]['scratch'] for k in slots])
+                      for ex, row0, rows, slots in alt_plan]
+    self._alt_scratch0 = scratch0
     return batch, plan, image_shape
+
+  def _max_sample_height(self) -> int:
+    return max(so.pileup_height for so in self._options.sample_options)
+
+  def _merge_alt_channels(self, images: np.ndarray, n_examples: int, image_shape) -> None:
+    """FillPileupArray's channel modes (pileup_image_native.h:246-271) on the encoder's
+    output: the two trailing channels of every reference-image row block come from
+    channel 5 (diff_channels) / 0 (base_channels) of alt image 1 and alt image 2, zero when
+    alt 1 is missing, alt 1's again when alt 2 is missing; rows are zipped by index."""
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    if not self._alt_plan:
+      return
+    h_img, w, c = image_shape
+    c_enc = len(self._chan_enums)
+    ch = 5 if self._alt_mode == aap.DIFF_CHANNELS else 0
+    hs = self._max_sample_height()
+    examples = images[:n_examples * h_img * w * c].reshape(n_examples, h_img, w, c)
+    scratch = images[self._alt_scratch0:]
+    scratch = scratch[:len(scratch) // (hs * w * c) * (hs * w * c)].reshape(-1, hs, w, c)
+    for ex, row0, rows, slots in self._alt_plan:
+      if slots[0] is None:
+        continue
+      block = examples[ex, row0:row0 + rows]
+      block[:, :, c_enc] = scratch[slots[0], :rows, :, ch]
+      block[:, :, c_enc + 1] = scratch[slots[1] if slots[1] is not None else slots[0], :rows, :, ch]
 
   def encode_region(self, candidates, reads_per_sample, sample_order,
                     mean_coverage_per_sample, stats, role=None) -> Tuple[List[bytes], List[int]]:
@@ -348,7 +496,9 @@ class ExamplesGenerator:
       self._device_encoder = _Encoder(pic, pic.width, self._device)
     if n_chan_total < len(self._chan_enums):
       raise ValueError('num_channels smaller than the encoder channel list')
-    images, _ = self._device_encoder.encode(batch, n_chan_total)
+    # (row-block layouts leave the blocks of missing alt images untouched: zero)
+    images, _ = self._device_encoder.encode(batch, n_chan_total, min_bytes=len(plan) * example_bytes)
+    self._merge_alt_channels(images, len(plan), image_shape)
     examples = []
     for k, (ci, combo) in enumerate(plan):
       label = self._labels[ci] if self._labels else None
@@ -372,6 +522,9 @@ class ExamplesGenerator:
                                                  mean_coverage_per_sample)
     if not plan:
       return []
+    if getattr(self, '_alt_plan', None) or self._alt_mode != 'none':
+      raise NotImplementedError('alt-aligned pileups go through write_examples_in_region / encode_region; '
+                                'the fused device path does not merge alt images yet')
     if list(image_shape) != list(model.input_shape):
       raise ValueError('example shape %s != model shape %s' % (image_shape, list(model.input_shape)))
     pic = self._options.pic_options
@@ -458,8 +611,24 @@ def _concat_tables(tables: List[packing.ReadTable]):
   keys = [k for t in tables for k in _rank_keys(t)]
   uniq = {k: i for i, k in enumerate(sorted(set(keys)))}
   ranks = np.array([uniq[k] for k in keys], np.uint32)
-  opt = lambda name: (np.concatenate([getattr(t, name) for t in tables])
-                      if all(getattr(t, name) is not None for t in tables) else None)
+  def opt(name):
+    """Optional arrays: absent everywhere -> None; absent in some tables (an empty table, reads
+    without modification tags) -> zeros of the right length there."""
+    have = [getattr(t, name) for t in tables]
+    if all(h is None for h in have):
+      return None
+    like = next(h for h in have if h is not None)
+    parts = []
+    for t, h in zip(tables, have):
+      if h is None:
+        if name == 'read_sort_pos':
+          h = t.read_pos.astype(like.dtype)
+        elif name == 'read_aux':
+          h = np.zeros((t.n_reads,) + like.shape[1:], like.dtype)
+        else:                                  # per-base arrays
+          h = np.zeros(len(t.bases), like.dtype)
+      parts.append(h)
+    return np.concatenate(parts)
   merged = packing.ReadTable(
       n_reads=n, read_pos=cat('read_pos', np.int32), read_sort_pos=opt('read_sort_pos'),
       read_seq_off=np.concatenate(seq_off).astype(np.uint32),

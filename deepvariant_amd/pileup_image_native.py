@@ -29,9 +29,9 @@ class _Encoder:
                                             C.byref(self.handle)))
 
   def encode(self, batch: packing.PackedBatch, out_channels: int,
-             stream=None):
+             stream=None, min_bytes: int = 0):
     b, keep = batch.to_ctypes()
-    out = np.zeros(batch.out_bytes(out_channels), np.uint8)
+    out = np.zeros(max(batch.out_bytes(out_channels), min_bytes), np.uint8)
     rows = np.zeros(max(batch.n_items, 1), np.int32)
     _lib.check(_lib.lib().dv_encode_batch(
         self.handle, C.byref(b), out_channels, out.ctypes.data,

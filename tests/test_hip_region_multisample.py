@@ -172,3 +172,150 @@ def test_trim_reads_for_pileup_long_reads():
                           alignment_positions=original)
     np.testing.assert_array_equal(img, want, err_msg='candidate at %d' % v.start)
   assert moved > 50          # the trimming did cut reads (their starts moved to the window)
+
+
+def _haplotype_reads(rng, ref_seq, variants, n, lo, hi):
+  """Reads sampled from the reference or from one of the alt haplotypes of `variants`
+  [(pos, ref_bases, alt_bases)], with the matching CIGAR and ~1 % substitutions."""
+  reads = []
+  for i in range(n):
+    start = int(rng.integers(lo, hi))
+    length = int(rng.integers(150, 420))
+    end = start + length
+    carried = [v for v in variants if start + 12 <= v[0] and v[0] + len(v[1]) + 12 <= end and rng.random() < 0.55]
+    seq, cigar, pos = [], [], start
+    def add(op, ln):
+      if ln <= 0:
+        return
+      if cigar and cigar[-1].operation == op:
+        cigar[-1] = T.CigarUnit(op, cigar[-1].operation_length + ln)
+      else:
+        cigar.append(T.CigarUnit(op, ln))
+    for vpos, refb, altb in sorted(carried):
+      if vpos < pos:
+        continue                                      # overlapping variants: keep the first
+      seq.append(ref_seq[pos:vpos + 1])
+      add(1, vpos + 1 - pos)                          # up to and including the anchor base
+      if len(refb) == 1 and len(altb) == 1:           # SNP: replace the anchor itself
+        seq[-1] = seq[-1][:-1] + altb
+      elif len(altb) > len(refb):                     # insertion after the anchor
+        seq.append(altb[1:])
+        add(2, len(altb) - 1)
+      else:                                           # deletion after the anchor
+        add(3, len(refb) - 1)
+      pos = vpos + len(refb)
+    seq.append(ref_seq[pos:end])
+    add(1, end - pos)
+    bases = list(''.join(seq))
+    for j in range(len(bases)):
+      if rng.random() < 0.01:
+        bases[j] = 'ACGT'[int(rng.integers(0, 4))]
+    bases = ''.join(bases)
+    reads.append(T.Read(
+        fragment_name='m%d' % i, read_number=0, number_reads=1, fragment_length=0,
+        aligned_sequence=bases, aligned_quality=bytes(rng.integers(8, 50, size=len(bases)).astype(np.uint8)),
+        alignment=T.LinearAlignment(position=T.Position('chr1', start, bool(rng.integers(0, 2))),
+                                    mapping_quality=int(rng.integers(1, 61)), cigar=cigar)))
+    if rng.random() < 0.7:
+      reads[-1].info['HP'] = T.ListValue(values=[T.Value(int_value=int(rng.integers(0, 3)))])
+  return reads
+
+
+@pytest.mark.parametrize('mode,types', [('diff_channels', 'all'), ('base_channels', 'indels'),
+                                        ('rows', 'all'), ('single_row', 'indels')])
+def test_alt_aligned_pileups(mode, types):
+  """--alt_aligned_pileup (the PacBio / ONT models use diff_channels): per candidate and alt
+  allele the reads are trimmed to the window, realigned to the alt haplotype
+  (CreateHaplotype + RealignReadsToHaplotype, make_examples_native.cc:553-626) and drawn
+  against it; the alt images become two extra channels or extra row blocks
+  (FillPileupArray, pileup_image_native.h:214-307).
+
+  The product draws reference and alt images of the whole region in ONE encoder launch and
+  merges on the host; the oracle side restates the reference's per-candidate steps with
+  proto-shaped inputs.  The aligner itself is shared by both sides: it is pinned by the
+  reference's vectors in tests/test_fast_pass_aligner_cpu.py."""
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from oracle import oracle as O
+  rng = np.random.default_rng(101)
+  width, height = 99, 40
+  hw = (width - 1) // 2
+  channels = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype']
+  extra = {'diff_channels': ['diff_channels_alternate_allele_1', 'diff_channels_alternate_allele_2'],
+           'base_channels': ['base_channels_alternate_allele_1', 'base_channels_alternate_allele_2']}.get(mode, [])
+  pic = F.options(channels + extra, width, height, sort_by_haplotypes=True, min_mapq=1,
+                  alt_aligned_pileup=mode, types_to_alt_align=types)
+  enc_pic = F.options(channels, width, height, sort_by_haplotypes=True, min_mapq=1)   # what the oracle draws
+  options = T.MakeExamplesOptions(
+      pic_options=pic, sample_options=[T.SampleOptions(role='main', name='m', pileup_height=height)])
+  ref = _Ref(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=5000)))
+  variants = []
+  for pos in sorted(set(rng.integers(900, 3600, size=26).tolist())):
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+      refb = ref.seq[pos]
+      altb = [b for b in 'ACGT' if b != refb][int(rng.integers(0, 3))]
+    elif kind == 1:
+      refb = ref.seq[pos]
+      altb = refb + ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 9))))
+    else:
+      refb = ref.seq[pos:pos + 1 + int(rng.integers(1, 9))]
+      altb = refb[0]
+    if variants and pos < variants[-1][0] + 30:
+      continue
+    variants.append((pos, refb, altb))
+  reads = _haplotype_reads(rng, ref.seq, variants, 420, 600, 3700)
+  cands = []
+  for k, (pos, refb, altb) in enumerate(variants):
+    alts = [altb]
+    if k % 4 == 0:                                          # a second alt: three combinations
+      alts.append(refb[0] + 'TTG' if len(altb) <= len(refb) else [b for b in 'ACGT' if b != refb[0]][0])
+    support = {a: T.SupportingReads(read_names=[]) for a in alts}
+    for r in _query(reads, pos, pos + len(refb)):
+      if rng.random() < 0.5:
+        support[alts[int(rng.integers(0, len(alts)))]].read_names.append(
+            '%s/%d' % (r.fragment_name, r.read_number))
+    cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + len(refb), refb, alts),
+                                   allele_support=support))
+  gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=ref)
+  stats = {}
+  examples, shape = gen.encode_region(cands, [reads], [0], [0.0], stats, role='main')
+  mult = {'rows': 3, 'single_row': 2}.get(mode, 1)
+  assert shape == [height * mult, width, len(channels) + len(extra)]
+  k = n_alt_images = n_plain = 0
+  for cand in cands:
+    v = cand.variant
+    window = men.get_reference_bases_for_pileup(ref, v, width)
+    needs_alt = A.need_alt_alignment(pic, v)
+    overlapping = _query(reads, v.start - 5, v.end + 5)
+    if needs_alt:
+      r0, r1 = A.calculate_alignment_region(v, hw, len(ref.seq))
+      drawn, starts = A.trim_reads(overlapping, r0, r1)
+    else:
+      drawn, starts = overlapping, None
+    for combo in men.alt_allele_combinations(cand, pic.multi_allelic_mode):
+      img = np.frombuffer(pw.decode_example(examples[k])['image/encoded'][0], np.uint8).reshape(shape)
+      k += 1
+      want_ref = O.build_pileup(enc_pic, cand, window, drawn, v.start - hw, list(combo),
+                                pileup_height=height, alignment_positions=starts)
+      alts = [None, None]
+      if needs_alt:
+        for a, alt in enumerate(combo[:2]):
+          hap, h0, h1 = A.create_haplotype(ref, v, alt, hw)
+          assert len(hap) >= width
+          re = fpa.realign_reads_to_haplotype(hap, drawn, 'chr1', h0, h1, ref, men.DEFAULT_ALN_CONFIG)
+          kept = [(r, s) for r, s in zip(re, starts) if r is not None]
+          alts[a] = O.build_pileup(enc_pic, cand, hap[:width], [r for r, _ in kept], v.start - hw,
+                                   list(combo), pileup_height=height,
+                                   alignment_positions=[s for _, s in kept])
+          n_alt_images += 1
+      else:
+        n_plain += 1
+      want = A.fill_pileup_array(want_ref, alts, mode, A.get_alt_image_row_indices(mode, list(combo)))
+      if want.shape[2] < shape[2]:      # channel modes without alt images keep the two channels at zero
+        want = np.concatenate([want, np.zeros(want.shape[:2] + (shape[2] - want.shape[2],), np.uint8)], axis=2)
+      np.testing.assert_array_equal(img, want, err_msg='%s: candidate at %d, alts %s' % (mode, v.start, combo))
+  assert k == len(examples) and n_alt_images > 10
+  assert types == 'all' or n_plain > 0       # 'indels': SNP candidates draw untrimmed reads, no alt images
