@@ -28,7 +28,7 @@ import numpy as np
 from deepvariant_amd import dv_types as T
 
 K_DEFAULT_MINIMUM_READ_OVERLAP = 15   # alt_aligned_pileup_lib.h kDefaultMinimumReadOverlap
-K_REF_ALIGN_MARGIN = 20               # alt_aligned_pileup_lib.cc kRefAlignMargin
+K_REF_ALIGN_MARGIN = 0                # alt_aligned_pileup_lib.cc:62 kRefAlignMargin
 
 # nucleus CigarUnit::Operation values (third_party/nucleus/protos/cigar.proto:38-82)
 _REF_ADVANCING = frozenset((1, 3, 4, 8, 9))    # M D N = X

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 from deepvariant_amd import _lib
 from deepvariant_amd import dv_types as T
 
-K_REF_ALIGN_MARGIN = 20   # alt_aligned_pileup_lib.cc kRefAlignMargin
+K_REF_ALIGN_MARGIN = 0    # alt_aligned_pileup_lib.cc:62 kRefAlignMargin (the window realigner's is 20)
 
 BUILD_INDEX, INIT_LOCAL_ALIGNER, ALIGN_HAPLOTYPES, POSITION_MAPS, LOCAL_ALIGN_READS, SCORE_THRESHOLD = range(6)
 

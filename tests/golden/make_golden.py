@@ -128,7 +128,7 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__' and 'pacbio' not in sys.argv[1:]:
+if __name__ == '__main__' and not any(a.startswith('pacbio') for a in sys.argv[1:]):
   main()
 
 
@@ -270,3 +270,97 @@ def main_pacbio(n_keep=120):
 
 if __name__ == '__main__' and 'pacbio' in sys.argv[1:]:
   main_pacbio()
+
+
+# ---------------------------------------------------------------------------
+# PacBio golden, alt-aligned channels (channels 8 and 9 of golden.pacbio_examples: the
+# base_differs_from_ref channel of the reads realigned to the haplotype of alt 1 / alt 2,
+# make_examples_native.cc:553-626, pileup_image_native.h:246-271).
+# What the raw BAM + FASTA determine: for every indel candidate (types_to_alt_align =
+# "indels") the SET of alt-image rows -- the reference sorts them by phasing tags the
+# testdata does not carry.  This pins trim_reads + create_haplotype + the realigner
+# (FastPassAligner and the libssw restatement) against the reference's own output.
+# ---------------------------------------------------------------------------
+def alt_rows_for_example(opts, fasta, v, combo, trimmed, realign):
+  """-> [set of diff-channel rows of alt image k] for the (<= 2) alts of `combo`."""
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  hw = (opts.width - 1) // 2
+  call = T.DeepVariantCall(variant=v)
+  out = []
+  for alt in combo[:2]:
+    hap, h0, h1 = A.create_haplotype(fasta, v, alt, hw)
+    rows = set()
+    for r in realign(hap, trimmed, h0, h1):
+      if r is None:
+        continue
+      row = O.encode_read(opts, call, hap[:opts.width], r, v.start - hw, [])
+      if row is not None:
+        rows.add(np.ascontiguousarray(row[0][:, 5]).tobytes())
+    out.append(rows)
+  return out
+
+
+def main_pacbio_alt(keep_every=2):
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  opts = pacbio_options()
+  hw = (opts.width - 1) // 2
+  band = opts.reference_band_height
+  fasta = genomics_io.FastaReader(os.path.join(REF, 'input/grch38.chr20_and_21_10M.fa.gz'))
+  _, reads = genomics_io.read_bam(
+      os.path.join(REF, 'input/test_pacbio.chr20_100kbp_at_9mb.bam'), 'chr20',
+      8_900_000, 9_200_000)
+  reads = [r for r in reads if not (r.duplicate_fragment or r.failed_vendor_quality_checks or
+                                    r.secondary_alignment or r.supplementary_alignment)
+           and r.alignment.mapping_quality >= 1]
+  pic = T.PileupImageOptions(alt_aligned_pileup='diff_channels', types_to_alt_align='indels')
+  realign = lambda hap, trimmed, h0, h1: fpa.realign_reads_to_haplotype(
+      hap, trimmed, 'chr20', h0, h1, fasta, men.DEFAULT_ALN_CONFIG)
+  n_images = n_need = 0
+  rows, hits = [0, 0], [0, 0]
+  kept_examples, kept_reads = [], []
+  for rec in tfrecord.read_tfrecords(os.path.join(REF, 'golden.pacbio_examples.tfrecord.gz'),
+                                     verify_crc=True):
+    ex = pw.decode_example(rec)
+    shape = ex['image/shape']
+    img = np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(shape)
+    v = pw.decode_variant(ex['variant/encoded'][0])
+    combo = alt_combination(T.DeepVariantCall(variant=v),
+                            pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+    n_images += 1
+    if not A.need_alt_alignment(pic, v):
+      assert not img[:, :, 8:].any()          # SNPs: the two channels stay zero
+      continue
+    n_need += 1
+    overlapping = [r for r in reads if O.read_overlaps(
+        r, v.start - opts.read_overlap_buffer_bp, v.end + opts.read_overlap_buffer_bp)]
+    r0, r1 = A.calculate_alignment_region(v, hw, fasta.n_bases('chr20'))
+    trimmed, _ = A.trim_reads(overlapping, r0, r1)
+    ours = alt_rows_for_example(opts, fasta, v, combo, trimmed, realign)
+    if len(combo) == 1:
+      assert (img[:, :, 9] == img[:, :, 8]).all()   # a missing alt 2 repeats alt 1
+    for a in range(len(ours)):
+      gold = [r for r in range(band, shape[0]) if img[r, :, 8 + a].any()]
+      rows[a] += len(gold)
+      hits[a] += sum(np.ascontiguousarray(img[r, :, 8 + a]).tobytes() in ours[a] for r in gold)
+    if n_need % keep_every == 0:
+      haps = [A.create_haplotype(fasta, v, alt, hw) for alt in combo[:2]]
+      kept_examples.append(dict(
+          call=T.DeepVariantCall(variant=v), alt_alleles=combo, ref_window=haps[0][0],
+          read_idx=list(range(len(kept_reads), len(kept_reads) + len(trimmed))),
+          image=np.ascontiguousarray(img[:, :, 8:]), full=False,
+          hap2=haps[1][0] if len(haps) > 1 else '', hap_range=(haps[0][1], haps[0][2])))
+      kept_reads.extend(trimmed)
+  print('pacbio alt: images', n_images, 'indel candidates', n_need, 'alt rows', rows, 'reproduced', hits,
+        'kept', len(kept_examples), 'examples /', len(kept_reads), 'trimmed reads')
+  hap2 = '\n'.join(e['hap2'] for e in kept_examples)
+  golden_io.save(
+      os.path.join(ROOT, 'tests/golden/pacbio_alt_chr20.npz'), kept_reads, kept_examples,
+      hap2=np.frombuffer(hap2.encode(), np.uint8),
+      hap_range=np.array([e['hap_range'] for e in kept_examples], np.int64),
+      stats=np.array([n_images, n_need] + rows + hits, np.int64))
+
+
+if __name__ == '__main__' and 'pacbio_alt' in sys.argv[1:]:
+  main_pacbio_alt()

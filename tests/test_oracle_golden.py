@@ -107,3 +107,65 @@ def test_golden_pacbio_rows():
     n_hit += b
   assert len(examples) == 134 and n_rows > 4000
   assert n_hit == n_rows
+
+
+# ---------------------------------------------------------------------------
+# PacBio golden, the two alt-aligned channels (8, 9).  Fixture: tests/golden/
+# pacbio_alt_chr20.npz (make_golden.py pacbio_alt): every second indel candidate of
+# golden.pacbio_examples with ITS window-trimmed reads, the alt haplotypes and the golden
+# alt channels.  The product's realigner (libdvhip: FastPassAligner + the libssw
+# restatement, over the C ABI) realigns the reads to each haplotype, the oracle draws the
+# base_differs_from_ref row of every realigned read, and every golden alt-channel row must
+# be one of them (row ORDER needs the phasing tags the testdata lacks).
+# ---------------------------------------------------------------------------
+PACBIO_ALT_FIXTURE = os.path.join(os.path.dirname(__file__), 'golden', 'pacbio_alt_chr20.npz')
+
+
+class _HaplotypeContig:
+  """ref_reader stand-in: the realigner only asks for the contig length here (margin 0)."""
+
+  def n_bases(self, contig):
+    return 1 << 40
+
+  def get_bases(self, contig, start, end):
+    raise AssertionError('kRefAlignMargin is 0: no reference padding is fetched')
+
+
+def test_golden_pacbio_alt_aligned_channels():
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  from tests.golden.make_golden import pacbio_options
+  reads, examples, z = golden_io.load(PACBIO_ALT_FIXTURE)
+  # measured by make_golden.py over ALL 401 golden images: 131 indel candidates, every one
+  # of their 4,406 alt-1 rows and 1,123 alt-2 rows reproduced
+  assert z['stats'].tolist() == [401, 131, 4406, 1123, 4406, 1123]
+  opts = pacbio_options()
+  hw = (opts.width - 1) // 2
+  band = opts.reference_band_height
+  hap2 = bytes(z['hap2']).decode().split('\n')
+  n_rows = n_hit = n_alt2 = 0
+  for k, ex in enumerate(examples):
+    call, combo = ex['call'], ex['alt_alleles']
+    v = call.variant
+    trimmed = [reads[i] for i in ex['read_idx']]
+    h0, h1 = (int(x) for x in z['hap_range'][k])
+    assert h0 == v.start - hw
+    img = ex['image']                                     # [100, 147, 2] = golden channels 8, 9
+    for a, hap in enumerate([ex['ref_window'], hap2[k]][:len(combo)]):
+      realigned = fpa.realign_reads_to_haplotype(hap, trimmed, v.reference_name, h0, h1,
+                                                 _HaplotypeContig(), men.DEFAULT_ALN_CONFIG)
+      ours = set()
+      for r in realigned:
+        if r is None:
+          continue
+        row = O.encode_read(opts, call, hap[:opts.width], r, v.start - hw, [])
+        if row is not None:
+          ours.add(np.ascontiguousarray(row[0][:, 5]).tobytes())
+      gold = [r for r in range(band, img.shape[0]) if img[r, :, a].any()]
+      n_rows += len(gold)
+      n_alt2 += a
+      n_hit += sum(np.ascontiguousarray(img[r, :, a]).tobytes() in ours for r in gold)
+    if len(combo) == 1:
+      np.testing.assert_array_equal(img[:, :, 1], img[:, :, 0])
+  assert len(examples) == 65 and n_alt2 > 5 and n_rows > 2500
+  assert n_hit == n_rows
