@@ -13,7 +13,8 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdvhip.so')
+# DV_LIB_PATH: A/B runs of two builds (tools/); the product always loads the in-tree library
+LIB_PATH = os.environ.get('DV_LIB_PATH') or os.path.join(_HERE, 'libdvhip.so')
 
 DV_MAX_CHANNELS = 16
 DV_READ_AUX_STRIDE = 8

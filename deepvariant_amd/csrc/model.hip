@@ -264,11 +264,15 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   const int n_full = p.n_chunks / kSlabChunks;
   const int rem = p.n_chunks - n_full * kSlabChunks;
   for (int s = 0; s < n_full; ++s) {
-    const bool more = s + 1 < p.n_slabs;
-    if (more) DV_LOAD_SLAB(s + 1)
+    // The next slab's global loads are UNCONDITIONAL (the last trip re-reads its own slab
+    // into the idle buffer): behind an `if` the compiler has to assume at the first
+    // pixel-fragment wait that they were not issued and emits vmcnt(7) -- which, when they
+    // were, drains the whole four-chunk prefetch queue at every slab start.
+    const int next = s + 1 < p.n_slabs ? s + 1 : s;
+    DV_LOAD_SLAB(next)
     conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base,
                                    xf, acc);
-    if (more) DV_STORE_SLAB((s + 1) & 1)
+    DV_STORE_SLAB((s + 1) & 1)
     __syncthreads();
   }
   // Tail slab (n_chunks % 8 chunks), in straight-line groups of 4: K is padded
