@@ -367,10 +367,10 @@ def parity_sample(host_batch, opts, C, model, images, probs, n=64):
 
 def pmc_traffic(n_items):
   """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-  gfx950 x2 correction + WRITE_SIZE; profiles/r01q_pmc_hbm_traffic.txt).  bench.py cannot
+  gfx950 x2 correction + WRITE_SIZE; profiles/r02_pmc_hbm_traffic.txt).  bench.py cannot
   run the counter passes itself, so this is only reported for the batch they were taken at."""
   path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                      'r01q_pmc_traffic.json')
+                      'r02_pmc_traffic.json')
   try:
     with open(path) as f:
       t = json.load(f)
