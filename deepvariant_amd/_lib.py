@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     'dv_aligner_read_alignment', 'dv_aligner_merge_alignment', 'dv_aligner_is_normalized',
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
     'dv_merge_cigar_op', 'dv_local_align',
+    'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free',
 ]
 
 
@@ -162,6 +163,19 @@ class DvLocalAlignment(C.Structure):
               ('cigar', C.c_char * 512)]
 
 
+class DvAlleleCounterOptions(C.Structure):
+  _fields_ = [('interval_start', C.c_int64), ('interval_end', C.c_int64),
+              ('reads_interval_start', C.c_int64), ('reads_interval_end', C.c_int64),
+              ('ref_bases', C.c_char_p), ('ref_start', C.c_int64), ('n_ref_bases', C.c_int64),
+              ('contig_n_bases', C.c_int64), ('min_mapping_quality', C.c_int32),
+              ('min_base_quality', C.c_int32), ('keep_legacy_behavior', C.c_int32)]
+
+
+class DvAlleleEvent(C.Structure):
+  _fields_ = [('position', C.c_int32), ('read', C.c_uint32), ('read_offset', C.c_uint32),
+              ('length', C.c_uint16), ('type', C.c_uint8), ('low_quality', C.c_uint8)]
+
+
 class DvModelDesc(C.Structure):
   _fields_ = [('height', C.c_int32), ('width', C.c_int32),
               ('channels', C.c_int32), ('num_classes', C.c_int32),
@@ -249,6 +263,10 @@ def lib():
     l.dv_positions_map.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
     l.dv_merge_cigar_op.argtypes = [C.c_void_p, C.c_int32, C.c_char, C.c_int32, C.c_int32]
     l.dv_local_align.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int32] * 4 + [C.c_void_p]
+    l.dv_count_alleles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_allele_counts_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    l.dv_allele_counts_free.argtypes = [C.c_void_p]
+    l.dv_allele_counts_free.restype = None
     _lib = l
   return _lib
 

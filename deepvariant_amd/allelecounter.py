@@ -1,0 +1,289 @@
+"""Host mirror of the reference's AlleleCounter over the C ABI (`dv_count_alleles`).
+
+  AlleleCounter(ref, range, candidate_positions, options)   deepvariant/allelecounter.h:206-518
+  .add(read, sample) / .counts() / .summary_counts()        deepvariant/allelecounter.cc:873-1008
+  sum_allele_counts / total_allele_counts                    deepvariant/allelecounter.cc:78-203
+
+The reference adds reads one by one on the CPU; here `add` only queues them and the first
+call that needs results packs the queue (packing.ReadTable) and counts the whole region in
+ONE kernel launch (deepvariant_amd/csrc/allele_counter.hip).  There is no CPU path.
+normalize_cigar restates AlleleCounter::NormalizeCigar (:777-845) for --normalize_reads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from deepvariant_amd import _lib
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import packing
+
+REFERENCE, SUBSTITUTION, INSERTION, DELETION, SOFT_CLIP = 1, 2, 3, 4, 5   # AlleleType
+
+
+class Allele:
+  """deepvariant.proto Allele: bases, type, count, is_low_quality."""
+
+  def __init__(self, bases: str, type_: int, count: int = 1, is_low_quality: bool = False):
+    self.bases, self.type, self.count, self.is_low_quality = bases, type_, count, is_low_quality
+
+  def __repr__(self):
+    return 'Allele(%r, %d, %d%s)' % (self.bases, self.type, self.count, ', low quality' if self.is_low_quality else '')
+
+
+class AlleleCount:
+  """deepvariant.proto AlleleCount (the fields the candidate caller reads)."""
+
+  def __init__(self, reference_name: str, position: int, ref_base: str):
+    self.position = T.Position(reference_name, position, False)
+    self.ref_base = ref_base
+    self.ref_supporting_read_count = 0
+    self.read_alleles: Dict[str, Allele] = {}
+    self.track_ref_reads = False
+
+
+def sum_allele_counts(allele_count: AlleleCount, include_low_quality: bool = False) -> List[Allele]:
+  """SumAlleleCounts (:78-117): std::map order = (bases, type) ascending, then the synthetic
+  reference allele."""
+  sums: Dict[Tuple[str, int], int] = {}
+  for allele in allele_count.read_alleles.values():
+    if include_low_quality or not allele.is_low_quality:
+      k = (allele.bases, allele.type)
+      sums[k] = sums.get(k, 0) + 1
+  out = [Allele(b, t, n) for (b, t), n in sorted(sums.items())]
+  if allele_count.ref_supporting_read_count > 0 and not allele_count.track_ref_reads:
+    out.append(Allele(allele_count.ref_base, REFERENCE, allele_count.ref_supporting_read_count))
+  return out
+
+
+def total_allele_counts(allele_count: AlleleCount, include_low_quality: bool = False) -> int:
+  """TotalAlleleCounts (:165-176)."""
+  n = sum(1 for a in allele_count.read_alleles.values()
+          if (not a.is_low_quality or include_low_quality) and a.type != REFERENCE)
+  return n + allele_count.ref_supporting_read_count
+
+
+class AlleleCounter:
+  def __init__(self, ref_reader, reference_name: str, start: int, end: int,
+               candidate_positions: Sequence[int] = (), min_mapping_quality: int = 0,
+               min_base_quality: int = 0, keep_legacy_behavior: bool = False,
+               full_range: Optional[Tuple[int, int]] = None, track_ref_reads: bool = False):
+    if track_ref_reads or candidate_positions:
+      raise NotImplementedError('track_ref_reads (REFERENCE read alleles at candidate positions)')
+    self._ref = ref_reader
+    self._contig, self._start, self._end = reference_name, int(start), int(end)
+    self._reads_start = min(self._start, full_range[0]) if full_range else self._start
+    self._reads_end = max(self._end, full_range[1]) if full_range else self._end
+    self._opt = (int(min_mapping_quality), int(min_base_quality), bool(keep_legacy_behavior))
+    self._reads: List = []
+    self._table: Optional[packing.ReadTable] = None
+    self._counts: Optional[List[AlleleCount]] = None
+    self._n_counted = 0
+
+  # ---- the reference's interface
+  def interval_length(self) -> int:
+    return self._end - self._start
+
+  def add(self, read, sample: str = ''):
+    if self._table is not None:
+      raise ValueError('reads were handed over as a packed table; add() cannot be mixed in')
+    self._reads.append(read)
+    self._counts = None
+
+  def add_table(self, table: packing.ReadTable):
+    """All reads of the region at once, already packed (packing.ReadTable.from_bam / from_reads)."""
+    if self._reads:
+      raise ValueError('add() was used; add_table() cannot be mixed in')
+    self._table = table
+    self._counts = None
+
+  def counts(self) -> List[AlleleCount]:
+    if self._counts is None:
+      self._run()
+    return self._counts
+
+  def n_counted_reads(self) -> int:
+    self.counts()
+    return self._n_counted
+
+  def summary_counts(self, left_padding: int = 0, right_padding: int = 0):
+    """SummaryCounts (:986-1008) -> [(reference_name, position, ref_base, ref_supporting_read_count,
+    total_read_count)]."""
+    counts = self.counts()
+    if left_padding < 0 or right_padding < 0 or left_padding + right_padding >= len(counts):
+      raise ValueError('Check failed: left_padding + right_padding < counts_.size()')
+    return [(self._contig, c.position.position, c.ref_base, c.ref_supporting_read_count, total_allele_counts(c))
+            for c in counts[left_padding:len(counts) - right_padding]]
+
+  # ---- the launch
+  def _run(self):
+    table = self._table if self._table is not None else packing.ReadTable.from_reads(self._reads)
+    n_contig = self._ref.n_bases(self._contig)
+    # reference window: the reads interval plus room for the longest deletion anchored inside it
+    ops, lens = table.cigar & 15, table.cigar >> 4
+    margin = int(lens[ops == 3].max()) + 1 if (ops == 3).any() else 1
+    w0 = max(0, self._reads_start - 1)
+    w1 = min(n_contig, self._reads_end + margin)
+    window = self._ref.get_bases(self._contig, w0, w1).encode()
+    interval_ref = self._ref.get_bases(self._contig, self._start, self._end)
+    opt = _lib.DvAlleleCounterOptions(
+        self._start, self._end, self._reads_start, self._reads_end, window, w0, len(window), n_contig,
+        self._opt[0], self._opt[1], int(self._opt[2]))
+    b, keep = packing.PackedBatch(table=table, width=3).to_ctypes()
+    handle = C.c_void_p()
+    lib = _lib.lib()
+    _lib.check(lib.dv_count_alleles(C.byref(b), C.byref(opt), C.byref(handle), None))
+    del keep
+    try:
+      refc = C.POINTER(C.c_int32)()
+      events = C.POINTER(_lib.DvAlleleEvent)()
+      n_events, n_counted = C.c_uint32(), C.c_int32()
+      length = lib.dv_allele_counts_arrays(handle, C.byref(refc), C.byref(events), C.byref(n_events),
+                                           C.byref(n_counted))
+      counts = [AlleleCount(self._contig, self._start + i, interval_ref[i]) for i in range(length)]
+      for i in range(length):
+        counts[i].ref_supporting_read_count = int(refc[i])
+      seq_off = table.read_seq_off
+      bases = table.bases
+      for k in range(n_events.value):
+        ev = events[k]
+        s0 = int(seq_off[ev.read]) + ev.read_offset
+        if ev.type == SUBSTITUTION:
+          text = chr(bases[s0])
+        else:
+          anchor_pos = self._start + ev.position          # the base the indel is anchored on
+          prev = chr(bases[s0 - 1]) if ev.read_offset > 0 else window[anchor_pos - w0:anchor_pos - w0 + 1].decode()
+          if ev.type == DELETION:
+            text = prev + window[anchor_pos + 1 - w0:anchor_pos + 1 - w0 + ev.length].decode()
+          else:
+            text = prev + bytes(bases[s0:s0 + ev.length]).decode()
+        # a later read with the same key overwrites (read_alleles is a map keyed by ReadKey)
+        counts[ev.position].read_alleles[table.keys[ev.read]] = Allele(text, ev.type, 1, bool(ev.low_quality))
+      self._counts, self._n_counted = counts, int(n_counted.value)
+    finally:
+      lib.dv_allele_counts_free(handle)
+
+
+# ---------------------------------------------------------------- NormalizeCigar (host)
+_MATCH_OPS = (1, 8, 9)
+
+
+def _is_match(op) -> bool:
+  return op in _MATCH_OPS
+
+
+def _merge_operations(cigar: List[List[int]], i: int) -> bool:
+  """MergeOperations (:561-590) on cigar[i], cigar[i + 1] = [op, length] pairs."""
+  a, b = cigar[i], cigar[i + 1]
+  if a[0] == b[0] or (_is_match(a[0]) and _is_match(b[0])):
+    a[1] += b[1]
+    b[1] = 0
+  elif a[0] in (2, 3) and b[0] in (2, 3):
+    lo, rest = min(a[1], b[1]), max(a[1], b[1]) - min(a[1], b[1])
+    if a[1] > b[1]:
+      b[0] = a[0]
+    a[0], a[1] = 1, lo
+    b[1] = rest
+  else:
+    return False
+  return True
+
+
+def _swipe_and_merge(cigar: List[List[int]]) -> bool:
+  """SwipeAndMerge (:706-730)."""
+  modified, merged = False, True
+  while merged:
+    merged = False
+    before = len(cigar)
+    cigar[:] = [c for c in cigar if c[1] != 0]
+    modified |= len(cigar) < before
+    for i in range(len(cigar) - 1):
+      if _merge_operations(cigar, i):
+        merged = True
+        break
+    modified |= merged
+  return modified
+
+
+def _handle_heading_indel(cigar: List[List[int]], i: int) -> int:
+  """HandleHeadingIndel (:630-648)."""
+  if not (i == 0 or (cigar and cigar[0][0] == 5 and i == 1)):
+    raise ValueError('Check failed: heading indel position')
+  if i >= len(cigar):
+    return 0
+  if cigar[i][0] == 3:
+    shift = cigar[i][1]
+    del cigar[i]
+    return shift
+  if cigar[i][0] == 2:
+    shift = -cigar[i][1]
+    cigar[i][0] = 1
+    return shift
+  return 0
+
+
+def _shift_operation(shift: int, i: int, cigar: List[List[int]]) -> int:
+  """ShiftOperation (:654-693)."""
+  if i == 0 or (cigar and i == 1 and cigar[0][0] == 5):
+    return _handle_heading_indel(cigar, i)
+  prev = cigar[i - 1]
+  if prev[0] == 5:
+    raise ValueError('Check failed: soft clip in the middle of a CIGAR')
+  if not _is_match(prev[0]):
+    return 0
+  if shift > prev[1]:
+    raise ValueError('Check failed: shift <= prev_op->operation_length()')
+  prev[1] -= shift
+  if i + 1 == len(cigar):
+    cigar.insert(i + 1, [1, shift])
+  else:
+    cigar[i + 1][1] += shift
+  return 0
+
+
+def normalize_cigar(read_seq: str, interval_offset: int, cigar: Sequence, ref_bases: str):
+  """AlleleCounter::NormalizeCigar (:777-845): left-aligns indels against `ref_bases` (the
+  counter's reads-interval reference; `interval_offset` = read start in it).
+  -> (is_modified, [CigarUnit], read_shift)."""
+  norm = [[c.operation, c.operation_length] for c in cigar]
+  read_shift = 0
+  if not norm:
+    return False, [], 0
+  modified = False
+  for _ in range(100000000):
+    read_offset = 0
+    cur = interval_offset + read_shift
+    prev_len = norm[0][1]
+    shifted = False
+    for i, (op, n) in enumerate(norm):
+      shift = 0
+      if op in (2, 3):
+        while prev_len > 0 and (
+            (op == 3 and read_offset > 0 and cur + n - 1 < len(ref_bases) and
+             read_seq[read_offset - 1] == ref_bases[cur + n - 1]) or
+            (op == 2 and cur > 0 and read_offset + n - 1 < len(read_seq) and
+             read_seq[read_offset + n - 1] == ref_bases[cur - 1])):
+          cur -= 1
+          prev_len -= 1
+          read_offset -= 1
+          shift += 1
+        if shift > 0:
+          read_shift += _shift_operation(shift, i, norm)
+          modified = shifted = True
+          break
+      prev_len = n
+      if op in _MATCH_OPS:
+        read_offset += n
+        cur += n
+      elif op in (5, 2):
+        read_offset += n
+      elif op in (3, 7, 4):
+        cur += n
+    merged = _swipe_and_merge(norm)
+    modified |= merged
+    if not shifted and not merged:
+      break
+  read_shift += _handle_heading_indel(norm, 0)
+  return modified, [T.CigarUnit(op, n) for op, n in norm], read_shift

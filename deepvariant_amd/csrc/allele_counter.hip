@@ -1,0 +1,340 @@
+// allele_counter.hip -- AlleleCounter::Add for a whole region's reads in one launch
+// (the per-read, per-base integer work in front of the hot path).
+//
+// Replaces the read loop around AlleleCounter::Add (deepvariant/allelecounter.cc:873-979,
+// called per read from make_examples_core.py's region processor) together with
+// MakeIndelReadAllele (:402-469), GetPrevBase (:386-400), CanBasesBeUsed (:206-229) and
+// AddReadAlleles (:471-543).  Input is the packed read table the encoder already uses
+// (dv_batch's read fields); output is what AlleleCount holds per position:
+//   * ref_supporting_read_count[interval length]          (atomic adds)
+//   * one EVENT per non-reference read allele that landed in the interval
+//     (position, read, type, low-quality flag, where its bases are) -- the host turns
+//     events into read_alleles maps / allele sums; no string ever exists on the device.
+// One wave per read: CIGAR operations are walked in order (wave-uniform), the bases of an
+// alignment-match run are handled 64 at a time, indel quality / canonical-base checks are
+// wave reductions.  The reference's "an indel supersedes the base it is anchored on" rule
+// (AddReadAlleles: of two consecutive read alleles at the same position the first is
+// dropped) is a one-entry pending slot per wave.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "dv_internal.h"
+
+struct dv_allele_counts {
+  std::vector<int32_t> ref_count;
+  std::vector<dv_allele_event> events;   // sorted by (position, read, read_offset)
+  int32_t n_reads_counted = 0;
+};
+
+namespace {
+
+enum : int { kRef = 1, kSub = 2, kIns = 3, kDel = 4, kSoft = 5 };   // AlleleType
+enum : int { opM = 1, opI = 2, opD = 3, opN = 4, opS = 5, opH = 6, opP = 7, opEQ = 8, opX = 9 };
+
+struct CountArgs {
+  int32_t n_reads;
+  const int32_t* read_pos;
+  const uint32_t* seq_off;
+  const uint32_t* cigar_off;
+  const uint8_t* mapq;
+  const uint8_t* bases;
+  const uint8_t* quals;
+  const uint32_t* cigar;
+  const uint8_t* ref;        // reference bases of [ref_start, ref_start + n_ref)
+  int64_t ref_start, n_ref;
+  int64_t reads_start, reads_end;   // IsValidRefOffset: the reads interval
+  int64_t interval_start, interval_len;
+  int64_t contig_len;
+  int32_t min_mapq, min_bq, legacy;
+  int32_t* ref_count;        // [interval_len]
+  dv_allele_event* events;
+  uint32_t event_cap;
+  uint32_t* counters;        // [0] events wanted, [1] reads counted, [2] reference window too small
+};
+
+__device__ __forceinline__ bool canonical(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+
+struct Entry {
+  bool have;
+  int64_t abs_pos;           // absolute reference position of the allele
+  int type, low;
+  uint32_t read_offset, length;
+};
+
+__device__ __forceinline__ void emit(const CountArgs& a, uint32_t read, const Entry& e) {
+  const int64_t p = e.abs_pos - a.interval_start;
+  if (p < 0 || p >= a.interval_len) return;            // IsValidIntervalOffset
+  if (e.type == kRef) {
+    if (!e.low) atomicAdd(&a.ref_count[p], 1);
+    return;
+  }
+  const uint32_t slot = atomicAdd(&a.counters[0], 1u);
+  if (slot < a.event_cap) {
+    dv_allele_event ev;
+    ev.position = static_cast<int32_t>(p);
+    ev.read = read;
+    ev.read_offset = e.read_offset;
+    ev.length = e.length > 0xffffu ? 0xffffu : static_cast<uint16_t>(e.length);
+    ev.type = static_cast<uint8_t>(e.type);
+    ev.low_quality = static_cast<uint8_t>(e.low);
+    a.events[slot] = ev;
+  }
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// One base of an alignment-match run -> its read allele (or none).
+__device__ __forceinline__ Entry base_entry(const CountArgs& a, uint32_t s0, int64_t abs_pos, uint32_t b) {
+  Entry e{};
+  if (abs_pos < a.reads_start || abs_pos >= a.reads_end) return e;        // IsValidRefOffset
+  const uint8_t base = a.bases[s0 + b], q = a.quals[s0 + b];
+  if (!canonical(base) || (a.legacy && q < a.min_bq)) return e;            // CanBasesBeUsed(len 1)
+  e.have = true;
+  e.abs_pos = abs_pos;
+  e.type = a.ref[abs_pos - a.ref_start] == base ? kRef : kSub;
+  e.low = (!a.legacy && q < a.min_bq) ? 1 : 0;
+  e.read_offset = b;
+  e.length = 1;
+  return e;
+}
+
+__global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= static_cast<uint32_t>(a.n_reads)) return;
+  if (a.mapq[r] < a.min_mapq) return;
+  if (lane == 0) atomicAdd(&a.counters[1], 1u);
+  const uint32_t s0 = a.seq_off[r];
+  uint32_t read_offset = 0;
+  int64_t abs_pos = a.read_pos[r];
+  Entry pending{};
+  for (uint32_t c = a.cigar_off[r]; c < a.cigar_off[r + 1]; ++c) {
+    const uint32_t word = a.cigar[c];
+    const int op = word & 15;
+    const uint32_t n = word >> 4;
+    if (op == opM || op == opEQ || op == opX) {
+      // nothing later can share the pending entry's position any more
+      if (pending.have && lane == 0) emit(a, r, pending);
+      pending.have = false;
+      for (uint32_t i = lane; i + 1 < n; i += 64) {
+        const Entry e = base_entry(a, s0, abs_pos + i, read_offset + i);
+        if (e.have) emit(a, r, e);
+      }
+      if (n > 0) pending = base_entry(a, s0, abs_pos + n - 1, read_offset + n - 1);   // may be superseded
+      read_offset += n;
+      abs_pos += n;
+    } else if (op == opI || op == opS || op == opD) {
+      // MakeIndelReadAllele: anchored on the base before it.  An allele outside the interval is
+      // dropped by AddReadAlleles whatever it is (and so is anything it could supersede), so
+      // its validity -- which may need reference bases far from the interval -- is not computed.
+      Entry e{};
+      int prev = -1;
+      const int64_t rel = abs_pos - 1 - a.interval_start;
+      const bool wanted = rel >= 0 && rel < a.interval_len;
+      if (!wanted) {
+        // fall through with prev = -1: no entry
+      } else if (read_offset == 0) {
+        const int64_t pp = abs_pos - 1;                                  // RefBases(ref_offset - 1, 1)
+        if (pp >= 0 && pp < a.contig_len) {
+          if (pp >= a.ref_start && pp < a.ref_start + a.n_ref) {
+            prev = a.ref[pp - a.ref_start];
+          } else if (lane == 0) {
+            atomicAdd(&a.counters[2], 1u);
+          }
+        }
+      } else {
+        prev = a.bases[s0 + read_offset - 1];
+      }
+      bool ok = prev >= 0 && canonical(static_cast<uint8_t>(prev));
+      int low = 0;
+      if (ok && op != opD) {                                             // CanBasesBeUsed over the run
+        int qsum = 0, bad = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+          const uint8_t b = a.bases[s0 + read_offset + i], q = a.quals[s0 + read_offset + i];
+          qsum += q;
+          bad += (!canonical(b) || (a.legacy && q < a.min_bq)) ? 1 : 0;
+        }
+        qsum = wave_sum(qsum);
+        bad = wave_sum(bad);
+        ok = bad == 0;
+        low = (!a.legacy && static_cast<int64_t>(qsum) < static_cast<int64_t>(a.min_bq) * n) ? 1 : 0;
+      }
+      if (ok && op == opD) {                                             // the deleted reference bases
+        if (n == 0 || abs_pos < 0 || abs_pos + n > a.contig_len) {
+          ok = false;
+        } else if (abs_pos < a.ref_start || abs_pos + n > a.ref_start + a.n_ref) {
+          ok = false;
+          if (lane == 0) atomicAdd(&a.counters[2], 1u);
+        } else {
+          int bad = 0;
+          for (uint32_t i = lane; i < n; i += 64) bad += canonical(a.ref[abs_pos - a.ref_start + i]) ? 0 : 1;
+          ok = wave_sum(bad) == 0;
+        }
+      }
+      if (ok) {
+        e.have = true;
+        e.abs_pos = abs_pos - 1;
+        e.type = op == opD ? kDel : op == opI ? kIns : kSoft;
+        e.low = low;
+        e.read_offset = read_offset;
+        e.length = n;
+      }
+      // AddReadAlleles: of two consecutive alleles at one position the first is dropped.  A
+      // skipped allele (position -1 in the reference) never equals a real position.
+      if (pending.have && !(e.have && e.abs_pos == pending.abs_pos) && lane == 0) emit(a, r, pending);
+      pending = e;
+      if (op == opD) {
+        abs_pos += n;
+      } else {
+        read_offset += n;
+      }
+    } else if (op == opN || op == opP) {
+      abs_pos += n;
+    }
+  }
+  if (pending.have && lane == 0) emit(a, r, pending);
+}
+
+template <typename T>
+int to_device(dv::DeviceBuffer& buf, const T* src, size_t count, int memory, const T** out, hipStream_t stream) {
+  if (memory != DV_MEM_HOST) {
+    *out = src;
+    return DV_OK;
+  }
+  if (int rc = buf.reserve(std::max<size_t>(count, 1) * sizeof(T))) return rc;
+  DV_HIP_CHECK(hipMemcpyAsync(buf.ptr, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+  *out = static_cast<const T*>(buf.ptr);
+  return DV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_allele_counts** out, void* stream_v) {
+  if (!b || !o || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: null");
+  if (b->n_reads < 0 || o->interval_end < o->interval_start || !o->ref_bases || o->n_ref_bases <= 0 ||
+      o->min_base_quality < 0 || o->min_mapping_quality < 0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: bad argument");
+  }
+  if (b->n_reads && (!b->read_pos || !b->read_seq_off || !b->read_cigar_off || !b->read_mapq || !b->bases ||
+                     !b->quals || !b->cigar)) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: read table field missing");
+  }
+  const int64_t reads_start = std::min(o->interval_start, o->reads_interval_start);
+  const int64_t reads_end = std::max(o->interval_end, o->reads_interval_end);
+  if (o->ref_start > reads_start || o->ref_start + o->n_ref_bases < reads_end) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: the reference window must cover the reads interval");
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    return dv::fail(DV_ERR_NO_DEVICE, "dv_count_alleles: no HIP device (there is no CPU fallback)");
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int64_t len = o->interval_end - o->interval_start;
+  auto res = std::make_unique<dv_allele_counts>();
+  res->ref_count.assign(static_cast<size_t>(len), 0);
+  if (b->n_reads == 0 || len == 0) {
+    *out = res.release();
+    return DV_OK;
+  }
+  dv::DeviceBuffer up[7], d_ref, d_cnt, d_ev, d_ctr;
+  struct Release {
+    dv::DeviceBuffer* v[11];
+    ~Release() {
+      for (dv::DeviceBuffer* p : v) p->release();
+    }
+  } rel{{&up[0], &up[1], &up[2], &up[3], &up[4], &up[5], &up[6], &d_ref, &d_cnt, &d_ev, &d_ctr}};
+  CountArgs a{};
+  a.n_reads = b->n_reads;
+  const size_t n = static_cast<size_t>(b->n_reads);
+  if (int rc = to_device(up[0], b->read_pos, n, b->memory, &a.read_pos, stream)) return rc;
+  if (int rc = to_device(up[1], b->read_seq_off, n + 1, b->memory, &a.seq_off, stream)) return rc;
+  if (int rc = to_device(up[2], b->read_cigar_off, n + 1, b->memory, &a.cigar_off, stream)) return rc;
+  if (int rc = to_device(up[3], b->read_mapq, n, b->memory, &a.mapq, stream)) return rc;
+  if (int rc = to_device(up[4], b->bases, b->n_bases, b->memory, &a.bases, stream)) return rc;
+  if (int rc = to_device(up[5], b->quals, b->n_bases, b->memory, &a.quals, stream)) return rc;
+  if (int rc = to_device(up[6], b->cigar, b->n_cigar, b->memory, &a.cigar, stream)) return rc;
+  if (int rc = d_ref.reserve(static_cast<size_t>(o->n_ref_bases))) return rc;
+  DV_HIP_CHECK(hipMemcpyAsync(d_ref.ptr, o->ref_bases, static_cast<size_t>(o->n_ref_bases), hipMemcpyHostToDevice,
+                              stream));
+  a.ref = static_cast<const uint8_t*>(d_ref.ptr);
+  a.ref_start = o->ref_start;
+  a.n_ref = o->n_ref_bases;
+  a.reads_start = reads_start;
+  a.reads_end = reads_end;
+  a.interval_start = o->interval_start;
+  a.interval_len = len;
+  a.contig_len = o->contig_n_bases > 0 ? o->contig_n_bases : o->ref_start + o->n_ref_bases;
+  a.min_mapq = o->min_mapping_quality;
+  a.min_bq = o->min_base_quality;
+  a.legacy = o->keep_legacy_behavior ? 1 : 0;
+  if (int rc = d_cnt.reserve(static_cast<size_t>(len) * sizeof(int32_t))) return rc;
+  if (int rc = d_ctr.reserve(4 * sizeof(uint32_t))) return rc;
+  a.ref_count = static_cast<int32_t*>(d_cnt.ptr);
+  a.counters = static_cast<uint32_t*>(d_ctr.ptr);
+  // events: substitutions are a few per cent of the bases, indels at most one per CIGAR op;
+  // the counter keeps counting past the capacity, so a second pass sizes it exactly
+  uint32_t cap = b->n_cigar + b->n_bases / 8 + 4096;
+  uint32_t ctr[4] = {0, 0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    if (int rc = d_ev.reserve(static_cast<size_t>(cap) * sizeof(dv_allele_event))) return rc;
+    a.events = static_cast<dv_allele_event*>(d_ev.ptr);
+    a.event_cap = cap;
+    DV_HIP_CHECK(hipMemsetAsync(d_cnt.ptr, 0, static_cast<size_t>(len) * sizeof(int32_t), stream));
+    DV_HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 4 * sizeof(uint32_t), stream));
+    {
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      hipLaunchKernelGGL(count_alleles_kernel, dim3((b->n_reads + 3) / 4), dim3(256), 0, stream, a);
+    }
+    DV_HIP_CHECK(hipGetLastError());
+    DV_HIP_CHECK(hipMemcpyAsync(ctr, d_ctr.ptr, sizeof(ctr), hipMemcpyDeviceToHost, stream));
+    DV_HIP_CHECK(hipStreamSynchronize(stream));
+    if (ctr[0] <= cap) break;
+    cap = ctr[0];
+  }
+  if (ctr[2] != 0) {
+    return dv::fail(DV_ERR_BAD_INPUT,
+                    "dv_count_alleles: an indel reaches outside the reference window (pass more margin)");
+  }
+  res->n_reads_counted = static_cast<int32_t>(ctr[1]);
+  res->events.resize(ctr[0]);
+  DV_HIP_CHECK(hipMemcpyAsync(res->ref_count.data(), d_cnt.ptr, static_cast<size_t>(len) * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, stream));
+  if (ctr[0]) {
+    DV_HIP_CHECK(hipMemcpyAsync(res->events.data(), d_ev.ptr, static_cast<size_t>(ctr[0]) * sizeof(dv_allele_event),
+                                hipMemcpyDeviceToHost, stream));
+  }
+  DV_HIP_CHECK(hipStreamSynchronize(stream));
+  // (position, read, read_offset): one read can leave two alleles at one position when a
+  // skipped allele sits between them (1I 4S 2D with an unusable soft clip: the insertion is
+  // not superseded, the deletion is added after it); read offsets order them as the CIGAR
+  // does, so the consumer's "later entry overwrites" matches read_alleles[key] = allele.
+  std::sort(res->events.begin(), res->events.end(), [](const dv_allele_event& x, const dv_allele_event& y) {
+    if (x.position != y.position) return x.position < y.position;
+    if (x.read != y.read) return x.read < y.read;
+    return x.read_offset < y.read_offset;
+  });
+  *out = res.release();
+  return DV_OK;
+}
+
+int dv_allele_counts_arrays(const dv_allele_counts* c, const int32_t** ref_supporting_read_count,
+                            const dv_allele_event** events, uint32_t* n_events, int32_t* n_reads_counted) {
+  if (!c) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_allele_counts_arrays: null");
+  if (ref_supporting_read_count) *ref_supporting_read_count = c->ref_count.data();
+  if (events) *events = c->events.data();
+  if (n_events) *n_events = static_cast<uint32_t>(c->events.size());
+  if (n_reads_counted) *n_reads_counted = c->n_reads_counted;
+  return static_cast<int>(c->ref_count.size());
+}
+
+void dv_allele_counts_free(dv_allele_counts* c) { delete c; }
+
+}  // extern "C"

@@ -429,6 +429,45 @@ int dv_merge_cigar_op(char* cigar, int32_t cap, char op, int32_t length, int32_t
 int dv_local_align(const char* reference, const char* query, int32_t match, int32_t mismatch,
                    int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
 
+/* ---- allele counting (device) -------------------------------------------------
+ * Replaces the per-read loop around AlleleCounter::Add for one region
+ * (deepvariant/allelecounter.cc:873-979 with MakeIndelReadAllele :402-469, GetPrevBase
+ * :386-400, CanBasesBeUsed :206-229, AddReadAlleles :471-543; constructed as in :349-369).
+ * The reads come as the read-table fields of a dv_batch (host or device memory); the result
+ * is AlleleCount's content per interval position: ref_supporting_read_count plus one event
+ * per non-reference read allele (the host builds read_alleles / allele sums from events:
+ * deepvariant_amd/allelecounter.py).  Not produced: methylation fields, REFERENCE read
+ * alleles of track_ref_reads, sample_alleles. */
+typedef struct dv_allele_counter_options {
+  int64_t interval_start, interval_end;             /* AlleleCounter's range (counts are reported here) */
+  int64_t reads_interval_start, reads_interval_end; /* full_range (:349-369); pass the interval again if unused */
+  const char* ref_bases;                            /* reference of [ref_start, ref_start + n_ref_bases): must cover the
+                                                       reads interval; indels that reach outside it are an error */
+  int64_t ref_start, n_ref_bases;
+  int64_t contig_n_bases;                           /* RefBases validity (:371-384); 0 = end of the window */
+  int32_t min_mapping_quality, min_base_quality;    /* AlleleCounterOptions.read_requirements */
+  int32_t keep_legacy_behavior;                     /* AlleleCounterOptions.keep_legacy_behavior */
+} dv_allele_counter_options;
+
+typedef struct dv_allele_event {   /* one ReadAllele that AddReadAlleles stores in read_alleles */
+  int32_t position;      /* offset in the interval */
+  uint32_t read;         /* index in the read table */
+  uint32_t read_offset;  /* SUBSTITUTION: the base; INSERTION / SOFT_CLIP: first inserted base; DELETION: next read base */
+  uint16_t length;       /* operation length (1 for substitutions) */
+  uint8_t type;          /* AlleleType: 2 SUBSTITUTION, 3 INSERTION, 4 DELETION, 5 SOFT_CLIP */
+  uint8_t low_quality;   /* Allele.is_low_quality */
+} dv_allele_event;
+
+typedef struct dv_allele_counts dv_allele_counts;  /* owns the host copies of the result */
+
+int dv_count_alleles(const dv_batch* reads, const dv_allele_counter_options* options, dv_allele_counts** out,
+                     void* stream);
+/* Events are sorted by (position, read, read_offset) = the order AddReadAlleles stores them
+ * for one position.  Returns the interval length. */
+int dv_allele_counts_arrays(const dv_allele_counts* c, const int32_t** ref_supporting_read_count,
+                            const dv_allele_event** events, uint32_t* n_events, int32_t* n_reads_counted);
+void dv_allele_counts_free(dv_allele_counts* c);
+
 /* CRC32C (Castagnoli) as used by TFRecord framing
  * (third_party/nucleus/io/example_writer.cc:88-104 via tensorflow::io::RecordWriter). */
 uint32_t dv_crc32c(const uint8_t* data, size_t n);

@@ -1,0 +1,132 @@
+"""The device AlleleCounter (dv_count_alleles, allele_counter.hip) against the oracle (GPU):
+the reference's own vectors (deepvariant/allelecounter_test.cc via tests/allelecounter_vectors.py)
+and a seeded fuzz over every CIGAR op, qualities around the threshold, N bases, reads
+hanging off both ends of the interval and of the contig, duplicate read keys."""
+import numpy as np
+import pytest
+
+from deepvariant_amd import allelecounter as A
+from deepvariant_amd import dv_types as T
+from oracle import allelecounter_ref as R
+from tests import allelecounter_vectors as V
+
+pytestmark = pytest.mark.gpu
+CASES = V.cases()
+
+
+def _compare(got_counts, oracle):
+  assert len(got_counts) == len(oracle.counts)
+  for i, (g, w) in enumerate(zip(got_counts, oracle.counts)):
+    assert g.ref_base == w.ref_base and g.position.position == w.position, i
+    assert g.ref_supporting_read_count == w.ref_supporting_read_count, i
+    got = {k: (a.bases, a.type, a.is_low_quality) for k, a in g.read_alleles.items()}
+    want = {k: (a.bases, a.type, a.is_low_quality) for k, a in w.read_alleles.items()}
+    assert got == want, i
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_reference_vectors(case):
+  name, contig, start, end, reads, expected = case
+  counter = A.AlleleCounter(V.TestRef(), contig, start, end, min_base_quality=V.MIN_BQ)
+  oracle = R.AlleleCounter(V.TestRef(), contig, start, end, min_base_quality=V.MIN_BQ)
+  for r in reads:
+    counter.add(r)
+    oracle.add(r)
+  assert counter.n_counted_reads() == len(reads)
+  for i, (ac, want) in enumerate(zip(counter.counts(), expected)):
+    got = sorted((a.bases, a.type, a.count) for a in A.sum_allele_counts(ac))
+    assert got == sorted(want), (name, i)
+    assert A.total_allele_counts(ac) == sum(n for _, _, n in want)
+  _compare(counter.counts(), oracle)
+
+
+def test_low_mapq_reads_are_ignored():
+  counter = A.AlleleCounter(V.TestRef(), 'chr1', 0, 4, min_mapping_quality=10)
+  counter.add(V.make_read('chr1', 0, 'ACGT', ['4M'], mapq=0))
+  assert counter.n_counted_reads() == 0
+  assert all(A.total_allele_counts(ac) == 0 for ac in counter.counts())
+
+
+class _Ref:
+  def __init__(self, seq):
+    self.seq = seq
+
+  def n_bases(self, contig):
+    return len(self.seq)
+
+  def get_bases(self, contig, start, end):
+    return self.seq[start:end]
+
+
+def _fuzz_reads(rng, ref, n, lo, hi, long_reads):
+  reads = []
+  for i in range(n):
+    cigar, qlen = [], 0
+    for _ in range(int(rng.integers(1, 40 if long_reads else 7))):
+      op = int(rng.choice([1, 1, 1, 8, 9, 2, 3, 4, 5, 6, 7]))
+      ln = int(rng.integers(1, 200 if long_reads and op in (1, 8, 9) else 9))
+      if cigar and cigar[-1].operation == op:
+        continue
+      cigar.append(T.CigarUnit(op, ln))
+      qlen += ln if op in (1, 2, 5, 8, 9) else 0
+    if qlen == 0:
+      cigar.append(T.CigarUnit(1, 3))
+      qlen += 3
+    start = int(rng.integers(lo, hi))
+    # bases: mostly the reference at the implied position, some substitutions, a few N
+    seq, pos = [], start
+    for cu in cigar:
+      if cu.operation in (1, 8, 9):
+        for k in range(cu.operation_length):
+          rb = ref.seq[pos + k] if 0 <= pos + k < len(ref.seq) else 'A'
+          u = rng.random()
+          seq.append(rb if u < 0.9 and rb in 'ACGT' else 'N' if u > 0.985 else 'ACGT'[int(rng.integers(0, 4))])
+        pos += cu.operation_length
+      elif cu.operation in (2, 5):
+        seq += ['ACGTN'[int(rng.integers(0, 5 if rng.random() < 0.1 else 4))] for _ in range(cu.operation_length)]
+      elif cu.operation in (3, 4, 7):
+        pos += cu.operation_length
+    quals = rng.integers(5, 45, size=qlen).astype(np.uint8)
+    dup = rng.random() < 0.08 and reads
+    reads.append(T.Read(
+        fragment_name=reads[int(rng.integers(0, len(reads)))].fragment_name if dup else 'f%d' % i,
+        read_number=int(rng.integers(0, 2)), number_reads=2, aligned_sequence=''.join(seq),
+        aligned_quality=bytes(quals),
+        alignment=T.LinearAlignment(position=T.Position('c', start, bool(rng.integers(0, 2))),
+                                    mapping_quality=int(rng.integers(0, 61)), cigar=cigar)))
+  return reads
+
+
+@pytest.mark.parametrize('seed,long_reads,legacy', [(1, False, False), (2, False, True), (3, True, False),
+                                                    (4, True, True)])
+def test_fuzz_against_the_oracle(seed, long_reads, legacy):
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000))
+  seq = seq[:700] + 'NN' + seq[702:2500] + 'N' + seq[2501:]
+  ref = _Ref(seq)
+  for (start, end), (lo, hi) in (((1000, 2000), (700, 2100)), ((0, 400), (0, 420)), ((5600, 6000), (5300, 5990))):
+    reads = _fuzz_reads(rng, ref, 700 if not long_reads else 200, lo, hi, long_reads)
+    kw = dict(min_mapping_quality=10, min_base_quality=20, keep_legacy_behavior=legacy)
+    counter = A.AlleleCounter(ref, 'c', start, end, **kw)
+    oracle = R.AlleleCounter(ref, 'c', start, end, **kw)
+    for r in reads:
+      counter.add(r)
+      oracle.add(r)
+    assert counter.n_counted_reads() == oracle.n_reads_counted
+    _compare(counter.counts(), oracle)
+    n_alleles = sum(len(c.read_alleles) for c in oracle.counts)
+    assert n_alleles > 150 and sum(c.ref_supporting_read_count for c in oracle.counts) > 400
+
+
+def test_full_range_form():
+  """The constructor with full_range (allelecounter.cc:349-369): bases are valid over the
+  wider reads interval, counts are reported for the inner interval only."""
+  rng = np.random.default_rng(9)
+  ref = _Ref(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=3000)))
+  reads = _fuzz_reads(rng, ref, 300, 800, 1700, False)
+  counter = A.AlleleCounter(ref, 'c', 1000, 1500, min_base_quality=15, full_range=(900, 1600))
+  oracle = R.AlleleCounter(ref, 'c', 1000, 1500, min_base_quality=15, full_range=(900, 1600))
+  for r in reads:
+    counter.add(r)
+    oracle.add(r)
+  _compare(counter.counts(), oracle)
