@@ -130,3 +130,27 @@ def test_full_range_form():
     counter.add(r)
     oracle.add(r)
   _compare(counter.counts(), oracle)
+
+
+def test_golden_region_counts_and_candidates():
+  """The Illumina golden region (2,737 raw NA12878 reads around the 78 golden candidates): the
+  device counter equals the oracle at every one of the ~9.8 K positions, and the candidate
+  caller on top of it reproduces the golden DeepVariantCalls exactly as far as the raw reads
+  determine them (72 of 78 calls, 47 with identical allele_support -- the reference realigns
+  reads first; tests/test_oracle_golden.py pins the same numbers through the oracle)."""
+  from tests import golden_io
+  from tests import test_oracle_golden as G
+  reads, examples, _ = golden_io.load(G.FIXTURE)
+  ref = G._WindowRef(examples)
+  lo = min(ex['call'].variant.start for ex in examples)
+  hi = max(ex['call'].variant.end for ex in examples)
+  kw = dict(min_mapping_quality=5, min_base_quality=10)
+  counter = A.AlleleCounter(ref, 'chr20', lo, hi, **kw)
+  oracle = R.AlleleCounter(ref, 'chr20', lo, hi, **kw)
+  for r in reads:
+    counter.add(r)
+    oracle.add(r)
+  assert counter.n_counted_reads() == oracle.n_reads_counted == len(reads) > 2500
+  _compare(counter.counts(), oracle)
+  counts = counter.counts()
+  assert G.golden_candidate_agreement(examples, lambda pos: counts[pos - lo]) == (78, 72, 47)
