@@ -41,7 +41,7 @@ def parse_args():
                   help='candidate sites per step per GPU; ~5 % more pileups (multi-allelic '
                        'sites give 3) -- 7700 sites fill one 8192-example forward')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
-  ap.add_argument('--mode', choices=['resident', 'host'], default='resident',
+  ap.add_argument('--mode', choices=['resident', 'host', 'alleles'], default='resident',
                   help="'resident' (default, the contract's metric): inputs already in HBM. "
                        "'host': host-inclusive -- every step packs the region's candidates and "
                        'reads natively (dv_pack_region), uploads them over PCIe and runs the GPU '
@@ -181,6 +181,10 @@ def run_rank(args, rank, local_rank, world):
   work = torch.cuda.Stream(device=dev)
   torch.cuda.set_stream(work)
 
+  if args.mode == 'alleles':
+    if world > 1:
+      raise SystemExit('--mode alleles runs on one GPU')
+    return allele_counting(args, host_batch, dev)
   if args.mode == 'host':
     if world != 1:
       raise SystemExit('--mode host runs on one GPU')
@@ -337,6 +341,90 @@ def host_inclusive(args, host_batch, opts, C, enc, model, dev):
       'pack_ms_per_step': 1e3 * pipe.pack_seconds / args.steps,
       'staging_ms_per_step': 1e3 * pipe.stage_seconds / args.steps,
       'upload_bytes_per_step': upload_bytes,
+  }))
+
+
+def allele_counting(args, host_batch, dev):
+  """SURVEY 8f row f2 (the step in front of the path): AlleleCounter::Add over the bench
+  workload's reads with dv_count_alleles -- one wave per read, read table resident in HBM.
+  A second metric line, never the contract's `value`.  The reference for the reads is
+  rebuilt from the reads themselves (the synthetic batch only carries per-candidate
+  windows), so most bases are reference matches, as in real data."""
+  import ctypes as C
+  from deepvariant_amd import _lib
+  from deepvariant_amd.device_batch import DeviceBatch
+  t = host_batch.table
+  n = t.n_reads
+  lo = int(t.read_pos.min())
+  hi = int(t.read_end.max()) + 64
+  rng = np.random.default_rng(3)
+  ref = np.frombuffer(b'ACGT', np.uint8)[rng.integers(0, 4, size=hi - lo)].copy()
+  ops, lens = t.cigar & 15, t.cigar >> 4
+  for r in range(n):                      # untimed setup: lay the reads' matched runs onto the reference
+    p, q = int(t.read_pos[r]) - lo, int(t.read_seq_off[r])
+    for c in range(int(t.read_cigar_off[r]), int(t.read_cigar_off[r + 1])):
+      op, ln = int(ops[c]), int(lens[c])
+      if op in (1, 8, 9):
+        ref[p:p + ln] = t.bases[q:q + ln]
+        p += ln
+        q += ln
+      elif op in (2, 5):
+        q += ln
+      elif op in (3, 4, 7):
+        p += ln
+  ref_bytes = ref.tobytes()
+  dbatch = DeviceBatch(host_batch, dev)
+  opt = _lib.DvAlleleCounterOptions(lo, hi - 64, lo, hi - 64, ref_bytes, lo, len(ref_bytes), hi, 5, 10, 0)
+  lib = _lib.lib()
+  stream = torch.cuda.current_stream(dev).cuda_stream
+
+  def step():
+    h = C.c_void_p()
+    _lib.check(lib.dv_count_alleles(C.byref(dbatch.c), C.byref(opt), C.byref(h), C.c_void_p(stream)))
+    return h
+
+  def summary(h):
+    refc = C.POINTER(C.c_int32)()
+    n_ev, n_cnt = C.c_uint32(), C.c_int32()
+    length = lib.dv_allele_counts_arrays(h, C.byref(refc), None, C.byref(n_ev), C.byref(n_cnt))
+    total = int(np.ctypeslib.as_array(refc, shape=(length,)).sum())
+    lib.dv_allele_counts_free(h)
+    return total, int(n_ev.value), int(n_cnt.value)
+
+  for _ in range(max(args.warmup, 1)):
+    first = summary(step())
+  torch.cuda.synchronize(dev)
+  lib.dv_set_profiling(1)
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    last = summary(step())
+  torch.cuda.synchronize(dev)
+  elapsed = time.perf_counter() - t0
+  kernel_ms = lib.dv_profile_ms(2)
+  launches = lib.dv_last_profile_count()
+  lib.dv_set_profiling(0)
+  assert last == first                      # atomics only add: the counts are run-to-run identical
+  n_bases = int(t.read_seq_off[-1])
+  # what the kernel has to touch per read: bases + qualities, CIGAR words, position / offsets /
+  # mapq, the reference under every matched base, one 4-byte atomic per reference match
+  alg = 2 * n_bases + 4 * int(t.read_cigar_off[-1]) + 13 * n + n_bases + 4 * last[0]
+  gbs = alg * launches / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+  print(json.dumps({
+      'metric': 'reads/sec (allele counting, dv_count_alleles)',
+      'value': n * args.steps / elapsed,
+      'unit': 'reads/s',
+      'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': 1e3 * elapsed / args.steps,
+      'higher_is_better': True, 'data': 'synthetic', 'dtype': 'u8 / int32 atomics',
+      'config': {'workload': 'the reads of the resident-mode batch (synthetic 30x Illumina)',
+                 'reads_per_step': n, 'bases_per_step': n_bases, 'interval_bases': hi - 64 - lo,
+                 'ref_supporting_reads_counted': last[0], 'non_reference_events': last[1],
+                 'reads_counted': last[2],
+                 'includes': 'kernel + result download + host sort of the events (whole call)'},
+      'roofline': {'kernel': 'count_alleles_kernel', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                   'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                   'bytes_per_launch': alg, 'avg_launch_ms': kernel_ms / max(launches, 1),
+                   'bases_per_s': n_bases * launches / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
   }))
 
 
