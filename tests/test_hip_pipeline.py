@@ -175,3 +175,83 @@ def test_region_from_native_bam_table_equals_region_from_read_protos(tmp_path):
     outs.append(list(tfrecord.read_tfrecords(path)))
     assert stats['n_examples'] == len(outs[-1]) >= 12
   assert outs[0] == outs[1]
+
+
+def test_reads_to_probabilities_chain():
+  """The whole product chain on one synthetic region, no files and no golden inputs in
+  between: reads -> device allele counts (dv_count_alleles) -> candidate caller ->
+  ExamplesGenerator.call_variants_in_region (dv_encode_batch + dv_model_infer) ->
+  CallVariantsOutput.  The oracle chain runs the same steps with the Python allele counter,
+  the C++ encoder restatement and the fp32 CNN; candidates and tensors must be identical,
+  probabilities within 1e-3."""
+  from deepvariant_amd import allelecounter as ac
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd import variant_calling as vc
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from oracle import allelecounter_ref as AR
+  from oracle import inception_ref as R
+  from oracle import oracle as O
+  from tests import fuzz_inputs as F
+  from tests import test_hip_region_multisample as M
+
+  rng = np.random.default_rng(2024)
+  width, height = 221, 100
+  pic = F.options(T.PILEUP_DEFAULT_CHANNELS + ['insert_size'], width, height)
+  options = T.MakeExamplesOptions(pic_options=pic,
+                                  sample_options=[T.SampleOptions(role='main', name='s', pileup_height=height)])
+  ref = M._Ref(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000)))
+  variants = []
+  for pos in range(1200, 4600, 170):
+    kind = int(rng.integers(0, 3))
+    refb = ref.seq[pos] if kind < 2 else ref.seq[pos:pos + 1 + int(rng.integers(1, 5))]
+    altb = ([b for b in 'ACGT' if b != refb][0] if kind == 0 else
+            refb + 'GATT'[:int(rng.integers(1, 5))] if kind == 1 else refb[0])
+    variants.append((pos, refb, altb))
+  reads = M._haplotype_reads(rng, ref.seq, variants, 900, 700, 4700)
+  for r in reads:
+    r.number_reads, r.fragment_length = 2, int(rng.integers(-600, 600))
+  start, end = 1000, 4800
+  kw = dict(min_mapping_quality=5, min_base_quality=10)
+  counter = ac.AlleleCounter(ref, 'chr1', start, end, **kw)
+  oracle_counter = AR.AlleleCounter(ref, 'chr1', start, end, **kw)
+  for r in reads:
+    counter.add(r)
+    oracle_counter.add(r)
+  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.06, sample_name='s'))
+  cands = caller.calls_from_allele_counter(counter)
+  # the oracle chain's candidates (Python counter -> the same caller) must be the same calls
+  want_counts = []
+  for c in oracle_counter.counts:
+    a = ac.AlleleCount('chr1', c.position, c.ref_base)
+    a.ref_supporting_read_count = c.ref_supporting_read_count
+    a.read_alleles = {k: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for k, v in c.read_alleles.items()}
+    want_counts.append(a)
+  want_cands = caller.calls_from_allele_counts(want_counts)
+  key = lambda c: (c.variant.start, c.variant.reference_bases, tuple(c.variant.alternate_bases),
+                   tuple(sorted((k, tuple(sorted(s.read_names))) for k, s in c.allele_support.items())))
+  assert [key(c) for c in cands] == [key(c) for c in want_cands]
+  found = {c.variant.start for c in cands}
+  assert len(cands) >= 15 and sum(v[0] in found for v in variants) >= 15    # the planted variants are found
+
+  weights = R.make_random_model(7, seed=8)
+  model = InceptionV3((height, width, 7), max_batch=64)
+  model.load_flat_weights(weights.export_flat())
+  gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=ref)
+  cvos = gen.call_variants_in_region(cands, [reads], [0], [0.0], model)
+  hw = (width - 1) // 2
+  k = 0
+  worst = 0.0
+  for cand in cands:
+    v = cand.variant
+    window = men.get_reference_bases_for_pileup(ref, v, width)
+    overlapping = M._query(reads, v.start - 5, v.end + 5)
+    for combo in men.alt_allele_combinations(cand, pic.multi_allelic_mode):
+      image = O.build_pileup(pic, cand, window, overlapping, v.start - hw, list(combo), pileup_height=height)
+      with torch.no_grad():
+        want = weights(torch.from_numpy(image[None])).numpy()[0]
+      _, got_alt, got_probs = pw.decode_call_variants_output(cvos[k])
+      assert got_alt == [v.alternate_bases.index(a) for a in combo]
+      worst = max(worst, float(np.abs(np.array(got_probs) - want).max()))
+      k += 1
+  assert k == len(cvos) and worst <= 2e-3, worst   # round_gls rounds the emitted values to 1e-10 steps
