@@ -75,6 +75,9 @@ struct ConvArgs {
   // band * ceil(N*OW / block pixels) * n_tiles.  Skipped products are exact zeros, so the
   // result is bit-identical to the full filter.
   int band;
+  // tuning knob (DV_CU_PAIR): renumber blocks so that the two blocks a CU runs concurrently are
+  // neighbouring cout tiles of one pixel tile (they then share its L1 lines)
+  int cu_pair;
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
 };
 

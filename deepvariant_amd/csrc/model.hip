@@ -165,7 +165,17 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   // the same pixel tile, which re-read the same input -- share an XCD's L2.
   const int nwg = gridDim.x;
   const int xq = nwg >> 3, xr = nwg & 7;
-  const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  int xi = blockIdx.x >> 3;
+  if (p.cu_pair) {
+    // An XCD hands its blocks to its 32 CUs in turn: block xi runs on CU xi % 32, and with two
+    // blocks per CU the ones 32 apart share a CU.  Give those two consecutive logical numbers.
+    const int cnt = xcd < xr ? xq + 1 : xq;
+    if (xi < cnt / 64 * 64) {
+      const int w = xi & 63;
+      xi = (xi & ~63) + (w & 31) * 2 + (w >> 5);
+    }
+  }
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int n_tile = logical % p.n_tiles;
   int pix_block = logical / p.n_tiles;
@@ -1433,6 +1443,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.Cin = op.cin;
       a.OH = op.oh;
       a.OW = op.ow;
+      static const int cu_pair = getenv("DV_CU_PAIR") ? atoi(getenv("DV_CU_PAIR")) : 0;
+      a.cu_pair = cu_pair;
       a.band = op.band;
       a.KH = op.band ? op.band : op.kh;
       a.KW = op.kw;

@@ -192,3 +192,70 @@ def test_bgzf_isize_is_capped(tmp_path):
     f.write(blk)
   with pytest.raises(_lib.DvError, match='64 KiB'):
     packing.ReadTable.from_bam(path, 'chrA', 0, 1000)
+
+
+NUCLEUS_TESTDATA = '/root/reference/third_party/nucleus/testdata'
+
+
+@pytest.mark.skipif(not os.path.isdir(NUCLEUS_TESTDATA), reason='reference testdata not in this container')
+def test_known_answers_of_the_reference_sam_reader_tests():
+  """Counts and coordinates the REFERENCE's own tests hold for its test.bam
+  (third_party/nucleus/io/sam_reader_test.cc:311-418: SimpleQueriesWork,
+  ThatRangeIsExactlyCorrect, QueriedRespectsReadRequirements) -- an anchor for the native
+  reader that does not go through this repo's Python reader."""
+  path = os.path.join(NUCLEUS_TESTDATA, 'test.bam')
+  everything = dict(keep_duplicates=True, keep_supplementary=True, keep_secondary=True, keep_failed_qc=True,
+                    keep_improperly_placed=True)
+  # default ReadRequirements: 105 of the 106 records (the unmapped one goes); min_mapping_quality 38: 104
+  assert packing.ReadTable.from_bam(path, 'chr20', 9999999, 10000100).n_reads == 105
+  assert packing.ReadTable.from_bam(path, 'chr20', 9999999, 10000100, min_mapping_quality=38).n_reads == 104
+  t = packing.ReadTable.from_bam(path, 'chr20', 999999, 100000000, **everything)
+  assert t.n_reads == 105                                         # aligned reads only, whatever the flags
+  hist = {int(q): int((t.read_mapq == q).sum()) for q in np.unique(t.read_mapq)}
+  assert hist == {37: 1, 60: 104}                                 # "samtools view | cut -f 5 | sort | uniq -c"
+  assert packing.ReadTable.from_bam(path, 'chr20', 999999, 2000000).n_reads == 0
+  assert packing.ReadTable.from_bam(path, 'chr10', 9999999, 10000000).n_reads == 0
+  # ThatRangeIsExactlyCorrect: this read spans [9999911, 10000010)
+  name = 'HSQ1004:134:C0D8DACXX:4:1304:21341:94622'
+  i = [k.rsplit('/', 1)[0] for k in t.keys].index(name)
+  assert (int(t.read_pos[i]), int(t.read_end[i])) == (9999911, 10000010)
+  present = lambda a, b: name in [k.rsplit('/', 1)[0] for k in
+                                  packing.ReadTable.from_bam(path, 'chr20', a, b, **everything).keys]
+  assert present(9999911, 10000010) and present(9999912, 10000009)
+  assert present(9999901, 9999912) and not present(9999901, 9999911)
+  assert present(10000009, 10000020) and not present(10000010, 10000020)
+
+
+def test_query_reads_matches_the_table_query():
+  """dv_query_reads (InMemoryReader::Query + ReadOverlapsRegion, make_examples_native.cc:802-810,
+  nucleus/util/utils.cc:172-188) against ReadTable.query and a direct restatement, on reads
+  with every reference-consuming / non-consuming CIGAR op."""
+  import ctypes as C
+  from deepvariant_amd import _lib
+  rng = np.random.default_rng(4)
+  n = 500
+  pos = rng.integers(0, 3000, size=n).astype(np.int32)
+  cig, off = [], [0]
+  for _ in range(n):
+    ops = [(int(rng.integers(1, 60)) << 4) | int(op) for op in rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9],
+                                                                         size=int(rng.integers(1, 6)))]
+    cig += ops
+    off.append(len(cig))
+  cig, off = np.array(cig, np.uint32), np.array(off, np.uint32)
+  ref_len = np.array([sum(int(w) >> 4 for w in cig[off[i]:off[i + 1]] if (int(w) & 15) in (1, 3, 4, 8, 9))
+                      for i in range(n)], np.int64)
+  q0 = rng.integers(-50, 3100, size=64).astype(np.int64)
+  q1 = q0 + rng.integers(0, 400, size=64)
+  lib = _lib.lib()
+  lib.dv_query_reads.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+  list_off = np.zeros(65, np.uint32)
+  _lib.check(lib.dv_query_reads(n, pos.ctypes.data, off.ctypes.data, cig.ctypes.data, 64, q0.ctypes.data,
+                                q1.ctypes.data, list_off.ctypes.data, None))
+  reads = np.zeros(max(int(list_off[-1]), 1), np.uint32)
+  _lib.check(lib.dv_query_reads(n, pos.ctypes.data, off.ctypes.data, cig.ctypes.data, 64, q0.ctypes.data,
+                                q1.ctypes.data, list_off.ctypes.data, reads.ctypes.data))
+  assert list_off[-1] > 500
+  for k in range(64):
+    want = [r for r in range(n) if q1[k] > pos[r] and q0[k] < pos[r] + ref_len[r]]
+    assert reads[list_off[k]:list_off[k + 1]].tolist() == want, k
