@@ -221,9 +221,10 @@ def _haplotype_reads(rng, ref_seq, variants, n, lo, hi):
   return reads
 
 
-@pytest.mark.parametrize('mode,types', [('diff_channels', 'all'), ('base_channels', 'indels'),
-                                        ('rows', 'all'), ('single_row', 'indels')])
-def test_alt_aligned_pileups(mode, types):
+@pytest.mark.parametrize('mode,types,pacbio', [('diff_channels', 'all', False), ('base_channels', 'indels', False),
+                                               ('rows', 'all', False), ('single_row', 'indels', False),
+                                               ('diff_channels', 'indels', True)])
+def test_alt_aligned_pileups(mode, types, pacbio):
   """--alt_aligned_pileup (the PacBio / ONT models use diff_channels): per candidate and alt
   allele the reads are trimmed to the window, realigned to the alt haplotype
   (CreateHaplotype + RealignReadsToHaplotype, make_examples_native.cc:553-626) and drawn
@@ -240,9 +241,11 @@ def test_alt_aligned_pileups(mode, types):
   from deepvariant_amd import protowire as pw
   from oracle import oracle as O
   rng = np.random.default_rng(101)
-  width, height = 99, 40
+  # pacbio: exactly the released PacBio model's tensor (deepvariant/json/deepvariant.pacbio.savedmodel/
+  # model.example_info.json: shape [100, 147, 10], channels [1..7, 26, 9, 10], diff_channels, indels)
+  width, height = (147, 100) if pacbio else (99, 40)
   hw = (width - 1) // 2
-  channels = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype']
+  channels = list(T.PILEUP_DEFAULT_CHANNELS) + ['haplotype'] + (['supplementary_alignment'] if pacbio else [])
   extra = {'diff_channels': ['diff_channels_alternate_allele_1', 'diff_channels_alternate_allele_2'],
            'base_channels': ['base_channels_alternate_allele_1', 'base_channels_alternate_allele_2']}.get(mode, [])
   pic = F.options(channels + extra, width, height, sort_by_haplotypes=True, min_mapq=1,
@@ -267,6 +270,9 @@ def test_alt_aligned_pileups(mode, types):
       continue
     variants.append((pos, refb, altb))
   reads = _haplotype_reads(rng, ref.seq, variants, 420, 600, 3700)
+  if pacbio:
+    for r in reads:
+      r.supplementary_alignment = bool(rng.random() < 0.2)
   cands = []
   for k, (pos, refb, altb) in enumerate(variants):
     alts = [altb]
@@ -284,6 +290,7 @@ def test_alt_aligned_pileups(mode, types):
   examples, shape = gen.encode_region(cands, [reads], [0], [0.0], stats, role='main')
   mult = {'rows': 3, 'single_row': 2}.get(mode, 1)
   assert shape == [height * mult, width, len(channels) + len(extra)]
+  assert not pacbio or shape == [100, 147, 10]
   k = n_alt_images = n_plain = 0
   for cand in cands:
     v = cand.variant
