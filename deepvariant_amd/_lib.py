@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     'dv_aligner_read_alignment', 'dv_aligner_merge_alignment', 'dv_aligner_is_normalized',
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
     'dv_merge_cigar_op', 'dv_local_align',
-    'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free',
+    'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
 
 
@@ -163,6 +163,11 @@ class DvLocalAlignment(C.Structure):
               ('cigar', C.c_char * 512)]
 
 
+class DvAltMergeEntry(C.Structure):
+  _fields_ = [('example', C.c_int64), ('first_row', C.c_int32), ('rows', C.c_int32),
+              ('scratch_alt1', C.c_int64), ('scratch_alt2', C.c_int64)]
+
+
 class DvAlleleCounterOptions(C.Structure):
   _fields_ = [('interval_start', C.c_int64), ('interval_end', C.c_int64),
               ('reads_interval_start', C.c_int64), ('reads_interval_end', C.c_int64),
@@ -267,6 +272,8 @@ def lib():
     l.dv_allele_counts_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     l.dv_allele_counts_free.argtypes = [C.c_void_p]
     l.dv_allele_counts_free.restype = None
+    l.dv_merge_alt_channels.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     _lib = l
   return _lib
 

@@ -460,6 +460,26 @@ class ExamplesGenerator:
   def _max_sample_height(self) -> int:
     return max(so.pileup_height for so in self._options.sample_options)
 
+  def _merge_alt_channels_device(self, flat, image_shape) -> None:
+    """_merge_alt_channels on images that stay in HBM (dv_merge_alt_channels)."""
+    import ctypes as C
+    import torch
+    from deepvariant_amd import _lib
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    h_img, w, c = image_shape
+    entries = [(ex, row0, rows, slots) for ex, row0, rows, slots in self._alt_plan if slots[0] is not None]
+    if not entries:
+      return
+    arr = (_lib.DvAltMergeEntry * len(entries))()
+    for k, (ex, row0, rows, slots) in enumerate(entries):
+      arr[k].example, arr[k].first_row, arr[k].rows = ex, row0, rows
+      arr[k].scratch_alt1 = slots[0]
+      arr[k].scratch_alt2 = slots[1] if slots[1] is not None else -1
+    _lib.check(_lib.lib().dv_merge_alt_channels(
+        flat.data_ptr(), self._alt_scratch0, h_img * w * c, self._max_sample_height() * w * c, w, c,
+        len(self._chan_enums), 5 if self._alt_mode == aap.DIFF_CHANNELS else 0, arr, len(entries),
+        C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)))
+
   def _merge_alt_channels(self, images: np.ndarray, n_examples: int, image_shape) -> None:
     """FillPileupArray's channel modes (pileup_image_native.h:246-271) on the encoder's
     output: the two trailing channels of every reference-image row block come from
@@ -522,9 +542,6 @@ class ExamplesGenerator:
                                                  mean_coverage_per_sample)
     if not plan:
       return []
-    if getattr(self, '_alt_plan', None) or self._alt_mode != 'none':
-      raise NotImplementedError('alt-aligned pileups go through write_examples_in_region / encode_region; '
-                                'the fused device path does not merge alt images yet')
     if list(image_shape) != list(model.input_shape):
       raise ValueError('example shape %s != model shape %s' % (image_shape, list(model.input_shape)))
     pic = self._options.pic_options
@@ -532,8 +549,16 @@ class ExamplesGenerator:
       self._device_encoder = _Encoder(pic, pic.width, self._device)
     dev = torch.device('cuda', self._device)
     dbatch = DeviceBatch(batch, dev, pic.reference_band_height)
-    images = torch.empty([len(plan)] + list(image_shape), dtype=torch.uint8, device=dev)
-    dbatch.encode(self._device_encoder, image_shape[2], images)
+    example_bytes = int(np.prod(image_shape))
+    n_bytes = max(batch.out_bytes(image_shape[2]), len(plan) * example_bytes)
+    # alt-aligned layouts: alt images are items of the same launch (rows in place -- missing
+    # ones must read as zero -- or scratch images behind the examples for the channel modes)
+    alt = self._alt_mode != 'none'
+    flat = (torch.zeros if alt else torch.empty)(n_bytes, dtype=torch.uint8, device=dev)
+    images = flat[:len(plan) * example_bytes].view([len(plan)] + list(image_shape))
+    dbatch.encode(self._device_encoder, image_shape[2], flat)
+    if self._alt_plan:
+      self._merge_alt_channels_device(flat, image_shape)
     gls = cv.round_gls_batch(model(images).cpu().numpy(), 10)
     out = []
     for (ci, combo), row in zip(plan, gls):

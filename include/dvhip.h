@@ -429,6 +429,24 @@ int dv_merge_cigar_op(char* cigar, int32_t cap, char op, int32_t length, int32_t
 int dv_local_align(const char* reference, const char* query, int32_t match, int32_t mismatch,
                    int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
 
+/* ---- alt-aligned channel merge (device) --------------------------------------
+ * FillPileupArray's diff_channels / base_channels modes (deepvariant/pileup_image_native.h:
+ * 246-271) on images that stay in HBM: `images` holds the examples followed, from
+ * `scratch_offset`, by scratch images of `scratch_image_bytes` each (the alt images, items of
+ * the same dv_encode_batch launch); per entry the two channels first_alt_channel, +1 of rows
+ * [first_row, first_row + rows) of one example receive channel `source_channel` (5 or 0) of
+ * scratch image scratch_alt1 and scratch_alt2 (alt 1 again when scratch_alt2 < 0). */
+typedef struct dv_alt_merge_entry {
+  int64_t example;
+  int32_t first_row, rows;
+  int64_t scratch_alt1, scratch_alt2;
+} dv_alt_merge_entry;
+
+int dv_merge_alt_channels(uint8_t* images, uint64_t scratch_offset, uint64_t example_bytes,
+                          uint64_t scratch_image_bytes, int32_t width, int32_t channels,
+                          int32_t first_alt_channel, int32_t source_channel,
+                          const dv_alt_merge_entry* entries, int32_t n_entries, void* stream);
+
 /* ---- allele counting (device) -------------------------------------------------
  * Replaces the per-read loop around AlleleCounter::Add for one region
  * (deepvariant/allelecounter.cc:873-979 with MakeIndelReadAllele :402-469, GetPrevBase

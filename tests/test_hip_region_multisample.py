@@ -221,25 +221,9 @@ def _haplotype_reads(rng, ref_seq, variants, n, lo, hi):
   return reads
 
 
-@pytest.mark.parametrize('mode,types,pacbio', [('diff_channels', 'all', False), ('base_channels', 'indels', False),
-                                               ('rows', 'all', False), ('single_row', 'indels', False),
-                                               ('diff_channels', 'indels', True)])
-def test_alt_aligned_pileups(mode, types, pacbio):
-  """--alt_aligned_pileup (the PacBio / ONT models use diff_channels): per candidate and alt
-  allele the reads are trimmed to the window, realigned to the alt haplotype
-  (CreateHaplotype + RealignReadsToHaplotype, make_examples_native.cc:553-626) and drawn
-  against it; the alt images become two extra channels or extra row blocks
-  (FillPileupArray, pileup_image_native.h:214-307).
-
-  The product draws reference and alt images of the whole region in ONE encoder launch and
-  merges on the host; the oracle side restates the reference's per-candidate steps with
-  proto-shaped inputs.  The aligner itself is shared by both sides: it is pinned by the
-  reference's vectors in tests/test_fast_pass_aligner_cpu.py."""
-  from deepvariant_amd import alt_aligned_pileup_lib as A
-  from deepvariant_amd import fast_pass_aligner as fpa
-  from deepvariant_amd import make_examples_native as men
-  from deepvariant_amd import protowire as pw
-  from oracle import oracle as O
+def _alt_region(mode, types, pacbio):
+  """Reference, haplotype-carrying reads and candidates (SNPs, insertions, deletions, some
+  with two alts) for the alt-aligned tests."""
   rng = np.random.default_rng(101)
   # pacbio: exactly the released PacBio model's tensor (deepvariant/json/deepvariant.pacbio.savedmodel/
   # model.example_info.json: shape [100, 147, 10], channels [1..7, 26, 9, 10], diff_channels, indels)
@@ -285,6 +269,32 @@ def test_alt_aligned_pileups(mode, types, pacbio):
             '%s/%d' % (r.fragment_name, r.read_number))
     cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + len(refb), refb, alts),
                                    allele_support=support))
+  return dict(pic=pic, enc_pic=enc_pic, options=options, ref=ref, reads=reads, cands=cands, width=width,
+              height=height, hw=hw, channels=channels, extra=extra)
+
+
+@pytest.mark.parametrize('mode,types,pacbio', [('diff_channels', 'all', False), ('base_channels', 'indels', False),
+                                               ('rows', 'all', False), ('single_row', 'indels', False),
+                                               ('diff_channels', 'indels', True)])
+def test_alt_aligned_pileups(mode, types, pacbio):
+  """--alt_aligned_pileup (the PacBio / ONT models use diff_channels): per candidate and alt
+  allele the reads are trimmed to the window, realigned to the alt haplotype
+  (CreateHaplotype + RealignReadsToHaplotype, make_examples_native.cc:553-626) and drawn
+  against it; the alt images become two extra channels or extra row blocks
+  (FillPileupArray, pileup_image_native.h:214-307).
+
+  The product draws reference and alt images of the whole region in ONE encoder launch and
+  merges on the host; the oracle side restates the reference's per-candidate steps with
+  proto-shaped inputs.  The aligner itself is shared by both sides: it is pinned by the
+  reference's vectors in tests/test_fast_pass_aligner_cpu.py."""
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from oracle import oracle as O
+  g = _alt_region(mode, types, pacbio)
+  pic, enc_pic, options, ref, reads, cands = (g[k] for k in ('pic', 'enc_pic', 'options', 'ref', 'reads', 'cands'))
+  width, height, hw, channels, extra = (g[k] for k in ('width', 'height', 'hw', 'channels', 'extra'))
   gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=ref)
   stats = {}
   examples, shape = gen.encode_region(cands, [reads], [0], [0.0], stats, role='main')
@@ -326,3 +336,31 @@ def test_alt_aligned_pileups(mode, types, pacbio):
       np.testing.assert_array_equal(img, want, err_msg='%s: candidate at %d, alts %s' % (mode, v.start, combo))
   assert k == len(examples) and n_alt_images > 10
   assert types == 'all' or n_plain > 0       # 'indels': SNP candidates draw untrimmed reads, no alt images
+
+
+@pytest.mark.parametrize('mode,types,pacbio', [('diff_channels', 'indels', True), ('rows', 'all', False),
+                                               ('base_channels', 'all', True)])
+def test_fused_device_path_with_alt_aligned_layouts(mode, types, pacbio):
+  """call_variants_in_region with alt-aligned pileups: the alt images are items of the same
+  launch, the channel merge runs on the device (dv_merge_alt_channels), nothing returns to the
+  host before the CNN.  CallVariantsOutput must equal classifying the examples of
+  encode_region (whose tensors test_alt_aligned_pileups checks against the oracle)."""
+  import torch
+  from deepvariant_amd import call_variants as cv
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd.inception_v3 import InceptionV3
+  g = _alt_region(mode, types, pacbio)
+  gen = men.ExamplesGenerator(g['options'], {}, test_mode=True, ref_reader=g['ref'])
+  examples, shape = gen.encode_region(g['cands'], [g['reads']], [0], [0.0], {}, role='main')
+  model = InceptionV3(tuple(shape), max_batch=64)
+  model.init_random(seed=5)
+  cvos = gen.call_variants_in_region(g['cands'], [g['reads']], [0], [0.0], model)
+  assert len(cvos) == len(examples) > 20
+  imgs = np.stack([np.frombuffer(pw.decode_example(e)['image/encoded'][0], np.uint8).reshape(shape)
+                   for e in examples])
+  want = cv.round_gls_batch(model(torch.from_numpy(imgs).cuda()).cpu().numpy(), 10)
+  for k, (cvo, ex) in enumerate(zip(cvos, examples)):
+    _, alt, probs = pw.decode_call_variants_output(cvo)
+    assert alt == pw.decode_alt_allele_indices(pw.decode_example(ex)['alt_allele_indices/encoded'][0])
+    assert probs == want[k].tolist(), k
