@@ -130,7 +130,7 @@ class DvPackReads(C.Structure):
 
 class DvPackOptions(C.Structure):
   _fields_ = [('width', C.c_int32), ('read_overlap_buffer_bp', C.c_int32),
-              ('pileup_height', C.c_int32), ('example_bytes', C.c_uint64)]
+              ('pileup_height', C.c_int32), ('n_threads', C.c_int32), ('example_bytes', C.c_uint64)]
 
 
 class DvPackCandidate(C.Structure):

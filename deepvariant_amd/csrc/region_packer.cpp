@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -91,94 +92,137 @@ int dv_pack_region(const dv_pack_reads* reads, const dv_pack_options* opt, int32
     for (int32_t k = 0; k < n; ++k) pos_sorted[k] = reads->read_pos[order[k]];
     spos = pos_sorted.data();
   }
-  auto pr = std::make_unique<dv_packed_region>();
-  pr->list_read.reserve(static_cast<size_t>(n) + 1024);
-  pr->list_code.reserve(static_cast<size_t>(n) + 1024);
-  pr->list_group.reserve(static_cast<size_t>(n) + 1024);
-  pr->item_list_off.push_back(0);
+  // Candidates are independent: a contiguous slice per thread, each into its own
+  // dv_packed_region, concatenated in candidate order (offsets shifted) afterwards.
   const int half = (opt->width - 1) / 2;
   struct Sup {
     uint32_t key_off, key_len;
     uint8_t first_alt, last_alt;
   };
-  std::unordered_multimap<uint64_t, Sup> sup;
-  std::vector<uint32_t> picked;
-  std::vector<uint8_t> first_alt, group;
-  for (int32_t ci = 0; ci < n_candidates; ++ci) {
-    const dv_pack_candidate& c = cands[ci];
-    if (c.ref_idx < 0) continue;  // no reference window: the reference skips the candidate (:650-653)
-    if (c.n_alts < 0 || c.n_alts > 32) return dv::fail(DV_ERR_INVALID_ARGUMENT, "n_alts out of range");
-    // ---- allele_support of this candidate: key -> (first alt, last alt) ----
-    sup.clear();
-    for (uint32_t j = c.first_support; j < c.first_support + c.n_support; ++j) {
-      const char* k = support_keys + support_key_off[j];
-      const uint32_t kl = static_cast<uint32_t>(std::strlen(k));
-      const uint64_t h = fnv1a(k, kl);
-      const uint8_t alt = support_alt[j];
-      if (alt >= c.n_alts) return dv::fail(DV_ERR_INVALID_ARGUMENT, "support_alt out of range");
-      bool found = false;
-      auto range = sup.equal_range(h);
-      for (auto it = range.first; it != range.second; ++it) {
-        if (it->second.key_len == kl && std::memcmp(support_keys + it->second.key_off, k, kl) == 0) {
-          it->second.first_alt = std::min(it->second.first_alt, alt);
-          it->second.last_alt = std::max(it->second.last_alt, alt);
-          found = true;
-          break;
-        }
+  auto pack_slice = [&](int32_t c_begin, int32_t c_end, dv_packed_region* pr, std::string* error) {
+    pr->item_list_off.push_back(0);
+    std::unordered_multimap<uint64_t, Sup> sup;
+    std::vector<uint32_t> picked;
+    std::vector<uint8_t> first_alt, group;
+    for (int32_t ci = c_begin; ci < c_end; ++ci) {
+      const dv_pack_candidate& c = cands[ci];
+      if (c.ref_idx < 0) continue;  // no reference window: the reference skips the candidate (:650-653)
+      if (c.n_alts < 0 || c.n_alts > 32) {
+        *error = "n_alts out of range";
+        return;
       }
-      if (!found) sup.emplace(h, Sup{support_key_off[j], kl, alt, alt});
-    }
-    // ---- Query: reads overlapping the window, caller order ----
-    const int64_t q0 = c.start - opt->read_overlap_buffer_bp;
-    const int64_t q1 = c.end + opt->read_overlap_buffer_bp;
-    picked.clear();
-    const int32_t lo = static_cast<int32_t>(
-        std::lower_bound(spos, spos + n,
-                         static_cast<int32_t>(std::max<int64_t>(q0 - max_span + 1, INT32_MIN))) - spos);
-    const int32_t hi = static_cast<int32_t>(
-        std::lower_bound(spos + lo, spos + n, static_cast<int32_t>(std::min<int64_t>(q1, INT32_MAX))) - spos);
-    for (int32_t k = lo; k < hi; ++k) {
-      const int32_t r = sorted ? k : order[k];
-      if (q1 > reads->read_pos[r] && q0 < reads->read_end[r]) picked.push_back(static_cast<uint32_t>(r));
-    }
-    if (!sorted) std::sort(picked.begin(), picked.end());
-    first_alt.assign(picked.size(), 255);
-    group.assign(picked.size(), static_cast<uint8_t>(c.n_alts));
-    if (!sup.empty()) {
-      for (size_t j = 0; j < picked.size(); ++j) {
-        const uint32_t r = picked[j];
-        auto range = sup.equal_range(rhash[r]);
+      // ---- allele_support of this candidate: key -> (first alt, last alt) ----
+      sup.clear();
+      for (uint32_t j = c.first_support; j < c.first_support + c.n_support; ++j) {
+        const char* k = support_keys + support_key_off[j];
+        const uint32_t kl = static_cast<uint32_t>(std::strlen(k));
+        const uint64_t h = fnv1a(k, kl);
+        const uint8_t alt = support_alt[j];
+        if (alt >= c.n_alts) {
+          *error = "support_alt out of range";
+          return;
+        }
+        bool found = false;
+        auto range = sup.equal_range(h);
         for (auto it = range.first; it != range.second; ++it) {
-          const char* k = support_keys + it->second.key_off;
-          const char* nm = reads->names + reads->name_off[r];
-          if (it->second.key_len == rlen[r] + 2 && std::memcmp(k, nm, rlen[r]) == 0 &&
-              k[rlen[r]] == '/' && k[rlen[r] + 1] == static_cast<char>('0' + reads->read_number[r])) {
-            first_alt[j] = it->second.first_alt;
-            group[j] = it->second.last_alt;
+          if (it->second.key_len == kl && std::memcmp(support_keys + it->second.key_off, k, kl) == 0) {
+            it->second.first_alt = std::min(it->second.first_alt, alt);
+            it->second.last_alt = std::max(it->second.last_alt, alt);
+            found = true;
             break;
           }
         }
+        if (!found) sup.emplace(h, Sup{support_key_off[j], kl, alt, alt});
+      }
+      // ---- Query: reads overlapping the window, caller order ----
+      const int64_t q0 = c.start - opt->read_overlap_buffer_bp;
+      const int64_t q1 = c.end + opt->read_overlap_buffer_bp;
+      picked.clear();
+      const int32_t lo = static_cast<int32_t>(
+          std::lower_bound(spos, spos + n,
+                           static_cast<int32_t>(std::max<int64_t>(q0 - max_span + 1, INT32_MIN))) - spos);
+      const int32_t hi = static_cast<int32_t>(
+          std::lower_bound(spos + lo, spos + n, static_cast<int32_t>(std::min<int64_t>(q1, INT32_MAX))) - spos);
+      for (int32_t k = lo; k < hi; ++k) {
+        const int32_t r = sorted ? k : order[k];
+        if (q1 > reads->read_pos[r] && q0 < reads->read_end[r]) picked.push_back(static_cast<uint32_t>(r));
+      }
+      if (!sorted) std::sort(picked.begin(), picked.end());
+      first_alt.assign(picked.size(), 255);
+      group.assign(picked.size(), static_cast<uint8_t>(c.n_alts));
+      if (!sup.empty()) {
+        for (size_t j = 0; j < picked.size(); ++j) {
+          const uint32_t r = picked[j];
+          auto range = sup.equal_range(rhash[r]);
+          for (auto it = range.first; it != range.second; ++it) {
+            const char* k = support_keys + it->second.key_off;
+            const char* nm = reads->names + reads->name_off[r];
+            if (it->second.key_len == rlen[r] + 2 && std::memcmp(k, nm, rlen[r]) == 0 &&
+                k[rlen[r]] == '/' && k[rlen[r] + 1] == static_cast<char>('0' + reads->read_number[r])) {
+              first_alt[j] = it->second.first_alt;
+              group[j] = it->second.last_alt;
+              break;
+            }
+          }
+        }
+      }
+      // ---- one item per alt combination ----
+      for (uint32_t k = 0; k < c.n_combos; ++k) {
+        const uint32_t mask = combo_masks[c.first_combo + k];
+        pr->item_variant_start.push_back(static_cast<int32_t>(c.start));
+        pr->item_image_start.push_back(static_cast<int32_t>(c.start - half));
+        pr->item_ref_idx.push_back(static_cast<uint32_t>(c.ref_idx));
+        pr->item_height.push_back(static_cast<uint16_t>(opt->pileup_height));
+        pr->item_candidate.push_back(ci);
+        pr->item_combo.push_back(mask);
+        for (size_t j = 0; j < picked.size(); ++j) {
+          pr->list_read.push_back(picked[j]);
+          pr->list_code.push_back(first_alt[j] == 255 ? 0 : ((mask >> first_alt[j]) & 1u) ? 1 : 2);
+          pr->list_group.push_back(group[j]);
+        }
+        pr->item_list_off.push_back(static_cast<uint32_t>(pr->list_read.size()));
+        pr->max_list_len = std::max<uint32_t>(pr->max_list_len, static_cast<uint32_t>(picked.size()));
       }
     }
-    // ---- one item per alt combination ----
-    for (uint32_t k = 0; k < c.n_combos; ++k) {
-      const uint32_t mask = combo_masks[c.first_combo + k];
-      const size_t item = pr->item_height.size();
-      pr->item_variant_start.push_back(static_cast<int32_t>(c.start));
-      pr->item_image_start.push_back(static_cast<int32_t>(c.start - half));
-      pr->item_ref_idx.push_back(static_cast<uint32_t>(c.ref_idx));
-      pr->item_height.push_back(static_cast<uint16_t>(opt->pileup_height));
-      pr->item_out_off.push_back(static_cast<uint64_t>(item) * opt->example_bytes);
-      pr->item_candidate.push_back(ci);
-      pr->item_combo.push_back(mask);
-      for (size_t j = 0; j < picked.size(); ++j) {
-        pr->list_read.push_back(picked[j]);
-        pr->list_code.push_back(first_alt[j] == 255 ? 0 : ((mask >> first_alt[j]) & 1u) ? 1 : 2);
-        pr->list_group.push_back(group[j]);
-      }
-      pr->item_list_off.push_back(static_cast<uint32_t>(pr->list_read.size()));
-      pr->max_list_len = std::max<uint32_t>(pr->max_list_len, static_cast<uint32_t>(picked.size()));
+  };
+  int n_threads = opt->n_threads > 0 ? opt->n_threads : 1;
+  n_threads = std::max(1, std::min(n_threads, n_candidates / 64));   // small regions: one thread
+  std::vector<std::unique_ptr<dv_packed_region>> parts;
+  std::vector<std::string> errors(n_threads);
+  for (int t = 0; t < n_threads; ++t) parts.push_back(std::make_unique<dv_packed_region>());
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) {
+      pool.emplace_back(pack_slice, static_cast<int32_t>(static_cast<int64_t>(n_candidates) * t / n_threads),
+                        static_cast<int32_t>(static_cast<int64_t>(n_candidates) * (t + 1) / n_threads),
+                        parts[t].get(), &errors[t]);
     }
+    pack_slice(0, static_cast<int32_t>(static_cast<int64_t>(n_candidates) / n_threads), parts[0].get(), &errors[0]);
+    for (std::thread& th : pool) th.join();
+  }
+  for (const std::string& e : errors) {
+    if (!e.empty()) return dv::fail(DV_ERR_INVALID_ARGUMENT, e);
+  }
+  std::unique_ptr<dv_packed_region> pr = std::move(parts[0]);
+  for (int t = 1; t < n_threads; ++t) {
+    const dv_packed_region& q = *parts[t];
+    const uint32_t shift = static_cast<uint32_t>(pr->list_read.size());
+    auto append = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    append(pr->item_variant_start, q.item_variant_start);
+    append(pr->item_image_start, q.item_image_start);
+    append(pr->item_ref_idx, q.item_ref_idx);
+    append(pr->item_height, q.item_height);
+    append(pr->item_candidate, q.item_candidate);
+    append(pr->item_combo, q.item_combo);
+    append(pr->list_read, q.list_read);
+    append(pr->list_code, q.list_code);
+    append(pr->list_group, q.list_group);
+    for (size_t k = 1; k < q.item_list_off.size(); ++k) pr->item_list_off.push_back(q.item_list_off[k] + shift);
+    pr->max_list_len = std::max(pr->max_list_len, q.max_list_len);
+  }
+  pr->item_out_off.resize(pr->item_height.size());
+  for (size_t item = 0; item < pr->item_out_off.size(); ++item) {
+    pr->item_out_off[item] = static_cast<uint64_t>(item) * opt->example_bytes;
   }
   *out = pr.release();
   return DV_OK;

@@ -45,7 +45,8 @@ class RegionInputs:
   the timed pipeline never touches Python objects per read or per candidate."""
 
   def __init__(self, table: packing.ReadTable, candidates: Sequence, combos, windows: Sequence[str],
-               width: int, read_overlap_buffer_bp: int, pileup_height: int, example_bytes: int):
+               width: int, read_overlap_buffer_bp: int, pileup_height: int, example_bytes: int,
+               pack_threads: int = 8):
     self.table = table
     self.width = width
     self.n_candidates = len(candidates)
@@ -56,7 +57,7 @@ class RegionInputs:
     self.reads = _lib.DvPackReads(table.n_reads, self.read_pos.ctypes.data, self.read_end.ctypes.data,
                                   blob.ctypes.data, offs.ctypes.data, nums.ctypes.data)
     self.opt = _lib.DvPackOptions(int(width), int(read_overlap_buffer_bp), int(pileup_height),
-                                  int(example_bytes))
+                                  int(pack_threads), int(example_bytes))
     self.cands = (_lib.DvPackCandidate * max(len(candidates), 1))()
     masks, keys, alts_of, wins = [], [], [], []
     for i, cand in enumerate(candidates):

@@ -11,6 +11,8 @@ cross to the device (include/dvhip.h, `dv_batch`).
 """
 from __future__ import annotations
 
+import os
+
 import dataclasses
 from typing import Dict, List, Optional, Sequence
 
@@ -447,7 +449,7 @@ def pack_region_native(table: 'ReadTable', candidates: Sequence, combos: Sequenc
                            blob.ctypes.data, offs.ctypes.data if offs.size else None,
                            nums.ctypes.data if nums.size else None)
   opt = _lib.DvPackOptions(int(width), int(read_overlap_buffer_bp), int(pileup_height),
-                           int(example_bytes))
+                           int(os.environ.get('DV_PACK_THREADS', '4')), int(example_bytes))
   n = len(candidates)
   cands = (_lib.DvPackCandidate * max(n, 1))()
   masks: List[int] = []

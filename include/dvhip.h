@@ -322,6 +322,7 @@ typedef struct dv_pack_options {
   int32_t width;                   /* pic_options.width: image_start = variant.start - (width-1)/2 */
   int32_t read_overlap_buffer_bp;  /* pic_options.read_overlap_buffer_bp (5) */
   int32_t pileup_height;           /* sample_options.pileup_height */
+  int32_t n_threads;               /* host threads over the candidates; 0 / 1 = the calling thread only */
   uint64_t example_bytes;          /* bytes of one example: item k is written at k * example_bytes */
 } dv_pack_options;
 

@@ -51,9 +51,11 @@ def _same(a, b, groups):
   assert (batch_a.list_group is None) == (batch_b.list_group is None)
 
 
-@pytest.mark.parametrize('sort_by_support', [False, True])
-@pytest.mark.parametrize('shuffle_reads', [False, True])
-def test_native_packer_equals_python_packer(sort_by_support, shuffle_reads):
+@pytest.mark.parametrize('sort_by_support,shuffle_reads,n_cands,threads', [
+    (False, False, 60, 4), (True, False, 60, 4), (False, True, 60, 4), (True, True, 60, 4),
+    (True, False, 700, 1), (True, True, 700, 8)])      # 700 candidates: slices on several host threads
+def test_native_packer_equals_python_packer(sort_by_support, shuffle_reads, n_cands, threads, monkeypatch):
+  monkeypatch.setenv('DV_PACK_THREADS', str(threads))
   rng = np.random.default_rng(5 + sort_by_support + 2 * shuffle_reads)
   width = 61
   pic = F.options(T.PILEUP_CHANNELS_WITH_INSERT_SIZE, width, 40,
@@ -75,7 +77,7 @@ def test_native_packer_equals_python_packer(sort_by_support, shuffle_reads):
   if not shuffle_reads:
     reads.sort(key=lambda r: r.alignment.position.position)
   cands = []
-  for pos in sorted(rng.integers(0, 2990, size=60).tolist()):   # duplicates and contig edges included
+  for pos in sorted(rng.integers(0, 2990, size=n_cands).tolist()):   # duplicates and contig edges included
     refb = ref.seq[pos]
     alts = [b for b in 'ACGT' if b != refb][:int(rng.integers(1, 4))]
     support = {}
