@@ -336,7 +336,7 @@ def host_inclusive(args, host_batch, opts, C, enc, model, dev):
                       'read-name lists' % (W, C),
           'candidates_per_step': n_items,
           'reads_per_step': int(table.n_reads),
-          'host_threads': 'one packer thread + the launching thread',
+          'host_threads': 'one packer thread (dv_pack_region on 8 host threads) + the launching thread',
       },
       'pack_ms_per_step': 1e3 * pipe.pack_seconds / args.steps,
       'staging_ms_per_step': 1e3 * pipe.stage_seconds / args.steps,

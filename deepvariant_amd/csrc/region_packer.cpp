@@ -70,11 +70,32 @@ int dv_pack_region(const dv_pack_reads* reads, const dv_pack_options* opt, int32
   std::vector<uint32_t> rlen(n);
   bool sorted = true;
   int64_t max_span = 1;
+  {
+    // key hashes of all reads: slices on the same number of host threads as the candidates
+    const int nt = std::max(1, std::min(opt->n_threads > 0 ? opt->n_threads : 1, n / 4096));
+    std::vector<int> bad(nt, 0);
+    auto hash_slice = [&](int t) {
+      const int32_t r0 = static_cast<int32_t>(static_cast<int64_t>(n) * t / nt);
+      const int32_t r1 = static_cast<int32_t>(static_cast<int64_t>(n) * (t + 1) / nt);
+      for (int32_t r = r0; r < r1; ++r) {
+        const char* nm = reads->names + reads->name_off[r];
+        rlen[r] = static_cast<uint32_t>(std::strlen(nm));
+        if (reads->read_number[r] > 9) {
+          bad[t] = 1;
+          return;
+        }
+        rhash[r] = key_hash(nm, rlen[r], reads->read_number[r]);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(hash_slice, t);
+    hash_slice(0);
+    for (std::thread& th : pool) th.join();
+    for (int b : bad) {
+      if (b) return dv::fail(DV_ERR_BAD_INPUT, "read_number > 9");
+    }
+  }
   for (int32_t r = 0; r < n; ++r) {
-    const char* nm = reads->names + reads->name_off[r];
-    rlen[r] = static_cast<uint32_t>(std::strlen(nm));
-    if (reads->read_number[r] > 9) return dv::fail(DV_ERR_BAD_INPUT, "read_number > 9");
-    rhash[r] = key_hash(nm, rlen[r], reads->read_number[r]);
     if (r && reads->read_pos[r] < reads->read_pos[r - 1]) sorted = false;
     max_span = std::max<int64_t>(max_span, reads->read_end[r] - reads->read_pos[r]);
   }
