@@ -22,9 +22,37 @@
 
 #include "dv_internal.h"
 
+// Results live in pinned host memory (the count array of a 7.7 Mb interval is 31 MB: 1.3 ms
+// over PCIe from pinned memory, 5 ms into pageable).
+template <typename T>
+struct PinnedArray {
+  T* ptr = nullptr;
+  size_t n = 0;
+  int reserve(size_t count) {
+    release();
+    if (count == 0) return DV_OK;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return dv::fail(DV_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    n = count;
+    return DV_OK;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    n = 0;
+  }
+  ~PinnedArray() { release(); }
+};
+
 struct dv_allele_counts {
-  std::vector<int32_t> ref_count;
+  PinnedArray<int32_t> ref_count;
+  PinnedArray<dv_allele_event> raw;      // as the kernel left them
   std::vector<dv_allele_event> events;   // sorted by (position, read, read_offset)
+  std::vector<int32_t> empty_counts;
+  int64_t length = 0;
   int32_t n_reads_counted = 0;
 };
 
@@ -63,23 +91,54 @@ struct Entry {
   uint32_t read_offset, length;
 };
 
-__device__ __forceinline__ void emit(const CountArgs& a, uint32_t read, const Entry& e) {
+// Reference matches are by far the most frequent outcome (one per aligned base) and pile up
+// ~coverage-deep on neighbouring positions: a workgroup counts them in an LDS window that
+// starts at its first read and flushes the non-zero counters once, so the device-scope
+// atomics shrink by about the pile-up depth of the group's reads; positions outside the
+// window (unsorted or very long reads) go straight to memory.
+constexpr int kWindow = 4096;        // positions per workgroup window (16 KB of LDS)
+constexpr int kReadsPerWave = 16;    // a workgroup of 4 waves takes 64 consecutive reads
+
+constexpr int kBlockEvents = 1024;   // events staged per workgroup before they take global slots
+
+struct BlockState {
+  int window[kWindow];
+  dv_allele_event events[kBlockEvents];
+  int n_events, n_reads;
+  uint32_t event_base;
+};
+
+__device__ __forceinline__ void emit(const CountArgs& a, uint32_t read, const Entry& e, BlockState* bs,
+                                     int64_t window_start) {
+  int* window = bs->window;
   const int64_t p = e.abs_pos - a.interval_start;
   if (p < 0 || p >= a.interval_len) return;            // IsValidIntervalOffset
   if (e.type == kRef) {
-    if (!e.low) atomicAdd(&a.ref_count[p], 1);
+    if (!e.low) {
+      const int64_t w = e.abs_pos - window_start;
+      if (w >= 0 && w < kWindow) {
+        atomicAdd(&window[w], 1);
+      } else {
+        atomicAdd(&a.ref_count[p], 1);
+      }
+    }
     return;
   }
-  const uint32_t slot = atomicAdd(&a.counters[0], 1u);
-  if (slot < a.event_cap) {
-    dv_allele_event ev;
-    ev.position = static_cast<int32_t>(p);
-    ev.read = read;
-    ev.read_offset = e.read_offset;
-    ev.length = e.length > 0xffffu ? 0xffffu : static_cast<uint16_t>(e.length);
-    ev.type = static_cast<uint8_t>(e.type);
-    ev.low_quality = static_cast<uint8_t>(e.low);
-    a.events[slot] = ev;
+  dv_allele_event ev;
+  ev.position = static_cast<int32_t>(p);
+  ev.read = read;
+  ev.read_offset = e.read_offset;
+  ev.length = e.length > 0xffffu ? 0xffffu : static_cast<uint16_t>(e.length);
+  ev.type = static_cast<uint8_t>(e.type);
+  ev.low_quality = static_cast<uint8_t>(e.low);
+  // One counter for the whole launch serialises at ~20 ns per atomic (a quarter of a million
+  // events = the whole kernel time): stage in LDS, take the global slots once per workgroup.
+  const int local = atomicAdd(&bs->n_events, 1);
+  if (local < kBlockEvents) {
+    bs->events[local] = ev;
+  } else {
+    const uint32_t slot = atomicAdd(&a.counters[0], 1u);
+    if (slot < a.event_cap) a.events[slot] = ev;
   }
 }
 
@@ -104,12 +163,10 @@ __device__ __forceinline__ Entry base_entry(const CountArgs& a, uint32_t s0, int
   return e;
 }
 
-__global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= static_cast<uint32_t>(a.n_reads)) return;
+__device__ __forceinline__ void count_read(const CountArgs& a, uint32_t r, int lane, BlockState* window,
+                                           int64_t window_start) {
   if (a.mapq[r] < a.min_mapq) return;
-  if (lane == 0) atomicAdd(&a.counters[1], 1u);
+  if (lane == 0) atomicAdd(&window->n_reads, 1);
   const uint32_t s0 = a.seq_off[r];
   uint32_t read_offset = 0;
   int64_t abs_pos = a.read_pos[r];
@@ -120,11 +177,11 @@ __global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
     const uint32_t n = word >> 4;
     if (op == opM || op == opEQ || op == opX) {
       // nothing later can share the pending entry's position any more
-      if (pending.have && lane == 0) emit(a, r, pending);
+      if (pending.have && lane == 0) emit(a, r, pending, window, window_start);
       pending.have = false;
       for (uint32_t i = lane; i + 1 < n; i += 64) {
         const Entry e = base_entry(a, s0, abs_pos + i, read_offset + i);
-        if (e.have) emit(a, r, e);
+        if (e.have) emit(a, r, e, window, window_start);
       }
       if (n > 0) pending = base_entry(a, s0, abs_pos + n - 1, read_offset + n - 1);   // may be superseded
       read_offset += n;
@@ -187,7 +244,7 @@ __global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
       }
       // AddReadAlleles: of two consecutive alleles at one position the first is dropped.  A
       // skipped allele (position -1 in the reference) never equals a real position.
-      if (pending.have && !(e.have && e.abs_pos == pending.abs_pos) && lane == 0) emit(a, r, pending);
+      if (pending.have && !(e.have && e.abs_pos == pending.abs_pos) && lane == 0) emit(a, r, pending, window, window_start);
       pending = e;
       if (op == opD) {
         abs_pos += n;
@@ -198,7 +255,37 @@ __global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
       abs_pos += n;
     }
   }
-  if (pending.have && lane == 0) emit(a, r, pending);
+  if (pending.have && lane == 0) emit(a, r, pending, window, window_start);
+}
+
+__global__ __launch_bounds__(256) void count_alleles_kernel(CountArgs a) {
+  __shared__ BlockState bs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * (4 * kReadsPerWave);
+  for (int i = threadIdx.x; i < kWindow; i += 256) bs.window[i] = 0;
+  if (threadIdx.x == 0) bs.n_events = bs.n_reads = 0;
+  const int64_t window_start = a.read_pos[first];      // reads arrive position-sorted (BAM order)
+  __syncthreads();
+  for (int k = 0; k < kReadsPerWave; ++k) {
+    const uint32_t r = first + k * 4 + wave;           // neighbouring reads side by side on the four waves
+    if (r < static_cast<uint32_t>(a.n_reads)) count_read(a, r, lane, &bs, window_start);
+  }
+  __syncthreads();
+  const int n_ev = bs.n_events < kBlockEvents ? bs.n_events : kBlockEvents;
+  if (threadIdx.x == 0) {
+    bs.event_base = n_ev ? atomicAdd(&a.counters[0], static_cast<uint32_t>(n_ev)) : 0u;
+    if (bs.n_reads) atomicAdd(&a.counters[1], static_cast<uint32_t>(bs.n_reads));
+  }
+  for (int i = threadIdx.x; i < kWindow; i += 256) {
+    const int v = bs.window[i];
+    const int64_t p = window_start + i - a.interval_start;
+    if (v != 0 && p >= 0 && p < a.interval_len) atomicAdd(&a.ref_count[p], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_ev; i += 256) {
+    const uint32_t slot = bs.event_base + i;
+    if (slot < a.event_cap) a.events[slot] = bs.events[i];
+  }
 }
 
 template <typename T>
@@ -239,18 +326,22 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const int64_t len = o->interval_end - o->interval_start;
   auto res = std::make_unique<dv_allele_counts>();
-  res->ref_count.assign(static_cast<size_t>(len), 0);
+  res->length = len;
   if (b->n_reads == 0 || len == 0) {
+    res->empty_counts.assign(static_cast<size_t>(len), 0);
     *out = res.release();
     return DV_OK;
   }
-  dv::DeviceBuffer up[7], d_ref, d_cnt, d_ev, d_ctr;
+  // result / reference scratch is kept per host thread (grow-only): a region driver calls this
+  // once per region and hipMalloc + hipFree of ~100 MB cost more than the kernel
+  static thread_local dv::DeviceBuffer d_ref, d_cnt, d_ev, d_ctr;
+  dv::DeviceBuffer up[7];
   struct Release {
-    dv::DeviceBuffer* v[11];
+    dv::DeviceBuffer* v[7];
     ~Release() {
       for (dv::DeviceBuffer* p : v) p->release();
     }
-  } rel{{&up[0], &up[1], &up[2], &up[3], &up[4], &up[5], &up[6], &d_ref, &d_cnt, &d_ev, &d_ctr}};
+  } rel{{&up[0], &up[1], &up[2], &up[3], &up[4], &up[5], &up[6]}};
   CountArgs a{};
   a.n_reads = b->n_reads;
   const size_t n = static_cast<size_t>(b->n_reads);
@@ -281,7 +372,7 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   a.counters = static_cast<uint32_t*>(d_ctr.ptr);
   // events: substitutions are a few per cent of the bases, indels at most one per CIGAR op;
   // the counter keeps counting past the capacity, so a second pass sizes it exactly
-  uint32_t cap = b->n_cigar + b->n_bases / 8 + 4096;
+  uint32_t cap = b->n_cigar + b->n_bases / 16 + 4096;
   uint32_t ctr[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; ++pass) {
     if (int rc = d_ev.reserve(static_cast<size_t>(cap) * sizeof(dv_allele_event))) return rc;
@@ -291,7 +382,8 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
     DV_HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 4 * sizeof(uint32_t), stream));
     {
       dv::ProfileScope prof(dv::kProfOther, stream);
-      hipLaunchKernelGGL(count_alleles_kernel, dim3((b->n_reads + 3) / 4), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(count_alleles_kernel, dim3((b->n_reads + 4 * kReadsPerWave - 1) / (4 * kReadsPerWave)),
+                         dim3(256), 0, stream, a);
     }
     DV_HIP_CHECK(hipGetLastError());
     DV_HIP_CHECK(hipMemcpyAsync(ctr, d_ctr.ptr, sizeof(ctr), hipMemcpyDeviceToHost, stream));
@@ -304,23 +396,56 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
                     "dv_count_alleles: an indel reaches outside the reference window (pass more margin)");
   }
   res->n_reads_counted = static_cast<int32_t>(ctr[1]);
-  res->events.resize(ctr[0]);
-  DV_HIP_CHECK(hipMemcpyAsync(res->ref_count.data(), d_cnt.ptr, static_cast<size_t>(len) * sizeof(int32_t),
+  if (int rc = res->ref_count.reserve(static_cast<size_t>(len))) return rc;
+  if (int rc = res->raw.reserve(ctr[0])) return rc;
+  DV_HIP_CHECK(hipMemcpyAsync(res->ref_count.ptr, d_cnt.ptr, static_cast<size_t>(len) * sizeof(int32_t),
                               hipMemcpyDeviceToHost, stream));
   if (ctr[0]) {
-    DV_HIP_CHECK(hipMemcpyAsync(res->events.data(), d_ev.ptr, static_cast<size_t>(ctr[0]) * sizeof(dv_allele_event),
+    DV_HIP_CHECK(hipMemcpyAsync(res->raw.ptr, d_ev.ptr, static_cast<size_t>(ctr[0]) * sizeof(dv_allele_event),
                                 hipMemcpyDeviceToHost, stream));
   }
   DV_HIP_CHECK(hipStreamSynchronize(stream));
-  // (position, read, read_offset): one read can leave two alleles at one position when a
-  // skipped allele sits between them (1I 4S 2D with an unusable soft clip: the insertion is
+  // Order: (position, read, read_offset).  One read can leave two alleles at one position when
+  // a skipped allele sits between them (1I 4S 2D with an unusable soft clip: the insertion is
   // not superseded, the deletion is added after it); read offsets order them as the CIGAR
   // does, so the consumer's "later entry overwrites" matches read_alleles[key] = allele.
-  std::sort(res->events.begin(), res->events.end(), [](const dv_allele_event& x, const dv_allele_event& y) {
-    if (x.position != y.position) return x.position < y.position;
-    if (x.read != y.read) return x.read < y.read;
-    return x.read_offset < y.read_offset;
-  });
+  // LSD radix sort on (position << 32 | read), 16 bits a pass, then the rare ties by offset.
+  {
+    const size_t n_ev = ctr[0];
+    std::vector<uint64_t> key(n_ev), key2(n_ev);
+    std::vector<uint32_t> idx(n_ev), idx2(n_ev);
+    uint64_t all = 0;
+    for (size_t i = 0; i < n_ev; ++i) {
+      key[i] = (static_cast<uint64_t>(static_cast<uint32_t>(res->raw.ptr[i].position)) << 32) | res->raw.ptr[i].read;
+      idx[i] = static_cast<uint32_t>(i);
+      all |= key[i];
+    }
+    for (int shift = 0; shift < 64; shift += 16) {
+      if (((all >> shift) & 0xffffu) == 0) continue;      // these 16 bits are zero everywhere
+      size_t count[65537] = {0};
+      for (size_t i = 0; i < n_ev; ++i) ++count[((key[i] >> shift) & 0xffffu) + 1];
+      for (int c = 0; c < 65536; ++c) count[c + 1] += count[c];
+      for (size_t i = 0; i < n_ev; ++i) {
+        const size_t d = count[(key[i] >> shift) & 0xffffu]++;
+        key2[d] = key[i];
+        idx2[d] = idx[i];
+      }
+      key.swap(key2);
+      idx.swap(idx2);
+    }
+    res->events.resize(n_ev);
+    for (size_t i = 0; i < n_ev; ++i) res->events[i] = res->raw.ptr[idx[i]];
+    for (size_t i = 0; i + 1 < n_ev;) {
+      size_t j = i + 1;
+      while (j < n_ev && key[j] == key[i]) ++j;
+      if (j - i > 1) {
+        std::sort(res->events.begin() + i, res->events.begin() + j,
+                  [](const dv_allele_event& x, const dv_allele_event& y) { return x.read_offset < y.read_offset; });
+      }
+      i = j;
+    }
+    res->raw.release();
+  }
   *out = res.release();
   return DV_OK;
 }
@@ -328,11 +453,11 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
 int dv_allele_counts_arrays(const dv_allele_counts* c, const int32_t** ref_supporting_read_count,
                             const dv_allele_event** events, uint32_t* n_events, int32_t* n_reads_counted) {
   if (!c) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_allele_counts_arrays: null");
-  if (ref_supporting_read_count) *ref_supporting_read_count = c->ref_count.data();
+  if (ref_supporting_read_count) *ref_supporting_read_count = c->ref_count.ptr ? c->ref_count.ptr : c->empty_counts.data();
   if (events) *events = c->events.data();
   if (n_events) *n_events = static_cast<uint32_t>(c->events.size());
   if (n_reads_counted) *n_reads_counted = c->n_reads_counted;
-  return static_cast<int>(c->ref_count.size());
+  return static_cast<int>(c->length);
 }
 
 void dv_allele_counts_free(dv_allele_counts* c) { delete c; }
