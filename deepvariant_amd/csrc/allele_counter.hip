@@ -314,6 +314,25 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
                      !b->quals || !b->cigar)) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: read table field missing");
   }
+  if (b->memory == DV_MEM_HOST) {
+    // the same read-table checks dv_validate_batch applies (a device-resident table is the
+    // caller's to validate before the upload, as for dv_encode_batch)
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+      if (b->read_cigar_off[r + 1] < b->read_cigar_off[r] || b->read_cigar_off[r + 1] > b->n_cigar ||
+          b->read_seq_off[r + 1] < b->read_seq_off[r] || b->read_seq_off[r + 1] > b->n_bases) {
+        return dv::fail(DV_ERR_INVALID_ARGUMENT, "read offsets are not prefix sums within the arrays");
+      }
+      uint64_t qlen = 0;
+      for (uint32_t c = b->read_cigar_off[r]; c < b->read_cigar_off[r + 1]; ++c) {
+        const uint32_t op = b->cigar[c] & 0xF;
+        if (op < 1 || op > 9) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op");
+        if (op == 1 || op == 2 || op == 5 || op == 8 || op == 9) qlen += b->cigar[c] >> 4;
+      }
+      if (qlen > b->read_seq_off[r + 1] - b->read_seq_off[r]) {
+        return dv::fail(DV_ERR_BAD_INPUT, "CIGAR consumes more bases than aligned_sequence has");
+      }
+    }
+  }
   const int64_t reads_start = std::min(o->interval_start, o->reads_interval_start);
   const int64_t reads_end = std::max(o->interval_end, o->reads_interval_end);
   if (o->ref_start > reads_start || o->ref_start + o->n_ref_bases < reads_end) {

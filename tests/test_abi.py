@@ -75,3 +75,29 @@ def test_product_package_never_imports_the_oracle():
         text = open(os.path.join(dirpath, f)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
         assert 'libdvoracle' not in text, f
+
+
+def test_count_alleles_rejects_malformed_host_tables():
+  """dv_count_alleles validates a host-resident read table before any kernel could read it
+  (no GPU needed: the checks come first)."""
+  import ctypes as C
+  import numpy as np
+  from deepvariant_amd import _lib
+  b = _lib.DvBatch()
+  pos = np.array([5], np.int32)
+  seq_off = np.array([0, 3], np.uint32)
+  cig_off = np.array([0, 1], np.uint32)
+  mapq = np.array([60], np.uint8)
+  bases = np.frombuffer(b'ACG', np.uint8).copy()
+  quals = np.array([30, 30, 30], np.uint8)
+  b.memory, b.n_reads, b.n_bases, b.n_cigar = _lib.DV_MEM_HOST, 1, 3, 1
+  for name, arr in (('read_pos', pos), ('read_seq_off', seq_off), ('read_cigar_off', cig_off),
+                    ('read_mapq', mapq), ('bases', bases), ('quals', quals)):
+    setattr(b, name, arr.ctypes.data)
+  opt = _lib.DvAlleleCounterOptions(0, 20, 0, 20, b'A' * 40, 0, 40, 40, 0, 0, 0)
+  h = C.c_void_p()
+  for cigar, message in (((10 << 4) | 1, 'CIGAR consumes more bases'), ((3 << 4) | 12, 'Unrecognized CIGAR op')):
+    cig = np.array([cigar], np.uint32)
+    b.cigar = cig.ctypes.data
+    rc = _lib.lib().dv_count_alleles(C.byref(b), C.byref(opt), C.byref(h), None)
+    assert rc == _lib.DV_ERR_BAD_INPUT and message in _lib.lib().dv_last_error().decode()
