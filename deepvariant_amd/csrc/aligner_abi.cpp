@@ -24,11 +24,10 @@ int copy_text(const std::string& s, char* out, int32_t cap) {
   return DV_OK;
 }
 
-void fill(const dv::ReadAlignment& ra, dv_read_alignment* out) {
+int fill(const dv::ReadAlignment& ra, dv_read_alignment* out) {
   out->position = ra.position == dv::ReadAlignment::kNotAligned ? -1 : ra.position;
   out->score = ra.score;
-  std::strncpy(out->cigar, ra.cigar.c_str(), sizeof(out->cigar) - 1);
-  out->cigar[sizeof(out->cigar) - 1] = '\0';
+  return copy_text(ra.cigar, out->cigar, sizeof(out->cigar));   // never truncated silently
 }
 
 std::vector<std::string> strings(int32_t n, const char* const* v) {
@@ -133,7 +132,9 @@ int dv_aligner_fast_align(dv_aligner* h, const char* haplotype, int32_t* haploty
   int score = *haplotype_score;
   h->a.fast_align_reads_to_haplotype(haplotype, &score, &ra);
   *haplotype_score = score;
-  for (size_t i = 0; out && i < ra.size(); ++i) fill(ra[i], &out[i]);
+  for (size_t i = 0; out && i < ra.size(); ++i) {
+    if (int rc = fill(ra[i], &out[i])) return rc;
+  }
   return DV_OK;
 }
 
@@ -155,8 +156,7 @@ int dv_aligner_read_alignment(const dv_aligner* h, int32_t k, int32_t read, dv_r
       static_cast<size_t>(read) >= h->a.haplotype_alignments()[k].reads.size()) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_aligner_read_alignment: index");
   }
-  fill(h->a.haplotype_alignments()[k].reads[read], out);
-  return DV_OK;
+  return fill(h->a.haplotype_alignments()[k].reads[read], out);
 }
 
 int dv_aligner_merge_alignment(const dv_aligner* h, int32_t read, int32_t position, const char* read_cigar,
@@ -218,7 +218,7 @@ int dv_local_align(const char* reference, const char* query, int32_t match, int3
   dv::LocalAligner a(match, mismatch, gap_open, gap_extend);
   a.set_reference(reference);
   dv::LocalAlignment r;
-  if (!a.align(query, &r)) return dv::fail(DV_ERR_BAD_INPUT, "dv_local_align: empty sequence");
+  if (!a.align(query, &r)) return dv::fail(DV_ERR_BAD_INPUT, "dv_local_align: empty or oversized sequences");
   out->score = r.score;
   out->ref_begin = r.ref_begin;
   out->ref_end = r.ref_end;

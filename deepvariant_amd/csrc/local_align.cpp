@@ -86,6 +86,7 @@ bool LocalAligner::banded_cigar(const int8_t* ref, int ref_len, const int8_t* q,
                                 std::vector<std::pair<char, int>>* ops) const {
   int band = std::abs(ref_len - q_len) + 1;
   const size_t cells = static_cast<size_t>(q_len) * ref_len;
+  if (cells > (size_t{1} << 27)) return false;   // 128 M cells (~1.5 GB of tables): not a window-sized problem
   std::vector<int> H(cells), E(cells);
   std::vector<uint8_t> dE(cells), dF(cells), dH(cells);
   int best = 0;

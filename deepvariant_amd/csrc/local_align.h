@@ -40,7 +40,8 @@ class LocalAligner {
  public:
   LocalAligner(int match, int mismatch, int gap_open, int gap_extend);
   void set_reference(const std::string& reference);
-  // false if the query or the reference is empty (libssw's Align fails the same way)
+  // false if the query or the reference is empty (libssw's Align fails the same way), or if
+  // the aligned sub-problem exceeds 128 M cells (reads x haplotype here are window-sized)
   bool align(const std::string& query, LocalAlignment* out) const;
 
  private:
