@@ -148,10 +148,10 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 //    independent 32x32 accumulators keep the matrix pipe busy back to back.
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
-template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2)>
+template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks>
 __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
-  constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
+  constexpr int SLAB_HALFS = SLAB * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
   constexpr int W_PER_THREAD = SLAB_PIECES / kConvThreads;  // = 2 * NB
   constexpr int kPrefetch = prefetch_depth(NB, PT);
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
 
   // ---- weight slabs: global -> registers -> LDS ---------------------------
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
-                      static_cast<size_t>(band_r * p.n_tiles + n_tile) * p.n_slabs * SLAB_PIECES;
+                      static_cast<size_t>(band_r * p.n_tiles + n_tile) * p.n_slabs * (kSlabChunks * BN * 2);
+  const int n_slabs = (p.n_chunks + SLAB - 1) / SLAB;   // (the packed image is laid out in kSlabChunks units)
   uint4_t wreg[W_PER_THREAD];
 #define DV_LOAD_SLAB(s_)                                                                   \
   {                                                                                        \
@@ -271,17 +272,16 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   // reads 512 contiguous bytes: conflict-free for ds_read_b128 (a [cout][16]
   // image is 2-way conflicted: measured SQ_LDS_BANK_CONFLICT ~ LDS active).
   const int frag_off = (lane >> 5) * (BN * 8) + (lane & 31) * 8;  // halfs
-  const int n_full = p.n_chunks / kSlabChunks;
-  const int rem = p.n_chunks - n_full * kSlabChunks;
+  const int n_full = p.n_chunks / SLAB;
+  const int rem = p.n_chunks - n_full * SLAB;
   for (int s = 0; s < n_full; ++s) {
     // The next slab's global loads are UNCONDITIONAL (the last trip re-reads its own slab
     // into the idle buffer): behind an `if` the compiler has to assume at the first
     // pixel-fragment wait that they were not issued and emits vmcnt(7) -- which, when they
     // were, drains the whole four-chunk prefetch queue at every slab start.
-    const int next = s + 1 < p.n_slabs ? s + 1 : s;
+    const int next = s + 1 < n_slabs ? s + 1 : s;
     DV_LOAD_SLAB(next)
-    conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base,
-                                   xf, acc);
+    conv_slab<NB, PT, SLAB>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc);
     DV_STORE_SLAB((s + 1) & 1)
     __syncthreads();
   }
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   if (rem) {
     const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
     conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
-    if (rem > 4) {
-      conv_slab<NB, PT, 4, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+    if constexpr (SLAB > 4) {
+      if (rem > 4) conv_slab<NB, PT, 4, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
     }
   }
 #undef DV_LOAD_SLAB
@@ -815,6 +815,9 @@ struct dv_model {
     return static_cast<int>(buffers.size()) - 1;
   }
   static int pick_nb(int cout) {
+    // DV_NB6: 192-cout single tiles for 129..192-cout layers (see launch_conv6)
+    static const bool nb6 = getenv("DV_NB6") != nullptr && atoi(getenv("DV_NB6")) != 0;
+    if (nb6 && cout > 128 && cout <= 192) return 6;
     // Cost of a cout tiling ~ tiles x (nb MFMA columns + 1 pixel-fragment stream): a
     // 160-wide layer is cheaper as 2 x 96 (one sixth padding) than as 5 x 32, whose
     // blocks re-load every pixel fragment five times.  Ties -> less padding.
@@ -1218,6 +1221,18 @@ struct dv_model {
 
 namespace {
 
+// 192-cout tiles (NB = 6), one pixel fragment per wave: the pixel operand -- the texture-
+// addresser path that bounds the other shapes -- is fetched once for all 192
+// couts instead of once per 96-cout tile.  Weight slabs of 4 chunks keep two blocks per CU.
+void launch_conv6(const ConvArgs& a, hipStream_t stream) {
+  const long rows = a.band ? a.band : 1;
+  const long row_px = a.band ? static_cast<long>(a.N) * a.OW : a.M;
+  const long blocks = rows * ((row_px + 127) / 128) * a.n_tiles;
+  constexpr size_t lds = static_cast<size_t>(2) * 4 * 192 * kChunk * 2;
+  hipLaunchKernelGGL((conv_mfma_kernel<6, 1, 2, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kConvThreads), lds,
+                     stream, a);
+}
+
 template <int NB>
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int n_tiles = a.n_tiles;
@@ -1527,6 +1542,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         case 1: launch_conv<1>(a, stream); break;
         case 2: launch_conv<2>(a, stream); break;
         case 3: launch_conv<3>(a, stream); break;
+        case 6: launch_conv6(a, stream); break;
         default: launch_conv<4>(a, stream); break;
       }
     } else {
