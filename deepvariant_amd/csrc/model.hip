@@ -1053,6 +1053,9 @@ struct dv_model {
       }
       if (follower) continue;
       op.band = h;
+      // the row-band 7x1 layers are the one shape where a single 192-cout tile (launch_conv6)
+      // measured faster than two 96-cout tiles (-5...-13 %); DV_NO_BAND_NB6 keeps two tiles
+      if (op.cout > 128 && op.cout <= 192 && op.nb == 3 && getenv("DV_NO_BAND_NB6") == nullptr) op.nb = 6;
       op.n_chunks = h * op.kw * (op.cin / kChunk);
       op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;
     }
