@@ -48,6 +48,8 @@ ABI_SYMBOLS = [
     'dv_aligner_read_alignment', 'dv_aligner_merge_alignment', 'dv_aligner_is_normalized',
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
     'dv_merge_cigar_op', 'dv_local_align',
+    'dv_debruijn_build', 'dv_debruijn_destroy', 'dv_debruijn_kmer_size', 'dv_debruijn_haplotypes',
+    'dv_debruijn_graphviz',
     'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
 
@@ -163,6 +165,11 @@ class DvLocalAlignment(C.Structure):
               ('cigar', C.c_char * 512)]
 
 
+class DvDebruijnOptions(C.Structure):
+  _fields_ = [(n, C.c_int32) for n in ('min_k', 'max_k', 'step_k', 'min_mapq', 'min_base_quality',
+                                       'min_edge_weight', 'max_num_paths', 'disable_graph_pruning')]
+
+
 class DvAltMergeEntry(C.Structure):
   _fields_ = [('example', C.c_int64), ('first_row', C.c_int32), ('rows', C.c_int32),
               ('scratch_alt1', C.c_int64), ('scratch_alt2', C.c_int64)]
@@ -268,6 +275,13 @@ def lib():
     l.dv_positions_map.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
     l.dv_merge_cigar_op.argtypes = [C.c_void_p, C.c_int32, C.c_char, C.c_int32, C.c_int32]
     l.dv_local_align.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int32] * 4 + [C.c_void_p]
+    l.dv_debruijn_build.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p,
+                                                                                  C.c_int32, C.c_void_p, C.c_void_p]
+    l.dv_debruijn_destroy.argtypes = [C.c_void_p]
+    l.dv_debruijn_destroy.restype = None
+    l.dv_debruijn_kmer_size.argtypes = [C.c_void_p]
+    l.dv_debruijn_haplotypes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_debruijn_graphviz.argtypes = [C.c_void_p, C.c_void_p]
     l.dv_count_alleles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     l.dv_allele_counts_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     l.dv_allele_counts_free.argtypes = [C.c_void_p]

@@ -53,7 +53,7 @@ def sum_allele_counts(allele_count: AlleleCount, include_low_quality: bool = Fal
       k = (allele.bases, allele.type)
       sums[k] = sums.get(k, 0) + 1
   out = [Allele(b, t, n) for (b, t), n in sorted(sums.items())]
-  if allele_count.ref_supporting_read_count > 0 and not allele_count.track_ref_reads:
+  if allele_count.ref_supporting_read_count > 0 and not getattr(allele_count, 'track_ref_reads', False):
     out.append(Allele(allele_count.ref_base, REFERENCE, allele_count.ref_supporting_read_count))
   return out
 

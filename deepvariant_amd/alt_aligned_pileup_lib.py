@@ -11,10 +11,8 @@ Mirrors, function by function,
   deepvariant/pileup_image_native.h:214-335      FillPileupArray, FillPileupArrayBySample
 with the reference's own test vectors in tests/test_alt_aligned_pileup_lib_cpu.py.
 
-Not here (not built): RealignReadsToHaplotype -- the FastPassAligner
-(deepvariant/realigner/fast_pass_aligner.cc) that produces the alt-aligned reads.  Everything
-on both sides of it is: the trimmed reads it consumes and the image layouts its results
-are drawn into.
+RealignReadsToHaplotype -- the FastPassAligner that produces the alt-aligned reads -- is
+deepvariant_amd/fast_pass_aligner.py (native: csrc/fast_pass_aligner.cpp).
 
 Images are numpy uint8 [rows, width, channels] (the HWC bytes of `image/encoded`); an
 "empty" alt image is None.

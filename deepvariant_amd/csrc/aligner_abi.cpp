@@ -6,12 +6,20 @@
 #include <string>
 #include <vector>
 
+#include "debruijn_graph.h"
 #include "dv_internal.h"
 #include "fast_pass_aligner.h"
 
 struct dv_aligner {
   dv::FastPassAligner a;
   std::vector<uint32_t> cigar_words;
+};
+
+struct dv_debruijn_graph {
+  std::unique_ptr<dv::DeBruijnGraph> g;
+  std::vector<std::string> haplotypes;
+  std::vector<const char*> haplotype_ptrs;
+  std::string dot;
 };
 
 namespace {
@@ -226,6 +234,73 @@ int dv_local_align(const char* reference, const char* query, int32_t match, int3
   out->query_end = r.query_end;
   out->mismatches = r.mismatches;
   return copy_text(r.cigar, out->cigar, sizeof(out->cigar));
+}
+
+// ---- local assembly (debruijn_graph.cpp)
+
+int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals,
+                      const uint32_t* read_seq_off, const uint8_t* read_mapq, int32_t n_table_reads,
+                      const int32_t* reads, int32_t n_reads, const dv_debruijn_options* o,
+                      dv_debruijn_graph** out) {
+  if (!out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_build: null out");
+  *out = nullptr;
+  if (!ref || ref_len < 0 || !o || n_reads < 0 || n_table_reads < 0 ||
+      (n_reads > 0 && (!bases || !quals || !read_seq_off || !read_mapq || !reads))) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_build: null argument");
+  }
+  if (o->step_k <= 0 || o->min_k <= 0) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_build: min_k and step_k must be positive");
+  }
+  std::vector<dv::AssemblyRead> rs;
+  rs.reserve(n_reads);
+  for (int32_t i = 0; i < n_reads; ++i) {
+    const int32_t r = reads[i];
+    if (r < 0 || r >= n_table_reads || read_seq_off[r + 1] < read_seq_off[r]) {
+      return dv::fail(DV_ERR_BAD_INPUT, "dv_debruijn_build: read index outside the table");
+    }
+    const uint32_t a = read_seq_off[r], b = read_seq_off[r + 1];
+    rs.push_back(dv::AssemblyRead{std::string_view(reinterpret_cast<const char*>(bases) + a, b - a), quals + a,
+                                  read_mapq[r]});
+  }
+  dv::DeBruijnOptions opt;
+  opt.min_k = o->min_k;
+  opt.max_k = o->max_k;
+  opt.step_k = o->step_k;
+  opt.min_mapq = o->min_mapq;
+  opt.min_base_quality = o->min_base_quality;
+  opt.min_edge_weight = o->min_edge_weight;
+  opt.max_num_paths = o->max_num_paths;
+  opt.disable_graph_pruning = o->disable_graph_pruning != 0;
+  auto g = dv::DeBruijnGraph::build(std::string_view(ref, static_cast<size_t>(ref_len)), rs, opt);
+  if (!g) return DV_OK;            // no acyclic graph for any k: *out stays NULL
+  auto h = std::make_unique<dv_debruijn_graph>();
+  h->g = std::move(g);
+  *out = h.release();
+  return DV_OK;
+}
+
+void dv_debruijn_destroy(dv_debruijn_graph* h) { delete h; }
+
+int dv_debruijn_kmer_size(const dv_debruijn_graph* h) {
+  if (!h) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_kmer_size: null");
+  return h->g->kmer_size();
+}
+
+int dv_debruijn_haplotypes(dv_debruijn_graph* h, int32_t* n, const char* const** haplotypes) {
+  if (!h || !n || !haplotypes) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_haplotypes: null");
+  h->haplotypes = h->g->candidate_haplotypes();
+  h->haplotype_ptrs.clear();
+  for (const std::string& s : h->haplotypes) h->haplotype_ptrs.push_back(s.c_str());
+  *n = static_cast<int32_t>(h->haplotypes.size());
+  *haplotypes = h->haplotype_ptrs.data();
+  return DV_OK;
+}
+
+int dv_debruijn_graphviz(dv_debruijn_graph* h, const char** text) {
+  if (!h || !text) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_graphviz: null");
+  h->dot = h->g->graphviz();
+  *text = h->dot.c_str();
+  return DV_OK;
 }
 
 }  // extern "C"

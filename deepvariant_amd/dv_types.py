@@ -135,6 +135,14 @@ class Position:
 
 
 @dataclass
+class Range:
+  """nucleus.genomics.v1.Range: [start, end) on reference_name."""
+  reference_name: str = ''
+  start: int = 0
+  end: int = 0
+
+
+@dataclass
 class LinearAlignment:
   position: Position = field(default_factory=Position)
   mapping_quality: int = 0

@@ -134,6 +134,39 @@ class FastPassAligner:
       res.append((out[i].status, out[i].position, cig))
     return res
 
+  def realign_reads(self, reads: Sequence) -> List[Optional[T.Read]]:
+    """FastPassAligner::AlignReads on Read objects (fast_pass_aligner.cc:183-232, :510-590):
+    per input read the read with its new alignment, the unchanged read (no better alignment,
+    or the merged CIGAR was rejected), or None where the reference returns an empty Read
+    (force_alignment and nothing found)."""
+    out = []
+    for read, (status, position, cigar) in zip(reads, self.align_reads([r.aligned_sequence for r in reads])):
+      if status == 2:
+        out.append(None)
+      elif status == 0:
+        out.append(read)
+      else:
+        out.append(with_alignment(read, position, cigar))
+    return out
+
+
+def with_alignment(read, position: int, cigar) -> T.Read:
+  """A copy of `read` whose alignment start and CIGAR are replaced (RealignReadsToReference,
+  fast_pass_aligner.cc:510-590: everything else is merged over from the input read)."""
+  p = read.alignment.position
+  return T.Read(
+      fragment_name=read.fragment_name, read_number=read.read_number,
+      number_reads=read.number_reads, fragment_length=read.fragment_length,
+      proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
+      failed_vendor_quality_checks=read.failed_vendor_quality_checks,
+      secondary_alignment=read.secondary_alignment,
+      supplementary_alignment=read.supplementary_alignment,
+      aligned_sequence=read.aligned_sequence, aligned_quality=read.aligned_quality,
+      alignment=T.LinearAlignment(position=T.Position(p.reference_name, position, p.reverse_strand),
+                                  mapping_quality=read.alignment.mapping_quality,
+                                  cigar=[T.CigarUnit(op, ln) for op, ln in cigar]),
+      info=dict(read.info), base_modifications=dict(read.base_modifications))
+
 
 def positions_map(cigar: str, haplotype_size: int) -> List[int]:
   out = (C.c_int32 * max(haplotype_size, 1))()
@@ -173,24 +206,4 @@ def realign_reads_to_haplotype(haplotype: str, reads: Sequence, contig: str, ref
                             ref_suffix_len=ext_end - ref_end, **cfg)
   aligner.set_reference(target, ext_start)
   aligner.set_haplotypes([target])
-  out = []
-  for read, (status, position, cigar) in zip(reads, aligner.align_reads([r.aligned_sequence for r in reads])):
-    if status == 2:
-      out.append(None)
-    elif status == 0:
-      out.append(read)
-    else:
-      p = read.alignment.position
-      out.append(T.Read(
-          fragment_name=read.fragment_name, read_number=read.read_number,
-          number_reads=read.number_reads, fragment_length=read.fragment_length,
-          proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
-          failed_vendor_quality_checks=read.failed_vendor_quality_checks,
-          secondary_alignment=read.secondary_alignment,
-          supplementary_alignment=read.supplementary_alignment,
-          aligned_sequence=read.aligned_sequence, aligned_quality=read.aligned_quality,
-          alignment=T.LinearAlignment(position=T.Position(p.reference_name, position, p.reverse_strand),
-                                      mapping_quality=read.alignment.mapping_quality,
-                                      cigar=[T.CigarUnit(op, ln) for op, ln in cigar]),
-          info=dict(read.info), base_modifications=dict(read.base_modifications)))
-  return out
+  return aligner.realign_reads(reads)

@@ -1,0 +1,358 @@
+"""The window realigner: select windows with read evidence of variation, assemble candidate
+haplotypes per window, re-align each read to its best haplotype and through it to the
+reference.  Same names and behaviour as deepvariant/realigner/realigner.py:
+
+  realigner_config / window_selector_config      :276-414   (flag defaults :60-274)
+  AssemblyRegion, assign_reads_to_assembled_regions, split_reads   :538-672
+  Realigner.call_debruijn_graph / call_fast_pass_aligner / realign_reads / align_to_haplotype
+                                                  :675-893
+  trim_cigar / trim_read                          :896-1010 (shared with alt_aligned_pileup_lib)
+
+The three compute stages are native: per-position allele counts on the device
+(allele_counter.hip, one launch per region), graphs in csrc/debruijn_graph.cpp, alignment in
+csrc/fast_pass_aligner.cpp + local_align.cpp.  A region's reads are packed ONCE
+(packing.ReadTable) and that table feeds the counter and every window's graph.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Optional, Sequence, Tuple
+
+from deepvariant_amd import alt_aligned_pileup_lib
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import fast_pass_aligner
+from deepvariant_amd import packing
+from deepvariant_amd.realigner import debruijn_graph
+from deepvariant_amd.realigner import utils
+from deepvariant_amd.realigner import window_selector
+from deepvariant_amd.realigner.debruijn_graph import DeBruijnGraphOptions
+from deepvariant_amd.realigner.window_selector import (
+    ALLELE_COUNT_LINEAR, VARIANT_READS, AlleleCountLinearModel, VariantReadsThresholdModel,
+    WindowSelectorModel, WindowSelectorOptions)
+
+_UNSET_WS_INT_FLAG = -1
+_REF_ALIGN_MARGIN = 20                  # realigner.py:263
+_DEFAULT_MIN_SUPPORTING_READS = 2
+_DEFAULT_MAX_SUPPORTING_READS = 300
+_MIN_SPLIT_LEN = 15
+_MIN_ALLELE_SUPPORT = 2
+
+_ALLELE_COUNT_LINEAR_MODEL_DEFAULT = WindowSelectorModel(     # realigner.py:266-278
+    model_type=ALLELE_COUNT_LINEAR,
+    allele_count_linear_model=AlleleCountLinearModel(
+        bias=-0.683379, coeff_soft_clip=2.997000, coeff_substitution=-0.086644, coeff_insertion=2.493585,
+        coeff_deletion=1.795914, coeff_reference=-0.059787, decision_boundary=3))
+
+
+@dataclasses.dataclass
+class AlignerOptions:
+  """deepvariant/protos/realigner.proto AlignerOptions (the fields FastPassAligner reads)."""
+  match: int = 4
+  mismatch: int = 6
+  gap_open: int = 8
+  gap_extend: int = 2
+  k: int = 23
+  error_rate: float = 0.01
+  max_num_of_mismatches: int = 2
+  realignment_similarity_threshold: float = 0.16934
+  kmer_size: int = 32
+  force_alignment: bool = False
+  realign_all: bool = False
+  read_size: int = 0
+
+
+@dataclasses.dataclass
+class RealignerOptions:
+  ws_config: WindowSelectorOptions
+  dbg_config: DeBruijnGraphOptions
+  aln_config: AlignerOptions
+  split_skip_reads: bool = False
+  normalize_reads: bool = False
+
+
+@dataclasses.dataclass
+class CandidateHaplotypes:
+  """realigner.proto CandidateHaplotypes: a window and the haplotypes assembled for it."""
+  span: T.Range
+  haplotypes: List[str]
+
+
+_FLAG_DEFAULTS = dict(                   # realigner.py:60-262
+    ws_use_window_selector_model=False, ws_window_selector_model=None,
+    ws_min_num_supporting_reads=_UNSET_WS_INT_FLAG, ws_max_num_supporting_reads=_UNSET_WS_INT_FLAG,
+    ws_min_mapq=20, ws_min_base_quality=20, ws_min_windows_distance=80, ws_max_window_size=1000,
+    realign_all=False, ws_region_expansion_in_bp=20,
+    dbg_min_k=10, dbg_max_k=101, dbg_step_k=1, dbg_min_mapq=14, dbg_min_base_quality=15,
+    dbg_min_edge_weight=2, dbg_max_num_paths=256, dbg_disable_graph_pruning=False,
+    aln_match=4, aln_mismatch=6, aln_gap_open=8, aln_gap_extend=2, aln_k=23, aln_error_rate=0.01,
+    max_num_mismatches=2, realignment_similarity_threshold=0.16934, split_skip_reads=False, kmer_size=32,
+    keep_legacy_allele_counter_behavior=False, enable_strict_insertion_filter=False, normalize_reads=False)
+
+
+def _flags(overrides: dict) -> dict:
+  unknown = set(overrides) - set(_FLAG_DEFAULTS)
+  if unknown:
+    raise ValueError('unknown realigner flag(s): %s' % ', '.join(sorted(unknown)))
+  flags = dict(_FLAG_DEFAULTS)
+  flags.update(overrides)
+  return flags
+
+
+def window_selector_config(**overrides) -> WindowSelectorOptions:
+  """window_selector_config(flags) (:276-366); flags by keyword, the reference's defaults.
+  `ws_window_selector_model` is a WindowSelectorModel (the reference reads a text proto)."""
+  f = _flags(overrides)
+  if not f['ws_use_window_selector_model']:
+    if f['ws_window_selector_model'] is not None:
+      raise ValueError('Cannot specify a ws_window_selector_model if ws_use_window_selector_model is False.')
+    lo, hi = f['ws_min_num_supporting_reads'], f['ws_max_num_supporting_reads']
+    model = WindowSelectorModel(
+        model_type=VARIANT_READS,
+        variant_reads_model=VariantReadsThresholdModel(
+            min_num_supporting_reads=_DEFAULT_MIN_SUPPORTING_READS if lo == _UNSET_WS_INT_FLAG else lo,
+            max_num_supporting_reads=_DEFAULT_MAX_SUPPORTING_READS if hi == _UNSET_WS_INT_FLAG else hi))
+  else:
+    if f['ws_min_num_supporting_reads'] != _UNSET_WS_INT_FLAG:
+      raise ValueError('Cannot use both ws_min_num_supporting_reads and ws_use_window_selector_model flags.')
+    if f['ws_max_num_supporting_reads'] != _UNSET_WS_INT_FLAG:
+      raise ValueError('Cannot use both ws_max_num_supporting_reads and ws_use_window_selector_model flags.')
+    model = f['ws_window_selector_model'] or _ALLELE_COUNT_LINEAR_MODEL_DEFAULT
+  if model.model_type == VARIANT_READS:
+    m = model.variant_reads_model
+    if m.max_num_supporting_reads < m.min_num_supporting_reads:
+      raise ValueError('ws_min_supporting_reads should be smaller than ws_max_supporting_reads.')
+  return WindowSelectorOptions(
+      min_mapq=f['ws_min_mapq'], min_base_quality=f['ws_min_base_quality'],
+      min_windows_distance=f['ws_min_windows_distance'], max_window_size=f['ws_max_window_size'],
+      region_expansion_in_bp=f['ws_region_expansion_in_bp'], window_selector_model=model,
+      keep_legacy_behavior=f['keep_legacy_allele_counter_behavior'], realign_all=f['realign_all'],
+      min_allele_support=_MIN_ALLELE_SUPPORT,
+      enable_strict_insertion_filter=f['enable_strict_insertion_filter'])
+
+
+def realigner_config(**overrides) -> RealignerOptions:
+  """realigner_config(flags) (:368-414)."""
+  f = _flags(overrides)
+  return RealignerOptions(
+      ws_config=window_selector_config(**overrides),
+      dbg_config=DeBruijnGraphOptions(
+          min_k=f['dbg_min_k'], max_k=f['dbg_max_k'], step_k=f['dbg_step_k'], min_mapq=f['dbg_min_mapq'],
+          min_base_quality=f['dbg_min_base_quality'], min_edge_weight=f['dbg_min_edge_weight'],
+          max_num_paths=f['dbg_max_num_paths'], disable_graph_pruning=f['dbg_disable_graph_pruning']),
+      aln_config=AlignerOptions(
+          match=f['aln_match'], mismatch=f['aln_mismatch'], gap_open=f['aln_gap_open'],
+          gap_extend=f['aln_gap_extend'], k=f['aln_k'], error_rate=f['aln_error_rate'],
+          max_num_of_mismatches=f['max_num_mismatches'],
+          realignment_similarity_threshold=f['realignment_similarity_threshold'], kmer_size=f['kmer_size'],
+          force_alignment=False, realign_all=f['realign_all']),
+      split_skip_reads=f['split_skip_reads'], normalize_reads=f['normalize_reads'])
+
+
+class AssemblyRegion:
+  """A window with its candidate haplotypes and the reads assigned to it (:538-593)."""
+
+  def __init__(self, candidate_haplotypes: CandidateHaplotypes):
+    self.candidate_haplotypes = candidate_haplotypes
+    self.reads: List = []
+    self._read_span: Optional[T.Range] = None
+
+  def __str__(self):
+    return 'AssemblyRegion(region={}, span={}) with {} haplotypes and {} reads'.format(
+        self.region, self.read_span, len(self.haplotypes), len(self.reads))
+
+  @property
+  def haplotypes(self) -> List[str]:
+    return self.candidate_haplotypes.haplotypes
+
+  @property
+  def region(self) -> T.Range:
+    return self.candidate_haplotypes.span
+
+  @property
+  def read_span(self) -> Optional[T.Range]:
+    if self._read_span is None and self.reads:
+      spans = [utils.read_range(r) for r in self.reads]
+      self._read_span = utils.make_range(spans[0].reference_name, min(s.start for s in spans),
+                                         max(s.end for s in spans))
+    return self._read_span
+
+  def add_read(self, read):
+    self.reads.append(read)
+    self._read_span = None
+
+
+def assign_reads_to_assembled_regions(assembled_regions: Sequence[AssemblyRegion], reads: Sequence) -> List:
+  """Every read goes to the region it overlaps most (ties: the first); returns the reads that
+  overlap none (:596-619)."""
+  regions = [ar.region for ar in assembled_regions]
+  unassigned = []
+  for read in reads:
+    i = utils.find_max_overlapping(utils.read_range(read), regions)
+    if i is not None:
+      assembled_regions[i].add_read(read)
+    else:
+      unassigned.append(read)
+  return unassigned
+
+
+def _new_part(read, part: int) -> T.Read:
+  """copy_read (:622-639): everything but the alignment payload, renamed `<name>_p<part>`."""
+  p = read.alignment.position
+  return T.Read(
+      fragment_name='%s_p%d' % (read.fragment_name, part), read_number=read.read_number,
+      number_reads=read.number_reads, fragment_length=read.fragment_length,
+      proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
+      failed_vendor_quality_checks=read.failed_vendor_quality_checks,
+      secondary_alignment=read.secondary_alignment, supplementary_alignment=read.supplementary_alignment,
+      aligned_sequence='', aligned_quality=[],
+      alignment=T.LinearAlignment(position=T.Position(p.reference_name, 0, p.reverse_strand),
+                                  mapping_quality=read.alignment.mapping_quality, cigar=[]),
+      info=dict(read.info), base_modifications=dict(read.base_modifications))
+
+
+def split_reads(reads: Sequence) -> List:
+  """Reads with SKIP (N) operations are cut there into parts; parts shorter than 15 bases are
+  dropped (:642-672)."""
+  out = []
+  for read in reads:
+    cigar = read.alignment.cigar
+    if not any(c.operation == utils.SKIP for c in cigar):
+      out.append(read)
+      continue
+    part = 0
+    new_read = _new_part(read, part)
+    read_start = read_offset = reference_offset = 0
+    for n, c in enumerate(cigar):
+      last = n + 1 == len(cigar)
+      if c.operation in utils.REF_ADVANCING_OPS:
+        if not new_read.alignment.position.position:
+          new_read.alignment.position.position = read.alignment.position.position + reference_offset
+        reference_offset += c.operation_length
+      if c.operation in utils.READ_ADVANCING_OPS:
+        read_offset += c.operation_length
+      if c.operation != utils.SKIP:
+        new_read.alignment.cigar.append(T.CigarUnit(c.operation, c.operation_length))
+      if c.operation == utils.SKIP or last:
+        new_read.aligned_sequence = read.aligned_sequence[read_start:read_offset]
+        new_read.aligned_quality = read.aligned_quality[read_start:read_offset]
+        if len(new_read.aligned_sequence) >= _MIN_SPLIT_LEN:
+          out.append(new_read)
+        if not last:
+          read_start = read_offset
+          part += 1
+          new_read = _new_part(read, part)
+  return out
+
+
+class Realigner:
+  """Realigner(config, ref_reader) (:675-893).  `ref_reader`: n_bases(contig) /
+  get_bases(contig, start, end), as everywhere in this package."""
+
+  def __init__(self, config: RealignerOptions, ref_reader, shared_header=None, allele_counter_cls=None):
+    # allele_counter_cls: see window_selector._candidates_from_reads (CPU tests of the host
+    # logic only; the product counts on the device)
+    self.config = config
+    self.ref_reader = ref_reader
+    self.shared_header = shared_header
+    self._allele_counter_cls = allele_counter_cls
+
+  # ---- reference access in the reference's terms
+  def _is_valid(self, r: T.Range) -> bool:          # GenomeReference::IsValidInterval, reference.cc:95-102
+    try:
+      n = self.ref_reader.n_bases(r.reference_name)
+    except KeyError:
+      return False
+    return 0 <= r.start <= r.end and r.start < n and r.end <= n
+
+  def _query(self, r: T.Range) -> str:
+    if not self._is_valid(r):
+      raise ValueError('Invalid interval: %s:%d-%d' % (r.reference_name, r.start, r.end))
+    return self.ref_reader.get_bases(r.reference_name, r.start, r.end)
+
+  def call_debruijn_graph(self, windows: Sequence[T.Range], reads: Sequence, table=None) -> List[CandidateHaplotypes]:
+    """One graph per window over the reads that overlap it (:703-738)."""
+    if table is None:
+      table = packing.ReadTable.from_reads(list(reads))
+    spans = [utils.read_range(r) for r in reads]
+    out = []
+    for window in windows:
+      if window.end - window.start > self.config.ws_config.max_window_size:
+        continue
+      if not self._is_valid(window):
+        continue
+      ref = self._query(window)
+      window_reads = [i for i, s in enumerate(spans) if utils.ranges_overlap(s, window)]
+      graph = debruijn_graph.build_from_table(ref, table, window_reads, self.config.dbg_config)
+      haplotypes = [ref] if graph is None else graph.candidate_haplotypes()
+      if haplotypes and haplotypes != [ref]:
+        out.append(CandidateHaplotypes(span=window, haplotypes=haplotypes))
+    return out
+
+  def _aligner(self, read_size: int, force_alignment: bool, prefix_len: int, suffix_len: int):
+    a = self.config.aln_config
+    return fast_pass_aligner.FastPassAligner(
+        match=a.match, mismatch=a.mismatch, gap_open=a.gap_open, gap_extend=a.gap_extend,
+        kmer_size=a.kmer_size, read_size=read_size, max_num_of_mismatches=a.max_num_of_mismatches,
+        realignment_similarity_threshold=a.realignment_similarity_threshold, force_alignment=force_alignment,
+        normalize_reads=self.config.normalize_reads, ref_prefix_len=prefix_len, ref_suffix_len=suffix_len)
+
+  def call_fast_pass_aligner(self, assembled_region: AssemblyRegion) -> List:
+    """Realign the region's reads against its haplotypes, each padded with the reference out
+    to the reads' span + 20 (:740-793)."""
+    if not assembled_region.reads:
+      return []
+    region = assembled_region.region
+    contig = region.reference_name
+    span = assembled_region.read_span
+    ref_start = max(0, min(span.start, region.start) - _REF_ALIGN_MARGIN)
+    ref_end = min(self.ref_reader.n_bases(contig), max(span.end, region.end) + _REF_ALIGN_MARGIN)
+    ref_prefix = self._query(utils.make_range(contig, ref_start, region.start))
+    ref = self._query(region)
+    if ref_end <= region.end:      # no room for a suffix: keep the original alignments
+      return assembled_region.reads
+    ref_suffix = self._query(utils.make_range(contig, region.end, ref_end))
+    aligner = self._aligner(len(assembled_region.reads[0].aligned_sequence), False, len(ref_prefix),
+                            len(ref_suffix))
+    aligner.set_reference(ref_prefix + ref + ref_suffix, ref_start)
+    aligner.set_haplotypes([ref_prefix + target + ref_suffix for target in assembled_region.haplotypes])
+    return aligner.realign_reads(assembled_region.reads)
+
+  def realign_reads(self, reads: Sequence, region: T.Range) -> Tuple[List[CandidateHaplotypes], List]:
+    """-> (candidate haplotypes per assembled window, all input reads: first the ones no window
+    claimed, then window by window; order differs from the input) (:795-855)."""
+    if not reads:
+      return [], []
+    if self.config.split_skip_reads:
+      reads = split_reads(reads)
+    reads = list(reads)
+    table = packing.ReadTable.from_reads(reads)
+    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, reads, region, table=table,
+                                             allele_counter_cls=self._allele_counter_cls)
+    candidate_haplotypes = self.call_debruijn_graph(windows, reads, table=table)
+    assembled_regions = [AssemblyRegion(ch) for ch in candidate_haplotypes]
+    realigned = assign_reads_to_assembled_regions(assembled_regions, reads)
+    for assembled_region in assembled_regions:
+      realigned.extend(self.call_fast_pass_aligner(assembled_region))
+    return candidate_haplotypes, realigned
+
+  def align_to_haplotype(self, this_haplotype: str, haplotypes: Sequence[str], prefix: str, suffix: str,
+                         reads: Sequence, contig: str, ref_start: int) -> List:
+    """Reads aligned to a graph of haplotypes, reported in `this_haplotype`'s coordinates
+    (:857-893); an entry is None where the reference returns an empty Read."""
+    if not reads:
+      return []
+    margin = min(len(prefix), len(suffix), 100)
+    aligner = self._aligner(len(reads[0].aligned_sequence), True, len(prefix) - margin, len(suffix) - margin)
+    aligner.set_reference(prefix + this_haplotype + suffix, ref_start)
+    aligner.set_haplotypes([prefix + target + suffix for target in haplotypes])
+    return aligner.realign_reads(reads)
+
+
+def trim_cigar(cigar, ref_trim: int, ref_length: int):
+  """realigner.trim_cigar (:896-968); the same routine as TrimCigar in alt_aligned_pileup_lib."""
+  return alt_aligned_pileup_lib.trim_cigar(cigar, ref_trim, ref_length)
+
+
+def trim_read(read, region: T.Range):
+  """realigner.trim_read (:971-1010)."""
+  return alt_aligned_pileup_lib.trim_read(read, region.start, region.end)

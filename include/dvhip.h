@@ -430,6 +430,32 @@ int dv_merge_cigar_op(char* cigar, int32_t cap, char op, int32_t length, int32_t
 int dv_local_align(const char* reference, const char* query, int32_t match, int32_t mismatch,
                    int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
 
+/* ---- local assembly for the window realigner (host only) -----------------------
+ * Replaces deepvariant/realigner/debruijn_graph.{h,cc} (DeBruijnGraph::Build,
+ * CandidateHaplotypes, GraphViz; python binding deepvariant/realigner/python/
+ * debruijn_graph_pybind.cc).  Options are DeBruijnGraphOptions (deepvariant/protos/
+ * realigner.proto).  Reads come as the region's packed read table (dv_batch's bases / quals /
+ * read_seq_off / read_mapq arrays) plus the indices of the reads that overlap the window, in
+ * the order the reference would add them. */
+typedef struct dv_debruijn_graph dv_debruijn_graph;
+
+typedef struct dv_debruijn_options {
+  int32_t min_k, max_k, step_k;
+  int32_t min_mapq, min_base_quality, min_edge_weight, max_num_paths;
+  int32_t disable_graph_pruning;
+} dv_debruijn_options;
+
+/* *out = NULL (and DV_OK) when no k gives an acyclic graph: debruijn_graph.build() -> None. */
+int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals,
+                      const uint32_t* read_seq_off, const uint8_t* read_mapq, int32_t n_table_reads,
+                      const int32_t* reads, int32_t n_reads, const dv_debruijn_options* options,
+                      dv_debruijn_graph** out);
+void dv_debruijn_destroy(dv_debruijn_graph* g);
+int dv_debruijn_kmer_size(const dv_debruijn_graph* g);                                 /* kmer_size */
+/* candidate_haplotypes(): sorted; strings owned by the graph until its next call. */
+int dv_debruijn_haplotypes(dv_debruijn_graph* g, int32_t* n, const char* const** haplotypes);
+int dv_debruijn_graphviz(dv_debruijn_graph* g, const char** text);                     /* graphviz */
+
 /* ---- alt-aligned channel merge (device) --------------------------------------
  * FillPileupArray's diff_channels / base_channels modes (deepvariant/pileup_image_native.h:
  * 246-271) on images that stay in HBM: `images` holds the examples followed, from

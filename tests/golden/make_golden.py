@@ -14,9 +14,10 @@ Illumina WGS golden (BASELINE.json configs[0]):
   min_base_quality 10).
 
 The golden images were produced AFTER the reference's realigner rewrote some
-reads, which this repo does not (yet) restate, so the fixture records, next to
-each golden image, the reads of the *raw* BAM that overlap the candidate.  The
-acceptance checks (tests/test_oracle_golden.py) are:
+reads; this fixture records, next to each golden image, the reads of the *raw*
+BAM that overlap the candidate (the realigner's own input is the `realigner`
+fixture further down, with which tests/test_oracle_golden.py reproduces all 84
+images and 78 candidates exactly).  The raw-read acceptance checks are:
   * reference-band rows bit-exact in 84/84 images,
   * every golden read row that equals the raw-BAM encoding of some read
     (>= 80 % of all rows; the rest are realigner-rewritten reads),
@@ -128,7 +129,7 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__' and not any(a.startswith('pacbio') for a in sys.argv[1:]):
+if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner')) for a in sys.argv[1:]):
   main()
 
 
@@ -364,3 +365,49 @@ def main_pacbio_alt(keep_every=2):
 
 if __name__ == '__main__' and 'pacbio_alt' in sys.argv[1:]:
   main_pacbio_alt()
+
+
+# ---------------------------------------------------------------------------
+# Window realigner fixture
+#   realigner_chr20.npz:
+#     ref_bases / ref_start    chr20:9,995,000-10,100,600 of ucsc.hg19.chr20.unittest.fasta.gz
+#     n_contig_bases           63,025,520
+#     reads (golden_io)        every read of NA12878_S1.chr20.10_10p1mb.bam that the tests below use
+#     sets_*                   named read subsets (indices into `reads`):
+#       wgs     reads make_examples sees for --regions chr20:10,000,000-10,010,000 (reader filter as
+#               in main()), i.e. the input of the realigner for golden.calling_examples
+#       ex1/ex2 reads overlapping the two regions of realigner_test.py:296-360
+#               (test_realigner_example_region; SamReader without read requirements)
+#       dbg0    reads overlapping chr20:10,000,000-10,000,100 (debruijn_graph_wrap_test.py
+#               test_straightforward_region); test_complex_region uses ex1's region
+# ---------------------------------------------------------------------------
+def main_realigner():
+  fasta = genomics_io.FastaReader(os.path.join(REF, 'input/ucsc.hg19.chr20.unittest.fasta.gz'))
+  bam = os.path.join(REF, 'input/NA12878_S1.chr20.10_10p1mb.bam')
+  ref_start, ref_end = 9_995_000, 10_100_600
+  wanted = dict(wgs=(10_000_000, 10_010_000, True), ex1=(10_095_378, 10_095_500, False),
+                ex2=(10_046_079, 10_046_307, False), dbg0=(9_999_999, 10_000_100, False))
+  reads, index_of, sets = [], {}, {}
+  for name, (lo, hi, filtered) in wanted.items():
+    _, rs = genomics_io.read_bam(bam, 'chr20', lo, hi)
+    if filtered:
+      rs = reader_filter(rs)
+    ids = []
+    for r in rs:
+      key = (r.fragment_name, r.read_number, r.alignment.position.position)
+      if key not in index_of:
+        index_of[key] = len(reads)
+        reads.append(r)
+      ids.append(index_of[key])
+    sets['sets_' + name] = np.array(ids, np.int32)
+    print(name, len(ids), 'reads')
+  d = golden_io.pack_reads(reads)
+  d.update(sets)
+  d['ref_bases'] = np.frombuffer(fasta.get_bases('chr20', ref_start, ref_end).encode(), np.uint8)
+  d['ref_start'] = np.array([ref_start], np.int64)
+  d['n_contig_bases'] = np.array([fasta.n_bases('chr20')], np.int64)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/realigner_chr20.npz'), **d)
+
+
+if __name__ == '__main__' and 'realigner' in sys.argv[1:]:
+  main_realigner()

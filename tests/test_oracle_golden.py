@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+from deepvariant_amd import dv_types as T
 from oracle import oracle as O
 from tests import golden_io
 from tests.golden.make_golden import wgs_options
@@ -177,11 +178,12 @@ def test_golden_pacbio_alt_aligned_channels():
 # counting + the candidate caller run on the fixture's RAW BAM reads with make_examples'
 # defaults (min_mapping_quality 5, min_base_quality 10, vsc_min_count 2 / 2,
 # vsc_min_fraction 0.12 / 0.06).  The reference realigns reads before it counts alleles
-# (realigner ON for this golden), which is not restated, so -- as for the image rows --
-# the pinned numbers are what the raw reads determine: measured over the whole region with
-# all 6,014 reads: 72 of 78 calls identical in (position, reference bases, alternate bases),
-# 47 of them with identical allele_support read-name lists.  The fixture holds every read
-# that overlaps a golden candidate, so the counts AT the golden positions are complete.
+# (realigner ON for this golden); THIS test skips the realigner on purpose and pins what the
+# raw reads alone determine: 72 of 78 calls identical in (position, reference bases,
+# alternate bases), 47 of them with identical allele_support read-name lists.  The fixture
+# holds every read that overlaps a golden candidate, so the counts AT the golden positions
+# are complete.  With the realigner in front (test_golden_illumina_chain_with_realigner at
+# the end of this file) all 78 calls and their supporting reads are reproduced.
 # ---------------------------------------------------------------------------
 def golden_candidate_agreement(examples, counts_at):
   """-> (identical calls, identical calls with identical support) over the golden candidates."""
@@ -241,3 +243,88 @@ def test_golden_candidates_from_raw_reads():
 
   n, same, same_support = golden_candidate_agreement(examples, counts_at)
   assert (n, same, same_support) == (78, 72, 47)
+
+
+# ---------------------------------------------------------------------------
+# The whole make_examples chain behind golden.calling_examples / golden.calling_candidates
+# (BASELINE.json configs[0]; make_examples_test.py:363-395: realigner ON, partition 1000):
+#   reads of the region -> window realigner -> AlleleCounter -> candidate caller -> pileup images.
+# Product code: the realigner (window selection logic, de Bruijn assembly, FastPassAligner) and
+# the candidate caller.  Oracle code on this GPU-less leg: the per-position allele counts and
+# the encoder.  tests/test_hip_realigner.py runs the chain with the device counter and encoder.
+# Result: all 78 golden candidates (same alleles, same supporting reads) and all 84 golden
+# images bit-exact.
+# ---------------------------------------------------------------------------
+def run_golden_chain(make_counter, realigner_counter_cls, build_image):
+  """-> (found calls by (start, ref, alts), images by example index)."""
+  from deepvariant_amd import variant_calling as vc
+  from deepvariant_amd.realigner import realigner as R
+  from deepvariant_amd.realigner import utils as U
+  from tests import realigner_fixture as RF
+  from tests.golden import make_golden as MG
+  ref, sets = RF.load()
+  _, examples, _ = golden_io.load(FIXTURE)
+  opts = MG.wgs_options()
+  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=realigner_counter_cls)
+  caller = vc.VariantCaller(vc.VariantCallerOptions(
+      min_count_snps=2, min_count_indels=2, min_fraction_snps=0.12, min_fraction_indels=0.06))
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  found, region_reads = {}, []
+  for start in range(9_999_999, 10_010_000, 1000):            # --regions chr20:10,000,000-10,010,000
+    region = T.Range('chr20', start, min(start + 1000, 10_010_000))
+    in_reads = [r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]
+    _, realigned = rl.realign_reads(in_reads, region)
+    in_region = [r for r in realigned if U.ranges_overlap(U.read_range(r), region)]
+    for call in caller.calls_from_allele_counts(make_counter(ref, region, in_region)):
+      v = call.variant
+      found[(v.start, v.reference_bases, tuple(v.alternate_bases))] = call
+    region_reads.append((region, realigned))
+  hw = (opts.width - 1) // 2
+  images = []
+  for ex in examples:
+    v = ex['call'].variant
+    pool = next(rs for region, rs in region_reads if region.start <= v.start < region.end)
+    q0, q1 = v.start - opts.read_overlap_buffer_bp, v.end + opts.read_overlap_buffer_bp
+    overlapping = [r for r in pool if O.read_overlaps(r, q0, q1)]
+    images.append(build_image(opts, ex, overlapping, v.start - hw))
+  return found, examples, images
+
+
+def check_golden_chain(found, examples, images):
+  gold = {}
+  for ex in examples:
+    v = ex['call'].variant
+    gold[(v.start, v.reference_bases, tuple(v.alternate_bases))] = ex['call']
+  assert set(found) == set(gold) and len(gold) == 78
+  for k, g in gold.items():
+    a = {x: sorted(s.read_names) for x, s in found[k].allele_support.items()}
+    b = {x: sorted(s.read_names) for x, s in g.allele_support.items()}
+    assert a == b, k
+  assert len(images) == 84
+  for ex, image in zip(examples, images):
+    assert np.array_equal(image, ex['image']), ex['call'].variant.start
+
+
+def test_golden_illumina_chain_with_realigner():
+  from deepvariant_amd import allelecounter as ac
+  from oracle import allelecounter_ref as AR
+  from tests import realigner_fixture as RF
+
+  def make_counter(ref, region, reads):
+    counter = AR.AlleleCounter(ref, region.reference_name, region.start, region.end, min_mapping_quality=5,
+                               min_base_quality=10)
+    for r in reads:
+      counter.add(r)
+    out = []
+    for c in counter.counts:
+      a = ac.AlleleCount(region.reference_name, c.position, c.ref_base)
+      a.ref_supporting_read_count = c.ref_supporting_read_count
+      a.read_alleles = {k: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for k, v in c.read_alleles.items()}
+      out.append(a)
+    return out
+
+  def build_image(opts, ex, reads, image_start):
+    return O.build_pileup(opts, ex['call'], ex['ref_window'], reads, image_start, ex['alt_alleles'])
+
+  check_golden_chain(*run_golden_chain(make_counter, RF.OracleAlleleCounter, build_image))
