@@ -1,0 +1,119 @@
+"""One region of make_examples, single sample: reads -> window realigner -> allele counts ->
+candidate calls -> pileup examples (or, fused, genotype probabilities).  The part of
+deepvariant/make_examples_core.py's RegionProcessor that joins the hot path's stages:
+
+  RegionProcessor.realign_reads          make_examples_core.py:2479-2518
+  RegionProcessor.candidates_in_region   make_examples_core.py:2840-3010 (one sample, no gVCF,
+                                         no phasing, no normalize_reads)
+  RegionProcessor.process                make_examples_core.py:2215-2380
+  partition                              ranges.RangeSet.partition (1000-base calling regions)
+
+Every stage below is this package's own: realigner/ (device allele counts for window
+selection, native assembly and alignment), allelecounter.AlleleCounter (device),
+variant_calling.VariantCaller (host), make_examples_native.ExamplesGenerator (device encoder,
+optionally fused with the CNN).  File handling, sharding, labelling, gVCF and multi-sample
+plumbing of the reference's make_examples are outside SURVEY.md section 8.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+from deepvariant_amd import allelecounter
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import make_examples_native
+from deepvariant_amd import variant_calling
+from deepvariant_amd.realigner import realigner as realigner_module
+from deepvariant_amd.realigner import utils
+
+
+@dataclasses.dataclass
+class RegionProcessorOptions:
+  """The MakeExamplesOptions fields this slice reads (flag defaults of make_examples_options.py)."""
+  realigner_enabled: bool = True
+  realigner_options: Optional[realigner_module.RealignerOptions] = None    # None = realigner_config()
+  max_read_length_to_realign: int = 500
+  vsc_min_count_snps: int = 2
+  vsc_min_count_indels: int = 2
+  vsc_min_fraction_snps: float = 0.12
+  vsc_min_fraction_indels: float = 0.06
+  keep_legacy_allele_counter_behavior: bool = False
+  partition_size: int = 1000
+
+
+def partition(region: T.Range, size: int) -> Iterator[T.Range]:
+  """Calling regions of at most `size` bases, in order."""
+  if size <= 0:
+    raise ValueError('partition size must be positive')
+  for start in range(region.start, region.end, size):
+    yield T.Range(region.reference_name, start, min(start + size, region.end))
+
+
+class RegionProcessor:
+  def __init__(self, options: T.MakeExamplesOptions, ref_reader, processor_options: Optional[RegionProcessorOptions] = None,
+               example_filenames: Optional[Dict[str, str]] = None, device: int = 0):
+    if len(options.sample_options) != 1:
+      raise NotImplementedError('RegionProcessor handles one sample; multi-sample regions go through '
+                                'ExamplesGenerator directly')
+    self.options = options
+    self.ref_reader = ref_reader
+    self.processor_options = processor_options or RegionProcessorOptions()
+    po = self.processor_options
+    self.realigner = None
+    if po.realigner_enabled:
+      self.realigner = realigner_module.Realigner(po.realigner_options or realigner_module.realigner_config(),
+                                                  ref_reader)
+    sample = options.sample_options[0]
+    self.variant_caller = variant_calling.VariantCaller(variant_calling.VariantCallerOptions(
+        po.vsc_min_count_snps, po.vsc_min_count_indels, po.vsc_min_fraction_snps, po.vsc_min_fraction_indels,
+        sample_name=sample.name))
+    self.generator = make_examples_native.ExamplesGenerator(
+        options, example_filenames or {}, test_mode=not example_filenames, device=device, ref_reader=ref_reader)
+
+  def realign_reads(self, reads: Sequence, region: T.Range) -> List:
+    """Reads longer than max_read_length_to_realign bypass the realigner and come first."""
+    if self.realigner is None:
+      return list(reads)
+    limit = self.processor_options.max_read_length_to_realign
+    if limit == 0:
+      return self.realigner.realign_reads(reads, region)[1]
+    long_reads = [r for r in reads if len(r.aligned_sequence) > limit]
+    short_reads = [r for r in reads if len(r.aligned_sequence) <= limit]
+    return long_reads + self.realigner.realign_reads(short_reads, region)[1]
+
+  def candidates_in_region(self, region: T.Range, reads: Sequence) -> List[T.DeepVariantCall]:
+    """Allele counts over `region` from the reads that overlap it (one kernel launch), then the
+    candidate caller."""
+    rr = self.options.pic_options.read_requirements
+    in_region = [r for r in reads if utils.ranges_overlap(utils.read_range(r), region)]
+    if not in_region:
+      return []
+    counter = allelecounter.AlleleCounter(
+        self.ref_reader, region.reference_name, region.start, region.end,
+        min_mapping_quality=rr.min_mapping_quality, min_base_quality=rr.min_base_quality,
+        keep_legacy_behavior=self.processor_options.keep_legacy_allele_counter_behavior)
+    for read in in_region:
+      counter.add(read, self.options.sample_options[0].name)
+    return self.variant_caller.calls_from_allele_counter(counter)
+
+  def process(self, region: T.Range, reads: Sequence) -> Tuple[List[T.DeepVariantCall], List]:
+    """-> (candidates, the region's reads as the pileup images must see them)."""
+    realigned = self.realign_reads(reads, region)
+    return self.candidates_in_region(region, realigned), realigned
+
+  def examples_in_region(self, region: T.Range, reads: Sequence, stats: Optional[dict] = None
+                         ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
+    """-> (candidates, serialised tf.Examples in candidate / alt-combination order)."""
+    candidates, realigned = self.process(region, reads)
+    if not candidates:
+      return candidates, []
+    examples, _ = self.generator.encode_region(candidates, [realigned], [0], [0.0], stats if stats is not None else {})
+    return candidates, examples
+
+  def call_variants_in_region(self, region: T.Range, reads: Sequence, model) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
+    """Fused: -> (candidates, serialised CallVariantsOutput per example); the images never
+    leave the device."""
+    candidates, realigned = self.process(region, reads)
+    if not candidates:
+      return candidates, []
+    return candidates, self.generator.call_variants_in_region(candidates, [realigned], [0], [0.0], model)

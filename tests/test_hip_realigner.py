@@ -1,0 +1,90 @@
+"""The window realigner and the region chain on the GPU: everything that the CPU tests run
+with the oracle's allele counts (tests/test_window_selector_cpu.py, test_realigner_cpu.py,
+test_oracle_golden.py::test_golden_illumina_chain_with_realigner) runs here with the product's
+device AlleleCounter and device encoder, no oracle in the loop:
+
+  * the reference's window-selector vectors (window_selector_test.py),
+  * the two known-answer regions of realigner_test.py (windows, haplotypes) and identical
+    realigned reads as the oracle-counted run,
+  * BASELINE.json configs[0] end to end through make_examples_core.RegionProcessor:
+    raw reads of chr20:10,000,000-10,010,000 -> realigner -> dv_count_alleles -> candidate
+    caller -> dv_encode_batch: all 78 golden candidates with their supporting reads and all
+    84 golden images, bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from deepvariant_amd import dv_types as T
+from tests import golden_io
+from tests import realigner_fixture as RF
+from tests import window_selector_vectors as V
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'illumina_wgs_chr20.npz')
+
+
+def test_window_selector_vectors_device_counts():
+  for case in V.CASES:
+    V.run_case(case)                                   # counter_cls None = the device AlleleCounter
+  for read_mapq in range(10, 15):
+    for min_mapq in range(8, 17):
+      V.run_case(('threshold', [('AGA', 10, '3M', None, read_mapq)], [11] if read_mapq >= min_mapq else [], {}),
+                 min_mapq=min_mapq)
+
+
+@pytest.mark.parametrize('name,lo,hi,window', [('ex1', 10_095_378, 10_095_500, (10_095_351, 10_095_553)),
+                                               ('ex2', 10_046_079, 10_046_307, (10_046_095, 10_046_267))])
+@pytest.mark.parametrize('use_model', [True, False])
+def test_example_regions_device_counts(name, lo, hi, window, use_model):
+  from deepvariant_amd.realigner import realigner as R
+  ref, sets = RF.load()
+  config = R.realigner_config(ws_use_window_selector_model=use_model)
+  region = T.Range('chr20', lo, hi)
+  got_w, got_r = R.Realigner(config, ref).realign_reads(sets[name], region)
+  want_w, want_r = R.Realigner(config, ref, allele_counter_cls=RF.OracleAlleleCounter).realign_reads(sets[name], region)
+  assert got_w == want_w and got_r == want_r
+  assert len(got_r) == len(sets[name])
+  if use_model:
+    assert (got_w[0].span.start, got_w[0].span.end) == window and len(got_w[0].haplotypes) == 2
+
+
+def test_golden_illumina_chain_on_device():
+  from deepvariant_amd import make_examples_core as mec
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd.realigner import utils as U
+  from tests.golden.make_golden import wgs_options
+  ref, sets = RF.load()
+  _, examples, _ = golden_io.load(GOLDEN)
+  pic = wgs_options()
+  options = T.MakeExamplesOptions(pic_options=pic,
+                                  sample_options=[T.SampleOptions(role='main', name='NA12878', pileup_height=100)])
+  proc = mec.RegionProcessor(options, ref)
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  found, images = {}, {}
+  for region in mec.partition(T.Range('chr20', 9_999_999, 10_010_000), 1000):
+    in_reads = [r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]
+    candidates, encoded = proc.examples_in_region(region, in_reads)
+    for c in candidates:
+      v = c.variant
+      found[(v.start, v.reference_bases, tuple(v.alternate_bases))] = c
+    for blob in encoded:
+      ex = pw.decode_example(blob)
+      v = pw.decode_variant(ex['variant/encoded'][0])
+      alts = tuple(v.alternate_bases[i] for i in pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+      images[(v.start, alts)] = np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(ex['image/shape'])
+  gold = {}
+  for ex in examples:
+    v = ex['call'].variant
+    gold[(v.start, v.reference_bases, tuple(v.alternate_bases))] = ex['call']
+  assert set(found) == set(gold) and len(gold) == 78
+  for k, g in gold.items():
+    a = {x: sorted(s.read_names) for x, s in found[k].allele_support.items()}
+    b = {x: sorted(s.read_names) for x, s in g.allele_support.items()}
+    assert a == b, k
+  assert len(images) == len(examples) == 84
+  for ex in examples:
+    key = (ex['call'].variant.start, tuple(ex['alt_alleles']))
+    assert np.array_equal(images[key], ex['image']), key
