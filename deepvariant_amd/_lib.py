@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     'dv_aligner_stage', 'dv_aligner_fast_align', 'dv_aligner_haplotype_info',
     'dv_aligner_read_alignment', 'dv_aligner_merge_alignment', 'dv_aligner_is_normalized',
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
-    'dv_merge_cigar_op', 'dv_local_align',
+    'dv_merge_cigar_op', 'dv_local_align', 'dv_local_align_many',
     'dv_debruijn_build', 'dv_debruijn_destroy', 'dv_debruijn_kmer_size', 'dv_debruijn_haplotypes',
     'dv_debruijn_graphviz',
     'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
@@ -275,6 +275,7 @@ def lib():
     l.dv_positions_map.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
     l.dv_merge_cigar_op.argtypes = [C.c_void_p, C.c_int32, C.c_char, C.c_int32, C.c_int32]
     l.dv_local_align.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int32] * 4 + [C.c_void_p]
+    l.dv_local_align_many.argtypes = [C.c_char_p, C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
     l.dv_debruijn_build.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p,
                                                                                   C.c_int32, C.c_void_p, C.c_void_p]
     l.dv_debruijn_destroy.argtypes = [C.c_void_p]

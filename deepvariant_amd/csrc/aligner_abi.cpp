@@ -236,6 +236,33 @@ int dv_local_align(const char* reference, const char* query, int32_t match, int3
   return copy_text(r.cigar, out->cigar, sizeof(out->cigar));
 }
 
+// n queries against one reference through the 16-lane batch path; out[k].score < 0 marks a
+// query the aligner refuses (empty, or an oversized sub-problem)
+int dv_local_align_many(const char* reference, int32_t n, const char* const* queries, int32_t match,
+                        int32_t mismatch, int32_t gap_open, int32_t gap_extend, dv_local_alignment* out) {
+  if (!reference || n < 0 || (n > 0 && (!queries || !out))) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_local_align_many");
+  dv::LocalAligner a(match, mismatch, gap_open, gap_extend);
+  a.set_reference(reference);
+  std::vector<dv::LocalAlignment> results;
+  std::vector<char> ok;
+  a.align_many_to_reference(strings(n, queries), &results, &ok);
+  for (int32_t k = 0; k < n; ++k) {
+    const dv::LocalAlignment& r = results[k];
+    out[k].score = ok[k] ? r.score : -1;
+    out[k].ref_begin = r.ref_begin;
+    out[k].ref_end = r.ref_end;
+    out[k].query_begin = r.query_begin;
+    out[k].query_end = r.query_end;
+    out[k].mismatches = r.mismatches;
+    out[k].cigar[0] = '\0';
+    if (ok[k]) {
+      const int rc = copy_text(r.cigar, out[k].cigar, sizeof(out[k].cigar));
+      if (rc != DV_OK) return rc;
+    }
+  }
+  return DV_OK;
+}
+
 // ---- local assembly (debruijn_graph.cpp)
 
 int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals,

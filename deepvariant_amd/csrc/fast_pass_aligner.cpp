@@ -251,6 +251,9 @@ void FastPassAligner::align_haplotypes_to_reference() {   // :336-375
       alignments_.push_back(std::move(ha));
     }
   }
+  // the haplotypes that differ from the reference are aligned to it together (16 per SIMD batch)
+  std::vector<HaplotypeAlignment*> todo;
+  std::vector<std::string> queries;
   for (HaplotypeAlignment& ha : alignments_) {
     const std::string& hap = haplotypes_[ha.haplotype_index];
     if (hap == reference_) {
@@ -259,14 +262,21 @@ void FastPassAligner::align_haplotypes_to_reference() {   // :336-375
       ha.cigar_ops = parse_cigar(ha.cigar);
       ha.ref_pos = 0;
     } else {
-      LocalAlignment al;
-      if (aligner_->align(hap, &al) && al.score > 0) {
-        ha.is_reference = al.cigar == std::to_string(hap.size()) + "=";
-        ha.cigar = al.cigar;
-        ha.cigar_ops = parse_cigar(al.cigar);
-        ha.ref_pos = static_cast<uint64_t>(al.ref_begin);
-      }
+      todo.push_back(&ha);
+      queries.push_back(hap);
     }
+  }
+  std::vector<LocalAlignment> results;
+  std::vector<char> ok;
+  aligner_->align_many_to_reference(queries, &results, &ok);
+  for (size_t k = 0; k < todo.size(); ++k) {
+    const LocalAlignment& al = results[k];
+    if (!ok[k] || al.score <= 0) continue;
+    HaplotypeAlignment& ha = *todo[k];
+    ha.is_reference = al.cigar == std::to_string(queries[k].size()) + "=";
+    ha.cigar = al.cigar;
+    ha.cigar_ops = parse_cigar(al.cigar);
+    ha.ref_pos = static_cast<uint64_t>(al.ref_begin);
   }
 }
 
@@ -278,17 +288,29 @@ void FastPassAligner::calculate_position_maps() {   // :652-657
 
 void FastPassAligner::local_align_reads_to_haplotypes(int score_threshold) {   // :377-418
   const int threshold = static_cast<uint16_t>(score_threshold);
+  // the haplotypes a read is aligned to do not depend on the read: encode them once
+  std::vector<HaplotypeAlignment*> targets;
+  std::vector<CodedSequence> coded;
+  for (HaplotypeAlignment& ha : alignments_) {
+    const bool forced = force_alignment_ && ha.is_reference;
+    if (ha.haplotype_score == 0 && !forced) continue;
+    targets.push_back(&ha);
+    coded.push_back(encode_sequence(haplotypes_[ha.haplotype_index]));
+  }
+  std::vector<const CodedSequence*> refs;
+  for (const CodedSequence& c : coded) refs.push_back(&c);
+  std::vector<LocalAlignment> results;
+  std::vector<char> ok;
   for (size_t r = 0; r < reads_.size(); ++r) {
     bool aligned = false;
     for (const HaplotypeAlignment& ha : alignments_) aligned = aligned || ha.reads[r].score > 0;
-    if (aligned) continue;
-    for (HaplotypeAlignment& ha : alignments_) {
-      const bool forced = force_alignment_ && ha.is_reference;
-      if (ha.haplotype_score == 0 && !forced) continue;
-      aligner_->set_reference(haplotypes_[ha.haplotype_index]);
-      LocalAlignment al;
-      if (!aligner_->align(reads_[r], &al) || al.score <= 0) continue;
-      if (al.score >= threshold || forced) {
+    if (aligned || targets.empty()) continue;
+    aligner_->align_to_many(refs, reads_[r], &results, &ok);
+    for (size_t t = 0; t < targets.size(); ++t) {
+      HaplotypeAlignment& ha = *targets[t];
+      const LocalAlignment& al = results[t];
+      if (!ok[t] || al.score <= 0) continue;
+      if (al.score >= threshold || (force_alignment_ && ha.is_reference)) {
         ha.reads[r].score = al.score;
         ha.reads[r].cigar = al.cigar;
         ha.reads[r].position = static_cast<uint16_t>(al.ref_begin);

@@ -23,7 +23,115 @@ std::vector<int8_t> translate(const std::string& s) {
   return out;
 }
 
+// ---- the sweep for 16 (reference, query) pairs at once --------------------------------------
+// Lane l runs sweep()'s recurrence for pair l: same H, E, F, the same "first column whose
+// maximum exceeds every earlier one" and the same saved column.  Values fit int16: H <= match *
+// |query| (checked by the caller), E and F never drop below -gap_open because H >= 0.  Lanes
+// walk their sequences with a step of +1 or -1 (the reverse pass), shorter ones are padded with
+// symbols that match nothing: a padded cell is always strictly below a real cell that was seen
+// earlier, so it can neither start a new maximum nor be picked as its row.
+constexpr int kLanes = 16;
+typedef int16_t Lanes __attribute__((vector_size(2 * kLanes)));
+
+struct SweepLane {
+  const int8_t* ref = nullptr;
+  int ref_step = 1, ref_len = 0;
+  const int8_t* q = nullptr;
+  int q_step = 1, q_len = 0;
+  int stop_at = -1;                     // the reverse pass stops once this score is reached
+  int best = 0, best_ref = -1, best_q = -1;   // indices in walking order
+};
+
+struct SweepParams {
+  int match, mismatch, gap_open, gap_extend;
+};
+
+static inline __attribute__((always_inline)) void sweep_lanes_body(SweepLane* lanes, const SweepParams& p) {
+  int n = 0, columns = 0;
+  for (int l = 0; l < kLanes; ++l) {
+    n = std::max(n, lanes[l].q_len);
+    columns = std::max(columns, lanes[l].ref_len);
+  }
+  const Lanes zero = {};
+  const Lanes match = zero + static_cast<int16_t>(p.match), miss = zero - static_cast<int16_t>(p.mismatch);
+  const Lanes go = zero + static_cast<int16_t>(p.gap_open), ge = zero + static_cast<int16_t>(p.gap_extend);
+  static thread_local std::vector<Lanes> qv, prev, cur, e_col, best_col;
+  qv.resize(n);
+  prev.assign(n, zero);
+  cur.assign(n, zero);
+  e_col.assign(n, zero);
+  best_col.assign(n, zero);
+  Lanes stop = zero - static_cast<int16_t>(1);
+  for (int l = 0; l < kLanes; ++l) {
+    const SweepLane& a = lanes[l];
+    stop[l] = static_cast<int16_t>(a.ref_len > 0 ? a.stop_at : 0);    // an empty lane is "done" at score 0
+    for (int j = 0; j < n; ++j) {
+      const int8_t c = j < a.q_len ? a.q[j * a.q_step] : 4;
+      qv[j][l] = c < 4 ? c : 5;                                          // 'N' and padding match nothing
+    }
+  }
+  Lanes best = zero, best_ref = zero - static_cast<int16_t>(1);
+  for (int i = 0; i < columns; ++i) {
+    Lanes r;
+    for (int l = 0; l < kLanes; ++l) r[l] = i < lanes[l].ref_len ? lanes[l].ref[i * lanes[l].ref_step] : 4;
+    Lanes f = zero, diag = zero, col_max = zero;
+    for (int j = 0; j < n; ++j) {
+      const Lanes eq = r == qv[j];
+      Lanes h = diag + ((eq & match) | (~eq & miss));
+      const Lanes e = e_col[j];
+      h = __builtin_elementwise_max(__builtin_elementwise_max(h, e), __builtin_elementwise_max(f, zero));
+      diag = prev[j];
+      cur[j] = h;
+      col_max = __builtin_elementwise_max(col_max, h);
+      const Lanes open = h - go;
+      e_col[j] = __builtin_elementwise_max(e - ge, open);
+      f = __builtin_elementwise_max(f - ge, open);
+    }
+    prev.swap(cur);
+    const Lanes improved = col_max > best;
+    bool any = false;
+    for (int l = 0; l < kLanes; ++l) any = any || improved[l];
+    if (any) {
+      best = __builtin_elementwise_max(best, col_max);
+      best_ref = (improved & (zero + static_cast<int16_t>(i))) | (~improved & best_ref);
+      for (int j = 0; j < n; ++j) best_col[j] = (improved & prev[j]) | (~improved & best_col[j]);
+      const Lanes done = best == stop;
+      bool all = true;
+      for (int l = 0; l < kLanes; ++l) all = all && done[l];
+      if (all) break;
+    }
+  }
+  for (int l = 0; l < kLanes; ++l) {
+    SweepLane& a = lanes[l];
+    a.best = best[l];
+    a.best_ref = best_ref[l];
+    a.best_q = -1;
+    for (int j = 0; j < a.q_len && a.best > 0; ++j) {
+      if (best_col[j][l] == best[l]) {
+        a.best_q = j;
+        break;
+      }
+    }
+  }
+}
+
+__attribute__((target("avx2"))) void sweep_lanes_avx2(SweepLane* lanes, const SweepParams& p) {
+  sweep_lanes_body(lanes, p);
+}
+void sweep_lanes_generic(SweepLane* lanes, const SweepParams& p) { sweep_lanes_body(lanes, p); }
+
+void sweep_lanes(SweepLane* lanes, const SweepParams& p) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) {
+    sweep_lanes_avx2(lanes, p);
+  } else {
+    sweep_lanes_generic(lanes, p);
+  }
+}
+
 }  // namespace
+
+CodedSequence encode_sequence(const std::string& s) { return translate(s); }
 
 LocalAligner::LocalAligner(int match, int mismatch, int gap_open, int gap_extend)
     : match_(match), mismatch_(mismatch), gap_open_(gap_open), gap_extend_(gap_extend) {
@@ -87,12 +195,20 @@ bool LocalAligner::banded_cigar(const int8_t* ref, int ref_len, const int8_t* q,
   int band = std::abs(ref_len - q_len) + 1;
   const size_t cells = static_cast<size_t>(q_len) * ref_len;
   if (cells > (size_t{1} << 27)) return false;   // 128 M cells (~1.5 GB of tables): not a window-sized problem
-  std::vector<int> H(cells), E(cells);
-  std::vector<uint8_t> dE(cells), dF(cells), dH(cells);
+  // every cell read below was written in the same band iteration (a row's neighbours above
+  // and to the left are read only when they lie inside that row's band), so the tables are
+  // neither cleared nor re-allocated between calls
+  static thread_local std::vector<int> H, E;
+  static thread_local std::vector<uint8_t> dE, dF, dH;
+  if (H.size() < cells) {
+    H.resize(cells);
+    E.resize(cells);
+    dE.resize(cells);
+    dF.resize(cells);
+    dH.resize(cells);
+  }
   int best = 0;
   for (;;) {
-    std::fill(H.begin(), H.end(), 0);
-    std::fill(E.begin(), E.end(), 0);
     for (int i = 0; i < q_len; ++i) {
       const int beg = std::max(0, i - band), end = std::min(ref_len - 1, i + band);
       const int up_beg = std::max(0, i - 1 - band), up_end = std::min(ref_len - 1, i - 1 + band);
@@ -131,7 +247,7 @@ bool LocalAligner::banded_cigar(const int8_t* ref, int ref_len, const int8_t* q,
   char op = 'M', prev_op = 'M';
   std::vector<std::pair<char, int>> rev;
   while (i > 0) {
-    if (j < 0) return false;
+    if (j < 0 || j < i - band || j > i + band) return false;   // left the band: nothing was computed there
     const size_t c = static_cast<size_t>(i) * ref_len + j;
     const int d = state == 2 ? dH[c] : state == 0 ? dE[c] : dF[c];
     switch (d) {
@@ -167,19 +283,114 @@ bool LocalAligner::align(const std::string& query, LocalAlignment* out) const {
   *out = LocalAlignment();
   if (query.empty() || ref_.empty()) return false;
   const std::vector<int8_t> q = translate(query);
-  const int ref_len = static_cast<int>(ref_.size()), q_len = static_cast<int>(q.size());
   int score1, ref_end, q_end;
-  sweep(ref_.data(), 0, ref_len - 1, +1, q, -1, &score1, &ref_end, &q_end);
+  sweep(ref_.data(), 0, static_cast<int>(ref_.size()) - 1, +1, q, -1, &score1, &ref_end, &q_end);
+  return finish(ref_, q, score1, ref_end, q_end, out);
+}
+
+void LocalAligner::align_to_many(const std::vector<const CodedSequence*>& references, const std::string& query,
+                                 std::vector<LocalAlignment>* out, std::vector<char>* ok) const {
+  const CodedSequence q = translate(query);
+  std::vector<const CodedSequence*> queries(references.size(), &q);
+  align_pairs(references, queries, out, ok);
+}
+
+void LocalAligner::align_many_to_reference(const std::vector<std::string>& queries, std::vector<LocalAlignment>* out,
+                                           std::vector<char>* ok) const {
+  std::vector<CodedSequence> coded;
+  coded.reserve(queries.size());
+  for (const std::string& s : queries) coded.push_back(translate(s));
+  std::vector<const CodedSequence*> refs(queries.size(), &ref_), qs;
+  for (const CodedSequence& c : coded) qs.push_back(&c);
+  align_pairs(refs, qs, out, ok);
+}
+
+void LocalAligner::align_pairs(const std::vector<const CodedSequence*>& references,
+                               const std::vector<const CodedSequence*>& queries, std::vector<LocalAlignment>* out,
+                               std::vector<char>* ok) const {
+  const size_t m = references.size();
+  out->assign(m, LocalAlignment());
+  ok->assign(m, 0);
+  const SweepParams params{match_, mismatch_, gap_open_, gap_extend_};
+  for (size_t base = 0; base < m; base += kLanes) {
+    const size_t count = std::min<size_t>(kLanes, m - base);
+    // int16 lanes: scores and column indices must fit
+    bool lanes_fit = count > 1 && gap_open_ < 16000 && mismatch_ < 16000 && match_ < 16000;
+    for (size_t l = 0; l < count; ++l) {
+      lanes_fit = lanes_fit && static_cast<int64_t>(match_) * static_cast<int64_t>(queries[base + l]->size()) < 32000 &&
+                  references[base + l]->size() < 32000;
+    }
+    if (!lanes_fit) {
+      for (size_t l = 0; l < count; ++l) {
+        const CodedSequence& ref = *references[base + l];
+        const CodedSequence& q = *queries[base + l];
+        if (ref.empty() || q.empty()) continue;
+        int score1, ref_end, q_end;
+        sweep(ref.data(), 0, static_cast<int>(ref.size()) - 1, +1, q, -1, &score1, &ref_end, &q_end);
+        (*ok)[base + l] = finish(ref, q, score1, ref_end, q_end, &(*out)[base + l]);
+      }
+      continue;
+    }
+    SweepLane fwd[kLanes], rev[kLanes];
+    for (size_t l = 0; l < count; ++l) {
+      const CodedSequence& ref = *references[base + l];
+      const CodedSequence& q = *queries[base + l];
+      if (ref.empty() || q.empty()) continue;
+      fwd[l].ref = ref.data();
+      fwd[l].ref_len = static_cast<int>(ref.size());
+      fwd[l].q = q.data();
+      fwd[l].q_len = static_cast<int>(q.size());
+    }
+    sweep_lanes(fwd, params);
+    bool any_reverse = false;
+    for (size_t l = 0; l < count; ++l) {
+      if (fwd[l].ref_len == 0) continue;
+      (*out)[base + l].score = fwd[l].best;
+      if (fwd[l].best <= 0) {
+        (*ok)[base + l] = 1;                      // nothing aligned: align() returns true with score 0
+        continue;
+      }
+      rev[l].ref = fwd[l].ref + fwd[l].best_ref;  // walk back from the end point
+      rev[l].ref_step = -1;
+      rev[l].ref_len = fwd[l].best_ref + 1;
+      rev[l].q = fwd[l].q + fwd[l].best_q;
+      rev[l].q_step = -1;
+      rev[l].q_len = fwd[l].best_q + 1;
+      rev[l].stop_at = fwd[l].best;
+      any_reverse = true;
+    }
+    if (!any_reverse) continue;
+    sweep_lanes(rev, params);
+    for (size_t l = 0; l < count; ++l) {
+      if (rev[l].ref_len == 0 || rev[l].best != fwd[l].best) continue;      // ok stays 0, as in finish()
+      const int ref_end = fwd[l].best_ref, q_end = fwd[l].best_q;
+      (*ok)[base + l] = describe(*references[base + l], *queries[base + l], fwd[l].best, ref_end - rev[l].best_ref,
+                                 ref_end, q_end - rev[l].best_q, q_end, &(*out)[base + l]);
+    }
+  }
+}
+
+bool LocalAligner::finish(const CodedSequence& ref, const CodedSequence& q, int score1, int ref_end, int q_end,
+                          LocalAlignment* out) const {
+  *out = LocalAlignment();
   out->score = score1;
   if (score1 <= 0) return true;
   std::vector<int8_t> rq(q.begin(), q.begin() + q_end + 1);
   std::reverse(rq.begin(), rq.end());
   int score2, ref_begin, k;
-  sweep(ref_.data(), ref_end, 0, -1, rq, score1, &score2, &ref_begin, &k);
+  sweep(ref.data(), ref_end, 0, -1, rq, score1, &score2, &ref_begin, &k);
   if (score2 != score1) return false;
-  const int q_begin = q_end - k;
+  return describe(ref, q, score1, ref_begin, ref_end, q_end - k, q_end, out);
+}
+
+// CIGAR and text form of the alignment whose corner points are known
+bool LocalAligner::describe(const CodedSequence& ref, const CodedSequence& q, int score1, int ref_begin, int ref_end,
+                            int q_begin, int q_end, LocalAlignment* out) const {
+  *out = LocalAlignment();
+  out->score = score1;
+  const int q_len = static_cast<int>(q.size());
   std::vector<std::pair<char, int>> ops;
-  if (!banded_cigar(ref_.data() + ref_begin, ref_end - ref_begin + 1, q.data() + q_begin,
+  if (!banded_cigar(ref.data() + ref_begin, ref_end - ref_begin + 1, q.data() + q_begin,
                     q_end - q_begin + 1, score1, &ops)) {
     return false;
   }
@@ -199,7 +410,7 @@ bool LocalAligner::align(const std::string& query, LocalAlignment* out) const {
       int run = 0;
       bool run_eq = true;
       for (int t = 0; t < o.second; ++t, ++ri, ++qi) {
-        const bool eq = ref_[ri] == q[qi];
+        const bool eq = ref[ri] == q[qi];
         if (run && eq != run_eq) {
           emit(run, run_eq ? '=' : 'X');
           run = 0;

@@ -36,6 +36,10 @@ struct LocalAlignment {
   std::string cigar;                     // e.g. "3S4=1X4=1I5=2S"; empty if nothing aligned
 };
 
+// a reference sequence in the aligner's 0..4 codes (A C G T other)
+using CodedSequence = std::vector<int8_t>;
+CodedSequence encode_sequence(const std::string& s);
+
 class LocalAligner {
  public:
   LocalAligner(int match, int mismatch, int gap_open, int gap_extend);
@@ -43,6 +47,20 @@ class LocalAligner {
   // false if the query or the reference is empty (libssw's Align fails the same way), or if
   // the aligned sub-problem exceeds 128 M cells (reads x haplotype here are window-sized)
   bool align(const std::string& query, LocalAlignment* out) const;
+  // The same alignments of ONE query against MANY references (the realigner aligns a read to
+  // every assembled haplotype): the forward pass -- nine tenths of the work -- runs for 16
+  // references at a time, one per int16 SIMD lane, each lane the exact scalar recurrence.
+  // ok[k] is what align() would return for references[k].
+  void align_to_many(const std::vector<const CodedSequence*>& references, const std::string& query,
+                     std::vector<LocalAlignment>* out, std::vector<char>* ok) const;
+  // ... MANY queries against the reference of set_reference() (haplotypes -> reference window)
+  void align_many_to_reference(const std::vector<std::string>& queries, std::vector<LocalAlignment>* out,
+                               std::vector<char>* ok) const;
+  // ... and the general form: pair k = (references[k], queries[k]); both passes of the search
+  // (end point, then start point on the reversed prefixes) run 16 pairs at a time
+  void align_pairs(const std::vector<const CodedSequence*>& references,
+                   const std::vector<const CodedSequence*>& queries, std::vector<LocalAlignment>* out,
+                   std::vector<char>* ok) const;
 
  private:
   int score(int8_t a, int8_t b) const { return mat_[a * 5 + b]; }
@@ -51,6 +69,11 @@ class LocalAligner {
              int stop_at, int* best, int* best_ref, int* best_q) const;
   bool banded_cigar(const int8_t* ref, int ref_len, const int8_t* q, int q_len, int target,
                     std::vector<std::pair<char, int>>* ops) const;
+  // reverse pass + CIGAR for a forward result (score1 at ref_end / q_end)
+  bool finish(const CodedSequence& ref, const CodedSequence& q, int score1, int ref_end, int q_end,
+              LocalAlignment* out) const;
+  bool describe(const CodedSequence& ref, const CodedSequence& q, int score1, int ref_begin, int ref_end,
+                int q_begin, int q_end, LocalAlignment* out) const;
 
   int match_, mismatch_, gap_open_, gap_extend_;
   int8_t mat_[25];

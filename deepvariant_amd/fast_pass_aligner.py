@@ -188,6 +188,16 @@ def local_align(reference: str, query: str, match=2, mismatch=2, gap_open=3, gap
   return out
 
 
+def local_align_many(reference: str, queries: Sequence[str], match=2, mismatch=2, gap_open=3, gap_extend=1):
+  """`local_align` of every query against one reference through the 16-lane batch path;
+  an entry is None where local_align would raise."""
+  n = len(queries)
+  out = (_lib.DvLocalAlignment * max(n, 1))()
+  _lib.check(_lib.lib().dv_local_align_many(reference.encode(), n, _strings(queries), match, mismatch, gap_open,
+                                            gap_extend, out))
+  return [None if out[k].score < 0 else out[k] for k in range(n)]
+
+
 def realign_reads_to_haplotype(haplotype: str, reads: Sequence, contig: str, ref_start: int, ref_end: int,
                                ref_reader, aln_config: Optional[dict] = None) -> List[Optional[T.Read]]:
   """RealignReadsToHaplotype (alt_aligned_pileup_lib.cc:278-313).

@@ -429,6 +429,11 @@ int dv_merge_cigar_op(char* cigar, int32_t cap, char op, int32_t length, int32_t
 /* One local alignment (Aligner::SetReferenceSequence + Align). */
 int dv_local_align(const char* reference, const char* query, int32_t match, int32_t mismatch,
                    int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
+/* The same for n queries against one reference, 16 alignments per SIMD batch (the path the
+ * realigner uses for haplotypes -> reference and reads -> haplotypes); identical results.
+ * out[k].score = -1 where dv_local_align would fail (empty query). */
+int dv_local_align_many(const char* reference, int32_t n, const char* const* queries, int32_t match,
+                        int32_t mismatch, int32_t gap_open, int32_t gap_extend, dv_local_alignment* out);
 
 /* ---- local assembly for the window realigner (host only) -----------------------
  * Replaces deepvariant/realigner/debruijn_graph.{h,cc} (DeBruijnGraph::Build,

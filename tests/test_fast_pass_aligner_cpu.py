@@ -286,3 +286,52 @@ def test_force_alignment_against_the_haplotype_as_reference():
   assert out[1][0] == 1 and out[1][1] == 510 and sum(n for op, n in out[1][2] if op == 2) == 2
   assert out[2][0] == 1 and out[2][1] == 530 and [op for op, _ in out[2][2]] == [1, 3, 1]
   assert out[3][0] == 2
+
+
+# ---------------------------------------------------------------- SIMD batch path == scalar path
+def _fields(a):
+  return (a.score, a.ref_begin, a.ref_end, a.query_begin, a.query_end, a.mismatches, a.cigar)
+
+
+@pytest.mark.parametrize('seed,scoring', [(1, (4, 6, 8, 2)), (2, (2, 2, 3, 1)), (3, (1, 4, 6, 1)), (4, (4, 6, 8, 1))])
+def test_batched_alignment_equals_one_at_a_time(seed, scoring):
+  """The realigner aligns 16 (reference, query) pairs per SIMD batch (int16 lanes, forward and
+  reverse pass); every field must equal the scalar aligner's, which the libssw vectors pin.
+  Queries: mutated copies of reference pieces (substitutions, indels, N, soft-clipped junk),
+  pure junk, one-base and repeat sequences, lengths 1..400 in one batch."""
+  import numpy as np
+  rng = np.random.default_rng(seed)
+  letters = np.array(list('ACGT'))
+  reference = ''.join(rng.choice(letters, size=700))
+  reference = reference[:300] + 'TGA' * 15 + reference[300:500] + 'N' * 3 + reference[500:]
+  queries = []
+  for _ in range(75):
+    a = int(rng.integers(0, len(reference) - 50))
+    piece = list(reference[a:a + int(rng.integers(20, 400))])
+    for _ in range(int(rng.integers(0, 6))):
+      k = int(rng.integers(0, len(piece)))
+      kind = int(rng.integers(0, 4))
+      if kind == 0:
+        piece[k] = str(rng.choice(letters))
+      elif kind == 1:
+        piece[k:k] = list(rng.choice(letters, size=int(rng.integers(1, 12))))
+      elif kind == 2:
+        del piece[k:k + int(rng.integers(1, 12))]
+      else:
+        piece[k] = 'N'
+    clip = ''.join(rng.choice(letters, size=int(rng.integers(0, 10))))
+    queries.append(clip + ''.join(piece) + clip[::-1])
+  queries += [''.join(rng.choice(letters, size=30)), 'A', 'TGA' * 20, 'N' * 10, reference, reference[100:140].lower()]
+  got = F.local_align_many(reference, queries, *scoring)
+  assert len(got) == len(queries)
+  for q, g in zip(queries, got):
+    want = F.local_align(reference, q, *scoring)
+    assert g is not None and _fields(g) == _fields(want), q
+  # and with a single query (the batch path needs >= 2 pairs; one pair takes the scalar route)
+  assert _fields(F.local_align_many(reference, queries[:1], *scoring)[0]) == _fields(
+      F.local_align(reference, queries[0], *scoring))
+
+
+def test_batched_alignment_refuses_what_the_scalar_path_refuses():
+  got = F.local_align_many('ACGTACGT', ['ACGT', '', 'TTTT'])
+  assert got[1] is None and got[0].score == 8 and got[2].score == 2
