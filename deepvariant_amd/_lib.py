@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
     'dv_merge_cigar_op', 'dv_local_align', 'dv_local_align_many',
     'dv_debruijn_build', 'dv_debruijn_destroy', 'dv_debruijn_kmer_size', 'dv_debruijn_haplotypes',
-    'dv_debruijn_graphviz',
+    'dv_debruijn_graphviz', 'dv_phase_reads',
     'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
 
@@ -170,6 +170,15 @@ class DvDebruijnOptions(C.Structure):
                                        'min_edge_weight', 'max_num_paths', 'disable_graph_pruning')]
 
 
+class DvPhasingAllele(C.Structure):
+  _fields_ = [('bases_off', C.c_int64), ('bases_len', C.c_int32), ('is_ref', C.c_int32),
+              ('support_off', C.c_int64), ('n_support', C.c_int32), ('reserved', C.c_int32)]
+
+
+class DvPhasingCandidate(C.Structure):
+  _fields_ = [('start', C.c_int64), ('end', C.c_int64), ('allele_off', C.c_int32), ('n_alleles', C.c_int32)]
+
+
 class DvAltMergeEntry(C.Structure):
   _fields_ = [('example', C.c_int64), ('first_row', C.c_int32), ('rows', C.c_int32),
               ('scratch_alt1', C.c_int64), ('scratch_alt2', C.c_int64)]
@@ -180,7 +189,9 @@ class DvAlleleCounterOptions(C.Structure):
               ('reads_interval_start', C.c_int64), ('reads_interval_end', C.c_int64),
               ('ref_bases', C.c_char_p), ('ref_start', C.c_int64), ('n_ref_bases', C.c_int64),
               ('contig_n_bases', C.c_int64), ('min_mapping_quality', C.c_int32),
-              ('min_base_quality', C.c_int32), ('keep_legacy_behavior', C.c_int32)]
+              ('min_base_quality', C.c_int32), ('keep_legacy_behavior', C.c_int32),
+              ('track_ref_reads', C.c_int32), ('candidate_positions', C.c_void_p),
+              ('n_candidate_positions', C.c_int32)]
 
 
 class DvAlleleEvent(C.Structure):
@@ -283,6 +294,9 @@ def lib():
     l.dv_debruijn_kmer_size.argtypes = [C.c_void_p]
     l.dv_debruijn_haplotypes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.dv_debruijn_graphviz.argtypes = [C.c_void_p, C.c_void_p]
+    l.dv_phase_reads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int32]
     l.dv_count_alleles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     l.dv_allele_counts_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     l.dv_allele_counts_free.argtypes = [C.c_void_p]

@@ -4,6 +4,8 @@
   .add(read, sample) / .counts() / .summary_counts()        deepvariant/allelecounter.cc:873-1008
   sum_allele_counts / total_allele_counts                    deepvariant/allelecounter.cc:78-203
 
+track_ref_reads + candidate_positions (the two-pass scheme of make_examples_core.py:2880-2932) are
+supported: at candidate positions the reference-supporting reads come back by name too.
 The reference adds reads one by one on the CPU; here `add` only queues them and the first
 call that needs results packs the queue (packing.ReadTable) and counts the whole region in
 ONE kernel launch (deepvariant_amd/csrc/allele_counter.hip).  There is no CPU path.
@@ -70,8 +72,8 @@ class AlleleCounter:
                candidate_positions: Sequence[int] = (), min_mapping_quality: int = 0,
                min_base_quality: int = 0, keep_legacy_behavior: bool = False,
                full_range: Optional[Tuple[int, int]] = None, track_ref_reads: bool = False):
-    if track_ref_reads or candidate_positions:
-      raise NotImplementedError('track_ref_reads (REFERENCE read alleles at candidate positions)')
+    self._track_ref_reads = bool(track_ref_reads)
+    self._candidate_positions = np.ascontiguousarray(sorted(int(p) for p in candidate_positions), np.int64)
     self._ref = ref_reader
     self._contig, self._start, self._end = reference_name, int(start), int(end)
     self._reads_start = min(self._start, full_range[0]) if full_range else self._start
@@ -130,7 +132,9 @@ class AlleleCounter:
     interval_ref = self._ref.get_bases(self._contig, self._start, self._end)
     opt = _lib.DvAlleleCounterOptions(
         self._start, self._end, self._reads_start, self._reads_end, window, w0, len(window), n_contig,
-        self._opt[0], self._opt[1], int(self._opt[2]))
+        self._opt[0], self._opt[1], int(self._opt[2]), int(self._track_ref_reads),
+        self._candidate_positions.ctypes.data if len(self._candidate_positions) else None,
+        len(self._candidate_positions))
     b, keep = packing.PackedBatch(table=table, width=3).to_ctypes()
     handle = C.c_void_p()
     lib = _lib.lib()
@@ -145,12 +149,13 @@ class AlleleCounter:
       counts = [AlleleCount(self._contig, self._start + i, interval_ref[i]) for i in range(length)]
       for i in range(length):
         counts[i].ref_supporting_read_count = int(refc[i])
+        counts[i].track_ref_reads = self._track_ref_reads
       seq_off = table.read_seq_off
       bases = table.bases
       for k in range(n_events.value):
         ev = events[k]
         s0 = int(seq_off[ev.read]) + ev.read_offset
-        if ev.type == SUBSTITUTION:
+        if ev.type in (SUBSTITUTION, REFERENCE):
           text = chr(bases[s0])
         else:
           anchor_pos = self._start + ev.position          # the base the indel is anchored on

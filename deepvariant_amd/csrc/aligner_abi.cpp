@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "debruijn_graph.h"
+#include "direct_phasing.h"
 #include "dv_internal.h"
 #include "fast_pass_aligner.h"
 
@@ -327,6 +328,61 @@ int dv_debruijn_graphviz(dv_debruijn_graph* h, const char** text) {
   if (!h || !text) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_graphviz: null");
   h->dot = h->g->graphviz();
   *text = h->dot.c_str();
+  return DV_OK;
+}
+
+// ---- read phasing (direct_phasing.cpp)
+
+int dv_phase_reads(const dv_phasing_candidate* candidates, int32_t n_candidates, const dv_phasing_allele* alleles,
+                   int32_t n_alleles, const char* bases, int64_t n_bases, const int32_t* support_reads,
+                   const uint8_t* support_low_quality, int64_t n_support, int32_t n_reads,
+                   int32_t min_alleles_to_phase, int32_t* read_phases, int32_t* allele_phases,
+                   uint8_t* allele_flags, char* graphviz, int32_t graphviz_cap) {
+  if (n_candidates < 0 || n_alleles < 0 || n_reads < 0 || n_bases < 0 || n_support < 0 ||
+      (n_candidates > 0 && !candidates) || (n_alleles > 0 && !alleles) || (n_reads > 0 && !read_phases) ||
+      (n_support > 0 && (!support_reads || !support_low_quality)) || (n_bases > 0 && !bases)) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_phase_reads: null or negative argument");
+  }
+  std::vector<dv::PhasingCandidate> cs(n_candidates);
+  for (int32_t i = 0; i < n_candidates; ++i) {
+    const dv_phasing_candidate& c = candidates[i];
+    if (c.allele_off < 0 || c.n_alleles < 0 || static_cast<int64_t>(c.allele_off) + c.n_alleles > n_alleles) {
+      return dv::fail(DV_ERR_BAD_INPUT, "dv_phase_reads: candidate allele range outside the allele table");
+    }
+    cs[i].start = c.start;
+    cs[i].end = c.end;
+    for (int32_t k = 0; k < c.n_alleles; ++k) {
+      const dv_phasing_allele& a = alleles[c.allele_off + k];
+      if (a.bases_off < 0 || a.bases_len < 0 || a.bases_off + a.bases_len > n_bases || a.support_off < 0 ||
+          a.n_support < 0 || a.support_off + a.n_support > n_support) {
+        return dv::fail(DV_ERR_BAD_INPUT, "dv_phase_reads: allele range outside its table");
+      }
+      dv::PhasingAllele pa;
+      pa.bases.assign(bases + a.bases_off, static_cast<size_t>(a.bases_len));
+      pa.is_ref = a.is_ref != 0;
+      for (int64_t r = a.support_off; r < a.support_off + a.n_support; ++r) {
+        if (support_reads[r] >= n_reads) return dv::fail(DV_ERR_BAD_INPUT, "dv_phase_reads: read index out of range");
+        pa.support.push_back(dv::PhasingReadSupport{support_reads[r], support_low_quality[r] != 0});
+      }
+      cs[i].alleles.push_back(std::move(pa));
+    }
+  }
+  dv::DirectPhasing phasing(min_alleles_to_phase);
+  std::vector<int> phases;
+  std::string error;
+  if (!phasing.phase_reads(cs, n_reads, &phases, &error)) return dv::fail(DV_ERR_BAD_INPUT, error);
+  for (int32_t r = 0; r < n_reads; ++r) read_phases[r] = phases[r];
+  if (allele_phases || allele_flags) {
+    for (int32_t i = 0; i < n_candidates; ++i) {
+      const auto& per_allele = phasing.allele_phases()[i];
+      for (size_t k = 0; k < per_allele.size(); ++k) {
+        const int32_t at = candidates[i].allele_off + static_cast<int32_t>(k);
+        if (allele_phases) allele_phases[at] = per_allele[k].in_graph ? per_allele[k].phase : -1;
+        if (allele_flags) allele_flags[at] = per_allele[k].is_first_in_block ? 1 : 0;
+      }
+    }
+  }
+  if (graphviz) return copy_text(phasing.graphviz(), graphviz, graphviz_cap);
   return DV_OK;
 }
 

@@ -77,6 +77,7 @@ struct CountArgs {
   int64_t contig_len;
   int32_t min_mapq, min_bq, legacy;
   int32_t* ref_count;        // [interval_len]
+  const uint32_t* candidate_mask;   // track_ref_reads: bit p set = keep the reference reads of position p by name
   dv_allele_event* events;
   uint32_t event_cap;
   uint32_t* counters;        // [0] events wanted, [1] reads counted, [2] reference window too small
@@ -122,7 +123,8 @@ __device__ __forceinline__ void emit(const CountArgs& a, uint32_t read, const En
         atomicAdd(&a.ref_count[p], 1);
       }
     }
-    return;
+    // a REFERENCE read allele exists only where a candidate will be called (allelecounter.cc:504-512)
+    if (!a.candidate_mask || !((a.candidate_mask[p >> 5] >> (p & 31)) & 1u)) return;
   }
   dv_allele_event ev;
   ev.position = static_cast<int32_t>(p);
@@ -353,7 +355,7 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   }
   // result / reference scratch is kept per host thread (grow-only): a region driver calls this
   // once per region and hipMalloc + hipFree of ~100 MB cost more than the kernel
-  static thread_local dv::DeviceBuffer d_ref, d_cnt, d_ev, d_ctr;
+  static thread_local dv::DeviceBuffer d_ref, d_cnt, d_ev, d_ctr, d_mask;
   dv::DeviceBuffer up[7];
   struct Release {
     dv::DeviceBuffer* v[7];
@@ -385,13 +387,27 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   a.min_mapq = o->min_mapping_quality;
   a.min_bq = o->min_base_quality;
   a.legacy = o->keep_legacy_behavior ? 1 : 0;
+  size_t n_candidate_refs = 0;
+  if (o->track_ref_reads && o->n_candidate_positions > 0) {
+    if (!o->candidate_positions) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: candidate_positions is null");
+    std::vector<uint32_t> mask(static_cast<size_t>((len + 31) / 32), 0u);
+    for (int32_t k = 0; k < o->n_candidate_positions; ++k) {
+      const int64_t p = o->candidate_positions[k] - o->interval_start;
+      if (p >= 0 && p < len) mask[static_cast<size_t>(p >> 5)] |= 1u << (p & 31);
+    }
+    if (int rc = d_mask.reserve(mask.size() * sizeof(uint32_t))) return rc;
+    DV_HIP_CHECK(hipMemcpyAsync(d_mask.ptr, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    DV_HIP_CHECK(hipStreamSynchronize(stream));      // `mask` is a local
+    a.candidate_mask = static_cast<const uint32_t*>(d_mask.ptr);
+    n_candidate_refs = static_cast<size_t>(o->n_candidate_positions);
+  }
   if (int rc = d_cnt.reserve(static_cast<size_t>(len) * sizeof(int32_t))) return rc;
   if (int rc = d_ctr.reserve(4 * sizeof(uint32_t))) return rc;
   a.ref_count = static_cast<int32_t*>(d_cnt.ptr);
   a.counters = static_cast<uint32_t*>(d_ctr.ptr);
   // events: substitutions are a few per cent of the bases, indels at most one per CIGAR op;
   // the counter keeps counting past the capacity, so a second pass sizes it exactly
-  uint32_t cap = b->n_cigar + b->n_bases / 16 + 4096;
+  uint32_t cap = b->n_cigar + b->n_bases / 16 + 4096 + static_cast<uint32_t>(std::min<size_t>(n_candidate_refs * 64, 1u << 24));
   uint32_t ctr[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; ++pass) {
     if (int rc = d_ev.reserve(static_cast<size_t>(cap) * sizeof(dv_allele_event))) return rc;

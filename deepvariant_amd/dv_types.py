@@ -215,6 +215,13 @@ class SupportingReads:
 
 
 @dataclass
+class ReadSupport:
+  """DeepVariantCall.ReadSupport (the fields phasing reads)."""
+  read_name: str = ''
+  is_low_quality: bool = False
+
+
+@dataclass
 class AltAlleleIndices:
   indices: List[int] = field(default_factory=list)
 
@@ -225,6 +232,9 @@ class DeepVariantCall:
   allele_support: Dict[str, SupportingReads] = field(default_factory=dict)
   allele_frequency: Dict[str, float] = field(default_factory=dict)
   ref_support: List[str] = field(default_factory=list)
+  # allele_support_ext[allele].read_infos / ref_support_ext.read_infos (track_ref_reads, phasing)
+  allele_support_ext: Dict[str, List[ReadSupport]] = field(default_factory=dict)
+  ref_support_ext: List[ReadSupport] = field(default_factory=list)
   make_examples_alt_allele_indices: List[AltAlleleIndices] = field(
       default_factory=list)
 

@@ -3,15 +3,17 @@ candidate calls -> pileup examples (or, fused, genotype probabilities).  The par
 deepvariant/make_examples_core.py's RegionProcessor that joins the hot path's stages:
 
   RegionProcessor.realign_reads          make_examples_core.py:2479-2518
-  RegionProcessor.candidates_in_region   make_examples_core.py:2840-3010 (one sample, no gVCF,
-                                         no phasing, no normalize_reads)
+  RegionProcessor.candidates_in_region   make_examples_core.py:2840-3165 (one sample; incl. the
+                                         two-pass track_ref_reads counting and read phasing with
+                                         region padding; no gVCF, no normalize_reads, no
+                                         methylation-aware phasing)
   RegionProcessor.process                make_examples_core.py:2215-2380
   partition                              ranges.RangeSet.partition (1000-base calling regions)
 
 Every stage below is this package's own: realigner/ (device allele counts for window
 selection, native assembly and alignment), allelecounter.AlleleCounter (device),
-variant_calling.VariantCaller (host), make_examples_native.ExamplesGenerator (device encoder,
-optionally fused with the CNN).  File handling, sharding, labelling, gVCF and multi-sample
+variant_calling.VariantCaller (host), direct_phasing.DirectPhasing (native, host),
+make_examples_native.ExamplesGenerator (device encoder, optionally fused with the CNN).  File handling, sharding, labelling, gVCF and multi-sample
 plumbing of the reference's make_examples are outside SURVEY.md section 8.
 """
 from __future__ import annotations
@@ -20,6 +22,7 @@ import dataclasses
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 from deepvariant_amd import allelecounter
+from deepvariant_amd import direct_phasing
 from deepvariant_amd import dv_types as T
 from deepvariant_amd import make_examples_native
 from deepvariant_amd import variant_calling
@@ -39,6 +42,13 @@ class RegionProcessorOptions:
   vsc_min_fraction_indels: float = 0.06
   keep_legacy_allele_counter_behavior: bool = False
   partition_size: int = 1000
+  # long-read models (make_examples_options.py:670-700, 1152-1168): phase reads on the fly and
+  # tag them HP for the haplotype channel / sort_by_haplotypes; needs track_ref_reads
+  track_ref_reads: bool = False
+  phase_reads: bool = False
+  phase_reads_region_padding_pct: int = 20        # dv_constants.PHASE_READS_REGION_PADDING_PCT
+  phase_max_candidates: int = 5000
+  min_alleles_to_phase: int = 1
 
 
 def partition(region: T.Range, size: int) -> Iterator[T.Range]:
@@ -59,6 +69,9 @@ class RegionProcessor:
     self.ref_reader = ref_reader
     self.processor_options = processor_options or RegionProcessorOptions()
     po = self.processor_options
+    if po.phase_reads and not po.track_ref_reads:
+      raise ValueError('--track_ref_reads must be set to True when --phase_reads is set.')
+    self.direct_phasing = direct_phasing.DirectPhasing(po.min_alleles_to_phase) if po.phase_reads else None
     self.realigner = None
     if po.realigner_enabled:
       self.realigner = realigner_module.Realigner(po.realigner_options or realigner_module.realigner_config(),
@@ -81,25 +94,60 @@ class RegionProcessor:
     short_reads = [r for r in reads if len(r.aligned_sequence) <= limit]
     return long_reads + self.realigner.realign_reads(short_reads, region)[1]
 
-  def candidates_in_region(self, region: T.Range, reads: Sequence) -> List[T.DeepVariantCall]:
-    """Allele counts over `region` from the reads that overlap it (one kernel launch), then the
-    candidate caller."""
+  def _allele_counter(self, region: T.Range, reads: Sequence, candidate_positions=()):
     rr = self.options.pic_options.read_requirements
+    counter = allelecounter.AlleleCounter(
+        self.ref_reader, region.reference_name, region.start, region.end,
+        candidate_positions=candidate_positions, min_mapping_quality=rr.min_mapping_quality,
+        min_base_quality=rr.min_base_quality,
+        keep_legacy_behavior=self.processor_options.keep_legacy_allele_counter_behavior,
+        track_ref_reads=self.processor_options.track_ref_reads)
+    for read in reads:
+      counter.add(read, self.options.sample_options[0].name)
+    return counter
+
+  def candidates_in_region(self, region: T.Range, reads: Sequence,
+                           padded_region: Optional[T.Range] = None) -> List[T.DeepVariantCall]:
+    """Allele counts over the (padded) region from the reads that overlap `region` (one kernel
+    launch; two with track_ref_reads: the first finds the positions that will be called, the
+    second keeps their reference-supporting reads by name), the candidate caller, and -- with
+    phase_reads -- the phasing of those reads (their HP tags are REPLACED in place)."""
+    po = self.processor_options
     in_region = [r for r in reads if utils.ranges_overlap(utils.read_range(r), region)]
     if not in_region:
       return []
-    counter = allelecounter.AlleleCounter(
-        self.ref_reader, region.reference_name, region.start, region.end,
-        min_mapping_quality=rr.min_mapping_quality, min_base_quality=rr.min_base_quality,
-        keep_legacy_behavior=self.processor_options.keep_legacy_allele_counter_behavior)
-    for read in in_region:
-      counter.add(read, self.options.sample_options[0].name)
-    return self.variant_caller.calls_from_allele_counter(counter)
+    effective = padded_region or region
+    positions = ()
+    if po.track_ref_reads:
+      first_pass = self._allele_counter(effective, in_region)
+      positions = self.variant_caller.call_positions_from_allele_counts(first_pass.counts())
+    candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(effective, in_region, positions))
+    if self.direct_phasing is not None:
+      to_phase = [r for r in in_region if utils.ranges_overlap(utils.read_range(r), effective)]
+      for read in to_phase:
+        read.info.pop('HP', None)                 # an existing phasing must not leak into the images
+      if not (po.phase_max_candidates and len(candidates) > po.phase_max_candidates):
+        for read, phase in zip(to_phase, self.direct_phasing.phase(candidates, to_phase)):
+          if self.options.pic_options.reverse_haplotypes and phase in (1, 2):
+            phase = 1 + (phase % 2)
+          read.info['HP'] = T.ListValue(values=[T.Value(int_value=int(phase))])
+    if padded_region is not None:                 # filter_candidates_by_region, :2579-2606
+      candidates = [c for c in candidates if region.start <= c.variant.start < region.end]
+    return candidates
 
   def process(self, region: T.Range, reads: Sequence) -> Tuple[List[T.DeepVariantCall], List]:
     """-> (candidates, the region's reads as the pileup images must see them)."""
+    po = self.processor_options
     realigned = self.realign_reads(reads, region)
-    return self.candidates_in_region(region, realigned), realigned
+    padded = None
+    if po.phase_reads:
+      # HP tags are written on this region's own copies: a long read that overlaps two calling
+      # regions is phased in each (the labels 1 / 2 are only meaningful within a region)
+      realigned = [dataclasses.replace(r, info=dict(r.info)) for r in realigned]
+      if po.phase_reads_region_padding_pct > 0:
+        padding = int((region.end - region.start) * po.phase_reads_region_padding_pct / 100)
+        padded = utils.expand(region, padding, self.ref_reader.n_bases(region.reference_name))
+    return self.candidates_in_region(region, realigned, padded), realigned
 
   def examples_in_region(self, region: T.Range, reads: Sequence, stats: Optional[dict] = None
                          ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:

@@ -152,6 +152,18 @@ class VariantCaller:
   def calls_from_allele_counter(self, allele_counter) -> List[T.DeepVariantCall]:
     return self.calls_from_allele_counts(allele_counter.counts())
 
+  def call_positions_from_allele_counts(self, allele_counts: Sequence) -> List[int]:
+    """CallPositionsFromAlleleCounts / CallVariantPosition (variant_calling_multisample.cc:940-1004):
+    the positions that WILL become candidates -- the first pass of track_ref_reads, which tells
+    the allele counter where to keep the reference-supporting reads by name."""
+    out = []
+    for allele_count in allele_counts:
+      if not allele_count.ref_base or any(b not in _CANONICAL for b in allele_count.ref_base):
+        continue
+      if self.select_alt_alleles(allele_count):
+        out.append(allele_count.position.position)
+    return out
+
   # ---- annotations
   def _add_read_depths(self, allele_count, alt_alleles, allele_map, refbases, variant):
     """AddReadDepths (:298-351): DP, AD, VAF on the first call."""
@@ -183,5 +195,9 @@ class VariantCaller:
         alt = allele_map.get(_allele_order(allele))
         key = K_SUPPORTING_UNCALLED_ALLELE if alt is None else alt + suffix
         call.allele_support.setdefault(key, T.SupportingReads()).read_names.append(read_name)
-      elif self._options.track_ref_reads:
+        call.allele_support_ext.setdefault(key, []).append(T.ReadSupport(read_name, bool(allele.is_low_quality)))
+      else:
+        # REFERENCE read alleles exist only under track_ref_reads, at candidate positions
+        # (variant_calling_multisample.cc:1231-1247)
         call.ref_support.append(read_name)
+        call.ref_support_ext.append(T.ReadSupport(read_name, bool(allele.is_low_quality)))

@@ -461,6 +461,37 @@ int dv_debruijn_kmer_size(const dv_debruijn_graph* g);                          
 int dv_debruijn_haplotypes(dv_debruijn_graph* g, int32_t* n, const char* const** haplotypes);
 int dv_debruijn_graphviz(dv_debruijn_graph* g, const char** text);                     /* graphviz */
 
+/* ---- read phasing for the long-read path (host only) ---------------------------
+ * Replaces deepvariant/direct_phasing.{h,cc} (DirectPhasing::PhaseReads / GetPhasedVariants;
+ * python binding deepvariant/python/direct_phasing_pybind.cc).  A candidate is a
+ * DeepVariantCall reduced to what phasing reads: variant.start / end and, per called allele
+ * (allele_support_ext key, UNCALLED_ALLELE left out) plus one is_ref entry for
+ * ref_support_ext, the supporting reads as indices into the reads being phased (-1: a read
+ * that is not among them) with their is_low_quality flags. */
+typedef struct dv_phasing_allele {
+  int64_t bases_off;        /* into `bases` */
+  int32_t bases_len;
+  int32_t is_ref;
+  int64_t support_off;      /* into support_reads / support_low_quality */
+  int32_t n_support;
+  int32_t reserved;
+} dv_phasing_allele;
+
+typedef struct dv_phasing_candidate {
+  int64_t start, end;
+  int32_t allele_off, n_alleles;   /* into `alleles` */
+} dv_phasing_candidate;
+
+/* read_phases[n_reads] receives 0 / 1 / 2 (PhaseReads' return value).  Optional outputs, per
+ * allele-table entry: allele_phases (-1 = the allele is not a vertex of the graph) and
+ * allele_flags (1 = first site of its phase block) -- what GetPhasedVariants reads -- and
+ * the graph as text (GraphViz()).  Candidates must be strictly ordered by start. */
+int dv_phase_reads(const dv_phasing_candidate* candidates, int32_t n_candidates, const dv_phasing_allele* alleles,
+                   int32_t n_alleles, const char* bases, int64_t n_bases, const int32_t* support_reads,
+                   const uint8_t* support_low_quality, int64_t n_support, int32_t n_reads,
+                   int32_t min_alleles_to_phase, int32_t* read_phases, int32_t* allele_phases,
+                   uint8_t* allele_flags, char* graphviz, int32_t graphviz_cap);
+
 /* ---- alt-aligned channel merge (device) --------------------------------------
  * FillPileupArray's diff_channels / base_channels modes (deepvariant/pileup_image_native.h:
  * 246-271) on images that stay in HBM: `images` holds the examples followed, from
@@ -497,6 +528,12 @@ typedef struct dv_allele_counter_options {
   int64_t contig_n_bases;                           /* RefBases validity (:371-384); 0 = end of the window */
   int32_t min_mapping_quality, min_base_quality;    /* AlleleCounterOptions.read_requirements */
   int32_t keep_legacy_behavior;                     /* AlleleCounterOptions.keep_legacy_behavior */
+  /* AlleleCounterOptions.track_ref_reads + the constructor's candidate_positions (absolute, any order):
+   * at those positions reference-supporting reads are reported too, as events of type 1 (REFERENCE),
+   * so that the caller can name them (ref_support_ext, read phasing); allelecounter.cc:504-512 */
+  int32_t track_ref_reads;
+  const int64_t* candidate_positions;
+  int32_t n_candidate_positions;
 } dv_allele_counter_options;
 
 typedef struct dv_allele_event {   /* one ReadAllele that AddReadAlleles stores in read_alleles */
@@ -504,7 +541,8 @@ typedef struct dv_allele_event {   /* one ReadAllele that AddReadAlleles stores 
   uint32_t read;         /* index in the read table */
   uint32_t read_offset;  /* SUBSTITUTION: the base; INSERTION / SOFT_CLIP: first inserted base; DELETION: next read base */
   uint16_t length;       /* operation length (1 for substitutions) */
-  uint8_t type;          /* AlleleType: 2 SUBSTITUTION, 3 INSERTION, 4 DELETION, 5 SOFT_CLIP */
+  uint8_t type;          /* AlleleType: 2 SUBSTITUTION, 3 INSERTION, 4 DELETION, 5 SOFT_CLIP; 1 REFERENCE
+                            (track_ref_reads, candidate positions only; read_offset = the base) */
   uint8_t low_quality;   /* Allele.is_low_quality */
 } dv_allele_event;
 

@@ -8,9 +8,9 @@ Pinned by tests/test_allelecounter_oracle_cpu.py: the vectors of
 deepvariant/allelecounter_test.cc over third_party/nucleus/testdata/test.fasta.
 
 Restated: AlleleCounter::Add (:873-979), MakeIndelReadAllele (:402-469), GetPrevBase
-(:386-400), CanBasesBeUsed (:206-229), AddReadAlleles (:471-543), SumAlleleCounts (:78-117),
-TotalAlleleCounts (:165-176).  Not restated: methylation fields, track_ref_reads' REFERENCE
-read alleles, sample_alleles, NormalizeCigar (the product restates that one on the host:
+(:386-400), CanBasesBeUsed (:206-229), AddReadAlleles (:471-543, incl. track_ref_reads'
+REFERENCE read alleles at candidate positions), SumAlleleCounts (:78-117),
+TotalAlleleCounts (:165-176).  Not restated: methylation fields, sample_alleles, NormalizeCigar (the product restates that one on the host:
 deepvariant_amd/allelecounter.py, pinned by the reference's NormalizeCigar* vectors).
 """
 from __future__ import annotations
@@ -40,6 +40,7 @@ class AlleleCount:
     self.position, self.ref_base = position, ref_base
     self.ref_supporting_read_count = 0
     self.read_alleles: Dict[str, Allele] = {}
+    self.track_ref_reads = False
 
 
 class _ReadAllele:
@@ -58,7 +59,7 @@ def sum_allele_counts(ac: AlleleCount, include_low_quality=False) -> List[Allele
     if include_low_quality or not allele.is_low_quality:
       sums[(allele.bases, allele.type)] = sums.get((allele.bases, allele.type), 0) + 1
   out = [Allele(b, t, n) for (b, t), n in sorted(sums.items())]
-  if ac.ref_supporting_read_count > 0:
+  if ac.ref_supporting_read_count > 0 and not ac.track_ref_reads:
     out.append(Allele(ac.ref_base, REFERENCE, ac.ref_supporting_read_count))
   return out
 
@@ -74,7 +75,8 @@ class AlleleCounter:
   the full_range form (:349-369) when `full_range` is given."""
 
   def __init__(self, ref_reader, contig: str, start: int, end: int, min_mapping_quality=0,
-               min_base_quality=0, keep_legacy_behavior=False, full_range: Optional[Tuple[int, int]] = None):
+               min_base_quality=0, keep_legacy_behavior=False, full_range: Optional[Tuple[int, int]] = None,
+               candidate_positions=(), track_ref_reads=False):
     self.ref = ref_reader
     self.contig, self.start, self.end = contig, start, end
     r0, r1 = (min(start, full_range[0]), max(end, full_range[1])) if full_range else (start, end)
@@ -83,6 +85,10 @@ class AlleleCounter:
     self.min_mapq, self.min_bq, self.legacy = min_mapping_quality, min_base_quality, keep_legacy_behavior
     off = max(start - r0, 0)
     self.counts = [AlleleCount(start + i, self.ref_bases[i + off]) for i in range(end - start)]
+    self.track_ref_reads = track_ref_reads
+    self.candidate_offsets = frozenset(p - start for p in candidate_positions)    # Init, :305-307
+    for c in self.counts:
+      c.track_ref_reads = track_ref_reads                                         # :318
     self.n_reads_counted = 0
 
   # ---- helpers
@@ -170,5 +176,7 @@ class AlleleCounter:
       if ra.type == REFERENCE:
         if not ra.low_quality:
           ac.ref_supporting_read_count += 1
-        continue
+        # a REFERENCE read allele exists only at candidate positions, and only when asked (:504-512)
+        if not (self.track_ref_reads and ra.position in self.candidate_offsets):
+          continue
       ac.read_alleles[key] = Allele(ra.bases, ra.type, 1, ra.low_quality)

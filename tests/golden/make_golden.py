@@ -269,7 +269,7 @@ def main_pacbio(n_keep=120):
       stats=np.array([len(examples_all), n_ref_ok, n_rows, n_match], np.int64))
 
 
-if __name__ == '__main__' and 'pacbio' in sys.argv[1:]:
+if __name__ == '__main__' and 'pacbio' in sys.argv[1:] and 'pacbio_full' not in sys.argv[1:]:
   main_pacbio()
 
 
@@ -411,3 +411,44 @@ def main_realigner():
 
 if __name__ == '__main__' and 'realigner' in sys.argv[1:]:
   main_realigner()
+
+
+# ---------------------------------------------------------------------------
+# PacBio golden, whole chain (BASELINE.json configs[3] shape; make_examples_test.py:794-818)
+#   pacbio_full_chr20.npz:
+#     reads (golden_io)       the 281 HiFi reads make_examples reads for chr20:9,000,000-9,100,000
+#                             (min_mapping_quality 1, default read filter), UNCLIPPED
+#     ref_bases / ref_start   chr20:8,984,001-9,115,000 of grch38.chr20_and_21_10M.fa.gz
+#     g_images                golden.pacbio_examples.tfrecord.gz, all 401 x [100,147,10]
+#     g_meta                  per example: start, end, reference_bases, alternate_bases, alt_allele_indices
+# ---------------------------------------------------------------------------
+def main_pacbio_full():
+  fasta = genomics_io.FastaReader(os.path.join(REF, 'input/grch38.chr20_and_21_10M.fa.gz'))
+  _, reads = genomics_io.read_bam(
+      os.path.join(REF, 'input/test_pacbio.chr20_100kbp_at_9mb.bam'), 'chr20', 8_999_999, 9_100_000)
+  reads = [r for r in reads if not (r.duplicate_fragment or r.failed_vendor_quality_checks or
+                                    r.secondary_alignment or r.supplementary_alignment)
+           and r.alignment.mapping_quality >= 1]
+  for r in reads:
+    r.info.pop('HP', None)
+  images, meta = [], []
+  for rec in tfrecord.read_tfrecords(os.path.join(REF, 'golden.pacbio_examples.tfrecord.gz'), verify_crc=True):
+    ex = pw.decode_example(rec)
+    v = pw.decode_variant(ex['variant/encoded'][0])
+    idx = pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0])
+    images.append(np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(ex['image/shape']))
+    meta.append('\t'.join([str(v.start), str(v.end), v.reference_bases, ','.join(v.alternate_bases),
+                           ','.join(str(i) for i in idx)]))
+  ref_start, ref_end = 8_984_000, 9_115_000
+  d = golden_io.pack_reads(reads)
+  d['ref_bases'] = np.frombuffer(fasta.get_bases('chr20', ref_start, ref_end).encode(), np.uint8)
+  d['ref_start'] = np.array([ref_start], np.int64)
+  d['n_contig_bases'] = np.array([fasta.n_bases('chr20')], np.int64)
+  d['g_images'] = np.stack(images)
+  d['g_meta'] = np.frombuffer('\n'.join(meta).encode(), np.uint8)
+  print(len(reads), 'reads', len(images), 'images', d['g_images'].shape)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/pacbio_full_chr20.npz'), **d)
+
+
+if __name__ == '__main__' and 'pacbio_full' in sys.argv[1:]:
+  main_pacbio_full()

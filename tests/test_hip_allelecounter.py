@@ -118,6 +118,49 @@ def test_fuzz_against_the_oracle(seed, long_reads, legacy):
     assert n_alleles > 150 and sum(c.ref_supporting_read_count for c in oracle.counts) > 400
 
 
+@pytest.mark.parametrize('seed,long_reads,legacy', [(11, False, False), (12, True, False), (13, False, True)])
+def test_track_ref_reads_against_the_oracle(seed, long_reads, legacy):
+  """track_ref_reads with candidate positions (allelecounter.cc:504-512, the second pass of
+  make_examples_core.py:2880-2932): at the marked positions reference-supporting reads are kept
+  by name as REFERENCE read alleles -- including low-quality ones -- and nowhere else; the
+  synthetic reference allele disappears from the sums."""
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=4000))
+  ref = _Ref(seq[:1500] + 'N' + seq[1501:])
+  start, end = 1000, 2000
+  reads = _fuzz_reads(rng, ref, 600 if not long_reads else 150, 700, 2100, long_reads)
+  candidates = sorted(set(int(p) for p in rng.integers(start - 20, end + 20, size=160)))   # some outside
+  kw = dict(min_mapping_quality=10, min_base_quality=20, keep_legacy_behavior=legacy, track_ref_reads=True,
+            candidate_positions=candidates)
+  counter = A.AlleleCounter(ref, 'c', start, end, **kw)
+  oracle = R.AlleleCounter(ref, 'c', start, end, **kw)
+  for r in reads:
+    counter.add(r)
+    oracle.add(r)
+  _compare(counter.counts(), oracle)
+  marked = {p - start for p in candidates}
+  n_ref = n_low = 0
+  for i, c in enumerate(counter.counts()):
+    refs = [a for a in c.read_alleles.values() if a.type == A.REFERENCE]
+    assert not refs or i in marked
+    n_ref += len(refs)
+    n_low += sum(a.is_low_quality for a in refs)
+    assert all(a.bases == c.ref_base for a in refs)
+    assert all(a.type != A.REFERENCE or a.count == len(refs) for a in A.sum_allele_counts(c))   # no synthetic one
+    assert A.total_allele_counts(c) == c.ref_supporting_read_count + sum(
+        1 for a in c.read_alleles.values() if a.type != A.REFERENCE and not a.is_low_quality)
+  assert n_ref > 1000 and (legacy or n_low > 50)
+  # without candidate positions nothing is kept by name, the counts are the same
+  plain = A.AlleleCounter(ref, 'c', start, end, min_mapping_quality=10, min_base_quality=20,
+                          keep_legacy_behavior=legacy, track_ref_reads=True)
+  for r in reads:
+    plain.add(r)
+  for a, b in zip(plain.counts(), counter.counts()):
+    assert a.ref_supporting_read_count == b.ref_supporting_read_count
+    assert {k: v.bases for k, v in a.read_alleles.items()} == {
+        k: v.bases for k, v in b.read_alleles.items() if v.type != A.REFERENCE}
+
+
 def test_full_range_form():
   """The constructor with full_range (allelecounter.cc:349-369): bases are valid over the
   wider reads interval, counts are reported for the inner interval only."""

@@ -88,3 +88,40 @@ def test_golden_illumina_chain_on_device():
   for ex in examples:
     key = (ex['call'].variant.start, tuple(ex['alt_alleles']))
     assert np.array_equal(images[key], ex['image']), key
+
+
+def test_golden_pacbio_chain_on_device():
+  """BASELINE.json configs[3] shape end to end through make_examples_core.RegionProcessor with
+  the golden's flags (make_examples_test.py:794-818): raw HiFi reads -> dv_count_alleles twice
+  (track_ref_reads) -> candidate caller -> dv_phase_reads -> HP tags -> window-trimmed reads,
+  alt haplotypes, FastPassAligner, dv_encode_batch with the diff-channel merge.  All 341
+  golden variants and all 401 golden [100, 147, 10] images, bit for bit, no oracle in the loop."""
+  from deepvariant_amd import make_examples_core as mec
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd.realigner import utils as U
+  from tests import pacbio_chain as PC
+  ref, reads, meta, golden = PC.load()
+  options = T.MakeExamplesOptions(pic_options=PC.pic_options(True), trim_reads_for_pileup=True,
+                                  sample_options=[T.SampleOptions(role='main', name='s', pileup_height=100)])
+  po = mec.RegionProcessorOptions(realigner_enabled=False, vsc_min_fraction_indels=0.12, track_ref_reads=True,
+                                  phase_reads=True, partition_size=PC.PARTITION)
+  proc = mec.RegionProcessor(options, ref, po)
+  spans = [U.read_range(r) for r in reads]
+  images, variants = {}, set()
+  for region in mec.partition(PC.REGION, po.partition_size):
+    in_reads = [r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]
+    candidates, encoded = proc.examples_in_region(region, in_reads)
+    for c in candidates:
+      v = c.variant
+      variants.add((v.start, v.end, v.reference_bases, tuple(v.alternate_bases)))
+    for blob in encoded:
+      ex = pw.decode_example(blob)
+      v = pw.decode_variant(ex['variant/encoded'][0])
+      idx = tuple(pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+      assert ex['image/shape'] == [100, 147, 10]
+      images[(v.start, tuple(v.alternate_bases), idx)] = np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(100, 147, 10)
+  assert all('HP' not in r.info for r in reads)              # the caller's reads are left alone
+  assert variants == {m[:4] for m in meta} and len(variants) == 341
+  assert len(images) == len(meta) == 401
+  for k, (start, end, refb, alts, idx) in enumerate(meta):
+    assert np.array_equal(images[(start, alts, idx)], golden[k]), (k, start, alts, idx)

@@ -328,3 +328,97 @@ def test_golden_illumina_chain_with_realigner():
     return O.build_pileup(opts, ex['call'], ex['ref_window'], reads, image_start, ex['alt_alleles'])
 
   check_golden_chain(*run_golden_chain(make_counter, RF.OracleAlleleCounter, build_image))
+
+
+# ---------------------------------------------------------------------------
+# The long-read chain behind golden.pacbio_examples (BASELINE.json configs[3] shape;
+# make_examples_test.py:794-818: realigner off, 25 kb calling regions, track_ref_reads,
+# phase_reads with 20 % region padding, sort_by_haplotypes, trim_reads_for_pileup,
+# alt_aligned_pileup=diff_channels, vsc_min_fraction_indels 0.12):
+#   raw HiFi reads -> allele counts (two passes) -> candidate caller -> DirectPhasing -> HP tags ->
+#   trimmed reads, alt haplotypes, realigned reads -> [100, 147, 10] images.
+# Product code on this leg: candidate caller, read phasing (native), trimming / haplotypes /
+# FastPassAligner, image layout.  Oracle code: allele counts and the encoder.  Result: the 341
+# golden variants exactly, and every one of the 401 golden images bit-exact in all 10 channels.
+# tests/test_hip_realigner.py runs it with the device counter and encoder.  CPU time: the
+# oracle counter walks 4 M bases twice in Python, so this leg draws every 3rd image.
+# ---------------------------------------------------------------------------
+def test_golden_pacbio_chain_with_phasing():
+  from deepvariant_amd import allelecounter as ac
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import direct_phasing
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import variant_calling as vc
+  from deepvariant_amd.realigner import utils as U
+  from oracle import allelecounter_ref as AR
+  from tests import pacbio_chain as PC
+  ref, reads, meta, images = PC.load()
+  pic = PC.pic_options(True)
+  enc = PC.pic_options(False)
+  hw = (pic.width - 1) // 2
+  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.12, sample_name='s'))
+  phaser = direct_phasing.DirectPhasing(1)
+  n_contig = ref.n_bases('chr20')
+
+  def counts(region, rs, positions=()):
+    counter = AR.AlleleCounter(ref, 'chr20', region.start, region.end, min_mapping_quality=1, min_base_quality=10,
+                               track_ref_reads=True, candidate_positions=positions)
+    for r in rs:
+      counter.add(r)
+    out = []
+    for c in counter.counts:
+      a = ac.AlleleCount('chr20', c.position, c.ref_base)
+      a.ref_supporting_read_count, a.track_ref_reads = c.ref_supporting_read_count, True
+      a.read_alleles = {k: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for k, v in c.read_alleles.items()}
+      out.append(a)
+    return out
+
+  spans = [U.read_range(r) for r in reads]
+  found, pools = {}, []
+  for start in range(PC.REGION.start, PC.REGION.end, PC.PARTITION):
+    region = T.Range('chr20', start, min(start + PC.PARTITION, PC.REGION.end))
+    padded = U.expand(region, int((region.end - region.start) * 20 / 100), n_contig)
+    rs = [golden_io_copy(r) for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]
+    positions = caller.call_positions_from_allele_counts(counts(padded, rs))
+    candidates = caller.calls_from_allele_counts(counts(padded, rs, positions))
+    for r, phase in zip(rs, phaser.phase(candidates, rs)):
+      r.info['HP'] = T.ListValue(values=[T.Value(int_value=phase)])
+    for c in candidates:
+      if region.start <= c.variant.start < region.end:
+        v = c.variant
+        found[(v.start, v.end, v.reference_bases, tuple(v.alternate_bases))] = (c, len(pools))
+    pools.append(rs)
+  assert set(found) == {m[:4] for m in meta} and len(found) == 341
+
+  n_alt = 0
+  for k in range(0, len(meta), 3):
+    start, end, refb, alts, idx = meta[k]
+    cand, pool = found[(start, end, refb, alts)]
+    v = cand.variant
+    combo = [alts[i] for i in idx]
+    window = men.get_reference_bases_for_pileup(ref, v, pic.width)
+    overlapping = [r for r in pools[pool] if O.read_overlaps(r, v.start - 5, v.end + 5)]
+    r0, r1 = A.calculate_alignment_region(v, hw, n_contig)
+    drawn, starts = A.trim_reads(overlapping, r0, r1)            # trim_reads_for_pileup: every candidate
+    want = O.build_pileup(enc, cand, window, drawn, v.start - hw, combo, pileup_height=100,
+                          alignment_positions=starts)
+    alt_images = [None, None]
+    if A.need_alt_alignment(pic, v):
+      for a, alt in enumerate(combo[:2]):
+        hap, h0, h1 = A.create_haplotype(ref, v, alt, hw)
+        realigned = fpa.realign_reads_to_haplotype(hap, drawn, 'chr20', h0, h1, ref, men.DEFAULT_ALN_CONFIG)
+        kept = [(r, s) for r, s in zip(realigned, starts) if r is not None]
+        alt_images[a] = O.build_pileup(enc, cand, hap[:pic.width], [r for r, _ in kept], v.start - hw, combo,
+                                       pileup_height=100, alignment_positions=[s for _, s in kept])
+        n_alt += 1
+    full = A.fill_pileup_array(want, alt_images, 'diff_channels', A.get_alt_image_row_indices('diff_channels', combo))
+    if full.shape[2] < 10:
+      full = np.concatenate([full, np.zeros(full.shape[:2] + (10 - full.shape[2],), np.uint8)], axis=2)
+    assert np.array_equal(full, images[k]), (k, start, combo)
+  assert n_alt > 40
+
+
+def golden_io_copy(read):
+  import dataclasses
+  return dataclasses.replace(read, info=dict(read.info))
