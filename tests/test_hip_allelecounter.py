@@ -146,10 +146,11 @@ def test_track_ref_reads_against_the_oracle(seed, long_reads, legacy):
     n_ref += len(refs)
     n_low += sum(a.is_low_quality for a in refs)
     assert all(a.bases == c.ref_base for a in refs)
-    assert all(a.type != A.REFERENCE or a.count == len(refs) for a in A.sum_allele_counts(c))   # no synthetic one
+    assert all(a.type != A.REFERENCE or a.count == sum(not r.is_low_quality for r in refs)
+               for a in A.sum_allele_counts(c))                                     # no synthetic one
     assert A.total_allele_counts(c) == c.ref_supporting_read_count + sum(
         1 for a in c.read_alleles.values() if a.type != A.REFERENCE and not a.is_low_quality)
-  assert n_ref > 1000 and (legacy or n_low > 50)
+  assert n_ref > 150 and (legacy or n_low > 50)
   # without candidate positions nothing is kept by name, the counts are the same
   plain = A.AlleleCounter(ref, 'c', start, end, min_mapping_quality=10, min_base_quality=20,
                           keep_legacy_behavior=legacy, track_ref_reads=True)
