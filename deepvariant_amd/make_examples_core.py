@@ -13,8 +13,9 @@ deepvariant/make_examples_core.py's RegionProcessor that joins the hot path's st
 Every stage below is this package's own: realigner/ (device allele counts for window
 selection, native assembly and alignment), allelecounter.AlleleCounter (device),
 variant_calling.VariantCaller (host), direct_phasing.DirectPhasing (native, host),
-make_examples_native.ExamplesGenerator (device encoder, optionally fused with the CNN).  File handling, sharding, labelling, gVCF and multi-sample
-plumbing of the reference's make_examples are outside SURVEY.md section 8.
+make_examples_native.ExamplesGenerator (device encoder, optionally fused with the CNN).  File
+handling, sharding, labelling, gVCF and multi-sample plumbing of the reference's make_examples are
+outside SURVEY.md section 8.
 """
 from __future__ import annotations
 
