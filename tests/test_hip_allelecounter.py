@@ -156,10 +156,13 @@ def test_track_ref_reads_against_the_oracle(seed, long_reads, legacy):
                           keep_legacy_behavior=legacy, track_ref_reads=True)
   for r in reads:
     plain.add(r)
-  for a, b in zip(plain.counts(), counter.counts()):
+  for i, (a, b) in enumerate(zip(plain.counts(), counter.counts())):
     assert a.ref_supporting_read_count == b.ref_supporting_read_count
-    assert {k: v.bases for k, v in a.read_alleles.items()} == {
-        k: v.bases for k, v in b.read_alleles.items() if v.type != A.REFERENCE}
+    kept = {k: v.bases for k, v in b.read_alleles.items() if v.type != A.REFERENCE}
+    if i in marked:      # a later read with a duplicate key may replace a substitution by its REFERENCE allele
+      assert kept.items() <= {k: v.bases for k, v in a.read_alleles.items()}.items()
+    else:
+      assert kept == {k: v.bases for k, v in a.read_alleles.items()}
 
 
 def test_full_range_form():
