@@ -23,6 +23,8 @@ from deepvariant_amd import dv_types as T
 from deepvariant_amd import packing
 
 REFERENCE, SUBSTITUTION, INSERTION, DELETION, SOFT_CLIP = 1, 2, 3, 4, 5   # AlleleType
+_EVENT_DTYPE = np.dtype([('position', '<i4'), ('read', '<u4'), ('read_offset', '<u4'), ('length', '<u2'),
+                         ('type', 'u1'), ('low_quality', 'u1')])        # dv_allele_event
 
 
 class Allele:
@@ -82,32 +84,60 @@ class AlleleCounter:
     self._reads: List = []
     self._table: Optional[packing.ReadTable] = None
     self._counts: Optional[List[AlleleCount]] = None
+    self._alleles: Optional[Dict[int, Dict[str, Allele]]] = None
     self._n_counted = 0
 
   # ---- the reference's interface
   def interval_length(self) -> int:
     return self._end - self._start
 
+  def interval_start(self) -> int:
+    return self._start
+
   def add(self, read, sample: str = ''):
     if self._table is not None:
       raise ValueError('reads were handed over as a packed table; add() cannot be mixed in')
     self._reads.append(read)
-    self._counts = None
+    self._counts = self._alleles = None
 
   def add_table(self, table: packing.ReadTable):
     """All reads of the region at once, already packed (packing.ReadTable.from_bam / from_reads)."""
     if self._reads:
       raise ValueError('add() was used; add_table() cannot be mixed in')
     self._table = table
-    self._counts = None
+    self._counts = self._alleles = None
+
+  def _ensure(self):
+    if self._alleles is None:
+      self._run()
+
+  def _count_at(self, i: int) -> AlleleCount:
+    c = AlleleCount(self._contig, self._start + i, self._interval_ref[i])
+    c.ref_supporting_read_count = int(self._ref_counts[i])
+    c.track_ref_reads = self._track_ref_reads
+    c.read_alleles = self._alleles.get(i, {})
+    return c
 
   def counts(self) -> List[AlleleCount]:
+    """Counts(): one AlleleCount per position of the interval."""
+    self._ensure()
     if self._counts is None:
-      self._run()
+      self._counts = [self._count_at(i) for i in range(len(self._ref_counts))]
     return self._counts
 
+  def counts_with_read_alleles(self) -> List[AlleleCount]:
+    """Only the positions some read left a non-reference (or tracked reference) allele at, in
+    order -- all a candidate caller or window selector has to look at: a position without read
+    alleles has no alternate allele to select."""
+    self._ensure()
+    return [self._count_at(i) for i in sorted(self._alleles)]
+
+  def ref_supporting_read_counts(self) -> np.ndarray:
+    self._ensure()
+    return self._ref_counts
+
   def n_counted_reads(self) -> int:
-    self.counts()
+    self._ensure()
     return self._n_counted
 
   def summary_counts(self, left_padding: int = 0, right_padding: int = 0):
@@ -146,27 +176,30 @@ class AlleleCounter:
       n_events, n_counted = C.c_uint32(), C.c_int32()
       length = lib.dv_allele_counts_arrays(handle, C.byref(refc), C.byref(events), C.byref(n_events),
                                            C.byref(n_counted))
-      counts = [AlleleCount(self._contig, self._start + i, interval_ref[i]) for i in range(length)]
-      for i in range(length):
-        counts[i].ref_supporting_read_count = int(refc[i])
-        counts[i].track_ref_reads = self._track_ref_reads
+      self._interval_ref = interval_ref
+      self._ref_counts = np.ctypeslib.as_array(refc, shape=(length,)).copy() if length else np.zeros(0, np.int32)
+      n_ev = int(n_events.value)
+      ev = (np.ctypeslib.as_array(C.cast(events, C.POINTER(C.c_uint8)), shape=(n_ev * 16,)).view(_EVENT_DTYPE).copy()
+            if n_ev else np.zeros(0, _EVENT_DTYPE))
       seq_off = table.read_seq_off
       bases = table.bases
-      for k in range(n_events.value):
-        ev = events[k]
-        s0 = int(seq_off[ev.read]) + ev.read_offset
-        if ev.type in (SUBSTITUTION, REFERENCE):
+      keys = table.keys
+      s0_all = seq_off[ev['read']].astype(np.int64) + ev['read_offset']
+      alleles: Dict[int, Dict[str, Allele]] = {}
+      for k, (position, read, read_offset, length_k, type_k, low) in enumerate(ev.tolist()):
+        s0 = int(s0_all[k])
+        if type_k == SUBSTITUTION or type_k == REFERENCE:
           text = chr(bases[s0])
         else:
-          anchor_pos = self._start + ev.position          # the base the indel is anchored on
-          prev = chr(bases[s0 - 1]) if ev.read_offset > 0 else window[anchor_pos - w0:anchor_pos - w0 + 1].decode()
-          if ev.type == DELETION:
-            text = prev + window[anchor_pos + 1 - w0:anchor_pos + 1 - w0 + ev.length].decode()
+          anchor = self._start + position - w0              # the base the indel is anchored on
+          prev = chr(bases[s0 - 1]) if read_offset > 0 else window[anchor:anchor + 1].decode()
+          if type_k == DELETION:
+            text = prev + window[anchor + 1:anchor + 1 + length_k].decode()
           else:
-            text = prev + bytes(bases[s0:s0 + ev.length]).decode()
+            text = prev + bytes(bases[s0:s0 + length_k]).decode()
         # a later read with the same key overwrites (read_alleles is a map keyed by ReadKey)
-        counts[ev.position].read_alleles[table.keys[ev.read]] = Allele(text, ev.type, 1, bool(ev.low_quality))
-      self._counts, self._n_counted = counts, int(n_counted.value)
+        alleles.setdefault(position, {})[keys[read]] = Allele(text, type_k, 1, bool(low))
+      self._alleles, self._counts, self._n_counted = alleles, None, int(n_counted.value)
     finally:
       lib.dv_allele_counts_free(handle)
 

@@ -26,6 +26,7 @@ from deepvariant_amd import allelecounter
 from deepvariant_amd import direct_phasing
 from deepvariant_amd import dv_types as T
 from deepvariant_amd import make_examples_native
+from deepvariant_amd import packing
 from deepvariant_amd import variant_calling
 from deepvariant_amd.realigner import realigner as realigner_module
 from deepvariant_amd.realigner import utils
@@ -95,7 +96,7 @@ class RegionProcessor:
     short_reads = [r for r in reads if len(r.aligned_sequence) <= limit]
     return long_reads + self.realigner.realign_reads(short_reads, region)[1]
 
-  def _allele_counter(self, region: T.Range, reads: Sequence, candidate_positions=()):
+  def _allele_counter(self, region: T.Range, table, candidate_positions=()):
     rr = self.options.pic_options.read_requirements
     counter = allelecounter.AlleleCounter(
         self.ref_reader, region.reference_name, region.start, region.end,
@@ -103,8 +104,7 @@ class RegionProcessor:
         min_base_quality=rr.min_base_quality,
         keep_legacy_behavior=self.processor_options.keep_legacy_allele_counter_behavior,
         track_ref_reads=self.processor_options.track_ref_reads)
-    for read in reads:
-      counter.add(read, self.options.sample_options[0].name)
+    counter.add_table(table)        # the region's reads are packed once for both passes
     return counter
 
   def candidates_in_region(self, region: T.Range, reads: Sequence,
@@ -118,11 +118,12 @@ class RegionProcessor:
     if not in_region:
       return []
     effective = padded_region or region
+    table = packing.ReadTable.from_reads(in_region)
     positions = ()
     if po.track_ref_reads:
-      first_pass = self._allele_counter(effective, in_region)
-      positions = self.variant_caller.call_positions_from_allele_counts(first_pass.counts())
-    candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(effective, in_region, positions))
+      first_pass = self._allele_counter(effective, table)
+      positions = self.variant_caller.call_positions_from_allele_counter(first_pass)
+    candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(effective, table, positions))
     if self.direct_phasing is not None:
       to_phase = [r for r in in_region if utils.ranges_overlap(utils.read_range(r), effective)]
       for read in to_phase:

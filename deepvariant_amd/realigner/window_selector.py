@@ -81,13 +81,30 @@ def _allele_filter(allele, total_count: int, config: WindowSelectorOptions) -> b
   return True
 
 
+def _positions_with_read_alleles(allele_counter):
+  """(offset in the interval, AlleleCount) for the positions that carry read alleles; the others
+  add nothing to either model beyond their reference count."""
+  sparse = getattr(allele_counter, 'counts_with_read_alleles', None)
+  if sparse is None:
+    return [(i, ac) for i, ac in enumerate(allele_counter.counts()) if ac.read_alleles]
+  counts = sparse()
+  if not counts:
+    return []
+  start = allele_counter.interval_start()
+  return [(ac.position.position - start, ac) for ac in counts]
+
+
+def _ref_supporting_read_counts(allele_counter) -> np.ndarray:
+  dense = getattr(allele_counter, 'ref_supporting_read_counts', None)
+  if dense is not None:
+    return np.asarray(dense())
+  return np.array([ac.ref_supporting_read_count for ac in allele_counter.counts()], np.int64)
+
+
 def variant_reads_candidates_from_allele_counter(allele_counter, config: WindowSelectorOptions) -> List[int]:
   """VariantReadsWindowSelectorCandidates (:101-141)."""
-  counts = allele_counter.counts()
-  window_counts = np.zeros(len(counts), np.int64)
-  for i, ac in enumerate(counts):
-    if not ac.read_alleles:
-      continue
+  window_counts = np.zeros(allele_counter.interval_length(), np.int64)
+  for i, ac in _positions_with_read_alleles(allele_counter):
     total = allelecounter.total_allele_counts(ac)
     for allele in allelecounter.sum_allele_counts(ac):
       if not _allele_filter(allele, total, config):
@@ -107,15 +124,14 @@ def variant_reads_candidates_from_allele_counter(allele_counter, config: WindowS
 def allele_count_linear_candidates_from_allele_counter(allele_counter, model: AlleleCountLinearModel):
   """AlleleCountLinearWindowSelectorCandidates (:143-207); float32 like the reference."""
   f32 = np.float32
-  counts = allele_counter.counts()
-  scores = np.full(len(counts), f32(model.bias), np.float32)
+  scores = np.full(allele_counter.interval_length(), f32(model.bias), np.float32)
+  scores += _ref_supporting_read_counts(allele_counter).astype(np.float32) * f32(model.coeff_reference)
   coeff = {allelecounter.SUBSTITUTION: f32(model.coeff_substitution),
            allelecounter.SOFT_CLIP: f32(model.coeff_soft_clip),
            allelecounter.INSERTION: f32(model.coeff_insertion),
            allelecounter.DELETION: f32(model.coeff_deletion),
            allelecounter.REFERENCE: f32(model.coeff_reference)}
-  for i, ac in enumerate(counts):
-    _update_counts(f32(ac.ref_supporting_read_count) * f32(model.coeff_reference), i, i + 1, scores)
+  for i, ac in _positions_with_read_alleles(allele_counter):
     for allele in ac.read_alleles.values():
       n = len(allele.bases)
       by = f32(allele.count) * coeff[allele.type]

@@ -93,6 +93,12 @@ def _simplify_ref_alt(ref: str, alt: str) -> str:
   return '%s->%s' % (ref[:len(ref) - n], alt[:len(alt) - n])
 
 
+def _worth_looking_at(allele_counter):
+  """The AlleleCounts a caller has to visit: without read alleles there is no alternate allele."""
+  sparse = getattr(allele_counter, 'counts_with_read_alleles', None)
+  return sparse() if sparse is not None else allele_counter.counts()
+
+
 class VariantCaller:
   def __init__(self, options: VariantCallerOptions):
     for name in ('min_count_snps', 'min_count_indels', 'min_fraction_snps', 'min_fraction_indels',
@@ -150,7 +156,10 @@ class VariantCaller:
     return out
 
   def calls_from_allele_counter(self, allele_counter) -> List[T.DeepVariantCall]:
-    return self.calls_from_allele_counts(allele_counter.counts())
+    return self.calls_from_allele_counts(_worth_looking_at(allele_counter))
+
+  def call_positions_from_allele_counter(self, allele_counter) -> List[int]:
+    return self.call_positions_from_allele_counts(_worth_looking_at(allele_counter))
 
   def call_positions_from_allele_counts(self, allele_counts: Sequence) -> List[int]:
     """CallPositionsFromAlleleCounts / CallVariantPosition (variant_calling_multisample.cc:940-1004):

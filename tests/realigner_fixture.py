@@ -74,6 +74,9 @@ class OracleAlleleCounter:
   def add(self, read, sample=''):
     self._c.add(read)
 
+  def interval_length(self):
+    return len(self._c.counts)
+
   def counts(self):
     out = []
     for c in self._c.counts:
