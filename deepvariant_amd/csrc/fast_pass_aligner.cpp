@@ -297,19 +297,34 @@ void FastPassAligner::local_align_reads_to_haplotypes(int score_threshold) {   /
     targets.push_back(&ha);
     coded.push_back(encode_sequence(haplotypes_[ha.haplotype_index]));
   }
-  std::vector<const CodedSequence*> refs;
-  for (const CodedSequence& c : coded) refs.push_back(&c);
-  std::vector<LocalAlignment> results;
-  std::vector<char> ok;
+  // every (unplaced read, haplotype) pair goes through the aligner in one batch call: its SIMD
+  // lanes take 16 pairs at a time whatever read or haplotype they belong to
+  std::vector<size_t> unplaced;
+  std::vector<CodedSequence> coded_reads;
   for (size_t r = 0; r < reads_.size(); ++r) {
     bool aligned = false;
     for (const HaplotypeAlignment& ha : alignments_) aligned = aligned || ha.reads[r].score > 0;
     if (aligned || targets.empty()) continue;
-    aligner_->align_to_many(refs, reads_[r], &results, &ok);
+    unplaced.push_back(r);
+    coded_reads.push_back(encode_sequence(reads_[r]));
+  }
+  std::vector<const CodedSequence*> refs, queries;
+  for (size_t u = 0; u < unplaced.size(); ++u) {
+    for (const CodedSequence& c : coded) {
+      refs.push_back(&c);
+      queries.push_back(&coded_reads[u]);
+    }
+  }
+  std::vector<LocalAlignment> results;
+  std::vector<char> ok;
+  aligner_->align_pairs(refs, queries, &results, &ok);
+  for (size_t u = 0; u < unplaced.size(); ++u) {
+    const size_t r = unplaced[u];
     for (size_t t = 0; t < targets.size(); ++t) {
       HaplotypeAlignment& ha = *targets[t];
-      const LocalAlignment& al = results[t];
-      if (!ok[t] || al.score <= 0) continue;
+      const size_t k = u * targets.size() + t;
+      const LocalAlignment& al = results[k];
+      if (!ok[k] || al.score <= 0) continue;
       if (al.score >= threshold || (force_alignment_ && ha.is_reference)) {
         ha.reads[r].score = al.score;
         ha.reads[r].cigar = al.cigar;
