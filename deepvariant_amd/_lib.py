@@ -287,8 +287,8 @@ def lib():
     l.dv_merge_cigar_op.argtypes = [C.c_void_p, C.c_int32, C.c_char, C.c_int32, C.c_int32]
     l.dv_local_align.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int32] * 4 + [C.c_void_p]
     l.dv_local_align_many.argtypes = [C.c_char_p, C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
-    l.dv_debruijn_build.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p,
-                                                                                  C.c_int32, C.c_void_p, C.c_void_p]
+    l.dv_debruijn_build.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     l.dv_debruijn_destroy.argtypes = [C.c_void_p]
     l.dv_debruijn_destroy.restype = None
     l.dv_debruijn_kmer_size.argtypes = [C.c_void_p]

@@ -266,13 +266,13 @@ int dv_local_align_many(const char* reference, int32_t n, const char* const* que
 
 // ---- local assembly (debruijn_graph.cpp)
 
-int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals,
+int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals, int64_t n_bases,
                       const uint32_t* read_seq_off, const uint8_t* read_mapq, int32_t n_table_reads,
                       const int32_t* reads, int32_t n_reads, const dv_debruijn_options* o,
                       dv_debruijn_graph** out) {
   if (!out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_build: null out");
   *out = nullptr;
-  if (!ref || ref_len < 0 || !o || n_reads < 0 || n_table_reads < 0 ||
+  if (!ref || ref_len < 0 || !o || n_reads < 0 || n_table_reads < 0 || n_bases < 0 ||
       (n_reads > 0 && (!bases || !quals || !read_seq_off || !read_mapq || !reads))) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_debruijn_build: null argument");
   }
@@ -283,8 +283,8 @@ int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, co
   rs.reserve(n_reads);
   for (int32_t i = 0; i < n_reads; ++i) {
     const int32_t r = reads[i];
-    if (r < 0 || r >= n_table_reads || read_seq_off[r + 1] < read_seq_off[r]) {
-      return dv::fail(DV_ERR_BAD_INPUT, "dv_debruijn_build: read index outside the table");
+    if (r < 0 || r >= n_table_reads || read_seq_off[r + 1] < read_seq_off[r] || read_seq_off[r + 1] > n_bases) {
+      return dv::fail(DV_ERR_BAD_INPUT, "dv_debruijn_build: read index or its bases outside the table");
     }
     const uint32_t a = read_seq_off[r], b = read_seq_off[r + 1];
     rs.push_back(dv::AssemblyRead{std::string_view(reinterpret_cast<const char*>(bases) + a, b - a), quals + a,

@@ -66,7 +66,7 @@ def build_from_table(ref: str, table: packing.ReadTable, read_indices: Sequence[
   raw = ref.encode()
   handle = C.c_void_p()
   _lib.check(_lib.lib().dv_debruijn_build(
-      raw, len(raw), bases.ctypes.data, quals.ctypes.data, seq_off.ctypes.data, mapq.ctypes.data,
+      raw, len(raw), bases.ctypes.data, quals.ctypes.data, len(bases), seq_off.ctypes.data, mapq.ctypes.data,
       table.n_reads, idx.ctypes.data, len(idx), C.byref(opt), C.byref(handle)))
   return DeBruijnGraph(handle) if handle.value else None
 

@@ -451,7 +451,7 @@ typedef struct dv_debruijn_options {
 } dv_debruijn_options;
 
 /* *out = NULL (and DV_OK) when no k gives an acyclic graph: debruijn_graph.build() -> None. */
-int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals,
+int dv_debruijn_build(const char* ref, int64_t ref_len, const uint8_t* bases, const uint8_t* quals, int64_t n_bases,
                       const uint32_t* read_seq_off, const uint8_t* read_mapq, int32_t n_table_reads,
                       const int32_t* reads, int32_t n_reads, const dv_debruijn_options* options,
                       dv_debruijn_graph** out);
