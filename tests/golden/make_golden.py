@@ -129,7 +129,7 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner')) for a in sys.argv[1:]):
+if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner', 'illumina_alt')) for a in sys.argv[1:]):
   main()
 
 
@@ -452,3 +452,32 @@ def main_pacbio_full():
 
 if __name__ == '__main__' and 'pacbio_full' in sys.argv[1:]:
   main_pacbio_full()
+
+
+# ---------------------------------------------------------------------------
+# Illumina goldens with alt-aligned pileups (make_examples_test.py:736-792: training mode, 6 default
+# channels, realigner on, alt_aligned_pileup = rows | diff_channels, types_to_alt_align = indels)
+#   illumina_alt_aligned_chr20.npz: per mode the 49 labelled examples of
+#   golden.alt_aligned_pileup_{rows,diff_channels}_examples.tfrecord.gz -- images, variants, alt indices.
+#   Their inputs are the `wgs` reads / reference of realigner_chr20.npz.
+# ---------------------------------------------------------------------------
+def main_illumina_alt():
+  d = {}
+  for mode in ('rows', 'diff_channels'):
+    images, meta = [], []
+    for rec in tfrecord.read_tfrecords(
+        os.path.join(REF, 'golden.alt_aligned_pileup_%s_examples.tfrecord.gz' % mode), verify_crc=True):
+      ex = pw.decode_example(rec)
+      v = pw.decode_variant(ex['variant/encoded'][0])
+      idx = pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0])
+      images.append(np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(ex['image/shape']))
+      meta.append('\t'.join([str(v.start), str(v.end), v.reference_bases, ','.join(v.alternate_bases),
+                             ','.join(str(i) for i in idx)]))
+    d[mode + '_images'] = np.stack(images)
+    d[mode + '_meta'] = np.frombuffer('\n'.join(meta).encode(), np.uint8)
+    print(mode, d[mode + '_images'].shape)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/illumina_alt_aligned_chr20.npz'), **d)
+
+
+if __name__ == '__main__' and 'illumina_alt' in sys.argv[1:]:
+  main_illumina_alt()

@@ -125,3 +125,34 @@ def test_golden_pacbio_chain_on_device():
   assert len(images) == len(meta) == 401
   for k, (start, end, refb, alts, idx) in enumerate(meta):
     assert np.array_equal(images[(start, alts, idx)], golden[k]), (k, start, alts, idx)
+
+
+@pytest.mark.parametrize('mode,shape', [('rows', [300, 221, 6]), ('diff_channels', [100, 221, 8])])
+def test_golden_illumina_alt_aligned_on_device(mode, shape):
+  """golden.alt_aligned_pileup_{rows,diff_channels}_examples (make_examples_test.py:736-792) through
+  RegionProcessor: realigner, device counts, caller, alt-aligned images in the same encoder
+  launch (rows in place / diff channels merged on the host).  The 49 labelled examples of each
+  golden file are a subset of what calling mode emits; each must be identical."""
+  from deepvariant_amd import make_examples_core as mec
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd.realigner import utils as U
+  from tests import test_oracle_golden as G
+  ref, sets = RF.load()
+  meta, golden = G.load_alt_goldens(mode)
+  options = T.MakeExamplesOptions(pic_options=G.alt_pic_options(mode, True),
+                                  sample_options=[T.SampleOptions(role='main', name='NA12878', pileup_height=100)])
+  proc = mec.RegionProcessor(options, ref)
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  images = {}
+  for region in mec.partition(T.Range('chr20', 9_999_999, 10_010_000), 1000):
+    _, encoded = proc.examples_in_region(region, [r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)])
+    for blob in encoded:
+      ex = pw.decode_example(blob)
+      assert ex['image/shape'] == shape
+      v = pw.decode_variant(ex['variant/encoded'][0])
+      idx = tuple(pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+      images[(v.start, tuple(v.alternate_bases), idx)] = np.frombuffer(ex['image/encoded'][0], np.uint8).reshape(shape)
+  assert len(images) == 84
+  for k, (start, end, refb, alts, idx) in enumerate(meta):
+    assert np.array_equal(images[(start, alts, idx)], golden[k]), (mode, k, start)

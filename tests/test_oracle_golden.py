@@ -422,3 +422,105 @@ def test_golden_pacbio_chain_with_phasing():
 def golden_io_copy(read):
   import dataclasses
   return dataclasses.replace(read, info=dict(read.info))
+
+
+# ---------------------------------------------------------------------------
+# The Illumina goldens with alt-aligned pileups (make_examples_test.py:736-792): the same region,
+# reads and realigner as golden.calling_examples, six default channels, alt_aligned_pileup = rows
+# ([300, 221, 6]) or diff_channels ([100, 221, 8]), indel candidates realigned to their alt
+# haplotypes.  The golden files hold the 49 examples the training mode could label; every one of
+# them must come out bit-exact (the labels themselves are the truth-VCF labeler's, out of scope).
+# ---------------------------------------------------------------------------
+ALT_FIXTURE = os.path.join(os.path.dirname(__file__), 'golden', 'illumina_alt_aligned_chr20.npz')
+
+
+def load_alt_goldens(mode):
+  with np.load(ALT_FIXTURE) as f:
+    images = f[mode + '_images']
+    lines = bytes(f[mode + '_meta']).decode().split('\n')
+  meta = []
+  for line in lines:
+    start, end, ref, alts, idx = line.split('\t')
+    meta.append((int(start), int(end), ref, tuple(alts.split(',')), tuple(int(i) for i in idx.split(','))))
+  return meta, images
+
+
+def alt_pic_options(mode, with_alt):
+  rr = T.ReadRequirements(min_mapping_quality=5, min_base_quality=10, min_base_quality_mode=1)
+  o = T.default_options(rr)
+  extra = ['diff_channels_alternate_allele_1', 'diff_channels_alternate_allele_2'] if mode == 'diff_channels' else []
+  o.channels = list(T.PILEUP_DEFAULT_CHANNELS) + (extra if with_alt else [])
+  o.num_channels = len(o.channels)
+  if with_alt:
+    o.alt_aligned_pileup = mode
+    o.types_to_alt_align = 'indels'
+  return o
+
+
+@pytest.mark.parametrize('mode', ['rows', 'diff_channels'])
+def test_golden_illumina_alt_aligned_chain(mode):
+  from deepvariant_amd import allelecounter as ac
+  from deepvariant_amd import alt_aligned_pileup_lib as A
+  from deepvariant_amd import fast_pass_aligner as fpa
+  from deepvariant_amd import make_examples_native as men
+  from deepvariant_amd import variant_calling as vc
+  from deepvariant_amd.realigner import realigner as R
+  from deepvariant_amd.realigner import utils as U
+  from oracle import allelecounter_ref as AR
+  from tests import realigner_fixture as RF
+  ref, sets = RF.load()
+  meta, images = load_alt_goldens(mode)
+  pic, enc = alt_pic_options(mode, True), alt_pic_options(mode, False)
+  hw = (pic.width - 1) // 2
+  n_contig = ref.n_bases('chr20')
+  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=RF.OracleAlleleCounter)
+  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.06))
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  wanted_regions = sorted({(m[0] - 9_999_999) // 1000 for m in meta})
+  found = {}
+  for k in wanted_regions:
+    region = T.Range('chr20', 9_999_999 + 1000 * k, min(9_999_999 + 1000 * (k + 1), 10_010_000))
+    _, realigned = rl.realign_reads([r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)], region)
+    counter = AR.AlleleCounter(ref, 'chr20', region.start, region.end, min_mapping_quality=5, min_base_quality=10)
+    for r in realigned:
+      if U.ranges_overlap(U.read_range(r), region):
+        counter.add(r)
+    for c in counter.counts:
+      if not c.read_alleles:
+        continue
+      a = ac.AlleleCount('chr20', c.position, c.ref_base)
+      a.ref_supporting_read_count = c.ref_supporting_read_count
+      a.read_alleles = {n: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for n, v in c.read_alleles.items()}
+      call = caller.call_variant(a)
+      if call is not None:
+        v = call.variant
+        found[(v.start, v.end, v.reference_bases, tuple(v.alternate_bases))] = (call, realigned)
+  n_alt_images = 0
+  for k, (start, end, refb, alts, idx) in enumerate(meta):
+    cand, pool = found[(start, end, refb, alts)]
+    v = cand.variant
+    combo = [alts[i] for i in idx]
+    window = men.get_reference_bases_for_pileup(ref, v, pic.width)
+    overlapping = [r for r in pool if O.read_overlaps(r, v.start - 5, v.end + 5)]
+    needs_alt = A.need_alt_alignment(pic, v)
+    if needs_alt:
+      r0, r1 = A.calculate_alignment_region(v, hw, n_contig)
+      drawn, starts = A.trim_reads(overlapping, r0, r1)
+    else:
+      drawn, starts = overlapping, None
+    want = O.build_pileup(enc, cand, window, drawn, v.start - hw, combo, pileup_height=100, alignment_positions=starts)
+    alt_images = [None, None]
+    if needs_alt:
+      for a, alt in enumerate(combo[:2]):
+        hap, h0, h1 = A.create_haplotype(ref, v, alt, hw)
+        realigned = fpa.realign_reads_to_haplotype(hap, drawn, 'chr20', h0, h1, ref, men.DEFAULT_ALN_CONFIG)
+        kept = [(r, s) for r, s in zip(realigned, starts) if r is not None]
+        alt_images[a] = O.build_pileup(enc, cand, hap[:pic.width], [r for r, _ in kept], v.start - hw, combo,
+                                       pileup_height=100, alignment_positions=[s for _, s in kept])
+        n_alt_images += 1
+    full = A.fill_pileup_array(want, alt_images, mode, A.get_alt_image_row_indices(mode, combo))
+    if full.shape[2] < images.shape[3]:
+      full = np.concatenate([full, np.zeros(full.shape[:2] + (images.shape[3] - full.shape[2],), np.uint8)], axis=2)
+    assert full.shape == images[k].shape and np.array_equal(full, images[k]), (mode, k, start, combo)
+  assert len(meta) == 49 and n_alt_images >= 4      # the labelled set has few indels
