@@ -986,12 +986,13 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   a.n_channels = enc->konst.n_channels;
   a.row_buf_bytes = static_cast<int>((row_bytes + 16 + 15) & ~size_t(15));
 
-  size_t out_bytes = 0;
+  size_t out_bytes = 0, covered_bytes = 0;
   if (b->memory == DV_MEM_HOST) {
     // Validate what the reference would LOG(FATAL)/CHECK on, then stage.
     if (int rc = dv_validate_batch(b, enc->opt.reference_band_height)) return rc;
     for (int i = 0; i < b->n_items; ++i) {
       out_bytes = std::max<size_t>(out_bytes, b->item_out_off[i] + b->item_height[i] * row_bytes);
+      covered_bytes += b->item_height[i] * row_bytes;
     }
     size_t s = 0;
     const size_t nr = b->n_reads, ni = b->n_items;
@@ -1055,6 +1056,10 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     }
     if (int rc = enc->d_out.reserve(out_bytes)) return rc;
     d_out = static_cast<uint8_t*>(enc->d_out.ptr);
+    // The staging buffer is reused between calls and comes back whole: where the items leave
+    // gaps (the row blocks of alt images a candidate does not have) it must read as zero, not
+    // as the previous call's pixels.
+    if (covered_bytes < out_bytes) DV_HIP_CHECK(hipMemsetAsync(d_out, 0, out_bytes, stream));
     if (out_rows) {
       if (int rc = enc->d_rows.reserve(sizeof(int32_t) * b->n_items)) return rc;
       d_rows = static_cast<int32_t*>(enc->d_rows.ptr);
