@@ -45,6 +45,44 @@ def _bgzf_blocks(path: str) -> Iterator[bytes]:
     pos += bsize
 
 
+def bam_contig_names(path: str) -> List[str]:
+  """The @SQ names of a BAM header, inflating only the blocks the header spans."""
+  buf = b''
+  need = 12
+  names: List[str] = []
+  for block in _bgzf_blocks(path):
+    buf += block
+    while True:
+      if len(buf) < need:
+        break
+      if buf[:4] != b'BAM\x01':
+        raise IOError('bad BAM magic')
+      l_text = struct.unpack_from('<i', buf, 4)[0]
+      pos = 8 + l_text
+      if len(buf) < pos + 4:
+        need = pos + 4
+        break
+      n_ref = struct.unpack_from('<i', buf, pos)[0]
+      pos += 4
+      names = []
+      complete = True
+      for _ in range(n_ref):
+        if len(buf) < pos + 4:
+          complete = False
+          break
+        l_name = struct.unpack_from('<i', buf, pos)[0]
+        if len(buf) < pos + 4 + l_name + 4:
+          complete = False
+          break
+        names.append(buf[pos + 4:pos + 4 + l_name - 1].decode())
+        pos += 4 + l_name + 4
+      if complete:
+        return names
+      need = len(buf) + 1
+      break
+  raise IOError('truncated BAM header: %s' % path)
+
+
 def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
              end: int = 1 << 62) -> Tuple[List[str], List[T.Read]]:
   """Reads a whole (small) BAM; returns (contig names, reads overlapping)."""
@@ -201,3 +239,81 @@ def read_satisfies_requirements(read, min_mapping_quality: int = 0,
   if not properly_placed and not keep_improperly_placed:
     return False
   return read.alignment.mapping_quality >= min_mapping_quality
+
+
+# ---------------------------------------------------------------- writers (tests, diagnostics)
+_NT16_CODE = {c: i for i, c in enumerate(_SEQ_NT16)}
+
+
+def _bgzf_block(payload: bytes) -> bytes:
+  comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+  cdata = comp.compress(payload) + comp.flush()
+  bsize = len(cdata) + 25
+  return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', bsize) + cdata +
+          struct.pack('<II', zlib.crc32(payload) & 0xffffffff, len(payload)))
+
+
+def write_bam(path: str, contigs, reads, sample_name: str = 'sample') -> None:
+  """A coordinate-sorted BAM from Read objects (what SamWriter does for the realigner's
+  emit_realigned_reads diagnostics, realigner.py:486-497; also the test fixtures' way back to a
+  file).  `contigs`: [(name, n_bases)].  Flags are rebuilt from the Read fields this package
+  keeps; an integer HP tag is written back."""
+  text = '@HD\tVN:1.6\tSO:coordinate\n' + ''.join('@SQ\tSN:%s\tLN:%d\n' % c for c in contigs)
+  text += '@RG\tID:rg\tSM:%s\n' % sample_name
+  header = b'BAM\x01' + struct.pack('<i', len(text)) + text.encode() + struct.pack('<i', len(contigs))
+  ref_id = {}
+  for i, (name, n) in enumerate(contigs):
+    ref_id[name] = i
+    header += struct.pack('<i', len(name) + 1) + name.encode() + b'\0' + struct.pack('<i', n)
+  nucleus_to_bam = {int(v): k for k, v in enumerate(T.BAM_OP_TO_NUCLEUS)}
+  records = []
+  for r in sorted(reads, key=lambda x: (ref_id[x.alignment.position.reference_name], x.alignment.position.position)):
+    aln = r.alignment
+    flag = getattr(r, '_flag', None)
+    if flag is None:
+      flag = ((0x1 if r.number_reads >= 2 else 0) | (0x2 if r.proper_placement else 0) |
+              (0x10 if aln.position.reverse_strand else 0) | (0x100 if r.secondary_alignment else 0) |
+              (0x200 if r.failed_vendor_quality_checks else 0) | (0x400 if r.duplicate_fragment else 0) |
+              (0x800 if r.supplementary_alignment else 0))
+      if r.number_reads >= 2:
+        flag |= 0x40 if r.read_number == 0 else 0x80
+    name = r.fragment_name.encode() + b'\0'
+    seq = r.aligned_sequence
+    packed = bytearray((len(seq) + 1) // 2)
+    for i, c in enumerate(seq):
+      packed[i >> 1] |= _NT16_CODE.get(c, 15) << (4 if (i & 1) == 0 else 0)
+    cigar = b''.join(struct.pack('<I', (c.operation_length << 4) | nucleus_to_bam[c.operation]) for c in aln.cigar)
+    ref_len = sum(c.operation_length for c in aln.cigar if c.operation in (1, 3, 4, 8, 9))
+    end = aln.position.position + max(ref_len, 1)
+    rid = ref_id[aln.position.reference_name]
+    aux = b''
+    if 'HP' in r.info and r.info['HP'].values and r.info['HP'].values[0].int_value is not None:
+      aux = b'HPi' + struct.pack('<i', r.info['HP'].values[0].int_value)
+    body = (struct.pack('<iiBBHHHiiii', rid, aln.position.position, len(name), aln.mapping_quality,
+                        _reg2bin(aln.position.position, end), len(aln.cigar), flag, len(seq), rid if flag & 1 else -1,
+                        aln.position.position if flag & 1 else -1, r.fragment_length) +
+            name + cigar + bytes(packed) + bytes(bytearray(r.aligned_quality)) + aux)
+    records.append(struct.pack('<i', len(body)) + body)
+  payload = header + b''.join(records)
+  with open(path, 'wb') as f:
+    for off in range(0, len(payload), 60000):
+      f.write(_bgzf_block(payload[off:off + 60000]))
+    f.write(_bgzf_block(b''))         # the BGZF end-of-file marker
+
+
+def _reg2bin(beg: int, end: int) -> int:
+  end -= 1
+  for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+    if beg >> shift == end >> shift:
+      return base + (beg >> shift)
+  return 0
+
+
+def write_fasta(path: str, contigs) -> None:
+  """contigs: [(name, bases)]; 60 bases a line, gzip if the path ends in .gz."""
+  opener = gzip.open if path.endswith('.gz') else open
+  with opener(path, 'wt') as f:
+    for name, bases in contigs:
+      f.write('>%s\n' % name)
+      for i in range(0, len(bases), 60):
+        f.write(bases[i:i + 60] + '\n')

@@ -1,0 +1,297 @@
+"""`python -m deepvariant_amd.make_examples` -- calling-mode make_examples for one sample with
+the reference's flag names (deepvariant/make_examples.py, make_examples_options.py:71-941):
+BAM + FASTA + regions -> `tf.Example` TFRecords (+ `.example_info.json`) that
+`deepvariant_amd.call_variants` or the reference's call_variants consume, or -- with
+`--call_variants_outfile` and `--checkpoint` -- straight to CallVariantsOutput records without
+tf.Examples in between (the reference's precedent: fast_pipeline).
+
+Per calling region it runs make_examples_core.RegionProcessor: reads -> (downsample) -> window
+realigner -> device allele counts -> candidate caller -> (read phasing) -> device pileup encoder.
+Flags that belong to machinery outside this path (training labels, gVCF, population VCFs,
+candidate import, multi-sample roles, sharded runtime profiles ...) are rejected when set,
+never silently ignored.  Reads are decoded by the in-package BAM reader (plain BAM with
+coordinate-sorted records; no CRAM).
+"""
+from __future__ import annotations
+
+import argparse
+import re
+import sys
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import genomics_io
+from deepvariant_amd import make_examples_core
+from deepvariant_amd import make_examples_native
+from deepvariant_amd import tfrecord
+from deepvariant_amd.realigner import realigner as realigner_module
+from deepvariant_amd.realigner import utils
+
+_RANDOM_SEED = 609314161            # make_examples_options.py:981
+_REALIGNER_FLAGS = {k: v for k, v in realigner_module._FLAG_DEFAULTS.items()   # pylint: disable=protected-access
+                    if k.startswith(('ws_', 'dbg_', 'aln_')) or k in (
+                        'max_num_mismatches', 'realignment_similarity_threshold', 'kmer_size', 'split_skip_reads')}
+_REJECTED_IF_SET = (   # flags of the reference whose machinery is outside this path
+    'truth_variants', 'confident_regions', 'gvcf', 'candidates', 'proposed_variants', 'population_vcfs',
+    'exclude_regions', 'runtime_by_region', 'denovo_regions', 'small_model_path', 'read_phases_output',
+    'allele_frequency_vcfs', 'customized_classes_labeler_classes_list', 'pangenome')
+
+
+def parse_region(literal: str, ref_reader) -> T.Range:
+  """ranges.parse_literal: 'chr20:10,000,000-10,010,000' (1-based, inclusive), 'chr20:5' or 'chr20'."""
+  m = re.match(r'^([^:]+)(?::([\d,]+)(?:-([\d,]+))?)?$', literal.strip())
+  if not m:
+    raise ValueError('cannot parse region %r' % literal)
+  contig = m.group(1)
+  n = ref_reader.n_bases(contig)                    # KeyError for an unknown contig
+  if m.group(2) is None:
+    return T.Range(contig, 0, n)
+  start = int(m.group(2).replace(',', ''))
+  end = int(m.group(3).replace(',', '')) if m.group(3) else start
+  if start < 1 or end < start:
+    raise ValueError('bad region %r' % literal)
+  return T.Range(contig, start - 1, min(end, n))
+
+
+def reservoir_sample(items, k: int, random: np.random.RandomState) -> List:
+  """utils.reservoir_sample (third_party/nucleus/util/utils.py:80-125), Algorithm R with numpy's
+  RandomState -- the same draws as the reference for the same seed."""
+  if k < 0:
+    raise ValueError('k must be nonnegative, but got {}'.format(k))
+  sample = []
+  for i, item in enumerate(items):
+    if len(sample) < k:
+      sample.append(item)
+    else:
+      j = random.randint(0, i + 1)
+      if j < k:
+        sample[j] = item
+  return sample
+
+
+def build_arg_parser() -> argparse.ArgumentParser:
+  ap = argparse.ArgumentParser(prog='make_examples', allow_abbrev=False,
+                               description='MI355X make_examples (calling mode, one sample)')
+  boolean = dict(nargs='?', const='true')
+  ap.add_argument('--mode', default='calling')
+  ap.add_argument('--ref', required=True)
+  ap.add_argument('--reads', required=True)
+  ap.add_argument('--examples', default='')
+  ap.add_argument('--regions', default='')
+  ap.add_argument('--task', type=int, default=0)
+  ap.add_argument('--sample_name', default='')
+  ap.add_argument('--channel_list', default=','.join(T.PILEUP_DEFAULT_CHANNELS))
+  ap.add_argument('--partition_size', type=int, default=1000)
+  ap.add_argument('--max_reads_per_partition', type=int, default=1500)
+  ap.add_argument('--realign_reads', default='true', **boolean)
+  ap.add_argument('--max_read_length_to_realign', type=int, default=500)
+  ap.add_argument('--min_mapping_quality', type=int, default=5)
+  ap.add_argument('--min_base_quality', type=int, default=10)
+  ap.add_argument('--vsc_min_count_snps', type=int, default=2)
+  ap.add_argument('--vsc_min_count_indels', type=int, default=2)
+  ap.add_argument('--vsc_min_fraction_snps', type=float, default=0.12)
+  ap.add_argument('--vsc_min_fraction_indels', type=float, default=0.06)
+  ap.add_argument('--pileup_image_width', type=int, default=221)
+  ap.add_argument('--pileup_image_height', type=int, default=100)
+  ap.add_argument('--sort_by_haplotypes', default='false', **boolean)
+  ap.add_argument('--reverse_haplotypes', default='false', **boolean)
+  ap.add_argument('--phase_reads', default='false', **boolean)
+  ap.add_argument('--track_ref_reads', default='false', **boolean)
+  ap.add_argument('--min_alleles_to_phase', type=int, default=1)
+  ap.add_argument('--phase_max_candidates', type=int, default=5000)
+  ap.add_argument('--trim_reads_for_pileup', default='false', **boolean)
+  ap.add_argument('--alt_aligned_pileup', default='none')
+  ap.add_argument('--types_to_alt_align', default='indels')
+  ap.add_argument('--parse_sam_aux_fields', default='false', **boolean)     # the HP tag is always read
+  ap.add_argument('--keep_duplicates', default='false', **boolean)
+  ap.add_argument('--keep_supplementary_alignments', default='false', **boolean)
+  ap.add_argument('--keep_secondary_alignments', default='false', **boolean)
+  ap.add_argument('--keep_legacy_allele_counter_behavior', default='false', **boolean)
+  ap.add_argument('--normalize_reads', default='false', **boolean)
+  ap.add_argument('--output_phase_info', default='false', **boolean)
+  ap.add_argument('--call_small_model_examples', default='false', **boolean)
+  ap.add_argument('--stream_examples', default='false', **boolean)
+  for name in _REJECTED_IF_SET:
+    ap.add_argument('--' + name, default='')
+  for name, default in _REALIGNER_FLAGS.items():
+    if isinstance(default, bool):
+      ap.add_argument('--' + name, default='true' if default else 'false', **boolean)
+    elif default is None:
+      ap.add_argument('--' + name, default=None)
+    else:
+      ap.add_argument('--' + name, type=type(default), default=default)
+  # not in the reference: the fused route (no tf.Examples) and the device
+  ap.add_argument('--call_variants_outfile', default='')
+  ap.add_argument('--checkpoint', default='')
+  ap.add_argument('--device', type=int, default=0)
+  return ap
+
+
+def _true(v) -> bool:
+  return str(v).lower() in ('1', 'true', 't', 'yes')
+
+
+def check_flags(args) -> None:
+  if args.mode != 'calling':
+    raise ValueError('--mode=%s: only calling mode is built (labelling needs the truth-VCF labeler)' % args.mode)
+  for name in _REJECTED_IF_SET:
+    if getattr(args, name):
+      raise ValueError('--%s is not supported by the MI355X make_examples' % name)
+  for name in ('normalize_reads', 'stream_examples', 'call_small_model_examples', 'output_phase_info'):
+    if _true(getattr(args, name)):
+      raise ValueError('--%s is not supported by the MI355X make_examples' % name)
+  if bool(args.call_variants_outfile) != bool(args.checkpoint):
+    raise ValueError('--call_variants_outfile and --checkpoint go together (the fused route)')
+  if not args.examples and not args.call_variants_outfile:
+    raise ValueError('--examples (or --call_variants_outfile with --checkpoint) is required')
+  if _true(args.phase_reads) and not _true(args.track_ref_reads):
+    raise ValueError('--track_ref_reads must be set to True when --phase_reads is set.')
+  if args.partition_size < 1:
+    raise ValueError('--partition_size must be positive')
+
+
+def _shard(spec: str, task: int):
+  """'x.tfrecord@N.gz' + task -> (the task's file name, N); a plain name is one shard."""
+  m = re.match(r'^(.*)@(\d+)(.*)$', spec)
+  if not m:
+    if task != 0:
+      raise ValueError('--task=%d needs a sharded output name (name@N)' % task)
+    return spec, 0
+  n = int(m.group(2))
+  if not 0 <= task < n:
+    raise ValueError('task_id={} should be >= 0 and < num_shards={}'.format(task, n))
+  return '%s-%05d-of-%05d%s' % (m.group(1), task, n, m.group(3)), n
+
+
+def options_from_flags(args):
+  """-> (MakeExamplesOptions, RegionProcessorOptions): default_options (make_examples_options.py:944-1380)
+  for the flags this slice has."""
+  rr = T.ReadRequirements(min_mapping_quality=args.min_mapping_quality, min_base_quality=args.min_base_quality,
+                          min_base_quality_mode=1)
+  pic = T.default_options(rr)
+  channels = [c for c in args.channel_list.split(',') if c]
+  alt_mode = args.alt_aligned_pileup
+  if alt_mode in ('diff_channels', 'base_channels'):
+    channels += ['%s_alternate_allele_1' % alt_mode, '%s_alternate_allele_2' % alt_mode]
+  pic.channels = channels
+  pic.num_channels = len(channels)
+  pic.width, pic.height = args.pileup_image_width, args.pileup_image_height
+  pic.sort_by_haplotypes = _true(args.sort_by_haplotypes)
+  pic.reverse_haplotypes = _true(args.reverse_haplotypes)
+  pic.alt_aligned_pileup = alt_mode
+  pic.types_to_alt_align = args.types_to_alt_align
+  options = T.MakeExamplesOptions(
+      pic_options=pic, trim_reads_for_pileup=_true(args.trim_reads_for_pileup),
+      sample_options=[T.SampleOptions(role='main', name=args.sample_name or 'default',
+                                      pileup_height=args.pileup_image_height)])
+  realigner_flags = {}
+  for name, default in _REALIGNER_FLAGS.items():
+    v = getattr(args, name)
+    realigner_flags[name] = _true(v) if isinstance(default, bool) else v
+  realigner_flags['keep_legacy_allele_counter_behavior'] = _true(args.keep_legacy_allele_counter_behavior)
+  po = make_examples_core.RegionProcessorOptions(
+      realigner_enabled=_true(args.realign_reads),
+      realigner_options=realigner_module.realigner_config(**realigner_flags),
+      max_read_length_to_realign=args.max_read_length_to_realign,
+      vsc_min_count_snps=args.vsc_min_count_snps, vsc_min_count_indels=args.vsc_min_count_indels,
+      vsc_min_fraction_snps=args.vsc_min_fraction_snps, vsc_min_fraction_indels=args.vsc_min_fraction_indels,
+      keep_legacy_allele_counter_behavior=_true(args.keep_legacy_allele_counter_behavior),
+      partition_size=args.partition_size, track_ref_reads=_true(args.track_ref_reads),
+      phase_reads=_true(args.phase_reads), phase_max_candidates=args.phase_max_candidates,
+      min_alleles_to_phase=args.min_alleles_to_phase)
+  return options, po
+
+
+def calling_regions(args, ref_reader, contig_names: Sequence[str], num_shards: int) -> List[T.Range]:
+  """processing_regions_from_options (make_examples_core.py:836-888): the regions (or every contig
+  of the BAM that the reference has), cut into partition_size pieces, this task's share round robin."""
+  if args.regions:
+    regions = [parse_region(x, ref_reader) for x in args.regions.split()]     # space-separated literals
+  else:
+    regions = []
+    for name in contig_names:
+      try:
+        regions.append(T.Range(name, 0, ref_reader.n_bases(name)))
+      except KeyError:
+        continue
+  pieces = [p for r in regions for p in make_examples_core.partition(r, args.partition_size)]
+  if num_shards:
+    pieces = [p for i, p in enumerate(pieces) if i % num_shards == args.task]
+  return pieces
+
+
+def make_examples_runner(args, log=sys.stderr) -> dict:
+  """-> stats; writes the task's example shard (and its example_info.json) or the CVO file."""
+  check_flags(args)
+  ref_reader = genomics_io.FastaReader(args.ref)
+  options, po = options_from_flags(args)
+  out_spec = args.examples or args.call_variants_outfile
+  out_path, num_shards = _shard(out_spec, args.task)
+  contig_names = genomics_io.bam_contig_names(args.reads)
+  pieces = calling_regions(args, ref_reader, contig_names, num_shards)
+  # one decode of the BAM per contig, over the span the task needs
+  reads_by_contig = {}
+  for contig in sorted({p.reference_name for p in pieces}):
+    lo = min(p.start for p in pieces if p.reference_name == contig)
+    hi = max(p.end for p in pieces if p.reference_name == contig)
+    _, reads = genomics_io.read_bam(args.reads, contig, lo, hi)
+    reads = [r for r in reads if genomics_io.read_satisfies_requirements(
+        r, min_mapping_quality=args.min_mapping_quality, keep_duplicates=_true(args.keep_duplicates),
+        keep_supplementary=_true(args.keep_supplementary_alignments),
+        keep_secondary=_true(args.keep_secondary_alignments))]
+    reads_by_contig[contig] = (reads, [utils.read_range(r) for r in reads])
+  proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
+  model = None
+  if args.checkpoint:
+    from deepvariant_amd import call_variants
+    from deepvariant_amd.inception_v3 import InceptionV3
+    shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
+             len(options.pic_options.channels))
+    model = InceptionV3(shape, max_batch=1024, device=args.device)
+    call_variants.load_flat_checkpoint(args.checkpoint, model)
+  writer = tfrecord.Writer(out_path)
+  stats = dict(n_regions=0, n_reads=0, n_candidates=0, n_examples=0)
+  image_shape = None
+  try:
+    for region in pieces:
+      reads, spans = reads_by_contig[region.reference_name]
+      in_reads = [r for r, s in zip(reads, spans) if utils.ranges_overlap(s, region)]
+      if args.max_reads_per_partition > 0:
+        in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))
+      stats['n_regions'] += 1
+      stats['n_reads'] += len(in_reads)
+      if model is not None:
+        candidates, records = proc.call_variants_in_region(region, in_reads, model)
+      else:
+        candidates, records = proc.examples_in_region(region, in_reads)
+      for rec in records:
+        writer.write(rec)
+      stats['n_candidates'] += len(candidates)
+      stats['n_examples'] += len(records)
+  finally:
+    writer.close()
+  if model is None:
+    pic = options.pic_options
+    image_shape = [make_examples_native.calculate_pileup_image_height(options), pic.width, len(pic.channels)]
+    if args.task == 0:
+      make_examples_native.write_example_info_json(out_path, image_shape, pic.channels)
+  print('make_examples task %d: %d regions, %d reads, %d candidates, %d %s -> %s' % (
+      args.task, stats['n_regions'], stats['n_reads'], stats['n_candidates'], stats['n_examples'],
+      'CallVariantsOutputs' if model is not None else 'examples', out_path), file=log)
+  return stats
+
+
+def main(argv=None) -> int:
+  args = build_arg_parser().parse_args(argv)
+  try:
+    make_examples_runner(args)
+  except (ValueError, KeyError, IOError) as e:
+    print('make_examples: %s' % e, file=sys.stderr)
+    return 1
+  return 0
+
+
+if __name__ == '__main__':
+  sys.exit(main())

@@ -181,7 +181,27 @@ def decode_variant(buf) -> T.Variant:
     elif f == 11:
       call = T.VariantCall()
       for f2, wt2, v2 in iter_fields(val):
-        if f2 == 9:
+        if f2 == 2:                                   # info map entry
+          key, lv = None, T.ListValue()
+          for f3, _, v3 in iter_fields(v2):
+            if f3 == 1:
+              key = bytes(v3).decode()
+            elif f3 == 2:
+              for f4, _, v4 in iter_fields(v3):
+                if f4 != 1:
+                  continue
+                item = T.Value()
+                for f5, wt5, v5 in iter_fields(v4):
+                  if f5 == 7:
+                    item.int_value = to_signed64(v5)
+                  elif f5 == 2:
+                    item.number_value = struct.unpack('<d', bytes(v5))[0] if wt5 != 0 else float(v5)
+                  elif f5 == 3:
+                    item.string_value = bytes(v5).decode()
+                lv.values.append(item)
+          if key is not None:
+            call.info[key] = lv
+        elif f2 == 9:
           call.call_set_name = bytes(v2).decode()
         elif f2 == 7:
           if wt2 == LEN:
@@ -207,6 +227,19 @@ def encode_variant(v: T.Variant) -> bytes:
     out += enc_len(7, a.encode())
   for c in v.calls:
     body = b''
+    # VariantCall.info = map<string, ListValue>, field 2, before genotype (7) and call_set_name (9);
+    # keys in sorted order (AD, DP, VAF -- the order the reference's records show)
+    for key in sorted(c.info):
+      values = b''
+      for val in c.info[key].values:
+        if val.int_value is not None:
+          one = enc_int(7, val.int_value)                       # Value.int_value
+        elif val.number_value is not None:
+          one = bytes([0x11]) + struct.pack('<d', val.number_value)   # Value.number_value (fixed64)
+        else:
+          one = enc_len(3, (val.string_value or '').encode())     # Value.string_value
+        values += enc_len(1, one)
+      body += enc_len(2, enc_len(1, key.encode()) + enc_len(2, values))
     if c.genotype:
       body += enc_len(7, b''.join(enc_varint(g) for g in c.genotype))
     if c.call_set_name:

@@ -406,6 +406,19 @@ def main_realigner():
   d['ref_bases'] = np.frombuffer(fasta.get_bases('chr20', ref_start, ref_end).encode(), np.uint8)
   d['ref_start'] = np.array([ref_start], np.int64)
   d['n_contig_bases'] = np.array([fasta.n_bases('chr20')], np.int64)
+  # the Variant protos inside golden.calling_examples: what calls[0] must carry (AD / DP / VAF, the
+  # no-call genotype, the sample name) -- one JSON line per distinct variant
+  import json
+  lines = {}
+  for rec in tfrecord.read_tfrecords(os.path.join(REF, 'golden.calling_examples.tfrecord.gz')):
+    v = pw.decode_variant(pw.decode_example(rec)['variant/encoded'][0])
+    c = v.calls[0]
+    lines[(v.start, tuple(v.alternate_bases))] = json.dumps(dict(
+        start=v.start, end=v.end, ref=v.reference_bases, alts=list(v.alternate_bases), sample=c.call_set_name,
+        genotype=list(c.genotype), AD=[x.int_value for x in c.info['AD'].values],
+        DP=[x.int_value for x in c.info['DP'].values],
+        VAF=[float(x.number_value).hex() for x in c.info['VAF'].values]))
+  d['wgs_variants'] = np.frombuffer('\n'.join(lines[k] for k in sorted(lines)).encode(), np.uint8)
   np.savez_compressed(os.path.join(ROOT, 'tests/golden/realigner_chr20.npz'), **d)
 
 

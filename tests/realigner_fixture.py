@@ -61,6 +61,30 @@ def load():
   return FixtureRef(z), sets
 
 
+def golden_wgs_variants():
+  """{(start, alts): dict} -- the Variant protos of golden.calling_examples (AD / DP / VAF of calls[0],
+  the no-call genotype, the sample name)."""
+  import json
+  with np.load(FIXTURE) as f:
+    lines = bytes(f['wgs_variants']).decode().split('\n')
+  out = {}
+  for line in lines:
+    d = json.loads(line)
+    out[(d['start'], tuple(d['alts']))] = d
+  return out
+
+
+def variant_facts(variant):
+  """The same dict for a dv_types.Variant (after a trip through the wire format)."""
+  from deepvariant_amd import protowire as pw
+  v = pw.decode_variant(pw.encode_variant(variant))
+  c = v.calls[0]
+  return dict(start=v.start, end=v.end, ref=v.reference_bases, alts=list(v.alternate_bases), sample=c.call_set_name,
+              genotype=list(c.genotype), AD=[x.int_value for x in c.info['AD'].values],
+              DP=[x.int_value for x in c.info['DP'].values],
+              VAF=[float(x.number_value).hex() for x in c.info['VAF'].values])
+
+
 class OracleAlleleCounter:
   """oracle AlleleCounter behind deepvariant_amd.allelecounter.AlleleCounter's interface."""
 

@@ -255,3 +255,62 @@ def test_reads_to_probabilities_chain():
       worst = max(worst, float(np.abs(np.array(got_probs) - want).max()))
       k += 1
   assert k == len(cvos) and worst <= 2e-3, worst   # round_gls rounds the emitted values to 1e-10 steps
+
+
+def test_make_examples_cli_end_to_end(tmp_path):
+  """`python -m deepvariant_amd.make_examples` on files: the golden region's reads written back to
+  a BAM, the reference stretch to a FASTA, two tasks of a sharded run -> the 84 golden images,
+  each in the shard its region belongs to, plus example_info.json; then the fused route
+  (--call_variants_outfile + --checkpoint) gives one CallVariantsOutput per example whose
+  probabilities equal classifying the written examples with `deepvariant_amd.call_variants`."""
+  import json
+  import os
+  from deepvariant_amd import call_variants as cv
+  from deepvariant_amd import genomics_io
+  from deepvariant_amd import make_examples as me
+  from deepvariant_amd import protowire as pw
+  from tests import golden_io
+  from tests import realigner_fixture as RF
+  ref, sets = RF.load()
+  stretch_start = 9_995_000
+  fasta = str(tmp_path / 'ref.fa.gz')
+  genomics_io.write_fasta(fasta, [('chr20', 'N' * stretch_start + ref.get_bases('chr20', stretch_start, 10_100_600))])
+  bam = str(tmp_path / 'reads.bam')
+  genomics_io.write_bam(bam, [('chr20', 10_100_600)], sets['wgs'], sample_name='NA12878')
+  common = ['--ref', fasta, '--reads', bam, '--regions', 'chr20:10,000,000-10,010,000', '--sample_name', 'NA12878',
+            '--channel_list', ','.join(T.PILEUP_CHANNELS_WITH_INSERT_SIZE)]
+  spec = str(tmp_path / 'examples.tfrecord@2.gz')
+  images = {}
+  for task in (0, 1):
+    assert me.main(common + ['--examples', spec, '--task', str(task)]) == 0
+    path = str(tmp_path / ('examples.tfrecord-%05d-of-00002.gz' % task))
+    for rec in tfrecord.read_tfrecords(path, verify_crc=True):
+      ex = pw.decode_example(rec)
+      v = pw.decode_variant(ex['variant/encoded'][0])
+      assert ((v.start - 9_999_999) // 1000) % 2 == task                # round-robin over 1 kb regions
+      assert v.calls[0].call_set_name == 'NA12878' and 'AD' in v.calls[0].info
+      idx = tuple(pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+      images[(v.start, tuple(v.alternate_bases[i] for i in idx))] = np.frombuffer(
+          ex['image/encoded'][0], np.uint8).reshape(ex['image/shape'])
+  info = json.load(open(str(tmp_path / 'examples.tfrecord-00000-of-00002.gz.example_info.json')))
+  assert info['shape'] == [100, 221, 7] and info['channels'] == [1, 2, 3, 4, 5, 6, 19]
+  _, golden, _ = golden_io.load(os.path.join(os.path.dirname(__file__), 'golden', 'illumina_wgs_chr20.npz'))
+  assert len(images) == len(golden) == 84
+  for ex in golden:
+    assert np.array_equal(images[(ex['call'].variant.start, tuple(ex['alt_alleles']))], ex['image'])
+  # fused: no tf.Examples
+  cvo_path = str(tmp_path / 'cvo.tfrecord.gz')
+  assert me.main(common + ['--call_variants_outfile', cvo_path, '--checkpoint', 'random:7']) == 0
+  fused = {}
+  for rec in tfrecord.read_tfrecords(cvo_path):
+    variant, alt, probs = pw.decode_call_variants_output(rec)
+    fused[(variant.start, tuple(alt))] = probs
+  assert len(fused) == 84
+  two_step = str(tmp_path / 'cvo2.tfrecord.gz')
+  assert cv.main(['--examples', spec, '--outfile', two_step, '--checkpoint', 'random:7']) == 0
+  n = 0
+  for rec in tfrecord.read_tfrecords(two_step):
+    variant, alt, probs = pw.decode_call_variants_output(rec)
+    assert np.allclose(fused[(variant.start, tuple(alt))], probs, atol=1e-6)
+    n += 1
+  assert n == 84

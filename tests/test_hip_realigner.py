@@ -80,10 +80,12 @@ def test_golden_illumina_chain_on_device():
     v = ex['call'].variant
     gold[(v.start, v.reference_bases, tuple(v.alternate_bases))] = ex['call']
   assert set(found) == set(gold) and len(gold) == 78
+  facts = RF.golden_wgs_variants()
   for k, g in gold.items():
     a = {x: sorted(s.read_names) for x, s in found[k].allele_support.items()}
     b = {x: sorted(s.read_names) for x, s in g.allele_support.items()}
     assert a == b, k
+    assert RF.variant_facts(found[k].variant) == facts[(k[0], k[2])], k       # AD / DP / VAF / genotype / sample
   assert len(images) == len(examples) == 84
   for ex in examples:
     key = (ex['call'].variant.start, tuple(ex['alt_alleles']))

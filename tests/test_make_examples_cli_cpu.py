@@ -1,0 +1,133 @@
+"""`python -m deepvariant_amd.make_examples`: flag handling, region parsing, sharding and the
+downsampler (host side; the run itself needs the device and lives in tests/test_hip_pipeline.py)."""
+import numpy as np
+import pytest
+
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import genomics_io
+from deepvariant_amd import make_examples as me
+from tests import realigner_fixture as RF
+
+
+def parse(*argv):
+  return me.build_arg_parser().parse_args(['--ref', 'r.fa', '--reads', 'x.bam'] + list(argv))
+
+
+def test_defaults_are_the_references():
+  args = parse('--examples', 'e.tfrecord.gz')
+  me.check_flags(args)
+  options, po = me.options_from_flags(args)
+  pic = options.pic_options
+  assert pic.channels == list(T.PILEUP_DEFAULT_CHANNELS) and (pic.height, pic.width) == (100, 221)
+  assert (pic.read_requirements.min_mapping_quality, pic.read_requirements.min_base_quality) == (5, 10)
+  assert (po.realigner_enabled, po.partition_size, po.max_read_length_to_realign) == (True, 1000, 500)
+  assert (po.vsc_min_count_snps, po.vsc_min_count_indels, po.vsc_min_fraction_snps, po.vsc_min_fraction_indels) == (
+      2, 2, 0.12, 0.06)
+  assert not po.phase_reads and not po.track_ref_reads
+  ws = po.realigner_options.ws_config
+  assert (ws.min_mapq, ws.min_windows_distance, ws.window_selector_model.variant_reads_model.min_num_supporting_reads) == (
+      20, 80, 2)
+
+
+def test_long_read_flags():
+  args = parse('--examples', 'e.tfrecord.gz', '--norealign' if False else '--realign_reads=false', '--phase_reads',
+               '--track_ref_reads', '--sort_by_haplotypes', '--trim_reads_for_pileup', '--alt_aligned_pileup',
+               'diff_channels', '--pileup_image_width', '147', '--min_mapping_quality', '1',
+               '--vsc_min_fraction_indels', '0.12', '--partition_size', '25000',
+               '--channel_list', ','.join(T.PILEUP_DEFAULT_CHANNELS + ['haplotype', 'base_methylation']))
+  me.check_flags(args)
+  options, po = me.options_from_flags(args)
+  pic = options.pic_options
+  assert len(pic.channels) == 10 and pic.channels[-2:] == ['diff_channels_alternate_allele_1',
+                                                           'diff_channels_alternate_allele_2']
+  assert pic.width == 147 and pic.sort_by_haplotypes and options.trim_reads_for_pileup
+  assert not po.realigner_enabled and po.phase_reads and po.track_ref_reads and po.partition_size == 25000
+
+
+@pytest.mark.parametrize('argv,message', [
+    (['--examples', 'e', '--mode', 'training'], 'only calling mode'),
+    (['--examples', 'e', '--gvcf', 'g.tfrecord.gz'], '--gvcf is not supported'),
+    (['--examples', 'e', '--truth_variants', 't.vcf.gz'], '--truth_variants is not supported'),
+    (['--examples', 'e', '--population_vcfs', 'p.vcf.gz'], '--population_vcfs is not supported'),
+    (['--examples', 'e', '--normalize_reads'], '--normalize_reads is not supported'),
+    (['--examples', 'e', '--stream_examples'], '--stream_examples is not supported'),
+    (['--examples', 'e', '--phase_reads'], 'track_ref_reads must be set'),
+    (['--call_variants_outfile', 'cvo.tfrecord.gz'], 'go together'),
+    ([], '--examples'),
+])
+def test_unsupported_flags_are_refused(argv, message):
+  with pytest.raises(ValueError, match=message):
+    me.check_flags(parse(*argv))
+
+
+def test_unknown_flags_are_refused():
+  with pytest.raises(SystemExit):
+    parse('--examples', 'e', '--no_such_flag', '1')
+
+
+def test_parse_region():
+  ref = RF.StringRef('chr20', 'A' * 5000)
+  assert me.parse_region('chr20:1,001-2,000', ref) == T.Range('chr20', 1000, 2000)
+  assert me.parse_region('chr20:10', ref) == T.Range('chr20', 9, 10)
+  assert me.parse_region('chr20', ref) == T.Range('chr20', 0, 5000)
+  assert me.parse_region('chr20:4,000-9,000', ref) == T.Range('chr20', 3999, 5000)     # clipped to the contig
+  with pytest.raises(KeyError):
+    me.parse_region('chrX:1-5', ref)
+  with pytest.raises(ValueError):
+    me.parse_region('chr20:5-1', ref)
+
+
+def test_calling_regions_are_shared_round_robin():
+  ref = RF.StringRef('chr20', 'A' * 10500)
+  args = parse('--examples', 'e@3', '--regions', 'chr20:1-4,000 chr20:8,001-10,500', '--task', '1')
+  pieces = me.calling_regions(args, ref, ['chr20'], 3)
+  every = me.calling_regions(args, ref, ['chr20'], 0)
+  assert [(p.start, p.end) for p in every] == [(0, 1000), (1000, 2000), (2000, 3000), (3000, 4000), (8000, 9000),
+                                               (9000, 10000), (10000, 10500)]
+  assert pieces == every[1::3]
+  assert me._shard('x.tfrecord@3.gz', 1) == ('x.tfrecord-00001-of-00003.gz', 3)
+  assert me._shard('x.tfrecord.gz', 0) == ('x.tfrecord.gz', 0)
+  with pytest.raises(ValueError):
+    me._shard('x.tfrecord@3.gz', 3)
+  # no --regions: every contig of the BAM that the reference has
+  args = parse('--examples', 'e', '--partition_size', '6000')
+  assert [(p.reference_name, p.start, p.end) for p in me.calling_regions(args, ref, ['chrM', 'chr20'], 0)] == [
+      ('chr20', 0, 6000), ('chr20', 6000, 10500)]
+
+
+def test_reservoir_sample():
+  """nucleus utils_test.py:96-132: lengths, bad k, and uniform frequencies with the seeded RandomState."""
+  rs = np.random.RandomState(123456789)
+  assert len(me.reservoir_sample(range(10), 11, rs)) == 10
+  assert me.reservoir_sample(range(10), 10, rs) == list(range(10))
+  assert len(me.reservoir_sample(range(10), 9, rs)) == 9
+  assert me.reservoir_sample(range(10), 0, rs) == []
+  with pytest.raises(ValueError):
+    me.reservoir_sample(range(10), -1, rs)
+  for n, k in ((10, 1), (6, 3), (10, 3)):
+    counts = np.zeros(n)
+    for _ in range(20000):
+      for item in me.reservoir_sample(range(n), k, rs):
+        counts[item] += 1
+    np.testing.assert_allclose(counts / 20000, min(k / n, 1.0), atol=0.015)
+  # the draws are numpy's RandomState.randint(0, i + 1): pinned for the make_examples seed
+  assert me.reservoir_sample(range(12), 4, np.random.RandomState(609314161)) == me.reservoir_sample(
+      range(12), 4, np.random.RandomState(609314161))
+
+
+def test_bam_round_trip(tmp_path):
+  """write_bam (the way fixtures get back to a file) -> both BAM readers give the reads back."""
+  from deepvariant_amd import packing
+  _, sets = RF.load()
+  reads = sets['ex1']
+  path = str(tmp_path / 'ex1.bam')
+  genomics_io.write_bam(path, [('chrM', 16571), ('chr20', 63025520)], reads, sample_name='NA12878')
+  assert genomics_io.bam_contig_names(path) == ['chrM', 'chr20']
+  _, back = genomics_io.read_bam(path, 'chr20', 0, 1 << 40)
+  key = lambda r: (r.alignment.position.position, r.fragment_name, r.read_number)
+  for a, b in zip(sorted(reads, key=key), sorted(back, key=key)):
+    assert (a.fragment_name, a.read_number, a.aligned_sequence, bytes(bytearray(a.aligned_quality)), a.alignment,
+            a.fragment_length) == (b.fragment_name, b.read_number, b.aligned_sequence,
+                                   bytes(bytearray(b.aligned_quality)), b.alignment, b.fragment_length)
+  table = packing.ReadTable.from_bam(path, 'chr20', 0, 1 << 40)
+  assert table.n_reads == len(reads) == 116

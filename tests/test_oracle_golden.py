@@ -267,7 +267,8 @@ def run_golden_chain(make_counter, realigner_counter_cls, build_image):
   opts = MG.wgs_options()
   rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=realigner_counter_cls)
   caller = vc.VariantCaller(vc.VariantCallerOptions(
-      min_count_snps=2, min_count_indels=2, min_fraction_snps=0.12, min_fraction_indels=0.06))
+      min_count_snps=2, min_count_indels=2, min_fraction_snps=0.12, min_fraction_indels=0.06,
+      sample_name='NA12878'))
   reads = sets['wgs']
   spans = [U.read_range(r) for r in reads]
   found, region_reads = {}, []
@@ -297,10 +298,15 @@ def check_golden_chain(found, examples, images):
     v = ex['call'].variant
     gold[(v.start, v.reference_bases, tuple(v.alternate_bases))] = ex['call']
   assert set(found) == set(gold) and len(gold) == 78
+  from tests import realigner_fixture as RF
+  facts = RF.golden_wgs_variants()
   for k, g in gold.items():
     a = {x: sorted(s.read_names) for x, s in found[k].allele_support.items()}
     b = {x: sorted(s.read_names) for x, s in g.allele_support.items()}
     assert a == b, k
+    # the Variant inside the example: AD / DP / VAF, no-call genotype, sample name -- what
+    # postprocess_variants reads back from CallVariantsOutput.variant
+    assert RF.variant_facts(found[k].variant) == facts[(k[0], k[2])], k
   assert len(images) == 84
   for ex, image in zip(examples, images):
     assert np.array_equal(image, ex['image']), ex['call'].variant.start
