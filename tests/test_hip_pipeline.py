@@ -269,6 +269,7 @@ def test_make_examples_cli_end_to_end(tmp_path):
   from deepvariant_amd import genomics_io
   from deepvariant_amd import make_examples as me
   from deepvariant_amd import protowire as pw
+  from deepvariant_amd import tfrecord
   from tests import golden_io
   from tests import realigner_fixture as RF
   ref, sets = RF.load()
