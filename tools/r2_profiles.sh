@@ -15,3 +15,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/write -- python $
 python $R/profiles/summarize_pmc.py $(find $R/$O/write -name '*.db' | head -1) > $R/$O/pmc_write.txt
 rm -rf $R/$O/stats $R/$O/fetch $R/$O/write
 head -14 $R/$O/kernel_stats.txt
+cd $R
+timeout 300 python bench.py --mode alleles > $O/bench_alleles.json 2>> $O/bench.err; cat $O/bench_alleles.json
+timeout 300 python tools/r2_region_chain.py > $O/region_chain.txt 2>&1; cat $O/region_chain.txt
