@@ -101,3 +101,50 @@ def test_count_alleles_rejects_malformed_host_tables():
     b.cigar = cig.ctypes.data
     rc = _lib.lib().dv_count_alleles(C.byref(b), C.byref(opt), C.byref(h), None)
     assert rc == _lib.DV_ERR_BAD_INPUT and message in _lib.lib().dv_last_error().decode()
+
+
+def test_realigner_and_phasing_entry_points_reject_malformed_input():
+  """dv_debruijn_build / dv_phase_reads / dv_local_align_many validate before they index."""
+  import ctypes as C
+  import numpy as np
+  l = _lib.lib()
+  opt = _lib.DvDebruijnOptions(10, 20, 1, 0, 0, 2, 16, 0)
+  handle = C.c_void_p()
+  bases = np.frombuffer(b'ACGTACGTAC', np.uint8)
+  quals = np.full(10, 30, np.uint8)
+  off = np.array([0, 10], np.uint32)
+  mapq = np.array([60], np.uint8)
+  def build(ref=b'ACGTTGCAAGCTTGGATCCA', n_bases=10, reads=(0,), n_table=1, options=opt, seq_off=off):
+    idx = np.ascontiguousarray(reads, np.int32)
+    return l.dv_debruijn_build(ref, len(ref), bases.ctypes.data, quals.ctypes.data, n_bases, seq_off.ctypes.data,
+                               mapq.ctypes.data, n_table, idx.ctypes.data, len(idx), C.byref(options), C.byref(handle))
+  assert build() == _lib.DV_OK
+  if handle.value:
+    l.dv_debruijn_destroy(handle)
+  assert build(reads=(1,)) != _lib.DV_OK                       # read index outside the table
+  assert build(reads=(-1,)) != _lib.DV_OK
+  assert build(n_bases=5) != _lib.DV_OK                        # the read's bases end past the array
+  assert build(seq_off=np.array([10, 0], np.uint32)) != _lib.DV_OK
+  assert build(options=_lib.DvDebruijnOptions(0, 20, 1, 0, 0, 2, 16, 0)) != _lib.DV_OK     # min_k 0
+  assert build(options=_lib.DvDebruijnOptions(10, 20, 0, 0, 0, 2, 16, 0)) != _lib.DV_OK    # step_k 0
+  assert 'dv_debruijn_build' in l.dv_last_error().decode()
+
+  cand = (_lib.DvPhasingCandidate * 1)(_lib.DvPhasingCandidate(100, 101, 0, 2))
+  alleles = (_lib.DvPhasingAllele * 2)(_lib.DvPhasingAllele(0, 1, 0, 0, 2, 0), _lib.DvPhasingAllele(1, 1, 0, 2, 2, 0))
+  support = np.array([0, 1, 2, 3], np.int32)
+  lowq = np.zeros(4, np.uint8)
+  phases = np.zeros(4, np.int32)
+  def phase(n_alleles=2, n_bases=2, n_support=4, n_reads=4, sup=support):
+    return l.dv_phase_reads(cand, 1, alleles, n_alleles, b'AC', n_bases, sup.ctypes.data, lowq.ctypes.data, n_support,
+                            n_reads, 1, phases.ctypes.data, None, None, None, 0)
+  assert phase() == _lib.DV_OK
+  assert phase(n_alleles=1) != _lib.DV_OK                      # the candidate's allele range leaves the table
+  assert phase(n_bases=1) != _lib.DV_OK                        # an allele's bases leave the string
+  assert phase(n_support=3) != _lib.DV_OK                      # ... its support range too
+  assert phase(n_reads=3) != _lib.DV_OK                        # a read index >= n_reads
+  assert phase(n_reads=-1) != _lib.DV_OK
+  assert 'dv_phase_reads' in l.dv_last_error().decode()
+
+  out = (_lib.DvLocalAlignment * 1)()
+  assert l.dv_local_align_many(None, 1, None, 2, 2, 3, 1, out) != _lib.DV_OK
+  assert l.dv_local_align_many(b'ACGT', -1, None, 2, 2, 3, 1, out) != _lib.DV_OK
