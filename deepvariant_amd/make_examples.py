@@ -283,8 +283,22 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   return stats
 
 
+def absl_booleans(ap: argparse.ArgumentParser, argv: Sequence[str]) -> List[str]:
+  """absl's `--noflag` spelling of `--flag=false` (scripts/run_deepvariant.py passes
+  `--norealign_reads`), for the flags that are boolean here."""
+  booleans = {a.dest for a in ap._actions if a.nargs == '?' and a.const == 'true'}   # pylint: disable=protected-access
+  out = []
+  for arg in argv:
+    if arg.startswith('--no') and '=' not in arg and arg[4:] in booleans:
+      out.append('--%s=false' % arg[4:])
+    else:
+      out.append(arg)
+  return out
+
+
 def main(argv=None) -> int:
-  args = build_arg_parser().parse_args(argv)
+  ap = build_arg_parser()
+  args = ap.parse_args(absl_booleans(ap, sys.argv[1:] if argv is None else argv))
   try:
     make_examples_runner(args)
   except (ValueError, KeyError, IOError) as e:

@@ -60,6 +60,16 @@ def test_unsupported_flags_are_refused(argv, message):
     me.check_flags(parse(*argv))
 
 
+def test_absl_negated_booleans():
+  ap = me.build_arg_parser()
+  argv = me.absl_booleans(ap, ['--ref', 'r', '--reads', 'b', '--examples', 'e', '--norealign_reads', '--phase_reads',
+                               '--notrim_reads_for_pileup', '--nonsense'])
+  assert argv[-4:] == ['--realign_reads=false', '--phase_reads', '--trim_reads_for_pileup=false', '--nonsense']
+  args = ap.parse_args(argv[:-1] + ['--track_ref_reads'])
+  _, po = me.options_from_flags(args)
+  assert not po.realigner_enabled and po.phase_reads
+
+
 def test_unknown_flags_are_refused():
   with pytest.raises(SystemExit):
     parse('--examples', 'e', '--no_such_flag', '1')
