@@ -122,11 +122,77 @@ def build_arg_parser() -> argparse.ArgumentParser:
       ap.add_argument('--' + name, default=None)
     else:
       ap.add_argument('--' + name, type=type(default), default=default)
-  # not in the reference: the fused route (no tf.Examples) and the device
-  ap.add_argument('--call_variants_outfile', default='')
+  # --checkpoint / --checkpoint_json: where model.example_info.json (channels + flags_for_calling) is
+  # looked up, as in the reference; with --call_variants_outfile (not in the reference) the weights
+  # are loaded too and CallVariantsOutput records are written instead of tf.Examples
   ap.add_argument('--checkpoint', default='')
+  ap.add_argument('--checkpoint_json', default='')
+  ap.add_argument('--call_variants_outfile', default='')
   ap.add_argument('--device', type=int, default=0)
   return ap
+
+
+_SMALL_MODEL_FLAGS = ('call_small_model_examples', 'trained_small_model_path', 'small_model_indel_gq_threshold',
+                      'small_model_snp_gq_threshold', 'small_model_vaf_context_window_size',
+                      'small_model_emit_all_candidates')
+
+
+def model_example_info_path(checkpoint: str, checkpoint_json: str = '') -> str:
+  """get_model_example_info_json_path (make_examples_core.py:3780-3822); '' if there is none
+  (a `random:<seed>` or flat-array checkpoint has no json)."""
+  import os
+  if checkpoint_json:
+    return checkpoint_json
+  if not checkpoint or checkpoint.startswith('random:'):
+    return ''
+  model_dir = checkpoint if os.path.exists(os.path.join(checkpoint, 'saved_model.pb')) else os.path.dirname(checkpoint)
+  for name in ('model.example_info.json', 'example_info.json'):
+    cand = os.path.join(model_dir, name)
+    if os.path.exists(cand):
+      return cand
+  return ''
+
+
+def apply_flags_for_calling(ap: argparse.ArgumentParser, args, argv: Sequence[str], log=sys.stderr) -> None:
+  """apply_flags_for_calling (make_examples_core.py:3825-3905) + the channel list of the model
+  (make_examples_options.py:1058-1078): command line > model.example_info.json > defaults.  The
+  json's small-model flags are skipped with a note -- the small model is not built, every
+  candidate goes to the CNN -- whereas on the command line they are an error."""
+  import json
+  path = model_example_info_path(args.checkpoint, args.checkpoint_json)
+  if not path:
+    return
+  with open(path) as f:
+    info = json.load(f)
+  present = set()
+  for arg in argv:
+    if arg.startswith('--'):
+      name = arg[2:].split('=', 1)[0]
+      present.add(name)
+      if name.startswith('no'):
+        present.add(name[2:])
+  known = {a.dest: a for a in ap._actions}                       # pylint: disable=protected-access
+  for name, value in (info.get('flags_for_calling') or {}).items():
+    if name in _SMALL_MODEL_FLAGS:
+      print('make_examples: %s from %s skipped (no small model here: all candidates are classified by the CNN)'
+            % (name, path), file=log)
+      continue
+    if name not in known:
+      raise ValueError('Flag "%s" (from %s) is not defined as an application flag.' % (name, path))
+    if name in present:
+      continue
+    setattr(args, name, str(value).lower() if isinstance(value, bool) else value)
+  if ('partition_size' in present) != ('max_reads_per_partition' in present):
+    raise ValueError('Both --partition_size and --max_reads_per_partition must be set together, or not at all.')
+  channels = info.get('channels')
+  if channels:
+    by_enum = {v: k for k, v in T.CHANNEL_NAME_TO_INFO_ENUM.items()}
+    names = []
+    for c in channels:
+      if c not in by_enum:
+        raise ValueError('Channel "%s" does not map to an available opt channel' % c)
+      names.append(by_enum[c])
+    args.model_channels = names
 
 
 def _true(v) -> bool:
@@ -142,8 +208,8 @@ def check_flags(args) -> None:
   for name in ('normalize_reads', 'stream_examples', 'call_small_model_examples', 'output_phase_info'):
     if _true(getattr(args, name)):
       raise ValueError('--%s is not supported by the MI355X make_examples' % name)
-  if bool(args.call_variants_outfile) != bool(args.checkpoint):
-    raise ValueError('--call_variants_outfile and --checkpoint go together (the fused route)')
+  if args.call_variants_outfile and not args.checkpoint:
+    raise ValueError('--call_variants_outfile needs --checkpoint (the fused route)')
   if not args.examples and not args.call_variants_outfile:
     raise ValueError('--examples (or --call_variants_outfile with --checkpoint) is required')
   if _true(args.phase_reads) and not _true(args.track_ref_reads):
@@ -171,10 +237,14 @@ def options_from_flags(args):
   rr = T.ReadRequirements(min_mapping_quality=args.min_mapping_quality, min_base_quality=args.min_base_quality,
                           min_base_quality_mode=1)
   pic = T.default_options(rr)
-  channels = [c for c in args.channel_list.split(',') if c]
   alt_mode = args.alt_aligned_pileup
-  if alt_mode in ('diff_channels', 'base_channels'):
-    channels += ['%s_alternate_allele_1' % alt_mode, '%s_alternate_allele_2' % alt_mode]
+  if getattr(args, 'model_channels', None):        # the model's own list (it names the alt channels itself)
+    channels = list(args.model_channels)
+  else:
+    channels = [c for c in re.split('[, ]+', args.channel_list.replace(
+        'BASE_CHANNELS', ','.join(T.PILEUP_DEFAULT_CHANNELS))) if c]
+    if alt_mode in ('diff_channels', 'base_channels'):
+      channels += ['%s_alternate_allele_1' % alt_mode, '%s_alternate_allele_2' % alt_mode]
   pic.channels = channels
   pic.num_channels = len(channels)
   pic.width, pic.height = args.pileup_image_width, args.pileup_image_height
@@ -244,7 +314,7 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
     reads_by_contig[contig] = (reads, [utils.read_range(r) for r in reads])
   proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
   model = None
-  if args.checkpoint:
+  if args.call_variants_outfile:
     from deepvariant_amd import call_variants
     from deepvariant_amd.inception_v3 import InceptionV3
     shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
@@ -298,10 +368,12 @@ def absl_booleans(ap: argparse.ArgumentParser, argv: Sequence[str]) -> List[str]
 
 def main(argv=None) -> int:
   ap = build_arg_parser()
-  args = ap.parse_args(absl_booleans(ap, sys.argv[1:] if argv is None else argv))
+  argv = absl_booleans(ap, sys.argv[1:] if argv is None else argv)
+  args = ap.parse_args(argv)
   try:
+    apply_flags_for_calling(ap, args, argv)
     make_examples_runner(args)
-  except (ValueError, KeyError, IOError) as e:
+  except (ValueError, KeyError, IOError, OSError) as e:
     print('make_examples: %s' % e, file=sys.stderr)
     return 1
   return 0

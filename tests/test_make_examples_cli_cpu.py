@@ -52,7 +52,7 @@ def test_long_read_flags():
     (['--examples', 'e', '--normalize_reads'], '--normalize_reads is not supported'),
     (['--examples', 'e', '--stream_examples'], '--stream_examples is not supported'),
     (['--examples', 'e', '--phase_reads'], 'track_ref_reads must be set'),
-    (['--call_variants_outfile', 'cvo.tfrecord.gz'], 'go together'),
+    (['--call_variants_outfile', 'cvo.tfrecord.gz'], 'needs --checkpoint'),
     ([], '--examples'),
 ])
 def test_unsupported_flags_are_refused(argv, message):
@@ -141,3 +141,57 @@ def test_bam_round_trip(tmp_path):
                                    bytes(bytearray(b.aligned_quality)), b.alignment, b.fragment_length)
   table = packing.ReadTable.from_bam(path, 'chr20', 0, 1 << 40)
   assert table.n_reads == len(reads) == 116
+
+
+PACBIO_MODEL_JSON = {     # deepvariant/json/deepvariant.pacbio.savedmodel/model.example_info.json
+    'version': '1.10.0', 'shape': [100, 147, 10], 'channels': [1, 2, 3, 4, 5, 6, 7, 26, 9, 10],
+    'flags_for_calling': {
+        'alt_aligned_pileup': 'diff_channels', 'call_small_model_examples': True,
+        'keep_supplementary_alignments': True, 'max_reads_per_partition': 600, 'min_mapping_quality': 1,
+        'parse_sam_aux_fields': True, 'partition_size': 25000, 'phase_reads': True, 'pileup_image_height': 100,
+        'pileup_image_width': 147, 'realign_reads': False, 'small_model_indel_gq_threshold': 16,
+        'small_model_snp_gq_threshold': 15, 'small_model_vaf_context_window_size': 51, 'sort_by_haplotypes': True,
+        'track_ref_reads': True, 'trained_small_model_path': '/opt/smallmodels/pacbio',
+        'trim_reads_for_pileup': True, 'vsc_min_fraction_indels': 0.12}}
+
+
+def test_flags_for_calling_come_from_the_model_json(tmp_path):
+  """apply_flags_for_calling (make_examples_core.py:3825-3905): command line > model.example_info.json >
+  defaults; the channel list is the model's; the released PacBio model's json gives its 10-channel tensor."""
+  import io
+  import json
+  model_dir = tmp_path / 'model'
+  model_dir.mkdir()
+  (model_dir / 'saved_model.pb').write_bytes(b'')
+  (model_dir / 'model.example_info.json').write_text(json.dumps(PACBIO_MODEL_JSON))
+  ap = me.build_arg_parser()
+  argv = ['--ref', 'r', '--reads', 'b', '--examples', 'e', '--checkpoint', str(model_dir), '--vsc_min_fraction_indels',
+          '0.2']
+  args = ap.parse_args(argv)
+  log = io.StringIO()
+  me.apply_flags_for_calling(ap, args, argv, log=log)
+  me.check_flags(args)
+  options, po = me.options_from_flags(args)
+  pic = options.pic_options
+  assert [T.CHANNEL_NAME_TO_INFO_ENUM[c] for c in pic.channels] == PACBIO_MODEL_JSON['channels']
+  assert (pic.width, pic.height, pic.alt_aligned_pileup, pic.sort_by_haplotypes) == (147, 100, 'diff_channels', True)
+  assert pic.read_requirements.min_mapping_quality == 1 and options.trim_reads_for_pileup
+  assert (po.realigner_enabled, po.phase_reads, po.track_ref_reads, po.partition_size) == (False, True, True, 25000)
+  assert args.max_reads_per_partition == 600 and me._true(args.keep_supplementary_alignments)
+  assert po.vsc_min_fraction_indels == 0.2                      # the command line wins over the json's 0.12
+  assert 'call_small_model_examples' in log.getvalue()          # skipped with a note, not silently
+  # partition_size and max_reads_per_partition only together on the command line
+  argv = argv + ['--partition_size', '1000']
+  with pytest.raises(ValueError, match='must be set together'):
+    me.apply_flags_for_calling(ap, ap.parse_args(argv), argv, log=log)
+  # a json flag this program does not have at all is an error, as in the reference
+  bad = dict(PACBIO_MODEL_JSON, flags_for_calling={'no_such_flag': 1})
+  (model_dir / 'model.example_info.json').write_text(json.dumps(bad))
+  argv = ['--ref', 'r', '--reads', 'b', '--examples', 'e', '--checkpoint', str(model_dir)]
+  with pytest.raises(ValueError, match='not defined as an application flag'):
+    me.apply_flags_for_calling(ap, ap.parse_args(argv), argv, log=log)
+  # --checkpoint_json overrides the lookup; random:<seed> checkpoints have no json
+  assert me.model_example_info_path('random:1') == ''
+  assert me.model_example_info_path(str(model_dir), 'x.json') == 'x.json'
+  assert me.model_example_info_path(str(model_dir / 'ckpt-1')) == str(model_dir / 'model.example_info.json')
+  assert me.model_example_info_path(str(tmp_path / 'elsewhere' / 'ckpt-1')) == ''
