@@ -15,7 +15,9 @@ csrc/fast_pass_aligner.cpp + local_align.cpp.  A region's reads are packed ONCE
 """
 from __future__ import annotations
 
+import concurrent.futures
 import dataclasses
+import os
 from typing import List, Optional, Sequence, Tuple
 
 from deepvariant_amd import alt_aligned_pileup_lib
@@ -29,6 +31,22 @@ from deepvariant_amd.realigner.debruijn_graph import DeBruijnGraphOptions
 from deepvariant_amd.realigner.window_selector import (
     ALLELE_COUNT_LINEAR, VARIANT_READS, AlleleCountLinearModel, VariantReadsThresholdModel,
     WindowSelectorModel, WindowSelectorOptions)
+
+# Windows of a region are independent: their assembly and alignment calls (native, the GIL is
+# released inside ctypes) run on a small thread pool; results are collected in window order.
+_THREADS = max(1, int(os.environ.get('DV_REALIGN_THREADS', '4')))
+_pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
+
+
+def _map_in_order(fn, items):
+  global _pool
+  items = list(items)
+  if _THREADS == 1 or len(items) < 2:
+    return [fn(x) for x in items]
+  if _pool is None:
+    _pool = concurrent.futures.ThreadPoolExecutor(max_workers=_THREADS, thread_name_prefix='dv-realign')
+  return list(_pool.map(fn, items))
+
 
 _UNSET_WS_INT_FLAG = -1
 _REF_ALIGN_MARGIN = 20                  # realigner.py:263
@@ -274,19 +292,19 @@ class Realigner:
     if table is None:
       table = packing.ReadTable.from_reads(list(reads))
     spans = [utils.read_range(r) for r in reads]
-    out = []
-    for window in windows:
-      if window.end - window.start > self.config.ws_config.max_window_size:
-        continue
-      if not self._is_valid(window):
-        continue
+    usable = [w for w in windows
+              if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
+
+    def assemble(window):
       ref = self._query(window)
       window_reads = [i for i, s in enumerate(spans) if utils.ranges_overlap(s, window)]
       graph = debruijn_graph.build_from_table(ref, table, window_reads, self.config.dbg_config)
       haplotypes = [ref] if graph is None else graph.candidate_haplotypes()
       if haplotypes and haplotypes != [ref]:
-        out.append(CandidateHaplotypes(span=window, haplotypes=haplotypes))
-    return out
+        return CandidateHaplotypes(span=window, haplotypes=haplotypes)
+      return None
+
+    return [ch for ch in _map_in_order(assemble, usable) if ch is not None]
 
   def _aligner(self, read_size: int, force_alignment: bool, prefix_len: int, suffix_len: int):
     a = self.config.aln_config
@@ -331,8 +349,8 @@ class Realigner:
     candidate_haplotypes = self.call_debruijn_graph(windows, reads, table=table)
     assembled_regions = [AssemblyRegion(ch) for ch in candidate_haplotypes]
     realigned = assign_reads_to_assembled_regions(assembled_regions, reads)
-    for assembled_region in assembled_regions:
-      realigned.extend(self.call_fast_pass_aligner(assembled_region))
+    for aligned in _map_in_order(self.call_fast_pass_aligner, assembled_regions):
+      realigned.extend(aligned)
     return candidate_haplotypes, realigned
 
   def align_to_haplotype(self, this_haplotype: str, haplotypes: Sequence[str], prefix: str, suffix: str,
