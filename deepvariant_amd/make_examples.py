@@ -208,6 +208,9 @@ def check_flags(args) -> None:
   for name in ('normalize_reads', 'stream_examples', 'call_small_model_examples', 'output_phase_info'):
     if _true(getattr(args, name)):
       raise ValueError('--%s is not supported by the MI355X make_examples' % name)
+  if args.ws_window_selector_model:
+    raise ValueError('--ws_window_selector_model: text-proto window selector models are not parsed here '
+                     '(--ws_use_window_selector_model selects the built-in linear model)')
   if args.call_variants_outfile and not args.checkpoint:
     raise ValueError('--call_variants_outfile needs --checkpoint (the fused route)')
   if not args.examples and not args.call_variants_outfile:

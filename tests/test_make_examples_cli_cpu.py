@@ -52,6 +52,7 @@ def test_long_read_flags():
     (['--examples', 'e', '--normalize_reads'], '--normalize_reads is not supported'),
     (['--examples', 'e', '--stream_examples'], '--stream_examples is not supported'),
     (['--examples', 'e', '--phase_reads'], 'track_ref_reads must be set'),
+    (['--examples', 'e', '--ws_window_selector_model', 'm.pbtxt'], 'not parsed here'),
     (['--call_variants_outfile', 'cvo.tfrecord.gz'], 'needs --checkpoint'),
     ([], '--examples'),
 ])
