@@ -9,8 +9,8 @@ Per calling region it runs make_examples_core.RegionProcessor: reads -> (downsam
 realigner -> device allele counts -> candidate caller -> (read phasing) -> device pileup encoder.
 Flags that belong to machinery outside this path (training labels, gVCF, population VCFs,
 candidate import, multi-sample roles, sharded runtime profiles ...) are rejected when set,
-never silently ignored.  Reads are decoded by the in-package BAM reader (plain BAM with
-coordinate-sorted records; no CRAM).
+never silently ignored.  Reads come through the native BAM reader (dv_bam_read_region: plain BAM,
+.bai region queries; no CRAM).
 """
 from __future__ import annotations
 
@@ -25,6 +25,7 @@ from deepvariant_amd import dv_types as T
 from deepvariant_amd import genomics_io
 from deepvariant_amd import make_examples_core
 from deepvariant_amd import make_examples_native
+from deepvariant_amd import packing
 from deepvariant_amd import tfrecord
 from deepvariant_amd.realigner import realigner as realigner_module
 from deepvariant_amd.realigner import utils
@@ -309,11 +310,12 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   for contig in sorted({p.reference_name for p in pieces}):
     lo = min(p.start for p in pieces if p.reference_name == contig)
     hi = max(p.end for p in pieces if p.reference_name == contig)
-    _, reads = genomics_io.read_bam(args.reads, contig, lo, hi)
-    reads = [r for r in reads if genomics_io.read_satisfies_requirements(
-        r, min_mapping_quality=args.min_mapping_quality, keep_duplicates=_true(args.keep_duplicates),
-        keep_supplementary=_true(args.keep_supplementary_alignments),
-        keep_secondary=_true(args.keep_secondary_alignments))]
+    # the native reader (dv_bam_read_region: .bai region query when the index is there, parallel
+    # BGZF inflate, nucleus' read requirements), then Read objects for the host stages
+    reads = packing.ReadTable.from_bam(
+        args.reads, contig, lo, hi, min_mapping_quality=args.min_mapping_quality,
+        keep_duplicates=_true(args.keep_duplicates), keep_supplementary=_true(args.keep_supplementary_alignments),
+        keep_secondary=_true(args.keep_secondary_alignments)).to_reads(contig)
     reads_by_contig[contig] = (reads, [utils.read_range(r) for r in reads])
   proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
   model = None

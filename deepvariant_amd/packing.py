@@ -345,6 +345,39 @@ class ReadTable:
     finally:
       lib.dv_read_table_free(handle)
 
+  def to_reads(self, reference_name: str) -> List:
+    """Read objects (dv_types.Read) back from the packed table -- what the region chain's host
+    stages (realigner glue, phasing) take.  The table does not keep pairing / QC flags (the
+    native reader has already applied the read requirements), so number_reads is 2 and those
+    flags are False."""
+    seq = self.bases.tobytes().decode('latin-1')
+    quals = self.quals.tobytes()
+    seq_off = self.read_seq_off.tolist()
+    cig_off = self.read_cigar_off.tolist()
+    ops = (self.cigar & 15).tolist()
+    lens = (self.cigar >> 4).tolist()
+    pos = self.read_pos.tolist()
+    mapq = self.read_mapq.tolist()
+    flags = self.read_flags.tolist()
+    frag = self.read_frag_len.tolist()
+    hp = self.read_hp.tolist()
+    out = []
+    for i in range(self.n_reads):
+      name, _, number = self.keys[i].rpartition('/')
+      info = {}
+      if hp[i] != _lib.DV_HP_NONE:
+        info['HP'] = T.ListValue(values=[T.Value(int_value=hp[i])])
+      out.append(T.Read(
+          fragment_name=name, read_number=int(number), number_reads=2,
+          supplementary_alignment=bool(flags[i] & DV_READ_SUPPLEMENTARY), fragment_length=frag[i],
+          aligned_sequence=seq[seq_off[i]:seq_off[i + 1]], aligned_quality=quals[seq_off[i]:seq_off[i + 1]],
+          alignment=T.LinearAlignment(
+              position=T.Position(reference_name, pos[i], bool(flags[i] & DV_READ_REVERSE)),
+              mapping_quality=mapq[i],
+              cigar=[T.CigarUnit(ops[k], lens[k]) for k in range(cig_off[i], cig_off[i + 1])]),
+          info=info))
+    return out
+
   def query(self, start: int, end: int) -> np.ndarray:
     """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""
     return np.nonzero((end > self.read_pos) & (start < self.read_end))[0].astype(

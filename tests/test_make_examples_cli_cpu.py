@@ -196,3 +196,25 @@ def test_flags_for_calling_come_from_the_model_json(tmp_path):
   assert me.model_example_info_path(str(model_dir), 'x.json') == 'x.json'
   assert me.model_example_info_path(str(model_dir / 'ckpt-1')) == str(model_dir / 'model.example_info.json')
   assert me.model_example_info_path(str(tmp_path / 'elsewhere' / 'ckpt-1')) == ''
+
+
+def test_native_table_to_reads(tmp_path):
+  """packing.ReadTable.from_bam(...).to_reads(): the native reader's table turned back into Read
+  objects equals the Python BAM reader + read requirements, field by field (what the CLI feeds
+  the region chain)."""
+  from deepvariant_amd import packing
+  _, sets = RF.load()
+  reads = sets['ex2'] + sets['dbg0']
+  reads[3].info['HP'] = T.ListValue(values=[T.Value(int_value=2)])
+  path = str(tmp_path / 'r.bam')
+  genomics_io.write_bam(path, [('chr20', 63025520)], reads)
+  for lo, hi, mapq in ((0, 1 << 40, 0), (10_046_100, 10_046_200, 30)):
+    got = packing.ReadTable.from_bam(path, 'chr20', lo, hi, min_mapping_quality=mapq).to_reads('chr20')
+    _, want = genomics_io.read_bam(path, 'chr20', lo, hi)
+    want = [r for r in want if genomics_io.read_satisfies_requirements(r, min_mapping_quality=mapq)]
+    assert len(got) == len(want) > 20
+    for a, b in zip(got, want):
+      assert (a.fragment_name, a.read_number, a.aligned_sequence, bytes(a.aligned_quality), a.alignment,
+              a.fragment_length, a.supplementary_alignment, {k: v.values[0].int_value for k, v in a.info.items()}) == (
+                  b.fragment_name, b.read_number, b.aligned_sequence, bytes(bytearray(b.aligned_quality)), b.alignment,
+                  b.fragment_length, b.supplementary_alignment, {k: v.values[0].int_value for k, v in b.info.items()})
