@@ -106,6 +106,10 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
+    // DV_ABLATE_* (tools/ablate_conv.sh): timing ablations, results are WRONG by construction --
+    // _W reuses the first chunk's weight fragments, _X never refills the pixel fragments,
+    // _LOOP skips the K loop, _EPI (conv_common.h) suppresses the output stores.
+#ifndef DV_ABLATE_W
     if (j + 1 < R) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -113,6 +117,12 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
             wslab + (j + 1) * BN * kChunk + (nb * 32) * 8);
       }
     }
+#else
+    if (j + 1 < R) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wf[(j + 1) & 1][nb] = wf[j & 1][nb];
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     half8_t xh[PT];
 #pragma unroll
@@ -126,11 +136,13 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
       }
     }
     // refill the slot just consumed with chunk (current + kPrefetch)
+#ifndef DV_ABLATE_X
     const unsigned soff = walk.off();
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       xf[(S0 + j) % kPrefetch][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
     }
+#endif
     walk.advance(p);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -272,8 +284,13 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   // reads 512 contiguous bytes: conflict-free for ds_read_b128 (a [cout][16]
   // image is 2-way conflicted: measured SQ_LDS_BANK_CONFLICT ~ LDS active).
   const int frag_off = (lane >> 5) * (BN * 8) + (lane & 31) * 8;  // halfs
+#ifdef DV_ABLATE_LOOP
+  const int n_full = p.n_chunks < 0 ? 1 : 0;
+  const int rem = 0;
+#else
   const int n_full = p.n_chunks / SLAB;
   const int rem = p.n_chunks - n_full * SLAB;
+#endif
   for (int s = 0; s < n_full; ++s) {
     // The next slab's global loads are UNCONDITIONAL (the last trip re-reads its own slab
     // into the idle buffer): behind an `if` the compiler has to assume at the first
