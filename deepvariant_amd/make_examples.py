@@ -80,6 +80,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--ref', required=True)
   ap.add_argument('--reads', required=True)
   ap.add_argument('--examples', default='')
+  ap.add_argument('--candidate_positions', default='')     # output of --mode candidate_sweep
   ap.add_argument('--regions', default='')
   ap.add_argument('--task', type=int, default=0)
   ap.add_argument('--sample_name', default='')
@@ -201,8 +202,13 @@ def _true(v) -> bool:
 
 
 def check_flags(args) -> None:
-  if args.mode != 'calling':
-    raise ValueError('--mode=%s: only calling mode is built (labelling needs the truth-VCF labeler)' % args.mode)
+  if args.mode not in ('calling', 'candidate_sweep'):
+    raise ValueError('--mode=%s: calling and candidate_sweep are built (labelling needs the truth-VCF labeler)'
+                     % args.mode)
+  if args.mode == 'candidate_sweep':
+    if not args.candidate_positions:
+      raise ValueError('--mode candidate_sweep writes --candidate_positions')
+    return
   for name in _REJECTED_IF_SET:
     if getattr(args, name):
       raise ValueError('--%s is not supported by the MI355X make_examples' % name)
@@ -278,18 +284,22 @@ def options_from_flags(args):
   return options, po
 
 
+def requested_regions(args, ref_reader, contig_names: Sequence[str]) -> List[T.Range]:
+  if args.regions:
+    return [parse_region(x, ref_reader) for x in args.regions.split()]     # space-separated literals
+  regions = []
+  for name in contig_names:
+    try:
+      regions.append(T.Range(name, 0, ref_reader.n_bases(name)))
+    except KeyError:
+      continue
+  return regions
+
+
 def calling_regions(args, ref_reader, contig_names: Sequence[str], num_shards: int) -> List[T.Range]:
   """processing_regions_from_options (make_examples_core.py:836-888): the regions (or every contig
   of the BAM that the reference has), cut into partition_size pieces, this task's share round robin."""
-  if args.regions:
-    regions = [parse_region(x, ref_reader) for x in args.regions.split()]     # space-separated literals
-  else:
-    regions = []
-    for name in contig_names:
-      try:
-        regions.append(T.Range(name, 0, ref_reader.n_bases(name)))
-      except KeyError:
-        continue
+  regions = requested_regions(args, ref_reader, contig_names)
   pieces = [p for r in regions for p in make_examples_core.partition(r, args.partition_size)]
   if num_shards:
     pieces = [p for i, p in enumerate(pieces) if i % num_shards == args.task]
@@ -301,7 +311,8 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   check_flags(args)
   ref_reader = genomics_io.FastaReader(args.ref)
   options, po = options_from_flags(args)
-  out_spec = args.examples or args.call_variants_outfile
+  sweep = args.mode == 'candidate_sweep'
+  out_spec = args.candidate_positions if sweep else (args.examples or args.call_variants_outfile)
   out_path, num_shards = _shard(out_spec, args.task)
   contig_names = genomics_io.bam_contig_names(args.reads)
   pieces = calling_regions(args, ref_reader, contig_names, num_shards)
@@ -326,8 +337,29 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
              len(options.pic_options.channels))
     model = InceptionV3(shape, max_batch=1024, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
-  writer = tfrecord.Writer(out_path)
   stats = dict(n_regions=0, n_reads=0, n_candidates=0, n_examples=0)
+  if sweep:
+    # int32 positions per calling region, END_OF_PARTITION after each, END_OF_REGION where a
+    # requested region ends (make_examples_core.py:3592-3605) -- input of a later run's
+    # partitioning by candidates
+    region_ends = {(r.reference_name, r.end) for r in requested_regions(args, ref_reader, contig_names)}
+    with open(out_path, 'wb') as f:
+      for region in pieces:
+        reads, spans = reads_by_contig[region.reference_name]
+        in_reads = [r for r, s in zip(reads, spans) if utils.ranges_overlap(s, region)]
+        if args.max_reads_per_partition > 0:
+          in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))
+        positions = proc.find_candidate_positions(region, in_reads)
+        if (region.reference_name, region.end) in region_ends:
+          positions = positions + [make_examples_core.END_OF_REGION]
+        f.write(np.array(positions, np.int32).tobytes())
+        stats['n_regions'] += 1
+        stats['n_reads'] += len(in_reads)
+        stats['n_candidates'] += sum(p >= 0 for p in positions)
+    print('make_examples task %d: %d regions, %d reads, %d candidate positions -> %s' % (
+        args.task, stats['n_regions'], stats['n_reads'], stats['n_candidates'], out_path), file=log)
+    return stats
+  writer = tfrecord.Writer(out_path)
   image_shape = None
   try:
     for region in pieces:

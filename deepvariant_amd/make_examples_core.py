@@ -53,6 +53,10 @@ class RegionProcessorOptions:
   min_alleles_to_phase: int = 1
 
 
+END_OF_REGION = -1        # make_examples_core.py:125-129: markers in a candidate-positions file
+END_OF_PARTITION = -2
+
+
 def partition(region: T.Range, size: int) -> Iterator[T.Range]:
   """Calling regions of at most `size` bases, in order."""
   if size <= 0:
@@ -136,6 +140,15 @@ class RegionProcessor:
     if padded_region is not None:                 # filter_candidates_by_region, :2579-2606
       candidates = [c for c in candidates if region.start <= c.variant.start < region.end]
     return candidates
+
+  def find_candidate_positions(self, region: T.Range, reads: Sequence) -> List[int]:
+    """candidate_sweep mode (make_examples_core.py:2117-2189): the positions at which the RAW reads
+    of the region (no realigner) would make the caller emit a candidate, then END_OF_PARTITION."""
+    in_region = [r for r in reads if utils.ranges_overlap(utils.read_range(r), region)]
+    if not in_region:
+      return [END_OF_PARTITION]
+    counter = self._allele_counter(region, packing.ReadTable.from_reads(in_region))
+    return self.variant_caller.call_positions_from_allele_counter(counter) + [END_OF_PARTITION]
 
   def process(self, region: T.Range, reads: Sequence) -> Tuple[List[T.DeepVariantCall], List]:
     """-> (candidates, the region's reads as the pileup images must see them)."""

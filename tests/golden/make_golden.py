@@ -418,6 +418,9 @@ def main_realigner():
         genotype=list(c.genotype), AD=[x.int_value for x in c.info['AD'].values],
         DP=[x.int_value for x in c.info['DP'].values],
         VAF=[float(x.number_value).hex() for x in c.info['VAF'].values]))
+  # golden.candidate_positions (make_examples_test.py candidate_sweep mode): int32 positions of the raw-read
+  # candidates per 1 kb partition, -2 after each partition, -1 at the end of the region
+  d['wgs_candidate_positions'] = np.fromfile(os.path.join(REF, 'golden.candidate_positions'), np.int32)
   d['wgs_variants'] = np.frombuffer('\n'.join(lines[k] for k in sorted(lines)).encode(), np.uint8)
   np.savez_compressed(os.path.join(ROOT, 'tests/golden/realigner_chr20.npz'), **d)
 

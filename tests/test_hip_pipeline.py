@@ -299,6 +299,11 @@ def test_make_examples_cli_end_to_end(tmp_path):
   assert len(images) == len(golden) == 84
   for ex in golden:
     assert np.array_equal(images[(ex['call'].variant.start, tuple(ex['alt_alleles']))], ex['image'])
+  # candidate_sweep mode: the reference's golden.candidate_positions, byte for byte
+  sweep = str(tmp_path / 'positions.bin')
+  assert me.main(common + ['--mode', 'candidate_sweep', '--candidate_positions', sweep]) == 0
+  with np.load(RF.FIXTURE) as f:
+    assert np.fromfile(sweep, np.int32).tolist() == f['wgs_candidate_positions'].tolist()
   # fused: no tf.Examples
   cvo_path = str(tmp_path / 'cvo.tfrecord.gz')
   assert me.main(common + ['--call_variants_outfile', cvo_path, '--checkpoint', 'random:7']) == 0

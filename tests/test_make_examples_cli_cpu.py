@@ -45,7 +45,8 @@ def test_long_read_flags():
 
 
 @pytest.mark.parametrize('argv,message', [
-    (['--examples', 'e', '--mode', 'training'], 'only calling mode'),
+    (['--examples', 'e', '--mode', 'training'], 'calling and candidate_sweep are built'),
+    (['--mode', 'candidate_sweep'], 'writes --candidate_positions'),
     (['--examples', 'e', '--gvcf', 'g.tfrecord.gz'], '--gvcf is not supported'),
     (['--examples', 'e', '--truth_variants', 't.vcf.gz'], '--truth_variants is not supported'),
     (['--examples', 'e', '--population_vcfs', 'p.vcf.gz'], '--population_vcfs is not supported'),

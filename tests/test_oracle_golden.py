@@ -530,3 +530,36 @@ def test_golden_illumina_alt_aligned_chain(mode):
       full = np.concatenate([full, np.zeros(full.shape[:2] + (images.shape[3] - full.shape[2],), np.uint8)], axis=2)
     assert full.shape == images[k].shape and np.array_equal(full, images[k]), (mode, k, start, combo)
   assert len(meta) == 49 and n_alt_images >= 4      # the labelled set has few indels
+
+
+def test_golden_candidate_positions():
+  """golden.candidate_positions (make_examples_test.py, --mode candidate_sweep): per 1 kb partition the
+  positions where the RAW reads (no realigner) make the caller emit a candidate, -2 after each
+  partition, -1 at the end of the region.  Oracle counts + the product's CallVariantPosition."""
+  from deepvariant_amd import allelecounter as ac
+  from deepvariant_amd import variant_calling as vc
+  from deepvariant_amd.realigner import utils as U
+  from oracle import allelecounter_ref as AR
+  from tests import realigner_fixture as RF
+  ref, sets = RF.load()
+  with np.load(RF.FIXTURE) as f:
+    golden = f['wgs_candidate_positions'].tolist()
+  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.06))
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  got = []
+  for start in range(9_999_999, 10_010_000, 1000):
+    region = T.Range('chr20', start, min(start + 1000, 10_010_000))
+    counter = AR.AlleleCounter(ref, 'chr20', region.start, region.end, min_mapping_quality=5, min_base_quality=10)
+    for r, s in zip(reads, spans):
+      if U.ranges_overlap(s, region):
+        counter.add(r)
+    counts = []
+    for c in counter.counts:
+      a = ac.AlleleCount('chr20', c.position, c.ref_base)
+      a.ref_supporting_read_count = c.ref_supporting_read_count
+      a.read_alleles = {k: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for k, v in c.read_alleles.items()}
+      counts.append(a)
+    got += caller.call_positions_from_allele_counts(counts) + [-2]
+  got.append(-1)
+  assert got == golden and len(golden) == 94 and sum(p >= 0 for p in golden) == 82
