@@ -1,6 +1,8 @@
 // common.hip -- error handling, device buffers, profiling hooks and the small
 // host-side helpers of the C ABI (CRC32C, DownsampleReadIndices, Query).
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -39,36 +41,36 @@ void DeviceBuffer::release() {
 }
 
 // ---- profiling: event pairs around launches, summed per kind -------------
-struct EventPair {
-  hipEvent_t a, b;
-};
-static bool g_profiling = false;
-static std::vector<EventPair> g_events[kProfKinds];
-static std::vector<EventPair> g_pool;
+// Scopes on different host threads record concurrently: a scope holds its own pair and the
+// shared pool / per-kind lists are only touched under g_prof_mu.
+static std::atomic<bool> g_profiling{false};
+static std::mutex g_prof_mu;
+static std::vector<ProfileEvents> g_events[kProfKinds];
+static std::vector<ProfileEvents> g_pool;
 
+bool profiling_enabled() { return g_profiling.load(std::memory_order_relaxed); }
 
-bool profiling_enabled() { return g_profiling; }
-
-static EventPair take_pair() {
-  if (!g_pool.empty()) {
-    EventPair p = g_pool.back();
-    g_pool.pop_back();
-    return p;
+ProfileEvents profile_begin(hipStream_t stream) {
+  ProfileEvents p;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_pool.empty()) {
+      p = g_pool.back();
+      g_pool.pop_back();
+    }
   }
-  EventPair p;
-  (void)hipEventCreate(&p.a);
-  (void)hipEventCreate(&p.b);
+  if (!p.a) {
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+  }
+  (void)hipEventRecord(p.a, stream);
   return p;
 }
 
-void profile_begin(int kind, hipStream_t stream) {
-  EventPair p = take_pair();
-  (void)hipEventRecord(p.a, stream);
-  g_events[kind].push_back(p);
-}
-
-void profile_end(int kind, hipStream_t stream) {
-  (void)hipEventRecord(g_events[kind].back().b, stream);
+void profile_end(int kind, const ProfileEvents& ev, hipStream_t stream) {
+  (void)hipEventRecord(ev.b, stream);
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_events[kind].push_back(ev);
 }
 
 }  // namespace dv
@@ -86,7 +88,8 @@ int dv_device_count(void) {
 }
 
 int dv_set_profiling(int enabled) {
-  dv::g_profiling = enabled != 0;
+  dv::g_profiling.store(enabled != 0);
+  std::lock_guard<std::mutex> lock(dv::g_prof_mu);
   for (int k = 0; k < dv::kProfKinds; ++k) {
     for (auto& p : dv::g_events[k]) dv::g_pool.push_back(p);
     dv::g_events[k].clear();
@@ -95,23 +98,28 @@ int dv_set_profiling(int enabled) {
 }
 
 // Sums and clears the recorded launches of `kind`; also returns the launch
-// count through dv_last_profile_count().
-static int g_last_count = 0;
+// count through dv_last_profile_count() (of the calling thread's last dv_profile_ms).
+static thread_local int g_last_count = 0;
 
 double dv_profile_ms(int kind) {
   if (kind < 0 || kind >= dv::kProfKinds) return 0.0;
+  std::vector<dv::ProfileEvents> mine;
+  {
+    std::lock_guard<std::mutex> lock(dv::g_prof_mu);
+    mine.swap(dv::g_events[kind]);
+  }
   double total = 0.0;
   g_last_count = 0;
-  for (auto& p : dv::g_events[kind]) {
+  for (auto& p : mine) {
     if (hipEventSynchronize(p.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
       total += ms;
       ++g_last_count;
     }
-    dv::g_pool.push_back(p);
   }
-  dv::g_events[kind].clear();
+  std::lock_guard<std::mutex> lock(dv::g_prof_mu);
+  for (auto& p : mine) dv::g_pool.push_back(p);
   return total;
 }
 
@@ -120,8 +128,8 @@ int dv_last_profile_count(void) { return g_last_count; }
 // CRC32C, slicing-by-8 tables (Castagnoli polynomial, reflected 0x82F63B78).
 uint32_t dv_crc32c(const uint8_t* data, size_t n) {
   static uint32_t table[8][256];
-  static bool init = false;
-  if (!init) {
+  static std::once_flag once;
+  std::call_once(once, [] {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
@@ -130,8 +138,7 @@ uint32_t dv_crc32c(const uint8_t* data, size_t n) {
     for (int k = 1; k < 8; ++k)
       for (uint32_t i = 0; i < 256; ++i)
         table[k][i] = (table[k - 1][i] >> 8) ^ table[0][table[k - 1][i] & 0xFF];
-    init = true;
-  }
+  });
   uint32_t crc = 0xFFFFFFFFu;
   while (n >= 8) {
     uint32_t lo, hi;

@@ -34,18 +34,25 @@ struct DeviceBuffer {
 
 // Optional per-launch timing with HIP events on the launch stream.
 enum ProfileKind { kProfEncoder = 0, kProfConv = 1, kProfOther = 2, kProfKinds = 3 };
+// Callable from any number of host threads: a scope owns its event pair between begin and
+// end, the shared lists behind them are guarded by a mutex (common.hip).
+struct ProfileEvents {
+  hipEvent_t a = nullptr, b = nullptr;
+};
 bool profiling_enabled();
-void profile_begin(int kind, hipStream_t stream);
-void profile_end(int kind, hipStream_t stream);
+ProfileEvents profile_begin(hipStream_t stream);
+void profile_end(int kind, const ProfileEvents& ev, hipStream_t stream);
 
 struct ProfileScope {
   int kind;
   hipStream_t stream;
-  ProfileScope(int k, hipStream_t s) : kind(k), stream(s) {
-    if (profiling_enabled()) profile_begin(kind, stream);
+  bool on;
+  ProfileEvents ev;
+  ProfileScope(int k, hipStream_t s) : kind(k), stream(s), on(profiling_enabled()) {
+    if (on) ev = profile_begin(stream);
   }
   ~ProfileScope() {
-    if (profiling_enabled()) profile_end(kind, stream);
+    if (on) profile_end(kind, ev, stream);
   }
 };
 

@@ -678,7 +678,9 @@ struct dv_encoder {
   dv_encoder_options opt{};
   EncConst konst{};
   dv::DeviceBuffer d_konst, d_perm_off, d_perm, d_out, d_rows;
-  int perm_cap = 0;
+  int perm_dense = 0;                    // pi_n is present for every n <= perm_dense
+  std::vector<uint32_t> perm_off_host;   // [n] -> offset into perm_host, kPermAbsent if not built
+  std::vector<uint16_t> perm_host;
   std::vector<dv::DeviceBuffer> staging;
 };
 
@@ -772,6 +774,10 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
         ref = static_cast<uint8_t>(o.allele_unsupporting_read_alpha);  // sic (:61-65)
         break;
       case DV_CH_ALLELE_SAMPLE_PROBABILITY: kind = kAuxList; ref = 0; break;
+      case DV_CH_READ_SUPPORTS_VARIANT_FUZZY:  // read_supports_variant_fuzzy_channel.cc:115-119
+        kind = kAuxList;
+        ref = k->lut_support[0];
+        break;
       default:
         return dv::fail(DV_ERR_UNSUPPORTED,
                         "channel enum " + std::to_string(o.channels[c]) +
@@ -779,6 +785,15 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
     }
     k->kind[c] = kind;
     k->ref_const[c] = ref;
+  }
+  {  // list_aux is ONE byte per (item, read): at most one channel can be drawn from it
+    int n_list_aux = 0;
+    for (int c = 0; c < o.n_channels; ++c) n_list_aux += k->kind[c] == kAuxList ? 1 : 0;
+    if (n_list_aux > 1) {
+      return dv::fail(DV_ERR_UNSUPPORTED,
+                      "at most one of allele_frequency / read_supports_variant_fuzzy / "
+                      "allele_sample_probability per channel set");
+    }
   }
   for (int d = 0; d < DV_MAX_CHANNELS / 4; ++d) {
     k->ref_konst[d] = 0;
@@ -797,38 +812,90 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
   return DV_OK;
 }
 
-// Uploads pi_n for every n <= cap.  pi_n is a pure function of (n, seed)
-// because the reference passes the generator by value into
-// DownsampleReadIndices (pileup_image_native.cc:153-165,327,343).
-int ensure_perm_table(dv_encoder* enc, int need) {
-  if (need <= enc->perm_cap) return DV_OK;
-  int cap = std::max(256, enc->perm_cap);
-  while (cap < need) cap *= 2;
-  if (cap > 65535) {
+// pi_n (DownsampleReadIndices' permutation of n read indices) is a pure function of
+// (n, seed) because the reference passes the generator by value
+// (pileup_image_native.cc:153-165,327,343), so it is a table lookup on the device.
+// The table is DENSE for n <= kPermDense (every depth a whole-genome run meets; grown by
+// doubling) and SPARSE above it: a pile-up deeper than that (amplicon data) adds only the
+// permutations of the depths that actually occur, so a 10,000-deep item costs 20 KB and
+// one shuffle instead of a quadratic table of every n below it.
+constexpr int kPermDense = 1024;
+constexpr uint32_t kPermAbsent = 0xFFFFFFFFu;
+
+void append_perm(dv_encoder* enc, int n) {
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::mt19937_64 gen(enc->opt.random_seed);
+  std::shuffle(idx.begin(), idx.end(), gen);
+  enc->perm_off_host[n] = static_cast<uint32_t>(enc->perm_host.size());
+  for (int i = 0; i < n; ++i) enc->perm_host.push_back(static_cast<uint16_t>(idx[i]));
+}
+
+// Makes pi_n available for every n <= min(max_n, kPermDense) and for every n in `deep`.
+int ensure_perm_table(dv_encoder* enc, int max_n, const std::vector<int>& deep) {
+  if (max_n > 65535) {
     return dv::fail(DV_ERR_UNSUPPORTED, "more than 65535 reads in one pileup");
   }
-  std::vector<uint32_t> off(cap + 2, 0);
-  size_t total = 0;
-  for (int n = 0; n <= cap; ++n) {
-    off[n] = static_cast<uint32_t>(total);
-    total += n;
+  bool changed = false;
+  if (static_cast<int>(enc->perm_off_host.size()) < max_n + 2) {
+    enc->perm_off_host.resize(max_n + 2, kPermAbsent);
+    changed = true;
   }
-  std::vector<uint16_t> perm(total);
-  std::vector<int> idx;
-  for (int n = 2; n <= cap; ++n) {
-    idx.resize(n);
-    std::iota(idx.begin(), idx.end(), 0);
-    std::mt19937_64 gen(enc->opt.random_seed);
-    std::shuffle(idx.begin(), idx.end(), gen);
-    for (int i = 0; i < n; ++i) perm[off[n] + i] = static_cast<uint16_t>(idx[i]);
+  const int want_dense = std::min(max_n, kPermDense);
+  if (want_dense > enc->perm_dense) {
+    int cap = std::max(256, enc->perm_dense);
+    while (cap < want_dense) cap *= 2;
+    cap = std::min(cap, kPermDense);
+    if (static_cast<int>(enc->perm_off_host.size()) < cap + 2) {
+      enc->perm_off_host.resize(cap + 2, kPermAbsent);
+    }
+    for (int n = enc->perm_dense + 1; n <= cap; ++n) {
+      if (enc->perm_off_host[n] == kPermAbsent) append_perm(enc, n);
+    }
+    enc->perm_dense = cap;
+    changed = true;
   }
-  if (int rc = enc->d_perm_off.reserve(off.size() * 4)) return rc;
-  if (int rc = enc->d_perm.reserve(std::max<size_t>(perm.size() * 2, 16))) return rc;
-  DV_HIP_CHECK(hipMemcpy(enc->d_perm_off.ptr, off.data(), off.size() * 4,
-                         hipMemcpyHostToDevice));
-  DV_HIP_CHECK(hipMemcpy(enc->d_perm.ptr, perm.data(), perm.size() * 2,
-                         hipMemcpyHostToDevice));
-  enc->perm_cap = cap;
+  for (int n : deep) {
+    if (n > enc->perm_dense && enc->perm_off_host[n] == kPermAbsent) {
+      append_perm(enc, n);
+      changed = true;
+    }
+  }
+  if (!changed) return DV_OK;
+  // (reserve() may free the old allocation: hipFree waits for the kernels that read it)
+  if (int rc = enc->d_perm_off.reserve(enc->perm_off_host.size() * 4)) return rc;
+  if (int rc = enc->d_perm.reserve(std::max<size_t>(enc->perm_host.size() * 2, 16))) return rc;
+  DV_HIP_CHECK(hipMemcpy(enc->d_perm_off.ptr, enc->perm_off_host.data(),
+                         enc->perm_off_host.size() * 4, hipMemcpyHostToDevice));
+  if (!enc->perm_host.empty()) {
+    DV_HIP_CHECK(hipMemcpy(enc->d_perm.ptr, enc->perm_host.data(), enc->perm_host.size() * 2,
+                           hipMemcpyHostToDevice));
+  }
+  return DV_OK;
+}
+
+// The list lengths above the dense range, from the batch's item_list_off (read back from
+// the device for a DV_MEM_DEVICE batch -- only when max_list_len says such items may exist).
+int deep_list_lengths(const dv_encoder* enc, const dv_batch* b, hipStream_t stream,
+                      std::vector<int>* deep) {
+  deep->clear();
+  if (static_cast<int>(b->max_list_len) <= kPermDense) return DV_OK;
+  std::vector<uint32_t> tmp;
+  const uint32_t* off = b->item_list_off;
+  if (b->memory != DV_MEM_HOST) {
+    tmp.resize(static_cast<size_t>(b->n_items) + 1);
+    DV_HIP_CHECK(hipStreamSynchronize(stream));
+    DV_HIP_CHECK(hipMemcpy(tmp.data(), b->item_list_off, tmp.size() * 4, hipMemcpyDeviceToHost));
+    off = tmp.data();
+  }
+  for (int i = 0; i < b->n_items; ++i) {
+    const uint32_t n = off[i + 1] - off[i];
+    if (n > b->max_list_len) return dv::fail(DV_ERR_INVALID_ARGUMENT, "max_list_len too small");
+    if (static_cast<int>(n) > kPermDense) deep->push_back(static_cast<int>(n));
+  }
+  std::sort(deep->begin(), deep->end());
+  deep->erase(std::unique(deep->begin(), deep->end()), deep->end());
+  (void)enc;
   return DV_OK;
 }
 
@@ -881,7 +948,7 @@ int dv_encoder_create(const dv_encoder_options* options, int device,
     hipError_t e = hipMemcpy(enc->d_konst.ptr, &k, sizeof(k), hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = dv::fail(DV_ERR_HIP, hipGetErrorString(e));
   }
-  if (rc == DV_OK) rc = ensure_perm_table(enc, 256);
+  if (rc == DV_OK) rc = ensure_perm_table(enc, 256, {});
   if (rc != DV_OK) {
     dv_encoder_destroy(enc);
     return rc;
@@ -973,7 +1040,11 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   DV_HIP_CHECK(hipSetDevice(enc->device));
-  if (int rc = ensure_perm_table(enc, static_cast<int>(b->max_list_len))) return rc;
+  {
+    std::vector<int> deep;
+    if (int rc = deep_list_lengths(enc, b, stream, &deep)) return rc;
+    if (int rc = ensure_perm_table(enc, static_cast<int>(b->max_list_len), deep)) return rc;
+  }
 
   const int W = enc->opt.width;
   const size_t row_bytes = static_cast<size_t>(W) * out_channels;

@@ -204,6 +204,10 @@ class Variant:
   reference_bases: str = ''
   alternate_bases: List[str] = field(default_factory=list)
   calls: List[VariantCall] = field(default_factory=list)
+  # variant.info (e.g. ALT_PS, the per-allele phase the fuzzy support channel reads) and the
+  # alt alleles the caller rejected (variants.proto:75,90)
+  info: Dict[str, ListValue] = field(default_factory=dict)
+  alternate_bases_rejected: List[str] = field(default_factory=list)
   # Opaque serialized form when the variant was decoded from the wire; used to
   # re-emit `variant/encoded` byte-for-byte.
   serialized: Optional[bytes] = None
@@ -231,6 +235,7 @@ class DeepVariantCall:
   variant: Variant = field(default_factory=Variant)
   allele_support: Dict[str, SupportingReads] = field(default_factory=dict)
   allele_frequency: Dict[str, float] = field(default_factory=dict)
+  rejected_allele_support: Dict[str, SupportingReads] = field(default_factory=dict)
   ref_support: List[str] = field(default_factory=list)
   # allele_support_ext[allele].read_infos / ref_support_ext.read_infos (track_ref_reads, phasing)
   allele_support_ext: Dict[str, List[ReadSupport]] = field(default_factory=dict)

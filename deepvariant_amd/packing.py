@@ -28,7 +28,7 @@ DV_READ_REVERSE, DV_READ_SUPPLEMENTARY, DV_READ_HAS_5MC, DV_READ_HAS_6MA = 1, 2,
 _READ_AUX_SLOT = {11: 0, 12: 1, 13: 2, 14: 3, 15: 4}
 _SEQ_AUX_CHANNELS = (16, 17)        # is_homopolymer, homopolymer_weighted: per-base pixels
 _REF_AUX_CHANNELS = (15, 16, 17)    # ... and gc_content: per-window reference-row pixels
-_LIST_AUX_CHANNELS = (8, 27)
+_LIST_AUX_CHANNELS = (8, 25, 27)   # one pixel per (item, read), computed on the host
 
 
 def channel_enums(pic_options) -> List[int]:
@@ -441,6 +441,108 @@ def allele_frequency_pixels(pic_options, dv_call, alt_alleles, table, read_idx
       log10_af = np.float32(np.log10(np.float64(af)))
       out[j] = int(((log10_min - log10_af) / log10_min) * np.float32(254)) & 0xFF
   return out
+
+
+def fuzzy_read_supports_alt(dv_call, alt_alleles: Sequence[str], key: str, hp_value: int) -> int:
+  """ReadSupportsVariantFuzzyChannel::ReadSupportsAlt
+  (channels/read_supports_variant_fuzzy_channel.cc:119-288) for the read `key` with HP tag
+  `hp_value` (0 = no tag): 1 = supports an alt of the image, 10 / 9 = supports another
+  allele of the same phase that is one / two bases longer or shorter than an alt of the
+  image, 2 = supports some other alt, 0 = none of these."""
+  variant = dv_call.variant
+  all_alts = list(variant.alternate_bases)
+  image_alts = list(alt_alleles)
+  # CalculateAlelePhases: ALT_PS value i + 1 belongs to alt allele i (value 0 is the reference's)
+  phases = [0] * len(all_alts)
+  info = getattr(variant, 'info', None) or {}
+  if 'ALT_PS' in info:
+    values = info['ALT_PS'].values
+    for i in range(len(all_alts)):
+      phases[i] = int(values[i + 1].int_value) if len(values) > i + 1 else 0
+
+  def read_support(allele: str, names) -> int:   # CalculateReadSupport
+    if key not in names:
+      return 0
+    if allele in image_alts:
+      return 1
+    for image_alt in image_alts:
+      g = all_alts.index(image_alt) if image_alt in all_alts else len(all_alts)
+      if g >= len(phases):   # CHECK_LT(image_alt_allele_global_index, alt_allele_phases.size())
+        raise ValueError('alt allele %r of the image is not an alt of the candidate' % image_alt)
+      if phases[g] == 0 or hp_value == 0 or phases[g] == hp_value:
+        d = abs(len(image_alt) - len(allele))
+        if d == 1:
+          return 10
+        if d == 2:
+          return 9
+    return 2
+
+  support = dv_call.allele_support
+  for alt in all_alts:
+    if alt in support:
+      rs = read_support(alt, support[alt].read_names)
+      if rs in (1, 10, 9):
+        return rs
+  rejected = getattr(dv_call, 'rejected_allele_support', None) or {}
+  for alt in getattr(variant, 'alternate_bases_rejected', None) or []:
+    if alt in rejected:
+      rs = read_support(alt, rejected[alt].read_names)
+      if rs != 0:
+        return rs
+  if dv_call.ref_support:
+    rs = read_support(variant.reference_bases, dv_call.ref_support)
+    if rs in (10, 9):
+      return rs
+  return 0
+
+
+def fuzzy_support_color(pic_options, code: int) -> int:
+  """ReadSupportsVariantFuzzyChannel::SupportsAltColor (:290-312), fp32 like the reference."""
+  if code == 0:
+    alpha = np.float32(pic_options.allele_unsupporting_read_alpha)
+  elif code == 1:
+    alpha = np.float32(pic_options.allele_supporting_read_alpha)
+  elif code == 10:
+    alpha = np.float32(0.90)
+  elif code == 9:
+    alpha = np.float32(0.80)
+  elif code == 8:
+    alpha = np.float32(0.70)
+  elif code == 2:
+    alpha = np.float32(pic_options.other_allele_supporting_read_alpha)
+  else:
+    raise ValueError('read_supports_alt can only be 0/1/8/9/10/2')
+  return int(np.float32(254.0) * alpha) & 0xFF
+
+
+def fuzzy_support_pixels(pic_options, dv_call, alt_alleles, table, read_idx) -> np.ndarray:
+  """The read_supports_variant_fuzzy pixel of every listed read (constant along the read,
+  so it travels in list_aux like the allele-frequency pixel)."""
+  out = np.zeros(len(read_idx), np.uint8)
+  sets = _FuzzyCall(dv_call)
+  for j, r in enumerate(read_idx):
+    hp = int(table.read_hp[r])
+    code = fuzzy_read_supports_alt(sets, alt_alleles, table.keys[r],
+                                   0 if hp == _lib.DV_HP_NONE else hp)
+    out[j] = fuzzy_support_color(pic_options, code)
+  return out
+
+
+class _FuzzyCall:
+  """A DeepVariantCall view whose read-name lists are sets (membership is all the fuzzy
+  channel asks of them), so a deep pile-up does not rescan the lists per read."""
+
+  class _Names:
+    def __init__(self, names):
+      self.read_names = frozenset(names)
+
+  def __init__(self, dv_call):
+    self.variant = dv_call.variant
+    self.allele_support = {k: self._Names(v.read_names)
+                           for k, v in dv_call.allele_support.items()}
+    rej = getattr(dv_call, 'rejected_allele_support', None) or {}
+    self.rejected_allele_support = {k: self._Names(v.read_names) for k, v in rej.items()}
+    self.ref_support = frozenset(dv_call.ref_support or [])
 
 
 def _native_names(table: 'ReadTable'):

@@ -73,6 +73,10 @@ class PileupImageEncoderNative:
       raise NotImplementedError(
           'allele_sample_probability iterates a proto map in hash order in the '
           'reference; not reproduced')
+    if sum(e in packing._LIST_AUX_CHANNELS for e in self._channel_enums) > 1:
+      raise NotImplementedError(
+          'allele_frequency and read_supports_variant_fuzzy in one channel set: the packed '
+          'batch carries one host-computed pixel per (candidate, read)')
     self._encoders: Dict[int, _Encoder] = {}
 
   # ------------------------------------------------------------------ helpers
@@ -97,6 +101,8 @@ class PileupImageEncoderNative:
   def _list_aux(self, dv_call, alt_alleles, table, idx):
     if not self._need_list_aux:
       return None
+    if 25 in self._channel_enums:
+      return packing.fuzzy_support_pixels(self._options, dv_call, alt_alleles, table, idx)
     return packing.allele_frequency_pixels(self._options, dv_call, alt_alleles,
                                            table, idx)
 

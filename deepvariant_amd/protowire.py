@@ -165,10 +165,38 @@ def encode_example(features: Dict[str, object]) -> bytes:
 
 # -------------------------------------------------------------------- Variant
 
+def _decode_info_entry(buf):
+  """One entry of a map<string, ListValue> (variants.proto:90,162) -> (key, ListValue)."""
+  key, lv = None, T.ListValue()
+  for f3, _, v3 in iter_fields(buf):
+    if f3 == 1:
+      key = bytes(v3).decode()
+    elif f3 == 2:
+      for f4, _, v4 in iter_fields(v3):
+        if f4 != 1:
+          continue
+        item = T.Value()
+        for f5, wt5, v5 in iter_fields(v4):
+          if f5 == 7:
+            item.int_value = to_signed64(v5)
+          elif f5 == 2:
+            item.number_value = struct.unpack('<d', bytes(v5))[0] if wt5 != 0 else float(v5)
+          elif f5 == 3:
+            item.string_value = bytes(v5).decode()
+        lv.values.append(item)
+  return key, lv
+
+
 def decode_variant(buf) -> T.Variant:
   v = T.Variant(serialized=bytes(buf))
   for f, wt, val in iter_fields(buf):
-    if f == 14:
+    if f == 10:                                       # variant.info
+      key, lv = _decode_info_entry(val)
+      if key is not None:
+        v.info[key] = lv
+    elif f == 17:
+      v.alternate_bases_rejected.append(bytes(val).decode())
+    elif f == 14:
       v.reference_name = bytes(val).decode()
     elif f == 16:
       v.start = to_signed64(val)
@@ -182,23 +210,7 @@ def decode_variant(buf) -> T.Variant:
       call = T.VariantCall()
       for f2, wt2, v2 in iter_fields(val):
         if f2 == 2:                                   # info map entry
-          key, lv = None, T.ListValue()
-          for f3, _, v3 in iter_fields(v2):
-            if f3 == 1:
-              key = bytes(v3).decode()
-            elif f3 == 2:
-              for f4, _, v4 in iter_fields(v3):
-                if f4 != 1:
-                  continue
-                item = T.Value()
-                for f5, wt5, v5 in iter_fields(v4):
-                  if f5 == 7:
-                    item.int_value = to_signed64(v5)
-                  elif f5 == 2:
-                    item.number_value = struct.unpack('<d', bytes(v5))[0] if wt5 != 0 else float(v5)
-                  elif f5 == 3:
-                    item.string_value = bytes(v5).decode()
-                lv.values.append(item)
+          key, lv = _decode_info_entry(v2)
           if key is not None:
             call.info[key] = lv
         elif f2 == 9:
@@ -300,6 +312,15 @@ def decode_deepvariant_call(buf) -> T.DeepVariantCall:
           names = [bytes(v3).decode() for f3, _, v3 in iter_fields(v2)
                    if f3 == 1]
       call.allele_support[key] = T.SupportingReads(read_names=names)
+    elif f == 10:  # rejected_allele_support
+      key, names = '', []
+      for f2, _, v2 in iter_fields(val):
+        if f2 == 1:
+          key = bytes(v2).decode()
+        elif f2 == 2:
+          names = [bytes(v3).decode() for f3, _, v3 in iter_fields(v2)
+                   if f3 == 1]
+      call.rejected_allele_support[key] = T.SupportingReads(read_names=names)
     elif f == 3:  # map<string, float>
       key, fv = '', 0.0
       for f2, _, v2 in iter_fields(val):

@@ -68,6 +68,7 @@ enum {
   DV_CH_MEAN_COVERAGE = 22,
   DV_CH_BASE_METHYLATION = 23,
   DV_CH_BASE_6MA = 24,
+  DV_CH_READ_SUPPORTS_VARIANT_FUZZY = 25, /* pixel supplied in list_aux */
   DV_CH_SUPPLEMENTARY_ALIGNMENT = 26,
   DV_CH_ALLELE_SAMPLE_PROBABILITY = 27, /* pixel supplied in list_aux */
 };

@@ -151,6 +151,18 @@ typedef struct dvo_call {
   const char* const* af_alleles;
   const float* af_values;
   int32_t n_ref_support;
+  /* read_supports_variant_fuzzy only (channels/read_supports_variant_fuzzy_channel.cc) */
+  const char* reference_bases;          /* variant.reference_bases, NULL -> "" */
+  const char* const* ref_support_names; /* ref_support[n_ref_support], may be NULL */
+  int32_t alt_ps_present;               /* variant.info contains "ALT_PS" */
+  int32_t n_alt_ps;                     /* info["ALT_PS"].values_size() */
+  const int32_t* alt_ps;                /* values(i).int_value() */
+  int32_t n_rejected_alts;              /* variant.alternate_bases_rejected */
+  const char* const* rejected_alts;
+  int32_t n_rejected_support;           /* rejected_allele_support entries */
+  const char* const* rejected_support_alleles;
+  const int32_t* rejected_support_offsets; /* [n_rejected_support+1] */
+  const char* const* rejected_support_names;
 } dvo_call;
 
 const char* dvo_last_error(void);
@@ -181,6 +193,10 @@ int dvo_build_pileup(const dvo_options* opt, const dvo_call* call,
                      const int64_t* alignment_positions,
                      const int32_t* channels_to_blank, int n_blank,
                      uint8_t* out_hwc, int32_t* out_row_read);
+
+/* ReadSupportsVariantFuzzyChannel::ReadSupportsAlt: 0 / 1 / 2 / 10 / 9. */
+int dvo_fuzzy_read_supports_alt(const dvo_call* call, const dvo_read* read,
+                                const char* const* alt_alleles, int n_alt_alleles);
 
 /* DownsampleReadIndices (pileup_image_native.cc:153-165): iota, shuffled with
  * std::mt19937_64(seed) iff n > max_reads.  out[n]. */

@@ -83,6 +83,7 @@ struct ReadChannels {
   int n_alt_alleles;
 
   std::optional<unsigned char> supports_variant_color;
+  std::optional<unsigned char> fuzzy_color;
   std::optional<unsigned char> insert_size_color;
   std::optional<unsigned char> haplotype_color;
   std::optional<unsigned char> allele_frequency_color;
@@ -162,6 +163,109 @@ struct ReadChannels {
       alpha = opt.allele_unsupporting_read_alpha;
     } else if (read_supports_alt == 1) {
       alpha = opt.allele_supporting_read_alpha;
+    } else {
+      alpha = opt.other_allele_supporting_read_alpha;
+    }
+    return static_cast<int>(kMaxPixelValueAsFloat * alpha);
+  }
+
+  // ---- channels/read_supports_variant_fuzzy_channel.cc ---------------------
+  // CalculateAlelePhases (:78-99): ALT_PS value i+1 is alt allele i's phase.
+  std::vector<int> FuzzyAllelePhases(int num_alt_alleles) const {
+    std::vector<int> phases(num_alt_alleles, 0);
+    if (call->alt_ps_present) {
+      for (int i = 0; i < num_alt_alleles; ++i) {
+        phases[i] = call->n_alt_ps > i + 1 ? call->alt_ps[i + 1] : 0;
+      }
+    }
+    return phases;
+  }
+
+  // CalculateReadSupport (:119-186) over one allele's supporting read names.
+  int FuzzyReadSupport(const std::string& alt_allele, const char* const* names, int n_names,
+                       const std::string& key, const std::vector<int>& phases) const {
+    for (int n = 0; n < n_names; ++n) {
+      const std::string read_name = names[n];
+      const bool alt_in_alt_alleles = InAltAlleles(alt_allele);
+      if (read_name == key && alt_in_alt_alleles) {
+        return 1;
+      } else if (read_name == key && !alt_in_alt_alleles) {
+        for (int ia = 0; ia < n_alt_alleles; ++ia) {
+          int global = 0;
+          for (int a = 0; a < call->n_alts; ++a) {
+            if (std::string(call->alts[a]) == alt_alleles[ia]) break;
+            ++global;
+          }
+          if (global >= static_cast<int>(phases.size())) {  // CHECK_LT (:147)
+            const_cast<ReadChannels*>(this)->error = true;
+            return 0;
+          }
+          int hp_value = 0;  // read.info["HP"].values(0).int_value(), 0 if absent (:149-155)
+          if (read->hp_present && read->hp_n_values > 0) {
+            hp_value = read->hp_is_int ? read->hp_value : 0;
+          }
+          if (phases[global] == 0 || hp_value == 0 ||
+              (phases[global] == hp_value && hp_value != 0)) {
+            const int d = std::abs(static_cast<int>(strlen(alt_alleles[ia])) -
+                                   static_cast<int>(alt_allele.size()));
+            if (d == 1) return 10;  // kFuzzySupportValueOneBaseDifference
+            if (d == 2) return 9;   // kFuzzySupportValueTwoBasesDifference
+          }
+        }
+        return 2;
+      }
+    }
+    return 0;
+  }
+
+  // ReadSupportsAlt (:205-288): called alts, then rejected alts, then the reference allele.
+  int FuzzyReadSupportsAlt() const {
+    const std::string key = ReadKey(*read);
+    const std::vector<int> phases = FuzzyAllelePhases(call->n_alts);
+    for (int a = 0; a < call->n_alts; ++a) {
+      const std::string alt_allele = call->alts[a];
+      const int s = FindSupport(alt_allele);
+      if (s >= 0) {
+        const int rs = FuzzyReadSupport(
+            alt_allele, call->support_names + call->support_offsets[s],
+            call->support_offsets[s + 1] - call->support_offsets[s], key, phases);
+        if (rs == 1 || rs == 10 || rs == 9) return rs;
+      }
+    }
+    for (int a = 0; a < call->n_rejected_alts; ++a) {
+      const std::string alt_allele = call->rejected_alts[a];
+      for (int s = 0; s < call->n_rejected_support; ++s) {
+        if (alt_allele != call->rejected_support_alleles[s]) continue;
+        const int rs = FuzzyReadSupport(
+            alt_allele, call->rejected_support_names + call->rejected_support_offsets[s],
+            call->rejected_support_offsets[s + 1] - call->rejected_support_offsets[s], key,
+            phases);
+        if (rs != 0) return rs;
+        break;
+      }
+    }
+    if (call->n_ref_support > 0 && call->ref_support_names != nullptr) {
+      const std::string ref = call->reference_bases ? call->reference_bases : "";
+      const int rs = FuzzyReadSupport(ref, call->ref_support_names, call->n_ref_support, key,
+                                      phases);
+      if (rs == 10 || rs == 9) return rs;
+    }
+    return 0;
+  }
+
+  // SupportsAltColor (:290-312)
+  int FuzzySupportsAltColor(int read_supports_alt) const {
+    float alpha;
+    if (read_supports_alt == 0) {
+      alpha = opt.allele_unsupporting_read_alpha;
+    } else if (read_supports_alt == 1) {
+      alpha = opt.allele_supporting_read_alpha;
+    } else if (read_supports_alt == 10) {
+      alpha = 0.90;  // kReadSupportAltWithinOneBase (a float in the reference)
+    } else if (read_supports_alt == 9) {
+      alpha = 0.80;  // kReadSupportAltWithinTwoBases
+    } else if (read_supports_alt == 8) {
+      alpha = 0.70;
     } else {
       alpha = opt.other_allele_supporting_read_alpha;
     }
@@ -358,6 +462,12 @@ struct ReadChannels {
         }
         data[col] = supports_variant_color.value();
         return true;
+      case DVO_CH_READ_SUPPORTS_VARIANT_FUZZY:  // read_supports_variant_fuzzy_channel.cc:101-113
+        if (!fuzzy_color.has_value()) {
+          fuzzy_color = static_cast<unsigned char>(FuzzySupportsAltColor(FuzzyReadSupportsAlt()));
+        }
+        data[col] = fuzzy_color.value();
+        return true;
       case DVO_CH_BASE_DIFFERS_FROM_REF:  // base_differs_from_ref_channel.cc:43-51
         data[col] = MatchesRefColor(read_base == ref_base);
         return true;
@@ -520,6 +630,9 @@ bool FillRefBase(const dvo_options& opt, int ch,
       return true;
     case DVO_CH_READ_SUPPORTS_VARIANT:  // read_supports_variant_channel.cc:68-72
       ref_data[col] = rc.SupportsAltColor(0);
+      return true;
+    case DVO_CH_READ_SUPPORTS_VARIANT_FUZZY:  // read_supports_variant_fuzzy_channel.cc:115-119
+      ref_data[col] = rc.FuzzySupportsAltColor(0);
       return true;
     case DVO_CH_BASE_DIFFERS_FROM_REF:  // base_differs_from_ref_channel.cc:53-57
       ref_data[col] = rc.MatchesRefColor(true);
@@ -980,6 +1093,16 @@ int dvo_build_pileup(const dvo_options* opt, const dvo_call* call,
     for (size_t i = 0; i < row_read.size(); ++i) out_row_read[i] = row_read[i];
   }
   return n;
+}
+
+int dvo_fuzzy_read_supports_alt(const dvo_call* call, const dvo_read* read,
+                                const char* const* alt_alleles, int n_alt_alleles) {
+  dvo_options opt;
+  memset(&opt, 0, sizeof(opt));
+  ReadChannels rc{opt, call, read, alt_alleles, n_alt_alleles};
+  const int rs = rc.FuzzyReadSupportsAlt();
+  if (rc.error) return fail("CHECK_LT(image_alt_allele_global_index, alt_allele_phases.size())");
+  return rs;
 }
 
 int dvo_downsample_indices(int n, int max_reads, uint32_t seed, int32_t* out) {

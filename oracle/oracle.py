@@ -85,6 +85,15 @@ class DvoCall(C.Structure):
       ('n_af', C.c_int32), ('af_alleles', C.POINTER(C.c_char_p)),
       ('af_values', C.POINTER(C.c_float)),
       ('n_ref_support', C.c_int32),
+      ('reference_bases', C.c_char_p),
+      ('ref_support_names', C.POINTER(C.c_char_p)),
+      ('alt_ps_present', C.c_int32), ('n_alt_ps', C.c_int32),
+      ('alt_ps', C.POINTER(C.c_int32)),
+      ('n_rejected_alts', C.c_int32), ('rejected_alts', C.POINTER(C.c_char_p)),
+      ('n_rejected_support', C.c_int32),
+      ('rejected_support_alleles', C.POINTER(C.c_char_p)),
+      ('rejected_support_offsets', C.POINTER(C.c_int32)),
+      ('rejected_support_names', C.POINTER(C.c_char_p)),
   ]
 
 
@@ -262,7 +271,33 @@ def _make_call(dv_call, keep: _Keep) -> DvoCall:
   c.af_alleles = _str_array(af_keys, keep)
   af_vals = keep(np.array([af[k] for k in af_keys] or [0], dtype=np.float32))
   c.af_values = af_vals.ctypes.data_as(C.POINTER(C.c_float))
-  c.n_ref_support = len(getattr(dv_call, 'ref_support', []) or [])
+  ref_support = list(getattr(dv_call, 'ref_support', []) or [])
+  c.n_ref_support = len(ref_support)
+  # read_supports_variant_fuzzy inputs
+  c.reference_bases = keep((dv_call.variant.reference_bases or '').encode())
+  c.ref_support_names = _str_array(ref_support, keep)
+  info = getattr(dv_call.variant, 'info', None) or {}
+  if 'ALT_PS' in info:
+    vals = [int(v.int_value) for v in info['ALT_PS'].values]
+    c.alt_ps_present = 1
+    c.n_alt_ps = len(vals)
+    ps = keep(np.array(vals or [0], dtype=np.int32))
+    c.alt_ps = ps.ctypes.data_as(C.POINTER(C.c_int32))
+  rejected = list(getattr(dv_call.variant, 'alternate_bases_rejected', []) or [])
+  c.n_rejected_alts = len(rejected)
+  c.rejected_alts = _str_array(rejected, keep)
+  rsup = getattr(dv_call, 'rejected_allele_support', None) or {}
+  ralleles = list(rsup.keys())
+  rnames: List[str] = []
+  roffs = [0]
+  for a in ralleles:
+    rnames.extend(rsup[a].read_names)
+    roffs.append(len(rnames))
+  c.n_rejected_support = len(ralleles)
+  c.rejected_support_alleles = _str_array(ralleles, keep)
+  roffs_arr = keep(np.array(roffs, dtype=np.int32))
+  c.rejected_support_offsets = roffs_arr.ctypes.data_as(C.POINTER(C.c_int32))
+  c.rejected_support_names = _str_array(rnames, keep)
   return c
 
 
@@ -335,6 +370,21 @@ def build_pileup(pic_options, dv_call, ref_bases: str, reads, image_start_pos,
   if return_row_reads:
     return out, rc, row_read
   return out
+
+
+def fuzzy_read_supports_alt(dv_call, read, alt_alleles) -> int:
+  """ReadSupportsVariantFuzzyChannel::ReadSupportsAlt -> 0 / 1 / 2 / 10 / 9."""
+  keep = _Keep()
+  c = _make_call(dv_call, keep)
+  r = DvoRead()
+  _fill_read(r, read, keep)
+  alts = _str_array(list(alt_alleles), keep)
+  L = lib()
+  L.dvo_fuzzy_read_supports_alt.restype = C.c_int
+  rc = L.dvo_fuzzy_read_supports_alt(C.byref(c), C.byref(r), alts, len(alt_alleles))
+  if rc < 0:
+    raise _err()
+  return rc
 
 
 def downsample_indices(n: int, max_reads: int, seed: int) -> np.ndarray:

@@ -23,11 +23,11 @@ def query_len(cigar):
 
 
 def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
-              with_mods=False, n_alts=2):
+              with_mods=False, n_alts=2, fuzzy=False):
   hw = (width - 1) // 2
   ref_window = ''.join('ACGTN'[int(i)] for i in rng.choice(5, size=width,
                                                            p=[.24, .24, .24, .24, .04]))
-  alts = ['C', 'G', 'T'][:n_alts]
+  alts = (['AC', 'ACC', 'ACCCC'] if fuzzy else ['C', 'G', 'T'])[:n_alts]
   reads = []
   for i in range(n_reads):
     cigar = random_cigar(rng)
@@ -63,6 +63,16 @@ def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
   call = T.DeepVariantCall(
       variant=T.Variant('chr1', variant_start, variant_start + 1, 'A', alts),
       allele_support=support)
+  if fuzzy and n_reads:
+    # what read_supports_variant_fuzzy reads besides allele_support: per-allele phases, the
+    # rejected alleles with their reads, the reference-supporting reads
+    pick = lambda k: [keys[int(j)] for j in rng.integers(0, n_reads, size=k)]
+    call.variant.info['ALT_PS'] = T.ListValue(
+        values=[T.Value(int_value=int(v)) for v in rng.integers(0, 3, size=n_alts + 1)])
+    call.variant.alternate_bases_rejected = ['ACCC', 'ACCCCCCC']
+    call.rejected_allele_support = {'ACCC': T.SupportingReads(pick(3)),
+                                    'ACCCCCCC': T.SupportingReads(pick(2))}
+    call.ref_support = pick(4)
   combo = [alts[int(j)] for j in sorted(set(rng.integers(0, n_alts, size=int(rng.integers(1, 3))).tolist()))]
   return call, ref_window, reads, variant_start - hw, combo
 
@@ -95,4 +105,7 @@ CONFIGS = [
                                                  'homopolymer_weighted'], 45, 26, {}, {}),
     ('sort_by_support', T.PILEUP_DEFAULT_CHANNELS, 41, 24,
      dict(sort_by_alt_allele_support=True), {}),
+    ('fuzzy_support', T.PILEUP_DEFAULT_CHANNELS + ['haplotype', 'read_supports_variant_fuzzy'],
+     61, 40, dict(sort_by_haplotypes=True, other_allele_supporting_read_alpha=0.3),
+     dict(with_hp=True, fuzzy=True)),
 ]

@@ -513,3 +513,73 @@ def check_get_channel_data(encode_read_with_blank, blank):
   assert ch('homopolymer_weighted')[9] == 33
   assert ch('blank')[1] == 0
   assert ch('insert_size')[1] == 254
+
+
+# ---- read_supports_variant_fuzzy -------------------------------------------------------
+# channels/read_supports_variant_fuzzy_channel_test.cc:98-158 (7 TEST_Fs, 11 expectations) and
+# pileup_channel_lib_test.cc:288-368 (ReadSupportsAltFuzzy, 4 expectations).
+# (ref, alts, allele_support, ALT_PS values or None, ref_support, read name, read number, HP or
+#  None, alts of the image, expected ReadSupportsAlt)
+def _fuzzy_lib_case(read, hp, expected):
+  return ('GGGCGC', ['GGGCGCATT', 'GGGCGCAT', 'GGGCGCATTT', 'GGGCGCA'],
+          {'GGGCGCATT': ['Read1/1'], 'GGGCGCAT': ['Read2/1'], 'GGGCGCATTT': ['Read3/1'],
+           'GGGCGCA': ['Read4/1']}, [1, 1, 1, 2], [], read, 1, hp, ['GGGCGCATT'], expected)
+
+
+FUZZY_CASES = [
+    # ExactMatch
+    ('A', ['AC', 'ACC'], {'AC': ['read1/0'], 'ACC': ['read2/0']}, [0, 1, 1], [], 'read1', 0, 1, ['AC'], 1),
+    ('A', ['AC', 'ACC'], {'AC': ['read1/0'], 'ACC': ['read2/0']}, [0, 1, 1], [], 'read2', 0, 1, ['AC'], 10),
+    ('A', ['AC', 'ACC'], {'AC': ['read1/0'], 'ACC': ['read2/0']}, [0, 1, 1], [], 'read1', 0, 1, ['ACC'], 10),
+    ('A', ['AC', 'ACC'], {'AC': ['read1/0'], 'ACC': ['read2/0']}, [0, 1, 1], [], 'read2', 0, 1, ['ACC'], 1),
+    # FuzzyMatch1bp, FuzzyMatch2bp
+    ('A', ['AC', 'ACC'], {'ACC': ['read1/0']}, [0, 1, 1], [], 'read1', 0, 1, ['AC'], 10),
+    ('A', ['AC', 'ACCC'], {'ACCC': ['read1/0']}, [0, 1, 1], [], 'read1', 0, 1, ['AC'], 9),
+    # FuzzyMatchPhaseMismatch (read HP 2, allele phase 1), FuzzyMatchPhaseZero
+    ('A', ['AC', 'ACC'], {'ACC': ['read1/0']}, [0, 1, 1], [], 'read1', 0, 2, ['AC'], 0),
+    ('A', ['AC', 'ACC'], {'ACC': ['read1/0']}, [0, 0, 0], [], 'read1', 0, 1, ['AC'], 10),
+    # RefSupport: a reference-supporting read is one base away from "AA", three from "ATGC"
+    ('A', ['ATGC', 'AA'], {}, None, ['read1/0'], 'read1', 0, None, ['ATGC'], 0),
+    ('A', ['ATGC', 'AA'], {}, None, ['read1/0'], 'read1', 0, None, ['AA'], 10),
+    # pileup_channel_lib_test.cc ReadSupportsAltFuzzy
+    _fuzzy_lib_case('Read1', 1, 1), _fuzzy_lib_case('Read2', 1, 10),
+    _fuzzy_lib_case('Read3', 1, 10), _fuzzy_lib_case('Read4', 2, 0),
+]
+
+
+def fuzzy_inputs(case):
+  ref, alts, support, alt_ps, ref_support, name, number, hp, image_alts, expected = case
+  variant = T.Variant(reference_name='chr1', start=10, end=10 + len(ref), reference_bases=ref,
+                      alternate_bases=list(alts))
+  if alt_ps is not None:
+    variant.info['ALT_PS'] = T.ListValue(values=[T.Value(int_value=v) for v in alt_ps])
+  call = T.DeepVariantCall(
+      variant=variant,
+      allele_support={k: _supporting_reads(*v) for k, v in support.items()},
+      ref_support=list(ref_support))
+  read = T.make_read('A', start=10, cigar='1M', quals=[50], name=name)
+  read.read_number = number
+  if hp is not None:
+    read.info['HP'] = T.ListValue(values=[T.Value(int_value=hp)])
+  return call, read, image_alts, expected
+
+
+def fuzzy_color(options, code):
+  # ReadSupportsVariantFuzzyChannel::SupportsAltColor (:290-312) in fp32
+  alpha = {0: options.allele_unsupporting_read_alpha, 1: options.allele_supporting_read_alpha,
+           2: options.other_allele_supporting_read_alpha, 10: 0.90, 9: 0.80}[code]
+  return int(np.float32(254.0) * np.float32(alpha))
+
+
+def check_fuzzy_channel(make, case):
+  """The fuzzy-support pixel of a one-base read drawn through the encoder's own interface,
+  and the reference row (SupportsAltColor(0))."""
+  call, read, image_alts, expected = fuzzy_inputs(case)
+  options = default_options(channels=['read_base', 'read_supports_variant_fuzzy'],
+                            other_allele_supporting_read_alpha=0.3)
+  enc = make(options)
+  actual = enc.encode_read(call, 'TAT', read, 9, image_alts)
+  assert list(actual[0, 1]) == [250, fuzzy_color(options, expected)]
+  assert list(actual[0, 0]) == [0, 0] and list(actual[0, 2]) == [0, 0]
+  ref_row = enc.encode_reference('TAT')
+  assert list(ref_row[0, :, 1]) == [fuzzy_color(options, 0)] * 3

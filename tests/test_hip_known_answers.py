@@ -70,6 +70,11 @@ def test_custom_channels(case):
   KA.check_custom_channel(make, *case)
 
 
+@pytest.mark.parametrize('case', KA.FUZZY_CASES)
+def test_read_supports_variant_fuzzy(case):
+  KA.check_fuzzy_channel(make, case)
+
+
 def test_custom_multi():
   KA.check_custom_multi(make)
 
@@ -82,7 +87,7 @@ def test_build_pileup(name):
 def test_unsupported_channel_fails_loudly():
   from deepvariant_amd import _lib
   with pytest.raises(_lib.DvError) as e:
-    make(KA.default_options(['read_supports_variant_fuzzy'])).encode_reference('ACGTA')
+    make(KA.default_options(['homopolymer_insertion_quality'])).encode_reference('ACGTA')
   assert e.value.status == _lib.DV_ERR_UNSUPPORTED
 
 

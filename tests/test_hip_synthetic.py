@@ -78,3 +78,50 @@ def test_longread_shapes_bit_exact(kind, n):
   if kind == 'ont':
     off = np.asarray(batch.item_list_off)
     assert (np.diff(off) > 95).any()      # the shuffle-and-truncate path ran
+
+
+def test_pileups_deeper_than_the_dense_shuffle_table():
+  """DownsampleReadIndices on amplicon-depth pile-ups (pileup_image_native.cc:153-165): the
+  device looks the permutation up in a table that is dense up to 1024 reads and holds only
+  the depths that occur above that.  Items of 1500 / 2600 / 5003 list entries (reads of
+  their site repeated), host batch and device-resident batch, against the oracle's
+  std::shuffle; then a second call with a NEW depth on the same encoder (the table grows)."""
+  import torch
+  from deepvariant_amd import synth
+  from deepvariant_amd.device_batch import DeviceBatch
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  opts = synth.illumina_options(7)
+  enc = _Encoder(opts, opts.width)
+  rng = np.random.default_rng(5)
+
+  def deep_batch(depths, seed):
+    batch = synth.make_illumina_batch(24, seed=seed, options=opts)
+    off = np.array(batch.item_list_off)
+    reads = np.concatenate(batch.list_read_chunks)
+    codes = np.concatenate(batch.list_code_chunks)
+    n0 = batch.n_items
+    for k, depth in enumerate(depths):
+      i = k % n0
+      pick = rng.integers(off[i], off[i + 1], size=depth)
+      batch.add_item(batch.item_variant_start[i], batch.item_image_start[i],
+                     batch.item_ref_idx[i], reads[pick], codes[pick], height=100,
+                     out_off=batch.n_items * 100 * 221 * 7)
+    return batch
+
+  batch = deep_batch([1500, 2600, 5003, 1025], seed=21)
+  out, rows = enc.encode(batch, 7)
+  want, want_rows = O.encode_packed(opts, batch, 7, n_threads=8)
+  np.testing.assert_array_equal(rows, want_rows)
+  np.testing.assert_array_equal(out, want)
+  assert (rows[-4:] == 95).all()
+
+  batch2 = deep_batch([3001, 1500], seed=22)     # 3001 is new to the encoder's table
+  want2, want_rows2 = O.encode_packed(opts, batch2, 7, n_threads=8)
+  dev = DeviceBatch(batch2, torch.device('cuda:0'))
+  out2 = torch.empty(batch2.out_bytes(7), dtype=torch.uint8, device='cuda:0')
+  rows2 = torch.empty(batch2.n_items, dtype=torch.int32, device='cuda:0')
+  dev.encode(enc, 7, out2, rows2)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(rows2.cpu().numpy(), want_rows2)
+  np.testing.assert_array_equal(out2.cpu().numpy(), want2)

@@ -60,6 +60,11 @@ def test_custom_channels(case):
   KA.check_custom_channel(make, *case)
 
 
+@pytest.mark.parametrize('case', KA.FUZZY_CASES)
+def test_read_supports_variant_fuzzy(case):
+  KA.check_fuzzy_channel(make, case)
+
+
 def test_custom_multi():
   KA.check_custom_multi(make)
 

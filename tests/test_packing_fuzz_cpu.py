@@ -21,6 +21,9 @@ def test_packed_equals_proto_path_fuzz(name, channels, width, height, okw, ckw):
                                            'identity', 'gap_compressed_identity'))
   if okw.get('sort_by_alt_allele_support'):
     pytest.skip('the packed adapter cannot rebuild allele groups; GPU fuzz covers it')
+  if 'read_supports_variant_fuzzy' in channels:
+    pytest.skip('the packed adapter has no candidate to recompute fuzzy support from; '
+                'tests/test_fuzzy_channel_cpu.py and the GPU fuzz cover it')
   for trial in range(8):
     n_reads = int(rng.choice([0, 2, 12, height, 2 * height + 5]))
     call, ref, reads, start, combo = F.make_case(rng, width, n_reads, **dict(ckw))
