@@ -156,6 +156,50 @@ bool find_int_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1, int3
   return false;
 }
 
+// The uint32 array of a `B:I` aux tag (CG: the real CIGAR of a record with more than 65535
+// operations, SAMv1 4.2.2).  Returns false when the tag is absent or of another type.
+bool find_u32_array_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1,
+                        const uint8_t** data, uint32_t* count) {
+  const uint8_t* p = aux;
+  auto size_of = [](uint8_t ty) -> int {
+    switch (ty) {
+      case 'A': case 'c': case 'C': return 1;
+      case 's': case 'S': return 2;
+      case 'i': case 'I': case 'f': return 4;
+      default: return 0;
+    }
+  };
+  while (p + 3 <= end) {
+    const bool hit = p[0] == static_cast<uint8_t>(t0) && p[1] == static_cast<uint8_t>(t1);
+    const uint8_t ty = p[2];
+    p += 3;
+    const int sz = size_of(ty);
+    if (sz) {
+      if (p + sz > end) return false;
+      p += sz;
+    } else if (ty == 'Z' || ty == 'H') {
+      while (p < end && *p) ++p;
+      ++p;
+    } else if (ty == 'B') {
+      if (p + 5 > end) return false;
+      const int sub = size_of(p[0]);
+      if (!sub) return false;
+      const uint64_t n = le32(p + 1);
+      if (static_cast<uint64_t>(end - (p + 5)) < n * sub) return false;
+      if (hit) {
+        if (p[0] != 'I') return false;
+        *data = p + 5;
+        *count = static_cast<uint32_t>(n);
+        return true;
+      }
+      p += 5 + n * sub;
+    } else {
+      return false;
+    }
+  }
+  return false;
+}
+
 // ---- record decoding ------------------------------------------------------------
 struct RegionFilter {
   dv_read_requirements rq{};
@@ -208,8 +252,26 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   if (static_cast<int32_t>(mapq) < rq.min_mapping_quality) return DV_OK;
   const uint8_t* name = r + 32;
   const uint8_t* cig = name + l_read_name;
+  const uint8_t* const seq = cig + 4 * n_cigar;
+  const uint8_t* const qual = seq + (l_seq + 1) / 2;
+  // Long CIGARs (ONT / HiFi reads with more than 65535 operations): the record carries the
+  // placeholder <l_seq>S<reference span>N and the real operations sit in the CG:B:I tag.
+  // htslib swaps them in on read (sam.c bam_tag2cigar), so nucleus' SamReader -- and
+  // therefore the reference -- only ever sees the real CIGAR.
+  uint32_t n_ops = n_cigar;   // operations of the effective CIGAR
+  if (n_cigar == 2) {
+    const uint32_t c0 = le32(cig), c1 = le32(cig + 4);
+    if ((c0 & 0xF) == 4 && (c0 >> 4) == l_seq && (c1 & 0xF) == 3) {
+      const uint8_t* cg = nullptr;
+      uint32_t n_cg = 0;
+      if (find_u32_array_tag(qual + l_seq, r + block_size, 'C', 'G', &cg, &n_cg) && n_cg > 0) {
+        cig = cg;
+        n_ops = n_cg;
+      }
+    }
+  }
   int64_t ref_len = 0, query_len = 0;
-  for (unsigned k = 0; k < n_cigar; ++k) {
+  for (unsigned k = 0; k < n_ops; ++k) {
     const uint32_t v = le32(cig + 4 * k);
     const unsigned op = v & 0xF;
     if (op > 8) return dv::fail(DV_ERR_BAD_INPUT, "Unrecognized CIGAR op in BAM record");
@@ -218,15 +280,13 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   }
   // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
   if (!(f.end > rpos && f.start < rpos + std::max<int64_t>(ref_len, 1))) return DV_OK;
-  const uint8_t* seq = cig + 4 * n_cigar;
-  const uint8_t* qual = seq + (l_seq + 1) / 2;
   if (l_seq && qual[0] == 0xff) {
     return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
   }
   // The encoder indexes bases / qualities by CIGAR query offsets without bounds checks (like
   // the reference, whose SAM parser rejects such records: "CIGAR and query sequence are of
   // different length"); SEQ '*' (l_seq = 0) with a query-consuming CIGAR is the common case.
-  if (n_cigar && query_len != static_cast<int64_t>(l_seq)) {
+  if (n_ops && query_len != static_cast<int64_t>(l_seq)) {
     return dv::fail(DV_ERR_BAD_INPUT, "CIGAR and query sequence are of different length");
   }
   t->pos.push_back(rpos);
@@ -238,7 +298,7 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   t->frag_len.push_back(tlen);
   int32_t hp = 0;
   t->hp.push_back(find_int_tag(qual + l_seq, r + block_size, 'H', 'P', &hp) ? hp : DV_HP_NONE);
-  for (unsigned k = 0; k < n_cigar; ++k) {
+  for (unsigned k = 0; k < n_ops; ++k) {
     const uint32_t v = le32(cig + 4 * k);
     t->cigar.push_back(((v >> 4) << 4) | ((v & 0xF) + 1));  // kHtslibCigarToProto
   }

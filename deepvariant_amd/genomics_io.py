@@ -122,6 +122,18 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
     p += (l_seq + 1) // 2
     qual = bytes(rec[p:p + l_seq])
     p += l_seq
+    if (n_cigar == 2 and cigar[0].operation == T.BAM_OP_TO_NUCLEUS[4] and
+        cigar[0].operation_length == l_seq and cigar[1].operation == T.BAM_OP_TO_NUCLEUS[3]):
+      # more than 65535 operations: the real CIGAR is the CG:B:I tag (SAMv1 4.2.2); htslib
+      # swaps it in on read, so nucleus only ever sees the real one
+      long_cigar = _find_u32_array_tag(rec[p:], b'CG')
+      if long_cigar:
+        cigar, ref_len = [], 0
+        for v in long_cigar:
+          op, ln = v & 0xF, v >> 4
+          cigar.append(T.CigarUnit(T.BAM_OP_TO_NUCLEUS[op], ln))
+          if op in (0, 2, 3, 7, 8):
+            ref_len += ln
     if ref_id < 0 or (flag & 0x4) or (contig is not None and names[ref_id] != contig):
       continue
     if not (end > rpos and start < rpos + max(ref_len, 1)):
@@ -185,6 +197,32 @@ def _find_int_tag(aux, tag: bytes) -> Optional[int]:
     elif ty == b'B':
       sub = bytes(aux[p:p + 1])
       cnt = struct.unpack_from('<i', aux, p + 1)[0]
+      p += 5 + cnt * _AUX_SIZES[sub]
+    else:
+      return None
+  return None
+
+
+def _find_u32_array_tag(aux, tag: bytes) -> Optional[List[int]]:
+  """The values of a `B:I` aux tag, or None."""
+  p, n = 0, len(aux)
+  while p + 3 <= n:
+    t = bytes(aux[p:p + 2])
+    ty = bytes(aux[p + 2:p + 3])
+    p += 3
+    if ty in _AUX_SIZES:
+      p += _AUX_SIZES[ty]
+    elif ty in (b'Z', b'H'):
+      while aux[p] != 0:
+        p += 1
+      p += 1
+    elif ty == b'B':
+      sub = bytes(aux[p:p + 1])
+      cnt = struct.unpack_from('<i', aux, p + 1)[0]
+      if t == tag:
+        if sub != b'I':
+          return None
+        return list(struct.unpack_from('<%dI' % cnt, aux, p + 5))
       p += 5 + cnt * _AUX_SIZES[sub]
     else:
       return None

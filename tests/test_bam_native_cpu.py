@@ -259,3 +259,42 @@ def test_query_reads_matches_the_table_query():
   for k in range(64):
     want = [r for r in range(n) if q1[k] > pos[r] and q0[k] < pos[r] + ref_len[r]]
     assert reads[list_off[k]:list_off[k + 1]].tolist() == want, k
+
+
+def test_long_cigar_in_the_cg_tag(tmp_path):
+  """A record with more than 65535 CIGAR operations stores <l_seq>S<span>N and keeps the real
+  operations in CG:B:I (SAMv1 4.2.2); htslib -- hence nucleus' SamReader -- hands out the real
+  CIGAR (sam.c bam_tag2cigar).  Native reader == Python restatement == the operations written;
+  a CG tag on a record whose CIGAR is NOT the placeholder is ignored, as htslib does."""
+  rng = np.random.default_rng(3)
+  n_ops = 70001
+  ops = []
+  for k in range(n_ops):
+    ops.append((1 + int(rng.integers(0, 3)), 'MID'[k % 3] if 0 < k < n_ops - 1 else 'M'))
+  l_seq = sum(n for n, op in ops if op in 'MI')
+  span = sum(n for n, op in ops if op in 'MD')
+  cg = b'CGBI' + struct.pack('<i', n_ops) + b''.join(
+      struct.pack('<I', (n << 4) | BAM_OPS.index(op)) for n, op in ops)
+  refs = [('chrA', 400000)]
+  hdr = b'BAM\x01' + struct.pack('<i', 0) + struct.pack('<i', 1)
+  hdr += struct.pack('<i', 5) + b'chrA\0' + struct.pack('<i', 400000)
+  long_rec = _record(rng, 0, 1000, 'ont_read', 0, 60, [(l_seq, 'S'), (span, 'N')], -1, 0,
+                     aux=b'HPC\x02' + cg + b'XAZtail\0')
+  # same tag on an ordinary record: not a placeholder, the tag is just an aux field
+  plain = _record(rng, 0, 2000, 'plain', 0, 60, [(30, 'M'), (2, 'D'), (20, 'M')], -1, 0,
+                  aux=b'CGBI' + struct.pack('<iI', 1, (50 << 4) | 0))
+  path = str(tmp_path / 'long.bam')
+  with open(path, 'wb') as f:
+    f.write(_bgzf(hdr + long_rec + plain, block=30000))
+  nat = packing.ReadTable.from_bam(path, 'chrA', 0, 1 << 40)
+  py = _python_table(path, 'chrA', 0, 1 << 40)
+  _assert_same(nat, py)
+  assert nat.n_reads == 2
+  c0, c1 = int(nat.read_cigar_off[0]), int(nat.read_cigar_off[1])
+  assert c1 - c0 == n_ops
+  want = np.array([(n << 4) | (BAM_OPS.index(op) + 1) for n, op in ops], np.uint32)
+  np.testing.assert_array_equal(np.asarray(nat.cigar[c0:c1]), want)
+  assert int(nat.read_end[0]) == 1000 + span and int(nat.read_hp[0]) == 2
+  assert int(nat.read_cigar_off[2]) - c1 == 3
+  # the region test uses the real span: a window past the placeholder-free end finds nothing
+  assert packing.ReadTable.from_bam(path, 'chrA', 1000 + span + 5, 1000 + span + 50).n_reads == 0
