@@ -79,6 +79,13 @@ struct ConvArgs {
   // neighbouring cout tiles of one pixel tile (they then share its L1 lines)
   int cu_pair;
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
+  // Blank-row skipping (opt-in, DV_BLANK_SKIP): blank_row[n] = first output row of
+  // example n whose receptive field lies entirely in the zero rows below the pile-up.  Such
+  // outputs equal the response of the all-blank image at the same position (blank_src: ONE
+  // example in the output tensor's geometry), so a block whose pixels all lie there copies
+  // instead of multiplying -- bit-identical.  Single-branch launches only; NULL = off.
+  const int* blank_row;
+  const _Float16* blank_src;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));

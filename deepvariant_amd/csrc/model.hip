@@ -148,6 +148,42 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
   }
 }
 
+// Blank-row skipping (ConvArgs::blank_row): the wave's PT*32 pixels x NB*32 couts copied from the
+// all-blank image's response instead of computed.  Lanes l / l+32 take alternate 8-cout
+// groups; all loads are issued before the first store.
+template <int NB, int PT>
+__device__ __forceinline__ void copy_blank_wave(const ConvArgs& p, int n_tile, const int (&pn)[PT],
+                                                const int (&poh)[PT], const int (&pow_)[PT],
+                                                const bool (&mvalid)[PT], int lane) {
+  const ConvBranch& b = p.br[0];
+  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+  const int hi = lane >> 5;
+  const uint4_t* src = reinterpret_cast<const uint4_t*>(p.blank_src);
+  uint4_t* dst = reinterpret_cast<uint4_t*>(b.out);
+  uint4_t v[PT][NB * 2];
+  unsigned at[PT][NB * 2];
+  bool ok[PT][NB * 2];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const unsigned rel = static_cast<unsigned>((poh[pt] + b.og.halo) * b.og.wp + pow_[pt] + b.og.halo);
+#pragma unroll
+    for (int j = 0; j < NB * 2; ++j) {
+      const int g = n_tile * NB * 4 + 2 * j + hi;
+      ok[pt][j] = mvalid[pt] && g * 8 < b.Cout;
+      at[pt][j] = static_cast<unsigned>(b.out_goff + g) * gstride + rel;
+      v[pt][j] = ok[pt][j] ? src[at[pt][j]] : uint4_t{0u, 0u, 0u, 0u};
+    }
+  }
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const unsigned img = static_cast<unsigned>(pn[pt] * b.og.groups) * gstride;
+#pragma unroll
+    for (int j = 0; j < NB * 2; ++j) {
+      if (ok[pt][j]) dst[img + at[pt][j]] = v[pt][j];
+    }
+  }
+}
+
 // Implicit-GEMM convolution, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].
 //
 //  * The block's weight tile (NB*32 couts) streams through LDS in slabs of 8
@@ -160,12 +196,14 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
 //    independent 32x32 accumulators keep the matrix pipe busy back to back.
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
-template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks>
-__global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs p) {
+template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
+  constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8)
   constexpr int SLAB_HALFS = SLAB * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
-  constexpr int W_PER_THREAD = SLAB_PIECES / kConvThreads;  // = 2 * NB
+  constexpr int W_PER_THREAD = SLAB_PIECES / kThreads;   // = 2 * NB with four waves
+  static_assert(SLAB_PIECES % kThreads == 0, "slab does not split evenly over the block");
   constexpr int kPrefetch = prefetch_depth(NB, PT);
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 
@@ -196,7 +234,7 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
     band_r = pix_block % p.band;   // rows minor: the H blocks reading the same images are neighbours
     pix_block /= p.band;
   }
-  const int m_block = pix_block * (128 * PT);
+  const int m_block = pix_block * (32 * PT * WAVES);
 
   // Buffer offsets are 32 bit, tensors are not (8 K examples x 1.4 MB): every wave
   // addresses the input relative to the first example it touches (n0), through its
@@ -232,6 +270,29 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
     pow_[pt] = ow;
   }
 
+  // Blank-row skipping (opt-in): a pixel range that lies in ONE example, from a row at or past
+  // that example's first blank-determined row, is copied instead of computed.  Decided for the
+  // whole block (no slab traffic, no barriers) and per wave (the wave keeps its share of the
+  // weight-slab copies and the barriers, but issues no pixel loads and no MFMAs).
+  bool wave_blank = false;
+  if (p.blank_row != nullptr) {
+    auto range_blank = [&](int m_lo, int m_hi) -> bool {  // pixels [m_lo, m_hi), uniform arguments
+      m_hi = min(m_hi, p.M);
+      if (m_lo >= m_hi) return false;
+      int nf, pf, nl, pl, ohf, owf;
+      divmod_small(m_lo, ohow, p.rcp_ohow, nf, pf);
+      divmod_small(m_hi - 1, ohow, p.rcp_ohow, nl, pl);
+      divmod_small(pf, p.OW, p.rcp_ow, ohf, owf);
+      return nf == nl && ohf >= p.blank_row[nf];
+    };
+    if (range_blank(m_block, m_block + 32 * PT * WAVES)) {   // block-uniform, before any barrier
+      copy_blank_wave<NB, PT>(p, n_tile, pn, poh, pow_, mvalid, lane);
+      return;
+    }
+    const int m_wave = m_block + wave * (32 * PT);
+    wave_blank = __builtin_amdgcn_readfirstlane(range_blank(m_wave, m_wave + 32 * PT) ? 1 : 0) != 0;
+  }
+
   const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
   const size_t in_left = p.in_bytes - in_off;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -248,12 +309,12 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
     const uint4_t* src_ = reinterpret_cast<const uint4_t*>(wsrc) +                         \
                           static_cast<size_t>(s_) * SLAB_PIECES + tid;                     \
     _Pragma("unroll") for (int j_ = 0; j_ < W_PER_THREAD; ++j_) wreg[j_] =                \
-        src_[j_ * kConvThreads];                                                           \
+        src_[j_ * kThreads];                                                           \
   }
 #define DV_STORE_SLAB(buf_)                                                                \
   {                                                                                        \
     uint4_t* dst_ = reinterpret_cast<uint4_t*>(smem + (buf_) * SLAB_HALFS) + tid;          \
-    _Pragma("unroll") for (int j_ = 0; j_ < W_PER_THREAD; ++j_) dst_[j_ * kConvThreads] = \
+    _Pragma("unroll") for (int j_ = 0; j_ < W_PER_THREAD; ++j_) dst_[j_ * kThreads] = \
         wreg[j_];                                                                          \
   }
 
@@ -284,6 +345,17 @@ __global__ __launch_bounds__(kConvThreads, MINB) void conv_mfma_kernel(ConvArgs 
   // reads 512 contiguous bytes: conflict-free for ds_read_b128 (a [cout][16]
   // image is 2-way conflicted: measured SQ_LDS_BANK_CONFLICT ~ LDS active).
   const int frag_off = (lane >> 5) * (BN * 8) + (lane & 31) * 8;  // halfs
+  if (wave_blank) {   // wave-uniform: same slab copies and barriers as the computing waves
+    const int n_full_b = p.n_chunks / SLAB;
+    for (int s = 0; s < n_full_b; ++s) {
+      const int next = s + 1 < (p.n_chunks + SLAB - 1) / SLAB ? s + 1 : s;
+      DV_LOAD_SLAB(next)
+      DV_STORE_SLAB((s + 1) & 1)
+      __syncthreads();
+    }
+    copy_blank_wave<NB, PT>(p, n_tile, pn, poh, pow_, mvalid, lane);
+    return;
+  }
 #ifdef DV_ABLATE_LOOP
   const int n_full = p.n_chunks < 0 ? 1 : 0;
   const int rem = 0;
@@ -605,6 +677,52 @@ __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix
   dst[at + plane] = *reinterpret_cast<uint4*>(&v[8]);
 }
 
+// Blank-row skipping (opt-in, DV_BLANK_SKIP): one workgroup per image finds the last row that
+// holds a nonzero byte, scanning from the bottom (a 30x pileup is zero below row ~40, so about
+// 60 % of the image is read once), and turns it into the first blank-determined row of the
+// stem's tensors: an output whose receptive field sees only zero rows equals the all-blank
+// image's output at the same position.
+//   conv1 3x3/2 valid: rows 2y..2y+2   -> y >= ceil(r / 2)         (= conv2, 3x3 valid on those)
+//   conv3 3x3 same:    rows y-1..y+1   -> y >= t2 + 1
+//   max-pool 3x3/2:    rows 2y..2y+2   -> y >= ceil(t3 / 2)        (= the 1x1 and the 3x3 valid 80->192)
+// thr[k * stride + n], k = 0: rows used, 1: conv2 output, 2: stem_b output, 3: 3x3 80->192 output.
+__global__ __launch_bounds__(256) void blank_rows_kernel(const uint8_t* images, int H, int row_bytes,
+                                                         int* thr, int stride) {
+  __shared__ int last;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const unsigned img_bytes = static_cast<unsigned>(H) * row_bytes;   // multiple of 4 (checked by the host)
+  const uint32_t* img = reinterpret_cast<const uint32_t*>(images + static_cast<size_t>(n) * img_bytes);
+  const int n_dw = static_cast<int>(img_bytes / 4);
+  if (tid == 0) last = -1;
+  __syncthreads();
+  constexpr int kPer = 16;   // dwords per thread and trip: 16 KB of the image per barrier
+  for (int hi = n_dw; hi > 0; hi -= 256 * kPer) {
+    uint32_t v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {   // all loads in flight before the first compare
+      const int i = hi - 1 - (k * 256 + tid);
+      v[k] = i >= 0 ? img[i] : 0u;
+    }
+    int mine = -1;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = hi - 1 - (k * 256 + tid);
+      if (v[k] != 0) mine = max(mine, 4 * i + 3 - (__clz(v[k]) >> 3));   // its highest nonzero byte
+    }
+    if (mine >= 0) atomicMax(&last, mine);
+    __syncthreads();
+    if (last >= 0) break;   // uniform: read after the barrier
+  }
+  if (tid == 0) {
+    const int r = last < 0 ? 0 : last / row_bytes + 1;
+    const int t2 = (r + 1) / 2, t3 = t2 + 1, t4 = (t3 + 1) / 2;
+    thr[n] = r;
+    thr[stride + n] = t2;
+    thr[2 * stride + n] = t4;
+    thr[3 * stride + n] = t4;
+  }
+}
+
 struct PoolArgs {
   const _Float16* in;
   _Float16* out;
@@ -816,6 +934,12 @@ struct dv_model {
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
+  // opt-in blank-row skipping (DV_BLANK_SKIP=1)
+  bool blank_skip = false;        // requested and applicable to this model
+  bool blank_ready = false;       // the blank responses have been computed (after load_weights)
+  int blank_conv4_op = -1;        // op index of the stem's 3x3 80->192
+  dv::DeviceBuffer d_blank_thr;   // int32 [4][max_batch], blank_rows_kernel
+  dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output for the all-blank image (one example)
   bool loaded = false;
   struct GraphEntry {
     int n;
@@ -1119,6 +1243,7 @@ struct dv_model {
       buffers[ops[2].out_buf] = {1, 1, 64, 0};  // conv3 output: LDS only
     }
     x = conv(x, 192, 3, 3, 1, false);
+    blank_conv4_op = static_cast<int>(ops.size()) - 1;
     // The stem's second max-pool has ONE consumer launch -- mixed0's four 1x1 heads, grouped
     // (the pooled branch projects before it averages) -- so it is taken on the fly there
     // (conv_pool1x1_kernel) and the pooled tensor is never written.  DV_NO_POOL2_FUSE keeps
@@ -1272,6 +1397,21 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
     if (!no_pt4 && !force_pt && blocks2 >= 4096 && (NB == 1 || a.KH * a.KW >= 25)) {
       hipLaunchKernelGGL((conv_mfma_kernel<NB, 4>), dim3(static_cast<unsigned>(blocks(512))),
                          dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+      return;
+    }
+  }
+  // tuning experiments: 4-chunk weight slabs; 8-wave blocks of 512 pixels
+  static const bool slab4 = getenv("DV_CONV_SLAB4") != nullptr;
+  static const bool w8 = getenv("DV_CONV_W8") != nullptr;
+  if constexpr (NB >= 3 && NB <= 4) {
+    if (slab4 && blocks2 >= 512) {
+      hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2, 4>), dim3(static_cast<unsigned>(blocks2)),
+                         dim3(kConvThreads), static_cast<size_t>(2) * 4 * NB * 32 * kChunk * 2, stream, a);
+      return;
+    }
+    if (w8 && blocks2 >= 1024) {
+      hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 1, kSlabChunks, 8>), dim3(static_cast<unsigned>(blocks(512))),
+                         dim3(512), conv_lds_bytes<NB>(), stream, a);
       return;
     }
   }
@@ -1523,6 +1663,12 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       const int tiles = (subs + op.nb - 1) / op.nb;
       a.n_tiles = tiles;
+      if (m->blank_ready && m->blank_conv4_op >= 0 && &op == &m->ops[m->blank_conv4_op] &&
+          a.n_branches == 1 && !op.band && !op.v2 && !op.pool_in) {
+        a.blank_row = static_cast<const int*>(m->d_blank_thr.ptr) + 3 * m->desc.max_batch;
+        a.blank_src = static_cast<const _Float16*>(m->d_blank_conv4.ptr);
+        tr_label += " [blank rows copied]";
+      }
       oi += op.group_followers;  // the followers ran in this launch
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
                   " tiles" + std::to_string(tiles);
@@ -1659,6 +1805,15 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
   if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
+  // opt-in: skip the stem work that only sees the zero rows below the pile-up;
+  // needs the uint8 front end, a single-branch 3x3 80->192 and whole dwords per image
+  if (getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0 &&
+      m->ops[0].first_u8 && m->blank_conv4_op >= 0 && m->ops[m->blank_conv4_op].group_followers == 0 &&
+      (static_cast<size_t>(desc->height) * desc->width * desc->channels) % 4 == 0) {
+    if (int rc = m->d_blank_thr.reserve(static_cast<size_t>(4) * desc->max_batch * sizeof(int))) return rc;
+    DV_HIP_CHECK(hipMemset(m->d_blank_thr.ptr, 0, m->d_blank_thr.cap));
+    m->blank_skip = true;
+  }
   *out = m.release();
   return DV_OK;
 }
@@ -1672,6 +1827,8 @@ void dv_model_destroy(dv_model* m) {
   m->d_dense_w.release();
   m->d_dense_b.release();
   m->d_tbl.release();
+  m->d_blank_thr.release();
+  m->d_blank_conv4.release();
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   delete m;
 }
@@ -1704,6 +1861,43 @@ int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
   if (cin) *cin = l.cin;
   if (cout) *cout = l.cout;
   if (param_offset) *param_offset = l.param_off;
+  return DV_OK;
+}
+
+static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* probs, hipStream_t stream);
+
+// Blank-row skipping: the stem's response to the all-blank (all-zero) image, computed once per
+// set of weights by the ordinary kernels -- the same arithmetic that produces those values
+// inside a real image -- and kept as the source of the blank tiles.
+static int prepare_blank_responses(dv_model* m) {
+  m->blank_ready = false;
+  if (!m->blank_skip) return DV_OK;
+  for (auto& g : m->graphs) {   // captured without the blank arguments
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipGraphExecDestroy(g.exec);
+  }
+  m->graphs.clear();
+  const size_t img_bytes = static_cast<size_t>(m->desc.height) * m->desc.width * m->desc.channels;
+  dv::DeviceBuffer zero_img, probs;
+  int rc = zero_img.reserve(img_bytes);
+  if (rc == DV_OK) rc = probs.reserve(sizeof(float) * m->desc.num_classes);
+  if (rc == DV_OK && hipMemset(zero_img.ptr, 0, img_bytes) != hipSuccess) rc = dv::fail(DV_ERR_HIP, "hipMemset");
+  if (rc == DV_OK) rc = enqueue_forward(m, static_cast<const uint8_t*>(zero_img.ptr), 1,
+                                        static_cast<float*>(probs.ptr), nullptr);
+  if (rc == DV_OK && hipDeviceSynchronize() != hipSuccess) rc = dv::fail(DV_ERR_HIP, "blank forward failed");
+  if (rc == DV_OK) {
+    const int buf = m->ops[m->blank_conv4_op].out_buf;
+    const size_t bytes = m->buffers[buf].bytes_per_example();
+    rc = m->d_blank_conv4.reserve(bytes);
+    if (rc == DV_OK && hipMemcpy(m->d_blank_conv4.ptr, m->dbuf[buf].ptr, bytes,
+                                 hipMemcpyDeviceToDevice) != hipSuccess) {
+      rc = dv::fail(DV_ERR_HIP, "copying the blank response");
+    }
+  }
+  zero_img.release();
+  probs.release();
+  if (rc != DV_OK) return rc;
+  m->blank_ready = true;
   return DV_OK;
 }
 
@@ -1839,7 +2033,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
   DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dw + static_cast<size_t>(dl.cin) * dl.cout,
                          dl.cout * 4, hipMemcpyHostToDevice));
   m->loaded = true;
-  return DV_OK;
+  return prepare_blank_responses(m);
 }
 
 // Testing hook: copies activation buffer `index` (NHWC fp16, first n examples)
@@ -1878,6 +2072,12 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
     for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
       const int sb = std::min(stem_sub_batch(), nb - sb0);
       const uint8_t* img = images + (done + sb0) * img_bytes;
+      if (m->blank_ready) {
+        dv::ProfileScope prof(dv::kProfOther, stream);
+        hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, img, m->desc.height,
+                           m->desc.width * m->desc.channels, static_cast<int*>(m->d_blank_thr.ptr),
+                           m->desc.max_batch);
+      }
       if (!m->ops[0].first_u8) {
         const size_t n_pix = static_cast<size_t>(sb) * m->desc.height * m->desc.width;
         dv::ProfileScope prof(dv::kProfOther, stream);
