@@ -393,6 +393,99 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
   conv_epilogue<NB, PT>(acc, p, n_tile, pn, poh, pow_, mvalid, lane);
 }
 
+// Resident-weight variant of conv_mfma_kernel for layers whose whole cout tile fits the CU's LDS
+// (K * NB*32 halfs <= ~150 KB: the 3x3 80->192, short-K 1x1 heads).  DESIGN.md 7: halving a
+// launch's MFMA work and pixel traffic moved it by 10 %, so what a block of the streaming
+// kernel waits for is its weight slabs (global -> registers -> LDS behind a barrier per slab,
+// 138 KB per 256-pixel block on the 3x3 80->192).  Here a PERSISTENT block of eight waves
+// copies its cout tile's packed weights into LDS once; after that there is no barrier and no
+// weight traffic at all: every wave walks its own sequence of PT*32-pixel tiles with the same
+// straight-line slab code (conv_slab), the same K order and the same epilogue, so results are
+// bit-identical to conv_mfma_kernel's.  Blocks b and b + 8 (same XCD, same L2) take the
+// cout tiles of the same pixels.
+template <int NB, int PT>
+__global__ __launch_bounds__(512, 1) void conv_resident_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int WAVES = 8, kThreads = WAVES * 64;
+  constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
+  constexpr int kPrefetch = prefetch_depth(NB, PT);
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int n_tile = (blk >> 3) % p.n_tiles;
+  const int seq = (blk & 7) + 8 * ((blk >> 3) / p.n_tiles);
+  const int n_seq = 8 * ((static_cast<int>(gridDim.x) >> 3) / p.n_tiles);
+  {  // the cout tile's weights: [slab][chunk][2 k-groups][cout][8], contiguous in the packed image
+    const uint4_t* wsrc = reinterpret_cast<const uint4_t*>(p.w) +
+                          static_cast<size_t>(n_tile) * p.n_slabs * (kSlabChunks * BN * 2);
+    uint4_t* wdst = reinterpret_cast<uint4_t*>(smem);
+    const int pieces = p.n_slabs * (kSlabChunks * BN * 2);
+    for (int i = tid; i < pieces; i += kThreads) wdst[i] = wsrc[i];
+  }
+  __syncthreads();
+  const int frag_off = (lane >> 5) * (BN * 8) + (lane & 31) * 8;  // halfs
+  const int ohow = p.OH * p.OW;
+  const int n_full = p.n_chunks / kSlabChunks;
+  const int rem = p.n_chunks - n_full * kSlabChunks;
+  const int n_wave_tiles = (p.M + 32 * PT - 1) / (32 * PT);
+  for (int wt = seq * WAVES + wave; wt < n_wave_tiles; wt += n_seq * WAVES) {
+    int n0 = 0;
+    unsigned base[PT];
+    int pn[PT], poh[PT], pow_[PT];
+    bool mvalid[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = (wt * PT + pt) * 32 + (lane & 31);
+      int n, pix, oh, ow;
+      mvalid[pt] = m < p.M;
+      divmod_small(mvalid[pt] ? m : 0, ohow, p.rcp_ohow, n, pix);
+      divmod_small(pix, p.OW, p.rcp_ow, oh, ow);
+      const int iy = oh * p.stride - p.pad_h + p.ig.halo;
+      const int ix = ow * p.stride - p.pad_w + p.ig.halo;
+      if (pt == 0) n0 = __builtin_amdgcn_readfirstlane(n);
+      base[pt] = mvalid[pt]
+                     ? static_cast<unsigned>(((((n - n0) * p.ig.groups + (lane >> 5)) * p.ig.hp + iy) *
+                                                  p.ig.wp + ix) * 16)
+                     : 0x80000000u;
+      pn[pt] = n;
+      poh[pt] = oh;
+      pow_[pt] = ow;
+    }
+    const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
+    const size_t in_left = p.in_bytes - in_off;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in) + in_off), 0,
+        static_cast<unsigned>(in_left < 0x7fffffffu ? in_left : 0x7fffffffu), 0x00020000);
+    uint4_t xf[kPrefetch][PT];
+    float16_t acc[NB][PT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
+    ChunkWalk walk{0, 0, 0u, 0u};
+#pragma unroll
+    for (int d = 0; d < kPrefetch; ++d) {
+      const unsigned soff = walk.off();
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        xf[d][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+      }
+      walk.advance(p);
+    }
+    for (int s = 0; s < n_full; ++s) {
+      conv_slab<NB, PT, kSlabChunks>(p, rsrc, smem + s * SLAB_HALFS + frag_off, walk, base, xf, acc);
+    }
+    if (rem) {
+      const _Float16* wslab = smem + n_full * SLAB_HALFS + frag_off;
+      conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
+      if (rem > 4) conv_slab<NB, PT, 4, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+    }
+    conv_epilogue<NB, PT>(acc, p, n_tile, pn, poh, pow_, mvalid, lane);
+  }
+}
+
 // MaxPooling2D(3, strides 2) fused into the 1x1 convolution that consumes it (stem:
 // maxpool -> 64->80): the pooled tensor (0.16 MB / example written and read back) never
 // exists.  A pixel fragment is the element-wise maximum of the nine 16-byte pieces of its
@@ -1478,6 +1571,21 @@ void dump_trace(hipStream_t stream) {
   g_trace->clear();
 }
 
+// conv_resident_kernel applies when the whole 96-cout tile fits the LDS next to nothing else,
+// the launch has enough pixels to give every wave of a persistent grid several tiles, and no
+// special mode is on.  DV_RESIDENT=0 keeps conv_mfma_kernel everywhere; DV_RESIDENT=2 widens it
+// from the 3x3 80->192 to every eligible 96-cout-tile layer (tuning).
+bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
+  const char* env = getenv("DV_RESIDENT");   // read per launch set-up (tests toggle it between models)
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || op.nb != 3 || op.band || op.v2 || op.pool_in || a.blank_row != nullptr) return false;
+  const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
+  if (lds > 150 * 1024 || m->n_cus < 8 * a.n_tiles) return false;
+  if (static_cast<long>(a.M) < static_cast<long>(m->n_cus) * 8 * 64 * 4) return false;
+  if (mode >= 2) return true;
+  return m->blank_conv4_op >= 0 && &op == &m->ops[m->blank_conv4_op];
+}
+
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
             int shifted_buf = -1, int out_example_off = 0, const uint8_t* images = nullptr) {
   for (int oi = first; oi < last; ++oi) {
@@ -1703,6 +1811,16 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
           case 3: hipLaunchKernelGGL((conv_pool1x1_kernel<3>), grid, dim3(kConvThreads), lds, stream, a); break;
           default: hipLaunchKernelGGL((conv_pool1x1_kernel<4>), grid, dim3(kConvThreads), lds, stream, a); break;
         }
+      } else if (resident_ok(m, op, a)) {
+        const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
+        static const bool attr = [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_resident_kernel<3, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          return true;
+        }();
+        (void)attr;
+        const int grid = m->n_cus / (8 * a.n_tiles) * (8 * a.n_tiles);
+        hipLaunchKernelGGL((conv_resident_kernel<3, 2>), dim3(grid), dim3(512), lds, stream, a);
       } else
       switch (op.nb) {
         case 1: launch_conv<1>(a, stream); break;
