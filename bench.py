@@ -261,7 +261,7 @@ def run_rank(args, rank, local_rank, world):
         },
         'roofline': {
             'kernel': 'conv kernels: stem_a/stem_b (fused stem), imgconv_kernel, '
-                      'conv_mfma_kernel<NB,PT> (all 94 conv layers)',
+                      'conv_mfma_kernel<NB,PT>, conv_resident_kernel (all 94 conv layers)',
             'bound': 'mfma',
             'achieved': conv_tflops,
             'peak': MFMA_F16_PEAK_TFLOPS,

@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-CONV = ('conv_mfma_kernel', 'conv_pool1x1_kernel', 'conv_first_u8_kernel', 'stem_a_kernel',
+CONV = ('conv_mfma_kernel', 'conv_resident_kernel', 'conv_pool1x1_kernel', 'conv_first_u8_kernel', 'stem_a_kernel',
         'stem_b_kernel', 'imgconv_kernel')
 
 
