@@ -1783,6 +1783,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (op.pool_in) tr_label += " <- maxpool3s2";
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
+      const bool resident = !op.v2 && !op.pool_in && resident_ok(m, op, a);
+      if (resident) tr_label += " [weights resident in LDS]";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
       if (op.v2) {
@@ -1811,7 +1813,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
           case 3: hipLaunchKernelGGL((conv_pool1x1_kernel<3>), grid, dim3(kConvThreads), lds, stream, a); break;
           default: hipLaunchKernelGGL((conv_pool1x1_kernel<4>), grid, dim3(kConvThreads), lds, stream, a); break;
         }
-      } else if (resident_ok(m, op, a)) {
+      } else if (resident) {
         const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
         static const bool attr = [] {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_resident_kernel<3, 2>),
