@@ -251,6 +251,10 @@ class FastaReader:
   def n_bases(self, contig: str) -> int:
     return len(self._contigs[contig])
 
+  def contig_names(self) -> List[str]:
+    """Contig names in file order (the order the reference's regions are processed in)."""
+    return list(self._contigs)
+
   def get_bases(self, contig: str, start: int, end: int) -> str:
     return self._contigs[contig][start:end]
 

@@ -297,12 +297,24 @@ def requested_regions(args, ref_reader, contig_names: Sequence[str]) -> List[T.R
 
 
 def calling_regions(args, ref_reader, contig_names: Sequence[str], num_shards: int) -> List[T.Range]:
-  """processing_regions_from_options (make_examples_core.py:836-888): the regions (or every contig
-  of the BAM that the reference has), cut into partition_size pieces, this task's share round robin."""
-  regions = requested_regions(args, ref_reader, contig_names)
-  pieces = [p for r in regions for p in make_examples_core.partition(r, args.partition_size)]
-  if num_shards:
-    pieces = [p for i, p in enumerate(pieces) if i % num_shards == args.task]
+  """processing_regions_from_options (make_examples_core.py:3380-3445): the contigs the BAM and the
+  reference share, in the reference's order, intersected with --regions (overlapping and adjacent
+  literals merged, clipped to the contigs, unknown contigs dropped), cut into partition_size pieces;
+  this task's share round robin (the examples go to TFRecords)."""
+  in_bam = set(contig_names)
+  contigs = []
+  for name in (ref_reader.contig_names() if hasattr(ref_reader, 'contig_names') else contig_names):
+    if name in in_bam:
+      try:
+        contigs.append((name, ref_reader.n_bases(name)))
+      except KeyError:
+        continue
+  include = requested_regions(args, ref_reader, contig_names) if args.regions else None
+  pieces = make_examples_core.regions_to_process(
+      contigs, args.partition_size, calling_regions=include,
+      task_id=args.task if num_shards else None, num_shards=num_shards if num_shards else None)
+  if not pieces and not contigs:
+    raise ValueError('The regions to call is empty. Check your --regions flag')
   return pieces
 
 

@@ -20,7 +20,7 @@ outside SURVEY.md section 8.
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 from deepvariant_amd import allelecounter
 from deepvariant_amd import direct_phasing
@@ -63,6 +63,125 @@ def partition(region: T.Range, size: int) -> Iterator[T.Range]:
     raise ValueError('partition size must be positive')
   for start in range(region.start, region.end, size):
     yield T.Range(region.reference_name, start, min(start + size, region.end))
+
+
+def _contig_tuples(contigs) -> List[Tuple[str, int]]:
+  return [(c[0], int(c[1])) if isinstance(c, (tuple, list)) else (c.name, int(c.n_bases)) for c in contigs]
+
+
+def merge_ranges(ranges: Iterable[T.Range], contig_order: Optional[Sequence[str]] = None,
+                 known_contigs_only: bool = False) -> List[T.Range]:
+  """What iterating a nucleus `RangeSet` yields (third_party/nucleus/util/ranges.py:77-147):
+  overlapping AND adjacent ranges merged (`merge_overlaps(strict=False)`), sorted by contig --
+  in `contig_order` (the FASTA's) when given, else by name -- then by start.  With
+  `known_contigs_only` a range on a contig outside `contig_order` is an error, as it is for a
+  RangeSet built with `contigs`."""
+  by_contig: Dict[str, List[Tuple[int, int]]] = {}
+  for r in ranges:
+    by_contig.setdefault(r.reference_name, []).append((int(r.start), int(r.end)))
+  if contig_order is not None:
+    pos = {name: i for i, name in enumerate(contig_order)}
+    if known_contigs_only:
+      for name in by_contig:
+        if name not in pos:
+          raise ValueError('Range on an unrecognized contig: %s' % name)
+    names = sorted(by_contig, key=lambda n: (pos.get(n, len(pos)), n))
+  else:
+    names = sorted(by_contig)
+  out = []
+  for name in names:
+    merged: List[List[int]] = []
+    for start, end in sorted(by_contig[name]):
+      if merged and start <= merged[-1][1]:          # overlapping or touching
+        merged[-1][1] = max(merged[-1][1], end)
+      else:
+        merged.append([start, end])
+    out.extend(T.Range(name, a, b) for a, b in merged)
+  return out
+
+
+def intersect_ranges(a: Sequence[T.Range], b: Sequence[T.Range],
+                     contig_order: Optional[Sequence[str]] = None) -> List[T.Range]:
+  """`RangeSet.intersection` (ranges.py:204-279): the bases common to both sets; contigs present
+  in only one of them drop out."""
+  a, b = merge_ranges(a, contig_order), merge_ranges(b, contig_order)
+  b_by: Dict[str, List[T.Range]] = {}
+  for r in b:
+    b_by.setdefault(r.reference_name, []).append(r)
+  out = []
+  for r in a:
+    for o in b_by.get(r.reference_name, ()):
+      lo, hi = max(r.start, o.start), min(r.end, o.end)
+      if lo < hi:
+        out.append(T.Range(r.reference_name, lo, hi))
+  return merge_ranges(out, contig_order)
+
+
+def exclude_ranges(a: Sequence[T.Range], b: Sequence[T.Range],
+                   contig_order: Optional[Sequence[str]] = None) -> List[T.Range]:
+  """`RangeSet.exclude_regions` (ranges.py:281-300): `a` with every base of `b` chopped out."""
+  cut_by: Dict[str, List[T.Range]] = {}
+  for r in merge_ranges(b, contig_order):
+    cut_by.setdefault(r.reference_name, []).append(r)
+  out = []
+  for r in merge_ranges(a, contig_order):
+    start = r.start
+    for c in cut_by.get(r.reference_name, ()):
+      if c.end <= start or c.start >= r.end:
+        continue
+      if c.start > start:
+        out.append(T.Range(r.reference_name, start, c.start))
+      start = max(start, c.end)
+    if start < r.end:
+      out.append(T.Range(r.reference_name, start, r.end))
+  return out
+
+
+def build_calling_regions(contigs, regions_to_include: Sequence[T.Range] = (),
+                          regions_to_exclude: Sequence[T.Range] = ()) -> List[T.Range]:
+  """calling_regions_utils.build_calling_regions (calling_regions_utils.py:48-98) without the
+  reference-N exclusion (`--discard_non_dna_regions`, default off): every base of `contigs`,
+  intersected with the regions to include if there are any, minus the regions to exclude."""
+  contigs = _contig_tuples(contigs)
+  order = [name for name, _ in contigs]
+  regions = [T.Range(name, 0, n) for name, n in contigs]
+  if regions_to_include:
+    regions = intersect_ranges(regions, regions_to_include, order)
+  if regions_to_exclude:
+    regions = exclude_ranges(regions, regions_to_exclude, order)
+  return merge_ranges(regions, order)
+
+
+def regions_to_process(contigs, partition_size: int, calling_regions: Optional[Sequence[T.Range]] = None,
+                       task_id: Optional[int] = None, num_shards: Optional[int] = None,
+                       round_robin_sampling: bool = True) -> List[T.Range]:
+  """make_examples_core.regions_to_process (make_examples_core.py:800-888): the contigs'
+  bases (intersected with `calling_regions`), in FASTA contig order, cut into pieces of at
+  most `partition_size`; with shards, task `task_id` takes the pieces i % num_shards ==
+  task_id -- the rule the reference applies whenever examples go to TFRecords, and the rule
+  the ranks of a multi-GPU run use (deepvariant_amd/dist.py) -- or, without round robin, the
+  task_id-th block of ceil(n / num_shards) consecutive pieces."""
+  if (task_id is None) != (num_shards is None):
+    raise ValueError('Both task_id and num_shards must be present if either is', task_id, num_shards)
+  if num_shards:
+    if num_shards < 0:
+      raise ValueError('num_shards={} must be >= 0'.format(num_shards))
+    if task_id < 0 or task_id >= num_shards:
+      raise ValueError('task_id={} should be >= 0 and < num_shards={}'.format(task_id, num_shards))
+  contigs = _contig_tuples(contigs)
+  order = [name for name, _ in contigs]
+  regions = [T.Range(name, 0, n) for name, n in contigs]
+  if calling_regions:
+    regions = intersect_ranges(regions, calling_regions, order)
+  else:
+    regions = merge_ranges(regions, order)
+  pieces = [p for r in regions for p in partition(r, partition_size)]
+  if num_shards:
+    if round_robin_sampling:
+      return [p for i, p in enumerate(pieces) if i % num_shards == task_id]
+    per_shard = -(-len(pieces) // num_shards)
+    return pieces[task_id * per_shard:(task_id + 1) * per_shard]
+  return pieces
 
 
 class RegionProcessor:
