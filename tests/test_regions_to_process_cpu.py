@@ -78,7 +78,8 @@ def test_regions_to_process_sharding(num_shards, round_robin):  # :786-804
                                   round_robin_sampling=round_robin)
     sharded.extend(part)
     if round_robin:   # the rule the ranks of a multi-GPU run use (deepvariant_amd/dist.py)
-      assert part == [r for i, r in enumerate(unsharded) if i % num_shards == task]
+      from deepvariant_amd import dist
+      assert part == dist.regions_for_rank(unsharded, task, num_shards)
   assert key(sharded) == key(unsharded) and len(sharded) == len(unsharded) == 60
 
 
