@@ -122,7 +122,8 @@ class DvReadRequirements(C.Structure):
               ('keep_secondary_alignments', C.c_int32),
               ('keep_supplementary_alignments', C.c_int32),
               ('keep_improperly_placed', C.c_int32),
-              ('min_mapping_quality', C.c_int32)]
+              ('min_mapping_quality', C.c_int32),
+              ('use_original_base_quality_scores', C.c_int32)]
 
 
 class DvPackReads(C.Structure):

@@ -200,6 +200,47 @@ bool find_u32_array_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1
   return false;
 }
 
+// The bytes of a `Z` aux tag (without the NUL), or false.
+bool find_string_tag(const uint8_t* aux, const uint8_t* end, char t0, char t1, const uint8_t** data,
+                     uint32_t* len) {
+  const uint8_t* p = aux;
+  auto size_of = [](uint8_t ty) -> int {
+    switch (ty) {
+      case 'A': case 'c': case 'C': return 1;
+      case 's': case 'S': return 2;
+      case 'i': case 'I': case 'f': return 4;
+      default: return 0;
+    }
+  };
+  while (p + 3 <= end) {
+    const bool hit = p[0] == static_cast<uint8_t>(t0) && p[1] == static_cast<uint8_t>(t1);
+    const uint8_t ty = p[2];
+    p += 3;
+    const int sz = size_of(ty);
+    if (sz) {
+      if (p + sz > end) return false;
+      p += sz;
+    } else if (ty == 'Z' || ty == 'H') {
+      const uint8_t* q = p;
+      while (q < end && *q) ++q;
+      if (hit && ty == 'Z') {
+        *data = p;
+        *len = static_cast<uint32_t>(q - p);
+        return true;
+      }
+      p = q + 1;
+    } else if (ty == 'B') {
+      if (p + 5 > end) return false;
+      const int sub = size_of(p[0]);
+      if (!sub) return false;
+      p += 5 + static_cast<size_t>(le32(p + 1)) * sub;
+    } else {
+      return false;
+    }
+  }
+  return false;
+}
+
 // ---- record decoding ------------------------------------------------------------
 struct RegionFilter {
   dv_read_requirements rq{};
@@ -280,7 +321,23 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
   }
   // nucleus::ReadOverlapsRegion on [start, end) with ReadEnd = pos + reference span
   if (!(f.end > rpos && f.start < rpos + std::max<int64_t>(ref_len, 1))) return DV_OK;
-  if (l_seq && qual[0] == 0xff) {
+  // AssignAlignedQuality (sam_reader.cc:722-760): QUAL, or the OQ tag when the original scores
+  // are asked for
+  const uint8_t* qsrc = qual;
+  int qsub = 0;
+  if (rq.use_original_base_quality_scores) {
+    const uint8_t* oq = nullptr;
+    uint32_t n_oq = 0;
+    if (!find_string_tag(qual + l_seq, r + block_size, 'O', 'Q', &oq, &n_oq)) {
+      return dv::fail(DV_ERR_BAD_INPUT, "use_original_base_quality_scores: a read has no OQ tag");
+    }
+    if (n_oq != l_seq) return dv::fail(DV_ERR_BAD_INPUT, "OQ tag and sequence are of different length");
+    for (uint32_t i = 0; i < n_oq; ++i) {
+      if (oq[i] < 33) return dv::fail(DV_ERR_BAD_INPUT, "OQ tag holds a character below '!'");
+    }
+    qsrc = oq;
+    qsub = 33;
+  } else if (l_seq && qual[0] == 0xff) {
     return dv::fail(DV_ERR_BAD_INPUT, "Could not read base quality scores");  // sam_reader.cc:752
   }
   // The encoder indexes bases / qualities by CIGAR query offsets without bounds checks (like
@@ -309,7 +366,13 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
     const uint8_t byte = seq[i >> 1];
     t->bases[b0 + i] = static_cast<uint8_t>(kNt16[(i & 1) ? (byte & 0xF) : (byte >> 4)]);
   }
-  t->quals.insert(t->quals.end(), qual, qual + l_seq);
+  {
+    const size_t q0 = t->quals.size();
+    t->quals.insert(t->quals.end(), qsrc, qsrc + l_seq);
+    if (qsub) {
+      for (size_t i = q0; i < t->quals.size(); ++i) t->quals[i] = static_cast<uint8_t>(t->quals[i] - qsub);
+    }
+  }
   t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
   t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
   t->names.insert(t->names.end(), name, name + l_read_name);  // includes the NUL

@@ -84,8 +84,12 @@ def bam_contig_names(path: str) -> List[str]:
 
 
 def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
-             end: int = 1 << 62) -> Tuple[List[str], List[T.Read]]:
-  """Reads a whole (small) BAM; returns (contig names, reads overlapping)."""
+             end: int = 1 << 62, use_original_quality_scores: bool = False
+             ) -> Tuple[List[str], List[T.Read]]:
+  """Reads a whole (small) BAM; returns (contig names, reads overlapping).  With
+  `use_original_quality_scores` the qualities are the OQ:Z tag's characters - 33
+  (sam_reader.cc:722-740); a read without the tag is an error here (nucleus leaves its
+  aligned_quality empty, which nothing downstream can draw)."""
   buf = b''.join(_bgzf_blocks(path))
   if buf[:4] != b'BAM\x01':
     raise IOError('bad BAM magic')
@@ -144,6 +148,13 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
       seq.append(_SEQ_NT16[(b >> 4) if (i & 1) == 0 else (b & 0xF)])
     info: Dict[str, T.ListValue] = {}
     aux = rec[p:]
+    if use_original_quality_scores:
+      oq = _find_string_tag(aux, b'OQ')
+      if oq is None:
+        raise ValueError('use_original_quality_scores: read %s has no OQ tag' % name)
+      if len(oq) != l_seq:
+        raise ValueError('OQ tag and sequence are of different length')
+      qual = bytes(c - 33 for c in oq)
     hp = _find_int_tag(aux, b'HP')
     if hp is not None:
       info['HP'] = T.ListValue(values=[T.Value(int_value=hp)])
@@ -194,6 +205,31 @@ def _find_int_tag(aux, tag: bytes) -> Optional[int]:
       while aux[p] != 0:
         p += 1
       p += 1
+    elif ty == b'B':
+      sub = bytes(aux[p:p + 1])
+      cnt = struct.unpack_from('<i', aux, p + 1)[0]
+      p += 5 + cnt * _AUX_SIZES[sub]
+    else:
+      return None
+  return None
+
+
+def _find_string_tag(aux, tag: bytes) -> Optional[bytes]:
+  """The bytes of a `Z` aux tag, or None."""
+  p, n = 0, len(aux)
+  while p + 3 <= n:
+    t = bytes(aux[p:p + 2])
+    ty = bytes(aux[p + 2:p + 3])
+    p += 3
+    if ty in _AUX_SIZES:
+      p += _AUX_SIZES[ty]
+    elif ty in (b'Z', b'H'):
+      q = p
+      while aux[q] != 0:
+        q += 1
+      if t == tag and ty == b'Z':
+        return bytes(aux[p:q])
+      p = q + 1
     elif ty == b'B':
       sub = bytes(aux[p:p + 1])
       cnt = struct.unpack_from('<i', aux, p + 1)[0]

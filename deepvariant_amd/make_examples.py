@@ -108,6 +108,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--types_to_alt_align', default='indels')
   ap.add_argument('--parse_sam_aux_fields', default='false', **boolean)     # the HP tag is always read
   ap.add_argument('--keep_duplicates', default='false', **boolean)
+  ap.add_argument('--use_original_quality_scores', default='false', **boolean)   # qualities from the OQ tag
   ap.add_argument('--keep_supplementary_alignments', default='false', **boolean)
   ap.add_argument('--keep_secondary_alignments', default='false', **boolean)
   ap.add_argument('--keep_legacy_allele_counter_behavior', default='false', **boolean)
@@ -338,7 +339,8 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
     reads = packing.ReadTable.from_bam(
         args.reads, contig, lo, hi, min_mapping_quality=args.min_mapping_quality,
         keep_duplicates=_true(args.keep_duplicates), keep_supplementary=_true(args.keep_supplementary_alignments),
-        keep_secondary=_true(args.keep_secondary_alignments)).to_reads(contig)
+        keep_secondary=_true(args.keep_secondary_alignments),
+        use_original_quality_scores=_true(args.use_original_quality_scores)).to_reads(contig)
     reads_by_contig[contig] = (reads, [utils.read_range(r) for r in reads])
   proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
   model = None

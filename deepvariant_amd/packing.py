@@ -302,14 +302,15 @@ class ReadTable:
                end: int = 1 << 62, min_mapping_quality: int = 0,
                keep_duplicates: bool = False, keep_supplementary: bool = False,
                keep_secondary: bool = False, keep_failed_qc: bool = False,
-               keep_improperly_placed: bool = False, n_threads: int = 4) -> 'ReadTable':
+               keep_improperly_placed: bool = False, n_threads: int = 4,
+               use_original_quality_scores: bool = False) -> 'ReadTable':
     """Native BAM -> packed table (dv_bam_read_region, include/dvhip.h): the reads of
     `contig` overlapping [start, end) that pass nucleus' ReadRequirements, in file order."""
     import ctypes as C
     lib = _lib.lib()
     req = _lib.DvReadRequirements(int(keep_duplicates), int(keep_failed_qc), int(keep_secondary),
                                   int(keep_supplementary), int(keep_improperly_placed),
-                                  int(min_mapping_quality))
+                                  int(min_mapping_quality), int(use_original_quality_scores))
     handle = C.c_void_p()
     _lib.check(lib.dv_bam_read_region(
         path.encode(), contig.encode() if contig is not None else None, int(start),

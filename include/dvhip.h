@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 1
+#define DV_ABI_VERSION 2
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -275,6 +275,11 @@ typedef struct dv_read_requirements {
   int32_t keep_supplementary_alignments;
   int32_t keep_improperly_placed;
   int32_t min_mapping_quality;
+  /* SamReaderOptions.use_original_base_quality_scores (third_party/nucleus/io/sam_reader.cc:722-740):
+   * qualities come from the OQ:Z aux tag (char - 33) instead of QUAL.  nucleus leaves
+   * aligned_quality EMPTY for a read without the tag -- which the encoder cannot draw -- so
+   * here such a read is an error (DV_ERR_BAD_INPUT). */
+  int32_t use_original_base_quality_scores;
 } dv_read_requirements;
 
 typedef struct dv_read_table dv_read_table; /* owns host arrays in dv_batch's read layout */

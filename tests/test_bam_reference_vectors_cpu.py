@@ -123,9 +123,9 @@ def _decode_read(buf):
   return r
 
 
-def _sam_to_bam(sam_path, bam_path):
-  """SAMv1 text -> BAM records (SAMv1 4.2), aux fields dropped (the golden comparison ignores
-  `info`, as the reference's does)."""
+def _sam_to_bam(sam_path, bam_path, keep_string_tags=()):
+  """SAMv1 text -> BAM records (SAMv1 4.2); of the aux fields only the `Z` tags named in
+  `keep_string_tags` are kept (the golden comparison ignores `info`, as the reference's does)."""
   contigs, recs = [], []
   for line in open(sam_path):
     line = line.rstrip('\n')
@@ -135,6 +135,13 @@ def _sam_to_bam(sam_path, bam_path):
     if line.startswith('@') or not line:
       continue
     q, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = line.split('\t')[:11]
+    aux = b''
+    for field in line.split('\t')[11:]:
+      tag, ty, value = field.split(':', 2)
+      if ty == 'Z' and tag in keep_string_tags:
+        aux += tag.encode() + b'Z' + value.encode() + b'\0'
+      elif ty == 'i' and tag == 'NM':            # something else in front of / behind the tag
+        aux += b'NMi' + struct.pack('<i', int(value))
     names = [c[0] for c in contigs]
     ref_id = names.index(rname) if rname != '*' else -1
     next_ref = ref_id if rnext == '=' else (names.index(rnext) if rnext != '*' else -1)
@@ -153,7 +160,7 @@ def _sam_to_bam(sam_path, bam_path):
     cig = b''.join(struct.pack('<I', (n << 4) | BAM_OPS.index(op)) for n, op in ops)
     body = (struct.pack('<iiBBHHHiiii', ref_id, int(pos) - 1, len(q) + 1, int(mapq), 0, len(ops),
                         int(flag), l_seq, next_ref, int(pnext) - 1, int(tlen)) +
-            q.encode() + b'\0' + cig + bytes(packed) + qb)
+            q.encode() + b'\0' + cig + bytes(packed) + qb + aux)
     recs.append(struct.pack('<i', len(body)) + body)
   hdr = b'BAM\x01' + struct.pack('<i', 0) + struct.pack('<i', len(contigs))
   for name, ln in contigs:
@@ -186,3 +193,28 @@ def test_conversion_matches_the_reference_golden_protos(tmp_path):
     assert bytes(np.asarray(t.quals[s0:s1])) == g['qual']
     span = sum(w >> 4 for w in g['cigar'] if (w & 0xF) in (1, 3, 4, 8, 9))
     assert int(t.read_end[i]) == g['pos'] + span
+
+
+def test_original_quality_scores_from_the_oq_tag(tmp_path):
+  """SamReaderTest.TestAlignedQualityOQ / ...WhenTagIsNotPresent (sam_reader_test.cc:96-141):
+  with use_original_base_quality_scores every quality of `test_oq.sam` is 'C' - 33 (its OQ tags
+  are all 'C'), QUAL is ignored; `test.sam` has no OQ tags -- nucleus leaves aligned_quality
+  EMPTY there, which the encoder cannot draw, so this reader reports it.  Native reader and
+  Python restatement agree."""
+  from deepvariant_amd import genomics_io
+  bam = str(tmp_path / 'oq.bam')
+  _sam_to_bam(os.path.join(HERE, 'test_oq.sam'), bam, keep_string_tags=('OQ', 'MD'))
+  plain = packing.ReadTable.from_bam(bam, None, 0, 1 << 40, **EVERYTHING)
+  oq = packing.ReadTable.from_bam(bam, None, 0, 1 << 40, use_original_quality_scores=True, **EVERYTHING)
+  assert oq.n_reads == plain.n_reads == 5
+  assert len(oq.quals) == len(plain.quals) and set(np.asarray(oq.quals).tolist()) == {ord('C') - 33}
+  assert set(np.asarray(plain.quals).tolist()) != {ord('C') - 33}
+  np.testing.assert_array_equal(np.asarray(oq.bases), np.asarray(plain.bases))
+  _, py = genomics_io.read_bam(bam, use_original_quality_scores=True)
+  assert [bytes(r.aligned_quality) for r in py] == [bytes([ord('C') - 33]) * len(r.aligned_sequence) for r in py]
+  no_tags = str(tmp_path / 'no_oq.bam')
+  _sam_to_bam(os.path.join(HERE, 'test.sam'), no_tags)
+  with pytest.raises(_lib.DvError, match='OQ'):
+    packing.ReadTable.from_bam(no_tags, None, 0, 1 << 40, use_original_quality_scores=True, **EVERYTHING)
+  with pytest.raises(ValueError, match='OQ'):
+    genomics_io.read_bam(no_tags, use_original_quality_scores=True)
