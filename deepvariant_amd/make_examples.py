@@ -36,7 +36,7 @@ _REALIGNER_FLAGS = {k: v for k, v in realigner_module._FLAG_DEFAULTS.items()   #
                         'max_num_mismatches', 'realignment_similarity_threshold', 'kmer_size', 'split_skip_reads')}
 _REJECTED_IF_SET = (   # flags of the reference whose machinery is outside this path
     'truth_variants', 'confident_regions', 'gvcf', 'candidates', 'proposed_variants', 'population_vcfs',
-    'exclude_regions', 'runtime_by_region', 'denovo_regions', 'small_model_path', 'read_phases_output',
+    'runtime_by_region', 'denovo_regions', 'small_model_path', 'read_phases_output',
     'allele_frequency_vcfs', 'customized_classes_labeler_classes_list', 'pangenome')
 
 
@@ -82,6 +82,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--examples', default='')
   ap.add_argument('--candidate_positions', default='')     # output of --mode candidate_sweep
   ap.add_argument('--regions', default='')
+  ap.add_argument('--exclude_regions', default='')      # space-separated literals, chopped out of the calling regions
   ap.add_argument('--task', type=int, default=0)
   ap.add_argument('--sample_name', default='')
   ap.add_argument('--channel_list', default=','.join(T.PILEUP_DEFAULT_CHANNELS))
@@ -310,12 +311,16 @@ def calling_regions(args, ref_reader, contig_names: Sequence[str], num_shards: i
         contigs.append((name, ref_reader.n_bases(name)))
       except KeyError:
         continue
-  include = requested_regions(args, ref_reader, contig_names) if args.regions else None
+  include = requested_regions(args, ref_reader, contig_names) if args.regions else []
+  exclude = [parse_region(x, ref_reader) for x in args.exclude_regions.split()]
+  calling = make_examples_core.build_calling_regions(contigs, include, exclude)
+  if not calling:
+    raise ValueError(
+        'The regions to call is empty. Check your --regions and --exclude_regions flags to make sure '
+        'they are not resulting in set of empty region to process.')        # make_examples_core.py:3424-3431
   pieces = make_examples_core.regions_to_process(
-      contigs, args.partition_size, calling_regions=include,
+      contigs, args.partition_size, calling_regions=calling,
       task_id=args.task if num_shards else None, num_shards=num_shards if num_shards else None)
-  if not pieces and not contigs:
-    raise ValueError('The regions to call is empty. Check your --regions flag')
   return pieces
 
 

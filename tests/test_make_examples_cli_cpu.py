@@ -107,6 +107,20 @@ def test_calling_regions_are_shared_round_robin():
       ('chr20', 0, 6000), ('chr20', 6000, 10500)]
 
 
+def test_regions_are_merged_clipped_and_excluded_like_the_reference():
+  """build_calling_regions + regions_to_process (calling_regions_utils.py:48-98,
+  make_examples_core.py:800-888): overlapping / adjacent literals merge, a literal past the contig
+  end is clipped, --exclude_regions is chopped out, nothing left is an error."""
+  ref = RF.StringRef('chr20', 'A' * 10500)
+  args = parse('--examples', 'e', '--regions', 'chr20:3,001-5,000 chr20:1-3,000 chr20:9,001-99,000',
+               '--exclude_regions', 'chr20:2,501-2,600 chr20:10,001-10,500', '--partition_size', '2000')
+  assert [(p.start, p.end) for p in me.calling_regions(args, ref, ['chr20'], 0)] == [
+      (0, 2000), (2000, 2500), (2600, 4600), (4600, 5000), (9000, 10000)]
+  args = parse('--examples', 'e', '--regions', 'chr20:1-100', '--exclude_regions', 'chr20')
+  with pytest.raises(ValueError, match='regions to call is empty'):
+    me.calling_regions(args, ref, ['chr20'], 0)
+
+
 def test_reservoir_sample():
   """nucleus utils_test.py:96-132: lengths, bad k, and uniform frequencies with the seeded RandomState."""
   rs = np.random.RandomState(123456789)
