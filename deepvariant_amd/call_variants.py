@@ -19,6 +19,7 @@ from typing import Iterable, List, Optional, Sequence
 import numpy as np
 
 from deepvariant_amd import protowire as pw
+from deepvariant_amd import sharded_file_utils
 from deepvariant_amd import tfrecord
 
 _GL_PRECISION = 10  # call_variants.py:83
@@ -83,14 +84,11 @@ def create_cvo(encoded_variant: bytes, gls: Sequence[float],
 
 
 def sharded_paths(spec: str) -> List[str]:
-  """`name@N.ext` -> N shard names; otherwise a glob / single file
-  (third_party/nucleus/io/sharded_file_utils.py)."""
-  m = re.match(r'^(.*)@(\d+)(.*)$', spec)
-  if m:
-    base, n, suffix = m.group(1), int(m.group(2)), m.group(3)
-    return ['%s-%05d-of-%05d%s' % (base, i, n, suffix) for i in range(n)]
-  paths = sorted(glob.glob(spec))
-  return paths or [spec]
+  """`name@N.ext` -> its N shard names; otherwise the files a pattern / comma list matches, or
+  the name itself (sharded_file_utils.glob_list_sharded_file_patterns as call_variants.py:889 uses it)."""
+  if sharded_file_utils.is_sharded_file_spec(spec):
+    return sharded_file_utils.generate_sharded_filenames(spec)
+  return sharded_file_utils.glob_list_sharded_file_patterns(spec) or [spec]
 
 
 def read_examples(paths: Iterable[str]):
@@ -114,7 +112,7 @@ def example_info_shape(examples_path: str) -> Optional[List[int]]:
 
 def is_sharded_filename(path: str) -> bool:
   """third_party/nucleus/io/sharded_file_utils.py:59,181-184 (`name-00003-of-00016[.ext]`)."""
-  return re.match(r'(.*)-(\d+)-of-(\d*[1-9]\d*)([^/]+)?$', path) is not None
+  return sharded_file_utils.is_sharded_filename(path)
 
 
 def call_variants(examples, outfile: str, model, batch_size: int = _DEFAULT_BATCH,

@@ -26,6 +26,7 @@ from deepvariant_amd import genomics_io
 from deepvariant_amd import make_examples_core
 from deepvariant_amd import make_examples_native
 from deepvariant_amd import packing
+from deepvariant_amd import sharded_file_utils
 from deepvariant_amd import tfrecord
 from deepvariant_amd.realigner import realigner as realigner_module
 from deepvariant_amd.realigner import utils
@@ -231,16 +232,16 @@ def check_flags(args) -> None:
 
 
 def _shard(spec: str, task: int):
-  """'x.tfrecord@N.gz' + task -> (the task's file name, N); a plain name is one shard."""
-  m = re.match(r'^(.*)@(\d+)(.*)$', spec)
-  if not m:
+  """'x.tfrecord@N.gz' + task -> (the task's file name, N); a plain name is one shard
+  (sharded_file_utils.resolve_filespecs, make_examples_core.py:3349-3360)."""
+  if not sharded_file_utils.is_sharded_file_spec(spec):
     if task != 0:
       raise ValueError('--task=%d needs a sharded output name (name@N)' % task)
     return spec, 0
-  n = int(m.group(2))
+  n = sharded_file_utils.parse_sharded_file_spec(spec)[1]
   if not 0 <= task < n:
     raise ValueError('task_id={} should be >= 0 and < num_shards={}'.format(task, n))
-  return '%s-%05d-of-%05d%s' % (m.group(1), task, n, m.group(3)), n
+  return sharded_file_utils.sharded_filename(spec, task), n
 
 
 def options_from_flags(args):
