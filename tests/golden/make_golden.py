@@ -129,7 +129,7 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner', 'illumina_alt')) for a in sys.argv[1:]):
+if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner', 'illumina_alt', 'nucleus_sam')) for a in sys.argv[1:]):
   main()
 
 
@@ -497,3 +497,22 @@ def main_illumina_alt():
 
 if __name__ == '__main__' and 'illumina_alt' in sys.argv[1:]:
   main_illumina_alt()
+
+
+# ---------------------------------------------------------------------------
+# nucleus' SamReader test inputs (third_party/nucleus/testdata/): test.bam (+ .bai), test.sam and
+# its golden Read protos, test_oq.sam -- the files sam_reader_test.cc runs on -- bundled as bytes.
+#   nucleus_sam.npz: one uint8 array per file; tests/test_bam_reference_vectors_cpu.py writes
+#   them back to a temporary directory.
+# ---------------------------------------------------------------------------
+def main_nucleus_sam():
+  src = '/root/reference/third_party/nucleus/testdata'
+  d = {}
+  for name in ('test.bam', 'test.bam.bai', 'test.sam', 'test.sam.golden.tfrecord', 'test_oq.sam'):
+    d[name.replace('.', '_')] = np.frombuffer(open(os.path.join(src, name), 'rb').read(), np.uint8)
+    print(name, d[name.replace('.', '_')].size)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/nucleus_sam.npz'), **d)
+
+
+if __name__ == '__main__' and 'nucleus_sam' in sys.argv[1:]:
+  main_nucleus_sam()

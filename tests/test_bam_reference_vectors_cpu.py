@@ -14,8 +14,10 @@ restatement:
   back natively: name, read number, position, strand, mapping quality, CIGAR, bases,
   qualities, fragment length and end of the five mapped reads equal the golden protos.
 
-Fixtures: tests/golden/nucleus/ = the four files verbatim from
-third_party/nucleus/testdata/ (reference test DATA; 31 KB)."""
+Fixtures: tests/golden/nucleus_sam.npz = the bytes of the five files of
+third_party/nucleus/testdata/ that sam_reader_test.cc runs on (reference test DATA, 18 KB
+compressed; bundled by tests/golden/make_golden.py nucleus_sam), written back to a temporary
+directory for the test session."""
 import os
 import struct
 
@@ -25,7 +27,14 @@ import pytest
 from deepvariant_amd import _lib, packing, protowire, tfrecord
 from tests.test_bam_native_cpu import BAM_OPS, _bgzf
 
-HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nucleus')
+import tempfile
+
+_BUNDLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nucleus_sam.npz')
+HERE = tempfile.mkdtemp(prefix='nucleus_sam_')
+with np.load(_BUNDLE) as _z:
+  for _name in ('test.bam', 'test.bam.bai', 'test.sam', 'test.sam.golden.tfrecord', 'test_oq.sam'):
+    with open(os.path.join(HERE, _name), 'wb') as _f:
+      _f.write(_z[_name.replace('.', '_')].tobytes())
 BAM = os.path.join(HERE, 'test.bam')
 EVERYTHING = dict(keep_duplicates=True, keep_supplementary=True, keep_secondary=True,
                   keep_failed_qc=True, keep_improperly_placed=True)
