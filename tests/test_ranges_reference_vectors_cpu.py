@@ -145,3 +145,50 @@ def test_find_max_overlapping_order_and_ties():
   two = [T.Range('1', 0, 5), T.Range('1', 5, 10)]
   for s in (two, two[::-1]):
     assert U.find_max_overlapping(q, s) == 0
+
+
+# ---- third_party/nucleus/util/utils_test.py:50-165: read_range / read_end / read_overlaps_region ----
+def test_read_range_and_end():
+  start = 10000001
+  for cigar, span in (('2M1I3M', 5), ('2M16D3M', 5 + 16)):
+    read = T.make_read('AAACAG', chrom='chrX', start=start, cigar=cigar, quals=list(range(10, 16)), name='read1')
+    r = U.read_range(read)
+    assert (r.reference_name, r.start, r.end) == ('chrX', start, start + span)
+
+
+_OVERLAPS = [
+    (0, 3, 'chr1', 4, 10, False), (0, 3, 'chr1', 3, 10, False), (0, 3, 'chr1', 2, 10, True),
+    (0, 3, 'chr1', 1, 10, True), (0, 3, 'chr1', 0, 10, True), (0, 3, 'chr1', 0, 1, True),
+    (0, 3, 'chr1', 0, 2, True), (0, 3, 'chr1', 0, 3, True), (0, 3, 'chr1', 1, 2, True),
+    (0, 3, 'chr1', 1, 3, True), (0, 3, 'chr1', 2, 3, True), (0, 3, 'chr1', 0, 4, True),
+    (0, 3, 'chr1', 1, 4, True), (0, 3, 'chr2', 1, 4, False),
+]
+
+
+@pytest.mark.parametrize('s1,e1,ref2,s2,e2,expected', _OVERLAPS)
+def test_read_overlaps_region(s1, e1, ref2, s2, e2, expected):
+  """The same answer from the three places that ask the question: the host utilities, the
+  oracle's ReadOverlaps and the C ABI's dv_query_reads (InMemoryReader::Query; one contig
+  per table, so the other-contig case is the host's)."""
+  import ctypes as C
+  import numpy as np
+  from deepvariant_amd import _lib
+  from oracle import oracle as O
+  nbp = e1 - s1
+  read = T.make_read('A' * nbp, chrom='chr1', start=s1, cigar='%dM' % nbp, quals=[30] * nbp)
+  region = T.Range(ref2, s2, e2)
+  assert U.ranges_overlap(U.read_range(read), region) is expected
+  assert U.ranges_overlap(region, U.read_range(read)) is expected
+  if ref2 == 'chr1':
+    assert O.read_overlaps(read, s2, e2) is expected
+    pos = np.array([s1], np.int32)
+    off = np.array([0, 1], np.uint32)
+    cig = np.array([(nbp << 4) | 1], np.uint32)
+    q0, q1 = np.array([s2], np.int64), np.array([e2], np.int64)
+    list_off = np.zeros(2, np.uint32)
+    lib = _lib.lib()
+    lib.dv_query_reads.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib.check(lib.dv_query_reads(1, pos.ctypes.data, off.ctypes.data, cig.ctypes.data, 1, q0.ctypes.data,
+                                  q1.ctypes.data, list_off.ctypes.data, None))
+    assert bool(list_off[1]) is expected
