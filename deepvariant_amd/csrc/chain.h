@@ -1,0 +1,46 @@
+// chain.hip's interface: a CHAIN of stride-1, 'same'-padded one-dimensional convolutions
+// (1 x k and k x 1, k <= 7: the factorised 7x7 branches of Inception-v3's 17x17 blocks,
+// deepvariant/keras_modeling.py:268-274 / SURVEY.md App. B mixed4..mixed8) as ONE persistent
+// launch whose intermediate tensors never leave the CU.
+#ifndef DV_CHAIN_H_
+#define DV_CHAIN_H_
+
+#include "conv_common.h"
+
+namespace dv {
+
+constexpr int kChainMaxLayers = 4;
+constexpr int kChainTilePx = 192;   // pixels of one tile (6 MFMA fragments), padded
+constexpr int kChainMaxTaps = 7;
+
+struct ChainLayer {
+  const _Float16* w;      // packed [chunk][tap][2 k-groups][cout_pad][8]
+  const float* shift;     // folded BatchNorm shift, readable up to cout_pad
+  int n_chunks;           // Cin / 16
+  int cout, cout_pad;     // cout_pad: multiple of 32
+  int taps;               // filter length (odd)
+  int horizontal;         // 1: 1 x taps, 0: taps x 1
+  unsigned slab_bytes;    // one chunk of weights: taps * 2 * cout_pad * 16
+};
+
+struct ChainArgs {
+  const _Float16* in;     // C8 tensor the first layer reads
+  convk::TensorGeom ig;
+  unsigned in_img_bytes;  // bytes of one example of `in`
+  int N, G, h, w;         // G whole images of h x w pixels per tile (G*h*w <= kChainTilePx)
+  int n_tiles;            // ceil(N / G); the last tile is shifted back to end at image N
+  int n_layers;
+  ChainLayer L[kChainMaxLayers];
+  _Float16* out;          // the last layer's destination (a concat buffer)
+  convk::TensorGeom og;
+  int out_goff;           // first destination channel group
+  unsigned act_bytes;     // LDS: activation tile [channel group][kChainTilePx][8]
+  unsigned slot_bytes;    // LDS: one weight-slab slot (two of them follow the activations)
+};
+
+size_t chain_lds_bytes(const ChainArgs& a);
+void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream);
+
+}  // namespace dv
+
+#endif  // DV_CHAIN_H_

@@ -1,0 +1,427 @@
+// chain.hip -- the factorised-7x7 branches of Inception-v3's 17x17 blocks as fused,
+// persistent gfx950 kernels: 1x7 -> 7x1 (-> 1x7 -> 7x1 -> 1x7) with every intermediate
+// tensor resident in LDS.
+//
+// Replaces the per-layer launches of tf_keras InceptionV3's mixed4..mixed7 branch7x7 /
+// branch7x7dbl chains and mixed8's branch7x7x3 head (deepvariant/keras_modeling.py:268-274
+// builds the backbone; SURVEY.md App. B has the graph).  Per layer these launches spent about
+// half of their time outside the K loop (prologue, output stores, fill / drain:
+// profiles/r02_conv_ablation.txt) and fetched their pixel operand through the vector L1,
+// which is what bounded them (TA 87-89 % busy).  Here
+//   * a workgroup owns a tile of G WHOLE images (G * h * w <= 192 pixels = 6 MFMA fragments)
+//     and walks the whole chain on it: the c-channel intermediate (<= 74 KB) lives in ONE LDS
+//     buffer that is rewritten in place between layers -- a layer's full output sits in the
+//     accumulators of the four computing waves when its input dies;
+//   * the pixel operand of every MFMA is a ds_read_b128 of that buffer (tile pixels are stored
+//     [map row][image][column], so a filter tap is a constant byte offset and a fragment of 32
+//     pixels spans at most two map rows: the k x 1 layers skip the taps that only meet the
+//     zero padding, like conv_mfma_kernel's row-band mode);
+//   * WAVE SPECIALISATION: waves 0-3 (one per SIMD) only read LDS and issue MFMAs; waves 4-7
+//     only move data -- the weight slab of the next 16-channel chunk (all taps, all output
+//     channels: 28-43 KB) and the next tile's input, by LDS-DMA (buffer_load ... lds) -- and
+//     meet the computing waves at one s_barrier per chunk.  The computing waves never wait on
+//     a vector-memory counter except for their own output stores.
+// The K order (channel chunk major, tap minor), the fp32 accumulation, the fp16 rounding of
+// every intermediate and the shift + ReLU are those of the per-layer kernels (model.hip), and
+// skipped taps only ever multiply zeros: results are bit-identical to the per-layer path
+// (tests/test_hip_chain.py).
+#include <cstdlib>
+
+#include "chain.h"
+
+namespace dv {
+namespace {
+
+using namespace convk;
+
+constexpr int CH_THREADS = 512;
+constexpr int CH_PT = 3;                 // pixel fragments per computing wave
+constexpr int CH_TPX = kChainTilePx;     // 192
+constexpr unsigned CH_CHUNK_LDS = 2 * CH_TPX * 16;   // bytes of one 16-channel chunk of the tile
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void barrier_after_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void barrier_after_dma() {
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned up = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const char*>((static_cast<unsigned long long>(up) << 32) | lo);
+}
+
+// One 16-channel chunk: NT filter taps x (NB cout subtiles x 3 pixel fragments) MFMAs.  The
+// fragments of tap i + 1 are requested before the MFMAs of tap i (two static register sets).
+template <int NB, int NT>
+__device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, unsigned a_tap_stride,
+                                           const unsigned (&b_addr)[CH_PT], unsigned b_tap_stride,
+                                           const unsigned (&mask)[CH_PT], unsigned zero_addr,
+                                           float16_t (&acc)[NB][CH_PT]) {
+  half8_t A[2][NB], B[2][CH_PT];
+  auto load = [&](int i, int s) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      A[s][nb] = *reinterpret_cast<const half8_t*>(smem + a_addr + i * a_tap_stride + nb * 512);
+    }
+#pragma unroll
+    for (int pt = 0; pt < CH_PT; ++pt) {
+      const unsigned ad = (mask[pt] >> i) & 1u ? b_addr[pt] + i * b_tap_stride : zero_addr;
+      B[s][pt] = *reinterpret_cast<const half8_t*>(smem + ad);
+    }
+  };
+  load(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    if (i + 1 < NT) load(i + 1, (i + 1) & 1);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) {
+        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i & 1][nb], B[i & 1][pt], acc[nb][pt], 0, 0, 0);
+      }
+    }
+    if (i + 1 < NT) {
+      // the next tap's NB + 3 requests (and their address selects) ride in the issue slots
+      // between this tap's MFMAs, one request per MFMA, instead of in a gap after them
+#pragma unroll
+      for (int k = 0; k < NB + CH_PT; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);     // VALU
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// shift + ReLU + fp16 of one 32-cout accumulator, lanes l / l+32 paired into standard C8 pieces:
+// piece[t] = output channels cbase + 8 * (2t + hi) .. +7 of this lane's pixel (conv_common.h's
+// epilogue arithmetic, so that values match the per-layer kernels bit for bit).
+__device__ __forceinline__ void chain_pieces(const float16_t& a, const float* shift, int cbase, bool relu,
+                                             int hi, uint4_t (&piece)[2]) {
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+  unsigned pk[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+    const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(shift + (cbase + 8 * q)));
+    const f4_t l4 = sp[0], u4 = sp[1];
+    const float2_t s0 = hi ? float2_t{u4[0], u4[1]} : float2_t{l4[0], l4[1]};
+    const float2_t s1 = hi ? float2_t{u4[2], u4[3]} : float2_t{l4[2], l4[3]};
+    const float2_t v0 = float2_t{a[4 * q], a[4 * q + 1]} + s0;
+    const float2_t v1 = float2_t{a[4 * q + 2], a[4 * q + 3]} + s1;
+    half2_t h0 = __builtin_convertvector(v0, half2_t), h1 = __builtin_convertvector(v1, half2_t);
+    if (relu) {
+      h0 = __builtin_elementwise_max(h0, zero2);
+      h1 = __builtin_elementwise_max(h1, zero2);
+    }
+    pk[q][0] = __builtin_bit_cast(unsigned, h0);
+    pk[q][1] = __builtin_bit_cast(unsigned, h1);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+    const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+    piece[t] = uint4_t{d0[0], d1[0], d0[1], d1[1]};
+  }
+}
+
+// ------------------------------------------------------------------ computing waves (0-3)
+// wave = (pixel half ph, cout half ch): fragments 3 ph .. 3 ph + 2 of the tile, the first /
+// second half of the layer's 32-cout subtiles.
+struct ChainLane {
+  int prow[CH_PT], pcol[CH_PT], pimg[CH_PT];
+  bool pval[CH_PT];
+  unsigned act_lane[CH_PT], px_piece[CH_PT];
+  int l31, hi;
+};
+
+// One layer on one tile for one computing wave: NB cout subtiles x 3 pixel fragments, NT taps
+// per chunk.  The accumulators are local to this instantiation (a switch over tap counts
+// around a shared accumulator array made the register allocator spill).
+template <int NB, int NT>
+__device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainLayer& L, bool last, char* smem,
+                                                const ChainLane& c, int sub_base, int t_lo, unsigned m0,
+                                                unsigned m1, unsigned m2, int n0, unsigned step) {
+  // everything the chunk loop needs sits in registers before it starts: the barriers are asm
+  // statements with a memory clobber, anything still in memory would be re-read after each
+  const unsigned m[CH_PT] = {m0, m1, m2};
+  const int pad = (L.taps - 1) >> 1;
+  const int Gw = p.G * p.w;
+  const int n_chunks = L.n_chunks;
+  const unsigned ring0 = p.act_bytes, slot_bytes = p.slot_bytes;
+  const unsigned zero_addr = p.act_bytes + 2 * p.slot_bytes;
+  const unsigned b_tap_stride = static_cast<unsigned>(L.horizontal ? 16 : Gw * 16);
+  const unsigned a_tap_stride = static_cast<unsigned>(2 * L.cout_pad * 16);
+  unsigned b0[CH_PT];
+#pragma unroll
+  for (int pt = 0; pt < CH_PT; ++pt) {
+    b0[pt] = c.act_lane[pt] + static_cast<unsigned>(t_lo - pad) * b_tap_stride;
+  }
+  const unsigned a_lane = static_cast<unsigned>((c.hi * L.cout_pad + sub_base * 32 + c.l31) * 16) +
+                          static_cast<unsigned>(t_lo) * a_tap_stride;
+  float16_t acc[NB][CH_PT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int pt = 0; pt < CH_PT; ++pt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
+
+  for (int cc = 0; cc < n_chunks; ++cc, ++step) {
+    barrier_after_lds();   // B(l, cc): this chunk's weight slab (and, first chunk, the tile) landed
+    const unsigned a_addr = ring0 + (step & 1u) * slot_bytes + a_lane;
+    unsigned b_addr[CH_PT];
+#pragma unroll
+    for (int pt = 0; pt < CH_PT; ++pt) b_addr[pt] = b0[pt] + static_cast<unsigned>(cc) * CH_CHUNK_LDS;
+    chain_step<NB, NT>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, acc);
+  }
+  barrier_after_lds();     // E(l): every wave is done reading this layer's input
+  if (!last) {
+    // the layer's output replaces its input in LDS: [group][pixel][8]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int cbase = (sub_base + nb) * 32;
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) {
+        uint4_t piece[2];
+        chain_pieces(acc[nb][pt], L.shift, cbase, true, c.hi, piece);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int group = cbase / 8 + 2 * t + c.hi;
+          if (group * 8 < L.cout) {
+            *reinterpret_cast<uint4_t*>(smem + static_cast<unsigned>(group) * (CH_TPX * 16) + c.px_piece[pt]) =
+                piece[t];
+          }
+        }
+      }
+    }
+  } else {
+    // the last layer goes to HBM, straight into the block's concat buffer
+    const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
+    uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int cbase = (sub_base + nb) * 32;
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) {
+        uint4_t piece[2];
+        chain_pieces(acc[nb][pt], L.shift, cbase, true, c.hi, piece);
+        const int n = n0 + c.pimg[pt];
+        const unsigned obase = static_cast<unsigned>(
+            ((n * p.og.groups + p.out_goff) * p.og.hp + c.prow[pt] + p.og.halo) * p.og.wp + c.pcol[pt] +
+            p.og.halo);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int group = cbase / 8 + 2 * t + c.hi;
+          if (c.pval[pt] && n < p.N && group * 8 < L.cout) {
+            outp[obase + static_cast<unsigned>(group) * gstride] = piece[t];
+          }
+        }
+      }
+    }
+  }
+  return step;
+}
+
+// the layer's barriers without any matrix work (a wave whose pixels are all padding)
+__device__ __forceinline__ unsigned chain_layer_idle(const ChainLayer& L, unsigned step) {
+  const int n_chunks = L.n_chunks;
+  for (int cc = 0; cc < n_chunks; ++cc, ++step) barrier_after_lds();
+  barrier_after_lds();
+  return step;
+}
+
+__device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, int wave, int lane) {
+  const int ph = wave & 1, ch = wave >> 1;
+  ChainLane c;
+  c.l31 = lane & 31;
+  c.hi = lane >> 5;
+  const int Gw = p.G * p.w, T = Gw * p.h;
+#pragma unroll
+  for (int pt = 0; pt < CH_PT; ++pt) {
+    const int px = (ph * CH_PT + pt) * 32 + c.l31;
+    c.pval[pt] = px < T;
+    const int q = c.pval[pt] ? px : 0;
+    c.prow[pt] = q / Gw;
+    const int rem = q - c.prow[pt] * Gw;
+    c.pimg[pt] = rem / p.w;
+    c.pcol[pt] = rem - c.pimg[pt] * p.w;
+    c.px_piece[pt] = static_cast<unsigned>(px) * 16u;
+    c.act_lane[pt] = static_cast<unsigned>(c.hi * CH_TPX + px) * 16u;
+  }
+  const unsigned zero_addr = p.act_bytes + 2 * p.slot_bytes;
+  if (wave == 0 && lane < 4) *reinterpret_cast<unsigned*>(smem + zero_addr + lane * 4) = 0u;
+
+  unsigned step = 0;
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int n0 = max(0, min(tile * p.G, p.N - p.G));
+    for (int l = 0; l < p.n_layers; ++l) {
+      const ChainLayer& L = p.L[l];
+      const bool last = l + 1 == p.n_layers;
+      const int pad = (L.taps - 1) >> 1;
+      // which taps meet the map, per lane and fragment; the wave walks the union of its lanes' taps
+      unsigned m[CH_PT], any = 0;
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) {
+        const int pos = L.horizontal ? c.pcol[pt] : c.prow[pt];
+        const int lim = L.horizontal ? p.w : p.h;
+        m[pt] = 0;
+#pragma unroll
+        for (int t = 0; t < kChainMaxTaps; ++t) {
+          if (t < L.taps && c.pval[pt] && static_cast<unsigned>(pos + t - pad) < static_cast<unsigned>(lim)) {
+            m[pt] |= 1u << t;
+          }
+        }
+        any |= m[pt];
+      }
+      unsigned wave_any = 0;
+#pragma unroll
+      for (int t = 0; t < kChainMaxTaps; ++t) {
+        if (__builtin_amdgcn_ballot_w64((any >> t) & 1u) != 0ull) wave_any |= 1u << t;
+      }
+      wave_any = __builtin_amdgcn_readfirstlane(wave_any);
+      int t_lo = wave_any ? __builtin_ctz(wave_any) : 0;
+      int nt = wave_any ? 32 - __builtin_clz(wave_any) - t_lo : 0;
+      // compiled tap counts: 3, 5, 6, 7 -- a range in between is widened (the extra taps read
+      // zeros through the lane masks, which is exact)
+      while (nt != 0 && nt != 3 && nt != 5 && nt != 6 && nt != 7) {
+        if (t_lo + nt < L.taps) {
+          ++nt;
+        } else {
+          --t_lo;
+          ++nt;
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) m[pt] >>= t_lo;
+      const int subs = L.cout_pad >> 5;
+      const int sub_base = ch ? (subs + 1) >> 1 : 0;
+      const int nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+#define DV_CHAIN_CASE(NB_, NT_) \
+  case NB_ * 8 + NT_: \
+    step = chain_layer<NB_, NT_>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step); \
+    break;
+      switch (nbw * 8 + nt) {   // wave-uniform
+        DV_CHAIN_CASE(2, 3) DV_CHAIN_CASE(2, 5) DV_CHAIN_CASE(2, 6) DV_CHAIN_CASE(2, 7)
+        DV_CHAIN_CASE(3, 3) DV_CHAIN_CASE(3, 5) DV_CHAIN_CASE(3, 6) DV_CHAIN_CASE(3, 7)
+        default: step = chain_layer_idle(L, step); break;   // nt == 0 (the host admits only nbw of 2 or 3)
+      }
+#undef DV_CHAIN_CASE
+    }
+  }
+}
+
+// ------------------------------------------------------------------ moving waves (4-7)
+__device__ __forceinline__ void chain_move(const ChainArgs& p, char* smem, int lw, int lane) {
+  const int Gw = p.G * p.w, T = Gw * p.h;
+  // source offset of tile pixel third*64 + lane, relative to (first image of the tile, group 0)
+  unsigned src[3];
+#pragma unroll
+  for (int third = 0; third < 3; ++third) {
+    const int px = third * 64 + lane;
+    const int q = px < T ? px : 0;
+    const int row = q / Gw, rem = q - row * Gw;
+    const int img = rem / p.w, col = rem - img * p.w;
+    src[third] = static_cast<unsigned>(img) * p.in_img_bytes +
+                 static_cast<unsigned>(((row + p.ig.halo) * p.ig.wp + col + p.ig.halo) * 16);
+  }
+  const unsigned plane_bytes = static_cast<unsigned>(p.ig.hp * p.ig.wp * 16);
+  const unsigned ring0 = p.act_bytes;
+  const int in_groups = p.L[0].n_chunks * 2;
+
+  auto issue_weights = [&](int l, int cc, unsigned slot) {
+    const ChainLayer& L = p.L[l];
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(L.w) + static_cast<size_t>(cc) * L.slab_bytes)),
+        0, L.slab_bytes, 0x00020000);
+    const int pieces = static_cast<int>(L.slab_bytes >> 10);
+    for (int j = lw; j < pieces; j += 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(smem + ring0 + slot * p.slot_bytes + j * 1024), 16,
+                                               lane * 16, j * 1024, 0, 0);
+    }
+  };
+  auto issue_tile = [&](int tile) {
+    const int n0 = max(0, min(tile * p.G, p.N - p.G));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(p.in) + static_cast<size_t>(n0) * p.in_img_bytes)),
+        0, 0x7fffffff, 0x00020000);
+    for (int g = 0; g < in_groups; ++g) {
+#pragma unroll
+      for (int third = 0; third < 3; ++third) {
+        if (((g * 3 + third) & 3) == lw) {   // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + (g * CH_TPX + third * 64) * 16), 16,
+                                                   src[third], g * plane_bytes, 0, 0);
+        }
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.n_tiles) return;
+  issue_weights(0, 0, 0u);
+  issue_tile(tile);
+  unsigned step = 0;
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    const bool more_tiles = tile + static_cast<int>(gridDim.x) < p.n_tiles;
+    for (int l = 0; l < p.n_layers; ++l) {
+      const int n_chunks = p.L[l].n_chunks;
+      for (int cc = 0; cc < n_chunks; ++cc, ++step) {
+        barrier_after_dma();   // B(l, cc): everything issued so far has landed
+        // the slot the computing waves left at this barrier takes the next chunk's slab
+        int nl = l, ncc = cc + 1;
+        if (ncc == n_chunks) {
+          ncc = 0;
+          nl = l + 1;
+        }
+        bool has_next = true;
+        if (nl == p.n_layers) {
+          nl = 0;
+          has_next = more_tiles;
+        }
+        if (has_next) issue_weights(nl, ncc, (step + 1u) & 1u);
+      }
+      barrier_only();          // E(l): the DMAs in flight stay in flight
+      if (l == p.n_layers - 1 && more_tiles) issue_tile(tile + gridDim.x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(CH_THREADS, 1) void chain_kernel(ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  if (static_cast<int>(blockIdx.x) >= p.n_tiles) return;
+  if (wave < 4) {
+    chain_compute(p, smem, wave, lane);
+  } else {
+    chain_move(p, smem, wave - 4, lane);
+  }
+}
+
+}  // namespace
+
+size_t chain_lds_bytes(const ChainArgs& a) {
+  return static_cast<size_t>(a.act_bytes) + 2 * static_cast<size_t>(a.slot_bytes) + 16;
+}
+
+void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream) {
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  const int grid = a.n_tiles < blocks ? a.n_tiles : blocks;
+  hipLaunchKernelGGL(chain_kernel, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+}
+
+}  // namespace dv

@@ -38,6 +38,7 @@
 #include "dv_internal.h"
 #include "conv_common.h"
 #include "imgconv.h"
+#include "chain.h"
 #include "stem_fused.h"
 
 using namespace dv::convk;
@@ -1004,6 +1005,11 @@ struct Op {
   int v2_tiles = 0;              // cout tiles of nb*32
   bool stem_a = false;           // first conv (uint8 input) + conv 3x3 32->32
   bool stem_b = false;           // conv 3x3 32->64 + maxpool 3x3/2 + conv 1x1 64->80
+  // chain.hip: this op and the chain_len - 1 ops behind it (1 x k / k x 1, each reading its
+  // predecessor) run as ONE launch; the tensors between them live in LDS only
+  int chain_len = 0;
+  int chain_g = 0;               // images per tile
+  bool in_chain = false;         // a non-leading member of a chain
 };
 
 struct LayerInfo {
@@ -1227,6 +1233,7 @@ struct dv_model {
       Op& op = ops[i];
       const int followers = op.type == kOpConv ? op.group_followers : 0;
       if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.stem_a && !op.stem_b &&
+          op.chain_len == 0 && !op.in_chain &&
           !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
           dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
         // 1x1 layers have no taps to share a patch between: the DMA count equals
@@ -1273,7 +1280,7 @@ struct dv_model {
     if (getenv("DV_NO_BAND") != nullptr) return;
     for (Op& op : ops) {
       if (op.type != kOpConv || op.first_u8 || op.pool_in || op.stem_a || op.stem_b || op.v2 ||
-          op.group_followers != 0 || op.stride != 1 || op.kh <= 1 || op.oh != op.ih) {
+          op.chain_len != 0 || op.in_chain || op.group_followers != 0 || op.stride != 1 || op.kh <= 1 || op.oh != op.ih) {
         continue;
       }
       const int h = op.ih;
@@ -1292,6 +1299,57 @@ struct dv_model {
       if (op.cout > 128 && op.cout <= 192 && op.nb == 3 && getenv("DV_NO_BAND_NB6") == nullptr) op.nb = 6;
       op.n_chunks = h * op.kw * (op.cin / kChunk);
       op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;
+    }
+  }
+
+  // Chains of one-dimensional 'same' convolutions in which every layer reads only its
+  // predecessor (the factorised 7x7 branches of mixed4..mixed8) run in chain.hip when a tile of
+  // G whole maps fills at least two thirds of the 192-pixel tile and the activation tile plus
+  // two weight slabs fit the CU's LDS.  DV_NO_CHAIN keeps the per-layer kernels.
+  void choose_chains() {
+    if (getenv("DV_NO_CHAIN") != nullptr) return;
+    std::vector<int> readers(buffers.size(), 0);
+    for (const Op& o : ops) readers[o.in_buf]++;
+    auto one_d = [](const Op& o) {
+      const int k = std::max(o.kh, o.kw);
+      return o.type == kOpConv && o.stride == 1 && (o.kh == 1) != (o.kw == 1) && k <= dv::kChainMaxTaps &&
+             (k & 1) && o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
+             !o.first_u8 && !o.pool_in && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
+             o.cin == o.cin_real;
+    };
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (!one_d(ops[i])) continue;
+      size_t len = 1;
+      while (i + len < ops.size() && len < static_cast<size_t>(dv::kChainMaxLayers)) {
+        const Op& prev = ops[i + len - 1];
+        const Op& next = ops[i + len];
+        if (!one_d(next) || next.in_buf != prev.out_buf || prev.out_coff != 0 || readers[prev.out_buf] != 1 ||
+            prev.cout % 32 != 0 || buffers[prev.out_buf].c != prev.cout) {
+          break;
+        }
+        ++len;
+      }
+      if (len < 2) continue;
+      const int P = ops[i].oh * ops[i].ow;
+      if (P > dv::kChainTilePx / 2) continue;
+      const int g = dv::kChainTilePx / P;
+      if (g * P < dv::kChainTilePx * 2 / 3) continue;
+      size_t act = 0, slot = 0;
+      for (size_t k = 0; k < len; ++k) {
+        const Op& o = ops[i + k];
+        act = std::max(act, static_cast<size_t>(o.cin / 8) * dv::kChainTilePx * 16);
+        slot = std::max(slot, static_cast<size_t>(o.kh * o.kw) * 2 * ((o.cout + 31) / 32 * 32) * 16);
+      }
+      if (act + 2 * slot + 16 > 160 * 1024) continue;
+      ops[i].chain_len = static_cast<int>(len);
+      ops[i].chain_g = g;
+      for (size_t k = 1; k < len; ++k) {
+        ops[i + k].in_chain = true;
+        const int c = ops[i + k - 1].cout;
+        buffers[ops[i + k].in_buf] = {1, 1, c, 0};   // LDS only
+      }
+      buffers[ops[i].in_buf].min_examples = std::max(buffers[ops[i].in_buf].min_examples, g);
+      i += len - 1;
     }
   }
 
@@ -1436,6 +1494,7 @@ struct dv_model {
       if (op.type == kOpAvgPool) need = 1;  // avgpool3s1_kernel reads its taps unconditionally
       buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
     }
+    choose_chains();
     choose_imgconv();
     choose_band();
     for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
@@ -1446,6 +1505,8 @@ struct dv_model {
       const int n_tiles = (subs + op.nb - 1) / op.nb;
       for (int gi = 0; gi <= op.group_followers; ++gi) ops[i + gi].w_off = packed_halfs;
       packed_halfs += op.first_u8 ? static_cast<size_t>(kFirstMaxChunks) * 32 * kChunk
+                      : (op.chain_len > 0 || op.in_chain)
+                          ? static_cast<size_t>(op.n_chunks) * 2 * ((op.cout + 31) / 32 * 32) * 8
                       : op.v2     ? static_cast<size_t>(op.v2_tiles) * op.v2_steps *
                                         dv::imgconv_wslab_halfs(op.kh, op.kw, op.nb)
                                   : static_cast<size_t>(op.band ? op.band : 1) * n_tiles * op.n_steps *
@@ -1681,6 +1742,51 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         dv::launch_stem_b(a, m->stem_b_grid, stream);
       }
       oi += 1;
+    } else if (op.type == kOpConv && op.chain_len > 0) {
+      const Op& last = m->ops[oi + op.chain_len - 1];
+      const BufferDesc& ib = m->buffers[op.in_buf];
+      const BufferDesc& lob = m->buffers[last.out_buf];
+      dv::ChainArgs a{};
+      a.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      a.ig = ib.geom();
+      a.in_img_bytes = static_cast<unsigned>(ib.bytes_per_example());
+      a.N = n;
+      a.G = op.chain_g;
+      a.h = op.oh;
+      a.w = op.ow;
+      a.n_tiles = (n + a.G - 1) / a.G;
+      a.n_layers = op.chain_len;
+      double tr_flops = 0;
+      std::string tr_label = "chain";
+      size_t act = 0, slot = 0;
+      for (int k = 0; k < op.chain_len; ++k) {
+        const Op& o = m->ops[oi + k];
+        dv::ChainLayer& cl = a.L[k];
+        cl.w = static_cast<const _Float16*>(m->d_w.ptr) + o.w_off;
+        cl.shift = static_cast<const float*>(m->d_shift.ptr) + o.shift_off;
+        cl.n_chunks = o.cin / kChunk;
+        cl.cout = o.cout;
+        cl.cout_pad = (o.cout + 31) / 32 * 32;
+        cl.taps = o.kh * o.kw;
+        cl.horizontal = o.kh == 1 ? 1 : 0;
+        cl.slab_bytes = static_cast<unsigned>(cl.taps * 2 * cl.cout_pad * 16);
+        act = std::max(act, static_cast<size_t>(o.cin / 8) * dv::kChainTilePx * 16);
+        slot = std::max(slot, static_cast<size_t>(cl.slab_bytes));
+        tr_flops += 2.0 * n * o.oh * o.ow * o.kh * o.kw * o.cin * o.cout;
+        tr_label += " " + std::to_string(o.kh) + "x" + std::to_string(o.kw) + ":" + std::to_string(o.cin) + "->" +
+                    std::to_string(o.cout);
+      }
+      a.act_bytes = static_cast<unsigned>(act);
+      a.slot_bytes = static_cast<unsigned>(slot);
+      a.out = static_cast<_Float16*>(m->dbuf[last.out_buf].ptr);
+      a.og = lob.geom();
+      a.out_goff = last.out_coff / 8;
+      tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " [fused, G=" + std::to_string(a.G) + "]";
+      TraceScope tr(stream, tr_label, tr_flops,
+                    2.0 * n * op.oh * op.ow * (static_cast<double>(op.cin) + last.cout));
+      dv::ProfileScope prof(dv::kProfConv, stream);
+      dv::launch_chain(a, m->n_cus, stream);
+      oi += op.chain_len - 1;
     } else if (op.type == kOpConv && op.first_u8) {
       FirstConvArgs f{};
       f.in = images;
@@ -2067,6 +2173,23 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
             for (int ci = 0; ci < l.cin; ++ci) {
               const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
               packed[op.w_off + ((static_cast<size_t>(kc) * 2 + g) * 32 + co) * 8 + ci] =
+                  static_cast<_Float16>(v * inv[co]);
+            }
+        }
+      continue;
+    }
+    if (op.chain_len > 0 || op.in_chain) {
+      // chain.hip: [channel chunk][tap][k-group][cout_pad][8]
+      const int cout_pad = (op.cout + 31) / 32 * 32, taps = op.kh * op.kw;
+      _Float16* dst = packed.data() + op.w_off;
+      for (int cc = 0; cc < l.cin / kChunk; ++cc)
+        for (int tap = 0; tap < taps; ++tap) {
+          const int kh = tap / op.kw, kw = tap % op.kw;
+          for (int co = 0; co < op.cout; ++co)
+            for (int jj = 0; jj < kChunk; ++jj) {
+              const int ci = cc * kChunk + jj;
+              const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
+              dst[(((static_cast<size_t>(cc) * taps + tap) * 2 + jj / 8) * cout_pad + co) * 8 + (jj % 8)] =
                   static_cast<_Float16>(v * inv[co]);
             }
         }

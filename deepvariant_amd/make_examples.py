@@ -225,6 +225,9 @@ def check_flags(args) -> None:
     raise ValueError('--call_variants_outfile needs --checkpoint (the fused route)')
   if not args.examples and not args.call_variants_outfile:
     raise ValueError('--examples (or --call_variants_outfile with --checkpoint) is required')
+  if args.examples and args.call_variants_outfile:
+    raise ValueError('--examples and --call_variants_outfile are two routes (tf.Examples, or CallVariantsOutput '
+                     'records straight from the device): give one of them')
   if _true(args.phase_reads) and not _true(args.track_ref_reads):
     raise ValueError('--track_ref_reads must be set to True when --phase_reads is set.')
   if args.partition_size < 1:
@@ -325,29 +328,63 @@ def calling_regions(args, ref_reader, contig_names: Sequence[str], num_shards: i
   return pieces
 
 
+class RegionReads:
+  """The reads of one calling region, as the reference's per-region `SamReader.query` returns them
+  (make_examples_core.py:2518-2560): every read whose alignment overlaps the region, in file order.
+
+  The BAM is decoded natively (dv_bam_read_region: .bai region query, parallel BGZF inflate,
+  nucleus' read requirements) in BLOCKS of neighbouring regions, so memory is bounded by one
+  block whatever the contig's size, and a region's reads are found by bisection on the sorted
+  alignment starts (window widened by the block's longest alignment) instead of a scan."""
+
+  BLOCK_BASES = 1 << 20
+
+  def __init__(self, args):
+    self._args = args
+    self._contig = None
+    self._lo = self._hi = 0
+    self._reads = []
+    self._starts = np.zeros(0, np.int64)
+    self._ends = np.zeros(0, np.int64)
+    self._max_span = 0
+
+  def _load(self, contig: str, lo: int, hi: int) -> None:
+    a = self._args
+    table = packing.ReadTable.from_bam(
+        a.reads, contig, lo, hi, min_mapping_quality=a.min_mapping_quality,
+        keep_duplicates=_true(a.keep_duplicates), keep_supplementary=_true(a.keep_supplementary_alignments),
+        keep_secondary=_true(a.keep_secondary_alignments),
+        use_original_quality_scores=_true(a.use_original_quality_scores))
+    self._reads = table.to_reads(contig)
+    self._starts = table.read_pos.astype(np.int64)
+    self._ends = table.read_end.astype(np.int64)
+    if self._starts.size > 1 and np.any(np.diff(self._starts) < 0):
+      raise ValueError('%s is not coordinate-sorted on %s' % (a.reads, contig))
+    self._max_span = int((self._ends - self._starts).max()) if self._starts.size else 0
+    self._contig, self._lo, self._hi = contig, lo, hi
+
+  def __call__(self, region: T.Range) -> list:
+    if region.reference_name != self._contig or region.start < self._lo or region.end > self._hi:
+      self._load(region.reference_name, region.start, max(region.end, region.start + self.BLOCK_BASES))
+    first = int(np.searchsorted(self._starts, region.start - self._max_span, side='left'))
+    last = int(np.searchsorted(self._starts, region.end, side='left'))      # start < region.end
+    keep = np.nonzero(self._ends[first:last] > region.start)[0] + first      # end > region.start
+    return [self._reads[i] for i in keep.tolist()]
+
+
 def make_examples_runner(args, log=sys.stderr) -> dict:
   """-> stats; writes the task's example shard (and its example_info.json) or the CVO file."""
   check_flags(args)
   ref_reader = genomics_io.FastaReader(args.ref)
   options, po = options_from_flags(args)
   sweep = args.mode == 'candidate_sweep'
-  out_spec = args.candidate_positions if sweep else (args.examples or args.call_variants_outfile)
+  # the output follows the active route: the fused route writes CallVariantsOutput records to
+  # --call_variants_outfile, the example route tf.Examples to --examples (check_flags refuses both)
+  out_spec = args.candidate_positions if sweep else (args.call_variants_outfile or args.examples)
   out_path, num_shards = _shard(out_spec, args.task)
   contig_names = genomics_io.bam_contig_names(args.reads)
   pieces = calling_regions(args, ref_reader, contig_names, num_shards)
-  # one decode of the BAM per contig, over the span the task needs
-  reads_by_contig = {}
-  for contig in sorted({p.reference_name for p in pieces}):
-    lo = min(p.start for p in pieces if p.reference_name == contig)
-    hi = max(p.end for p in pieces if p.reference_name == contig)
-    # the native reader (dv_bam_read_region: .bai region query when the index is there, parallel
-    # BGZF inflate, nucleus' read requirements), then Read objects for the host stages
-    reads = packing.ReadTable.from_bam(
-        args.reads, contig, lo, hi, min_mapping_quality=args.min_mapping_quality,
-        keep_duplicates=_true(args.keep_duplicates), keep_supplementary=_true(args.keep_supplementary_alignments),
-        keep_secondary=_true(args.keep_secondary_alignments),
-        use_original_quality_scores=_true(args.use_original_quality_scores)).to_reads(contig)
-    reads_by_contig[contig] = (reads, [utils.read_range(r) for r in reads])
+  reads_for = RegionReads(args)
   proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
   model = None
   if args.call_variants_outfile:
@@ -365,8 +402,7 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
     region_ends = {(r.reference_name, r.end) for r in requested_regions(args, ref_reader, contig_names)}
     with open(out_path, 'wb') as f:
       for region in pieces:
-        reads, spans = reads_by_contig[region.reference_name]
-        in_reads = [r for r, s in zip(reads, spans) if utils.ranges_overlap(s, region)]
+        in_reads = reads_for(region)
         if args.max_reads_per_partition > 0:
           in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))
         positions = proc.find_candidate_positions(region, in_reads)
@@ -383,8 +419,7 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   image_shape = None
   try:
     for region in pieces:
-      reads, spans = reads_by_contig[region.reference_name]
-      in_reads = [r for r, s in zip(reads, spans) if utils.ranges_overlap(s, region)]
+      in_reads = reads_for(region)
       if args.max_reads_per_partition > 0:
         in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))
       stats['n_regions'] += 1

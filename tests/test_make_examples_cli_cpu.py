@@ -233,3 +233,37 @@ def test_native_table_to_reads(tmp_path):
               a.fragment_length, a.supplementary_alignment, {k: v.values[0].int_value for k, v in a.info.items()}) == (
                   b.fragment_name, b.read_number, b.aligned_sequence, bytes(bytearray(b.aligned_quality)), b.alignment,
                   b.fragment_length, b.supplementary_alignment, {k: v.values[0].int_value for k, v in b.info.items()})
+
+
+def test_region_reads_equal_a_linear_scan(tmp_path, monkeypatch):
+  """RegionReads (block-wise native decode + bisection on the sorted starts) returns, per calling
+  region, exactly the reads a scan over the whole contig keeps -- also across block reloads."""
+  from deepvariant_amd import packing
+  _, sets = RF.load()
+  reads = sorted(sets['ex2'] + sets['dbg0'] + sets['ex1'], key=lambda r: r.alignment.position.position)
+  path = str(tmp_path / 'r.bam')
+  genomics_io.write_bam(path, [('chr20', 63025520)], reads)
+  args = me.build_arg_parser().parse_args(['--ref', 'x', '--reads', path, '--examples', 'e'])
+  monkeypatch.setattr(me.RegionReads, 'BLOCK_BASES', 700)     # several reloads over the span
+  table = packing.ReadTable.from_bam(path, 'chr20', 0, 1 << 40, min_mapping_quality=args.min_mapping_quality)
+  every = table.to_reads('chr20')
+  lo = min(r.alignment.position.position for r in every) - 50
+  hi = max(int(e) for e in table.read_end) + 50
+  reads_for = me.RegionReads(args)
+  n_total = 0
+  for start in range(lo, hi, 300):
+    region = T.Range('chr20', start, start + 300)
+    want = [r for r, s, e in zip(every, table.read_pos.tolist(), table.read_end.tolist())
+            if s < region.end and e > region.start]
+    got = reads_for(region)
+    assert [(r.fragment_name, r.read_number, r.alignment.position.position) for r in got] == [
+        (r.fragment_name, r.read_number, r.alignment.position.position) for r in want]
+    n_total += len(got)
+  assert n_total > len(every)            # reads that straddle region borders are returned by both sides
+
+
+def test_the_two_output_routes_exclude_each_other():
+  args = me.build_arg_parser().parse_args(['--ref', 'x', '--reads', 'y', '--examples', 'e.tfrecord',
+                                           '--call_variants_outfile', 'c.tfrecord', '--checkpoint', 'random:1'])
+  with pytest.raises(ValueError, match='two routes'):
+    me.check_flags(args)
