@@ -23,8 +23,8 @@ from deepvariant_amd import dv_types as T
 from deepvariant_amd import packing
 
 REFERENCE, SUBSTITUTION, INSERTION, DELETION, SOFT_CLIP = 1, 2, 3, 4, 5   # AlleleType
-_EVENT_DTYPE = np.dtype([('position', '<i4'), ('read', '<u4'), ('read_offset', '<u4'), ('length', '<u2'),
-                         ('type', 'u1'), ('low_quality', 'u1')])        # dv_allele_event
+_EVENT_DTYPE = np.dtype([('position', '<i4'), ('read', '<u4'), ('read_offset', '<u4'),
+                         ('length_type', '<u4')])        # dv_allele_event: length | type << 28 | low quality << 31
 
 
 class Allele:
@@ -186,7 +186,8 @@ class AlleleCounter:
       keys = table.keys
       s0_all = seq_off[ev['read']].astype(np.int64) + ev['read_offset']
       alleles: Dict[int, Dict[str, Allele]] = {}
-      for k, (position, read, read_offset, length_k, type_k, low) in enumerate(ev.tolist()):
+      for k, (position, read, read_offset, packed) in enumerate(ev.tolist()):
+        length_k, type_k, low = packed & 0x0fffffff, (packed >> 28) & 7, packed >> 31
         s0 = int(s0_all[k])
         if type_k == SUBSTITUTION or type_k == REFERENCE:
           text = chr(bases[s0])

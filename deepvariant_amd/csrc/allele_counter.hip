@@ -130,9 +130,8 @@ __device__ __forceinline__ void emit(const CountArgs& a, uint32_t read, const En
   ev.position = static_cast<int32_t>(p);
   ev.read = read;
   ev.read_offset = e.read_offset;
-  ev.length = e.length > 0xffffu ? 0xffffu : static_cast<uint16_t>(e.length);
-  ev.type = static_cast<uint8_t>(e.type);
-  ev.low_quality = static_cast<uint8_t>(e.low);
+  ev.length_type = (static_cast<uint32_t>(e.length) & 0x0fffffffu) | (static_cast<uint32_t>(e.type) << 28) |
+                   (e.low ? 0x80000000u : 0u);
   // One counter for the whole launch serialises at ~20 ns per atomic (a quarter of a million
   // events = the whole kernel time): stage in LDS, take the global slots once per workgroup.
   const int local = atomicAdd(&bs->n_events, 1);

@@ -36,6 +36,10 @@ struct ChainArgs {
   int out_goff;           // first destination channel group
   unsigned act_bytes;     // LDS: activation tile [channel group][kChainTilePx][8]
   unsigned slot_bytes;    // LDS: one weight-slab slot (two of them follow the activations)
+  int dma_loader;         // tuning (DV_CHAIN_DMA): move data by LDS-DMA instead of through registers
+  // tuning aid (DV_CHAIN_PROF, eager launches): shader-clock sums [block][computing wave][8] =
+  // wait at the chunk barriers, MFMA steps, wait at the layer barrier, LDS epilogue, HBM epilogue, set-up
+  unsigned long long* prof;
 };
 
 size_t chain_lds_bytes(const ChainArgs& a);

@@ -147,10 +147,16 @@ struct ChainLane {
 // One layer on one tile for one computing wave: NB cout subtiles x 3 pixel fragments, NT taps
 // per chunk.  The accumulators are local to this instantiation (a switch over tap counts
 // around a shared accumulator array made the register allocator spill).
-template <int NB, int NT>
+// tuning aid (DV_CHAIN_PROF): shader-clock sums per computing wave
+struct ChainProf {
+  unsigned long long wait_b = 0, mfma = 0, wait_e = 0, epi_lds = 0, epi_hbm = 0, setup = 0;
+};
+__device__ __forceinline__ unsigned long long chain_clock() { return __builtin_amdgcn_s_memtime(); }
+
+template <int NB, int NT, bool PROF>
 __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainLayer& L, bool last, char* smem,
                                                 const ChainLane& c, int sub_base, int t_lo, unsigned m0,
-                                                unsigned m1, unsigned m2, int n0, unsigned step) {
+                                                unsigned m1, unsigned m2, int n0, unsigned step, ChainProf& prof) {
   // everything the chunk loop needs sits in registers before it starts: the barriers are asm
   // statements with a memory clobber, anything still in memory would be re-read after each
   const unsigned m[CH_PT] = {m0, m1, m2};
@@ -176,15 +182,33 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
 
+  unsigned long long t0 = 0;
+  if (PROF) t0 = chain_clock();
   for (int cc = 0; cc < n_chunks; ++cc, ++step) {
     barrier_after_lds();   // B(l, cc): this chunk's weight slab (and, first chunk, the tile) landed
+    if (PROF) {
+      const unsigned long long t = chain_clock();
+      prof.wait_b += t - t0;
+      t0 = t;
+    }
     const unsigned a_addr = ring0 + (step & 1u) * slot_bytes + a_lane;
     unsigned b_addr[CH_PT];
 #pragma unroll
     for (int pt = 0; pt < CH_PT; ++pt) b_addr[pt] = b0[pt] + static_cast<unsigned>(cc) * CH_CHUNK_LDS;
     chain_step<NB, NT>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, acc);
+    if (PROF) {
+      asm volatile("" : "+v"(acc[0][0]));   // the step's MFMAs are issued before the clock is read
+      const unsigned long long t = chain_clock();
+      prof.mfma += t - t0;
+      t0 = t;
+    }
   }
   barrier_after_lds();     // E(l): every wave is done reading this layer's input
+  if (PROF) {
+    const unsigned long long t = chain_clock();
+    prof.wait_e += t - t0;
+    t0 = t;
+  }
   if (!last) {
     // the layer's output replaces its input in LDS: [group][pixel][8]
 #pragma unroll
@@ -229,6 +253,11 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
       }
     }
   }
+  if (PROF) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t = chain_clock();
+    (last ? prof.epi_hbm : prof.epi_lds) += t - t0;
+  }
   return step;
 }
 
@@ -240,7 +269,10 @@ __device__ __forceinline__ unsigned chain_layer_idle(const ChainLayer& L, unsign
   return step;
 }
 
+template <bool PROF>
 __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, int wave, int lane) {
+  ChainProf prof;
+  unsigned long long t_setup = 0;
   const int ph = wave & 1, ch = wave >> 1;
   ChainLane c;
   c.l31 = lane & 31;
@@ -265,6 +297,7 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const int n0 = max(0, min(tile * p.G, p.N - p.G));
     for (int l = 0; l < p.n_layers; ++l) {
+      if (PROF) t_setup = chain_clock();
       const ChainLayer& L = p.L[l];
       const bool last = l + 1 == p.n_layers;
       const int pad = (L.taps - 1) >> 1;
@@ -306,9 +339,10 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
       const int subs = L.cout_pad >> 5;
       const int sub_base = ch ? (subs + 1) >> 1 : 0;
       const int nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+      if (PROF) prof.setup += chain_clock() - t_setup;
 #define DV_CHAIN_CASE(NB_, NT_) \
   case NB_ * 8 + NT_: \
-    step = chain_layer<NB_, NT_>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step); \
+    step = chain_layer<NB_, NT_, PROF>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step, prof); \
     break;
       switch (nbw * 8 + nt) {   // wave-uniform
         DV_CHAIN_CASE(2, 3) DV_CHAIN_CASE(2, 5) DV_CHAIN_CASE(2, 6) DV_CHAIN_CASE(2, 7)
@@ -317,6 +351,15 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
       }
 #undef DV_CHAIN_CASE
     }
+  }
+  if (PROF && lane == 0 && p.prof != nullptr) {
+    unsigned long long* dst = p.prof + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 8;
+    dst[0] = prof.wait_b;
+    dst[1] = prof.mfma;
+    dst[2] = prof.wait_e;
+    dst[3] = prof.epi_lds;
+    dst[4] = prof.epi_hbm;
+    dst[5] = prof.setup;
   }
 }
 
@@ -395,15 +438,138 @@ __device__ __forceinline__ void chain_move(const ChainArgs& p, char* smem, int l
   }
 }
 
+// ------------------------------------------------------------------ moving waves, register-staged
+// The same schedule with the weight slabs and the next tile travelling global -> VGPR -> LDS.  An
+// LDS-DMA can only be issued once its LDS slot is free, i.e. ONE chunk ahead with two slots, and
+// the first GPU runs showed every chunk waiting for its slab (1.5 us per chunk against 0.75 us of
+// MFMA work).  Registers are the deeper buffer: the four moving waves have 1000 VGPRs to spare, so
+// the slab of chunk s + 3 is requested while chunk s multiplies (two chunks of lead), lands in
+// registers, and is copied into the slot chunk s + 1 left (ds_write_b128, ~550 cycles per slab)
+// while chunk s + 2 multiplies.  The next tile's input (<= 72 KB) is requested a whole tile
+// ahead and written right after the last layer has read the current one.  Every load is
+// unconditional (past-the-end pieces fall outside their buffer descriptor and return zero
+// without traffic), so the compiler's counted vmcnt waits stay exact.
+struct ChainPos {
+  int tile, l, cc;
+  bool valid;
+};
+
+__device__ __forceinline__ void chain_move_regs(const ChainArgs& p, char* smem, int lw, int lane) {
+  constexpr int MAXW = 11;   // 1 KB pieces of a weight slab per moving wave (slab <= 44 KB)
+  constexpr int MAXA = 18;   // 1 KB pieces of the input tile per moving wave (<= 72 KB)
+  const int Gw = p.G * p.w, T = Gw * p.h;
+  const int n_layers = p.n_layers, n_tiles = p.n_tiles, stride = static_cast<int>(gridDim.x);
+  const unsigned ring0 = p.act_bytes, slot_bytes = p.slot_bytes;
+  const unsigned plane_bytes = static_cast<unsigned>(p.ig.hp * p.ig.wp * 16);
+  const int in_pieces = p.L[0].n_chunks * 2 * 3;   // 64-pixel thirds of the input's channel groups
+  unsigned aoff[MAXA], adst[MAXA];
+#pragma unroll
+  for (int k = 0; k < MAXA; ++k) {
+    const int j = lw + 4 * k;
+    const int g = j / 3, third = j - 3 * g;
+    const int px = third * 64 + lane;
+    const int q = px < T ? px : 0;
+    const int row = q / Gw, rem = q - row * Gw;
+    const int img = rem / p.w, col = rem - img * p.w;
+    aoff[k] = j < in_pieces ? static_cast<unsigned>(img) * p.in_img_bytes + static_cast<unsigned>(g) * plane_bytes +
+                                  static_cast<unsigned>(((row + p.ig.halo) * p.ig.wp + col + p.ig.halo) * 16)
+                            : 0x80000000u;
+    adst[k] = static_cast<unsigned>((g * CH_TPX + third * 64 + lane) * 16);
+  }
+  auto next = [&](ChainPos q) {
+    if (!q.valid) return q;
+    if (q.cc + 1 < p.L[q.l].n_chunks) {
+      ++q.cc;
+      return q;
+    }
+    q.cc = 0;
+    if (q.l + 1 < n_layers) {
+      ++q.l;
+      return q;
+    }
+    q.l = 0;
+    q.tile += stride;
+    q.valid = q.tile < n_tiles;
+    return q;
+  };
+  uint4_t wA[MAXW], wB[MAXW], ta[MAXA];
+  auto load_w = [&](uint4_t (&w)[MAXW], const ChainPos& q) {
+    const ChainLayer& L = p.L[q.valid ? q.l : 0];
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(L.w) +
+                                      static_cast<size_t>(q.valid ? q.cc : 0) * L.slab_bytes)),
+        0, q.valid ? L.slab_bytes : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < MAXW; ++j) {
+      w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (lw + 4 * j) * 1024, 0);
+    }
+  };
+  auto store_w = [&](const uint4_t (&w)[MAXW], const ChainPos& q, unsigned slot) {
+    const int pieces = q.valid ? static_cast<int>(p.L[q.l].slab_bytes >> 10) : 0;
+    char* dst = smem + ring0 + slot * slot_bytes + lane * 16;
+#pragma unroll
+    for (int j = 0; j < MAXW; ++j) {
+      if (lw + 4 * j < pieces) *reinterpret_cast<uint4_t*>(dst + (lw + 4 * j) * 1024) = w[j];
+    }
+  };
+  auto load_tile = [&](int tile) {
+    const int t = tile < n_tiles ? tile : static_cast<int>(blockIdx.x);   // past the end: any valid tile
+    const int n0 = max(0, min(t * p.G, p.N - p.G));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(p.in) + static_cast<size_t>(n0) * p.in_img_bytes)),
+        0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) ta[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[k], 0, 0);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+      if (lw + 4 * k < in_pieces) *reinterpret_cast<uint4_t*>(smem + adst[k]) = ta[k];
+    }
+  };
+
+  ChainPos c0{static_cast<int>(blockIdx.x), 0, 0, true};
+  ChainPos c1 = next(c0), c2 = next(c1), c3 = next(c2);
+  load_w(wA, c0);
+  load_w(wB, c1);
+  load_tile(c0.tile);
+  store_tile();
+  store_w(wA, c0, 0u);
+  load_w(wA, c2);
+  // here: chunk 0 sits in slot 0, wB holds chunk 1, wA receives chunk 2, c3 is the next to request
+  unsigned s = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += stride) {
+    load_tile(tile + stride);
+    for (int l = 0; l < n_layers; ++l) {
+      const int n_chunks = p.L[l].n_chunks;   // even (checked by the host)
+      for (int cc = 0; cc < n_chunks; cc += 2) {
+        barrier_after_lds();                  // B(l, cc): the computing waves start chunk s
+        store_w(wB, c1, (s + 1u) & 1u);
+        load_w(wB, c3);
+        c1 = c2; c2 = c3; c3 = next(c3); ++s;
+        barrier_after_lds();                  // B(l, cc + 1)
+        store_w(wA, c1, (s + 1u) & 1u);
+        load_w(wA, c3);
+        c1 = c2; c2 = c3; c3 = next(c3); ++s;
+      }
+      barrier_after_lds();                    // E(l)
+    }
+    store_tile();                             // the last layer has read its input: the next tile moves in
+  }
+}
+
+template <bool PROF>
 __global__ __launch_bounds__(CH_THREADS, 1) void chain_kernel(ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   if (static_cast<int>(blockIdx.x) >= p.n_tiles) return;
   if (wave < 4) {
-    chain_compute(p, smem, wave, lane);
+    chain_compute<PROF>(p, smem, wave, lane);
+  } else if (p.dma_loader) {
+    chain_move(p, smem, wave - 4, lane);        // LDS-DMA, one chunk of lead (kept for A/B timing)
   } else {
-    chain_move(p, smem, wave - 4, lane);
+    chain_move_regs(p, smem, wave - 4, lane);
   }
 }
 
@@ -415,13 +581,19 @@ size_t chain_lds_bytes(const ChainArgs& a) {
 
 void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream) {
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr;
   const int grid = a.n_tiles < blocks ? a.n_tiles : blocks;
-  hipLaunchKernelGGL(chain_kernel, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+  if (a.prof != nullptr) {
+    hipLaunchKernelGGL(chain_kernel<true>, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+  } else {
+    hipLaunchKernelGGL(chain_kernel<false>, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+  }
 }
 
 }  // namespace dv

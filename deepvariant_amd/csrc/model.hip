@@ -594,8 +594,30 @@ constexpr size_t conv_lds_bytes() {
 // A lane's fragment = the 8 bytes at (pixel, tap) -- unaligned, fetched as the
 // 3 aligned dwords around it and funnel-shifted; byte C..7 belong to the next
 // pixel and meet zero weights.  'valid' convolutions only, Cout <= 32.
+// The caller's two pointers (uint8 images in, probabilities out) are read by the kernels from
+// this device-side table instead of being kernel arguments: a captured forward then depends on
+// the batch size only, and a caller that hands over a fresh tensor per region replays the same
+// hipGraph (dv_model_infer writes the table with a one-thread kernel ahead of every forward).
+struct ExtPtrs {
+  const uint8_t* images;
+  float* probs;
+};
+
+__global__ void set_ext_kernel(ExtPtrs* ext, const uint8_t* images, float* probs) {
+  ext->images = images;
+  ext->probs = probs;
+}
+
+__device__ __forceinline__ const uint8_t* ext_images(const ExtPtrs* ext, size_t off) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(ext->images + off);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned up = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const uint8_t*>((static_cast<unsigned long long>(up) << 32) | lo);
+}
+
 struct FirstConvArgs {
-  const uint8_t* in;        // [N][H][W][C]
+  const ExtPtrs* ext;       // images = ext->images + in_off: [N][H][W][C]
+  size_t in_off;
   const _Float16* w;        // packed [chunk][2 k-groups = taps][32][8]
   const float* shift;
   _Float16* out;
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
     for (int i = tid; i < p.n_chunks * 64; i += kConvThreads) dst[i] = src[i];
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(p.in), 0, p.in_bytes, 0x00020000);
+      const_cast<uint8_t*>(ext_images(p.ext, p.in_off)), 0, p.in_bytes, 0x00020000);
 
   unsigned base[PT], obase[PT];
   bool mvalid[PT];
@@ -750,10 +772,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
 }
 
 // uint8 [N,H,W,C] -> fp16 C8 [N][2][hp][wp][8]: (x - 128) / 128, exact in fp16.
-__global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix, int C,
+__global__ void preprocess_kernel(const ExtPtrs* ext, size_t in_off, _Float16* out, size_t n_pix, int C,
                                   int H, int W, TensorGeom og) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n_pix) return;
+  const uint8_t* in = ext->images + in_off;
   const uint8_t* px = in + i * C;
   _Float16 v[16];
 #pragma unroll
@@ -780,9 +803,10 @@ __global__ void preprocess_kernel(const uint8_t* in, _Float16* out, size_t n_pix
 //   conv3 3x3 same:    rows y-1..y+1   -> y >= t2 + 1
 //   max-pool 3x3/2:    rows 2y..2y+2   -> y >= ceil(t3 / 2)        (= the 1x1 and the 3x3 valid 80->192)
 // thr[k * stride + n], k = 0: rows used, 1: conv2 output, 2: stem_b output, 3: 3x3 80->192 output.
-__global__ __launch_bounds__(256) void blank_rows_kernel(const uint8_t* images, int H, int row_bytes,
+__global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, size_t in_off, int H, int row_bytes,
                                                          int* thr, int stride) {
   __shared__ int last;
+  const uint8_t* images = ext->images + in_off;
   const int n = blockIdx.x, tid = threadIdx.x;
   const unsigned img_bytes = static_cast<unsigned>(H) * row_bytes;   // multiple of 4 (checked by the host)
   const uint32_t* img = reinterpret_cast<const uint32_t*>(images + static_cast<size_t>(n) * img_bytes);
@@ -915,8 +939,9 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
 
 // GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
 __global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const float* w,
-                                                   const float* b, float* probs,
+                                                   const float* b, const ExtPtrs* ext, size_t probs_off,
                                                    TensorGeom g, int K) {
+  float* probs = ext->probs + probs_off;
   __shared__ float red[8][4];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1040,14 +1065,14 @@ struct dv_model {
   dv::DeviceBuffer d_blank_thr;   // int32 [4][max_batch], blank_rows_kernel
   dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output for the all-blank image (one example)
   bool loaded = false;
+  dv::DeviceBuffer d_ext;         // ExtPtrs: the caller's image / probability pointers of the running forward
   struct GraphEntry {
     int n;
-    const uint8_t* images;
-    float* probs;
     hipStream_t stream;
     hipGraphExec_t exec;
   };
   std::vector<GraphEntry> graphs;  // captured forwards, see dv_model_infer
+  int64_t graph_captures = 0, graph_replays = 0;
 
   // ---- builder ------------------------------------------------------------
   int new_buffer(int h, int w, int c) {
@@ -1341,6 +1366,11 @@ struct dv_model {
         slot = std::max(slot, static_cast<size_t>(o.kh * o.kw) * 2 * ((o.cout + 31) / 32 * 32) * 16);
       }
       if (act + 2 * slot + 16 > 160 * 1024) continue;
+      // the register-staged loader: slabs of at most 44 KB, input tiles of at most 72 KB, an even
+      // number of channel chunks per layer (its loop handles two chunks per trip)
+      bool fits = slot <= 44 * 1024 && act <= 72 * 1024;
+      for (size_t k = 0; k < len; ++k) fits = fits && (ops[i + k].cin / kChunk) % 2 == 0;
+      if (!fits) continue;
       ops[i].chain_len = static_cast<int>(len);
       ops[i].chain_g = g;
       for (size_t k = 1; k < len; ++k) {
@@ -1648,7 +1678,7 @@ bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
 }
 
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
-            int shifted_buf = -1, int out_example_off = 0, const uint8_t* images = nullptr) {
+            int shifted_buf = -1, int out_example_off = 0, size_t images_off = 0) {
   for (int oi = first; oi < last; ++oi) {
     const Op& op = m->ops[oi];
     const BufferDesc& ob = m->buffers[op.out_buf];
@@ -1659,7 +1689,9 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       const Op& c2 = m->ops[oi + 1];
       const BufferDesc& o2 = m->buffers[c2.out_buf];
       dv::StemAArgs a{};
-      a.in = images;
+      a.in = nullptr;
+      a.in_ind = &static_cast<const ExtPtrs*>(m->d_ext.ptr)->images;
+      a.in_off = images_off;
       a.w1 = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       a.w2 = static_cast<const _Float16*>(m->d_w.ptr) + c2.w_off;
       a.shift1 = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
@@ -1781,15 +1813,43 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.out = static_cast<_Float16*>(m->dbuf[last.out_buf].ptr);
       a.og = lob.geom();
       a.out_goff = last.out_coff / 8;
+      static const bool dma_loader = getenv("DV_CHAIN_DMA") != nullptr;   // tuning knob
+      a.dma_loader = dma_loader ? 1 : 0;
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " [fused, G=" + std::to_string(a.G) + "]";
       TraceScope tr(stream, tr_label, tr_flops,
                     2.0 * n * op.oh * op.ow * (static_cast<double>(op.cin) + last.cout));
       dv::ProfileScope prof(dv::kProfConv, stream);
-      dv::launch_chain(a, m->n_cus, stream);
+      static const bool chain_prof = getenv("DV_CHAIN_PROF") != nullptr;   // tuning aid, eager only
+      if (chain_prof && g_trace != nullptr) {
+        const int grid = std::min(a.n_tiles, m->n_cus);
+        const size_t words = static_cast<size_t>(grid) * 4 * 8;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, words * 8) == hipSuccess) {
+          (void)hipMemsetAsync(d, 0, words * 8, stream);
+          a.prof = d;
+          dv::launch_chain(a, m->n_cus, stream);
+          std::vector<unsigned long long> h(words);
+          (void)hipStreamSynchronize(stream);
+          (void)hipMemcpy(h.data(), d, words * 8, hipMemcpyDeviceToHost);
+          (void)hipFree(d);
+          for (int w = 0; w < 4; ++w) {
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < grid; ++b)
+              for (int i = 0; i < 6; ++i) sum[i] += static_cast<double>(h[(static_cast<size_t>(b) * 4 + w) * 8 + i]);
+            const double tiles = static_cast<double>(a.n_tiles);
+            fprintf(stderr, "[dv-chain wave %d] cycles/tile: chunk-barrier wait %.0f mfma steps %.0f layer-barrier wait %.0f "
+                            "lds epilogue %.0f hbm epilogue %.0f set-up %.0f\n", w, sum[0] / tiles, sum[1] / tiles,
+                    sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles);
+          }
+        }
+      } else {
+        dv::launch_chain(a, m->n_cus, stream);
+      }
       oi += op.chain_len - 1;
     } else if (op.type == kOpConv && op.first_u8) {
       FirstConvArgs f{};
-      f.in = images;
+      f.ext = static_cast<const ExtPtrs*>(m->d_ext.ptr);
+      f.in_off = images_off;
       f.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       f.shift = static_cast<const float*>(m->d_shift.ptr) + op.shift_off;
       f.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
@@ -2031,6 +2091,7 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (int rc = m->d_shift.reserve(m->shift_floats * 4)) return rc;
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
   if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
+  if (int rc = m->d_ext.reserve(sizeof(ExtPtrs))) return rc;
   // opt-in: skip the stem work that only sees the zero rows below the pile-up;
   // needs the uint8 front end, a single-branch 3x3 80->192 and whole dwords per image
   if (getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0 &&
@@ -2054,6 +2115,7 @@ void dv_model_destroy(dv_model* m) {
   m->d_dense_b.release();
   m->d_tbl.release();
   m->d_blank_thr.release();
+  m->d_ext.release();
   m->d_blank_conv4.release();
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   delete m;
@@ -2090,7 +2152,10 @@ int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
   return DV_OK;
 }
 
-static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* probs, hipStream_t stream);
+static int enqueue_forward(dv_model* m, int n, hipStream_t stream);
+static void set_ext(dv_model* m, const uint8_t* images, float* probs, hipStream_t stream) {
+  hipLaunchKernelGGL(set_ext_kernel, dim3(1), dim3(1), 0, stream, static_cast<ExtPtrs*>(m->d_ext.ptr), images, probs);
+}
 
 // Blank-row skipping: the stem's response to the all-blank (all-zero) image, computed once per
 // set of weights by the ordinary kernels -- the same arithmetic that produces those values
@@ -2108,8 +2173,10 @@ static int prepare_blank_responses(dv_model* m) {
   int rc = zero_img.reserve(img_bytes);
   if (rc == DV_OK) rc = probs.reserve(sizeof(float) * m->desc.num_classes);
   if (rc == DV_OK && hipMemset(zero_img.ptr, 0, img_bytes) != hipSuccess) rc = dv::fail(DV_ERR_HIP, "hipMemset");
-  if (rc == DV_OK) rc = enqueue_forward(m, static_cast<const uint8_t*>(zero_img.ptr), 1,
-                                        static_cast<float*>(probs.ptr), nullptr);
+  if (rc == DV_OK) {
+    set_ext(m, static_cast<const uint8_t*>(zero_img.ptr), static_cast<float*>(probs.ptr), nullptr);
+    rc = enqueue_forward(m, 1, nullptr);
+  }
   if (rc == DV_OK && hipDeviceSynchronize() != hipSuccess) rc = dv::fail(DV_ERR_HIP, "blank forward failed");
   if (rc == DV_OK) {
     const int buf = m->ops[m->blank_conv4_op].out_buf;
@@ -2303,10 +2370,11 @@ int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t
   return DV_OK;
 }
 
-// Enqueues the whole forward for `n` examples on `stream` (eager launches).
-static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* probs,
-                           hipStream_t stream) {
+// Enqueues the whole forward for `n` examples on `stream` (eager launches).  The caller's image
+// and probability pointers come from the device-side table (set_ext), not from kernel arguments.
+static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
   const size_t img_bytes = static_cast<size_t>(m->desc.height) * m->desc.width * m->desc.channels;
+  const ExtPtrs* ext = static_cast<const ExtPtrs*>(m->d_ext.ptr);
   // split evenly so that no launch is left with a sliver of a batch
   const int n_parts = (n + m->desc.max_batch - 1) / m->desc.max_batch;
   const int part = n_parts ? (n + n_parts - 1) / n_parts : 0;
@@ -2314,10 +2382,10 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
     const int nb = std::min(part, n - done);
     for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
       const int sb = std::min(stem_sub_batch(), nb - sb0);
-      const uint8_t* img = images + (done + sb0) * img_bytes;
+      const size_t img_off = static_cast<size_t>(done + sb0) * img_bytes;
       if (m->blank_ready) {
         dv::ProfileScope prof(dv::kProfOther, stream);
-        hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, img, m->desc.height,
+        hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, ext, img_off, m->desc.height,
                            m->desc.width * m->desc.channels, static_cast<int*>(m->d_blank_thr.ptr),
                            m->desc.max_batch);
       }
@@ -2325,11 +2393,11 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
         const size_t n_pix = static_cast<size_t>(sb) * m->desc.height * m->desc.width;
         dv::ProfileScope prof(dv::kProfOther, stream);
         hipLaunchKernelGGL(preprocess_kernel, dim3(static_cast<unsigned>((n_pix + 255) / 256)),
-                           dim3(256), 0, stream, img, static_cast<_Float16*>(m->dbuf[0].ptr),
+                           dim3(256), 0, stream, ext, img_off, static_cast<_Float16*>(m->dbuf[0].ptr),
                            n_pix, m->desc.channels, m->desc.height, m->desc.width,
                            m->buffers[0].geom());
       }
-      if (int rc = run_ops(m, 0, m->stem_ops_end, sb, stream, m->stem_out_buf, sb0, img)) return rc;
+      if (int rc = run_ops(m, 0, m->stem_ops_end, sb, stream, m->stem_out_buf, sb0, img_off)) return rc;
     }
     if (int rc = run_ops(m, m->stem_ops_end, static_cast<int>(m->ops.size()), nb, stream)) {
       return rc;
@@ -2339,8 +2407,8 @@ static int enqueue_forward(dv_model* m, const uint8_t* images, int n, float* pro
       hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, stream,
                          static_cast<const _Float16*>(m->dbuf[m->feat_buf].ptr),
                          static_cast<const float*>(m->d_dense_w.ptr),
-                         static_cast<const float*>(m->d_dense_b.ptr),
-                         probs + static_cast<size_t>(done) * m->desc.num_classes,
+                         static_cast<const float*>(m->d_dense_b.ptr), ext,
+                         static_cast<size_t>(done) * m->desc.num_classes,
                          m->buffers[m->feat_buf].geom(), m->desc.num_classes);
     }
   }
@@ -2355,33 +2423,37 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   if (n == 0) return DV_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   DV_HIP_CHECK(hipSetDevice(m->device));
-  // The forward is ~75 launches; replaying it as one hipGraph removes the per-launch gaps
-  // (measured +0.6 % at 8 K examples per forward, more for small batches).  Graphs are
-  // keyed by (n, images, probs, stream); per-launch event profiling and DV_OP_TRACE need
-  // eager launches, and the legacy default stream cannot be captured.
+  // The forward is ~65 launches; replaying it as one hipGraph removes the per-launch gaps
+  // (measured +0.6 % at 8 K examples per forward, more for small batches).  Graphs are keyed by
+  // (n, stream) only: the caller's pointers travel through the ExtPtrs table, written in stream
+  // order ahead of every forward, so fresh image tensors per region replay the same graph.
+  // Per-launch event profiling and DV_OP_TRACE need eager launches, and the legacy default
+  // stream cannot be captured.
   static const bool op_trace = getenv("DV_OP_TRACE") != nullptr;
   static const bool no_graph = getenv("DV_NO_GRAPH") != nullptr || op_trace;
   // a caller that is already capturing this stream gets plain launches (they join ITS graph)
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (stream != nullptr) (void)hipStreamIsCapturing(stream, &capturing);
+  set_ext(m, images, probs, stream);
   if (no_graph || dv::profiling_enabled() || stream == nullptr ||
       capturing != hipStreamCaptureStatusNone) {
     static std::vector<OpTrace> trace_store;
     g_trace = op_trace ? &trace_store : nullptr;
-    if (int rc = enqueue_forward(m, images, n, probs, stream)) return rc;
+    if (int rc = enqueue_forward(m, n, stream)) return rc;
     DV_HIP_CHECK(hipGetLastError());
     if (op_trace) dump_trace(stream);
     return DV_OK;
   }
   for (const dv_model::GraphEntry& g : m->graphs) {
-    if (g.n == n && g.images == images && g.probs == probs && g.stream == stream) {
+    if (g.n == n && g.stream == stream) {
       DV_HIP_CHECK(hipGraphLaunch(g.exec, stream));
+      ++m->graph_replays;
       return DV_OK;
     }
   }
   hipGraph_t graph = nullptr;
   DV_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-  const int rc = enqueue_forward(m, images, n, probs, stream);
+  const int rc = enqueue_forward(m, n, stream);
   const hipError_t ce = hipStreamEndCapture(stream, &graph);
   if (rc != DV_OK) {
     if (graph) (void)hipGraphDestroy(graph);
@@ -2390,7 +2462,7 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   if (ce != hipSuccess || graph == nullptr) {
     return dv::fail(DV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
   }
-  dv_model::GraphEntry e{n, images, probs, stream, nullptr};
+  dv_model::GraphEntry e{n, stream, nullptr};
   const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (ie != hipSuccess) {
@@ -2402,7 +2474,16 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
     m->graphs.erase(m->graphs.begin());
   }
   m->graphs.push_back(e);
+  ++m->graph_captures;
   DV_HIP_CHECK(hipGraphLaunch(e.exec, stream));
+  return DV_OK;
+}
+
+// Testing hook: how many forwards were captured into a new hipGraph / replayed from the cache.
+int dv_model_graph_stats(const dv_model* m, int64_t* captures, int64_t* replays) {
+  if (!m) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_graph_stats: null");
+  if (captures) *captures = m->graph_captures;
+  if (replays) *replays = m->graph_replays;
   return DV_OK;
 }
 

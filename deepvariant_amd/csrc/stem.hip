@@ -233,8 +233,15 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
     b2[f] = static_cast<unsigned>(A_OFF_C1 + hi * A_C1PLANE + (ty2[f] * A_C1W + tx2[f]) * 16);
   }
 
+  const uint8_t* in_base = p.in_ind != nullptr ? *p.in_ind + p.in_off : p.in;   // wave-uniform
+  {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(in_base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned up = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    in_base = reinterpret_cast<const uint8_t*>((static_cast<unsigned long long>(up) << 32) | lo);
+  }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(p.in), 0, p.in_bytes, 0x00020000);
+      const_cast<uint8_t*>(in_base), 0, p.in_bytes, 0x00020000);
   const int tiles_img = p.tiles_y * p.tiles_x;
   const unsigned img_in = static_cast<unsigned>(p.H * p.W * p.C);
   const size_t img_out = static_cast<size_t>(p.og.groups) * p.og.hp * p.og.wp;  // pieces

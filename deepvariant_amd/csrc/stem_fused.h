@@ -24,7 +24,10 @@ constexpr int kStemA_W1Halfs = 5 * 2 * 32 * 8;    // conv1: 5 chunks (2 taps x 8
 constexpr int kStemA_W2Halfs = 18 * 2 * 32 * 8;   // conv2: 9 taps x 2 channel chunks
 
 struct StemAArgs {
-  const uint8_t* in;      // [N][H][W][C]
+  const uint8_t* in;      // [N][H][W][C]; or, when in_ind is set, *in_ind + in_off (the caller's
+                          // pointer read from device memory, so that a captured graph does not bake it in)
+  const uint8_t* const* in_ind;
+  size_t in_off;
   const _Float16* w1;     // pack_stem_a_w1
   const _Float16* w2;     // pack_stem_a_w2
   const float* shift1;    // [32]

@@ -95,9 +95,10 @@ class InceptionV3(torch.nn.Module):
                        (tuple(images.shape[1:]), self.input_shape))
     images = images.contiguous()
     n = images.shape[0]
-    # dv_model_infer replays the forward as a hipGraph keyed by (n, images, probs, stream):
-    # the output lives in a model-owned buffer per batch size so that the key only
-    # changes with the caller's image buffer; callers get their own copy (n x 3 floats).
+    # dv_model_infer replays the forward as a hipGraph keyed by (n, stream) -- the image and
+    # output pointers travel through a device-side table, so fresh tensors replay the same
+    # graph.  The output lives in a model-owned buffer per batch size; callers get their own
+    # copy (n x 3 floats).
     out = self._out_buffers.get((n, images.device))
     if out is None:
       if len(self._out_buffers) >= 8:
@@ -109,6 +110,12 @@ class InceptionV3(torch.nn.Module):
         self._handle, images.data_ptr(), n, out.data_ptr(),
         C.c_void_p(stream)))
     return out.clone()
+
+  def graph_stats(self) -> Tuple[int, int]:
+    """(forwards captured into a new hipGraph, forwards replayed from the cache)."""
+    cap, rep = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().dv_model_graph_stats(self._handle, C.byref(cap), C.byref(rep)))
+    return cap.value, rep.value
 
   @property
   def conv_macs_per_example(self) -> int:

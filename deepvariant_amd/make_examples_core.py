@@ -204,7 +204,7 @@ class RegionProcessor:
     sample = options.sample_options[0]
     self.variant_caller = variant_calling.VariantCaller(variant_calling.VariantCallerOptions(
         po.vsc_min_count_snps, po.vsc_min_count_indels, po.vsc_min_fraction_snps, po.vsc_min_fraction_indels,
-        sample_name=sample.name))
+        sample_name=sample.name, track_ref_reads=po.track_ref_reads))
     self.generator = make_examples_native.ExamplesGenerator(
         options, example_filenames or {}, test_mode=not example_filenames, device=device, ref_reader=ref_reader)
 

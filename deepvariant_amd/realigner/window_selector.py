@@ -125,13 +125,22 @@ def allele_count_linear_candidates_from_allele_counter(allele_counter, model: Al
   """AlleleCountLinearWindowSelectorCandidates (:143-207); float32 like the reference."""
   f32 = np.float32
   scores = np.full(allele_counter.interval_length(), f32(model.bias), np.float32)
-  scores += _ref_supporting_read_counts(allele_counter).astype(np.float32) * f32(model.coeff_reference)
+  # float32 sums depend on their order; the reference walks the positions once and adds, at
+  # position i, first ref_supporting_read_count * coeff_reference to scores[i] and then i's read
+  # alleles over their footprints.  Same order here: the reference terms of all positions up
+  # to i go in right before i's alleles (they touch scores[j] only, so for every j the order
+  # is: footprints from positions < j, the reference term of j, footprints from positions >= j).
+  ref_terms = _ref_supporting_read_counts(allele_counter).astype(np.float32) * f32(model.coeff_reference)
+  done = 0
   coeff = {allelecounter.SUBSTITUTION: f32(model.coeff_substitution),
            allelecounter.SOFT_CLIP: f32(model.coeff_soft_clip),
            allelecounter.INSERTION: f32(model.coeff_insertion),
            allelecounter.DELETION: f32(model.coeff_deletion),
            allelecounter.REFERENCE: f32(model.coeff_reference)}
   for i, ac in _positions_with_read_alleles(allele_counter):
+    if i + 1 > done:
+      scores[done:i + 1] += ref_terms[done:i + 1]
+      done = i + 1
     for allele in ac.read_alleles.values():
       n = len(allele.bases)
       by = f32(allele.count) * coeff[allele.type]
@@ -143,6 +152,7 @@ def allele_count_linear_candidates_from_allele_counter(allele_counter, model: Al
         _update_counts(by, i + 1, i + n, scores)
       else:
         raise ValueError('Saw an Allele with an unexpected type %r' % (allele.type,))
+  scores[done:] += ref_terms[done:]
   return scores
 
 

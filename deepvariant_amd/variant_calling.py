@@ -205,8 +205,8 @@ class VariantCaller:
         key = K_SUPPORTING_UNCALLED_ALLELE if alt is None else alt + suffix
         call.allele_support.setdefault(key, T.SupportingReads()).read_names.append(read_name)
         call.allele_support_ext.setdefault(key, []).append(T.ReadSupport(read_name, bool(allele.is_low_quality)))
-      else:
-        # REFERENCE read alleles exist only under track_ref_reads, at candidate positions
-        # (variant_calling_multisample.cc:1231-1247)
+      elif self._options.track_ref_reads:
+        # REFERENCE read alleles are kept by name only under track_ref_reads, at candidate
+        # positions (variant_calling.cc:706, variant_calling_multisample.cc:1231-1247)
         call.ref_support.append(read_name)
         call.ref_support_ext.append(T.ReadSupport(read_name, bool(allele.is_low_quality)))

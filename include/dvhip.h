@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 2
+#define DV_ABI_VERSION 3
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -546,10 +546,11 @@ typedef struct dv_allele_event {   /* one ReadAllele that AddReadAlleles stores 
   int32_t position;      /* offset in the interval */
   uint32_t read;         /* index in the read table */
   uint32_t read_offset;  /* SUBSTITUTION: the base; INSERTION / SOFT_CLIP: first inserted base; DELETION: next read base */
-  uint16_t length;       /* operation length (1 for substitutions) */
-  uint8_t type;          /* AlleleType: 2 SUBSTITUTION, 3 INSERTION, 4 DELETION, 5 SOFT_CLIP; 1 REFERENCE
-                            (track_ref_reads, candidate positions only; read_offset = the base) */
-  uint8_t low_quality;   /* Allele.is_low_quality */
+  uint32_t length_type;  /* bits 0-27: operation length (1 for substitutions; a BAM CIGAR length has 28 bits,
+                            so long HiFi / ONT soft clips and deletions are exact);
+                            bits 28-30: AlleleType: 2 SUBSTITUTION, 3 INSERTION, 4 DELETION, 5 SOFT_CLIP;
+                            1 REFERENCE (track_ref_reads, candidate positions only; read_offset = the base);
+                            bit 31: Allele.is_low_quality */
 } dv_allele_event;
 
 typedef struct dv_allele_counts dv_allele_counts;  /* owns the host copies of the result */
@@ -612,6 +613,11 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n);
  *   probs   device fp32  [n, num_classes] */
 int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
                    void* stream);
+
+/* On a non-default stream the forward is captured once per (n, stream) into a hipGraph and
+ * replayed; the image / probability pointers are read from a device-side table, so they may
+ * change from call to call without a new capture.  Testing hook: captures and replays so far. */
+int dv_model_graph_stats(const dv_model* m, int64_t* captures, int64_t* replays);
 
 /* Testing hook: copy activation buffer `index` (fp16, channel-blocked
  * [n][c/8][h][w][8], first n examples of the last dv_model_infer) to host

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
   for sym in declared:
     assert hasattr(l, sym), sym
   assert sorted(_lib.ABI_SYMBOLS) == declared
-  assert l.dv_abi_version() == 2   # 2: dv_read_requirements.use_original_base_quality_scores
+  assert l.dv_abi_version() == 3   # 3: dv_allele_event.length_type (28-bit lengths), dv_model_graph_stats
 
 
 def test_host_helpers_need_no_gpu():

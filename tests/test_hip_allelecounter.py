@@ -201,3 +201,29 @@ def test_golden_region_counts_and_candidates():
   _compare(counter.counts(), oracle)
   counts = counter.counts()
   assert G.golden_candidate_agreement(examples, lambda pos: counts[pos - lo]) == (78, 72, 47)
+
+
+def test_operations_longer_than_16_bits():
+  """A HiFi / ONT soft clip, insertion or deletion longer than 65,535 bases keeps its full length
+  (dv_allele_event.length_type has the 28 bits of a BAM CIGAR length): the allele strings equal the
+  oracle's, base for base."""
+  rng = np.random.default_rng(9)
+  n = 200_000
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=n))
+  ref = _Ref(seq)
+
+  def bases(k):
+    return ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=k))
+  long_clip = V.make_read('c', 1000, bases(70_001) + seq[1000:1060], ['70001S', '60M'], name='clip')
+  long_ins = V.make_read('c', 1010, seq[1010:1020] + bases(66_000) + seq[1020:1050], ['10M', '66000I', '30M'],
+                         name='ins')
+  long_del = V.make_read('c', 1005, seq[1005:1015] + seq[1015 + 67_000:1015 + 67_040], ['10M', '67000D', '40M'],
+                         name='del')
+  counter = A.AlleleCounter(ref, 'c', 900, 1200)
+  oracle = R.AlleleCounter(ref, 'c', 900, 1200)
+  for r in (long_clip, long_ins, long_del):
+    counter.add(r)
+    oracle.add(r)
+  _compare(counter.counts(), oracle)
+  lengths = sorted(len(a.bases) for c in counter.counts() for a in c.read_alleles.values() if len(a.bases) > 60_000)
+  assert lengths == [66_001, 67_001, 70_002]

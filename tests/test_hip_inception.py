@@ -265,3 +265,29 @@ def test_second_stem_pool_fused_into_mixed0_is_bit_identical():
   pa, pb = fused(x).clone(), plain(x).clone()
   assert np.array_equal(fused.debug_tensor(-1, n), plain.debug_tensor(-1, n))
   assert torch.equal(pa, pb)
+
+
+def test_fresh_image_tensors_replay_the_captured_graph():
+  """The hipGraph cache is keyed by (n, stream): the caller's image / output pointers go through a
+  device-side table, so a new tensor per call (what a per-region driver does) must not recapture,
+  and every call must classify ITS images."""
+  import torch
+  from deepvariant_amd.inception_v3 import InceptionV3
+  shape = (100, 221, 7)
+  m = InceptionV3(shape, max_batch=32)
+  m.init_random(3)
+  rng = np.random.default_rng(5)
+  stream = torch.cuda.Stream()
+  keep, outs = [], []
+  with torch.cuda.stream(stream):
+    for i in range(6):
+      x = torch.from_numpy(rng.integers(0, 256, (24,) + shape, dtype=np.uint8)).cuda()
+      keep.append(x)                       # keep every tensor alive: six distinct device pointers
+      outs.append(m(x).cpu().numpy())
+    again = [m(x).cpu().numpy() for x in keep]
+  assert len({x.data_ptr() for x in keep}) == 6
+  captures, replays = m.graph_stats()
+  assert captures == 1 and replays == 11
+  for a, b in zip(outs, again):
+    np.testing.assert_array_equal(a, b)
+  assert max(np.abs(outs[0] - o).max() for o in outs[1:]) > 0      # different images, different answers

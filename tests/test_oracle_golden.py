@@ -363,7 +363,7 @@ def test_golden_pacbio_chain_with_phasing():
   pic = PC.pic_options(True)
   enc = PC.pic_options(False)
   hw = (pic.width - 1) // 2
-  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.12, sample_name='s'))
+  caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.12, sample_name='s', track_ref_reads=True))
   phaser = direct_phasing.DirectPhasing(1)
   n_contig = ref.n_bases('chr20')
 

@@ -1,12 +1,10 @@
-# round 3: first GPU run of the fused branch chains (chain.hip): parity, bench, per-launch table
+# round 3: chain.hip phase profile (s_memtime per phase) for both loaders + parity of this round's other GPU-side changes
 set -x
-mkdir -p gpurun_out/r3a
-timeout 900 python -m pytest tests/test_hip_chain.py -x -q > gpurun_out/r3a/pytest_chain.log 2>&1; echo "rc=$?" >> gpurun_out/r3a/pytest_chain.log
-tail -15 gpurun_out/r3a/pytest_chain.log
-timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r3a/bench.json 2> gpurun_out/r3a/bench.err; cat gpurun_out/r3a/bench.json
-DV_NO_CHAIN=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r3a/bench_nochain.json 2> gpurun_out/r3a/bench_nochain.err; cat gpurun_out/r3a/bench_nochain.json
-DV_OP_TRACE=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r3a/op_trace.err
-grep "dv-op" gpurun_out/r3a/op_trace.err | tail -80 > gpurun_out/r3a/op_trace.txt
-grep -E "chain|total" gpurun_out/r3a/op_trace.txt
-timeout 900 python -m pytest tests/test_hip_inception.py tests/test_hip_stem_fused.py tests/test_hip_resident.py -x -q > gpurun_out/r3a/pytest_cnn.log 2>&1; echo "rc=$?" >> gpurun_out/r3a/pytest_cnn.log
-tail -5 gpurun_out/r3a/pytest_cnn.log
+mkdir -p gpurun_out/r3c
+DV_OP_TRACE=1 DV_CHAIN_PROF=1 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r3c/prof_regs.err
+grep -E "dv-chain|chain " gpurun_out/r3c/prof_regs.err | tail -50 > gpurun_out/r3c/prof_regs.txt
+DV_CHAIN_DMA=1 DV_OP_TRACE=1 DV_CHAIN_PROF=1 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r3c/prof_dma.err
+grep -E "dv-chain|chain " gpurun_out/r3c/prof_dma.err | tail -50 > gpurun_out/r3c/prof_dma.txt
+cat gpurun_out/r3c/prof_regs.txt
+timeout 900 python -m pytest tests/test_hip_chain.py tests/test_hip_inception.py tests/test_hip_allelecounter.py tests/test_hip_blank_skip.py -x -q > gpurun_out/r3c/pytest.log 2>&1; echo "rc=$?" >> gpurun_out/r3c/pytest.log
+tail -8 gpurun_out/r3c/pytest.log
