@@ -56,9 +56,19 @@ __device__ __forceinline__ const char* uniform_ptr(const char* q) {
   return reinterpret_cast<const char*>((static_cast<unsigned long long>(up) << 32) | lo);
 }
 
-// One 16-channel chunk: NT filter taps x (NB cout subtiles x 3 pixel fragments) MFMAs.  The
-// fragments of tap i + 1 are requested before the MFMAs of tap i (two static register sets).
-template <int NB, int NT>
+// Which of a wave's NB x 3 (cout subtile, pixel fragment) MFMA tiles exist.  A layer of five
+// subtiles (160 channels) cannot be halved: 3 + 2 subtiles leaves two SIMDs idle a third of the
+// time.  Instead the pixel half's 15 tiles go 8 + 7: the first wave takes subtiles 0-2 WITHOUT
+// (subtile 2, fragment 2), the second subtiles 2-4 with ONLY fragment 2 of subtile 2.
+//   SKIP 0: all NB x 3     SKIP 1: without (nb 2, pt 2)     SKIP 2: without (nb 0, pt 0) and (nb 0, pt 1)
+template <int SKIP>
+__device__ __forceinline__ constexpr bool chain_tile(int nb, int pt) {
+  return SKIP == 1 ? !(nb == 2 && pt == 2) : SKIP == 2 ? !(nb == 0 && pt < 2) : true;
+}
+
+// One 16-channel chunk: NT filter taps x the wave's MFMA tiles.  The fragments of tap i + 1 are
+// requested between the MFMAs of tap i (two static register sets, one request per MFMA slot).
+template <int NB, int NT, int SKIP>
 __device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, unsigned a_tap_stride,
                                            const unsigned (&b_addr)[CH_PT], unsigned b_tap_stride,
                                            const unsigned (&mask)[CH_PT], unsigned zero_addr,
@@ -84,7 +94,9 @@ __device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, un
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
       for (int pt = 0; pt < CH_PT; ++pt) {
-        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i & 1][nb], B[i & 1][pt], acc[nb][pt], 0, 0, 0);
+        if (chain_tile<SKIP>(nb, pt)) {
+          acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i & 1][nb], B[i & 1][pt], acc[nb][pt], 0, 0, 0);
+        }
       }
     }
     if (i + 1 < NT) {
@@ -101,28 +113,23 @@ __device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, un
   }
 }
 
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
 // shift + ReLU + fp16 of one 32-cout accumulator, lanes l / l+32 paired into standard C8 pieces:
 // piece[t] = output channels cbase + 8 * (2t + hi) .. +7 of this lane's pixel (conv_common.h's
-// epilogue arithmetic, so that values match the per-layer kernels bit for bit).
-__device__ __forceinline__ void chain_pieces(const float16_t& a, const float* shift, int cbase, bool relu,
-                                             int hi, uint4_t (&piece)[2]) {
+// epilogue arithmetic, so that values match the per-layer kernels bit for bit).  sh[q] = the
+// shifts of couts cbase + 8q + 4hi .. +3, loaded by the caller (one 16-byte load per quad, all in
+// flight together -- scalar loads here cost a round trip each: 7 k cycles per layer, measured).
+__device__ __forceinline__ void chain_pieces(const float16_t& a, const float4_t (&sh)[4], uint4_t (&piece)[2]) {
   const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
   unsigned pk[4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
-    const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(shift + (cbase + 8 * q)));
-    const f4_t l4 = sp[0], u4 = sp[1];
-    const float2_t s0 = hi ? float2_t{u4[0], u4[1]} : float2_t{l4[0], l4[1]};
-    const float2_t s1 = hi ? float2_t{u4[2], u4[3]} : float2_t{l4[2], l4[3]};
-    const float2_t v0 = float2_t{a[4 * q], a[4 * q + 1]} + s0;
-    const float2_t v1 = float2_t{a[4 * q + 2], a[4 * q + 3]} + s1;
+    const float2_t v0 = float2_t{a[4 * q], a[4 * q + 1]} + float2_t{sh[q][0], sh[q][1]};
+    const float2_t v1 = float2_t{a[4 * q + 2], a[4 * q + 3]} + float2_t{sh[q][2], sh[q][3]};
     half2_t h0 = __builtin_convertvector(v0, half2_t), h1 = __builtin_convertvector(v1, half2_t);
-    if (relu) {
-      h0 = __builtin_elementwise_max(h0, zero2);
-      h1 = __builtin_elementwise_max(h1, zero2);
-    }
+    h0 = __builtin_elementwise_max(h0, zero2);
+    h1 = __builtin_elementwise_max(h1, zero2);
     pk[q][0] = __builtin_bit_cast(unsigned, h0);
     pk[q][1] = __builtin_bit_cast(unsigned, h1);
   }
@@ -136,7 +143,7 @@ __device__ __forceinline__ void chain_pieces(const float16_t& a, const float* sh
 
 // ------------------------------------------------------------------ computing waves (0-3)
 // wave = (pixel half ph, cout half ch): fragments 3 ph .. 3 ph + 2 of the tile, the first /
-// second half of the layer's 32-cout subtiles.
+// second half of the layer's 32-cout subtiles (8 + 7 tiles for five subtiles, chain_tile).
 struct ChainLane {
   int prow[CH_PT], pcol[CH_PT], pimg[CH_PT];
   bool pval[CH_PT];
@@ -144,16 +151,16 @@ struct ChainLane {
   int l31, hi;
 };
 
-// One layer on one tile for one computing wave: NB cout subtiles x 3 pixel fragments, NT taps
-// per chunk.  The accumulators are local to this instantiation (a switch over tap counts
-// around a shared accumulator array made the register allocator spill).
 // tuning aid (DV_CHAIN_PROF): shader-clock sums per computing wave
 struct ChainProf {
   unsigned long long wait_b = 0, mfma = 0, wait_e = 0, epi_lds = 0, epi_hbm = 0, setup = 0;
 };
 __device__ __forceinline__ unsigned long long chain_clock() { return __builtin_amdgcn_s_memtime(); }
 
-template <int NB, int NT, bool PROF>
+// One layer on one tile for one computing wave: NB cout subtiles x 3 pixel fragments (minus
+// SKIP), NT taps per chunk.  The accumulators are local to this instantiation (a switch over tap
+// counts around a shared accumulator array made the register allocator spill).
+template <int NB, int NT, int SKIP, bool PROF>
 __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainLayer& L, bool last, char* smem,
                                                 const ChainLane& c, int sub_base, int t_lo, unsigned m0,
                                                 unsigned m1, unsigned m2, int n0, unsigned step, ChainProf& prof) {
@@ -195,13 +202,22 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     unsigned b_addr[CH_PT];
 #pragma unroll
     for (int pt = 0; pt < CH_PT; ++pt) b_addr[pt] = b0[pt] + static_cast<unsigned>(cc) * CH_CHUNK_LDS;
-    chain_step<NB, NT>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, acc);
+    chain_step<NB, NT, SKIP>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, acc);
     if (PROF) {
-      asm volatile("" : "+v"(acc[0][0]));   // the step's MFMAs are issued before the clock is read
+      asm volatile("" : "+v"(acc[NB - 1][0]));   // the step's MFMAs are issued before the clock is read
       const unsigned long long t = chain_clock();
       prof.mfma += t - t0;
       t0 = t;
     }
+  }
+  // the folded BatchNorm shifts of this wave's couts: requested now, in flight across the barrier
+  float4_t sh[NB][4];
+  {
+    const float* sp = L.shift + (sub_base * 32 + 4 * c.hi);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh[nb][q] = *reinterpret_cast<const float4_t*>(sp + nb * 32 + 8 * q);
   }
   barrier_after_lds();     // E(l): every wave is done reading this layer's input
   if (PROF) {
@@ -209,6 +225,7 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     prof.wait_e += t - t0;
     t0 = t;
   }
+  const int cout = L.cout;
   if (!last) {
     // the layer's output replaces its input in LDS: [group][pixel][8]
 #pragma unroll
@@ -216,12 +233,13 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
       const int cbase = (sub_base + nb) * 32;
 #pragma unroll
       for (int pt = 0; pt < CH_PT; ++pt) {
+        if (!chain_tile<SKIP>(nb, pt)) continue;
         uint4_t piece[2];
-        chain_pieces(acc[nb][pt], L.shift, cbase, true, c.hi, piece);
+        chain_pieces(acc[nb][pt], sh[nb], piece);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int group = cbase / 8 + 2 * t + c.hi;
-          if (group * 8 < L.cout) {
+          if (group * 8 < cout) {
             *reinterpret_cast<uint4_t*>(smem + static_cast<unsigned>(group) * (CH_TPX * 16) + c.px_piece[pt]) =
                 piece[t];
           }
@@ -232,23 +250,27 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     // the last layer goes to HBM, straight into the block's concat buffer
     const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
     uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
+    unsigned obase[CH_PT];
+    bool ok[CH_PT];
+#pragma unroll
+    for (int pt = 0; pt < CH_PT; ++pt) {
+      const int n = n0 + c.pimg[pt];
+      ok[pt] = c.pval[pt] && n < p.N;
+      obase[pt] = static_cast<unsigned>(((n * p.og.groups + p.out_goff) * p.og.hp + c.prow[pt] + p.og.halo) * p.og.wp +
+                                        c.pcol[pt] + p.og.halo);
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int cbase = (sub_base + nb) * 32;
 #pragma unroll
       for (int pt = 0; pt < CH_PT; ++pt) {
+        if (!chain_tile<SKIP>(nb, pt)) continue;
         uint4_t piece[2];
-        chain_pieces(acc[nb][pt], L.shift, cbase, true, c.hi, piece);
-        const int n = n0 + c.pimg[pt];
-        const unsigned obase = static_cast<unsigned>(
-            ((n * p.og.groups + p.out_goff) * p.og.hp + c.prow[pt] + p.og.halo) * p.og.wp + c.pcol[pt] +
-            p.og.halo);
+        chain_pieces(acc[nb][pt], sh[nb], piece);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int group = cbase / 8 + 2 * t + c.hi;
-          if (c.pval[pt] && n < p.N && group * 8 < L.cout) {
-            outp[obase + static_cast<unsigned>(group) * gstride] = piece[t];
-          }
+          if (ok[pt] && group * 8 < cout) outp[obase[pt] + static_cast<unsigned>(group) * gstride] = piece[t];
         }
       }
     }
@@ -267,6 +289,12 @@ __device__ __forceinline__ unsigned chain_layer_idle(const ChainLayer& L, unsign
   for (int cc = 0; cc < n_chunks; ++cc, ++step) barrier_after_lds();
   barrier_after_lds();
   return step;
+}
+
+// Taps of a 1-D filter that meet the map for a pixel at `pos` of `lim`: t + pos - pad in [0, lim).
+__device__ __forceinline__ unsigned chain_tap_mask(int pos, int lim, int taps, int pad, bool valid) {
+  const int lo = max(0, pad - pos), hi = min(taps - 1, lim - 1 + pad - pos);
+  return valid && hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
 }
 
 template <bool PROF>
@@ -293,35 +321,26 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
   const unsigned zero_addr = p.act_bytes + 2 * p.slot_bytes;
   if (wave == 0 && lane < 4) *reinterpret_cast<unsigned*>(smem + zero_addr + lane * 4) = 0u;
 
-  unsigned step = 0;
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    const int n0 = max(0, min(tile * p.G, p.N - p.G));
-    for (int l = 0; l < p.n_layers; ++l) {
-      if (PROF) t_setup = chain_clock();
+  // Per layer, once per kernel: the taps the wave walks (the union of its lanes' taps: wave-wide
+  // ballots) and its share of the cout subtiles, packed t_lo | nt << 4 | nbw << 8 | skip << 12 |
+  // sub_base << 16.
+  unsigned cfg[kChainMaxLayers];
+#pragma unroll
+  for (int l = 0; l < kChainMaxLayers; ++l) {
+    cfg[l] = 0;
+    if (l < p.n_layers) {
       const ChainLayer& L = p.L[l];
-      const bool last = l + 1 == p.n_layers;
       const int pad = (L.taps - 1) >> 1;
-      // which taps meet the map, per lane and fragment; the wave walks the union of its lanes' taps
-      unsigned m[CH_PT], any = 0;
+      unsigned any = 0;
 #pragma unroll
       for (int pt = 0; pt < CH_PT; ++pt) {
-        const int pos = L.horizontal ? c.pcol[pt] : c.prow[pt];
-        const int lim = L.horizontal ? p.w : p.h;
-        m[pt] = 0;
-#pragma unroll
-        for (int t = 0; t < kChainMaxTaps; ++t) {
-          if (t < L.taps && c.pval[pt] && static_cast<unsigned>(pos + t - pad) < static_cast<unsigned>(lim)) {
-            m[pt] |= 1u << t;
-          }
-        }
-        any |= m[pt];
+        any |= chain_tap_mask(L.horizontal ? c.pcol[pt] : c.prow[pt], L.horizontal ? p.w : p.h, L.taps, pad, c.pval[pt]);
       }
       unsigned wave_any = 0;
 #pragma unroll
       for (int t = 0; t < kChainMaxTaps; ++t) {
         if (__builtin_amdgcn_ballot_w64((any >> t) & 1u) != 0ull) wave_any |= 1u << t;
       }
-      wave_any = __builtin_amdgcn_readfirstlane(wave_any);
       int t_lo = wave_any ? __builtin_ctz(wave_any) : 0;
       int nt = wave_any ? 32 - __builtin_clz(wave_any) - t_lo : 0;
       // compiled tap counts: 3, 5, 6, 7 -- a range in between is widened (the extra taps read
@@ -334,19 +353,49 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
           ++nt;
         }
       }
-#pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) m[pt] >>= t_lo;
       const int subs = L.cout_pad >> 5;
-      const int sub_base = ch ? (subs + 1) >> 1 : 0;
-      const int nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+      int sub_base, nbw, skip = 0;
+      if (subs == 5) {          // 8 + 7 tiles (chain_tile)
+        nbw = 3;
+        sub_base = ch ? 2 : 0;
+        skip = ch ? 2 : 1;
+      } else {
+        sub_base = ch ? (subs + 1) >> 1 : 0;
+        nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+      }
+      cfg[l] = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(t_lo) | static_cast<unsigned>(nt) << 4 |
+                                              static_cast<unsigned>(nbw) << 8 | static_cast<unsigned>(skip) << 12 |
+                                              static_cast<unsigned>(sub_base) << 16);
+    }
+  }
+
+  unsigned step = 0;
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int n0 = max(0, min(tile * p.G, p.N - p.G));
+    for (int l = 0; l < p.n_layers; ++l) {
+      if (PROF) t_setup = chain_clock();
+      const ChainLayer& L = p.L[l];
+      const bool last = l + 1 == p.n_layers;
+      const unsigned cf = l == 0 ? cfg[0] : l == 1 ? cfg[1] : l == 2 ? cfg[2] : cfg[3];
+      const int t_lo = cf & 15, nt = (cf >> 4) & 15, nbw = (cf >> 8) & 15, skip = (cf >> 12) & 15;
+      const int sub_base = cf >> 16;
+      const int pad = (L.taps - 1) >> 1;
+      unsigned m[CH_PT];
+#pragma unroll
+      for (int pt = 0; pt < CH_PT; ++pt) {
+        m[pt] = chain_tap_mask(L.horizontal ? c.pcol[pt] : c.prow[pt], L.horizontal ? p.w : p.h, L.taps, pad,
+                               c.pval[pt]) >> t_lo;
+      }
       if (PROF) prof.setup += chain_clock() - t_setup;
-#define DV_CHAIN_CASE(NB_, NT_) \
-  case NB_ * 8 + NT_: \
-    step = chain_layer<NB_, NT_, PROF>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step, prof); \
+#define DV_CHAIN_CASE(NB_, NT_, SKIP_) \
+  case SKIP_ * 64 + NB_ * 8 + NT_: \
+    step = chain_layer<NB_, NT_, SKIP_, PROF>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step, prof); \
     break;
-      switch (nbw * 8 + nt) {   // wave-uniform
-        DV_CHAIN_CASE(2, 3) DV_CHAIN_CASE(2, 5) DV_CHAIN_CASE(2, 6) DV_CHAIN_CASE(2, 7)
-        DV_CHAIN_CASE(3, 3) DV_CHAIN_CASE(3, 5) DV_CHAIN_CASE(3, 6) DV_CHAIN_CASE(3, 7)
+      switch (skip * 64 + nbw * 8 + nt) {   // wave-uniform
+        DV_CHAIN_CASE(2, 3, 0) DV_CHAIN_CASE(2, 5, 0) DV_CHAIN_CASE(2, 6, 0) DV_CHAIN_CASE(2, 7, 0)
+        DV_CHAIN_CASE(3, 3, 0) DV_CHAIN_CASE(3, 5, 0) DV_CHAIN_CASE(3, 6, 0) DV_CHAIN_CASE(3, 7, 0)
+        DV_CHAIN_CASE(3, 3, 1) DV_CHAIN_CASE(3, 5, 1) DV_CHAIN_CASE(3, 6, 1) DV_CHAIN_CASE(3, 7, 1)
+        DV_CHAIN_CASE(3, 3, 2) DV_CHAIN_CASE(3, 5, 2) DV_CHAIN_CASE(3, 6, 2) DV_CHAIN_CASE(3, 7, 2)
         default: step = chain_layer_idle(L, step); break;   // nt == 0 (the host admits only nbw of 2 or 3)
       }
 #undef DV_CHAIN_CASE

@@ -1813,8 +1813,10 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.out = static_cast<_Float16*>(m->dbuf[last.out_buf].ptr);
       a.og = lob.geom();
       a.out_goff = last.out_coff / 8;
-      static const bool dma_loader = getenv("DV_CHAIN_DMA") != nullptr;   // tuning knob
-      a.dma_loader = dma_loader ? 1 : 0;
+      // LDS-DMA loader by default; DV_CHAIN_REGS selects the register-staged one (two chunks of
+      // lead; measured 1-2 % slower: the computing waves, not the loaders, set the pace)
+      static const bool regs_loader = getenv("DV_CHAIN_REGS") != nullptr;   // tuning knob
+      a.dma_loader = regs_loader ? 0 : 1;
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " [fused, G=" + std::to_string(a.G) + "]";
       TraceScope tr(stream, tr_label, tr_flops,
                     2.0 * n * op.oh * op.ow * (static_cast<double>(op.cin) + last.cout));

@@ -64,3 +64,53 @@ def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None,
     out_i.append(recv[r, :c, k].to(torch.int64) +
                  (recv[r, :c, k + 1].to(torch.int64) << 24))
   return torch.cat(out_p), torch.cat(out_i)
+
+
+def gather_records(records: Sequence[bytes], device=None, group=None,
+                   max_chunk_bytes: int = 1 << 28) -> List[List[bytes]]:
+  """All ranks receive every rank's list of serialised records (CallVariantsOutput protos of the
+  fused route), rank by rank in the order they were produced.
+
+  Record lengths and bytes travel as two padded all-gathers (lengths int64, payload uint8; the
+  payload in chunks of at most `max_chunk_bytes` per rank so that the staging buffers stay
+  bounded whatever the run's size).  `device`: where the staging tensors live -- a CUDA device
+  under RCCL, None (CPU) under gloo."""
+  world = dist.get_world_size(group)
+  lengths = torch.tensor([len(r) for r in records], dtype=torch.int64)
+  total = int(lengths.sum()) if len(records) else 0
+  mine = torch.tensor([len(records), total], dtype=torch.int64, device=device)
+  sizes = torch.zeros((world, 2), dtype=torch.int64, device=device)
+  dist.all_gather_into_tensor(sizes.view(-1), mine, group=group)
+  sizes = sizes.cpu().tolist()
+  max_n = max(s[0] for s in sizes)
+  max_total = max(s[1] for s in sizes)
+  if max_n == 0:
+    return [[] for _ in range(world)]
+  send_len = torch.zeros(max_n, dtype=torch.int64, device=device)
+  send_len[:len(records)] = lengths.to(send_len.device)
+  recv_len = torch.empty(world * max_n, dtype=torch.int64, device=device)
+  dist.all_gather_into_tensor(recv_len, send_len, group=group)
+  recv_len = recv_len.view(world, max_n).cpu()
+  payload = torch.frombuffer(bytearray(b''.join(records)), dtype=torch.uint8) if total else torch.zeros(0, dtype=torch.uint8)
+  blobs = [bytearray() for _ in range(world)]
+  for lo in range(0, max_total, max_chunk_bytes):
+    width = min(max_chunk_bytes, max_total - lo)
+    send = torch.zeros(width, dtype=torch.uint8, device=device)
+    part = payload[lo:lo + width]
+    send[:part.numel()] = part.to(send.device)
+    recv = torch.empty(world * width, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, width).cpu()
+    for r in range(world):
+      have = max(0, min(width, sizes[r][1] - lo))
+      blobs[r] += recv[r, :have].numpy().tobytes()
+  out = []
+  for r in range(world):
+    lens = recv_len[r, :sizes[r][0]].tolist()
+    recs, at = [], 0
+    blob = bytes(blobs[r])
+    for n in lens:
+      recs.append(blob[at:at + n])
+      at += n
+    out.append(recs)
+  return out

@@ -134,6 +134,10 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--checkpoint_json', default='')
   ap.add_argument('--call_variants_outfile', default='')
   ap.add_argument('--device', type=int, default=0)
+  # not a reference flag: the node-level launcher that stands in for run_deepvariant's N processes
+  # (scripts/run_deepvariant.py:457-462) -- N ranks, rank r = task r of --call_variants_outfile name@N,
+  # one GPU each, one final all-gather of the CallVariantsOutput records
+  ap.add_argument('--gpus', type=int, default=1)
   return ap
 
 
@@ -232,6 +236,11 @@ def check_flags(args) -> None:
     raise ValueError('--track_ref_reads must be set to True when --phase_reads is set.')
   if args.partition_size < 1:
     raise ValueError('--partition_size must be positive')
+  if args.gpus < 1:
+    raise ValueError('--gpus must be positive')
+  if args.gpus > 1 and not args.call_variants_outfile:
+    raise ValueError('--gpus N shards the fused route (--call_variants_outfile name@N --checkpoint ...); '
+                     'for tf.Examples run N independent --task processes, as the reference does')
 
 
 def _shard(spec: str, task: int):
@@ -372,8 +381,28 @@ class RegionReads:
     return [self._reads[i] for i in keep.tolist()]
 
 
-def make_examples_runner(args, log=sys.stderr) -> dict:
-  """-> stats; writes the task's example shard (and its example_info.json) or the CVO file."""
+class RunnerHooks:
+  """What the runner builds per task.  The product uses these defaults; the multi-process CPU
+  tests substitute a processor / model that need no GPU (tests/test_make_examples_dist_cpu.py)."""
+
+  def make_processor(self, options, ref_reader, po, device):
+    return make_examples_core.RegionProcessor(options, ref_reader, po, device=device)
+
+  def make_model(self, args, options):
+    from deepvariant_amd import call_variants
+    from deepvariant_amd.inception_v3 import InceptionV3
+    shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
+             len(options.pic_options.channels))
+    model = InceptionV3(shape, max_batch=1024, device=args.device)
+    call_variants.load_flat_checkpoint(args.checkpoint, model)
+    return model
+
+
+def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = None, sink=None) -> dict:
+  """-> stats; writes the task's example shard (and its example_info.json) or the CVO file.
+  `sink` (write(bytes), close()) replaces the task's TFRecord file: the multi-GPU driver keeps
+  a rank's records in memory for the final gather."""
+  hooks = hooks or RunnerHooks()
   check_flags(args)
   ref_reader = genomics_io.FastaReader(args.ref)
   options, po = options_from_flags(args)
@@ -385,15 +414,8 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   contig_names = genomics_io.bam_contig_names(args.reads)
   pieces = calling_regions(args, ref_reader, contig_names, num_shards)
   reads_for = RegionReads(args)
-  proc = make_examples_core.RegionProcessor(options, ref_reader, po, device=args.device)
-  model = None
-  if args.call_variants_outfile:
-    from deepvariant_amd import call_variants
-    from deepvariant_amd.inception_v3 import InceptionV3
-    shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
-             len(options.pic_options.channels))
-    model = InceptionV3(shape, max_batch=1024, device=args.device)
-    call_variants.load_flat_checkpoint(args.checkpoint, model)
+  proc = hooks.make_processor(options, ref_reader, po, args.device)
+  model = hooks.make_model(args, options) if args.call_variants_outfile else None
   stats = dict(n_regions=0, n_reads=0, n_candidates=0, n_examples=0)
   if sweep:
     # int32 positions per calling region, END_OF_PARTITION after each, END_OF_REGION where a
@@ -415,7 +437,7 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
     print('make_examples task %d: %d regions, %d reads, %d candidate positions -> %s' % (
         args.task, stats['n_regions'], stats['n_reads'], stats['n_candidates'], out_path), file=log)
     return stats
-  writer = tfrecord.Writer(out_path)
+  writer = sink if sink is not None else tfrecord.Writer(out_path)
   image_shape = None
   try:
     for region in pieces:
@@ -445,6 +467,92 @@ def make_examples_runner(args, log=sys.stderr) -> dict:
   return stats
 
 
+class _MemorySink:
+  def __init__(self):
+    self.records: List[bytes] = []
+
+  def write(self, rec: bytes) -> None:
+    self.records.append(rec)
+
+  def close(self) -> None:
+    pass
+
+
+def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optional[RunnerHooks] = None) -> dict:
+  """One rank of `--gpus N`: the node-level form of what the reference runs as N make_examples
+  processes + N call_variants writer shards glued by files (scripts/run_deepvariant.py:457-462,
+  deepvariant/call_variants.py:934-951).  Rank r IS task r of N (regions i % N == r,
+  make_examples_core.py:879-888), runs the fused route on its own GPU with no inter-GPU traffic,
+  and the CallVariantsOutput records are exchanged once at the end (one all-gather: RCCL over
+  xGMI on GPUs, gloo in the CPU tests); rank 0 writes the N shard files, each byte-identical to
+  what an independent `--task r` run writes.  The process group must be initialised."""
+  import torch
+  from deepvariant_amd import dist as dvd
+  spec = args.call_variants_outfile
+  if not sharded_file_utils.is_sharded_file_spec(spec) or sharded_file_utils.parse_sharded_file_spec(spec)[1] != world:
+    raise ValueError('--gpus %d needs --call_variants_outfile name@%d (one shard per rank)' % (world, world))
+  args.task = rank
+  on_gpu = torch.cuda.is_available()
+  if on_gpu:
+    args.device = rank % torch.cuda.device_count()
+    torch.cuda.set_device(args.device)
+  sink = _MemorySink()
+  stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
+  device = torch.device('cuda', args.device) if on_gpu else None
+  per_rank = dvd.gather_records(sink.records, device=device)
+  if rank == 0:
+    for r, records in enumerate(per_rank):
+      writer = tfrecord.Writer(sharded_file_utils.sharded_filename(spec, r))
+      try:
+        for rec in records:
+          writer.write(rec)
+      finally:
+        writer.close()
+    print('make_examples --gpus %d: %s CallVariantsOutputs gathered from %d ranks -> %s' % (
+        world, '+'.join(str(len(x)) for x in per_rank), world, spec), file=log)
+  stats['n_gathered'] = sum(len(x) for x in per_rank)
+  return stats
+
+
+def _spawned_rank(rank: int, args, world: int, port: int) -> None:
+  import os
+  import torch
+  import torch.distributed as dist
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                    MASTER_PORT=str(port))
+  dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+  try:
+    distributed_runner(args, rank, world)
+  finally:
+    dist.destroy_process_group()
+
+
+def run_multi_gpu(args) -> None:
+  """`--gpus N`: under a launcher (torch.distributed.run: RANK / WORLD_SIZE set) this process is
+  one rank; otherwise the N ranks are spawned here, one process per GPU, 127.0.0.1 rendezvous."""
+  import os
+  import socket
+  import torch
+  import torch.distributed as dist
+  world = args.gpus
+  if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    if int(os.environ['WORLD_SIZE']) != world:
+      raise ValueError('--gpus must equal WORLD_SIZE')
+    dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    try:
+      distributed_runner(args, dist.get_rank(), world)
+    finally:
+      dist.destroy_process_group()
+    return
+  if torch.cuda.is_available() and torch.cuda.device_count() < world:
+    raise ValueError('--gpus %d but only %d GPU(s) are visible' % (world, torch.cuda.device_count()))
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  import torch.multiprocessing as mp
+  mp.spawn(_spawned_rank, args=(args, world, port), nprocs=world, join=True)
+
+
 def absl_booleans(ap: argparse.ArgumentParser, argv: Sequence[str]) -> List[str]:
   """absl's `--noflag` spelling of `--flag=false` (scripts/run_deepvariant.py passes
   `--norealign_reads`), for the flags that are boolean here."""
@@ -464,7 +572,11 @@ def main(argv=None) -> int:
   args = ap.parse_args(argv)
   try:
     apply_flags_for_calling(ap, args, argv)
-    make_examples_runner(args)
+    if args.gpus > 1:
+      check_flags(args)
+      run_multi_gpu(args)
+    else:
+      make_examples_runner(args)
   except (ValueError, KeyError, IOError, OSError) as e:
     print('make_examples: %s' % e, file=sys.stderr)
     return 1

@@ -53,3 +53,38 @@ def test_shards_and_all_gather_world2():
     for i, v in zip(ids, p0):
       assert abs(v - (i % 7) / 10.0) < 1e-6
   assert results[0][2] == results[1][2]
+
+
+def _records_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from deepvariant_amd import dist as dvd
+  if rank == 0:
+    mine = [bytes([i % 251]) * (1 + (7 * i) % 300) for i in range(57)] + [b'']
+  else:
+    mine = [b'rank1-%d' % i for i in range(3)]
+  got = dvd.gather_records(mine, max_chunk_bytes=1000)      # several payload chunks
+  empty = dvd.gather_records([])                            # nobody has anything
+  q.put((rank, got, empty))
+  dist.destroy_process_group()
+
+
+def test_gather_records_world2():
+  """Variable-length records, uneven counts, an empty record, chunked payload."""
+  world = 2
+  port = _free_port()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_records_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = sorted(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  want0 = [bytes([i % 251]) * (1 + (7 * i) % 300) for i in range(57)] + [b'']
+  want1 = [b'rank1-%d' % i for i in range(3)]
+  for _, got, empty in results:
+    assert got == [want0, want1]
+    assert empty == [[], []]
