@@ -354,7 +354,9 @@ def region_inputs_from_batch(batch: packing.PackedBatch, options):
   t = batch.table
   table = packing.ReadTable(**{f.name: getattr(t, f.name) for f in
                                __import__('dataclasses').fields(packing.ReadTable)})
-  table.keys = ['r%d/0' % i for i in range(t.n_reads)]
+  # names whose tuple<string, int> order (the reference's row tie-break, pileup_image_native.cc:75-102)
+  # IS the table's read_name_rank, so the proto-shaped form and the packed form describe one workload
+  table.keys = ['r%09d/0' % int(rank) for rank in t.read_name_rank]
   starts = np.asarray(batch.item_variant_start)
   off = np.asarray(batch.item_list_off)
   lr, lc = np.asarray(batch.list_read), np.asarray(batch.list_code)
