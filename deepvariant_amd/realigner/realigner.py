@@ -20,6 +20,8 @@ import dataclasses
 import os
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
+
 from deepvariant_amd import alt_aligned_pileup_lib
 from deepvariant_amd import dv_types as T
 from deepvariant_amd import fast_pass_aligner
@@ -167,16 +169,23 @@ def realigner_config(**overrides) -> RealignerOptions:
 
 
 class AssemblyRegion:
-  """A window with its candidate haplotypes and the reads assigned to it (:538-593)."""
+  """One assembled window: its candidate haplotypes and the reads assigned to it.  Same public
+  surface as the reference's class (deepvariant/realigner/realigner.py:538-593: `region`,
+  `haplotypes`, `reads`, `read_span`, `add_read`); the span of the assigned reads is kept as a
+  running [lowest start, highest end) instead of being recomputed from the read list."""
+
+  __slots__ = ('candidate_haplotypes', 'reads', '_lo', '_hi')
 
   def __init__(self, candidate_haplotypes: CandidateHaplotypes):
     self.candidate_haplotypes = candidate_haplotypes
     self.reads: List = []
-    self._read_span: Optional[T.Range] = None
+    self._lo: Optional[int] = None
+    self._hi: Optional[int] = None
 
   def __str__(self):
+    span = self.read_span
     return 'AssemblyRegion(region={}, span={}) with {} haplotypes and {} reads'.format(
-        self.region, self.read_span, len(self.haplotypes), len(self.reads))
+        self.region, span, len(self.haplotypes), len(self.reads))
 
   @property
   def haplotypes(self) -> List[str]:
@@ -188,77 +197,100 @@ class AssemblyRegion:
 
   @property
   def read_span(self) -> Optional[T.Range]:
-    if self._read_span is None and self.reads:
-      spans = [utils.read_range(r) for r in self.reads]
-      self._read_span = utils.make_range(spans[0].reference_name, min(s.start for s in spans),
-                                         max(s.end for s in spans))
-    return self._read_span
+    if self._lo is None:
+      return None
+    return utils.make_range(self.region.reference_name, self._lo, self._hi)
 
-  def add_read(self, read):
+  def _cover(self, start: int, end: int) -> None:
+    self._lo = start if self._lo is None else min(self._lo, start)
+    self._hi = end if self._hi is None else max(self._hi, end)
+
+  def add_read(self, read) -> None:
+    span = utils.read_range(read)
     self.reads.append(read)
-    self._read_span = None
+    self._cover(span.start, span.end)
+
+  def add_reads(self, reads: Sequence, starts, ends) -> None:
+    """Bulk form for reads whose alignment spans are already known (parallel arrays)."""
+    if len(reads):
+      self.reads.extend(reads)
+      self._cover(int(min(starts)), int(max(ends)))
+
+
+def _read_spans(reads: Sequence):
+  """(contig per read, starts int64, ends int64): ReadRange of every read, as arrays."""
+  spans = [utils.read_range(r) for r in reads]
+  return ([sp.reference_name for sp in spans], np.array([sp.start for sp in spans], np.int64),
+          np.array([sp.end for sp in spans], np.int64))
 
 
 def assign_reads_to_assembled_regions(assembled_regions: Sequence[AssemblyRegion], reads: Sequence) -> List:
-  """Every read goes to the region it overlaps most (ties: the first); returns the reads that
-  overlap none (:596-619)."""
-  regions = [ar.region for ar in assembled_regions]
-  unassigned = []
-  for read in reads:
-    i = utils.find_max_overlapping(utils.read_range(read), regions)
-    if i is not None:
-      assembled_regions[i].add_read(read)
-    else:
-      unassigned.append(read)
-  return unassigned
-
-
-def _new_part(read, part: int) -> T.Read:
-  """copy_read (:622-639): everything but the alignment payload, renamed `<name>_p<part>`."""
-  p = read.alignment.position
-  return T.Read(
-      fragment_name='%s_p%d' % (read.fragment_name, part), read_number=read.read_number,
-      number_reads=read.number_reads, fragment_length=read.fragment_length,
-      proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
-      failed_vendor_quality_checks=read.failed_vendor_quality_checks,
-      secondary_alignment=read.secondary_alignment, supplementary_alignment=read.supplementary_alignment,
-      aligned_sequence='', aligned_quality=[],
-      alignment=T.LinearAlignment(position=T.Position(p.reference_name, 0, p.reverse_strand),
-                                  mapping_quality=read.alignment.mapping_quality, cigar=[]),
-      info=dict(read.info), base_modifications=dict(read.base_modifications))
+  """Every read joins the window it shares most bases with -- the first such window on ties --
+  and the reads that touch no window are returned (the reference's rule,
+  deepvariant/realigner/realigner.py:596-619, evaluated for all reads x windows at once)."""
+  reads = list(reads)
+  if not reads:
+    return []
+  if not assembled_regions:
+    return reads
+  contigs, starts, ends = _read_spans(reads)
+  w_lo = np.array([ar.region.start for ar in assembled_regions], np.int64)
+  w_hi = np.array([ar.region.end for ar in assembled_regions], np.int64)
+  shared = np.minimum(ends[:, None], w_hi[None, :]) - np.maximum(starts[:, None], w_lo[None, :])
+  same_contig = np.array([[c == ar.region.reference_name for ar in assembled_regions] for c in contigs])
+  shared = np.where(same_contig, np.maximum(shared, 0), 0)
+  best = shared.argmax(axis=1)                    # argmax returns the FIRST maximum
+  claimed = shared[np.arange(len(reads)), best] > 0
+  for w, ar in enumerate(assembled_regions):
+    mine = np.nonzero(claimed & (best == w))[0]
+    ar.add_reads([reads[i] for i in mine], starts[mine], ends[mine])
+  return [reads[i] for i in np.nonzero(~claimed)[0]]
 
 
 def split_reads(reads: Sequence) -> List:
-  """Reads with SKIP (N) operations are cut there into parts; parts shorter than 15 bases are
-  dropped (:642-672)."""
+  """Spliced reads (CIGAR `N`) become one read per exon: the operations between two skips, the
+  bases and qualities they consume, the position where the part's first reference-consuming
+  operation starts, the name `<name>_p<k>` (k counts the parts, dropped ones included).  Parts
+  of fewer than 15 bases are dropped; reads without a skip pass through untouched.  Behaviour
+  of deepvariant/realigner/realigner.py:622-672, computed from the read's operation arrays."""
   out = []
   for read in reads:
-    cigar = read.alignment.cigar
-    if not any(c.operation == utils.SKIP for c in cigar):
+    ops = np.array([c.operation for c in read.alignment.cigar], np.int64)
+    if not (ops == utils.SKIP).any():
       out.append(read)
       continue
-    part = 0
-    new_read = _new_part(read, part)
-    read_start = read_offset = reference_offset = 0
-    for n, c in enumerate(cigar):
-      last = n + 1 == len(cigar)
-      if c.operation in utils.REF_ADVANCING_OPS:
-        if not new_read.alignment.position.position:
-          new_read.alignment.position.position = read.alignment.position.position + reference_offset
-        reference_offset += c.operation_length
-      if c.operation in utils.READ_ADVANCING_OPS:
-        read_offset += c.operation_length
-      if c.operation != utils.SKIP:
-        new_read.alignment.cigar.append(T.CigarUnit(c.operation, c.operation_length))
-      if c.operation == utils.SKIP or last:
-        new_read.aligned_sequence = read.aligned_sequence[read_start:read_offset]
-        new_read.aligned_quality = read.aligned_quality[read_start:read_offset]
-        if len(new_read.aligned_sequence) >= _MIN_SPLIT_LEN:
-          out.append(new_read)
-        if not last:
-          read_start = read_offset
-          part += 1
-          new_read = _new_part(read, part)
+    lens = np.array([c.operation_length for c in read.alignment.cigar], np.int64)
+    on_read = np.isin(ops, list(utils.READ_ADVANCING_OPS))
+    on_ref = np.isin(ops, list(utils.REF_ADVANCING_OPS))
+    read_after = np.cumsum(np.where(on_read, lens, 0))          # bases consumed up to and including op i
+    ref_before = np.cumsum(np.where(on_ref, lens, 0)) - np.where(on_ref, lens, 0)
+    cuts = np.nonzero(ops == utils.SKIP)[0].tolist()
+    if cuts[-1] != len(ops) - 1:
+      cuts.append(len(ops))                      # the stretch after the last skip
+    first = 0                                    # first operation of the current part
+    for part, cut in enumerate(cuts):
+      body = np.arange(first, cut)               # operations of this part (the skip itself excluded)
+      seq_lo = int(read_after[first - 1]) if first > 0 else 0
+      seq_hi = int(read_after[cut - 1]) if cut > 0 else 0
+      if seq_hi - seq_lo >= _MIN_SPLIT_LEN:
+        # the reference assigns the position at the first reference-consuming operation, and again
+        # at the next one while the value is still 0 ("unset"): the first non-zero start, else 0
+        anchors = [int(read.alignment.position.position + ref_before[i]) for i in body if on_ref[i]]
+        position = next((a for a in anchors if a), 0)
+        src = read.alignment.position
+        out.append(T.Read(
+            fragment_name='%s_p%d' % (read.fragment_name, part), read_number=read.read_number,
+            number_reads=read.number_reads, fragment_length=read.fragment_length,
+            proper_placement=read.proper_placement, duplicate_fragment=read.duplicate_fragment,
+            failed_vendor_quality_checks=read.failed_vendor_quality_checks,
+            secondary_alignment=read.secondary_alignment, supplementary_alignment=read.supplementary_alignment,
+            aligned_sequence=read.aligned_sequence[seq_lo:seq_hi], aligned_quality=read.aligned_quality[seq_lo:seq_hi],
+            alignment=T.LinearAlignment(
+                position=T.Position(src.reference_name, position, src.reverse_strand),
+                mapping_quality=read.alignment.mapping_quality,
+                cigar=[T.CigarUnit(int(ops[i]), int(lens[i])) for i in body]),
+            info=dict(read.info), base_modifications=dict(read.base_modifications)))
+      first = cut + 1
   return out
 
 
