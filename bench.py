@@ -41,7 +41,7 @@ def parse_args():
                   help='candidate sites per step per GPU; ~5 % more pileups (multi-allelic '
                        'sites give 3) -- 7700 sites fill one 8192-example forward')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
-  ap.add_argument('--mode', choices=['resident', 'host', 'alleles'], default='resident',
+  ap.add_argument('--mode', choices=['resident', 'host', 'alleles', 'bam'], default='resident',
                   help="'resident' (default, the contract's metric): inputs already in HBM. "
                        "'host': host-inclusive -- every step packs the region's candidates and "
                        'reads natively (dv_pack_region), uploads them over PCIe and runs the GPU '
@@ -70,6 +70,11 @@ def algorithmic_bytes_per_item(batch, out_channels):
 
 def main():
   args = parse_args()
+  if args.mode == 'bam':
+    if args.gpus != 1:
+      raise SystemExit('--mode bam runs one host process on one GPU')
+    bam_mode(args)
+    return
   if 'WORLD_SIZE' in os.environ:       # launched by torch.distributed.run: one rank per process
     run_rank(args, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
              int(os.environ['WORLD_SIZE']))
@@ -242,7 +247,7 @@ def run_rank(args, rank, local_rank, world):
     bytes_per_item = algorithmic_bytes_per_item(host_batch, C)
     enc_gbs = (bytes_per_item * n_items * args.steps / (enc_ms * 1e-3) / 1e9
                if enc_ms > 0 else 0.0)
-    conv_traffic, enc_traffic, traffic_note = pmc_traffic(n_items)
+    conv_traffic, enc_traffic, traffic_note = pmc_traffic(args, n_items) if world == 1 else (None, None, None)
     out = {
         'metric': 'candidate pileups/sec (encode+CNN)',
         'value': value,
@@ -267,8 +272,8 @@ def run_rank(args, rank, local_rank, world):
             'collective_backend': (dist.get_backend() if world > 1 else None),
         },
         'roofline': {
-            'kernel': 'conv kernels: stem_a/stem_b (fused stem), imgconv_kernel, '
-                      'conv_mfma_kernel<NB,PT>, conv_resident_kernel (all 94 conv layers)',
+            'kernel': 'conv kernels: stem_a/stem_b (fused stem), chain_kernel (fused 1x7/7x1 chains), '
+                      'imgconv_kernel, conv_mfma_kernel<NB,PT>, conv_resident_kernel (all 94 conv layers)',
             'bound': 'mfma',
             'achieved': conv_tflops,
             'peak': MFMA_F16_PEAK_TFLOPS,
@@ -435,6 +440,76 @@ def allele_counting(args, host_batch, dev):
   }))
 
 
+def bam_mode(args, log=sys.stderr):
+  """BASELINE.json configs[0] end to end on FILES: the reference tree's NA12878 30x Illumina slice
+  chr20:10,000,000-10,100,000 (BAM + .bai + FASTA, bundled by tests/golden/make_golden.py
+  na12878_100kb) -> make_examples' fused route -> CallVariantsOutput TFRecord, one host process,
+  one GPU.  Prints its own JSON line (examples/s with per-stage milliseconds and the host's core
+  count); never the contract's `value`, whose inputs are resident in HBM."""
+  import tempfile
+  from deepvariant_amd import genomics_io, make_examples as me, tfrecord
+  fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'na12878_100kb.npz')
+  stage = {}
+
+  def timed(label, fn):
+    def wrapper(*a, **k):
+      t0 = time.perf_counter()
+      try:
+        return fn(*a, **k)
+      finally:
+        stage[label] = stage.get(label, 0.0) + time.perf_counter() - t0
+    return wrapper
+
+  class Hooks(me.RunnerHooks):
+    def make_processor(self, options, ref_reader, po, device):
+      proc = super().make_processor(options, ref_reader, po, device)
+      proc.realign_reads = timed('realign (window selection on the device, assembly, alignment)', proc.realign_reads)
+      proc.candidates_in_region = timed('allele counts (device) + candidate caller', proc.candidates_in_region)
+      proc.generator.call_variants_in_region = timed(
+          'pack + encode + classify (device) + CallVariantsOutput protos', proc.generator.call_variants_in_region)
+      return proc
+
+  with tempfile.TemporaryDirectory() as tmp:
+    with np.load(fixture) as z:
+      bam = os.path.join(tmp, 'NA12878_S1.chr20.10_10p1mb.bam')
+      with open(bam, 'wb') as f:
+        f.write(z['bam'].tobytes())
+      with open(bam + '.bai', 'wb') as f:
+        f.write(z['bai'].tobytes())
+      fasta = os.path.join(tmp, 'ref.fa')
+      lo = int(z['ref_start'][0])
+      genomics_io.write_fasta(fasta, [('chr20', 'N' * lo + z['ref_bases'].tobytes().decode())])
+    me.RegionReads.__call__ = timed('BAM decode (native) + reads of the region', me.RegionReads.__call__)
+    tfrecord.Writer.write = timed('TFRecord(GZIP) write', tfrecord.Writer.write)
+    common = ['--ref', fasta, '--reads', bam, '--checkpoint', 'random:1234', '--sample_name', 'NA12878',
+              '--channel_list', 'BASE_CHANNELS,insert_size']
+    warm = me.build_arg_parser().parse_args(common + [
+        '--regions', 'chr20:10,000,000-10,003,000', '--call_variants_outfile', os.path.join(tmp, 'warm.cvo.tfrecord.gz')])
+    me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=Hooks())     # kernels loaded, graphs captured
+    stage.clear()
+    timed_args = me.build_arg_parser().parse_args(common + [
+        '--regions', 'chr20:10,000,000-10,100,000', '--call_variants_outfile', os.path.join(tmp, 'cvo.tfrecord.gz')])
+    t0 = time.perf_counter()
+    stats = me.make_examples_runner(timed_args, log=open(os.devnull, 'w'), hooks=Hooks())
+    elapsed = time.perf_counter() - t0
+    n_written = sum(1 for _ in tfrecord.read_tfrecords(os.path.join(tmp, 'cvo.tfrecord.gz')))
+  assert n_written == stats['n_examples']
+  print(json.dumps({
+      'metric': 'examples/sec, BAM + FASTA -> CallVariantsOutput (make_examples fused route), one host process',
+      'value': stats['n_examples'] / elapsed,
+      'unit': 'examples/s',
+      'n_gpus': 1,
+      'data': 'BASELINE.json configs[0]: NA12878 30x Illumina, chr20:10,000,000-10,100,000 (reference testdata, bundled)',
+      'wall_s': elapsed,
+      'regions': stats['n_regions'], 'reads': stats['n_reads'], 'candidates': stats['n_candidates'],
+      'examples': stats['n_examples'],
+      'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
+      'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
+      'host_cores': os.cpu_count(),
+      'note': 'not the contract metric: inputs start in files on the host, one Python process drives the region loop',
+  }))
+
+
 def parity_sample(region, opts, C, model, images, probs, n=512):
   """`n` SITES strided across the whole TIMED batch against the oracle, after the timed region.
 
@@ -505,10 +580,69 @@ def parity_sample(region, opts, C, model, images, probs, n=512):
   }
 
 
-def pmc_traffic(n_items):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-  gfx950 x2 correction + WRITE_SIZE; profiles/r02_pmc_hbm_traffic.txt).  bench.py cannot
-  run the counter passes itself, so this is only reported for the batch they were taken at."""
+CONV_KERNELS = ('conv_mfma_kernel', 'conv_resident_kernel', 'conv_pool1x1_kernel', 'conv_first_u8_kernel',
+                'stem_a_kernel', 'stem_b_kernel', 'imgconv_kernel', 'chain_kernel')
+
+
+def _pmc_pass(counter, args, timeout_s=300):
+  """One `rocprofv3 --kernel-trace --pmc <counter>` pass over a short run of THIS bench (child
+  process, 3 forward passes) -> {kernel name: (launches, bytes)}, forward passes.  Counters are in
+  KB (MI355X_MICROARCH.md, HBM section)."""
+  import glob
+  import shutil
+  import sqlite3
+  import subprocess
+  import tempfile
+  out = tempfile.mkdtemp(prefix='dvbench_pmc_', dir='/tmp')
+  try:
+    env = dict(os.environ, TMPDIR='/tmp', DV_BENCH_NO_PMC='1')
+    cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '--', sys.executable,
+           os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
+           '--batch', str(args.batch), '--channels', str(args.channels)]
+    subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dbs = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    suf = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like "
+                                     "'rocpd_kernel_dispatch%'")][0].replace('rocpd_kernel_dispatch', '')
+    rows = cur.execute(
+        f'select k.kernel_name, p.value, d.id from rocpd_pmc_event{suf} p '
+        f'join rocpd_info_pmc{suf} i on p.pmc_id=i.id '
+        f'join rocpd_kernel_dispatch{suf} d on p.event_id=d.event_id '
+        f'join rocpd_info_kernel_symbol{suf} k on d.kernel_id=k.id where i.name=?', (counter,))
+    agg = {}
+    for name, value, did in rows:
+      ids, total = agg.setdefault(name, (set(), [0.0]))
+      ids.add(did)
+      total[0] += value * 1024.0
+    return {k: (len(ids), total[0]) for k, (ids, total) in agg.items()}
+  finally:
+    shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_traffic(args, n_items):
+  """HBM bytes per launch of the conv kernels and of the encoder: FETCH_SIZE (doubled: gfx950
+  tallies a 128-byte request as 64 bytes) + WRITE_SIZE, measured IN THIS RUN by two separate
+  rocprofv3 --pmc passes over a short child run of this bench (same kernels, same batch), as the
+  guide's HBM section prescribes.  Falls back to the committed passes of round 2 (stale for kernels
+  changed since) when rocprofv3 is not on PATH or a pass fails; DV_BENCH_NO_PMC skips both."""
+  import shutil
+  if os.environ.get('DV_BENCH_NO_PMC') is None and shutil.which('rocprofv3') is not None:
+    try:
+      fetch = _pmc_pass('FETCH_SIZE', args)
+      write = _pmc_pass('WRITE_SIZE', args)
+      enc = [k for k in fetch if 'encode_items_kernel' in k][0]
+      passes = fetch[enc][0]
+      conv = [k for k in fetch if any(c in k for c in CONV_KERNELS)]
+      launches = sum(fetch[k][0] for k in conv)
+      conv_bytes = (2.0 * sum(fetch[k][1] for k in conv) + sum(write[k][1] for k in conv if k in write)) / launches
+      enc_bytes = (2.0 * fetch[enc][1] + write[enc][1]) / passes
+      return conv_bytes, enc_bytes, (
+          'bytes per launch measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2, gfx950) and '
+          '--pmc WRITE_SIZE, separate passes over a child run of %d forward passes, %d conv launches each' % (
+              passes, launches // max(passes, 1)))
+    except Exception as e:     # pylint: disable=broad-except
+      sys.stderr.write('bench: counter passes failed (%s: %s); using the committed ones\n' % (type(e).__name__, e))
   path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                       'r02_pmc_traffic.json')
   try:
@@ -521,7 +655,7 @@ def pmc_traffic(n_items):
   c, e = t['conv'], t['encoder']
   conv = (c['fetch_bytes_per_pass_x2'] + c['write_bytes_per_pass']) / c['launches_per_pass']
   enc = e['fetch_bytes_per_launch_x2'] + e['write_bytes_per_launch']
-  return conv, enc, 'bytes per launch, separate rocprofv3 --pmc passes: ' + t['source']
+  return conv, enc, 'STALE (round-2 kernels) bytes per launch, separate rocprofv3 --pmc passes: ' + t['source']
 
 
 def cpu_baseline(host_batch, opts, C, sample):

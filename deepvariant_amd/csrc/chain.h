@@ -10,33 +10,33 @@
 namespace dv {
 
 constexpr int kChainMaxLayers = 4;
-constexpr int kChainTilePx = 192;   // pixels of one tile (6 MFMA fragments), padded
-constexpr int kChainMaxTaps = 7;
+constexpr int kChainTilePx = 192;    // small maps (<= 96 pixels): G whole maps in 6 MFMA fragments, 1-D filters
+constexpr int kChainTilePxBig = 256; // maps of up to 256 pixels (the 35x35 stage): 8 fragments, 3x3 / 5x5 filters
+constexpr int kChainMaxTaps = 7;     // of a one-dimensional filter
 
 struct ChainLayer {
   const _Float16* w;      // packed [chunk][tap][2 k-groups][cout_pad][8]
   const float* shift;     // folded BatchNorm shift, readable up to cout_pad
   int n_chunks;           // Cin / 16
   int cout, cout_pad;     // cout_pad: multiple of 32
-  int taps;               // filter length (odd)
-  int horizontal;         // 1: 1 x taps, 0: taps x 1
-  unsigned slab_bytes;    // one chunk of weights: taps * 2 * cout_pad * 16
+  int kh, kw;             // filter (odd sizes, stride 1, 'same' padding): 1 x k / k x 1 (k <= 7), 3 x 3, 5 x 5
+  unsigned slab_bytes;    // one chunk of weights: kh * kw * 2 * cout_pad * 16
 };
 
 struct ChainArgs {
   const _Float16* in;     // C8 tensor the first layer reads
   convk::TensorGeom ig;
   unsigned in_img_bytes;  // bytes of one example of `in`
-  int N, G, h, w;         // G whole images of h x w pixels per tile (G*h*w <= kChainTilePx)
+  int N, G, h, w;         // G whole images of h x w pixels per tile (G*h*w <= tpx)
+  int tpx;                // kChainTilePx or kChainTilePxBig
   int n_tiles;            // ceil(N / G); the last tile is shifted back to end at image N
   int n_layers;
   ChainLayer L[kChainMaxLayers];
   _Float16* out;          // the last layer's destination (a concat buffer)
   convk::TensorGeom og;
   int out_goff;           // first destination channel group
-  unsigned act_bytes;     // LDS: activation tile [channel group][kChainTilePx][8]
+  unsigned act_bytes;     // LDS: activation tile [channel group][tpx][8]
   unsigned slot_bytes;    // LDS: one weight-slab slot (two of them follow the activations)
-  int dma_loader;         // tuning (DV_CHAIN_DMA): move data by LDS-DMA instead of through registers
   // tuning aid (DV_CHAIN_PROF, eager launches): shader-clock sums [block][computing wave][8] =
   // wait at the chunk barriers, MFMA steps, wait at the layer barrier, LDS epilogue, HBM epilogue, set-up
   unsigned long long* prof;

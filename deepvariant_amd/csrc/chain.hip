@@ -21,11 +21,16 @@
 //     channels: 28-43 KB) and the next tile's input, by LDS-DMA (buffer_load ... lds) -- and
 //     meet the computing waves at one s_barrier per chunk.  The computing waves never wait on
 //     a vector-memory counter except for their own output stores.
+// Two tile shapes: the 17x17 stage's small maps (<= 96 pixels: G whole maps in a 192-pixel tile,
+// waves = 2 pixel halves x 2 cout halves, 1 x k / k x 1 filters) and the 35x35 stage's maps (up to
+// 256 pixels: one or two maps in a 256-pixel tile, waves = 4 pixel quarters x all <= 96 couts,
+// 3x3 / 5x5 filters: the 3x3 -> 3x3 branch of mixed0..2 and the 5x5 layers).
 // The K order (channel chunk major, tap minor), the fp32 accumulation, the fp16 rounding of
 // every intermediate and the shift + ReLU are those of the per-layer kernels (model.hip), and
 // skipped taps only ever multiply zeros: results are bit-identical to the per-layer path
 // (tests/test_hip_chain.py).
 #include <cstdlib>
+#include <type_traits>
 
 #include "chain.h"
 
@@ -35,9 +40,6 @@ namespace {
 using namespace convk;
 
 constexpr int CH_THREADS = 512;
-constexpr int CH_PT = 3;                 // pixel fragments per computing wave
-constexpr int CH_TPX = kChainTilePx;     // 192
-constexpr unsigned CH_CHUNK_LDS = 2 * CH_TPX * 16;   // bytes of one 16-channel chunk of the tile
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -68,24 +70,42 @@ __device__ __forceinline__ constexpr bool chain_tile(int nb, int pt) {
 
 // One 16-channel chunk: NT filter taps x the wave's MFMA tiles.  The fragments of tap i + 1 are
 // requested between the MFMAs of tap i (two static register sets, one request per MFMA slot).
-template <int NB, int NT, int SKIP>
+// PRE: the first tap's pixel fragments were requested by the caller BEFORE the chunk barrier (the
+// activation tile does not change inside a layer; only the weight slab waits for the barrier).
+// KW: 0 = one-dimensional filter, tap i sits i * b_tap_stride bytes from the first (b_tap_stride =
+// one pixel or one tile row); > 0 = KW-wide two-dimensional filter, tap i = (i / KW) tile rows
+// (b_tap_stride bytes each) + (i % KW) pixels.
+template <int NB, int PT, int NT, int KW, int SKIP, bool PRE>
 __device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, unsigned a_tap_stride,
-                                           const unsigned (&b_addr)[CH_PT], unsigned b_tap_stride,
-                                           const unsigned (&mask)[CH_PT], unsigned zero_addr,
-                                           float16_t (&acc)[NB][CH_PT]) {
-  half8_t A[2][NB], B[2][CH_PT];
-  auto load = [&](int i, int s) {
+                                           const unsigned (&b_addr)[PT], unsigned b_tap_stride,
+                                           const unsigned (&mask)[PT], unsigned zero_addr,
+                                           const half8_t (&b_pre)[PT], float16_t (&acc)[NB][PT]) {
+  half8_t A[2][NB], B[2][PT];
+  auto load_a = [&](int i, int s) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       A[s][nb] = *reinterpret_cast<const half8_t*>(smem + a_addr + i * a_tap_stride + nb * 512);
     }
+  };
+  auto load_b = [&](int i, int s) {
+    const unsigned off = KW == 0 ? i * b_tap_stride : (i / (KW ? KW : 1)) * b_tap_stride + (i % (KW ? KW : 1)) * 16u;
 #pragma unroll
-    for (int pt = 0; pt < CH_PT; ++pt) {
-      const unsigned ad = (mask[pt] >> i) & 1u ? b_addr[pt] + i * b_tap_stride : zero_addr;
+    for (int pt = 0; pt < PT; ++pt) {
+      const unsigned ad = (mask[pt] >> i) & 1u ? b_addr[pt] + off : zero_addr;
       B[s][pt] = *reinterpret_cast<const half8_t*>(smem + ad);
     }
   };
-  load(0, 0);
+  auto load = [&](int i, int s) {
+    load_a(i, s);
+    load_b(i, s);
+  };
+  load_a(0, 0);
+  if (PRE) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) B[0][pt] = b_pre[pt];
+  } else {
+    load_b(0, 0);
+  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -93,17 +113,17 @@ __device__ __forceinline__ void chain_step(const char* smem, unsigned a_addr, un
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         if (chain_tile<SKIP>(nb, pt)) {
           acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i & 1][nb], B[i & 1][pt], acc[nb][pt], 0, 0, 0);
         }
       }
     }
     if (i + 1 < NT) {
-      // the next tap's NB + 3 requests (and their address selects) ride in the issue slots
+      // the next tap's NB + PT requests (and their address selects) ride in the issue slots
       // between this tap's MFMAs, one request per MFMA, instead of in a gap after them
 #pragma unroll
-      for (int k = 0; k < NB + CH_PT; ++k) {
+      for (int k = 0; k < NB + PT; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);     // MFMA
         __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);     // VALU
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
@@ -142,12 +162,14 @@ __device__ __forceinline__ void chain_pieces(const float16_t& a, const float4_t 
 }
 
 // ------------------------------------------------------------------ computing waves (0-3)
-// wave = (pixel half ph, cout half ch): fragments 3 ph .. 3 ph + 2 of the tile, the first /
-// second half of the layer's 32-cout subtiles (8 + 7 tiles for five subtiles, chain_tile).
+// PT = 3 (192-pixel tiles): wave = (pixel half ph, cout half ch): fragments 3 ph .. 3 ph + 2, the
+//   first / second half of the layer's 32-cout subtiles (8 + 7 tiles for five subtiles, chain_tile).
+// PT = 2 (256-pixel tiles): wave = pixel quarter: fragments 2 wave, 2 wave + 1, every subtile (<= 3).
+template <int PT>
 struct ChainLane {
-  int prow[CH_PT], pcol[CH_PT], pimg[CH_PT];
-  bool pval[CH_PT];
-  unsigned act_lane[CH_PT], px_piece[CH_PT];
+  int prow[PT], pcol[PT], pimg[PT];
+  bool pval[PT];
+  unsigned act_lane[PT], px_piece[PT];
   int l31, hi;
 };
 
@@ -157,41 +179,66 @@ struct ChainProf {
 };
 __device__ __forceinline__ unsigned long long chain_clock() { return __builtin_amdgcn_s_memtime(); }
 
-// One layer on one tile for one computing wave: NB cout subtiles x 3 pixel fragments (minus
+// One layer on one tile for one computing wave: NB cout subtiles x PT pixel fragments (minus
 // SKIP), NT taps per chunk.  The accumulators are local to this instantiation (a switch over tap
 // counts around a shared accumulator array made the register allocator spill).
-template <int NB, int NT, int SKIP, bool PROF>
+template <int NB, int PT, int NT, int KW, int SKIP, bool PROF>
 __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainLayer& L, bool last, char* smem,
-                                                const ChainLane& c, int sub_base, int t_lo, unsigned m0,
-                                                unsigned m1, unsigned m2, int n0, unsigned step, ChainProf& prof) {
+                                                const ChainLane<PT>& c, int sub_base, int t_lo,
+                                                const unsigned (&m_in)[PT], int n0, unsigned step, ChainProf& prof) {
   // everything the chunk loop needs sits in registers before it starts: the barriers are asm
   // statements with a memory clobber, anything still in memory would be re-read after each
-  const unsigned m[CH_PT] = {m0, m1, m2};
-  const int pad = (L.taps - 1) >> 1;
+  unsigned m[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) m[pt] = m_in[pt];
   const int Gw = p.G * p.w;
   const int n_chunks = L.n_chunks;
   const unsigned ring0 = p.act_bytes, slot_bytes = p.slot_bytes;
   const unsigned zero_addr = p.act_bytes + 2 * p.slot_bytes;
-  const unsigned b_tap_stride = static_cast<unsigned>(L.horizontal ? 16 : Gw * 16);
+  const unsigned chunk_lds = static_cast<unsigned>(2 * p.tpx * 16);      // one 16-channel chunk of the tile
+  const unsigned group_lds = static_cast<unsigned>(p.tpx * 16);
   const unsigned a_tap_stride = static_cast<unsigned>(2 * L.cout_pad * 16);
-  unsigned b0[CH_PT];
-#pragma unroll
-  for (int pt = 0; pt < CH_PT; ++pt) {
-    b0[pt] = c.act_lane[pt] + static_cast<unsigned>(t_lo - pad) * b_tap_stride;
+  // first tap of the walk relative to the output pixel, and the stride between taps (chain_step)
+  unsigned b_tap_stride, first_off;
+  if (KW == 0) {
+    const int pad = (L.kh * L.kw - 1) >> 1;
+    b_tap_stride = static_cast<unsigned>(L.kw > 1 ? 16 : Gw * 16);
+    first_off = static_cast<unsigned>(t_lo - pad) * b_tap_stride;
+  } else {
+    b_tap_stride = static_cast<unsigned>(Gw * 16);
+    first_off = static_cast<unsigned>(-(((L.kh - 1) >> 1) * Gw + ((L.kw - 1) >> 1)) * 16);
   }
+  unsigned b0[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) b0[pt] = c.act_lane[pt] + first_off;
   const unsigned a_lane = static_cast<unsigned>((c.hi * L.cout_pad + sub_base * 32 + c.l31) * 16) +
                           static_cast<unsigned>(t_lo) * a_tap_stride;
-  float16_t acc[NB][CH_PT];
+  float16_t acc[NB][PT];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int pt = 0; pt < CH_PT; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
 
   unsigned long long t0 = 0;
   if (PROF) t0 = chain_clock();
-  for (int cc = 0; cc < n_chunks; ++cc, ++step) {
+  // one chunk; PRE: tap 0's pixel fragments travel while the wave waits at the barrier (not for a
+  // layer's first chunk: its barrier is what makes the previous layer's output visible).  The
+  // first chunk is peeled off the loop -- a branch on `cc` around two instantiations inside the
+  // loop made the register allocator spill the accumulators.
+  auto chunk = [&](int cc, auto pre_tag) {
+    constexpr bool PRE = decltype(pre_tag)::value;
+    unsigned b_addr[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) b_addr[pt] = b0[pt] + static_cast<unsigned>(cc) * chunk_lds;
+    half8_t b_pre[PT];
+    if (PRE) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        b_pre[pt] = *reinterpret_cast<const half8_t*>(smem + (m[pt] & 1u ? b_addr[pt] : zero_addr));
+      }
+    }
     barrier_after_lds();   // B(l, cc): this chunk's weight slab (and, first chunk, the tile) landed
     if (PROF) {
       const unsigned long long t = chain_clock();
@@ -199,17 +246,17 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
       t0 = t;
     }
     const unsigned a_addr = ring0 + (step & 1u) * slot_bytes + a_lane;
-    unsigned b_addr[CH_PT];
-#pragma unroll
-    for (int pt = 0; pt < CH_PT; ++pt) b_addr[pt] = b0[pt] + static_cast<unsigned>(cc) * CH_CHUNK_LDS;
-    chain_step<NB, NT, SKIP>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, acc);
+    chain_step<NB, PT, NT, KW, SKIP, PRE>(smem, a_addr, a_tap_stride, b_addr, b_tap_stride, m, zero_addr, b_pre, acc);
     if (PROF) {
       asm volatile("" : "+v"(acc[NB - 1][0]));   // the step's MFMAs are issued before the clock is read
       const unsigned long long t = chain_clock();
       prof.mfma += t - t0;
       t0 = t;
     }
-  }
+    ++step;
+  };
+  chunk(0, std::false_type{});
+  for (int cc = 1; cc < n_chunks; ++cc) chunk(cc, std::true_type{});
   // the folded BatchNorm shifts of this wave's couts: requested now, in flight across the barrier
   float4_t sh[NB][4];
   {
@@ -232,7 +279,7 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     for (int nb = 0; nb < NB; ++nb) {
       const int cbase = (sub_base + nb) * 32;
 #pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         if (!chain_tile<SKIP>(nb, pt)) continue;
         uint4_t piece[2];
         chain_pieces(acc[nb][pt], sh[nb], piece);
@@ -240,8 +287,7 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
         for (int t = 0; t < 2; ++t) {
           const int group = cbase / 8 + 2 * t + c.hi;
           if (group * 8 < cout) {
-            *reinterpret_cast<uint4_t*>(smem + static_cast<unsigned>(group) * (CH_TPX * 16) + c.px_piece[pt]) =
-                piece[t];
+            *reinterpret_cast<uint4_t*>(smem + static_cast<unsigned>(group) * group_lds + c.px_piece[pt]) = piece[t];
           }
         }
       }
@@ -250,10 +296,10 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     // the last layer goes to HBM, straight into the block's concat buffer
     const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
     uint4_t* outp = reinterpret_cast<uint4_t*>(p.out);
-    unsigned obase[CH_PT];
-    bool ok[CH_PT];
+    unsigned obase[PT];
+    bool ok[PT];
 #pragma unroll
-    for (int pt = 0; pt < CH_PT; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
       const int n = n0 + c.pimg[pt];
       ok[pt] = c.pval[pt] && n < p.N;
       obase[pt] = static_cast<unsigned>(((n * p.og.groups + p.out_goff) * p.og.hp + c.prow[pt] + p.og.halo) * p.og.wp +
@@ -263,7 +309,7 @@ __device__ __forceinline__ unsigned chain_layer(const ChainArgs& p, const ChainL
     for (int nb = 0; nb < NB; ++nb) {
       const int cbase = (sub_base + nb) * 32;
 #pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         if (!chain_tile<SKIP>(nb, pt)) continue;
         uint4_t piece[2];
         chain_pieces(acc[nb][pt], sh[nb], piece);
@@ -291,24 +337,38 @@ __device__ __forceinline__ unsigned chain_layer_idle(const ChainLayer& L, unsign
   return step;
 }
 
-// Taps of a 1-D filter that meet the map for a pixel at `pos` of `lim`: t + pos - pad in [0, lim).
-__device__ __forceinline__ unsigned chain_tap_mask(int pos, int lim, int taps, int pad, bool valid) {
+// Positions t of a `taps`-long filter axis that meet the map for a pixel at `pos` of `lim`:
+// t + pos - pad in [0, lim).
+__device__ __forceinline__ unsigned chain_axis_mask(int pos, int lim, int taps, int pad) {
   const int lo = max(0, pad - pos), hi = min(taps - 1, lim - 1 + pad - pos);
-  return valid && hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+  return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
 }
 
-template <bool PROF>
+// Taps (row-major kh x kw) of the filter that meet the map for the pixel at (row, col).
+__device__ __forceinline__ unsigned chain_tap_mask(const ChainArgs& p, const ChainLayer& L, int row, int col, bool valid) {
+  if (!valid) return 0u;
+  const unsigned rows = chain_axis_mask(row, p.h, L.kh, (L.kh - 1) >> 1);
+  const unsigned cols = chain_axis_mask(col, p.w, L.kw, (L.kw - 1) >> 1);
+  unsigned m = 0;
+  for (int ty = 0; ty < L.kh; ++ty) {
+    if ((rows >> ty) & 1u) m |= cols << (ty * L.kw);
+  }
+  return m;
+}
+
+template <int PT, bool PROF>
 __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, int wave, int lane) {
   ChainProf prof;
   unsigned long long t_setup = 0;
-  const int ph = wave & 1, ch = wave >> 1;
-  ChainLane c;
+  // PT 3: two pixel halves x two cout halves; PT 2: four pixel quarters
+  const int ph = PT == 3 ? wave & 1 : wave, ch = PT == 3 ? wave >> 1 : 0;
+  ChainLane<PT> c;
   c.l31 = lane & 31;
   c.hi = lane >> 5;
   const int Gw = p.G * p.w, T = Gw * p.h;
 #pragma unroll
-  for (int pt = 0; pt < CH_PT; ++pt) {
-    const int px = (ph * CH_PT + pt) * 32 + c.l31;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int px = (ph * PT + pt) * 32 + c.l31;
     c.pval[pt] = px < T;
     const int q = c.pval[pt] ? px : 0;
     c.prow[pt] = q / Gw;
@@ -316,55 +376,63 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
     c.pimg[pt] = rem / p.w;
     c.pcol[pt] = rem - c.pimg[pt] * p.w;
     c.px_piece[pt] = static_cast<unsigned>(px) * 16u;
-    c.act_lane[pt] = static_cast<unsigned>(c.hi * CH_TPX + px) * 16u;
+    c.act_lane[pt] = static_cast<unsigned>(c.hi * p.tpx + px) * 16u;
   }
   const unsigned zero_addr = p.act_bytes + 2 * p.slot_bytes;
   if (wave == 0 && lane < 4) *reinterpret_cast<unsigned*>(smem + zero_addr + lane * 4) = 0u;
 
-  // Per layer, once per kernel: the taps the wave walks (the union of its lanes' taps: wave-wide
-  // ballots) and its share of the cout subtiles, packed t_lo | nt << 4 | nbw << 8 | skip << 12 |
-  // sub_base << 16.
+  // Per layer, once per kernel: the taps the wave walks (one-dimensional filters: the union of
+  // its lanes' taps, from wave-wide ballots; two-dimensional ones: all) and its share of the cout
+  // subtiles, packed t_lo | nt << 4 | nbw << 10 | skip << 14 | sub_base << 16.
   unsigned cfg[kChainMaxLayers];
 #pragma unroll
   for (int l = 0; l < kChainMaxLayers; ++l) {
     cfg[l] = 0;
     if (l < p.n_layers) {
       const ChainLayer& L = p.L[l];
-      const int pad = (L.taps - 1) >> 1;
-      unsigned any = 0;
+      const int taps = L.kh * L.kw;
+      int t_lo = 0, nt = taps;
+      if (L.kh == 1 || L.kw == 1) {
+        unsigned any = 0;
 #pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) {
-        any |= chain_tap_mask(L.horizontal ? c.pcol[pt] : c.prow[pt], L.horizontal ? p.w : p.h, L.taps, pad, c.pval[pt]);
-      }
-      unsigned wave_any = 0;
+        for (int pt = 0; pt < PT; ++pt) any |= chain_tap_mask(p, L, c.prow[pt], c.pcol[pt], c.pval[pt]);
+        unsigned wave_any = 0;
 #pragma unroll
-      for (int t = 0; t < kChainMaxTaps; ++t) {
-        if (__builtin_amdgcn_ballot_w64((any >> t) & 1u) != 0ull) wave_any |= 1u << t;
-      }
-      int t_lo = wave_any ? __builtin_ctz(wave_any) : 0;
-      int nt = wave_any ? 32 - __builtin_clz(wave_any) - t_lo : 0;
-      // compiled tap counts: 3, 5, 6, 7 -- a range in between is widened (the extra taps read
-      // zeros through the lane masks, which is exact)
-      while (nt != 0 && nt != 3 && nt != 5 && nt != 6 && nt != 7) {
-        if (t_lo + nt < L.taps) {
-          ++nt;
-        } else {
-          --t_lo;
-          ++nt;
+        for (int t = 0; t < kChainMaxTaps; ++t) {
+          if (__builtin_amdgcn_ballot_w64((any >> t) & 1u) != 0ull) wave_any |= 1u << t;
         }
+        t_lo = wave_any ? __builtin_ctz(wave_any) : 0;
+        nt = wave_any ? 32 - __builtin_clz(wave_any) - t_lo : 0;
+        // compiled tap counts: 3, 5, 6, 7 -- a range in between is widened (the extra taps read
+        // zeros through the lane masks, which is exact)
+        while (nt != 0 && nt != 3 && nt != 5 && nt != 6 && nt != 7) {
+          if (t_lo + nt < taps) {
+            ++nt;
+          } else {
+            --t_lo;
+            ++nt;
+          }
+        }
+      } else {
+        bool any_px = false;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) any_px = any_px || c.pval[pt];
+        if (__builtin_amdgcn_ballot_w64(any_px) == 0ull) nt = 0;
       }
       const int subs = L.cout_pad >> 5;
-      int sub_base, nbw, skip = 0;
-      if (subs == 5) {          // 8 + 7 tiles (chain_tile)
-        nbw = 3;
-        sub_base = ch ? 2 : 0;
-        skip = ch ? 2 : 1;
-      } else {
-        sub_base = ch ? (subs + 1) >> 1 : 0;
-        nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+      int sub_base = 0, nbw = subs, skip = 0;
+      if (PT == 3) {
+        if (subs == 5) {          // 8 + 7 tiles (chain_tile)
+          nbw = 3;
+          sub_base = ch ? 2 : 0;
+          skip = ch ? 2 : 1;
+        } else {
+          sub_base = ch ? (subs + 1) >> 1 : 0;
+          nbw = ch ? subs >> 1 : (subs + 1) >> 1;
+        }
       }
       cfg[l] = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(t_lo) | static_cast<unsigned>(nt) << 4 |
-                                              static_cast<unsigned>(nbw) << 8 | static_cast<unsigned>(skip) << 12 |
+                                              static_cast<unsigned>(nbw) << 10 | static_cast<unsigned>(skip) << 14 |
                                               static_cast<unsigned>(sub_base) << 16);
     }
   }
@@ -377,26 +445,29 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
       const ChainLayer& L = p.L[l];
       const bool last = l + 1 == p.n_layers;
       const unsigned cf = l == 0 ? cfg[0] : l == 1 ? cfg[1] : l == 2 ? cfg[2] : cfg[3];
-      const int t_lo = cf & 15, nt = (cf >> 4) & 15, nbw = (cf >> 8) & 15, skip = (cf >> 12) & 15;
+      const int t_lo = cf & 15, nt = (cf >> 4) & 63, nbw = (cf >> 10) & 15, skip = (cf >> 14) & 3;
       const int sub_base = cf >> 16;
-      const int pad = (L.taps - 1) >> 1;
-      unsigned m[CH_PT];
+      unsigned m[PT];
 #pragma unroll
-      for (int pt = 0; pt < CH_PT; ++pt) {
-        m[pt] = chain_tap_mask(L.horizontal ? c.pcol[pt] : c.prow[pt], L.horizontal ? p.w : p.h, L.taps, pad,
-                               c.pval[pt]) >> t_lo;
-      }
+      for (int pt = 0; pt < PT; ++pt) m[pt] = chain_tap_mask(p, L, c.prow[pt], c.pcol[pt], c.pval[pt]) >> t_lo;
       if (PROF) prof.setup += chain_clock() - t_setup;
-#define DV_CHAIN_CASE(NB_, NT_, SKIP_) \
-  case SKIP_ * 64 + NB_ * 8 + NT_: \
-    step = chain_layer<NB_, NT_, SKIP_, PROF>(p, L, last, smem, c, sub_base, t_lo, m[0], m[1], m[2], n0, step, prof); \
+#define DV_CHAIN_CASE(NB_, NT_, KW_, SKIP_) \
+  case SKIP_ * 1024 + NB_ * 64 + NT_: \
+    step = chain_layer<NB_, PT, NT_, KW_, SKIP_, PROF>(p, L, last, smem, c, sub_base, t_lo, m, n0, step, prof); \
     break;
-      switch (skip * 64 + nbw * 8 + nt) {   // wave-uniform
-        DV_CHAIN_CASE(2, 3, 0) DV_CHAIN_CASE(2, 5, 0) DV_CHAIN_CASE(2, 6, 0) DV_CHAIN_CASE(2, 7, 0)
-        DV_CHAIN_CASE(3, 3, 0) DV_CHAIN_CASE(3, 5, 0) DV_CHAIN_CASE(3, 6, 0) DV_CHAIN_CASE(3, 7, 0)
-        DV_CHAIN_CASE(3, 3, 1) DV_CHAIN_CASE(3, 5, 1) DV_CHAIN_CASE(3, 6, 1) DV_CHAIN_CASE(3, 7, 1)
-        DV_CHAIN_CASE(3, 3, 2) DV_CHAIN_CASE(3, 5, 2) DV_CHAIN_CASE(3, 6, 2) DV_CHAIN_CASE(3, 7, 2)
-        default: step = chain_layer_idle(L, step); break;   // nt == 0 (the host admits only nbw of 2 or 3)
+      if (PT == 3) {
+        switch (skip * 1024 + nbw * 64 + nt) {   // wave-uniform; one-dimensional filters
+          DV_CHAIN_CASE(2, 3, 0, 0) DV_CHAIN_CASE(2, 5, 0, 0) DV_CHAIN_CASE(2, 6, 0, 0) DV_CHAIN_CASE(2, 7, 0, 0)
+          DV_CHAIN_CASE(3, 3, 0, 0) DV_CHAIN_CASE(3, 5, 0, 0) DV_CHAIN_CASE(3, 6, 0, 0) DV_CHAIN_CASE(3, 7, 0, 0)
+          DV_CHAIN_CASE(3, 3, 0, 1) DV_CHAIN_CASE(3, 5, 0, 1) DV_CHAIN_CASE(3, 6, 0, 1) DV_CHAIN_CASE(3, 7, 0, 1)
+          DV_CHAIN_CASE(3, 3, 0, 2) DV_CHAIN_CASE(3, 5, 0, 2) DV_CHAIN_CASE(3, 6, 0, 2) DV_CHAIN_CASE(3, 7, 0, 2)
+          default: step = chain_layer_idle(L, step); break;   // nt == 0 (the host admits only these shapes)
+        }
+      } else {
+        switch (nbw * 64 + nt) {                  // 3x3 and 5x5 filters
+          DV_CHAIN_CASE(2, 9, 3, 0) DV_CHAIN_CASE(3, 9, 3, 0) DV_CHAIN_CASE(2, 25, 5, 0) DV_CHAIN_CASE(3, 25, 5, 0)
+          default: step = chain_layer_idle(L, step); break;
+        }
       }
 #undef DV_CHAIN_CASE
     }
@@ -413,18 +484,22 @@ __device__ __forceinline__ void chain_compute(const ChainArgs& p, char* smem, in
 }
 
 // ------------------------------------------------------------------ moving waves (4-7)
+// The weight slab of the next chunk and the next tile's input by LDS-DMA, one chunk of lead.  (A
+// register-staged variant with two chunks of lead -- global -> VGPR -> ds_write -- measured 1-2 %
+// SLOWER: the phase profile shows the computing waves, not the loaders, set the pace.)
 __device__ __forceinline__ void chain_move(const ChainArgs& p, char* smem, int lw, int lane) {
   const int Gw = p.G * p.w, T = Gw * p.h;
-  // source offset of tile pixel third*64 + lane, relative to (first image of the tile, group 0)
-  unsigned src[3];
+  const int parts = p.tpx >> 6;                 // 64-pixel parts of a channel group of the tile
+  // source offset of tile pixel part*64 + lane, relative to (first image of the tile, group 0)
+  unsigned src[4];
 #pragma unroll
-  for (int third = 0; third < 3; ++third) {
-    const int px = third * 64 + lane;
+  for (int part = 0; part < 4; ++part) {
+    const int px = part * 64 + lane;
     const int q = px < T ? px : 0;
     const int row = q / Gw, rem = q - row * Gw;
     const int img = rem / p.w, col = rem - img * p.w;
-    src[third] = static_cast<unsigned>(img) * p.in_img_bytes +
-                 static_cast<unsigned>(((row + p.ig.halo) * p.ig.wp + col + p.ig.halo) * 16);
+    src[part] = static_cast<unsigned>(img) * p.in_img_bytes +
+                static_cast<unsigned>(((row + p.ig.halo) * p.ig.wp + col + p.ig.halo) * 16);
   }
   const unsigned plane_bytes = static_cast<unsigned>(p.ig.hp * p.ig.wp * 16);
   const unsigned ring0 = p.act_bytes;
@@ -448,10 +523,10 @@ __device__ __forceinline__ void chain_move(const ChainArgs& p, char* smem, int l
         0, 0x7fffffff, 0x00020000);
     for (int g = 0; g < in_groups; ++g) {
 #pragma unroll
-      for (int third = 0; third < 3; ++third) {
-        if (((g * 3 + third) & 3) == lw) {   // wave-uniform
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + (g * CH_TPX + third * 64) * 16), 16,
-                                                   src[third], g * plane_bytes, 0, 0);
+      for (int part = 0; part < 4; ++part) {
+        if (part < parts && ((g * parts + part) & 3) == lw) {   // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + (g * p.tpx + part * 64) * 16), 16, src[part],
+                                                   g * plane_bytes, 0, 0);
         }
       }
     }
@@ -487,138 +562,16 @@ __device__ __forceinline__ void chain_move(const ChainArgs& p, char* smem, int l
   }
 }
 
-// ------------------------------------------------------------------ moving waves, register-staged
-// The same schedule with the weight slabs and the next tile travelling global -> VGPR -> LDS.  An
-// LDS-DMA can only be issued once its LDS slot is free, i.e. ONE chunk ahead with two slots, and
-// the first GPU runs showed every chunk waiting for its slab (1.5 us per chunk against 0.75 us of
-// MFMA work).  Registers are the deeper buffer: the four moving waves have 1000 VGPRs to spare, so
-// the slab of chunk s + 3 is requested while chunk s multiplies (two chunks of lead), lands in
-// registers, and is copied into the slot chunk s + 1 left (ds_write_b128, ~550 cycles per slab)
-// while chunk s + 2 multiplies.  The next tile's input (<= 72 KB) is requested a whole tile
-// ahead and written right after the last layer has read the current one.  Every load is
-// unconditional (past-the-end pieces fall outside their buffer descriptor and return zero
-// without traffic), so the compiler's counted vmcnt waits stay exact.
-struct ChainPos {
-  int tile, l, cc;
-  bool valid;
-};
-
-__device__ __forceinline__ void chain_move_regs(const ChainArgs& p, char* smem, int lw, int lane) {
-  constexpr int MAXW = 11;   // 1 KB pieces of a weight slab per moving wave (slab <= 44 KB)
-  constexpr int MAXA = 18;   // 1 KB pieces of the input tile per moving wave (<= 72 KB)
-  const int Gw = p.G * p.w, T = Gw * p.h;
-  const int n_layers = p.n_layers, n_tiles = p.n_tiles, stride = static_cast<int>(gridDim.x);
-  const unsigned ring0 = p.act_bytes, slot_bytes = p.slot_bytes;
-  const unsigned plane_bytes = static_cast<unsigned>(p.ig.hp * p.ig.wp * 16);
-  const int in_pieces = p.L[0].n_chunks * 2 * 3;   // 64-pixel thirds of the input's channel groups
-  unsigned aoff[MAXA], adst[MAXA];
-#pragma unroll
-  for (int k = 0; k < MAXA; ++k) {
-    const int j = lw + 4 * k;
-    const int g = j / 3, third = j - 3 * g;
-    const int px = third * 64 + lane;
-    const int q = px < T ? px : 0;
-    const int row = q / Gw, rem = q - row * Gw;
-    const int img = rem / p.w, col = rem - img * p.w;
-    aoff[k] = j < in_pieces ? static_cast<unsigned>(img) * p.in_img_bytes + static_cast<unsigned>(g) * plane_bytes +
-                                  static_cast<unsigned>(((row + p.ig.halo) * p.ig.wp + col + p.ig.halo) * 16)
-                            : 0x80000000u;
-    adst[k] = static_cast<unsigned>((g * CH_TPX + third * 64 + lane) * 16);
-  }
-  auto next = [&](ChainPos q) {
-    if (!q.valid) return q;
-    if (q.cc + 1 < p.L[q.l].n_chunks) {
-      ++q.cc;
-      return q;
-    }
-    q.cc = 0;
-    if (q.l + 1 < n_layers) {
-      ++q.l;
-      return q;
-    }
-    q.l = 0;
-    q.tile += stride;
-    q.valid = q.tile < n_tiles;
-    return q;
-  };
-  uint4_t wA[MAXW], wB[MAXW], ta[MAXA];
-  auto load_w = [&](uint4_t (&w)[MAXW], const ChainPos& q) {
-    const ChainLayer& L = p.L[q.valid ? q.l : 0];
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(L.w) +
-                                      static_cast<size_t>(q.valid ? q.cc : 0) * L.slab_bytes)),
-        0, q.valid ? L.slab_bytes : 0u, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < MAXW; ++j) {
-      w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (lw + 4 * j) * 1024, 0);
-    }
-  };
-  auto store_w = [&](const uint4_t (&w)[MAXW], const ChainPos& q, unsigned slot) {
-    const int pieces = q.valid ? static_cast<int>(p.L[q.l].slab_bytes >> 10) : 0;
-    char* dst = smem + ring0 + slot * slot_bytes + lane * 16;
-#pragma unroll
-    for (int j = 0; j < MAXW; ++j) {
-      if (lw + 4 * j < pieces) *reinterpret_cast<uint4_t*>(dst + (lw + 4 * j) * 1024) = w[j];
-    }
-  };
-  auto load_tile = [&](int tile) {
-    const int t = tile < n_tiles ? tile : static_cast<int>(blockIdx.x);   // past the end: any valid tile
-    const int n0 = max(0, min(t * p.G, p.N - p.G));
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(p.in) + static_cast<size_t>(n0) * p.in_img_bytes)),
-        0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < MAXA; ++k) ta[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[k], 0, 0);
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int k = 0; k < MAXA; ++k) {
-      if (lw + 4 * k < in_pieces) *reinterpret_cast<uint4_t*>(smem + adst[k]) = ta[k];
-    }
-  };
-
-  ChainPos c0{static_cast<int>(blockIdx.x), 0, 0, true};
-  ChainPos c1 = next(c0), c2 = next(c1), c3 = next(c2);
-  load_w(wA, c0);
-  load_w(wB, c1);
-  load_tile(c0.tile);
-  store_tile();
-  store_w(wA, c0, 0u);
-  load_w(wA, c2);
-  // here: chunk 0 sits in slot 0, wB holds chunk 1, wA receives chunk 2, c3 is the next to request
-  unsigned s = 0;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += stride) {
-    load_tile(tile + stride);
-    for (int l = 0; l < n_layers; ++l) {
-      const int n_chunks = p.L[l].n_chunks;   // even (checked by the host)
-      for (int cc = 0; cc < n_chunks; cc += 2) {
-        barrier_after_lds();                  // B(l, cc): the computing waves start chunk s
-        store_w(wB, c1, (s + 1u) & 1u);
-        load_w(wB, c3);
-        c1 = c2; c2 = c3; c3 = next(c3); ++s;
-        barrier_after_lds();                  // B(l, cc + 1)
-        store_w(wA, c1, (s + 1u) & 1u);
-        load_w(wA, c3);
-        c1 = c2; c2 = c3; c3 = next(c3); ++s;
-      }
-      barrier_after_lds();                    // E(l)
-    }
-    store_tile();                             // the last layer has read its input: the next tile moves in
-  }
-}
-
-template <bool PROF>
+template <int PT, bool PROF>
 __global__ __launch_bounds__(CH_THREADS, 1) void chain_kernel(ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   if (static_cast<int>(blockIdx.x) >= p.n_tiles) return;
   if (wave < 4) {
-    chain_compute<PROF>(p, smem, wave, lane);
-  } else if (p.dma_loader) {
-    chain_move(p, smem, wave - 4, lane);        // LDS-DMA, one chunk of lead (kept for A/B timing)
+    chain_compute<PT, PROF>(p, smem, wave, lane);
   } else {
-    chain_move_regs(p, smem, wave - 4, lane);
+    chain_move(p, smem, wave - 4, lane);
   }
 }
 
@@ -628,20 +581,25 @@ size_t chain_lds_bytes(const ChainArgs& a) {
   return static_cast<size_t>(a.act_bytes) + 2 * static_cast<size_t>(a.slot_bytes) + 16;
 }
 
-void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream) {
+template <int PT, bool PROF>
+static void launch_chain_as(const ChainArgs& a, int grid, hipStream_t stream) {
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<PT, PROF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr;
-  const int grid = a.n_tiles < blocks ? a.n_tiles : blocks;
-  if (a.prof != nullptr) {
-    hipLaunchKernelGGL(chain_kernel<true>, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+  hipLaunchKernelGGL((chain_kernel<PT, PROF>), dim3(grid), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+}
+
+void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream) {
+  int grid = a.n_tiles < blocks ? a.n_tiles : blocks;
+  if (grid < 1) grid = 1;
+  const bool prof = a.prof != nullptr;
+  if (a.tpx == 192) {
+    if (prof) launch_chain_as<3, true>(a, grid, stream); else launch_chain_as<3, false>(a, grid, stream);
   } else {
-    hipLaunchKernelGGL(chain_kernel<false>, dim3(grid > 0 ? grid : 1), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
+    if (prof) launch_chain_as<2, true>(a, grid, stream); else launch_chain_as<2, false>(a, grid, stream);
   }
 }
 

@@ -1034,6 +1034,7 @@ struct Op {
   // predecessor) run as ONE launch; the tensors between them live in LDS only
   int chain_len = 0;
   int chain_g = 0;               // images per tile
+  int chain_tpx = 0;             // pixels per tile (192: small maps, 1-D filters; 256: 35x35 stage, 3x3 / 5x5)
   bool in_chain = false;         // a non-leading member of a chain
 };
 
@@ -1327,52 +1328,70 @@ struct dv_model {
     }
   }
 
-  // Chains of one-dimensional 'same' convolutions in which every layer reads only its
-  // predecessor (the factorised 7x7 branches of mixed4..mixed8) run in chain.hip when a tile of
-  // G whole maps fills at least two thirds of the 192-pixel tile and the activation tile plus
-  // two weight slabs fit the CU's LDS.  DV_NO_CHAIN keeps the per-layer kernels.
+  // Chains of stride-1 'same' convolutions in which every layer reads only its predecessor run in
+  // chain.hip, intermediates in LDS:
+  //   * maps of <= 96 pixels (the 17x17 stage at WGS width), 1 x k / k x 1 filters: the factorised
+  //     7x7 branches of mixed4..mixed8 -- G whole maps in a 192-pixel tile, two layers or more;
+  //   * maps of 97..256 pixels (the 35x35 stage), 3x3 / 5x5 filters with 64..96 couts: the
+  //     3x3 -> 3x3 branch of mixed0..2, and the single 5x5 / 3x3 layers next to it (one-layer
+  //     "chains": both operands from LDS, loader waves) -- one or two maps in a 256-pixel tile.
+  // A tile must be at least two thirds full and the activation tile plus two weight slabs must
+  // fit the CU's LDS.  DV_NO_CHAIN keeps the per-layer kernels; DV_NO_CHAIN2D only those of the
+  // 35x35 stage; DV_CHAIN2D_MIN_LEN=1 also takes its single layers from imgconv.
   void choose_chains() {
     if (getenv("DV_NO_CHAIN") != nullptr) return;
+    const bool no_2d = getenv("DV_NO_CHAIN2D") != nullptr;
+    // measured (profiles/r03_chain2d_ab.txt): the 3x3 -> 3x3 pairs gain 6 % over two imgconv launches;
+    // single layers lose 5-30 % to imgconv (its tiles of two maps pipeline the next tile's input, a
+    // one-layer chain exposes it), so they stay there unless DV_CHAIN2D_MIN_LEN=1
+    const int min_len_2d = getenv("DV_CHAIN2D_MIN_LEN") ? atoi(getenv("DV_CHAIN2D_MIN_LEN")) : 2;
     std::vector<int> readers(buffers.size(), 0);
     for (const Op& o : ops) readers[o.in_buf]++;
-    auto one_d = [](const Op& o) {
-      const int k = std::max(o.kh, o.kw);
-      return o.type == kOpConv && o.stride == 1 && (o.kh == 1) != (o.kw == 1) && k <= dv::kChainMaxTaps &&
-             (k & 1) && o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
+    auto plain = [](const Op& o) {
+      return o.type == kOpConv && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
+             o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
              !o.first_u8 && !o.pool_in && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
-             o.cin == o.cin_real;
+             o.cin == o.cin_real && o.oh == o.ih && o.ow == o.iw;
+    };
+    auto one_d = [&](const Op& o) {
+      return plain(o) && (o.kh == 1) != (o.kw == 1) && std::max(o.kh, o.kw) <= dv::kChainMaxTaps;
+    };
+    auto two_d = [&](const Op& o) {
+      const int subs = (o.cout + 31) / 32;
+      return plain(o) && ((o.kh == 3 && o.kw == 3) || (o.kh == 5 && o.kw == 5)) && subs >= 2 && subs <= 3;
     };
     for (size_t i = 0; i < ops.size(); ++i) {
-      if (!one_d(ops[i])) continue;
+      const int P = ops[i].oh * ops[i].ow;
+      const bool big = P > dv::kChainTilePx / 2;
+      if (big ? (no_2d || P > dv::kChainTilePxBig || !two_d(ops[i])) : !one_d(ops[i])) continue;
+      auto member = [&](const Op& o) { return big ? two_d(o) : one_d(o); };
       size_t len = 1;
       while (i + len < ops.size() && len < static_cast<size_t>(dv::kChainMaxLayers)) {
         const Op& prev = ops[i + len - 1];
         const Op& next = ops[i + len];
-        if (!one_d(next) || next.in_buf != prev.out_buf || prev.out_coff != 0 || readers[prev.out_buf] != 1 ||
+        if (!member(next) || next.in_buf != prev.out_buf || prev.out_coff != 0 || readers[prev.out_buf] != 1 ||
             prev.cout % 32 != 0 || buffers[prev.out_buf].c != prev.cout) {
           break;
         }
         ++len;
       }
-      if (len < 2) continue;
-      const int P = ops[i].oh * ops[i].ow;
-      if (P > dv::kChainTilePx / 2) continue;
-      const int g = dv::kChainTilePx / P;
-      if (g * P < dv::kChainTilePx * 2 / 3) continue;
+      if (static_cast<int>(len) < (big ? min_len_2d : 2)) continue;
+      const int tpx = big ? dv::kChainTilePxBig : dv::kChainTilePx;
+      const int g = tpx / P;
+      if (g * P < tpx * 2 / 3) continue;
       size_t act = 0, slot = 0;
+      bool fits = true;
       for (size_t k = 0; k < len; ++k) {
         const Op& o = ops[i + k];
-        act = std::max(act, static_cast<size_t>(o.cin / 8) * dv::kChainTilePx * 16);
+        act = std::max(act, static_cast<size_t>(o.cin / 8) * tpx * 16);
         slot = std::max(slot, static_cast<size_t>(o.kh * o.kw) * 2 * ((o.cout + 31) / 32 * 32) * 16);
+        // the 192-pixel shape halves the couts between two waves: 4..6 subtiles of 32
+        if (!big) fits = fits && (o.cout + 31) / 32 >= 4 && (o.cout + 31) / 32 <= 6;
       }
-      if (act + 2 * slot + 16 > 160 * 1024) continue;
-      // the register-staged loader: slabs of at most 44 KB, input tiles of at most 72 KB, an even
-      // number of channel chunks per layer (its loop handles two chunks per trip)
-      bool fits = slot <= 44 * 1024 && act <= 72 * 1024;
-      for (size_t k = 0; k < len; ++k) fits = fits && (ops[i + k].cin / kChunk) % 2 == 0;
-      if (!fits) continue;
+      if (!fits || act + 2 * slot + 16 > 160 * 1024) continue;
       ops[i].chain_len = static_cast<int>(len);
       ops[i].chain_g = g;
+      ops[i].chain_tpx = tpx;
       for (size_t k = 1; k < len; ++k) {
         ops[i + k].in_chain = true;
         const int c = ops[i + k - 1].cout;
@@ -1784,6 +1803,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.in_img_bytes = static_cast<unsigned>(ib.bytes_per_example());
       a.N = n;
       a.G = op.chain_g;
+      a.tpx = op.chain_tpx;
       a.h = op.oh;
       a.w = op.ow;
       a.n_tiles = (n + a.G - 1) / a.G;
@@ -1799,10 +1819,10 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         cl.n_chunks = o.cin / kChunk;
         cl.cout = o.cout;
         cl.cout_pad = (o.cout + 31) / 32 * 32;
-        cl.taps = o.kh * o.kw;
-        cl.horizontal = o.kh == 1 ? 1 : 0;
-        cl.slab_bytes = static_cast<unsigned>(cl.taps * 2 * cl.cout_pad * 16);
-        act = std::max(act, static_cast<size_t>(o.cin / 8) * dv::kChainTilePx * 16);
+        cl.kh = o.kh;
+        cl.kw = o.kw;
+        cl.slab_bytes = static_cast<unsigned>(o.kh * o.kw * 2 * cl.cout_pad * 16);
+        act = std::max(act, static_cast<size_t>(o.cin / 8) * op.chain_tpx * 16);
         slot = std::max(slot, static_cast<size_t>(cl.slab_bytes));
         tr_flops += 2.0 * n * o.oh * o.ow * o.kh * o.kw * o.cin * o.cout;
         tr_label += " " + std::to_string(o.kh) + "x" + std::to_string(o.kw) + ":" + std::to_string(o.cin) + "->" +
@@ -1813,10 +1833,6 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.out = static_cast<_Float16*>(m->dbuf[last.out_buf].ptr);
       a.og = lob.geom();
       a.out_goff = last.out_coff / 8;
-      // LDS-DMA loader by default; DV_CHAIN_REGS selects the register-staged one (two chunks of
-      // lead; measured 1-2 % slower: the computing waves, not the loaders, set the pace)
-      static const bool regs_loader = getenv("DV_CHAIN_REGS") != nullptr;   // tuning knob
-      a.dma_loader = regs_loader ? 0 : 1;
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " [fused, G=" + std::to_string(a.G) + "]";
       TraceScope tr(stream, tr_label, tr_flops,
                     2.0 * n * op.oh * op.ow * (static_cast<double>(op.cin) + last.cout));

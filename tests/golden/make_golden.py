@@ -129,7 +129,7 @@ def main():
                      np.int64))
 
 
-if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner', 'illumina_alt', 'nucleus_sam')) for a in sys.argv[1:]):
+if __name__ == '__main__' and not any(a.startswith(('pacbio', 'realigner', 'illumina_alt', 'nucleus_sam', 'na12878_100kb')) for a in sys.argv[1:]):
   main()
 
 
@@ -516,3 +516,30 @@ def main_nucleus_sam():
 
 if __name__ == '__main__' and 'nucleus_sam' in sys.argv[1:]:
   main_nucleus_sam()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[0] as FILES for `bench.py --mode bam`: the reference tree's NA12878 30x
+# Illumina slice (deepvariant/testdata/input/NA12878_S1.chr20.10_10p1mb.bam + .bai, reads of
+# chr20:10,000,000-10,100,000) and the hg19 chr20 stretch around it from
+# ucsc.hg19.chr20.unittest.fasta.gz, bundled as bytes -- /root/reference does not exist on the GPU box.
+#   na12878_100kb.npz: bam, bai (uint8), ref_bases (uint8, chr20:[ref_start, ref_start + len)),
+#   ref_start, n_contig_bases.  bench.py writes them back into a temporary directory.
+# ---------------------------------------------------------------------------
+def main_na12878_100kb():
+  bam = os.path.join(REF, 'input/NA12878_S1.chr20.10_10p1mb.bam')
+  fasta = genomics_io.FastaReader(os.path.join(REF, 'input/ucsc.hg19.chr20.unittest.fasta.gz'))
+  lo, hi = 9_990_000, 10_110_000
+  n = fasta.n_bases('chr20')
+  hi = min(hi, n)
+  d = dict(bam=np.frombuffer(open(bam, 'rb').read(), np.uint8),
+           bai=np.frombuffer(open(bam + '.bai', 'rb').read(), np.uint8),
+           ref_bases=np.frombuffer(fasta.get_bases('chr20', lo, hi).encode(), np.uint8),
+           ref_start=np.array([lo], np.int64), n_contig_bases=np.array([n], np.int64))
+  for k, v in d.items():
+    print(k, v.size)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/na12878_100kb.npz'), **d)
+
+
+if __name__ == '__main__' and 'na12878_100kb' in sys.argv[1:]:
+  main_na12878_100kb()
