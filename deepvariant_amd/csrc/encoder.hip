@@ -32,6 +32,8 @@
 #include <numeric>
 #include <random>
 
+#include <type_traits>
+
 #include "dv_internal.h"
 
 namespace {
@@ -40,6 +42,7 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kColsPerLane = 4;  // a row is rendered in passes of 256 columns, 4 per lane
 constexpr int kMaxKept = 256;
+constexpr int kCigCache = 8;     // CIGAR words per kept read cached in LDS (power of two; longer CIGARs are read from global)
 constexpr int kPixDw = DV_MAX_CHANNELS / 4;  // dwords of one pixel's channel bytes
 constexpr int kInsertLutSize = 1008;
 
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   uint32_t* m_const = wave_tot + 8;                // [kMaxKept][pdw]
   uint32_t* m_sel_a = m_const + kMaxKept * pdw;    // dynamic bytes {base, qual, diff, 5mC}
   uint32_t* m_sel_b = m_sel_a + kMaxKept * pdw;    // dynamic byte  {6mA}
-  uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_sel_b + kMaxKept * pdw);
+  uint32_t* m_cig = m_sel_b + kMaxKept * pdw;      // [kMaxKept][kCigCache]: the first CIGAR words of each kept read
+  uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_cig + kMaxKept * kCigCache);
   // after the sort the key arrays are dead: they become the per-read metadata
   uint32_t* m_c0 = reinterpret_cast<uint32_t*>(key_hap);
   uint32_t* m_s0 = reinterpret_cast<uint32_t*>(key_pos);
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   const int wave = tid >> 6;
   const int item = blockIdx.x;
 
+  if (tid == 0) wave_tot[kWaves] = 0;   // "some kept read's CIGAR does not fit the LDS cache" (set in phase C')
   {  // constants -> LDS (16-byte copies)
     const uint4* src = reinterpret_cast<const uint4*>(a.konst);
     uint4* dst = reinterpret_cast<uint4*>(c);
@@ -414,6 +419,11 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         m_sel_b[tid * pdw + d] = sel_b[d];
       }
     }
+#pragma unroll
+    for (int k = 0; k < kCigCache; ++k) {
+      m_cig[tid * kCigCache + k] = rc0 + k < rc1 ? a.cigar[rc0 + k] : 0u;
+    }
+    if (rc1 - rc0 > static_cast<uint32_t>(kCigCache)) atomicOr(&wave_tot[kWaves], 1u);
     m_c0[tid] = rc0;   // (key_* / kept_* of this slot are dead from here on)
     m_s0[tid] = rs0;
     m_rpos[tid] = rp;
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   __syncthreads();
 
   // ---------------- phase D: render rows -------------------------------------
+  const bool any_long_cigar = wave_tot[kWaves] != 0;
   const int row_bytes = W * CO;
   const uint64_t out0 = a.item_out_off[item];
   int mc_limit = 0;  // rows [0, mc_limit) get the mean-coverage paint
@@ -433,213 +444,330 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   const int n_render = min(max(band + kept, mc_limit), H);
   uint8_t* rb = row_bufs + wave * a.row_buf_bytes;
   const uint8_t* ref = a.ref_windows + static_cast<size_t>(a.item_ref_idx[item]) * W;
+  const int n_pix_dw = pdw;
 
-  for (int row = wave; row < n_render; row += kWaves) {
-    const uint64_t g0 = out0 + static_cast<uint64_t>(row) * row_bytes;
-    // the row is staged at the byte phase of its global address so that it leaves as
-    // aligned 16-byte pieces
-    const uint64_t gaddr = reinterpret_cast<uint64_t>(a.out) + g0;
+  // The row is staged in LDS at the byte phase of its global address so that it leaves as
+  // aligned 16-byte pieces; `zero` clears the buffer first (rows that do not write every pixel).
+  auto row_begin = [&](int row, bool zero) -> uint8_t* {
+    const uint64_t gaddr = reinterpret_cast<uint64_t>(a.out) + out0 + static_cast<uint64_t>(row) * row_bytes;
     const int s = static_cast<int>(gaddr & 15);
-    const int ndw = (s + row_bytes + 3) >> 2;
-    uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
-    const bool read_row = row >= band && row < band + kept;
-    if (!read_row && row >= band) {  // reference and read rows write every pixel themselves
+    if (zero) {
+      const int ndw = (s + row_bytes + 3) >> 2;
+      uint32_t* rb32 = reinterpret_cast<uint32_t*>(rb);
       for (int k = lane; k < ndw; k += 64) rb32[k] = 0;
     }
     wave_sync();
-    uint8_t* px = rb + s;
+    return rb + s;
+  };
+  // LDS row -> HBM: aligned 16-byte pieces; the (<= 15 byte) ragged ends of the row go out as
+  // byte stores so neighbouring rows never race on a piece.
+  auto row_flush = [&](int row) {
+    wave_sync();
+    const uint64_t gaddr = reinterpret_cast<uint64_t>(a.out) + out0 + static_cast<uint64_t>(row) * row_bytes;
+    const int s = static_cast<int>(gaddr & 15);
+    uint8_t* gbase = reinterpret_cast<uint8_t*>(gaddr - s);
+    const int npc = (s + row_bytes + 15) >> 4;
+    const uint4* rb128 = reinterpret_cast<const uint4*>(rb);
+    for (int k = lane; k < npc; k += 64) {
+      const int lo = 16 * k - s;
+      if (lo >= 0 && lo + 16 <= row_bytes) {
+        *reinterpret_cast<uint4*>(gbase + 16 * k) = rb128[k];
+      }
+    }
+    // head: bytes [0, head) of the row; tail: bytes [tail0, row_bytes)
+    const int head = min((16 - s) & 15, row_bytes);
+    const int tail0 = max(head, ((s + row_bytes) & ~15) - s);
+    if (lane < head) gbase[s + lane] = rb[s + lane];
+    const int t = tail0 + lane - 16;  // lanes 16..31 take the tail
+    if (lane >= 16 && lane < 32 && t < row_bytes) gbase[s + t] = rb[s + t];
+    wave_sync();
+  };
+  auto paint_mean_cov = [&](uint8_t* px, int row) {
     const int mc_val = (row < mc_limit) ? (row < band ? 255 : 200) : -1;
+    if (c->mean_cov_channel >= 0 && mc_val >= 0) {
+      for (int col = lane; col < W; col += 64) px[col * CO + c->mean_cov_channel] = mc_val;
+    }
+  };
 
-    if (row < band) {
-      // EncodeReference (pileup_channel_lib.cc:263-293)
-      // pixel = per-channel constants, with the base-colour byte spliced in by v_perm
-      uint32_t rk[kPixDw], rs[kPixDw];
+  // What one read row needs from memory, for one pass of 64 * kColsPerLane columns: the
+  // wave-uniform metadata of its read (phase C'), per column the LAST event of the CIGAR walk
+  // (ev: 0 nothing, 1 aligned base, 2 indel anchor; ri: index of the read base) and the bytes
+  // that event points at.
+  struct RowIn {
+    int slot;
+    uint32_t flags, s0;
+    int ev[kColsPerLane], ri[kColsPerLane];
+    uint32_t bb[kColsPerLane], qq[kColsPerLane], rr[kColsPerLane];   // zero-extended bytes
+  };
+  // One CIGAR walk per pass (one pass for W <= 256): the ops come in with one coalesced vector
+  // load -- from the LDS cache of phase C' for reads of up to kCigCache operations, else from
+  // global memory -- and are broadcast with v_readlane, the running (ref_i, read_i) are
+  // wave-uniform (SGPRs), and every lane resolves the LAST event on each of its kColsPerLane
+  // columns (lane, lane+64, ...) in registers -- the reference overwrites in op order.  Then the
+  // bases / qualities / reference bases of all columns are REQUESTED; nothing waits for them here.
+  auto gather = [&](int row, int cb0, RowIn& in, auto lds_only_tag) {
+    constexpr bool kLdsOnly = decltype(lds_only_tag)::value;   // every kept read's CIGAR sits in the LDS cache
+    const uint8_t* const bases_p = a.bases;
+    const uint8_t* const quals_p = a.quals;
+    const uint8_t* const ref_p = ref;
+    const int slot = __builtin_amdgcn_readfirstlane(order[row - band]);
+    in.slot = slot;
+    in.flags = __builtin_amdgcn_readfirstlane(m_flags[slot]);
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(m_c0[slot]);
+    const uint32_t c1 = __builtin_amdgcn_readfirstlane(m_c1[slot]);
+    in.s0 = __builtin_amdgcn_readfirstlane(m_s0[slot]);
+    const int rpos = __builtin_amdgcn_readfirstlane(m_rpos[slot]);
 #pragma unroll
-      for (int d = 0; d < kPixDw; ++d) {
-        rk[d] = __builtin_amdgcn_readfirstlane(c->ref_konst[d]);
-        rs[d] = __builtin_amdgcn_readfirstlane(c->ref_sel[d]);
+    for (int q = 0; q < kColsPerLane; ++q) {
+      in.ev[q] = 0;
+      in.ri[q] = 0;
+    }
+    int ref_i = rpos, read_i = 0;
+    const int n_ops = static_cast<int>(c1 - c0);
+    for (int kb = 0; kb < n_ops; kb += 64) {
+      uint32_t cg_v;
+      if (kLdsOnly || n_ops <= kCigCache) {   // wave-uniform
+        cg_v = m_cig[slot * kCigCache + (lane & (kCigCache - 1))];
+      } else {
+        cg_v = (kb + lane < n_ops) ? a.cigar[c0 + kb + lane] : 0u;
       }
-      const size_t ref_row = static_cast<size_t>(a.item_ref_idx[item]) * W;
-      for (int col = lane; col < W; col += 64) {
-        uint32_t bv = c->lut_base[ref[col]];
-        if (a.ref_aux0) bv |= static_cast<uint32_t>(a.ref_aux0[ref_row + col]) << 8;
-        if (a.ref_aux1) bv |= static_cast<uint32_t>(a.ref_aux1[ref_row + col]) << 16;
-        if (a.ref_aux2) bv |= static_cast<uint32_t>(a.ref_aux2[ref_row + col]) << 24;
-        uint32_t o[kPixDw];
+      const int nk = min(64, n_ops - kb);
+      for (int k = 0; k < nk; ++k) {
+        const uint32_t cg = __builtin_amdgcn_readlane(cg_v, k);
+        const int op = cg & 0xF;
+        const int len = cg >> 4;
+        switch (op) {
+          case DV_CIGAR_ALIGNMENT_MATCH:
+          case DV_CIGAR_SEQUENCE_MATCH:
+          case DV_CIGAR_SEQUENCE_MISMATCH:
 #pragma unroll
-        for (int d = 0; d < kPixDw; ++d) o[d] = __builtin_amdgcn_perm(bv, rk[d], rs[d]);
-        store_pixel(px + col * CO, o, CO);
-      }
-      if (c->mean_cov_channel >= 0 && mc_val >= 0) {
-        for (int col = lane; col < W; col += 64)
-          px[col * CO + c->mean_cov_channel] = mc_val;
-      }
-    } else if (read_row) {
-      // wave-uniform metadata of this row's read, precomputed in phase C'
-      const int slot = __builtin_amdgcn_readfirstlane(order[row - band]);
-      const uint32_t flags = __builtin_amdgcn_readfirstlane(m_flags[slot]);
-      const uint32_t c0 = __builtin_amdgcn_readfirstlane(m_c0[slot]);
-      const uint32_t c1 = __builtin_amdgcn_readfirstlane(m_c1[slot]);
-      const uint32_t s0 = __builtin_amdgcn_readfirstlane(m_s0[slot]);
-      const int rpos = __builtin_amdgcn_readfirstlane(m_rpos[slot]);
-      uint32_t konst[kPixDw], sel_a[kPixDw], sel_b[kPixDw];
-      bool any_b = false;
-#pragma unroll
-      for (int d = 0; d < kPixDw; ++d) {
-        konst[d] = 0;
-        sel_a[d] = sel_b[d] = 0x03020100u;
-        if (d < pdw) {
-          konst[d] = __builtin_amdgcn_readfirstlane(m_const[slot * pdw + d]);
-          sel_a[d] = __builtin_amdgcn_readfirstlane(m_sel_a[slot * pdw + d]);
-          sel_b[d] = __builtin_amdgcn_readfirstlane(m_sel_b[slot * pdw + d]);
-        }
-        any_b |= sel_b[d] != 0x03020100u;
-      }
-      const int n_pix_dw = pdw;
-      for (int cb0 = 0; cb0 < W; cb0 += 64 * kColsPerLane) {
-      // One CIGAR walk per pass (one pass for W <= 256): the ops come in with one coalesced vector load and are
-      // broadcast with v_readlane, the running (ref_i, read_i) are wave-uniform (SGPRs),
-      // and every lane resolves the LAST event on each of its kColsPerLane columns
-      // (lane, lane+64, ...) in registers -- the reference overwrites in op order.
-      int ev[kColsPerLane], ri[kColsPerLane];  // ev: 0 nothing, 1 aligned base, 2 indel anchor
-#pragma unroll
-      for (int q = 0; q < kColsPerLane; ++q) {
-        ev[q] = 0;
-        ri[q] = 0;
-      }
-      int ref_i = rpos, read_i = 0;
-      const int n_ops = static_cast<int>(c1 - c0);
-      for (int kb = 0; kb < n_ops; kb += 64) {
-        const uint32_t cg_v = (kb + lane < n_ops) ? a.cigar[c0 + kb + lane] : 0u;
-        const int nk = min(64, n_ops - kb);
-        for (int k = 0; k < nk; ++k) {
-          const uint32_t cg = __builtin_amdgcn_readlane(cg_v, k);
-          const int op = cg & 0xF;
-          const int len = cg >> 4;
-          switch (op) {
-            case DV_CIGAR_ALIGNMENT_MATCH:
-            case DV_CIGAR_SEQUENCE_MATCH:
-            case DV_CIGAR_SEQUENCE_MISMATCH:
+            for (int q = 0; q < kColsPerLane; ++q) {
+              const int d = istart + cb0 + q * 64 + lane - ref_i;
+              if (d >= 0 && d < len) {
+                in.ev[q] = 1;
+                in.ri[q] = read_i + d;
+              }
+            }
+            ref_i += len;
+            read_i += len;
+            break;
+          case DV_CIGAR_INSERT:
+            if (ref_i > 0) {
 #pragma unroll
               for (int q = 0; q < kColsPerLane; ++q) {
-                const int d = istart + cb0 + q * 64 + lane - ref_i;
-                if (d >= 0 && d < len) {
-                  ev[q] = 1;
-                  ri[q] = read_i + d;
+                if (istart + cb0 + q * 64 + lane == ref_i - 1) {
+                  in.ev[q] = 2;
+                  in.ri[q] = read_i;
                 }
               }
-              ref_i += len;
-              read_i += len;
-              break;
-            case DV_CIGAR_INSERT:
-              if (ref_i > 0) {
+            }
+            read_i += len;
+            break;
+          case DV_CIGAR_CLIP_SOFT:
+            read_i += len;
+            break;
+          case DV_CIGAR_DELETE:
+            if (read_i > 0) {
 #pragma unroll
-                for (int q = 0; q < kColsPerLane; ++q) {
-                  if (istart + cb0 + q * 64 + lane == ref_i - 1) {
-                    ev[q] = 2;
-                    ri[q] = read_i;
-                  }
+              for (int q = 0; q < kColsPerLane; ++q) {
+                if (istart + cb0 + q * 64 + lane == ref_i - 1) {
+                  in.ev[q] = 2;
+                  in.ri[q] = read_i - 1;
                 }
               }
-              read_i += len;
-              break;
-            case DV_CIGAR_CLIP_SOFT:
-              read_i += len;
-              break;
-            case DV_CIGAR_DELETE:
-              if (read_i > 0) {
-#pragma unroll
-                for (int q = 0; q < kColsPerLane; ++q) {
-                  if (istart + cb0 + q * 64 + lane == ref_i - 1) {
-                    ev[q] = 2;
-                    ri[q] = read_i - 1;
-                  }
-                }
-              }
-              ref_i += len;
-              break;
-            case DV_CIGAR_SKIP:
-              ref_i += len;
-              break;
-            default:
-              break;
-          }
+            }
+            ref_i += len;
+            break;
+          case DV_CIGAR_SKIP:
+            ref_i += len;
+            break;
+          default:
+            break;
         }
       }
-      // bases / quals of all columns first (independent loads in flight), then the pixels
-      uint8_t bb[kColsPerLane], qq[kColsPerLane], rr[kColsPerLane];
+    }
+    // UNCONDITIONAL loads (columns without an event read the read's first base / the window's
+    // last column and are discarded in draw): behind a per-element condition hipcc branches
+    // around every load and waits for it on the spot -- twelve serial round trips per row.
+    // They are issued from inline assembly: the compiler's own wait insertion, which cannot
+    // count through draw's branches, would otherwise put `s_waitcnt vmcnt(0)` in front of the
+    // first use and so wait for the NEXT row's loads as well; wait_row() below waits exactly.
 #pragma unroll
-      for (int q = 0; q < kColsPerLane; ++q) {
-        const int col = cb0 + q * 64 + lane;
-        const bool on = col < W && ev[q] != 0;
-        bb[q] = on ? (ev[q] == 1 ? a.bases[s0 + ri[q]] : static_cast<uint8_t>(c->anchor_char)) : 0;
-        qq[q] = on ? a.quals[s0 + ri[q]] : 0;
-        rr[q] = on ? ref[col] : 0;
+    for (int q = 0; q < kColsPerLane; ++q) {
+      const int col = cb0 + q * 64 + lane;
+      const bool on = col < W && in.ev[q] != 0;
+      if (!on) {
+        in.ev[q] = 0;
+        in.ri[q] = 0;
       }
+      const uint32_t at = in.s0 + static_cast<uint32_t>(in.ri[q]);
+      const uint32_t rc = static_cast<uint32_t>(min(col, W - 1));
+      // `s_nop 4`: the base pointers may have been restored from spill lanes (v_readlane) right
+      // in front of the statement, and hipcc pads no hazards for the inside of an asm string
+      // (VALU-written SGPR -> VMEM address: 5 wait states)
+      asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2" : "=v"(in.bb[q]) : "v"(at), "s"(bases_p) : "memory");
+      asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2" : "=v"(in.qq[q]) : "v"(at), "s"(quals_p) : "memory");
+      asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2" : "=v"(in.rr[q]) : "v"(rc), "s"(ref_p) : "memory");
+    }
+  };
+  // The 3 * kColsPerLane loads of `in` have landed; the as many loads issued AFTER them (the
+  // next row's gather) may still be in flight.  Every destination register passes through the
+  // statement, so no use can be scheduled ahead of it.
+  static_assert(kColsPerLane == 4, "wait_row lists twelve registers");
+  auto wait_row = [&](RowIn& in, bool newer_in_flight) {
+    if (newer_in_flight) {
+      asm volatile("s_waitcnt vmcnt(12)"
+                   : "+v"(in.bb[0]), "+v"(in.bb[1]), "+v"(in.bb[2]), "+v"(in.bb[3]), "+v"(in.qq[0]), "+v"(in.qq[1]),
+                     "+v"(in.qq[2]), "+v"(in.qq[3]), "+v"(in.rr[0]), "+v"(in.rr[1]), "+v"(in.rr[2]), "+v"(in.rr[3])
+                   :: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(in.bb[0]), "+v"(in.bb[1]), "+v"(in.bb[2]), "+v"(in.bb[3]), "+v"(in.qq[0]), "+v"(in.qq[1]),
+                     "+v"(in.qq[2]), "+v"(in.qq[3]), "+v"(in.rr[0]), "+v"(in.rr[1]), "+v"(in.rr[2]), "+v"(in.rr[3])
+                   :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The pixels of one pass from the gathered bytes, into the LDS row.
+  auto draw = [&](const RowIn& in, int cb0, uint8_t* px) {
+    const int slot = in.slot;
+    const uint32_t flags = in.flags, s0 = in.s0;
+    uint32_t konst[kPixDw], sel_a[kPixDw], sel_b[kPixDw];
+    bool any_b = false;
 #pragma unroll
-      for (int q = 0; q < kColsPerLane; ++q) {
-        const int col = cb0 + q * 64 + lane;
-        if (col >= W) continue;
-        const uint8_t base = bb[q];
-        uint32_t o[kPixDw];
+    for (int d = 0; d < kPixDw; ++d) {
+      konst[d] = 0;
+      sel_a[d] = sel_b[d] = 0x03020100u;
+      if (d < pdw) {
+        konst[d] = __builtin_amdgcn_readfirstlane(m_const[slot * pdw + d]);
+        sel_a[d] = __builtin_amdgcn_readfirstlane(m_sel_a[slot * pdw + d]);
+        sel_b[d] = __builtin_amdgcn_readfirstlane(m_sel_b[slot * pdw + d]);
+      }
+      any_b |= sel_b[d] != 0x03020100u;
+    }
 #pragma unroll
-        for (int d = 0; d < kPixDw; ++d) o[d] = 0;
-        if (base != 0) {  // `read_base &&` (pileup_channel_lib.cc:139): a NUL base draws nothing
-          uint32_t dyn_a = c->lut_base[base] | (static_cast<uint32_t>(c->lut_bq[qq[q]]) << 8) |
-                           (static_cast<uint32_t>(c->diff[base == rr[q] ? 1 : 0]) << 16);
-          if ((flags & DV_READ_HAS_5MC) && a.mod_5mc) {
-            dyn_a |= static_cast<uint32_t>(c->lut_mod[a.mod_5mc[s0 + ri[q]]]) << 24;
-          }
+    for (int q = 0; q < kColsPerLane; ++q) {
+      const int col = cb0 + q * 64 + lane;
+      if (col >= W) continue;
+      // no event: nothing is drawn; an indel anchor draws the anchor character with the quality
+      // of the read base the event points at
+      const uint8_t base = in.ev[q] == 0 ? 0 : in.ev[q] == 1 ? static_cast<uint8_t>(in.bb[q])
+                                                              : static_cast<uint8_t>(c->anchor_char);
+      uint32_t o[kPixDw];
+#pragma unroll
+      for (int d = 0; d < kPixDw; ++d) o[d] = 0;
+      if (base != 0) {  // `read_base &&` (pileup_channel_lib.cc:139): a NUL base draws nothing
+        uint32_t dyn_a = c->lut_base[base] | (static_cast<uint32_t>(c->lut_bq[in.qq[q]]) << 8) |
+                         (static_cast<uint32_t>(c->diff[base == static_cast<uint8_t>(in.rr[q]) ? 1 : 0]) << 16);
+        if ((flags & DV_READ_HAS_5MC) && a.mod_5mc) {
+          dyn_a |= static_cast<uint32_t>(c->lut_mod[a.mod_5mc[s0 + in.ri[q]]]) << 24;
+        }
+#pragma unroll
+        for (int d = 0; d < kPixDw; ++d) {
+          if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_a, konst[d], sel_a[d]);
+        }
+        if (any_b) {
+          uint32_t dyn_b = 0;  // {6mA, is_homopolymer, homopolymer_weighted} pixels of this base
+          if ((flags & DV_READ_HAS_6MA) && a.mod_6ma) dyn_b = c->lut_mod[a.mod_6ma[s0 + in.ri[q]]];
+          if (a.base_aux0) dyn_b |= static_cast<uint32_t>(a.base_aux0[s0 + in.ri[q]]) << 8;
+          if (a.base_aux1) dyn_b |= static_cast<uint32_t>(a.base_aux1[s0 + in.ri[q]]) << 16;
 #pragma unroll
           for (int d = 0; d < kPixDw; ++d) {
-            if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_a, konst[d], sel_a[d]);
+            if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_b, o[d], sel_b[d]);
           }
-          if (any_b) {
-            uint32_t dyn_b = 0;  // {6mA, is_homopolymer, homopolymer_weighted} pixels of this base
-            if ((flags & DV_READ_HAS_6MA) && a.mod_6ma) dyn_b = c->lut_mod[a.mod_6ma[s0 + ri[q]]];
-            if (a.base_aux0) dyn_b |= static_cast<uint32_t>(a.base_aux0[s0 + ri[q]]) << 8;
-            if (a.base_aux1) dyn_b |= static_cast<uint32_t>(a.base_aux1[s0 + ri[q]]) << 16;
+        }
+      }
+      // every lane writes its whole pixel (zeros where the read draws nothing), so the
+      // row buffer needs no clearing pass
+      store_pixel(px + col * CO, o, CO);
+    }
+  };
+
+  // ---- reference rows: EncodeReference (pileup_channel_lib.cc:263-293)
+  for (int row = wave; row < min(band, n_render); row += kWaves) {
+    uint8_t* px = row_begin(row, false);
+    // pixel = per-channel constants, with the base-colour byte spliced in by v_perm
+    uint32_t rk[kPixDw], rs[kPixDw];
 #pragma unroll
-            for (int d = 0; d < kPixDw; ++d) {
-              if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_b, o[d], sel_b[d]);
-            }
-          }
-        }
-        // every lane writes its whole pixel (zeros where the read draws nothing), so the
-        // row buffer needs no clearing pass
-        store_pixel(px + col * CO, o, CO);
-      }
-      }  // column pass
-      if (c->mean_cov_channel >= 0 && mc_val >= 0) {
-        for (int col = lane; col < W; col += 64)
-          px[col * CO + c->mean_cov_channel] = mc_val;
-      }
-    } else {
-      // below the pileup but inside the mean-coverage paint
-      for (int col = lane; col < W; col += 64)
-        px[col * CO + c->mean_cov_channel] = mc_val;
+    for (int d = 0; d < kPixDw; ++d) {
+      rk[d] = __builtin_amdgcn_readfirstlane(c->ref_konst[d]);
+      rs[d] = __builtin_amdgcn_readfirstlane(c->ref_sel[d]);
     }
-    wave_sync();
-    // LDS row -> HBM: aligned 16-byte pieces; the (<= 15 byte) ragged ends of the row
-    // go out as byte stores so neighbouring rows never race on a piece.
-    {
-      uint8_t* gbase = reinterpret_cast<uint8_t*>(gaddr - s);
-      const int npc = (s + row_bytes + 15) >> 4;
-      const uint4* rb128 = reinterpret_cast<const uint4*>(rb);
-      for (int k = lane; k < npc; k += 64) {
-        const int lo = 16 * k - s;
-        if (lo >= 0 && lo + 16 <= row_bytes) {
-          *reinterpret_cast<uint4*>(gbase + 16 * k) = rb128[k];
+    const size_t ref_row = static_cast<size_t>(a.item_ref_idx[item]) * W;
+    for (int col = lane; col < W; col += 64) {
+      uint32_t bv = c->lut_base[ref[col]];
+      if (a.ref_aux0) bv |= static_cast<uint32_t>(a.ref_aux0[ref_row + col]) << 8;
+      if (a.ref_aux1) bv |= static_cast<uint32_t>(a.ref_aux1[ref_row + col]) << 16;
+      if (a.ref_aux2) bv |= static_cast<uint32_t>(a.ref_aux2[ref_row + col]) << 24;
+      uint32_t o[kPixDw];
+#pragma unroll
+      for (int d = 0; d < kPixDw; ++d) o[d] = __builtin_amdgcn_perm(bv, rk[d], rs[d]);
+      store_pixel(px + col * CO, o, CO);
+    }
+    paint_mean_cov(px, row);
+    row_flush(row);
+  }
+
+  // ---- read rows.  A row's pixels hang on a chain of dependent loads (row order -> CIGAR ->
+  // bases): ~1.5 us of latency against ~0.3 us of work, which is what bounded this kernel at
+  // 0.28 of the HBM roofline.  The wave therefore runs its rows as a two-stage
+  // software pipeline: the NEXT row's walk runs and its byte loads are issued before the
+  // CURRENT row's pixels are drawn, so those loads travel under a whole row of work; the CIGAR
+  // itself comes from LDS (phase C').  Single-pass images (W <= 256: every BASELINE shape) whose
+  // kept reads all have at most kCigCache CIGAR operations; other items take the plain
+  // row-at-a-time path.
+  const int read_end = band + kept;
+  int first_read = band + ((wave - band) % kWaves + kWaves) % kWaves;
+  if (W <= 64 * kColsPerLane && !any_long_cigar) {
+    if (first_read < read_end) {
+      // two named register sets, alternating (a copy `cur = next` would have to wait for the loads
+      // it copies): even trips draw `even` while `odd` is gathered, odd trips the other way round.
+      // Gathers are unconditional (past the end the wave gathers its last row again): a load
+      // count that depends on the path would make the compiler wait for everything at the next use.
+      RowIn even, odd;
+      const int last = first_read + (read_end - 1 - first_read) / kWaves * kWaves;   // this wave's last read row
+      gather(first_read, 0, even, std::true_type{});
+      for (int row = first_read; row < read_end; row += 2 * kWaves) {
+        gather(min(row + kWaves, last), 0, odd, std::true_type{});
+        {
+          wait_row(even, true);
+          uint8_t* px = row_begin(row, false);
+          draw(even, 0, px);
+          paint_mean_cov(px, row);
+          row_flush(row);
+        }
+        gather(min(row + 2 * kWaves, last), 0, even, std::true_type{});
+        if (row + kWaves < read_end) {
+          wait_row(odd, true);
+          uint8_t* px = row_begin(row + kWaves, false);
+          draw(odd, 0, px);
+          paint_mean_cov(px, row + kWaves);
+          row_flush(row + kWaves);
         }
       }
-      // head: bytes [0, head) of the row; tail: bytes [tail0, row_bytes)
-      const int head = min((16 - s) & 15, row_bytes);
-      const int tail0 = max(head, ((s + row_bytes) & ~15) - s);
-      if (lane < head) gbase[s + lane] = rb[s + lane];
-      const int t = tail0 + lane - 16;  // lanes 16..31 take the tail
-      if (lane >= 16 && lane < 32 && t < row_bytes) gbase[s + t] = rb[s + t];
     }
-    wave_sync();
+  } else {
+    for (int row = first_read; row < read_end; row += kWaves) {
+      uint8_t* px = row_begin(row, false);
+      for (int cb0 = 0; cb0 < W; cb0 += 64 * kColsPerLane) {
+        RowIn in;
+        gather(row, cb0, in, std::false_type{});
+        wait_row(in, false);
+        draw(in, cb0, px);
+      }
+      paint_mean_cov(px, row);
+      row_flush(row);
+    }
+  }
+
+  // ---- rows below the pileup but inside the mean-coverage paint
+  {
+    int row = read_end + ((wave - read_end) % kWaves + kWaves) % kWaves;
+    for (; row < n_render; row += kWaves) {
+      uint8_t* px = row_begin(row, true);
+      paint_mean_cov(px, row);
+      row_flush(row);
+    }
   }
 
   // ---------------- blank rows: 16-byte zero stores -------------------------
@@ -1144,6 +1272,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
 
   const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
                      3 * static_cast<size_t>(kMaxKept) * ((a.n_channels + 3) / 4) * 4 +
+                     static_cast<size_t>(kMaxKept) * kCigCache * 4 +
                      static_cast<size_t>(kWaves) * a.row_buf_bytes;
   {
     dv::ProfileScope prof(dv::kProfEncoder, stream);
