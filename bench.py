@@ -46,6 +46,8 @@ def parse_args():
                        "'host': host-inclusive -- every step packs the region's candidates and "
                        'reads natively (dv_pack_region), uploads them over PCIe and runs the GPU '
                        'path, double buffered (deepvariant_amd/host_pipeline.py); 1 GPU only')
+  ap.add_argument('--procs', type=int, default=1,
+                  help="--mode bam: host processes sharing the GPU (make_examples --ranks_per_gpu)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample', type=int, default=0,
                   help='candidates in the CPU-baseline sample (0 = auto)')
@@ -440,15 +442,93 @@ def allele_counting(args, host_batch, dev):
   }))
 
 
+def _bam_fixture(tmp):
+  """The bundled NA12878 slice as files: (bam path, fasta path)."""
+  from deepvariant_amd import genomics_io
+  fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'na12878_100kb.npz')
+  with np.load(fixture) as z:
+    bam = os.path.join(tmp, 'NA12878_S1.chr20.10_10p1mb.bam')
+    with open(bam, 'wb') as f:
+      f.write(z['bam'].tobytes())
+    with open(bam + '.bai', 'wb') as f:
+      f.write(z['bai'].tobytes())
+    fasta = os.path.join(tmp, 'ref.fa')
+    lo = int(z['ref_start'][0])
+    genomics_io.write_fasta(fasta, [('chr20', 'N' * lo + z['ref_bases'].tobytes().decode())])
+  return bam, fasta
+
+
+_BAM_DATA = 'BASELINE.json configs[0]: NA12878 30x Illumina, chr20:10,000,000-10,100,000 (reference testdata, bundled)'
+
+
+def _bam_args(me, tmp, bam, fasta, regions, out, extra=()):
+  return me.build_arg_parser().parse_args([
+      '--ref', fasta, '--reads', bam, '--checkpoint', 'random:1234', '--sample_name', 'NA12878',
+      '--channel_list', 'BASE_CHANNELS,insert_size', '--regions', regions, '--call_variants_outfile',
+      os.path.join(tmp, out)] + list(extra))
+
+
+def _bam_rank(rank, world, port, tmp, bam, fasta):
+  """One of `--procs R` host processes sharing GPU 0 (make_examples --ranks_per_gpu R): warm up
+  alone, then the product's distributed runner over the whole slice between two barriers."""
+  import torch.distributed as dist
+  from deepvariant_amd import make_examples as me, tfrecord
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                    MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  devnull = open(os.devnull, 'w')
+  try:
+    me.make_examples_runner(_bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm%d.cvo.tfrecord.gz' % rank),
+                            log=devnull)
+    spec = 'cvo.tfrecord@%d.gz' % world
+    timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', spec,
+                           ['--gpus', '1', '--ranks_per_gpu', str(world)])
+    dist.barrier()
+    t0 = time.perf_counter()
+    stats = me.distributed_runner(timed_args, rank, world, log=devnull)
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0, float(stats['n_regions']), float(stats['n_reads']),
+                            float(stats['n_candidates']), float(stats['n_examples'])], dtype=torch.float64)
+    wall = elapsed[:1].clone()
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.SUM)
+    if rank == 0:
+      from deepvariant_amd import sharded_file_utils
+      n_written = sum(sum(1 for _ in tfrecord.read_tfrecords(sharded_file_utils.sharded_filename(os.path.join(tmp, spec), r)))
+                      for r in range(world))
+      assert n_written == int(elapsed[4]) == stats['n_gathered']
+      print(json.dumps({
+          'metric': 'examples/sec, BAM + FASTA -> CallVariantsOutput (make_examples fused route), %d host '
+                    'processes sharing one GPU (make_examples --gpus 1 --ranks_per_gpu %d)' % (world, world),
+          'value': int(elapsed[4]) / float(wall[0]), 'unit': 'examples/s', 'n_gpus': 1, 'host_processes': world,
+          'data': _BAM_DATA, 'wall_s': float(wall[0]), 'regions': int(elapsed[1]), 'reads': int(elapsed[2]),
+          'candidates': int(elapsed[3]), 'examples': int(elapsed[4]), 'host_cores': os.cpu_count(),
+          'note': 'not the contract metric: inputs start in files on the host; wall = max over ranks between two '
+                  'barriers, includes the final gather of the records and rank 0 writing the %d shard files' % world,
+      }), flush=True)
+  finally:
+    dist.destroy_process_group()
+
+
 def bam_mode(args, log=sys.stderr):
   """BASELINE.json configs[0] end to end on FILES: the reference tree's NA12878 30x Illumina slice
   chr20:10,000,000-10,100,000 (BAM + .bai + FASTA, bundled by tests/golden/make_golden.py
-  na12878_100kb) -> make_examples' fused route -> CallVariantsOutput TFRecord, one host process,
-  one GPU.  Prints its own JSON line (examples/s with per-stage milliseconds and the host's core
-  count); never the contract's `value`, whose inputs are resident in HBM."""
+  na12878_100kb) -> make_examples' fused route -> CallVariantsOutput TFRecord on one GPU.  With
+  --procs 1 one host process (per-stage milliseconds in the line); with --procs R the product's
+  `--ranks_per_gpu R` driver: R processes, regions i % R == r, one GPU.  Prints its own JSON line;
+  never the contract's `value`, whose inputs are resident in HBM."""
   import tempfile
-  from deepvariant_amd import genomics_io, make_examples as me, tfrecord
-  fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'na12878_100kb.npz')
+  from deepvariant_amd import make_examples as me, tfrecord
+  if args.procs > 1:
+    import socket
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+      bam, fasta = _bam_fixture(tmp)
+      with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+      mp.spawn(_bam_rank, args=(args.procs, port, tmp, bam, fasta), nprocs=args.procs, join=True)
+    return
   stage = {}
 
   def timed(label, fn):
@@ -470,25 +550,13 @@ def bam_mode(args, log=sys.stderr):
       return proc
 
   with tempfile.TemporaryDirectory() as tmp:
-    with np.load(fixture) as z:
-      bam = os.path.join(tmp, 'NA12878_S1.chr20.10_10p1mb.bam')
-      with open(bam, 'wb') as f:
-        f.write(z['bam'].tobytes())
-      with open(bam + '.bai', 'wb') as f:
-        f.write(z['bai'].tobytes())
-      fasta = os.path.join(tmp, 'ref.fa')
-      lo = int(z['ref_start'][0])
-      genomics_io.write_fasta(fasta, [('chr20', 'N' * lo + z['ref_bases'].tobytes().decode())])
+    bam, fasta = _bam_fixture(tmp)
     me.RegionReads.__call__ = timed('BAM decode (native) + reads of the region', me.RegionReads.__call__)
     tfrecord.Writer.write = timed('TFRecord(GZIP) write', tfrecord.Writer.write)
-    common = ['--ref', fasta, '--reads', bam, '--checkpoint', 'random:1234', '--sample_name', 'NA12878',
-              '--channel_list', 'BASE_CHANNELS,insert_size']
-    warm = me.build_arg_parser().parse_args(common + [
-        '--regions', 'chr20:10,000,000-10,003,000', '--call_variants_outfile', os.path.join(tmp, 'warm.cvo.tfrecord.gz')])
+    warm = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm.cvo.tfrecord.gz')
     me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=Hooks())     # kernels loaded, graphs captured
     stage.clear()
-    timed_args = me.build_arg_parser().parse_args(common + [
-        '--regions', 'chr20:10,000,000-10,100,000', '--call_variants_outfile', os.path.join(tmp, 'cvo.tfrecord.gz')])
+    timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'cvo.tfrecord.gz')
     t0 = time.perf_counter()
     stats = me.make_examples_runner(timed_args, log=open(os.devnull, 'w'), hooks=Hooks())
     elapsed = time.perf_counter() - t0
@@ -499,7 +567,7 @@ def bam_mode(args, log=sys.stderr):
       'value': stats['n_examples'] / elapsed,
       'unit': 'examples/s',
       'n_gpus': 1,
-      'data': 'BASELINE.json configs[0]: NA12878 30x Illumina, chr20:10,000,000-10,100,000 (reference testdata, bundled)',
+      'data': _BAM_DATA,
       'wall_s': elapsed,
       'regions': stats['n_regions'], 'reads': stats['n_reads'], 'candidates': stats['n_candidates'],
       'examples': stats['n_examples'],
@@ -637,6 +705,13 @@ def pmc_traffic(args, n_items):
       launches = sum(fetch[k][0] for k in conv)
       conv_bytes = (2.0 * sum(fetch[k][1] for k in conv) + sum(write[k][1] for k in conv if k in write)) / launches
       enc_bytes = (2.0 * fetch[enc][1] + write[enc][1]) / passes
+      if os.environ.get('DV_BENCH_PMC_SAVE'):   # per-kernel table of the two passes, for profiles/
+        with open(os.environ['DV_BENCH_PMC_SAVE'], 'w') as f:
+          f.write('# bench.py same-run counter passes (%d forward passes of %d candidates): launches, FETCH_SIZE x2 '
+                  '(gfx950 correction) and WRITE_SIZE in MB per forward pass\n' % (passes, n_items))
+          for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+            f.write('%-90s %5d %12.1f %12.1f\n' % (k[:90], fetch[k][0] // passes, 2.0 * fetch[k][1] / passes / 1e6,
+                                                  write.get(k, (0, 0.0))[1] / passes / 1e6))
       return conv_bytes, enc_bytes, (
           'bytes per launch measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2, gfx950) and '
           '--pmc WRITE_SIZE, separate passes over a child run of %d forward passes, %d conv launches each' % (

@@ -138,6 +138,10 @@ def build_arg_parser() -> argparse.ArgumentParser:
   # (scripts/run_deepvariant.py:457-462) -- N ranks, rank r = task r of --call_variants_outfile name@N,
   # one GPU each, one final all-gather of the CallVariantsOutput records
   ap.add_argument('--gpus', type=int, default=1)
+  # host processes per GPU: the region loop up to the packed batch is host work (BAM decode,
+  # window realigner, candidate caller); R ranks share one GPU, as N make_examples processes share
+  # the reference's call_variants GPU.  world = gpus * ranks_per_gpu, rank r runs on GPU r // R
+  ap.add_argument('--ranks_per_gpu', type=int, default=1)
   return ap
 
 
@@ -238,7 +242,9 @@ def check_flags(args) -> None:
     raise ValueError('--partition_size must be positive')
   if args.gpus < 1:
     raise ValueError('--gpus must be positive')
-  if args.gpus > 1 and not args.call_variants_outfile:
+  if args.ranks_per_gpu < 1:
+    raise ValueError('--ranks_per_gpu must be positive')
+  if args.gpus * args.ranks_per_gpu > 1 and not args.call_variants_outfile:
     raise ValueError('--gpus N shards the fused route (--call_variants_outfile name@N --checkpoint ...); '
                      'for tf.Examples run N independent --task processes, as the reference does')
 
@@ -490,15 +496,18 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
   from deepvariant_amd import dist as dvd
   spec = args.call_variants_outfile
   if not sharded_file_utils.is_sharded_file_spec(spec) or sharded_file_utils.parse_sharded_file_spec(spec)[1] != world:
-    raise ValueError('--gpus %d needs --call_variants_outfile name@%d (one shard per rank)' % (world, world))
+    raise ValueError('--gpus x --ranks_per_gpu = %d ranks need --call_variants_outfile name@%d (one shard per rank)'
+                     % (world, world))
+  import torch.distributed as dist
   args.task = rank
   on_gpu = torch.cuda.is_available()
   if on_gpu:
-    args.device = rank % torch.cuda.device_count()
+    args.device = (rank // max(getattr(args, 'ranks_per_gpu', 1), 1)) % torch.cuda.device_count()
     torch.cuda.set_device(args.device)
   sink = _MemorySink()
   stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
-  device = torch.device('cuda', args.device) if on_gpu else None
+  # RCCL wants one rank per GPU; ranks that share a GPU exchange their (host) records over gloo
+  device = torch.device('cuda', args.device) if on_gpu and dist.get_backend() == 'nccl' else None
   per_rank = dvd.gather_records(sink.records, device=device)
   if rank == 0:
     for r, records in enumerate(per_rank):
@@ -514,13 +523,17 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
   return stats
 
 
+def _backend(args) -> str:
+  import torch
+  return 'nccl' if torch.cuda.is_available() and args.ranks_per_gpu == 1 else 'gloo'
+
+
 def _spawned_rank(rank: int, args, world: int, port: int) -> None:
   import os
-  import torch
   import torch.distributed as dist
   os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                     MASTER_PORT=str(port))
-  dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+  dist.init_process_group(_backend(args), rank=rank, world_size=world)
   try:
     distributed_runner(args, rank, world)
   finally:
@@ -534,18 +547,18 @@ def run_multi_gpu(args) -> None:
   import socket
   import torch
   import torch.distributed as dist
-  world = args.gpus
+  world = args.gpus * args.ranks_per_gpu
   if int(os.environ.get('WORLD_SIZE', '1')) > 1:
     if int(os.environ['WORLD_SIZE']) != world:
-      raise ValueError('--gpus must equal WORLD_SIZE')
-    dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+      raise ValueError('--gpus x --ranks_per_gpu must equal WORLD_SIZE')
+    dist.init_process_group(_backend(args))
     try:
       distributed_runner(args, dist.get_rank(), world)
     finally:
       dist.destroy_process_group()
     return
-  if torch.cuda.is_available() and torch.cuda.device_count() < world:
-    raise ValueError('--gpus %d but only %d GPU(s) are visible' % (world, torch.cuda.device_count()))
+  if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+    raise ValueError('--gpus %d but only %d GPU(s) are visible' % (args.gpus, torch.cuda.device_count()))
   with socket.socket() as sock:
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
@@ -572,7 +585,7 @@ def main(argv=None) -> int:
   args = ap.parse_args(argv)
   try:
     apply_flags_for_calling(ap, args, argv)
-    if args.gpus > 1:
+    if args.gpus * args.ranks_per_gpu > 1:
       check_flags(args)
       run_multi_gpu(args)
     else:

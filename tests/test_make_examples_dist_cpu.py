@@ -58,11 +58,11 @@ def _args(tmp, out, extra=()):
       list(extra))
 
 
-def _rank(rank, world, port, tmp):
+def _rank(rank, world, port, tmp, flags):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
-    args = _args(tmp, os.path.join(tmp, 'gathered.cvo.tfrecord@%d.gz' % world), ['--gpus', str(world)])
+    args = _args(tmp, os.path.join(tmp, 'gathered.cvo.tfrecord@%d.gz' % world), flags)
     me.distributed_runner(args, rank, world, log=open(os.devnull, 'w'), hooks=_StubHooks())
   finally:
     dist.destroy_process_group()
@@ -77,8 +77,10 @@ def _fixture(tmp):
   return len(reads)
 
 
+# two GPUs with one rank each, or one GPU shared by two host processes: the same two tasks
+@pytest.mark.parametrize('flags', [['--gpus', '2'], ['--gpus', '1', '--ranks_per_gpu', '2']], ids=['gpus2', 'ranks_per_gpu2'])
 @pytest.mark.timeout(600)
-def test_two_ranks_write_what_two_tasks_write(tmp_path):
+def test_two_ranks_write_what_two_tasks_write(tmp_path, flags):
   tmp = str(tmp_path)
   n_reads = _fixture(tmp)
   world = 2
@@ -92,7 +94,7 @@ def test_two_ranks_write_what_two_tasks_write(tmp_path):
   assert sum(len(x) for x in independent) <= n_reads
   # the node-level driver: two ranks over gloo, one gather, rank 0 writes both shards
   port = _free_port()
-  mp.spawn(_rank, args=(world, port, tmp), nprocs=world, join=True)
+  mp.spawn(_rank, args=(world, port, tmp, flags), nprocs=world, join=True)
   for task in range(world):
     got = list(tfrecord.read_tfrecords(os.path.join(tmp, 'gathered.cvo.tfrecord-%05d-of-%05d.gz' % (task, world))))
     assert got == independent[task]
@@ -108,3 +110,7 @@ def test_flag_checks():
   me.check_flags(args)
   with pytest.raises(ValueError, match='one shard per rank'):
     me.distributed_runner(args, 0, 2)
+  with pytest.raises(ValueError, match='fused route'):
+    me.check_flags(ap.parse_args(['--ref', 'r', '--reads', 'b', '--examples', 'e@2.gz', '--ranks_per_gpu', '2']))
+  with pytest.raises(ValueError, match='ranks_per_gpu'):
+    me.check_flags(ap.parse_args(['--ref', 'r', '--reads', 'b', '--examples', 'e.gz', '--ranks_per_gpu', '0']))
