@@ -489,7 +489,7 @@ def _bam_rank(rank, world, port, tmp, bam, fasta):
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0, float(stats['n_regions']), float(stats['n_reads']),
                             float(stats['n_candidates']), float(stats['n_examples'])], dtype=torch.float64)
-    wall = elapsed[:1].clone()
+    wall = torch.tensor([elapsed[0], stats['loop_s'], stats['setup_s']], dtype=torch.float64)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     dist.all_reduce(elapsed, op=dist.ReduceOp.SUM)
     if rank == 0:
@@ -501,10 +501,15 @@ def _bam_rank(rank, world, port, tmp, bam, fasta):
           'metric': 'examples/sec, BAM + FASTA -> CallVariantsOutput (make_examples fused route), %d host '
                     'processes sharing one GPU (make_examples --gpus 1 --ranks_per_gpu %d)' % (world, world),
           'value': int(elapsed[4]) / float(wall[0]), 'unit': 'examples/s', 'n_gpus': 1, 'host_processes': world,
-          'data': _BAM_DATA, 'wall_s': float(wall[0]), 'regions': int(elapsed[1]), 'reads': int(elapsed[2]),
+          'data': _BAM_DATA, 'wall_s': float(wall[0]), 'region_loop_s_max_over_ranks': float(wall[1]),
+          'setup_s_max_over_ranks': float(wall[2]),
+          'examples_per_s_region_loop_only': int(elapsed[4]) / float(wall[1]),
+          'regions': int(elapsed[1]), 'reads': int(elapsed[2]),
           'candidates': int(elapsed[3]), 'examples': int(elapsed[4]), 'host_cores': os.cpu_count(),
           'note': 'not the contract metric: inputs start in files on the host; wall = max over ranks between two '
-                  'barriers, includes the final gather of the records and rank 0 writing the %d shard files' % world,
+                  'barriers, includes every rank building its model and loading weights (setup_s: a fixed cost, '
+                  'large against this 100 kb slice), the final gather of the records and rank 0 writing the %d shard '
+                  'files' % world,
       }), flush=True)
   finally:
     dist.destroy_process_group()
@@ -568,7 +573,8 @@ def bam_mode(args, log=sys.stderr):
       'unit': 'examples/s',
       'n_gpus': 1,
       'data': _BAM_DATA,
-      'wall_s': elapsed,
+      'wall_s': elapsed, 'region_loop_s': stats['loop_s'], 'setup_s': stats['setup_s'],
+      'examples_per_s_region_loop_only': stats['n_examples'] / stats['loop_s'],
       'regions': stats['n_regions'], 'reads': stats['n_reads'], 'candidates': stats['n_candidates'],
       'examples': stats['n_examples'],
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},

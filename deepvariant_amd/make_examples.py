@@ -358,7 +358,8 @@ class RegionReads:
     self._args = args
     self._contig = None
     self._lo = self._hi = 0
-    self._reads = []
+    self._make = None
+    self._reads = {}
     self._starts = np.zeros(0, np.int64)
     self._ends = np.zeros(0, np.int64)
     self._max_span = 0
@@ -370,7 +371,10 @@ class RegionReads:
         keep_duplicates=_true(a.keep_duplicates), keep_supplementary=_true(a.keep_supplementary_alignments),
         keep_secondary=_true(a.keep_secondary_alignments),
         use_original_quality_scores=_true(a.use_original_quality_scores))
-    self._reads = table.to_reads(contig)
+    # Read objects are built on demand (a task of N touches 1/N of the block's reads) and kept
+    # for the neighbouring region, which shares the reads that straddle the boundary
+    self._make = table.read_factory(contig)
+    self._reads = {}
     self._starts = table.read_pos.astype(np.int64)
     self._ends = table.read_end.astype(np.int64)
     if self._starts.size > 1 and np.any(np.diff(self._starts) < 0):
@@ -384,7 +388,16 @@ class RegionReads:
     first = int(np.searchsorted(self._starts, region.start - self._max_span, side='left'))
     last = int(np.searchsorted(self._starts, region.end, side='left'))      # start < region.end
     keep = np.nonzero(self._ends[first:last] > region.start)[0] + first      # end > region.start
-    return [self._reads[i] for i in keep.tolist()]
+    out, cache, make = [], self._reads, self._make
+    for i in keep.tolist():
+      r = cache.get(i)
+      if r is None:
+        r = cache[i] = make(i)
+      out.append(r)
+    if first > 0 and len(cache) > 4 * len(out) + 4096:   # rows before this region are never asked for again
+      for i in [i for i in cache if i < first]:
+        del cache[i]
+    return out
 
 
 class RunnerHooks:
@@ -399,7 +412,9 @@ class RunnerHooks:
     from deepvariant_amd.inception_v3 import InceptionV3
     shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
              len(options.pic_options.channels))
-    model = InceptionV3(shape, max_batch=1024, device=args.device)
+    # activations are allocated for max_batch examples (6 MB each); R processes sharing a GPU
+    # each own a model, and a 1 kb region rarely yields more than a few dozen examples
+    model = InceptionV3(shape, max_batch=1024 if args.ranks_per_gpu == 1 else 256, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
     return model
 
@@ -408,6 +423,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   """-> stats; writes the task's example shard (and its example_info.json) or the CVO file.
   `sink` (write(bytes), close()) replaces the task's TFRecord file: the multi-GPU driver keeps
   a rank's records in memory for the final gather."""
+  import time
+  t_start = time.perf_counter()
   hooks = hooks or RunnerHooks()
   check_flags(args)
   ref_reader = genomics_io.FastaReader(args.ref)
@@ -445,6 +462,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
     return stats
   writer = sink if sink is not None else tfrecord.Writer(out_path)
   image_shape = None
+  t_loop = time.perf_counter()
+  stats['setup_s'] = t_loop - t_start        # flags, region list, processor, model + weights
   try:
     for region in pieces:
       in_reads = reads_for(region)
@@ -462,6 +481,7 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
       stats['n_examples'] += len(records)
   finally:
     writer.close()
+  stats['loop_s'] = time.perf_counter() - t_loop   # the region loop proper (BAM decode to the last record written)
   if model is None:
     pic = options.pic_options
     image_shape = [make_examples_native.calculate_pileup_image_height(options), pic.width, len(pic.channels)]

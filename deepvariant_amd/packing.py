@@ -173,107 +173,120 @@ class ReadTable:
   base_aux0: Optional[np.ndarray] = None  # is_homopolymer pixel per base
   base_aux1: Optional[np.ndarray] = None  # homopolymer_weighted pixel per base
 
+  @staticmethod
+  def _pack_read(r, need_aux: bool) -> tuple:
+    """Everything from_reads needs from one Read, in packed form: (alignment object, position,
+    mapq, flags, fragment length, bases, qualities, 5mC | None, 6mA | None, CIGAR words, end,
+    aux row | None, key, sort key).  Kept on the Read (`_dv_packed`): a region's reads are packed
+    several times (window selection, candidate calling, the encoder's batch) and most of them
+    are the same objects each time -- the realigner builds NEW Read objects for the reads it
+    moves, so a cached record is valid as long as `alignment` is still the object it was made
+    from (checked by the caller)."""
+    aln = r.alignment
+    p = aln.position.position
+    if not -(1 << 31) <= p < (1 << 31):
+      raise ValueError('alignment position does not fit int32')
+    mq = aln.mapping_quality
+    if not 0 <= mq <= 255:
+      raise ValueError('mapping_quality %d outside [0, 255]' % mq)
+    f = 0
+    if aln.position.reverse_strand:
+      f |= DV_READ_REVERSE
+    if getattr(r, 'supplementary_alignment', False):
+      f |= DV_READ_SUPPLEMENTARY
+    seq = r.aligned_sequence
+    sb = seq.encode() if isinstance(seq, str) else bytes(seq)
+    qb = bytes(bytearray(r.aligned_quality))
+    if len(qb) != len(sb):
+      raise ValueError('aligned_quality and aligned_sequence differ in length '
+                       'for read %s' % r.fragment_name)
+    mods = getattr(r, 'base_modifications', None) or {}
+    mod_bytes = [None, None]
+    for k, (key, bit) in enumerate(((T.K5MC, DV_READ_HAS_5MC), (T.K6MA, DV_READ_HAS_6MA))):
+      if key in mods:
+        mb = bytes(mods[key])
+        if len(mb) != len(sb):
+          raise ValueError('base_modifications length mismatch')
+        mod_bytes[k] = mb
+        f |= bit
+    e = p
+    qlen = 0
+    match_len = gap_len = 0
+    cig = []
+    for cu in aln.cigar:
+      op, ln = int(cu.operation), int(cu.operation_length)
+      if not 1 <= op <= 9:
+        raise ValueError('Unrecognized CIGAR op')  # reference: LOG(FATAL)
+      if not 0 <= ln < (1 << 28):
+        raise ValueError('CIGAR operation_length out of range')
+      cig.append((ln << 4) | op)
+      if op in (1, 8, 9, 3, 4):
+        e += ln
+      if op in (1, 2, 5, 8, 9):
+        qlen += ln
+      if op in (1, 8):
+        match_len += ln
+        gap_len += ln
+      elif op == 9:
+        gap_len += ln
+      elif op in (2, 3):
+        gap_len += 1
+    if qlen > len(sb):
+      raise ValueError('CIGAR consumes more bases than aligned_sequence has')
+    aux_row = None
+    if need_aux:
+      # read_mapping_percent / identity (identical arithmetic),
+      # avg_base_quality, gap_compressed_identity -- channels/*.cc.
+      aux_row = [0] * _lib.DV_READ_AUX_STRIDE
+      f32 = np.float32
+      pct = int(f32(match_len) / f32(max(len(sb), 1)) * f32(100)) if sb else 0
+      aux_row[0] = _scale_color(pct, 100)
+      aux_row[2] = _scale_color(pct, 100)
+      if qb:
+        if max(qb) > 93:
+          raise ValueError('Encountered base quality outside of bounds (0,93)')
+        aux_row[1] = _scale_color(int(f32(sum(qb)) / f32(len(qb))), 93)
+      if gap_len:
+        aux_row[3] = _scale_color(
+            int(f32(match_len) / f32(gap_len) * f32(100)), 100)
+      aux_row[4] = gc_content_pixel(sb)
+    return (aln, p, mq, f, r.fragment_length, sb, qb, mod_bytes[0], mod_bytes[1], cig, e, aux_row,
+            read_key(r), (r.fragment_name.encode(), int(r.read_number)))
+
   @classmethod
   def from_reads(cls, reads: Sequence, alignment_positions=None,
                  need_aux: bool = False, need_seq_aux: bool = False) -> 'ReadTable':
     n = len(reads)
-    pos = np.zeros(n, np.int32)
-    mapq = np.zeros(n, np.uint8)
-    flags = np.zeros(n, np.uint8)
-    frag = np.zeros(n, np.int32)
-    hp = np.full(n, _lib.DV_HP_NONE, np.int32)
+    recs = []
+    for r in reads:
+      rec = getattr(r, '_dv_packed', None)
+      if rec is None or rec[0] is not r.alignment or (need_aux and rec[11] is None):
+        rec = cls._pack_read(r, need_aux)
+        try:
+          r._dv_packed = rec   # pylint: disable=protected-access
+        except AttributeError:   # a real protobuf message: no cache
+          pass
+      recs.append(rec)
+    pos = np.array([x[1] for x in recs], np.int32).reshape(n)
+    mapq = np.array([x[2] for x in recs], np.uint8).reshape(n)
+    flags = np.array([x[3] for x in recs], np.uint8).reshape(n)
+    frag = np.array([x[4] for x in recs], np.int32).reshape(n)
+    hp = np.array([_hp_value(r) for r in reads], np.int32).reshape(n)
+    seqs = [x[5] for x in recs]
+    quals = [x[6] for x in recs]
     seq_off = np.zeros(n + 1, np.uint32)
+    np.cumsum([len(x) for x in seqs], out=seq_off[1:])
     cig_off = np.zeros(n + 1, np.uint32)
-    read_end = np.zeros(n, np.int64)
-    seqs, quals, cig = [], [], []
-    m5, m6 = [], []
-    any5 = any6 = False
-    aux = np.zeros((n, _lib.DV_READ_AUX_STRIDE), np.uint8) if need_aux else None
-    keys, sort_keys = [], []
-    for i, r in enumerate(reads):
-      aln = r.alignment
-      p = aln.position.position
-      if not -(1 << 31) <= p < (1 << 31):
-        raise ValueError('alignment position does not fit int32')
-      pos[i] = p
-      mq = aln.mapping_quality
-      if not 0 <= mq <= 255:
-        raise ValueError('mapping_quality %d outside [0, 255]' % mq)
-      mapq[i] = mq
-      f = 0
-      if aln.position.reverse_strand:
-        f |= DV_READ_REVERSE
-      if getattr(r, 'supplementary_alignment', False):
-        f |= DV_READ_SUPPLEMENTARY
-      frag[i] = r.fragment_length
-      hp[i] = _hp_value(r)
-      seq = r.aligned_sequence
-      sb = seq.encode() if isinstance(seq, str) else bytes(seq)
-      qb = bytes(bytearray(r.aligned_quality))
-      if len(qb) != len(sb):
-        raise ValueError('aligned_quality and aligned_sequence differ in length '
-                         'for read %s' % r.fragment_name)
-      seqs.append(sb)
-      quals.append(qb)
-      seq_off[i + 1] = seq_off[i] + len(sb)
-      mods = getattr(r, 'base_modifications', None) or {}
-      for key, store, bit in ((T.K5MC, m5, DV_READ_HAS_5MC),
-                              (T.K6MA, m6, DV_READ_HAS_6MA)):
-        if key in mods:
-          mb = bytes(mods[key])
-          if len(mb) != len(sb):
-            raise ValueError('base_modifications length mismatch')
-          store.append(mb)
-          f |= bit
-          if bit == DV_READ_HAS_5MC:
-            any5 = True
-          else:
-            any6 = True
-        else:
-          store.append(b'\0' * len(sb))
-      flags[i] = f
-      e = p
-      qlen = 0
-      match_len = gap_len = 0
-      for cu in aln.cigar:
-        op, ln = int(cu.operation), int(cu.operation_length)
-        if not 1 <= op <= 9:
-          raise ValueError('Unrecognized CIGAR op')  # reference: LOG(FATAL)
-        if not 0 <= ln < (1 << 28):
-          raise ValueError('CIGAR operation_length out of range')
-        cig.append((ln << 4) | op)
-        if op in (1, 8, 9, 3, 4):
-          e += ln
-        if op in (1, 2, 5, 8, 9):
-          qlen += ln
-        if op in (1, 8):
-          match_len += ln
-          gap_len += ln
-        elif op == 9:
-          gap_len += ln
-        elif op in (2, 3):
-          gap_len += 1
-      if qlen > len(sb):
-        raise ValueError('CIGAR consumes more bases than aligned_sequence has')
-      read_end[i] = e
-      cig_off[i + 1] = cig_off[i] + len(aln.cigar)
-      if need_aux:
-        # read_mapping_percent / identity (identical arithmetic),
-        # avg_base_quality, gap_compressed_identity -- channels/*.cc.
-        f32 = np.float32
-        pct = int(f32(match_len) / f32(max(len(sb), 1)) * f32(100)) if sb else 0
-        aux[i, 0] = _scale_color(pct, 100)
-        aux[i, 2] = _scale_color(pct, 100)
-        if qb:
-          if max(qb) > 93:
-            raise ValueError('Encountered base quality outside of bounds (0,93)')
-          aux[i, 1] = _scale_color(int(f32(sum(qb)) / f32(len(qb))), 93)
-        if gap_len:
-          aux[i, 3] = _scale_color(
-              int(f32(match_len) / f32(gap_len) * f32(100)), 100)
-        aux[i, 4] = gc_content_pixel(sb)
-      keys.append(read_key(r))
-      sort_keys.append((r.fragment_name.encode(), int(r.read_number)))
+    np.cumsum([len(x[9]) for x in recs], out=cig_off[1:])
+    cig = [w for x in recs for w in x[9]]
+    read_end = np.array([x[10] for x in recs], np.int64).reshape(n)
+    any5 = any(x[7] is not None for x in recs)
+    any6 = any(x[8] is not None for x in recs)
+    m5 = [x[7] if x[7] is not None else b'\0' * len(x[5]) for x in recs] if any5 else []
+    m6 = [x[8] if x[8] is not None else b'\0' * len(x[5]) for x in recs] if any6 else []
+    aux = np.array([x[11] for x in recs], np.uint8).reshape(n, _lib.DV_READ_AUX_STRIDE) if need_aux else None
+    keys = [x[12] for x in recs]
+    sort_keys = [x[13] for x in recs]
     # dense rank under the reference's tuple<string,int> ordering
     uniq = sorted(set(sort_keys))
     rank_of = {k: j for j, k in enumerate(uniq)}
@@ -351,6 +364,13 @@ class ReadTable:
     stages (realigner glue, phasing) take.  The table does not keep pairing / QC flags (the
     native reader has already applied the read requirements), so number_reads is 2 and those
     flags are False."""
+    make = self.read_factory(reference_name)
+    return [make(i) for i in range(self.n_reads)]
+
+  def read_factory(self, reference_name: str):
+    """-> f(i) = the Read object of table row i.  The table's arrays are unpacked into Python
+    lists once, so a caller that needs only some rows (make_examples.RegionReads: the reads of the
+    regions of ITS task) pays object construction for those rows only."""
     seq = self.bases.tobytes().decode('latin-1')
     quals = self.quals.tobytes()
     seq_off = self.read_seq_off.tolist()
@@ -362,22 +382,35 @@ class ReadTable:
     flags = self.read_flags.tolist()
     frag = self.read_frag_len.tolist()
     hp = self.read_hp.tolist()
-    out = []
-    for i in range(self.n_reads):
-      name, _, number = self.keys[i].rpartition('/')
+    keys = self.keys
+    raw = self.bases.tobytes()
+    words = self.cigar.tolist()
+    ends = self.read_end.tolist()
+    plain = self.mod_5mc is None and self.mod_6ma is None
+    strand_bits = DV_READ_REVERSE | DV_READ_SUPPLEMENTARY
+
+    def make(i: int):
+      name, _, number = keys[i].rpartition('/')
       info = {}
       if hp[i] != _lib.DV_HP_NONE:
         info['HP'] = T.ListValue(values=[T.Value(int_value=hp[i])])
-      out.append(T.Read(
+      s0, s1 = seq_off[i], seq_off[i + 1]
+      aln = T.LinearAlignment(
+          position=T.Position(reference_name, pos[i], bool(flags[i] & DV_READ_REVERSE)),
+          mapping_quality=mapq[i],
+          cigar=[T.CigarUnit(ops[k], lens[k]) for k in range(cig_off[i], cig_off[i + 1])])
+      read = T.Read(
           fragment_name=name, read_number=int(number), number_reads=2,
           supplementary_alignment=bool(flags[i] & DV_READ_SUPPLEMENTARY), fragment_length=frag[i],
-          aligned_sequence=seq[seq_off[i]:seq_off[i + 1]], aligned_quality=quals[seq_off[i]:seq_off[i + 1]],
-          alignment=T.LinearAlignment(
-              position=T.Position(reference_name, pos[i], bool(flags[i] & DV_READ_REVERSE)),
-              mapping_quality=mapq[i],
-              cigar=[T.CigarUnit(ops[k], lens[k]) for k in range(cig_off[i], cig_off[i + 1])]),
-          info=info))
-    return out
+          aligned_sequence=seq[s0:s1], aligned_quality=quals[s0:s1], alignment=aln, info=info)
+      if plain:
+        # the row this Read was made from IS its packed form (ReadTable._pack_read's record):
+        # from_reads on a list that contains it copies instead of walking the object again
+        read._dv_packed = (aln, pos[i], mapq[i], flags[i] & strand_bits, frag[i], raw[s0:s1], quals[s0:s1], None,
+                           None, words[cig_off[i]:cig_off[i + 1]], ends[i], None, keys[i],
+                           (name.encode(), int(number)))
+      return read
+    return make
 
   def query(self, start: int, end: int) -> np.ndarray:
     """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""
