@@ -322,3 +322,36 @@ def test_make_examples_cli_end_to_end(tmp_path):
       assert np.allclose(fused[(variant.start, tuple(alt))], probs, atol=1e-6)
       n += 1
   assert n == 84
+
+
+@pytest.mark.timeout(900)
+def test_make_examples_two_ranks_sharing_the_gpu(tmp_path):
+  """The product multi-rank driver on real hardware: `make_examples --gpus 1 --ranks_per_gpu 2`
+  spawns two host processes that share this GPU (own model each, regions i % 2 == r, fused route),
+  gathers their CallVariantsOutput records once and lets rank 0 write both shards.  Each shard
+  must be byte-identical to what an independent `--task r` run of the same command writes (the
+  reference's way of producing them: scripts/run_deepvariant.py:457-462)."""
+  from deepvariant_amd import genomics_io
+  from deepvariant_amd import make_examples as me
+  from deepvariant_amd import tfrecord
+  from tests import realigner_fixture as RF
+  ref, sets = RF.load()
+  stretch_start = 9_995_000
+  fasta = str(tmp_path / 'ref.fa')
+  genomics_io.write_fasta(fasta, [('chr20', 'N' * stretch_start + ref.get_bases('chr20', stretch_start, 10_100_600))])
+  bam = str(tmp_path / 'reads.bam')
+  genomics_io.write_bam(bam, [('chr20', 10_100_600)], sets['wgs'], sample_name='NA12878')
+  common = ['--ref', fasta, '--reads', bam, '--regions', 'chr20:10,000,000-10,010,000', '--sample_name', 'NA12878',
+            '--channel_list', ','.join(T.PILEUP_CHANNELS_WITH_INSERT_SIZE), '--checkpoint', 'random:7']
+  tasks = str(tmp_path / 'tasks.cvo.tfrecord@2.gz')
+  for task in (0, 1):
+    assert me.main(common + ['--call_variants_outfile', tasks, '--task', str(task)]) == 0
+  ranks = str(tmp_path / 'ranks.cvo.tfrecord@2.gz')
+  assert me.main(common + ['--call_variants_outfile', ranks, '--gpus', '1', '--ranks_per_gpu', '2']) == 0
+  total = 0
+  for r in (0, 1):
+    want = list(tfrecord.read_tfrecords(str(tmp_path / ('tasks.cvo.tfrecord-%05d-of-00002.gz' % r))))
+    got = list(tfrecord.read_tfrecords(str(tmp_path / ('ranks.cvo.tfrecord-%05d-of-00002.gz' % r))))
+    assert got == want and len(got) > 10
+    total += len(got)
+  assert total == 84
