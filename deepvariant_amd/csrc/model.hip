@@ -1544,6 +1544,21 @@ struct dv_model {
       buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
     }
     choose_chains();
+    if (getenv("DV_CHAIN_KEEP_HALO") == nullptr) {
+      // A fused chain DMAs the INTERIOR of its input into LDS and handles the map border itself
+      // (tap masks, the zero piece): its input tensor needs no halo in HBM.  Without one the rows
+      // of a map are contiguous (a 4x12 map plane is 768 bytes = six whole 128-byte lines), so the
+      // 1x1 head that produces the tensor stores whole lines instead of 192-byte row segments that
+      // start mid-line, and the chain's input DMA is one run per plane.
+      for (BufferDesc& b : buffers) b.halo = 0;
+      for (const Op& op : ops) {
+        if (op.in_chain) continue;
+        int need = 0;
+        if (op.type == kOpConv && op.chain_len == 0) need = std::max(op.pad_h, op.pad_w);
+        if (op.type == kOpAvgPool) need = 1;
+        buffers[op.in_buf].halo = std::max(buffers[op.in_buf].halo, need);
+      }
+    }
     choose_imgconv();
     choose_band();
     for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
