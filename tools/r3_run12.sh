@@ -1,3 +1,4 @@
+# NOTE: the DV_CHAIN_STAGGER knob this script sweeps was removed after the run (no effect; profiles/r03_chain2d_ab.txt)
 # round 3, GPU run 12: do the chain kernels' output stores leave as one burst?  DV_CHAIN_STAGGER = cycles between the
 # starts of 8 phase groups of workgroups; bench A/B + the chain phase profile with and without
 set -x

@@ -1,3 +1,4 @@
+# NOTE: gemm1x1_kernel and its DV_NO_GEMM1X1 knob were removed after this run (slower; profiles/r03_gemm1x1_experiment.txt)
 # round 3, GPU run 14: gemm1x1_kernel (grouped 1x1 heads, both operands through LDS): bit-identity, per-launch table, A/B
 set -x
 O=gpurun_out/r3o
