@@ -260,6 +260,23 @@ def test_region_reads_equal_a_linear_scan(tmp_path, monkeypatch):
         (r.fragment_name, r.read_number, r.alignment.position.position) for r in want]
     n_total += len(got)
   assert n_total > len(every)            # reads that straddle region borders are returned by both sides
+  # Read objects are built on demand and shared by neighbouring regions; rows behind the current
+  # region are dropped from the cache.  Order of the calls must not matter: every second region
+  # (a task of two), then the same regions backwards, give the same reads, and a read returned for
+  # two regions in a row is ONE object (its packed record travels with it).
+  def names(rs):
+    return [(r.fragment_name, r.read_number, r.alignment.position.position) for r in rs]
+  starts = list(range(lo, hi, 300))
+  forward = {s0: names(reads_for(T.Range('chr20', s0, s0 + 300))) for s0 in starts[::2]}
+  backward = {s0: names(reads_for(T.Range('chr20', s0, s0 + 300))) for s0 in reversed(starts[::2])}
+  assert forward == backward
+  straddled = [k for k in range(len(starts) - 1)
+               if any(s < starts[k + 1] < e for s, e in zip(table.read_pos.tolist(), table.read_end.tolist()))]
+  k = straddled[len(straddled) // 2]
+  a = reads_for(T.Range('chr20', starts[k], starts[k] + 300))          # (re)loads a block that holds both regions
+  b = reads_for(T.Range('chr20', starts[k + 1], starts[k + 1] + 300))
+  shared = {id(r) for r in a} & {id(r) for r in b}
+  assert shared and all(hasattr(r, '_dv_packed') for r in a)
 
 
 def test_the_two_output_routes_exclude_each_other():
