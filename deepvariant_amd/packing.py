@@ -14,6 +14,7 @@ from __future__ import annotations
 import os
 
 import dataclasses
+import functools
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -149,6 +150,49 @@ def _hp_value(read) -> int:
   return int(values[0].int_value)
 
 
+class LazyRead(T.Read):
+  """A Read made from a row of a packed table (ReadTable.read_factory) whose `alignment` -- a
+  LinearAlignment, a Position and one CigarUnit per operation: most of what building a Read costs
+  -- is created on first access.  Most reads of a calling region are never asked for it: window
+  selection, allele counting and the encoder's batch take the packed row the read carries
+  (`_dv_packed`), spans come from it too (realigner.utils.read_range); only the reads the realigner
+  assigns to a window are looked at as objects.  Everything else is an ordinary dv_types.Read."""
+
+  def __getattr__(self, name):
+    # reached only when normal lookup fails: `alignment` has a default_factory, so the class has no
+    # attribute of that name and an instance made without __init__ lands here
+    if name == 'alignment':
+      d = self.__dict__
+      build = d.pop('_dv_alignment', None)
+      if build is not None:
+        aln = d['alignment'] = build()
+        rec = d.get('_dv_packed')
+        if rec is not None and rec[0] is None:
+          d['_dv_packed'] = (aln,) + rec[1:]     # from now on the record is tied to this object
+        return aln
+    raise AttributeError(name)
+
+  def __eq__(self, other):
+    if not isinstance(other, T.Read):
+      return NotImplemented
+    return all(getattr(self, f.name) == getattr(other, f.name) for f in dataclasses.fields(T.Read))
+
+  __hash__ = None
+
+
+def packed_record(read):
+  """The read's cached ReadTable._pack_read record if it is still valid, else None: valid while
+  `alignment` is the object the record was made from, or -- a LazyRead -- has not been built."""
+  rec = getattr(read, '_dv_packed', None)
+  if rec is None:
+    return None
+  d = getattr(read, '__dict__', None)
+  aln = d.get('alignment') if d is not None else read.alignment
+  if aln is None:
+    return rec if rec[0] is None and '_dv_alignment' in d else None
+  return rec if rec[0] is aln else None
+
+
 @dataclasses.dataclass
 class ReadTable:
   """Structure-of-arrays image of a list of Read protos (one region)."""
@@ -259,8 +303,8 @@ class ReadTable:
     n = len(reads)
     recs = []
     for r in reads:
-      rec = getattr(r, '_dv_packed', None)
-      if rec is None or rec[0] is not r.alignment or (need_aux and rec[11] is None):
+      rec = packed_record(r)
+      if rec is None or (need_aux and rec[11] is None):
         rec = cls._pack_read(r, need_aux)
         try:
           r._dv_packed = rec   # pylint: disable=protected-access
@@ -389,26 +433,34 @@ class ReadTable:
     plain = self.mod_5mc is None and self.mod_6ma is None
     strand_bits = DV_READ_REVERSE | DV_READ_SUPPLEMENTARY
 
+    def make_alignment(i: int):
+      return T.LinearAlignment(
+          position=T.Position(reference_name, pos[i], bool(flags[i] & DV_READ_REVERSE)),
+          mapping_quality=mapq[i],
+          cigar=[T.CigarUnit(ops[k], lens[k]) for k in range(cig_off[i], cig_off[i + 1])])
+
     def make(i: int):
       name, _, number = keys[i].rpartition('/')
       info = {}
       if hp[i] != _lib.DV_HP_NONE:
         info['HP'] = T.ListValue(values=[T.Value(int_value=hp[i])])
       s0, s1 = seq_off[i], seq_off[i + 1]
-      aln = T.LinearAlignment(
-          position=T.Position(reference_name, pos[i], bool(flags[i] & DV_READ_REVERSE)),
-          mapping_quality=mapq[i],
-          cigar=[T.CigarUnit(ops[k], lens[k]) for k in range(cig_off[i], cig_off[i + 1])])
-      read = T.Read(
-          fragment_name=name, read_number=int(number), number_reads=2,
-          supplementary_alignment=bool(flags[i] & DV_READ_SUPPLEMENTARY), fragment_length=frag[i],
-          aligned_sequence=seq[s0:s1], aligned_quality=quals[s0:s1], alignment=aln, info=info)
-      if plain:
-        # the row this Read was made from IS its packed form (ReadTable._pack_read's record):
-        # from_reads on a list that contains it copies instead of walking the object again
-        read._dv_packed = (aln, pos[i], mapq[i], flags[i] & strand_bits, frag[i], raw[s0:s1], quals[s0:s1], None,
-                           None, words[cig_off[i]:cig_off[i + 1]], ends[i], None, keys[i],
-                           (name.encode(), int(number)))
+      if not plain:
+        return T.Read(
+            fragment_name=name, read_number=int(number), number_reads=2,
+            supplementary_alignment=bool(flags[i] & DV_READ_SUPPLEMENTARY), fragment_length=frag[i],
+            aligned_sequence=seq[s0:s1], aligned_quality=quals[s0:s1], alignment=make_alignment(i), info=info)
+      # the row this Read is made from IS its packed form (ReadTable._pack_read's record, alignment
+      # slot empty until the object exists): from_reads on a list that contains it copies the row
+      read = object.__new__(LazyRead)
+      read.__dict__ = {
+          'fragment_name': name, 'read_number': int(number), 'number_reads': 2, 'proper_placement': False,
+          'duplicate_fragment': False, 'failed_vendor_quality_checks': False, 'secondary_alignment': False,
+          'supplementary_alignment': bool(flags[i] & DV_READ_SUPPLEMENTARY), 'fragment_length': frag[i],
+          'aligned_sequence': seq[s0:s1], 'aligned_quality': quals[s0:s1], 'info': info, 'base_modifications': {},
+          '_dv_alignment': functools.partial(make_alignment, i), '_dv_contig': reference_name,
+          '_dv_packed': (None, pos[i], mapq[i], flags[i] & strand_bits, frag[i], raw[s0:s1], quals[s0:s1], None, None,
+                         words[cig_off[i]:cig_off[i + 1]], ends[i], None, keys[i], (name.encode(), int(number)))}
       return read
     return make
 

@@ -25,6 +25,13 @@ def make_range(reference_name: str, start: int, end: int) -> T.Range:
 
 def read_range(read) -> T.Range:
   """utils.read_range: alignment start .. start + reference bases the CIGAR covers."""
+  d = getattr(read, '__dict__', None)
+  if d is not None and 'alignment' not in d:
+    # a packing.LazyRead whose alignment has not been built: the span is in the packed table row
+    # it carries (same definition: start + the reference bases of M / = / X / D / N)
+    rec = d.get('_dv_packed')
+    if rec is not None and rec[0] is None and '_dv_alignment' in d:
+      return T.Range(d['_dv_contig'], rec[1], rec[10])
   p = read.alignment.position
   n = sum(c.operation_length for c in read.alignment.cigar if c.operation in REF_ADVANCING_OPS)
   return T.Range(p.reference_name, p.position, p.position + n)

@@ -66,3 +66,35 @@ def test_aux_columns_are_added_to_a_record_cached_without_them():
   with_aux = packing.ReadTable.from_reads(made, need_aux=True)
   want = packing.ReadTable.from_reads(reads, need_aux=True)
   assert with_aux.read_aux is not None and np.array_equal(with_aux.read_aux, want.read_aux)
+
+
+def test_lazy_reads_build_their_alignment_on_first_access_only():
+  """ReadTable.read_factory hands out packing.LazyRead objects: everything but `alignment` is there
+  at once; spans (realigner.utils.read_range) and tables (from_reads) come from the packed row
+  without building it; the first access builds exactly what an eager Read holds."""
+  from deepvariant_amd.realigner import utils as U
+  reads = _reads(300)
+  table = packing.ReadTable.from_reads(reads)
+  made = table.to_reads('chr20')
+  assert all(isinstance(r, packing.LazyRead) and isinstance(r, T.Read) and 'alignment' not in r.__dict__ for r in made)
+  spans = [U.read_range(r) for r in made]
+  again = packing.ReadTable.from_reads(made)
+  assert all('alignment' not in r.__dict__ for r in made)           # neither needed the objects
+  _same(table, again)
+  for r, src, span in zip(made, reads, spans):
+    assert span == U.read_range(src)                                # from the row == from the CIGAR
+    assert r.alignment == src.alignment and 'alignment' in r.__dict__
+    assert U.read_range(r) == span                                  # ... and again from the object
+    assert (r.fragment_name, r.read_number, r.aligned_sequence, bytes(r.aligned_quality), r.fragment_length) == (
+        src.fragment_name, src.read_number, src.aligned_sequence, bytes(bytearray(src.aligned_quality)), src.fragment_length)
+  _same(table, packing.ReadTable.from_reads(made))                  # records now tied to the built alignments
+  # a lazy read equals the eager Read with the same content, both ways round
+  eager = T.Read(fragment_name=made[0].fragment_name, read_number=made[0].read_number, number_reads=2,
+                 fragment_length=made[0].fragment_length, aligned_sequence=made[0].aligned_sequence,
+                 aligned_quality=made[0].aligned_quality, alignment=made[0].alignment, info=dict(made[0].info))
+  assert made[0] == eager and eager == made[0] and made[1] != eager
+  # dataclasses.replace (make_examples_core copies reads before tagging them) builds the alignment and a full object
+  fresh = table.to_reads('chr20')[5]
+  tagged = dataclasses.replace(fresh, info={'HP': T.ListValue(values=[T.Value(int_value=1)])})
+  assert tagged.alignment == reads[5].alignment and not hasattr(tagged, '_dv_packed')
+  assert int(packing.ReadTable.from_reads([tagged]).read_hp[0]) == 1
