@@ -45,8 +45,16 @@ def _bgzf_blocks(path: str) -> Iterator[bytes]:
     pos += bsize
 
 
+def is_cram(path: str) -> bool:
+  with open(path, 'rb') as f:
+    return f.read(4) == b'CRAM'
+
+
 def bam_contig_names(path: str) -> List[str]:
-  """The @SQ names of a BAM header, inflating only the blocks the header spans."""
+  """The @SQ names of a BAM (or CRAM) header, inflating only the blocks the header spans."""
+  if is_cram(path):
+    from deepvariant_amd import cram_reader
+    return cram_reader.cram_contig_names(path)
   buf = b''
   need = 12
   names: List[str] = []

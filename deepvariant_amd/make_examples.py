@@ -10,7 +10,8 @@ realigner -> device allele counts -> candidate caller -> (read phasing) -> devic
 Flags that belong to machinery outside this path (training labels, gVCF, population VCFs,
 candidate import, multi-sample roles, sharded runtime profiles ...) are rejected when set,
 never silently ignored.  Reads come through the native BAM reader (dv_bam_read_region: plain BAM,
-.bai region queries; no CRAM).
+.bai region queries) or, for a CRAM 3.0 file, through deepvariant_amd/cram_reader.py with --ref as
+its reference (--use_ref_for_cram, the reference's default).
 """
 from __future__ import annotations
 
@@ -110,6 +111,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--types_to_alt_align', default='indels')
   ap.add_argument('--parse_sam_aux_fields', default='false', **boolean)     # the HP tag is always read
   ap.add_argument('--keep_duplicates', default='false', **boolean)
+  ap.add_argument('--use_ref_for_cram', default='true', **boolean)   # make_examples_options.py:80-89
   ap.add_argument('--use_original_quality_scores', default='false', **boolean)   # qualities from the OQ tag
   ap.add_argument('--keep_supplementary_alignments', default='false', **boolean)
   ap.add_argument('--keep_secondary_alignments', default='false', **boolean)
@@ -359,6 +361,7 @@ class RegionReads:
     self._contig = None
     self._lo = self._hi = 0
     self._make = None
+    self._ref = None
     self._reads = {}
     self._starts = np.zeros(0, np.int64)
     self._ends = np.zeros(0, np.int64)
@@ -366,11 +369,21 @@ class RegionReads:
 
   def _load(self, contig: str, lo: int, hi: int) -> None:
     a = self._args
-    table = packing.ReadTable.from_bam(
-        a.reads, contig, lo, hi, min_mapping_quality=a.min_mapping_quality,
-        keep_duplicates=_true(a.keep_duplicates), keep_supplementary=_true(a.keep_supplementary_alignments),
-        keep_secondary=_true(a.keep_secondary_alignments),
+    requirements = dict(
+        min_mapping_quality=a.min_mapping_quality, keep_duplicates=_true(a.keep_duplicates),
+        keep_supplementary=_true(a.keep_supplementary_alignments), keep_secondary=_true(a.keep_secondary_alignments),
         use_original_quality_scores=_true(a.use_original_quality_scores))
+    if genomics_io.is_cram(a.reads):
+      # sam_reader.cc:560-640: htslib decodes against --ref (use_ref_for_cram) or the slices' own
+      # embedded reference; without either the file cannot be parsed
+      fetch = None
+      if _true(a.use_ref_for_cram):
+        if self._ref is None:
+          self._ref = genomics_io.FastaReader(a.ref)
+        fetch = self._ref.get_bases
+      table = packing.ReadTable.from_cram(a.reads, fetch, contig, lo, hi, **requirements)
+    else:
+      table = packing.ReadTable.from_bam(a.reads, contig, lo, hi, **requirements)
     # Read objects are built on demand (a task of N touches 1/N of the block's reads) and kept
     # for the neighbouring region, which shares the reads that straddle the boundary
     self._make = table.read_factory(contig)

@@ -355,6 +355,25 @@ class ReadTable:
                                   [np.zeros(0, np.uint8)]) if need_seq_aux else None))
 
   @classmethod
+  def from_cram(cls, path: str, fetch_reference, contig: Optional[str] = None, start: int = 0,
+                end: int = 1 << 62, min_mapping_quality: int = 0, keep_duplicates: bool = False,
+                keep_supplementary: bool = False, keep_secondary: bool = False, keep_failed_qc: bool = False,
+                keep_improperly_placed: bool = False, use_original_quality_scores: bool = False) -> 'ReadTable':
+    """CRAM 3.0 -> packed table: the same reads, in the same order, `from_bam` yields for the BAM
+    of the same alignments (deepvariant_amd/cram_reader.py decodes on the host;
+    `fetch_reference(contig, start, end)` supplies the bases a CRAM written against an external
+    reference leaves out -- the reference's --use_ref_for_cram)."""
+    from deepvariant_amd import cram_reader
+    from deepvariant_amd import genomics_io
+    _, reads = cram_reader.read_cram(path, fetch_reference, contig, start, min(end, 1 << 62),
+                                     use_original_quality_scores=use_original_quality_scores)
+    kept = [r for r in reads if genomics_io.read_satisfies_requirements(
+        r, min_mapping_quality=min_mapping_quality, keep_duplicates=keep_duplicates, keep_failed_qc=keep_failed_qc,
+        keep_secondary=keep_secondary, keep_supplementary=keep_supplementary,
+        keep_improperly_placed=keep_improperly_placed)]
+    return cls.from_reads(kept)
+
+  @classmethod
   def from_bam(cls, path: str, contig: Optional[str] = None, start: int = 0,
                end: int = 1 << 62, min_mapping_quality: int = 0,
                keep_duplicates: bool = False, keep_supplementary: bool = False,

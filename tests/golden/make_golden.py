@@ -543,3 +543,28 @@ def main_na12878_100kb():
 
 if __name__ == '__main__' and 'na12878_100kb' in sys.argv[1:]:
   main_na12878_100kb()
+
+
+def main_cram():
+  """CRAM fixtures: the reference tree's NA12878 slice as CRAM 3.0 (the file its make_examples
+  test runs with USE_CRAM, deepvariant/make_examples_test.py:330-369; the same alignments as the BAM
+  bundled in na12878_100kb.npz) and nucleus' own CRAM test files with their SAM text and FASTA
+  (third_party/nucleus/io/sam_test.py:250-300)."""
+  nucleus = os.path.join(os.path.dirname(REF), '..', 'third_party', 'nucleus', 'testdata')
+  files = {
+      'na12878_cram': os.path.join(REF, 'input/NA12878_S1.chr20.10_10p1mb.cram'),
+      'na12878_crai': os.path.join(REF, 'input/NA12878_S1.chr20.10_10p1mb.cram.crai'),
+      'nucleus_embed_ref_0': os.path.join(nucleus, 'test_cram.embed_ref_0_version_3.0.cram'),
+      'nucleus_embed_ref_1': os.path.join(nucleus, 'test_cram.embed_ref_1_version_3.0.cram'),
+      'nucleus_sam': os.path.join(nucleus, 'test_cram.sam'),
+      'nucleus_fasta': os.path.join(nucleus, 'test.fasta'),
+  }
+  d = {k: np.frombuffer(open(v, 'rb').read(), np.uint8) for k, v in files.items()}
+  for k, v in d.items():
+    print(k, v.size)
+  np.savez_compressed(os.path.join(ROOT, 'tests/golden/cram.npz'), **d)
+
+
+if __name__ == '__main__' and 'cram' in sys.argv[1:]:
+  main_cram()
+

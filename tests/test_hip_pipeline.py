@@ -355,3 +355,36 @@ def test_make_examples_two_ranks_sharing_the_gpu(tmp_path):
     assert got == want and len(got) > 10
     total += len(got)
   assert total == 84
+
+
+@pytest.mark.timeout(900)
+def test_make_examples_from_the_cram_reproduces_the_goldens(tmp_path):
+  """deepvariant/make_examples_test.py:330-369 (TestConditions.USE_CRAM): the same golden examples from
+  the CRAM form of the NA12878 slice, decoded against --ref (deepvariant_amd/cram_reader.py): all 84
+  golden images of chr20:10,000,000-10,010,000, bit for bit."""
+  from deepvariant_amd import genomics_io
+  from deepvariant_amd import make_examples as me
+  from deepvariant_amd import protowire as pw
+  from deepvariant_amd import tfrecord
+  golden_dir = os.path.join(os.path.dirname(__file__), 'golden')
+  with np.load(os.path.join(golden_dir, 'cram.npz')) as z:
+    cram = str(tmp_path / 'NA12878_S1.chr20.10_10p1mb.cram')
+    with open(cram, 'wb') as f:
+      f.write(z['na12878_cram'].tobytes())
+  with np.load(os.path.join(golden_dir, 'na12878_100kb.npz')) as z:
+    fasta = str(tmp_path / 'ref.fa')
+    genomics_io.write_fasta(fasta, [('chr20', 'N' * int(z['ref_start'][0]) + z['ref_bases'].tobytes().decode())])
+  out = str(tmp_path / 'examples.tfrecord.gz')
+  assert me.main(['--ref', fasta, '--reads', cram, '--regions', 'chr20:10,000,000-10,010,000', '--sample_name', 'NA12878',
+                  '--channel_list', ','.join(T.PILEUP_CHANNELS_WITH_INSERT_SIZE), '--examples', out]) == 0
+  images = {}
+  for rec in tfrecord.read_tfrecords(out, verify_crc=True):
+    ex = pw.decode_example(rec)
+    v = pw.decode_variant(ex['variant/encoded'][0])
+    idx = tuple(pw.decode_alt_allele_indices(ex['alt_allele_indices/encoded'][0]))
+    images[(v.start, tuple(v.alternate_bases[i] for i in idx))] = np.frombuffer(
+        ex['image/encoded'][0], np.uint8).reshape(ex['image/shape'])
+  _, golden, _ = golden_io.load(os.path.join(golden_dir, 'illumina_wgs_chr20.npz'))
+  assert len(images) == len(golden) == 84
+  for ex in golden:
+    assert np.array_equal(images[(ex['call'].variant.start, tuple(ex['alt_alleles']))], ex['image'])
