@@ -531,7 +531,99 @@ int inflate_member(FILE* f, uint64_t coff, std::vector<uint8_t>* out, size_t* cs
   return DV_OK;
 }
 
-// Indexed read: only the BGZF members the .bai points at are read and inflated.
+// ---- .csi index (CSIv1, samtools/hts-specs): the .bai scheme with a configurable leaf size (min_shift) and
+// depth, one `loffset` per bin instead of the 16 kb linear index, the whole file BGZF-compressed.
+// htslib writes it for contigs longer than 2^29 (`samtools index -c`) and reads it wherever it reads a .bai.
+int csi_chunks(const std::string& csi_path, int32_t ref, int64_t start, int64_t end, std::vector<Chunk>* chunks) {
+  FILE* f = std::fopen(csi_path.c_str(), "rb");
+  if (!f) return dv::fail(DV_ERR_BAD_INPUT, "cannot open " + csi_path);
+  std::vector<uint8_t> d;
+  {
+    struct Closer {
+      FILE* f;
+      ~Closer() { std::fclose(f); }
+    } closer{f};
+    uint64_t coff = 0;
+    for (;;) {
+      size_t csize = 0;
+      if (int rc = inflate_member(f, coff, &d, &csize)) return rc;
+      if (csize == 0) break;
+      coff += csize;
+    }
+  }
+  if (d.size() < 16 || std::memcmp(d.data(), "CSI\1", 4) != 0) return dv::fail(DV_ERR_BAD_INPUT, "bad CSI file: " + csi_path);
+  auto le64 = [&](size_t p) { return static_cast<uint64_t>(le32(&d[p])) | (static_cast<uint64_t>(le32(&d[p + 4])) << 32); };
+  const int min_shift = static_cast<int32_t>(le32(&d[4])), depth = static_cast<int32_t>(le32(&d[8]));
+  const int32_t l_aux = static_cast<int32_t>(le32(&d[12]));
+  if (min_shift < 0 || min_shift > 40 || depth < 0 || depth > 12 || l_aux < 0) return dv::fail(DV_ERR_BAD_INPUT, "bad CSI header");
+  size_t p = 16 + static_cast<size_t>(l_aux);
+  if (p + 4 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated CSI");
+  const int32_t n_ref = static_cast<int32_t>(le32(&d[p]));
+  p += 4;
+  if (ref >= n_ref) return dv::fail(DV_ERR_BAD_INPUT, "CSI has fewer references than the BAM");
+  const int64_t max_pos = 1ll << (min_shift + 3 * depth);
+  if (end > max_pos) end = max_pos;
+  if (start < 0) start = 0;
+  // reg2bins at every level; and the bins on the path from the leaf of `start` to the root, whose first
+  // existing loffset bounds the chunks from below (htslib hts_itr_query)
+  std::vector<uint64_t> bins, path;
+  for (int l = 0; l <= depth; ++l) {
+    const uint64_t t = ((1ull << (3 * l)) - 1) / 7;
+    const int s = min_shift + 3 * (depth - l);
+    if (end > start) {
+      for (uint64_t k = t + (static_cast<uint64_t>(start) >> s); k <= t + (static_cast<uint64_t>(end - 1) >> s); ++k) bins.push_back(k);
+    }
+    path.push_back(t + (static_cast<uint64_t>(start) >> s));
+  }
+  const uint64_t meta_bin = ((1ull << (3 * (depth + 1))) - 1) / 7 + 1;
+  std::vector<Chunk> found;
+  std::vector<uint64_t> path_off(path.size(), 0);
+  std::vector<bool> path_has(path.size(), false);
+  for (int32_t r = 0; r <= ref; ++r) {
+    if (p + 4 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated CSI");
+    const int32_t n_bin = static_cast<int32_t>(le32(&d[p]));
+    p += 4;
+    for (int32_t b = 0; b < n_bin; ++b) {
+      if (p + 16 > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated CSI");
+      const uint64_t bin = le32(&d[p]);
+      const uint64_t loffset = le64(p + 4);
+      const int32_t n_chunk = static_cast<int32_t>(le32(&d[p + 12]));
+      p += 16;
+      if (n_chunk < 0 || p + 16ull * n_chunk > d.size()) return dv::fail(DV_ERR_BAD_INPUT, "truncated CSI");
+      if (r == ref && bin != meta_bin) {
+        if (std::find(bins.begin(), bins.end(), bin) != bins.end()) {
+          for (int32_t c = 0; c < n_chunk; ++c) found.push_back({le64(p + 16 * c), le64(p + 16 * c + 8)});
+        }
+        for (size_t k = 0; k < path.size(); ++k) {
+          if (path[k] == bin) {
+            path_off[k] = loffset;
+            path_has[k] = true;
+          }
+        }
+      }
+      p += 16ull * n_chunk;
+    }
+  }
+  uint64_t min_off = 0;
+  for (size_t k = path.size(); k-- > 0;) {   // deepest existing bin on the path
+    if (path_has[k]) {
+      min_off = path_off[k];
+      break;
+    }
+  }
+  std::sort(found.begin(), found.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+  for (const Chunk& c : found) {
+    if (c.end <= min_off) continue;
+    if (!chunks->empty() && c.beg <= chunks->back().end) {
+      chunks->back().end = std::max(chunks->back().end, c.end);
+    } else {
+      chunks->push_back(c);
+    }
+  }
+  return DV_OK;
+}
+
+// Indexed read: only the BGZF members the .bai (or .csi) points at are read and inflated.
 int read_indexed(const char* path, const std::string& bai, const char* contig, RegionFilter f,
                  dv_read_table* t) {
   FILE* fp = std::fopen(path, "rb");
@@ -554,7 +646,11 @@ int read_indexed(const char* path, const std::string& bai, const char* contig, R
   }
   if (f.want_ref < 0) return dv::fail(DV_ERR_BAD_INPUT, std::string("contig not in the BAM header: ") + contig);
   std::vector<Chunk> chunks;
-  if (int rc = bai_chunks(bai, f.want_ref, f.start, f.end, &chunks)) return rc;
+  const bool is_csi = bai.size() > 4 && bai.compare(bai.size() - 4, 4, ".csi") == 0;
+  if (int rc = is_csi ? csi_chunks(bai, f.want_ref, f.start, f.end, &chunks)
+                      : bai_chunks(bai, f.want_ref, f.start, f.end, &chunks)) {
+    return rc;
+  }
   for (const Chunk& c : chunks) {
     buf.clear();
     uint64_t next = c.beg >> 16;                 // file offset of the next member to inflate
@@ -608,8 +704,8 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   // <path>.bai or <path minus .bam>.bai: seek + inflate only what the region needs
   std::string bai;
   if (contig && getenv("DV_BAM_NO_INDEX") == nullptr) {
-    for (const std::string& cand : {std::string(path) + ".bai",
-                                    std::string(path).substr(0, std::strlen(path) > 4 ? std::strlen(path) - 4 : 0) + ".bai"}) {
+    const std::string stem = std::string(path).substr(0, std::strlen(path) > 4 ? std::strlen(path) - 4 : 0);
+    for (const std::string& cand : {std::string(path) + ".bai", stem + ".bai", std::string(path) + ".csi", stem + ".csi"}) {
       if (FILE* f = std::fopen(cand.c_str(), "rb")) {
         std::fclose(f);
         bai = cand;

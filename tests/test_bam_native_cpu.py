@@ -298,3 +298,72 @@ def test_long_cigar_in_the_cg_tag(tmp_path):
   assert int(nat.read_cigar_off[2]) - c1 == 3
   # the region test uses the real span: a window past the placeholder-free end finds nothing
   assert packing.ReadTable.from_bam(path, 'chrA', 1000 + span + 5, 1000 + span + 50).n_reads == 0
+
+
+def _bai_to_csi(bai: bytes, depth: int) -> bytes:
+  """The same index as a CSIv1 file (hts-specs CSIv1.tex): min_shift 14, `depth` levels (5 = the
+  .bai's own bins; 6 = one more level on top, so every bin moves one level down with the same
+  offset inside its level), loffset of a bin = the linear-index entry of its first 16 kb window."""
+  assert bai[:4] == b'BAI\x01' and depth in (5, 6)
+  n_ref = struct.unpack_from('<i', bai, 4)[0]
+  p = 8
+  out = bytearray(b'CSI\x01' + struct.pack('<iii', 14, depth, 0) + struct.pack('<i', n_ref))
+  level_first = [((1 << (3 * l)) - 1) // 7 for l in range(8)]
+  for _ in range(n_ref):
+    n_bin = struct.unpack_from('<i', bai, p)[0]
+    p += 4
+    bins = []
+    for _b in range(n_bin):
+      b, n_chunk = struct.unpack_from('<Ii', bai, p)
+      p += 8
+      chunks = bai[p:p + 16 * n_chunk]
+      p += 16 * n_chunk
+      bins.append((b, n_chunk, chunks))
+    n_intv = struct.unpack_from('<i', bai, p)[0]
+    p += 4
+    linear = struct.unpack_from('<%dQ' % n_intv, bai, p)
+    p += 8 * n_intv
+    out += struct.pack('<i', n_bin)
+    for b, n_chunk, chunks in bins:
+      if b == 37450:                       # the metadata pseudo-bin: its number depends on the depth
+        new_bin, loffset = ((1 << (3 * (depth + 1))) - 1) // 7 + 1, 0
+      else:
+        level = max(l for l in range(6) if level_first[l] <= b)
+        k = b - level_first[level]
+        new_bin = level_first[level + depth - 5] + k
+        window = (k << (14 + 3 * (5 - level))) >> 14
+        loffset = linear[window] if window < n_intv else 0
+      out += struct.pack('<IQi', new_bin, loffset, n_chunk) + chunks
+  return _bgzf(bytes(out), block=60000)
+
+
+@pytest.mark.parametrize('depth', [5, 6])
+def test_csi_indexed_read_equals_bai_and_full_scan(tmp_path, depth, monkeypatch):
+  """A BAM indexed with .csi (what `samtools index -c` writes, needed for contigs beyond 2^29 bases;
+  htslib reads it wherever it reads a .bai) is queried through the same chunk logic: bins of every
+  level + the deepest existing bin's loffset.  Same reads as with the .bai and as the full scan."""
+  monkeypatch.delenv('DV_BAM_NO_INDEX', raising=False)
+  with np.load(os.path.join(os.path.dirname(__file__), 'golden', 'na12878_100kb.npz')) as z:
+    bam, bai = z['bam'].tobytes(), z['bai'].tobytes()
+  with_bai = str(tmp_path / 'a.bam')
+  with_csi = str(tmp_path / 'c.bam')
+  for path in (with_bai, with_csi):
+    with open(path, 'wb') as f:
+      f.write(bam)
+  with open(with_bai + '.bai', 'wb') as f:
+    f.write(bai)
+  with open(with_csi + '.csi', 'wb') as f:
+    f.write(_bai_to_csi(bai, depth))
+  for start, end in ((10_000_000, 10_001_000), (10_049_000, 10_066_500), (9_990_000, 10_000_050), (10_099_000, 10_200_000)):
+    a = packing.ReadTable.from_bam(with_bai, 'chr20', start, end, min_mapping_quality=5)
+    c = packing.ReadTable.from_bam(with_csi, 'chr20', start, end, min_mapping_quality=5)
+    _assert_same(a, c)
+    assert a.n_reads > 0
+  monkeypatch.setenv('DV_BAM_NO_INDEX', '1')
+  full = packing.ReadTable.from_bam(with_csi, 'chr20', 10_049_000, 10_066_500, min_mapping_quality=5)
+  monkeypatch.delenv('DV_BAM_NO_INDEX')
+  _assert_same(full, packing.ReadTable.from_bam(with_csi, 'chr20', 10_049_000, 10_066_500, min_mapping_quality=5))
+  # the index was really used: a .csi that points nowhere yields nothing
+  with open(with_csi + '.csi', 'wb') as f:
+    f.write(_bgzf(b"CSI\x01" + struct.pack("<iii", 14, depth, 0) + struct.pack("<i", 25) + struct.pack("<i", 0) * 25, block=60000))
+  assert packing.ReadTable.from_bam(with_csi, 'chr20', 10_049_000, 10_066_500).n_reads == 0
