@@ -552,11 +552,16 @@ def bam_mode(args, log=sys.stderr):
       proc.candidates_in_region = timed('allele counts (device) + candidate caller', proc.candidates_in_region)
       proc.generator.call_variants_in_region = timed(
           'pack + encode + classify (device) + CallVariantsOutput protos', proc.generator.call_variants_in_region)
+      proc.realign_table = timed('realign (window selection on the device, assembly, alignment)', proc.realign_table)
+      if os.environ.get('DV_REGION_OBJECTS') is None:   # (nested inside candidates_in_region on the object path)
+        proc.variant_caller.calls_from_allele_counter = timed(
+            'allele counts (device) + candidate caller', proc.variant_caller.calls_from_allele_counter)
       return proc
 
   with tempfile.TemporaryDirectory() as tmp:
     bam, fasta = _bam_fixture(tmp)
     me.RegionReads.__call__ = timed('BAM decode (native) + reads of the region', me.RegionReads.__call__)
+    me.RegionReads.table = timed('BAM decode (native) + rows of the region', me.RegionReads.table)
     tfrecord.Writer.write = timed('TFRecord(GZIP) write', tfrecord.Writer.write)
     warm = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm.cvo.tfrecord.gz')
     me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=Hooks())     # kernels loaded, graphs captured
@@ -576,7 +581,7 @@ def bam_mode(args, log=sys.stderr):
       'wall_s': elapsed, 'region_loop_s': stats['loop_s'], 'setup_s': stats['setup_s'],
       'examples_per_s_region_loop_only': stats['n_examples'] / stats['loop_s'],
       'regions': stats['n_regions'], 'reads': stats['n_reads'], 'candidates': stats['n_candidates'],
-      'examples': stats['n_examples'],
+      'examples': stats['n_examples'], 'table_path': stats.get('table_path'),
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
       'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
       'host_cores': os.cpu_count(),

@@ -134,6 +134,24 @@ class FastPassAligner:
       res.append((out[i].status, out[i].position, cig))
     return res
 
+  def align_reads_arrays(self, sequences: Sequence):
+    """AlignReads on bare sequences, results as arrays (the table path of the realigner):
+    -> (status int32[n], position int64[n], cigar_off int64[n + 1], CIGAR words uint32[...] in the
+    packed tables' encoding); status as in `align_reads`."""
+    import numpy as np
+    n = len(sequences)
+    self._n_reads += n
+    out = (_lib.DvRealignedRead * max(n, 1))()
+    words = C.POINTER(C.c_uint32)()
+    _lib.check(_lib.lib().dv_aligner_align_reads(self._h, n, _strings(sequences), out, C.byref(words)))
+    rec = np.frombuffer(out, dtype=np.dtype([('status', '<i4'), ('n_cigar', '<i4'), ('position', '<i8'),
+                                             ('cigar_off', '<u4'), ('reserved', '<u4')]), count=max(n, 1))[:n]
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(rec['n_cigar'], out=off[1:])
+    total = int(off[-1])
+    w = np.ctypeslib.as_array(words, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
+    return rec['status'].copy(), rec['position'].copy(), off, w
+
   def realign_reads(self, reads: Sequence) -> List[Optional[T.Read]]:
     """FastPassAligner::AlignReads on Read objects (fast_pass_aligner.cc:183-232, :510-590):
     per input read the read with its new alignment, the unchanged read (no better alignment,

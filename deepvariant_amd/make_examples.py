@@ -387,6 +387,7 @@ class RegionReads:
     # Read objects are built on demand (a task of N touches 1/N of the block's reads) and kept
     # for the neighbouring region, which shares the reads that straddle the boundary
     self._make = table.read_factory(contig)
+    self._table = table
     self._reads = {}
     self._starts = table.read_pos.astype(np.int64)
     self._ends = table.read_end.astype(np.int64)
@@ -395,12 +396,21 @@ class RegionReads:
     self._max_span = int((self._ends - self._starts).max()) if self._starts.size else 0
     self._contig, self._lo, self._hi = contig, lo, hi
 
-  def __call__(self, region: T.Range) -> list:
+  def _rows(self, region: T.Range):
     if region.reference_name != self._contig or region.start < self._lo or region.end > self._hi:
       self._load(region.reference_name, region.start, max(region.end, region.start + self.BLOCK_BASES))
     first = int(np.searchsorted(self._starts, region.start - self._max_span, side='left'))
     last = int(np.searchsorted(self._starts, region.end, side='left'))      # start < region.end
-    keep = np.nonzero(self._ends[first:last] > region.start)[0] + first      # end > region.start
+    return first, np.nonzero(self._ends[first:last] > region.start)[0] + first      # end > region.start
+
+  def table(self, region: T.Range) -> 'packing.ReadTable':
+    """The same reads as a packed table (rows of the decoded block): what the region chain's table
+    path takes (make_examples_core.RegionProcessor.*_table) -- no Read objects at all."""
+    _, keep = self._rows(region)
+    return self._table.take(keep)
+
+  def __call__(self, region: T.Range) -> list:
+    first, keep = self._rows(region)
     out, cache, make = [], self._reads, self._make
     for i in keep.tolist():
       r = cache.get(i)
@@ -475,10 +485,31 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
     return stats
   writer = sink if sink is not None else tfrecord.Writer(out_path)
   image_shape = None
+  # the table path (no Read objects between the BAM decoder and the encoder) where the
+  # configuration allows it; DV_REGION_OBJECTS=1 forces the object path (A/B, tests)
+  import os
+  use_tables = os.environ.get('DV_REGION_OBJECTS') is None and getattr(proc, 'table_path_ok', lambda: False)()
+  stats['table_path'] = bool(use_tables)
   t_loop = time.perf_counter()
   stats['setup_s'] = t_loop - t_start        # flags, region list, processor, model + weights
   try:
     for region in pieces:
+      if use_tables:
+        in_table = reads_for.table(region)
+        if 0 < args.max_reads_per_partition < in_table.n_reads:     # the same draws on row numbers
+          in_table = in_table.take(np.array(reservoir_sample(range(in_table.n_reads), args.max_reads_per_partition,
+                                                             np.random.RandomState(_RANDOM_SEED)), np.int64))
+        stats['n_regions'] += 1
+        stats['n_reads'] += in_table.n_reads
+        if model is not None:
+          candidates, records = proc.call_variants_in_region_table(region, in_table, model)
+        else:
+          candidates, records = proc.examples_in_region_table(region, in_table)
+        for rec in records:
+          writer.write(rec)
+        stats['n_candidates'] += len(candidates)
+        stats['n_examples'] += len(records)
+        continue
       in_reads = reads_for(region)
       if args.max_reads_per_partition > 0:
         in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))

@@ -20,6 +20,7 @@ outside SURVEY.md section 8.
 from __future__ import annotations
 
 import dataclasses
+import numpy as np
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 from deepvariant_amd import allelecounter
@@ -282,6 +283,64 @@ class RegionProcessor:
         padding = int((region.end - region.start) * po.phase_reads_region_padding_pct / 100)
         padded = utils.expand(region, padding, self.ref_reader.n_bases(region.reference_name))
     return self.candidates_in_region(region, realigned, padded), realigned
+
+  # ---- the table path: the region's reads stay a packed table from the BAM decoder to the
+  # encoder (make_examples.RegionReads.table); no Read objects.  It covers the default short-read
+  # calling configuration; everything that works on Read objects (read phasing, spliced-read
+  # splitting, trimmed / alt-aligned pileups, channels with per-read aux pixels) takes the
+  # object path above.
+  def table_path_ok(self) -> bool:
+    from deepvariant_amd import alt_aligned_pileup_lib as aap
+    po, gen = self.processor_options, self.generator
+    sample = self.options.sample_options[0]
+    return (not po.phase_reads and
+            not (self.realigner is not None and self.realigner.config.split_skip_reads) and
+            gen._alt_mode == aap.NONE and                                      # pylint: disable=protected-access
+            not getattr(self.options, 'trim_reads_for_pileup', False) and
+            not sample.keep_only_window_spanning_reads and
+            not gen._encoder_api._need_aux and not gen._encoder_api._need_seq_aux)   # pylint: disable=protected-access
+
+  def realign_table(self, table, region: T.Range):
+    """realign_reads on a table: reads longer than max_read_length_to_realign bypass the
+    realigner and come first."""
+    if self.realigner is None or table.n_reads == 0:
+      return table
+    limit = self.processor_options.max_read_length_to_realign
+    if limit == 0:
+      return self.realigner.realign_table(table, region)[1]
+    lengths = np.diff(table.read_seq_off.astype(np.int64))
+    long_rows = np.nonzero(lengths > limit)[0]
+    if not len(long_rows):
+      return self.realigner.realign_table(table, region)[1]
+    short = self.realigner.realign_table(table.take(np.nonzero(lengths <= limit)[0]), region)[1]
+    return packing.concat_tables([table.take(long_rows), short])
+
+  def process_table(self, region: T.Range, table) -> Tuple[List[T.DeepVariantCall], 'packing.ReadTable']:
+    realigned = self.realign_table(table, region)
+    rows = np.nonzero((realigned.read_end > region.start) & (region.end > realigned.read_pos.astype(np.int64)))[0]
+    if not len(rows):
+      return [], realigned
+    in_region = realigned.take(rows)
+    positions = ()
+    if self.processor_options.track_ref_reads:
+      first_pass = self._allele_counter(region, in_region)
+      positions = self.variant_caller.call_positions_from_allele_counter(first_pass)
+    candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(region, in_region, positions))
+    return candidates, realigned
+
+  def examples_in_region_table(self, region: T.Range, table, stats: Optional[dict] = None
+                               ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
+    candidates, realigned = self.process_table(region, table)
+    if not candidates:
+      return candidates, []
+    examples, _ = self.generator.encode_region(candidates, [realigned], [0], [0.0], stats if stats is not None else {})
+    return candidates, examples
+
+  def call_variants_in_region_table(self, region: T.Range, table, model) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
+    candidates, realigned = self.process_table(region, table)
+    if not candidates:
+      return candidates, []
+    return candidates, self.generator.call_variants_in_region(candidates, [realigned], [0], [0.0], model)
 
   def examples_in_region(self, region: T.Range, reads: Sequence, stats: Optional[dict] = None
                          ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:

@@ -483,10 +483,95 @@ class ReadTable:
       return read
     return make
 
+  # ---- the table as the unit the region chain passes along (make_examples' table path): rows
+  # are selected and realigned as arrays; no Read objects in between
+  @staticmethod
+  def _segments(offsets: np.ndarray, rows: np.ndarray):
+    """Indices of the elements of the variable-length segments `rows` of a flat array with
+    `offsets`, concatenated in that order, and the new offsets."""
+    off = offsets.astype(np.int64)
+    starts, lengths = off[rows], off[rows + 1] - off[rows]
+    new_off = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum(lengths, out=new_off[1:])
+    total = int(new_off[-1])
+    idx = np.arange(total, dtype=np.int64) + np.repeat(starts - new_off[:-1], lengths)
+    return idx, new_off
+
+  def take(self, rows) -> 'ReadTable':
+    """The table of the given rows, in the given order (a region's reads out of a decoded block,
+    the reads the realigner returns in its own order, ...)."""
+    rows = np.asarray(rows, np.int64)
+    seq_idx, seq_off = self._segments(self.read_seq_off, rows)
+    cig_idx, cig_off = self._segments(self.read_cigar_off, rows)
+    ranks = np.unique(self.read_name_rank[rows], return_inverse=True)[1].astype(np.uint32) if len(rows) else \
+        np.zeros(0, np.uint32)
+    per_base = lambda a: None if a is None else a[seq_idx]     # noqa: E731
+    keys = self.keys
+    return ReadTable(
+        n_reads=len(rows), read_pos=self.read_pos[rows],
+        read_sort_pos=None if self.read_sort_pos is None else self.read_sort_pos[rows],
+        read_seq_off=seq_off.astype(np.uint32), read_cigar_off=cig_off.astype(np.uint32),
+        read_mapq=self.read_mapq[rows], read_flags=self.read_flags[rows], read_frag_len=self.read_frag_len[rows],
+        read_hp=self.read_hp[rows], read_name_rank=ranks.reshape(len(rows)),
+        read_aux=None if self.read_aux is None else self.read_aux[rows],
+        bases=self.bases[seq_idx], quals=self.quals[seq_idx], mod_5mc=per_base(self.mod_5mc),
+        mod_6ma=per_base(self.mod_6ma), cigar=self.cigar[cig_idx], keys=[keys[i] for i in rows.tolist()],
+        read_end=self.read_end[rows], base_aux0=per_base(self.base_aux0), base_aux1=per_base(self.base_aux1))
+
+  def with_alignments(self, rows, positions, cigars: Sequence[np.ndarray]) -> 'ReadTable':
+    """A copy in which row rows[k] starts at positions[k] with the CIGAR words cigars[k]
+    (what FastPassAligner::RealignReadsToReference changes of a read, fast_pass_aligner.cc:510-590);
+    everything else is shared with `self`."""
+    if not len(rows):
+      return self
+    off = self.read_cigar_off.astype(np.int64)
+    pieces = [self.cigar[off[i]:off[i + 1]] for i in range(self.n_reads)]
+    pos = self.read_pos.copy()
+    end = self.read_end.copy()
+    for r, p, words in zip(np.asarray(rows).tolist(), np.asarray(positions).tolist(), cigars):
+      words = np.asarray(words, np.uint32)
+      pieces[r] = words
+      pos[r] = p
+      ops = words & 15
+      end[r] = p + int((words >> 4)[(ops == 1) | (ops == 8) | (ops == 9) | (ops == 3) | (ops == 4)].sum())
+    new_off = np.zeros(self.n_reads + 1, np.uint32)
+    np.cumsum([len(x) for x in pieces], out=new_off[1:])
+    return dataclasses.replace(self, read_pos=pos, read_end=end, read_cigar_off=new_off,
+                               cigar=np.concatenate(pieces).astype(np.uint32) if pieces else self.cigar)
+
   def query(self, start: int, end: int) -> np.ndarray:
     """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""
     return np.nonzero((end > self.read_pos) & (start < self.read_end))[0].astype(
         np.uint32)
+
+
+def concat_tables(tables: Sequence[ReadTable]) -> ReadTable:
+  """Rows of several tables of the same kind, one after the other."""
+  tables = [t for t in tables if t.n_reads]
+  if len(tables) == 1:
+    return tables[0]
+  if not tables:
+    raise ValueError('concat_tables: nothing to concatenate')
+  def cat(name):
+    parts = [getattr(t, name) for t in tables]
+    return None if any(p is None for p in parts) else np.concatenate(parts)
+  def offsets(name):
+    out = [np.zeros(1, np.int64)]
+    base = 0
+    for t in tables:
+      o = getattr(t, name).astype(np.int64)
+      out.append(o[1:] + base)
+      base += int(o[-1])
+    return np.concatenate(out).astype(np.uint32)
+  keys = [k for t in tables for k in t.keys]
+  order = {k: i for i, k in enumerate(sorted(set((k.rpartition('/')[0].encode(), int(k.rpartition('/')[2])) for k in keys)))}
+  ranks = np.array([order[(k.rpartition('/')[0].encode(), int(k.rpartition('/')[2]))] for k in keys], np.uint32)
+  return ReadTable(
+      n_reads=len(keys), read_pos=cat('read_pos'), read_sort_pos=cat('read_sort_pos'),
+      read_seq_off=offsets('read_seq_off'), read_cigar_off=offsets('read_cigar_off'), read_mapq=cat('read_mapq'),
+      read_flags=cat('read_flags'), read_frag_len=cat('read_frag_len'), read_hp=cat('read_hp'), read_name_rank=ranks,
+      read_aux=cat('read_aux'), bases=cat('bases'), quals=cat('quals'), mod_5mc=cat('mod_5mc'), mod_6ma=cat('mod_6ma'),
+      cigar=cat('cigar'), keys=keys, read_end=cat('read_end'), base_aux0=cat('base_aux0'), base_aux1=cat('base_aux1'))
 
 
 def support_codes(dv_call, alt_alleles: Sequence[str], table: ReadTable,

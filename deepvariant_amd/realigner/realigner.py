@@ -385,6 +385,85 @@ class Realigner:
       realigned.extend(aligned)
     return candidate_haplotypes, realigned
 
+  # ---- the same procedure on a packed table (make_examples' table path): no Read objects
+  def realign_table(self, table: 'packing.ReadTable', region: T.Range):
+    """`realign_reads` for the reads of a packed table: -> (candidate haplotypes per assembled window,
+    the table of ALL input reads -- first the ones no window claimed, then window by window, in
+    the order realign_reads returns them -- with the new alignment starts and CIGARs in place).
+    Window selection counts on the device from the table, assembly takes row indices, read to
+    window assignment and the write-back are array operations; only the read sequences of the
+    windows go to the aligner as strings."""
+    n = table.n_reads
+    if n == 0:
+      return [], table
+    if self.config.split_skip_reads:
+      raise NotImplementedError('split_skip_reads works on Read objects (realign_reads)')
+    # (an injected allele counter -- CPU tests of this host logic -- takes Read objects)
+    counted = range(n) if self._allele_counter_cls is None else table.to_reads(region.reference_name)
+    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, counted, region, table=table,
+                                             allele_counter_cls=self._allele_counter_cls)
+    starts = table.read_pos.astype(np.int64)
+    ends = table.read_end.astype(np.int64)
+    usable = [w for w in windows
+              if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
+
+    def assemble(window):
+      ref = self._query(window)
+      window_reads = np.nonzero((ends > window.start) & (window.end > starts))[0].tolist()
+      graph = debruijn_graph.build_from_table(ref, table, window_reads, self.config.dbg_config)
+      haplotypes = [ref] if graph is None else graph.candidate_haplotypes()
+      if haplotypes and haplotypes != [ref]:
+        return CandidateHaplotypes(span=window, haplotypes=haplotypes)
+      return None
+
+    candidate_haplotypes = [ch for ch in _map_in_order(assemble, usable) if ch is not None]
+    if not candidate_haplotypes:
+      return candidate_haplotypes, table
+    # every read joins the window it shares most bases with (first on ties); the rest pass through
+    w_lo = np.array([ch.span.start for ch in candidate_haplotypes], np.int64)
+    w_hi = np.array([ch.span.end for ch in candidate_haplotypes], np.int64)
+    shared = np.maximum(np.minimum(ends[:, None], w_hi[None, :]) - np.maximum(starts[:, None], w_lo[None, :]), 0)
+    best = shared.argmax(axis=1)
+    claimed = shared[np.arange(n), best] > 0
+    groups = [np.nonzero(claimed & (best == w))[0] for w in range(len(candidate_haplotypes))]
+    seq_off = table.read_seq_off.astype(np.int64)
+    bases = table.bases.tobytes()
+
+    def align(w):
+      rows = groups[w]
+      if not len(rows):
+        return None
+      ch = candidate_haplotypes[w]
+      window = ch.span
+      contig = window.reference_name
+      lo, hi = int(starts[rows].min()), int(ends[rows].max())
+      ref_start = max(0, min(lo, window.start) - _REF_ALIGN_MARGIN)
+      ref_end = min(self.ref_reader.n_bases(contig), max(hi, window.end) + _REF_ALIGN_MARGIN)
+      if ref_end <= window.end:      # no room for a suffix: keep the original alignments
+        return None
+      ref_prefix = self._query(utils.make_range(contig, ref_start, window.start))
+      ref = self._query(window)
+      ref_suffix = self._query(utils.make_range(contig, window.end, ref_end))
+      sequences = [bases[seq_off[r]:seq_off[r + 1]] for r in rows.tolist()]
+      aligner = self._aligner(len(sequences[0]), False, len(ref_prefix), len(ref_suffix))
+      aligner.set_reference(ref_prefix + ref + ref_suffix, ref_start)
+      aligner.set_haplotypes([ref_prefix + target + ref_suffix for target in ch.haplotypes])
+      return aligner.align_reads_arrays(sequences)
+
+    changed_rows, changed_pos, changed_cigars = [], [], []
+    for w, res in enumerate(_map_in_order(align, list(range(len(candidate_haplotypes))))):
+      if res is None:
+        continue
+      status, position, off, words = res
+      rows = groups[w]
+      for k in np.nonzero(status == 1)[0].tolist():
+        changed_rows.append(int(rows[k]))
+        changed_pos.append(int(position[k]))
+        changed_cigars.append(words[off[k]:off[k + 1]])
+    realigned = table.with_alignments(changed_rows, changed_pos, changed_cigars)
+    order = np.concatenate([np.nonzero(~claimed)[0]] + groups)
+    return candidate_haplotypes, realigned.take(order)
+
   def align_to_haplotype(self, this_haplotype: str, haplotypes: Sequence[str], prefix: str, suffix: str,
                          reads: Sequence, contig: str, ref_start: int) -> List:
     """Reads aligned to a graph of haplotypes, reported in `this_haplotype`'s coordinates

@@ -388,3 +388,38 @@ def test_make_examples_from_the_cram_reproduces_the_goldens(tmp_path):
   assert len(images) == len(golden) == 84
   for ex in golden:
     assert np.array_equal(images[(ex['call'].variant.start, tuple(ex['alt_alleles']))], ex['image'])
+
+
+@pytest.mark.timeout(900)
+def test_table_path_writes_what_the_object_path_writes(tmp_path, monkeypatch):
+  """make_examples keeps a region's reads as a packed table from the BAM decoder to the encoder
+  where the configuration allows it (RegionProcessor.table_path_ok); DV_REGION_OBJECTS=1 forces the
+  Read-object path.  Both must write byte-identical tf.Examples and CallVariantsOutputs (the goldens
+  above pin the table path; this pins the object path to it on a longer stretch)."""
+  from deepvariant_amd import genomics_io
+  from deepvariant_amd import make_examples as me
+  from deepvariant_amd import tfrecord
+  golden_dir = os.path.join(os.path.dirname(__file__), 'golden')
+  with np.load(os.path.join(golden_dir, 'na12878_100kb.npz')) as z:
+    bam = str(tmp_path / 'reads.bam')
+    with open(bam, 'wb') as f:
+      f.write(z['bam'].tobytes())
+    with open(bam + '.bai', 'wb') as f:
+      f.write(z['bai'].tobytes())
+    fasta = str(tmp_path / 'ref.fa')
+    genomics_io.write_fasta(fasta, [('chr20', 'N' * int(z['ref_start'][0]) + z['ref_bases'].tobytes().decode())])
+  common = ['--ref', fasta, '--reads', bam, '--regions', 'chr20:10,020,000-10,040,000', '--sample_name', 'NA12878',
+            '--channel_list', ','.join(T.PILEUP_CHANNELS_WITH_INSERT_SIZE)]
+  outs = {}
+  for name, objects in (('tables', False), ('objects', True)):
+    if objects:
+      monkeypatch.setenv('DV_REGION_OBJECTS', '1')
+    else:
+      monkeypatch.delenv('DV_REGION_OBJECTS', raising=False)
+    ex = str(tmp_path / (name + '.examples.tfrecord.gz'))
+    cvo = str(tmp_path / (name + '.cvo.tfrecord.gz'))
+    assert me.main(common + ['--examples', ex]) == 0
+    assert me.main(common + ['--call_variants_outfile', cvo, '--checkpoint', 'random:7']) == 0
+    outs[name] = (list(tfrecord.read_tfrecords(ex)), list(tfrecord.read_tfrecords(cvo)))
+  assert outs['tables'][0] == outs['objects'][0] and len(outs['tables'][0]) > 40
+  assert outs['tables'][1] == outs['objects'][1] and len(outs['tables'][1]) == len(outs['tables'][0])

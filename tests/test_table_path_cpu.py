@@ -1,0 +1,79 @@
+"""The region chain's table path (no Read objects between the BAM decoder and the encoder):
+packing.ReadTable.take / with_alignments / concat_tables and Realigner.realign_table must give,
+row for row, the table that packing the object path's reads gives (Realigner.realign_reads on the
+same reads, same order)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from deepvariant_amd import dv_types as T
+from deepvariant_amd import packing
+from deepvariant_amd.realigner import realigner as R
+from deepvariant_amd.realigner import utils as U
+from tests import realigner_fixture as RF
+
+
+def _same(a: packing.ReadTable, b: packing.ReadTable, ranks_as_order=True):
+  for f in dataclasses.fields(packing.ReadTable):
+    x, y = getattr(a, f.name), getattr(b, f.name)
+    if f.name == 'read_name_rank' and ranks_as_order:
+      # ranks are sort keys: equal up to an order-preserving relabelling
+      assert np.array_equal(np.argsort(x, kind='stable'), np.argsort(y, kind='stable'))
+      assert np.array_equal(np.unique(x, return_inverse=True)[1], np.unique(y, return_inverse=True)[1])
+    elif isinstance(x, np.ndarray):
+      assert isinstance(y, np.ndarray) and np.array_equal(x.astype(np.int64), y.astype(np.int64)), f.name
+    else:
+      assert x == y, f.name
+
+
+def test_take_and_concat_equal_packing_the_same_reads():
+  _, sets = RF.load()
+  reads = sets['wgs'][:500]
+  table = packing.ReadTable.from_reads(reads)
+  rng = np.random.default_rng(3)
+  rows = rng.permutation(500)[:137]
+  _same(table.take(rows), packing.ReadTable.from_reads([reads[i] for i in rows.tolist()]))
+  _same(table.take(np.zeros(0, np.int64)), packing.ReadTable.from_reads([]))
+  a, b = np.arange(0, 200), np.arange(350, 500)
+  _same(packing.concat_tables([table.take(a), table.take(b)]),
+        packing.ReadTable.from_reads([reads[i] for i in a.tolist() + b.tolist()]))
+
+
+def test_with_alignments_equals_repacking_moved_reads():
+  from deepvariant_amd import fast_pass_aligner as F
+  _, sets = RF.load()
+  reads = sets['wgs'][:60]
+  table = packing.ReadTable.from_reads(reads)
+  rows, positions, cigars, moved = [3, 17, 59], [], [], list(reads)
+  for k, r in enumerate(rows):
+    n = len(reads[r].aligned_sequence)
+    cigar = [(1, n - 10 - k), (2, 4), (3, 2 + k), (1, 6 + k)]        # M I D M
+    pos = reads[r].alignment.position.position + 5 + k
+    moved[r] = F.with_alignment(reads[r], pos, cigar)
+    positions.append(pos)
+    cigars.append(np.array([(ln << 4) | op for op, ln in cigar], np.uint32))
+  _same(table.with_alignments(rows, positions, cigars), packing.ReadTable.from_reads(moved))
+  assert table.with_alignments([], [], []) is table
+
+
+@pytest.mark.timeout(900)
+def test_realign_table_equals_realign_reads():
+  """The realigner on a table against the realigner on objects, per 1000-base region of the golden
+  slice (the goldens themselves pin the object path): same windows, same reads moved, same order."""
+  ref, sets = RF.load()
+  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=RF.OracleAlleleCounter)
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  n_moved = 0
+  for start in range(9_999_999, 10_010_000, 1000):
+    region = T.Range('chr20', start, min(start + 1000, 10_010_000))
+    in_reads = [r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]
+    table = packing.ReadTable.from_reads(in_reads)
+    ch_a, realigned = rl.realign_reads(in_reads, region)
+    ch_b, realigned_table = rl.realign_table(table, region)
+    assert [(c.span, c.haplotypes) for c in ch_a] == [(c.span, c.haplotypes) for c in ch_b]
+    want = packing.ReadTable.from_reads(realigned)
+    _same(realigned_table, want)
+    n_moved += int((np.sort(want.read_pos) != np.sort(table.read_pos)).sum())
+  assert n_moved > 50
