@@ -85,6 +85,8 @@ class AlleleCounter:
     self._table: Optional[packing.ReadTable] = None
     self._counts: Optional[List[AlleleCount]] = None
     self._alleles: Optional[Dict[int, Dict[str, Allele]]] = None
+    self._events = None
+    self._event_ctx = None
     self._n_counted = 0
 
   # ---- the reference's interface
@@ -98,20 +100,21 @@ class AlleleCounter:
     if self._table is not None:
       raise ValueError('reads were handed over as a packed table; add() cannot be mixed in')
     self._reads.append(read)
-    self._counts = self._alleles = None
+    self._counts = self._alleles = self._events = None
 
   def add_table(self, table: packing.ReadTable):
     """All reads of the region at once, already packed (packing.ReadTable.from_bam / from_reads)."""
     if self._reads:
       raise ValueError('add() was used; add_table() cannot be mixed in')
     self._table = table
-    self._counts = self._alleles = None
+    self._counts = self._alleles = self._events = None
 
   def _ensure(self):
-    if self._alleles is None:
+    if self._events is None:
       self._run()
 
   def _count_at(self, i: int) -> AlleleCount:
+    self._build_alleles()
     c = AlleleCount(self._contig, self._start + i, self._interval_ref[i])
     c.ref_supporting_read_count = int(self._ref_counts[i])
     c.track_ref_reads = self._track_ref_reads
@@ -130,6 +133,7 @@ class AlleleCounter:
     order -- all a candidate caller or window selector has to look at: a position without read
     alleles has no alternate allele to select."""
     self._ensure()
+    self._build_alleles()
     return [self._count_at(i) for i in sorted(self._alleles)]
 
   def ref_supporting_read_counts(self) -> np.ndarray:
@@ -181,6 +185,19 @@ class AlleleCounter:
       n_ev = int(n_events.value)
       ev = (np.ctypeslib.as_array(C.cast(events, C.POINTER(C.c_uint8)), shape=(n_ev * 16,)).view(_EVENT_DTYPE).copy()
             if n_ev else np.zeros(0, _EVENT_DTYPE))
+      # the Allele objects (texts cut out of the reads / the reference) are built on demand: the
+      # window selector's default model only needs the events' footprints (variant_read_window_counts)
+      self._events, self._event_ctx = ev, (table, window, w0)
+      self._alleles, self._counts, self._n_counted = None, None, int(n_counted.value)
+    finally:
+      lib.dv_allele_counts_free(handle)
+
+  def _build_alleles(self):
+    if self._alleles is not None:
+      return
+    ev = self._events
+    table, window, w0 = self._event_ctx
+    if True:
       seq_off = table.read_seq_off
       bases = table.bases
       keys = table.keys
@@ -200,9 +217,71 @@ class AlleleCounter:
             text = prev + bytes(bases[s0:s0 + length_k]).decode()
         # a later read with the same key overwrites (read_alleles is a map keyed by ReadKey)
         alleles.setdefault(position, {})[keys[read]] = Allele(text, type_k, 1, bool(low))
-      self._alleles, self._counts, self._n_counted = alleles, None, int(n_counted.value)
-    finally:
-      lib.dv_allele_counts_free(handle)
+      self._alleles, self._counts = alleles, None
+
+  def variant_read_window_counts(self, min_allele_support: int = 0, strict_insertion_filter: bool = False):
+    """VariantReadsWindowSelectorCandidates (window_selector.cc:101-141) straight from the events:
+    per position of the interval, the number of reads whose non-reference allele covers it
+    (substitution: its base; insertion / soft clip of n bases anchored at i: [i + 1 - n, i + 1 + n);
+    deletion: [i + 1, i + 1 + n)).  Every read allele counts once whatever it is grouped with, so
+    as long as no allele is filtered by its count (min_allele_support <= 1, no strict insertion
+    filter) the sum over alleles of count x footprint is the sum over events of their footprint.
+    With min_allele_support > 1 the events are grouped into alleles first -- by (position, type,
+    text), the text of a substitution being its base, that of the few indel / clip events cut out
+    as `_build_alleles` does -- and the events of alleles seen in fewer reads are dropped.
+    -> int64[interval_length], or None when the strict insertion filter needs allele totals."""
+    if strict_insertion_filter:
+      return None
+    self._ensure()
+    n = self._end - self._start
+    ev = self._events
+    out = np.zeros(n + 1, np.int64)
+    if not len(ev):
+      return out[:n]
+    packed = ev['length_type']
+    length = (packed & 0x0fffffff).astype(np.int64)
+    kind = (packed >> 28) & 7
+    low = (packed >> 31).astype(bool)
+    pos = ev['position'].astype(np.int64)
+    # read_alleles is a map keyed by the read's name/number: of two events of one key at one
+    # position the later one stands (supplementary alignments share their key)
+    table = self._event_ctx[0]
+    if len(set(table.keys)) != len(table.keys):
+      key_id = np.unique(np.array(table.keys), return_inverse=True)[1][ev['read']]
+      composite = pos * (int(key_id.max()) + 1) + key_id
+      last = len(ev) - 1 - np.unique(composite[::-1], return_index=True)[1]
+      keep = np.zeros(len(ev), bool)
+      keep[last] = True
+    else:
+      keep = np.ones(len(ev), bool)
+    keep &= ~low & (kind != REFERENCE)
+    if min_allele_support > 1 and keep.any():
+      _, window, w0 = self._event_ctx
+      bases, seq_off = table.bases, table.read_seq_off
+      s0_all = seq_off[ev['read']].astype(np.int64) + ev['read_offset']
+      ident = np.zeros(len(ev), np.int64)
+      sub = kind == SUBSTITUTION
+      ident[sub] = bases[np.minimum(s0_all[sub], max(len(bases) - 1, 0))] if len(bases) else 0
+      texts: Dict[bytes, int] = {}
+      for k in np.nonzero(keep & ~sub)[0].tolist():
+        s0, ln = int(s0_all[k]), int(length[k])
+        anchor = self._start + int(pos[k]) - w0
+        prev = bytes(bases[s0 - 1:s0]) if int(ev['read_offset'][k]) > 0 else window[anchor:anchor + 1]
+        text = prev + (window[anchor + 1:anchor + 1 + ln] if kind[k] == DELETION else bytes(bases[s0:s0 + ln]))
+        ident[k] = 256 + texts.setdefault(text, len(texts))
+      m = 257 + len(texts)
+      key = ((pos * 8 + kind.astype(np.int64)) * m + ident)[keep]
+      _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+      kept_rows = np.nonzero(keep)[0]
+      keep = np.zeros(len(ev), bool)
+      keep[kept_rows[cnt[inv] >= min_allele_support]] = True
+    lo = np.where(kind == SUBSTITUTION, pos, np.where(kind == DELETION, pos + 1, pos + 1 - length))
+    hi = np.where(kind == SUBSTITUTION, pos + 1, pos + 1 + length)
+    lo, hi = np.clip(lo[keep], 0, n), np.clip(hi[keep], 0, n)
+    ok = hi > lo
+    np.add.at(out, lo[ok], 1)
+    np.add.at(out, hi[ok], -1)
+    return np.cumsum(out)[:n]
 
 
 # ---------------------------------------------------------------- NormalizeCigar (host)

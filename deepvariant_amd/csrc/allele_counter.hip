@@ -17,30 +17,47 @@
 // dropped) is a one-entry pending slot per wave.
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
 #include "dv_internal.h"
 
-// Results live in pinned host memory (the count array of a 7.7 Mb interval is 31 MB: 1.3 ms
-// over PCIe from pinned memory, 5 ms into pageable).
+// Large results live in pinned host memory (the count array of a 7.7 Mb interval is 31 MB: 1.3 ms
+// over PCIe from pinned memory, 5 ms into pageable); small ones -- a 1 kb calling region's 4 KB of
+// counts and a few hundred events, once or twice per region -- in ordinary memory: pinning and
+// unpinning a buffer costs more than the whole call.
 template <typename T>
 struct PinnedArray {
   T* ptr = nullptr;
   size_t n = 0;
+  bool pinned = false;
   int reserve(size_t count) {
     release();
     if (count == 0) return DV_OK;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T), hipHostMallocDefault);
-    if (e != hipSuccess) {
-      ptr = nullptr;
-      return dv::fail(DV_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    if (count * sizeof(T) < (1u << 20)) {
+      ptr = static_cast<T*>(std::malloc(count * sizeof(T)));
+      if (!ptr) return dv::fail(DV_ERR_OUT_OF_MEMORY, "malloc");
+      pinned = false;
+    } else {
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T), hipHostMallocDefault);
+      if (e != hipSuccess) {
+        ptr = nullptr;
+        return dv::fail(DV_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+      }
+      pinned = true;
     }
     n = count;
     return DV_OK;
   }
   void release() {
-    if (ptr) (void)hipHostFree(ptr);
+    if (ptr) {
+      if (pinned) {
+        (void)hipHostFree(ptr);
+      } else {
+        std::free(ptr);
+      }
+    }
     ptr = nullptr;
     n = 0;
   }
@@ -355,13 +372,9 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   // result / reference scratch is kept per host thread (grow-only): a region driver calls this
   // once per region and hipMalloc + hipFree of ~100 MB cost more than the kernel
   static thread_local dv::DeviceBuffer d_ref, d_cnt, d_ev, d_ctr, d_mask;
-  dv::DeviceBuffer up[7];
-  struct Release {
-    dv::DeviceBuffer* v[7];
-    ~Release() {
-      for (dv::DeviceBuffer* p : v) p->release();
-    }
-  } rel{{&up[0], &up[1], &up[2], &up[3], &up[4], &up[5], &up[6]}};
+  // ... and so are the upload buffers of a host-resident table: seven hipMalloc + hipFree per call
+  // were most of the millisecond a 300-read region took (the kernel itself is a few microseconds)
+  static thread_local dv::DeviceBuffer up[7];
   CountArgs a{};
   a.n_reads = b->n_reads;
   const size_t n = static_cast<size_t>(b->n_reads);

@@ -524,20 +524,31 @@ class ReadTable:
     everything else is shared with `self`."""
     if not len(rows):
       return self
+    rows = np.asarray(rows, np.int64)
     off = self.read_cigar_off.astype(np.int64)
-    pieces = [self.cigar[off[i]:off[i + 1]] for i in range(self.n_reads)]
+    lengths = np.diff(off)
+    new_len = lengths.copy()
+    new_len[rows] = [len(w) for w in cigars]
+    new_off = np.zeros(self.n_reads + 1, np.int64)
+    np.cumsum(new_len, out=new_off[1:])
+    cigar = np.zeros(int(new_off[-1]), np.uint32)
+    # unchanged rows: one vectorised segment copy; changed rows: their new words
+    same = np.ones(self.n_reads, bool)
+    same[rows] = False
+    same_rows = np.nonzero(same)[0]
+    src, _ = self._segments(self.read_cigar_off, same_rows)
+    dst = np.arange(len(src), dtype=np.int64) + np.repeat(
+        new_off[same_rows] - (np.cumsum(lengths[same_rows]) - lengths[same_rows]), lengths[same_rows])
+    cigar[dst] = self.cigar[src]
     pos = self.read_pos.copy()
     end = self.read_end.copy()
-    for r, p, words in zip(np.asarray(rows).tolist(), np.asarray(positions).tolist(), cigars):
+    for r, p, words in zip(rows.tolist(), np.asarray(positions).tolist(), cigars):
       words = np.asarray(words, np.uint32)
-      pieces[r] = words
+      cigar[new_off[r]:new_off[r + 1]] = words
       pos[r] = p
       ops = words & 15
       end[r] = p + int((words >> 4)[(ops == 1) | (ops == 8) | (ops == 9) | (ops == 3) | (ops == 4)].sum())
-    new_off = np.zeros(self.n_reads + 1, np.uint32)
-    np.cumsum([len(x) for x in pieces], out=new_off[1:])
-    return dataclasses.replace(self, read_pos=pos, read_end=end, read_cigar_off=new_off,
-                               cigar=np.concatenate(pieces).astype(np.uint32) if pieces else self.cigar)
+    return dataclasses.replace(self, read_pos=pos, read_end=end, read_cigar_off=new_off.astype(np.uint32), cigar=cigar)
 
   def query(self, start: int, end: int) -> np.ndarray:
     """InMemoryReader::Query (make_examples_native.cc:802-810): caller order."""

@@ -103,6 +103,11 @@ def _ref_supporting_read_counts(allele_counter) -> np.ndarray:
 
 def variant_reads_candidates_from_allele_counter(allele_counter, config: WindowSelectorOptions) -> List[int]:
   """VariantReadsWindowSelectorCandidates (:101-141)."""
+  fast = getattr(allele_counter, 'variant_read_window_counts', None)
+  if fast is not None:      # the device counter: footprints straight from its event arrays
+    counts = fast(config.min_allele_support, config.enable_strict_insertion_filter)
+    if counts is not None:
+      return [int(x) for x in counts]
   window_counts = np.zeros(allele_counter.interval_length(), np.int64)
   for i, ac in _positions_with_read_alleles(allele_counter):
     total = allelecounter.total_allele_counts(ac)

@@ -227,3 +227,38 @@ def test_operations_longer_than_16_bits():
   _compare(counter.counts(), oracle)
   lengths = sorted(len(a.bases) for c in counter.counts() for a in c.read_alleles.values() if len(a.bases) > 60_000)
   assert lengths == [66_001, 67_001, 70_002]
+
+
+@pytest.mark.parametrize('seed,long_reads', [(21, False), (22, True), (23, False)])
+def test_window_counts_from_events_equal_the_allele_walk(seed, long_reads):
+  """AlleleCounter.variant_read_window_counts (the window selector's read-support profile computed
+  from the device's event arrays: footprints of the events of alleles seen in >= min_allele_support
+  reads, grouped by position / type / text) against the walk over Allele objects it replaces
+  (window_selector.variant_reads_candidates_from_allele_counter's loop, window_selector.cc:101-141)
+  -- on the fuzz reads: every CIGAR op, low-quality alleles, duplicate read keys, clipped ends."""
+  from deepvariant_amd.realigner import window_selector as W
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000))
+  ref = _Ref(seq)
+
+  class _ObjectsOnly:        # the same counter without the fast method: forces the walk
+    def __init__(self, counter):
+      self._c = counter
+    def __getattr__(self, name):
+      if name == 'variant_read_window_counts':
+        raise AttributeError(name)
+      return getattr(self._c, name)
+
+  for (start, end), (lo, hi) in (((1000, 2000), (700, 2100)), ((0, 400), (0, 420)), ((5600, 6000), (5300, 5990))):
+    reads = _fuzz_reads(rng, ref, 700 if not long_reads else 200, lo, hi, long_reads)
+    reads += reads[:40]                                   # the same keys again: later events overwrite
+    for support in (0, 1, 2, 3):
+      counter = A.AlleleCounter(ref, 'c', start, end, min_mapping_quality=10, min_base_quality=20)
+      for r in reads:
+        counter.add(r)
+      config = W.WindowSelectorOptions(min_allele_support=support)
+      fast = W.variant_reads_candidates_from_allele_counter(counter, config)
+      slow = W.variant_reads_candidates_from_allele_counter(_ObjectsOnly(counter), config)
+      assert fast == slow, support
+      assert support > 1 or sum(slow) > 0
+    assert counter.variant_read_window_counts(2, True) is None      # the strict filter needs allele totals
