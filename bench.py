@@ -553,6 +553,9 @@ def bam_mode(args, log=sys.stderr):
       proc.generator.call_variants_in_region = timed(
           'pack + encode + classify (device) + CallVariantsOutput protos', proc.generator.call_variants_in_region)
       proc.realign_table = timed('realign (window selection on the device, assembly, alignment)', proc.realign_table)
+      proc.generator.encode_region_on_device = timed('pack + encode (device)', proc.generator.encode_region_on_device)
+      proc.flush_queue = timed('classify (device, several regions per forward) + CallVariantsOutput protos',
+                               proc.flush_queue)
       if os.environ.get('DV_REGION_OBJECTS') is None:   # (nested inside candidates_in_region on the object path)
         proc.variant_caller.calls_from_allele_counter = timed(
             'allele counts (device) + candidate caller', proc.variant_caller.calls_from_allele_counter)

@@ -33,6 +33,7 @@ from deepvariant_amd.realigner import realigner as realigner_module
 from deepvariant_amd.realigner import utils
 
 _RANDOM_SEED = 609314161            # make_examples_options.py:981
+_CLASSIFY_AT = 256                  # fused route, table path: examples collected on the device per CNN forward
 _REALIGNER_FLAGS = {k: v for k, v in realigner_module._FLAG_DEFAULTS.items()   # pylint: disable=protected-access
                     if k.startswith(('ws_', 'dbg_', 'aln_')) or k in (
                         'max_num_mismatches', 'realignment_similarity_threshold', 'kmer_size', 'split_skip_reads')}
@@ -502,9 +503,16 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
         stats['n_regions'] += 1
         stats['n_reads'] += in_table.n_reads
         if model is not None:
-          candidates, records = proc.call_variants_in_region_table(region, in_table, model)
-        else:
-          candidates, records = proc.examples_in_region_table(region, in_table)
+          # drawn on the device now, classified with the regions around it (one CNN forward per
+          # _CLASSIFY_AT examples); records leave in region order
+          stats['n_candidates'] += len(proc.queue_region_table(region, in_table, model))
+          if proc.n_queued_examples >= _CLASSIFY_AT:
+            for records in proc.flush_queue(model):
+              for rec in records:
+                writer.write(rec)
+              stats['n_examples'] += len(records)
+          continue
+        candidates, records = proc.examples_in_region_table(region, in_table)
         for rec in records:
           writer.write(rec)
         stats['n_candidates'] += len(candidates)
@@ -523,6 +531,11 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
         writer.write(rec)
       stats['n_candidates'] += len(candidates)
       stats['n_examples'] += len(records)
+    if use_tables and model is not None:
+      for records in proc.flush_queue(model):
+        for rec in records:
+          writer.write(rec)
+        stats['n_examples'] += len(records)
   finally:
     writer.close()
   stats['loop_s'] = time.perf_counter() - t_loop   # the region loop proper (BAM decode to the last record written)

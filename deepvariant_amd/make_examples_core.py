@@ -206,6 +206,8 @@ class RegionProcessor:
     self.variant_caller = variant_calling.VariantCaller(variant_calling.VariantCallerOptions(
         po.vsc_min_count_snps, po.vsc_min_count_indels, po.vsc_min_fraction_snps, po.vsc_min_fraction_indels,
         sample_name=sample.name, track_ref_reads=po.track_ref_reads))
+    self._queue: List = []
+    self.n_queued_examples = 0
     self.generator = make_examples_native.ExamplesGenerator(
         options, example_filenames or {}, test_mode=not example_filenames, device=device, ref_reader=ref_reader)
 
@@ -341,6 +343,38 @@ class RegionProcessor:
     if not candidates:
       return candidates, []
     return candidates, self.generator.call_variants_in_region(candidates, [realigned], [0], [0.0], model)
+
+  # ---- deferred classification (table path, fused route): regions are drawn on the device one by
+  # one, their tensors wait there, and ONE CNN forward classifies a few hundred examples
+  def queue_region_table(self, region: T.Range, table, model) -> List[T.DeepVariantCall]:
+    candidates, realigned = self.process_table(region, table)
+    images, plan = (None, [])
+    if candidates:
+      images, plan = self.generator.encode_region_on_device(candidates, [realigned], [0], [0.0], model.input_shape)
+    self._queue.append((candidates, plan, images))
+    self.n_queued_examples += len(plan)
+    return candidates
+
+  def flush_queue(self, model) -> List[List[bytes]]:
+    """-> the CallVariantsOutput records of every queued region, in queue order.  Examples are
+    classified independently of their batch (no kernel reduces across examples), so the records
+    are the ones region-by-region classification gives, byte for byte."""
+    import torch
+    from deepvariant_amd import call_variants as cv
+    queue, self._queue, self.n_queued_examples = self._queue, [], 0
+    tensors = [img for _, plan, img in queue if plan]
+    out: List[List[bytes]] = []
+    if not tensors:
+      return [[] for _ in queue]
+    limit = model.max_batch
+    stacked = torch.cat(tensors) if len(tensors) > 1 else tensors[0]
+    rows = [cv.round_gls_batch(model(stacked[i:i + limit]).cpu().numpy(), 10) for i in range(0, stacked.shape[0], limit)]
+    gls = np.concatenate(rows)
+    at = 0
+    for candidates, plan, _ in queue:
+      out.append(self.generator.call_variants_outputs(candidates, plan, gls[at:at + len(plan)]) if plan else [])
+      at += len(plan)
+    return out
 
   def examples_in_region(self, region: T.Range, reads: Sequence, stats: Optional[dict] = None
                          ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:

@@ -535,15 +535,38 @@ class ExamplesGenerator:
     tf.Example, no GZIP, no host copy of the images.  Returns serialised
     CallVariantsOutput protos identical to what call_variants writes for the examples
     write_examples_in_region would have produced (same order)."""
-    import torch  # device memory + stream only
     from deepvariant_amd import call_variants as cv
+    images, plan = self.encode_region_on_device(candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
+                                                model.input_shape)
+    if not plan:
+      return []
+    gls = cv.round_gls_batch(model(images).cpu().numpy(), 10)
+    return self.call_variants_outputs(candidates, plan, gls)
+
+  def call_variants_outputs(self, candidates, plan, gls) -> List[bytes]:
+    """CallVariantsOutput records of one region's examples from their (rounded) likelihood rows."""
+    from deepvariant_amd import call_variants as cv
+    out = []
+    for (ci, combo), row in zip(plan, gls):
+      variant = candidates[ci].variant
+      alt_encoded, _ = encode_alt_alleles(variant, combo)
+      out.append(cv.create_cvo(pw.encode_variant(variant), row.tolist(), alt_encoded))
+    return out
+
+  def encode_region_on_device(self, candidates, reads_per_sample, sample_order, mean_coverage_per_sample,
+                              model_shape):
+    """The region's pileup tensors drawn on the device and LEFT there: -> (uint8 [n, H, W, C] CUDA
+    tensor or None, [(candidate index, alt combination)]).  call_variants_in_region classifies them
+    at once; a region driver may collect several regions' tensors and classify them together
+    (make_examples' fused route: one CNN forward per few hundred examples instead of one per region)."""
+    import torch  # device memory + stream only
     from deepvariant_amd.device_batch import DeviceBatch
     batch, plan, image_shape = self._plan_region(candidates, reads_per_sample, sample_order,
                                                  mean_coverage_per_sample)
     if not plan:
-      return []
-    if list(image_shape) != list(model.input_shape):
-      raise ValueError('example shape %s != model shape %s' % (image_shape, list(model.input_shape)))
+      return None, []
+    if list(image_shape) != list(model_shape):
+      raise ValueError('example shape %s != model shape %s' % (image_shape, list(model_shape)))
     pic = self._options.pic_options
     if self._device_encoder is None:
       self._device_encoder = _Encoder(pic, pic.width, self._device)
@@ -559,13 +582,7 @@ class ExamplesGenerator:
     dbatch.encode(self._device_encoder, image_shape[2], flat)
     if self._alt_plan:
       self._merge_alt_channels_device(flat, image_shape)
-    gls = cv.round_gls_batch(model(images).cpu().numpy(), 10)
-    out = []
-    for (ci, combo), row in zip(plan, gls):
-      variant = candidates[ci].variant
-      alt_encoded, _ = encode_alt_alleles(variant, combo)
-      out.append(cv.create_cvo(pw.encode_variant(variant), row.tolist(), alt_encoded))
-    return out
+    return images, plan
 
   def _encode_example(self, variant, alt_combination, image: np.ndarray,
                       image_shape, label, stats) -> bytes:
