@@ -467,8 +467,11 @@ class CramFile:
 
   def __init__(self, path: str, fetch_reference: Optional[Callable[[str, int, int], str]] = None):
     self.path = path
-    with open(path, 'rb') as f:
-      self.buf = f.read()
+    # the file is mapped, not read: a whole-genome CRAM is tens of gigabytes, a query touches the
+    # header container and the containers its index (or a scan of the container headers) selects
+    import mmap
+    self._file = open(path, 'rb')
+    self.buf = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
     b = self.buf
     if b[:4] != b'CRAM':
       raise IOError('Failed to parse BAM/CRAM file. %s: bad CRAM magic' % path)
@@ -514,6 +517,47 @@ class CramFile:
       if h['n_blocks'] > 0 and not (h['ref_id'] == -1 and h['n_records'] == 0 and h['start'] == 4542278):   # EOF marker
         yield h, blocks
       i = nxt
+
+  def _index(self):
+    """<path>.crai (gzip text: reference id, start, span, container offset, slice offset, slice
+    size per line; CRAM format specification, section 12) -> [(ref_id, start, span, container offset)],
+    or None when there is no index next to the file."""
+    if not hasattr(self, '_crai'):
+      self._crai = None
+      import os
+      for cand in (self.path + '.crai', self.path[:-5] + '.crai' if self.path.endswith('.cram') else None):
+        if cand and os.path.exists(cand):
+          rows = []
+          with gzip.open(cand, 'rt') as f:
+            for line in f:
+              parts = line.split('\t')
+              if len(parts) >= 4:
+                rows.append((int(parts[0]), int(parts[1]), int(parts[2]), int(parts[3])))
+          self._crai = rows
+          break
+    return self._crai
+
+  def containers_for(self, want_ref: int, start: int, end: int):
+    """The containers that can hold reads of reference `want_ref` overlapping [start, end): by the
+    .crai index when there is one (its offsets point at container headers), else by walking the
+    container headers."""
+    index = self._index()
+    if index is None:
+      for h, blocks in self.containers():
+        if h['ref_id'] >= 0 and (h['ref_id'] != want_ref or h['start'] - 1 >= end or h['start'] - 1 + h['span'] <= start):
+          continue
+        yield h, blocks
+      return
+    seen = set()
+    for ref_id, s0, span, offset in index:      # (a multi-reference slice has one line per reference)
+      if ref_id != want_ref or s0 - 1 >= end or s0 - 1 + span <= start:
+        continue
+      if offset in seen:
+        continue
+      seen.add(offset)
+      h, blocks, _ = self._container(offset)
+      if h['n_blocks'] > 0:
+        yield h, blocks
 
   # ---- one slice
   def _decode_slice(self, ch: _CompressionHeader, i: int, want_ref: Optional[int], lo: int, hi: int) -> List[CramRecord]:
@@ -771,10 +815,7 @@ class CramFile:
   def records(self, contig: Optional[str] = None, start: int = 0, end: int = 1 << 62) -> List[CramRecord]:
     want = self.contig_names.index(contig) if contig is not None else None
     out: List[CramRecord] = []
-    for h, blocks in self.containers():
-      if want is not None and h['ref_id'] >= 0 and (h['ref_id'] != want or h['start'] - 1 >= end or
-                                                     h['start'] - 1 + h['span'] <= start):
-        continue
+    for h, blocks in (self.containers() if want is None else self.containers_for(want, start, end)):
       first, _ = _read_block(self.buf, blocks)
       if first.content_type != 1:
         continue
