@@ -86,6 +86,9 @@ struct ConvArgs {
   // instead of multiplying -- bit-identical.  Single-branch launches only; NULL = off.
   const int* blank_row;
   const _Float16* blank_src;
+  // Split weights (model.hip): the packed image holds every K chunk twice, W_hi then
+  // W_lo = fp16(W - W_hi); n_chunks counts both, the pixel operand advances once per pair.
+  int split;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
