@@ -496,6 +496,217 @@ __global__ __launch_bounds__(512, 1) void conv_resident_kernel(ConvArgs p) {
   }
 }
 
+// conv_resident_kernel with the 3x3 / stride-2 max-pool that follows the convolution taken INSIDE
+// (stem: 3x3 80->192 -> max-pool -> mixed0).  The conv tensor (21 x 51 x 192 per example, 0.4 MB
+// written and read back: the worst launch of round 3 was the pooled re-read) never exists; only
+// the pooled tensor (10 x 25 x 192) is stored, and mixed0's heads become an ordinary grouped 1x1.
+//
+// Max-pooling commutes with every monotone map, so pooling the fp16 results of shift + ReLU is the
+// same as Keras' order -- results are bit-identical to the separate max-pool.
+//
+//  * A wave owns 32 POSITIONS of the flattened (example, conv column) index -- fragment f covers
+//    positions 30 f .. 30 f + 31, an overlap of two so that every 3-wide window that starts in
+//    the first 30 lies inside the wave (6 % of the MFMA work is recomputed) -- and walks DOWN the
+//    map two conv rows per step (the two pixel fragments of conv_slab<NB,2>: same K order, same
+//    weights resident in LDS, same straight-line slab code as conv_resident_kernel).
+//  * Vertical maximum: rows 2i, 2i+1, 2i+2 of one position sit in the same lane of three
+//    accumulator sets, so it is register-wise (v_pk_max_f16); max(row 2i+2, row 2i+3) is carried
+//    into the next step as 8 packed dwords per 32-cout subtile.
+//  * Horizontal maximum: positions +1 / +2 are lanes +1 / +2 of the same register
+//    (ds_bpermute_b32, no LDS memory); lanes on even columns then hold pooled pixels and store
+//    16-byte pieces after the usual permlane32_swap pairing.
+//  * The last step has one conv row only (row 2 PH) and runs conv_slab<NB,1>.
+template <int NB, int PT>
+__device__ __forceinline__ void resident_rows(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
+                                              const _Float16* wfrag, const unsigned (&base)[PT],
+                                              float16_t (&acc)[NB][PT]) {
+  constexpr int BN = NB * 32;
+  constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
+  constexpr int kPrefetch = prefetch_depth(NB, PT);
+  const int n_full = p.n_chunks / kSlabChunks;
+  const int rem = p.n_chunks - n_full * kSlabChunks;
+  uint4_t xf[kPrefetch][PT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][pt][i] = 0.f;
+  ChunkWalk walk{0, 0, 0u, 0u};
+#pragma unroll
+  for (int d = 0; d < kPrefetch; ++d) {
+    const unsigned soff = walk.off();
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xf[d][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+    walk.advance(p);
+  }
+  for (int s = 0; s < n_full; ++s) {
+    conv_slab<NB, PT, kSlabChunks>(p, rsrc, wfrag + s * SLAB_HALFS, walk, base, xf, acc);
+  }
+  if (rem) {
+    const _Float16* wslab = wfrag + n_full * SLAB_HALFS;
+    conv_slab<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
+    if (rem > 4) conv_slab<NB, PT, 4, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+  }
+}
+
+// shift + ReLU + fp16 of one conv row held in accumulators: pk[nb][q][hq] = couts
+// nb*32 + 8q + 4*(lane>>5) + 2hq + {0,1} of the lane's position (conv_epilogue's packing)
+template <int NB>
+__device__ __forceinline__ void pack_row(const float16_t (&acc)[NB], const ConvArgs& p, int n_tile, int hi,
+                                         unsigned (&pk)[NB][4][2]) {
+  const ConvBranch& b = p.br[0];
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int cbase = (n_tile * NB + nb) * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+      const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(b.shift + (cbase + 8 * q)));
+      const f4_t l4 = sp[0], u4 = sp[1];   // the shift array is padded past Cout
+      const float2_t s0 = hi ? float2_t{u4[0], u4[1]} : float2_t{l4[0], l4[1]};
+      const float2_t s1 = hi ? float2_t{u4[2], u4[3]} : float2_t{l4[2], l4[3]};
+      const float2_t v0 = float2_t{acc[nb][4 * q], acc[nb][4 * q + 1]} + s0;
+      const float2_t v1 = float2_t{acc[nb][4 * q + 2], acc[nb][4 * q + 3]} + s1;
+      pk[nb][q][0] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_convertvector(v0, half2_t), zero2));
+      pk[nb][q][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_convertvector(v1, half2_t), zero2));
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2_t, a),
+                                                                __builtin_bit_cast(half2_t, b)));
+}
+
+template <int NB>
+__global__ __launch_bounds__(512, 1) void conv_pool_resident_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int WAVES = 8, kThreads = WAVES * 64;
+  constexpr int kNew = 30;   // positions a fragment owns (the last two belong to the next one)
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int n_tile = (blk >> 3) % p.n_tiles;
+  const int seq = (blk & 7) + 8 * ((blk >> 3) / p.n_tiles);
+  const int n_seq = 8 * ((static_cast<int>(gridDim.x) >> 3) / p.n_tiles);
+  {
+    const uint4_t* wsrc = reinterpret_cast<const uint4_t*>(p.w) +
+                          static_cast<size_t>(n_tile) * p.n_slabs * (kSlabChunks * BN * 2);
+    uint4_t* wdst = reinterpret_cast<uint4_t*>(smem);
+    const int pieces = p.n_slabs * (kSlabChunks * BN * 2);
+    for (int i = tid; i < pieces; i += kThreads) wdst[i] = wsrc[i];
+  }
+  __syncthreads();
+  const _Float16* wfrag = smem + (lane >> 5) * (BN * 8) + (lane & 31) * 8;
+  const ConvBranch& b = p.br[0];
+  const int PH = b.og.h, PW = b.og.w;          // pooled map
+  const int n_pos = p.N * p.OW;
+  const int n_frag = (n_pos + kNew - 1) / kNew;
+  const unsigned row_b = static_cast<unsigned>(p.ig.wp) * 16u;
+  const int hi = lane >> 5, l32 = lane & 31;
+  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+  for (int f = seq * WAVES + wave; f < n_frag; f += n_seq * WAVES) {
+    const int pos = f * kNew + l32;
+    const bool valid = pos < n_pos;
+    int n, col;
+    divmod_small(valid ? pos : 0, p.OW, p.rcp_ow, n, col);
+    const int n0 = __builtin_amdgcn_readfirstlane(n);
+    // (example n - n0, channel group lane>>5, input row halo, input column col + halo): 'valid' conv
+    const unsigned base0 =
+        valid ? static_cast<unsigned>(((((n - n0) * p.ig.groups + hi) * p.ig.hp + p.ig.halo) * p.ig.wp + col +
+                                       p.ig.halo) * 16)
+              : 0x80000000u;
+    const size_t in_off = static_cast<size_t>(n0) * p.img_bytes;
+    const size_t in_left = p.in_bytes - in_off;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in) + in_off), 0,
+        static_cast<unsigned>(in_left < 0x7fffffffu ? in_left : 0x7fffffffu), 0x00020000);
+    // pooled pixel (n, s - 1, col / 2) leaves from this lane at step s
+    const bool emits = valid && l32 < kNew && (col & 1) == 0 && (col >> 1) < PW;
+    const unsigned obase0 = static_cast<unsigned>(
+        ((n * b.og.groups + b.out_goff) * b.og.hp + b.og.halo) * b.og.wp + (col >> 1) + b.og.halo);
+    const int nb_addr1 = ((lane + 1) & 63) * 4, nb_addr2 = ((lane + 2) & 63) * 4;
+    unsigned carry[NB][4][2];   // max(row 2s, row 2s+1) of the previous step
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) carry[nb][q][0] = carry[nb][q][1] = 0u;
+    for (int s = 0; s <= PH; ++s) {
+      unsigned top[NB][4][2];   // conv row 2s
+      if (s < PH) {
+        unsigned base[2] = {base0, base0};
+        if (valid) {
+          base[0] = base0 + static_cast<unsigned>(2 * s) * row_b;
+          base[1] = base[0] + row_b;
+        }
+        float16_t acc[NB][2];
+        resident_rows<NB, 2>(p, rsrc, wfrag, base, acc);
+        float16_t r0[NB], r1[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          r0[nb] = acc[nb][0];
+          r1[nb] = acc[nb][1];
+        }
+        unsigned bot[NB][4][2];
+        pack_row<NB>(r0, p, n_tile, hi, top);
+        pack_row<NB>(r1, p, n_tile, hi, bot);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              const unsigned t = top[nb][q][hq];
+              top[nb][q][hq] = pk_max(carry[nb][q][hq], t);   // rows 2s-2, 2s-1, 2s (s = 0: row 0 alone, unused)
+              carry[nb][q][hq] = pk_max(t, bot[nb][q][hq]);
+            }
+      } else {   // the last pooled row's third conv row
+        unsigned base[1] = {valid ? base0 + static_cast<unsigned>(2 * s) * row_b : base0};
+        float16_t acc[NB][1];
+        resident_rows<NB, 1>(p, rsrc, wfrag, base, acc);
+        float16_t r0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) r0[nb] = acc[nb][0];
+        pack_row<NB>(r0, p, n_tile, hi, top);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) top[nb][q][hq] = pk_max(carry[nb][q][hq], top[nb][q][hq]);
+      }
+      if (s == 0) continue;   // wave-uniform
+      const unsigned obase = obase0 + static_cast<unsigned>(s - 1) * static_cast<unsigned>(b.og.wp);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int cbase = (n_tile * NB + nb) * 32;
+        unsigned hm[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const unsigned v = top[nb][q][hq];
+            const unsigned v1 = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(nb_addr1, static_cast<int>(v)));
+            const unsigned v2 = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(nb_addr2, static_cast<int>(v)));
+            hm[q][hq] = pk_max(pk_max(v, v1), v2);
+          }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const auto d0 = __builtin_amdgcn_permlane32_swap(hm[2 * t][0], hm[2 * t + 1][0], false, false);
+          const auto d1 = __builtin_amdgcn_permlane32_swap(hm[2 * t][1], hm[2 * t + 1][1], false, false);
+          const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+          const int group = cbase / 8 + 2 * t + hi;
+          if (emits && group * 8 < b.Cout) outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+        }
+      }
+    }
+  }
+}
+
 // MaxPooling2D(3, strides 2) fused into the 1x1 convolution that consumes it (stem:
 // maxpool -> 64->80): the pooled tensor (0.16 MB / example written and read back) never
 // exists.  A pixel fragment is the element-wise maximum of the nine 16-byte pieces of its
@@ -1029,6 +1240,8 @@ struct Op {
   bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
   bool pool_in = false;          // 1x1 conv that max-pools (3x3, stride 2) its input on the fly
+  bool pool_out = false;         // conv whose output is max-pooled (3x3, stride 2) before it is stored
+                                 // (conv_pool_resident_kernel; oh / ow stay the conv's, the buffer is pooled)
   // Fused stem (stem.hip): the op marked stem_a / stem_b runs together with the op that
   // follows it as ONE launch; the tensor between them is never materialised.
   // imgconv.hip: whole-map tiles, both operands through LDS (set on the launch's leader op)
@@ -1268,7 +1481,7 @@ struct dv_model {
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& op = ops[i];
       const int followers = op.type == kOpConv ? op.group_followers : 0;
-      if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.stem_a && !op.stem_b &&
+      if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b &&
           op.chain_len == 0 && !op.in_chain &&
           !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
           dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
@@ -1315,7 +1528,7 @@ struct dv_model {
   void choose_band() {
     if (getenv("DV_NO_BAND") != nullptr) return;
     for (Op& op : ops) {
-      if (op.type != kOpConv || op.first_u8 || op.pool_in || op.stem_a || op.stem_b || op.v2 ||
+      if (op.type != kOpConv || op.first_u8 || op.pool_in || op.pool_out || op.stem_a || op.stem_b || op.v2 ||
           op.chain_len != 0 || op.in_chain || op.group_followers != 0 || op.stride != 1 || op.kh <= 1 || op.oh != op.ih) {
         continue;
       }
@@ -1351,16 +1564,23 @@ struct dv_model {
   // conv_mfma layer) for A/B runs.
   void choose_split() {
     const int first_layer_env = getenv("DV_SPLIT_FROM") ? atoi(getenv("DV_SPLIT_FROM")) : -1;  // per model (tests)
-    // mixed4 (the 17x17 stage) starts at conv layer 30 of the 94 (5 stem + 3 x 7 + 4), mixed8 at 70
-    const int first_layer = first_layer_env >= 0 ? first_layer_env : 30;
+    // mixed4 (the 17x17 stage) starts at conv layer 30 of the 94 (5 stem + 3 x 7 + 4), mixed8 at 70.
+    // The default set is a property of the LAYER, not of the kernel that happens to run it: 1x1
+    // layers from mixed4 on, 3-tap and 3x3 layers from mixed8 on -- never the factorised-7x7
+    // layers, which run as fused chains (and must give the same bits when DV_NO_CHAIN unfuses them).
+    auto wanted = [&](const Op& o) {
+      if (first_layer_env >= 0) return o.layer >= first_layer_env;
+      if (o.kh * o.kw == 1) return o.layer >= 30;
+      return o.layer >= 70 && std::max(o.kh, o.kw) <= 3;
+    };
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& op = ops[i];
       if (op.type != kOpConv) continue;
       const int followers = op.group_followers;
-      bool ok = !op.first_u8 && !op.pool_in && !op.stem_a && !op.stem_b && !op.v2 && op.chain_len == 0 &&
+      bool ok = !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b && !op.v2 && op.chain_len == 0 &&
                 !op.in_chain && !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.nb <= 4 &&
                 static_cast<int>(i) != blank_conv4_op;
-      for (int gi = 0; gi <= followers; ++gi) ok = ok && ops[i + gi].layer >= first_layer;
+      for (int gi = 0; gi <= followers; ++gi) ok = ok && wanted(ops[i + gi]);
       if (ok) {
         for (int gi = 0; gi <= followers; ++gi) {
           Op& o = ops[i + gi];
@@ -1395,7 +1615,7 @@ struct dv_model {
     auto plain = [](const Op& o) {
       return o.type == kOpConv && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
              o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
-             !o.first_u8 && !o.pool_in && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
+             !o.first_u8 && !o.pool_in && !o.pool_out && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
              o.cin == o.cin_real && o.oh == o.ih && o.ow == o.iw;
     };
     auto one_d = [&](const Op& o) {
@@ -1496,7 +1716,19 @@ struct dv_model {
     const bool fuse_pool2 = getenv("DV_NO_POOL2_FUSE") == nullptr && getenv("DV_NO_POOL_FUSE") == nullptr &&
                             getenv("DV_NO_GROUPING") == nullptr;
     const int pool2_ih = x.h, pool2_iw = x.w;
-    if (fuse_pool2) {
+    // Round 4: the pool moves into its PRODUCER (conv_pool_resident_kernel): the 21 x 51 x 192 tensor
+    // is never written, mixed0's heads read the pooled 10 x 25 x 192 tensor like any other block's.
+    // DV_NO_POOL2_IN_CONV keeps the round-3 arrangement (pool on load in the heads); so does the
+    // opt-in blank-row skipping, which works on the unpooled tensor.
+    const bool pool_in_conv = fuse_pool2 && getenv("DV_NO_POOL2_IN_CONV") == nullptr && ops.back().nb == 3 &&
+                              x.h >= 3 && x.w >= 3 &&
+                              !(getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0);
+    if (pool_in_conv) {
+      x.h = (x.h - 3) / 2 + 1;
+      x.w = (x.w - 3) / 2 + 1;
+      ops.back().pool_out = true;
+      buffers[x.buf] = {x.h, x.w, x.c, 0};
+    } else if (fuse_pool2) {
       x.h = (x.h - 3) / 2 + 1;
       x.w = (x.w - 3) / 2 + 1;
     } else {
@@ -1518,7 +1750,7 @@ struct dv_model {
       b3 = conv(b3, 96, 3, 3);
       conv(b3, 96, 3, 3, 1, true, out, 128);
       pooled_projection(x, pool_ch, out, 224);
-      if (fuse_pool2 && x.buf == stem_out_buf) {  // mixed0: its 1x1 heads pool their input
+      if (fuse_pool2 && !pool_in_conv && x.buf == stem_out_buf) {  // mixed0: its 1x1 heads pool their input
         for (size_t k = stem_ops_end; k < ops.size(); ++k) {
           if (ops[k].type == kOpConv && ops[k].in_buf == x.buf) {
             ops[k].pool_in = true;
@@ -2040,11 +2272,27 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
       if (op.split) tr_label += " [split W]";
-      const bool resident = !op.v2 && !op.pool_in && resident_ok(m, op, a);
+      const bool resident = !op.v2 && !op.pool_in && !op.pool_out && resident_ok(m, op, a);
       if (resident) tr_label += " [weights resident in LDS]";
+      if (op.pool_out) tr_label += " [weights resident in LDS] -> maxpool3s2";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
-      if (op.v2) {
+      if (op.pool_out) {
+        const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
+        static const bool attr = [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pool_resident_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          return true;
+        }();
+        (void)attr;
+        // one wave per fragment of 30 new positions of the (example, conv column) index; a persistent
+        // grid of up to one block per CU, in whole sets of 8 blocks per cout tile
+        const long frags = (static_cast<long>(n) * op.ow + 29) / 30;
+        const int per_set = 8 * a.n_tiles;
+        const long want = (frags + 8 * 8 - 1) / (8 * 8) * per_set;   // 8 waves x 8 blocks cover 64 fragments per set
+        const int grid = static_cast<int>(std::max<long>(per_set, std::min<long>(want, m->n_cus / per_set * per_set)));
+        hipLaunchKernelGGL((conv_pool_resident_kernel<3>), dim3(grid), dim3(512), lds, stream, a);
+      } else if (op.v2) {
         dv::ImgConvArgs ia = m->imgconv_geometry(op, op.v2_g);
         ia.c = a;
         ia.n_img_tiles = (n + op.v2_g - 1) / op.v2_g;
