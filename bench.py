@@ -38,9 +38,15 @@ def parse_args():
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--batch', type=int, default=7700,
-                  help='candidate sites per step per GPU; ~5 % more pileups (multi-allelic '
+                  help='candidate sites per step per GPU; ~5 %% more pileups (multi-allelic '
                        'sites give 3) -- 7700 sites fill one 8192-example forward')
   ap.add_argument('--channels', type=int, default=7, choices=[6, 7])
+  ap.add_argument('--workload', choices=['illumina30', 'hifi35', 'ont50'], default='illumina30',
+                  help="SURVEY.md 8(d) workloads.  'illumina30' (default) is the contract's metric: "
+                       "100x221x7, BASELINE configs[1].  'hifi35' (PACBIO model shape 100x147x10) and 'ont50' "
+                       "(ONT_R104 shape 100x199x9, pile-ups deeper than the image, ~14 CIGAR ops per read) "
+                       'print their own line: long-read channel sets with the two alt-aligned diff channels '
+                       '(a third of the candidates carry two alt-aligned images, merged on the device); 1 GPU')
   ap.add_argument('--mode', choices=['resident', 'host', 'alleles', 'bam'], default='resident',
                   help="'resident' (default, the contract's metric): inputs already in HBM. "
                        "'host': host-inclusive -- every step packs the region's candidates and "
@@ -49,6 +55,8 @@ def parse_args():
   ap.add_argument('--procs', type=int, default=1,
                   help="--mode bam: host processes sharing the GPU (make_examples --ranks_per_gpu)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--parity-sites', type=int, default=4096,
+                  help='sites of the timed batch checked against the oracle after the timed region')
   ap.add_argument('--cpu-sample', type=int, default=0,
                   help='candidates in the CPU-baseline sample (0 = auto)')
   return ap.parse_args()
@@ -71,6 +79,9 @@ def algorithmic_bytes_per_item(batch, out_channels):
 
 
 def main():
+  if len(sys.argv) == 3 and sys.argv[1] == '--cnn-worker':
+    _cnn_worker_main(sys.argv[2])
+    return
   args = parse_args()
   if args.mode == 'bam':
     if args.gpus != 1:
@@ -165,6 +176,11 @@ def run_rank(args, rank, local_rank, world):
   from deepvariant_amd.device_batch import DeviceBatch
   from deepvariant_amd.inception_v3 import InceptionV3
   from deepvariant_amd.pileup_image_native import _Encoder
+
+  if args.workload != 'illumina30':
+    if world > 1 or args.mode != 'resident':
+      raise SystemExit('--workload %s runs in resident mode on one GPU' % args.workload)
+    return longread_bench(args, dev, local_rank)
 
   C = args.channels
   opts = synth.illumina_options(C)
@@ -307,7 +323,7 @@ def run_rank(args, rank, local_rank, world):
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(host_batch, opts, C, args.cpu_sample)
-      out['parity'] = parity_sample(region, opts, C, model, images, probs)
+      out['parity'] = parity_sample(region, opts, C, model, images, probs, n=args.parity_sites)
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
@@ -592,6 +608,183 @@ def bam_mode(args, log=sys.stderr):
   }))
 
 
+def make_longread_workload(kind, n, seed=None):
+  """(options, packed batch, candidates with alt images, drawn channels, total channels): items 0..n-1 are the
+  reference-aligned pileups (example i at i * H*W*Ct), items n + 2k, n + 2k + 1 the two alt-aligned images of
+  candidate with_alt[k] in scratch space behind the examples."""
+  from deepvariant_amd import packing, synth
+  opts = synth.longread_options(kind)
+  H, W = opts.height, opts.width
+  c_enc = len(packing.channel_enums(opts))
+  Ct = c_enc + 2                                   # + the two alt-aligned diff channels
+  gen = synth.make_longread_batch(n, kind, seed=synth.SEED if seed is None else seed)
+  img_bytes = H * W * Ct
+  batch = packing.PackedBatch(table=gen.table, width=W)
+  batch.ref_windows_list = gen.ref_windows_list
+  off = np.asarray(gen.item_list_off)
+  lr, lc = np.asarray(gen.list_read), np.asarray(gen.list_code)
+  for i in range(n):
+    a, b = off[i], off[i + 1]
+    batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
+                   height=H, out_off=i * img_bytes)
+  with_alt = list(range(0, n, 3))
+  for k, i in enumerate(with_alt):
+    a, b = off[i], off[i + 1]
+    for j in range(2):
+      batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
+                     height=H, out_off=n * img_bytes + (2 * k + j) * img_bytes)
+  return opts, batch, with_alt, c_enc, Ct
+
+
+def longread_bench(args, dev, local_rank):
+  """`--workload hifi35 | ont50`: the long-read shapes of SURVEY.md 8(d) / BASELINE configs[3], [4] through
+  the same two entry points, one JSON line each (never the contract's `value`).
+
+  A step = dv_encode_batch over every image of the batch (the reference-aligned pileup of each candidate
+  plus, for every third candidate -- the indel share of the PacBio golden, 131 of 401 -- two alt-aligned
+  images of the same reads in scratch space behind the examples) -> dv_merge_alt_channels (the two
+  trailing diff channels, FillPileupArray's channel mode, deepvariant/pileup_image_native.h:246-271) ->
+  dv_model_infer at the released model's input shape.  Reference context: docs/metrics.md:77-86."""
+  import ctypes as CT
+  from deepvariant_amd import _lib, packing, synth
+  from deepvariant_amd.device_batch import DeviceBatch
+  from deepvariant_amd.inception_v3 import InceptionV3
+  from deepvariant_amd.pileup_image_native import _Encoder
+  kind = 'hifi' if args.workload == 'hifi35' else 'ont'
+  n = min(args.batch if args.batch != 7700 else 8192, 8192)
+  opts, batch, with_alt, c_enc, Ct = make_longread_workload(kind, n)
+  H, W = opts.height, opts.width
+  img_bytes = H * W * Ct
+  scratch0 = n * img_bytes
+  entries = (_lib.DvAltMergeEntry * len(with_alt))()
+  for k, i in enumerate(with_alt):
+    entries[k].example, entries[k].first_row, entries[k].rows = i, 0, H
+    entries[k].scratch_alt1, entries[k].scratch_alt2 = 2 * k, 2 * k + 1
+  n_images = batch.n_items
+  dbatch = DeviceBatch(batch, dev)
+  enc = _Encoder(opts, W, device=local_rank)
+  model = InceptionV3((H, W, Ct), max_batch=n, device=local_rank)
+  model.init_random(seed=1234)
+  flat = torch.zeros(n_images * img_bytes, dtype=torch.uint8, device=dev)
+  images = flat[:n * img_bytes].view(n, H, W, Ct)
+  rows = torch.empty(n_images, dtype=torch.int32, device=dev)
+  work = torch.cuda.Stream(device=dev)
+  torch.cuda.set_stream(work)
+  lib = _lib.lib()
+
+  def step():
+    dbatch.encode(enc, Ct, flat, rows)
+    _lib.check(lib.dv_merge_alt_channels(flat.data_ptr(), scratch0, img_bytes, img_bytes, W, Ct, c_enc, 5,
+                                         entries, len(with_alt), CT.c_void_p(work.cuda_stream)))
+    return model(images)
+
+  def sync_all():
+    torch.cuda.synchronize(dev)
+
+  elapsed, probs = timed_steps(step, sync_all, args.warmup, args.steps)
+  lib.dv_set_profiling(1)
+  for _ in range(args.steps):
+    step()
+  sync_all()
+  enc_ms = lib.dv_profile_ms(0)
+  enc_launches = lib.dv_last_profile_count()
+  conv_ms = lib.dv_profile_ms(1)
+  conv_launches = lib.dv_last_profile_count()
+  other_ms = lib.dv_profile_ms(2)
+  lib.dv_set_profiling(0)
+  assert torch.isfinite(probs).all()
+  conv_flops = 2.0 * model.conv_macs_per_example
+  conv_tflops = conv_flops * n * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+  # algorithmic bytes: every image's packed reads once per alignment drawn + the n example tensors
+  t = batch.table
+  seq_len = t.read_seq_off[1:].astype(np.int64) - t.read_seq_off[:-1]
+  n_cig = t.read_cigar_off[1:].astype(np.int64) - t.read_cigar_off[:-1]
+  per_read = 2 * seq_len + 8 * n_cig + 24 + 1
+  in_bytes = float(per_read[np.asarray(batch.list_read, np.int64)].sum()) + n_images * W
+  alg_bytes = in_bytes + float(n) * img_bytes
+  enc_gbs = alg_bytes * args.steps / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+  out = {
+      'metric': 'candidate pileups/sec (encode+CNN), %s' % args.workload,
+      'value': n * args.steps / elapsed, 'unit': 'candidates/s', 'n_gpus': 1, 'steps': args.steps,
+      'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 (encoder) / f16 MFMA, f32 accumulate (CNN)',
+      'data': 'synthetic',
+      'config': {
+          'workload': ('BASELINE configs[3] shape: synthetic PacBio HiFi 35x, PACBIO model input 100x147x10'
+                       if kind == 'hifi' else
+                       'BASELINE configs[4] shape: synthetic ONT R10.4 50x (10 % of the sites 96-160 reads deep, '
+                       '~3 % indel events per base), ONT_R104 model input 100x199x9') +
+                      '; channels = %d drawn + 2 alt-aligned diff channels; random-init weights' % c_enc,
+          'candidates_per_step': n, 'images_drawn_per_step': n_images,
+          'reads_per_step': int(t.n_reads), 'cigar_ops_per_read': float(n_cig.mean()),
+          'reads_listed_per_image': float(len(batch.list_read)) / n_images,
+      },
+      'roofline': {
+          'kernel': 'conv kernels (all 94 conv layers; inputs with more than 8 channels take preprocess_kernel + '
+                    'the per-layer stem instead of the fused uint8 stem)',
+          'bound': 'mfma', 'achieved': conv_tflops, 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+          'frac': conv_tflops / MFMA_F16_PEAK_TFLOPS, 'traffic': None, 'flops_per_candidate': conv_flops,
+          'avg_launch_ms': conv_ms / max(conv_launches, 1), 'launches': conv_launches,
+          'ms_per_step': conv_ms / args.steps,
+      },
+      'roofline_encoder': {
+          'kernel': 'encode_items_kernel', 'bound': 'hbm', 'achieved': enc_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': enc_gbs / HBM_PEAK_GBS, 'traffic': None, 'bytes_per_candidate': alg_bytes / n,
+          'avg_launch_ms': enc_ms / max(enc_launches, 1), 'launches': enc_launches,
+          'images_per_s': n_images * args.steps / (enc_ms * 1e-3) if enc_ms > 0 else 0.0,
+      },
+      'other_kernels_ms_per_step': other_ms / args.steps,
+  }
+  if not args.no_cpu_baseline:
+    out['parity'] = longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs)
+  print(json.dumps(out))
+
+
+def longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs, sample=192):
+  """The first `sample` examples of the timed batch against the oracle: tensors (the oracle draws the
+  reference-aligned and the two alt-aligned images, the diff channels are merged here in numpy as
+  FillPileupArray does) bit-exact, softmax within 1e-3 of the fp32 restatement."""
+  from deepvariant_amd import packing
+  from oracle import inception_ref, oracle as O
+  H, W = opts.height, opts.width
+  sample = min(sample, n)
+  img_bytes = H * W * Ct
+  alt_k = {i: k for k, i in enumerate(with_alt)}
+  off = np.asarray(batch.item_list_off)
+  lr, lc = np.asarray(batch.list_read), np.asarray(batch.list_code)
+  sub = packing.PackedBatch(table=batch.table, width=W)
+  sub.ref_windows_list = batch.ref_windows_list
+  slots = []
+  for i in range(sample):
+    for item in [i] + ([n + 2 * alt_k[i], n + 2 * alt_k[i] + 1] if i in alt_k else []):
+      a, b = off[item], off[item + 1]
+      sub.add_item(batch.item_variant_start[item], batch.item_image_start[item], batch.item_ref_idx[item],
+                   lr[a:b], lc[a:b], height=H, out_off=len(slots) * img_bytes)
+      slots.append((i, item))
+  raw, _ = O.encode_packed(opts, sub, Ct, n_threads=min(64, os.cpu_count() or 1))
+  drawn = raw.reshape(len(slots), H, W, Ct)
+  want = np.zeros((sample, H, W, Ct), np.uint8)
+  k = 0
+  for i in range(sample):
+    want[i] = drawn[k]
+    if i in alt_k:
+      want[i, :, :, c_enc] = drawn[k + 1][:, :, 5]
+      want[i, :, :, c_enc + 1] = drawn[k + 2][:, :, 5]
+      k += 2
+    k += 1
+  got = images[:sample].cpu().numpy()
+  ref = inception_ref.InceptionV3(Ct)
+  ref.load_flat(model.flat_weights)
+  torch.set_num_threads(min(64, os.cpu_count() or 1))
+  with torch.no_grad():
+    wp = torch.cat([ref(torch.from_numpy(got[i:i + 64]), channels_last=True) for i in range(0, sample, 64)])
+  dp = (probs[:sample].cpu() - wp).abs().max(1).values
+  return {'candidates': sample, 'pileup_tensors_bit_exact': bool((got == want).all()),
+          'max_abs_dp': float(dp.max()), 'mean_abs_dp': float(dp.mean()), 'tolerance': 1e-3,
+          'ok': bool(dp.max() <= 1e-3),
+          'oracle_prob_spread': float((wp.max(0).values - wp.min(0).values).max())}
+
+
 def parity_sample(region, opts, C, model, images, probs, n=512):
   """`n` SITES strided across the whole TIMED batch against the oracle, after the timed region.
 
@@ -780,21 +973,100 @@ def cpu_baseline(host_batch, opts, C, sample):
       t0 = time.perf_counter()
       ref(x, channels_last=best_cl)
       t_cnn = min(t_cnn, time.perf_counter() - t0)
-  per_item = t_enc / n_enc + t_cnn / n_cnn
+  # One torch process leaves most of a 256-core host idle (16 threads won the sweep in round 3); the
+  # reference fills a node with N independent shard processes (scripts/run_deepvariant.py:457-462).
+  # Same here: P = cores / best_threads classifier processes run concurrently, each on its own copy of
+  # the sample, and the node rate is what they finish together.
+  procs = max(1, cores // best_threads)
+  node_rate, used = _cnn_node_rate(C, imgs.reshape(-1, opts.height, opts.width, C)[:n_cnn], best_threads,
+                                   best_cl, procs)
+  one_rate = n_cnn / t_cnn
+  cnn_rate = max(node_rate, one_rate)
+  per_item = t_enc / n_enc + 1.0 / cnn_rate
   return {
       'value': 1.0 / per_item,
       'unit': 'candidates/s',
       'cores': cores,
+      'cores_used': used * best_threads if node_rate >= one_rate else best_threads,
       'kind': 'port',
       'sample': '%d candidates encoded by the C++ oracle on %d threads (%.2f s) '
-                '+ %d classified in one batch by fp32 torch-CPU Inception-v3 on %d threads '
-                '(best of 2: %.1f s); reference binaries cannot be built here (DESIGN.md)' %
-                (n_enc, cores, t_enc, n_cnn, best_threads, t_cnn),
+                '+ fp32 torch-CPU Inception-v3: %d processes x %d threads, each classifying the same %d '
+                'candidates in one batch, concurrently (node rate %.0f/s; one process alone %.0f/s); '
+                'reference binaries cannot be built here (DESIGN.md)' %
+                (n_enc, cores, t_enc, used, best_threads, n_cnn, node_rate, one_rate),
       'cnn_threads': best_threads,
+      'cnn_processes': used,
       'cnn_channels_last': best_cl,
       'encoder_candidates_per_s': n_enc / t_enc,
-      'cnn_candidates_per_s': n_cnn / t_cnn,
+      'cnn_candidates_per_s': cnn_rate,
+      'cnn_candidates_per_s_one_process': one_rate,
   }
+
+
+def _cnn_worker_main(spec):
+  """`bench.py --cnn-worker C,H,W,N,threads,channels_last`: one classifier process of the cpu_baseline
+  leg.  Prints READY after a warm-up, waits for a line on stdin, classifies N synthetic images in one
+  batch and prints the wall-clock span."""
+  C, H, W, n, threads, cl = (int(v) for v in spec.split(','))
+  from oracle import inception_ref
+  torch.set_num_threads(threads)
+  ref = inception_ref.make_random_model(C, seed=1)
+  x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (n, H, W, C), dtype=np.uint8))
+  with torch.no_grad():
+    ref(x[:8], channels_last=bool(cl))
+    print('READY', flush=True)
+    sys.stdin.readline()
+    t0 = time.time()
+    ref(x, channels_last=bool(cl))
+    print('SPAN %.6f %.6f' % (t0, time.time()), flush=True)
+
+
+def _cnn_node_rate(C, x, threads, channels_last, procs, timeout_s=240):
+  """`procs` classifier processes (own interpreters; `threads` torch threads each) classify a batch of
+  x's shape at the same time -> (candidates/s of the node, processes that finished).  Bounded by one
+  overall deadline; 0 when nothing finished."""
+  import select
+  import subprocess
+  n, H, W, _ = x.shape
+  spec = '%d,%d,%d,%d,%d,%d' % (C, H, W, n, threads, int(channels_last))
+  ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cnn-worker', spec],
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        for _ in range(procs)]
+  deadline = time.time() + timeout_s
+
+  def lines(prefix):
+    got = {}
+    while len(got) < len(ps) and time.time() < deadline:
+      waiting = [p.stdout for i, p in enumerate(ps) if i not in got and p.poll() is None]
+      if not waiting:
+        break
+      r, _, _ = select.select(waiting, [], [], max(0.0, min(5.0, deadline - time.time())))
+      for f in r:
+        i = [q.stdout for q in ps].index(f)
+        line = f.readline()
+        if line.startswith(prefix):
+          got[i] = line
+    return got
+  spans = []
+  try:
+    ready = lines('READY')
+    for i in ready:
+      ps[i].stdin.write('go\n')
+      ps[i].stdin.flush()
+    ps_all, ps[:] = ps[:], [ps[i] for i in ready]
+    for line in lines('SPAN').values():
+      _, b, e = line.split()
+      spans.append((float(b), float(e)))
+    ps[:] = ps_all
+  finally:
+    for p in ps:
+      if p.poll() is None:
+        p.kill()
+      p.wait()
+  if not spans:
+    return 0.0, 0
+  wall = max(e for _, e in spans) - min(b for b, _ in spans)
+  return len(spans) * n / wall, len(spans)
 
 
 def _first_items(batch, n):

@@ -196,8 +196,10 @@ class DvAlleleCounterOptions(C.Structure):
 
 
 class DvAlleleEvent(C.Structure):
+  # include/dvhip.h dv_allele_event (ABI v3): length_type = length (bits 0-27) | AlleleType (28-30) |
+  # is_low_quality (bit 31)
   _fields_ = [('position', C.c_int32), ('read', C.c_uint32), ('read_offset', C.c_uint32),
-              ('length', C.c_uint16), ('type', C.c_uint8), ('low_quality', C.c_uint8)]
+              ('length_type', C.c_uint32)]
 
 
 class DvModelDesc(C.Structure):

@@ -745,6 +745,13 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
           row_flush(row + kWaves);
         }
       }
+      // The loop leaves one or two redundant gathers in flight (12-24 asm loads the compiler cannot
+      // see) into `even` / `odd`.  Those registers are dead to the allocator from here on, so a load
+      // that lands late would overwrite whatever it puts there next (a store address, a counter):
+      // drain them while both sets are still live.  The asm loads must never outlive their
+      // destination registers' live range.  Costs nothing -- the tail has nothing to overlap with.
+      wait_row(even, false);
+      wait_row(odd, false);
     }
   } else {
     for (int row = first_read; row < read_end; row += kWaves) {

@@ -298,13 +298,10 @@ class Realigner:
   """Realigner(config, ref_reader) (:675-893).  `ref_reader`: n_bases(contig) /
   get_bases(contig, start, end), as everywhere in this package."""
 
-  def __init__(self, config: RealignerOptions, ref_reader, shared_header=None, allele_counter_cls=None):
-    # allele_counter_cls: see window_selector._candidates_from_reads (CPU tests of the host
-    # logic only; the product counts on the device)
+  def __init__(self, config: RealignerOptions, ref_reader, shared_header=None):
     self.config = config
     self.ref_reader = ref_reader
     self.shared_header = shared_header
-    self._allele_counter_cls = allele_counter_cls
 
   # ---- reference access in the reference's terms
   def _is_valid(self, r: T.Range) -> bool:          # GenomeReference::IsValidInterval, reference.cc:95-102
@@ -376,8 +373,7 @@ class Realigner:
       reads = split_reads(reads)
     reads = list(reads)
     table = packing.ReadTable.from_reads(reads)
-    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, reads, region, table=table,
-                                             allele_counter_cls=self._allele_counter_cls)
+    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, reads, region, table=table)
     candidate_haplotypes = self.call_debruijn_graph(windows, reads, table=table)
     assembled_regions = [AssemblyRegion(ch) for ch in candidate_haplotypes]
     realigned = assign_reads_to_assembled_regions(assembled_regions, reads)
@@ -398,10 +394,7 @@ class Realigner:
       return [], table
     if self.config.split_skip_reads:
       raise NotImplementedError('split_skip_reads works on Read objects (realign_reads)')
-    # (an injected allele counter -- CPU tests of this host logic -- takes Read objects)
-    counted = range(n) if self._allele_counter_cls is None else table.to_reads(region.reference_name)
-    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, counted, region, table=table,
-                                             allele_counter_cls=self._allele_counter_cls)
+    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, range(n), region, table=table)
     starts = table.read_pos.astype(np.int64)
     ends = table.read_end.astype(np.int64)
     usable = [w for w in windows

@@ -162,17 +162,16 @@ def allele_count_linear_candidates_from_allele_counter(allele_counter, model: Al
 
 
 def _candidates_from_reads(config: WindowSelectorOptions, ref_reader, reads: Sequence, region: T.Range,
-                           table=None, allele_counter_cls=None) -> List[int]:
+                           table=None) -> List[int]:
   """window_selector._candidates_from_reads (:40-86).  `table`: the reads already packed
-  (packing.ReadTable), so the counter does not pack them again.  `allele_counter_cls` exists
-  for the CPU tests of this host logic (they inject a counter with the same interface); the
-  product never passes one and counts on the device."""
+  (packing.ReadTable), so the counter does not pack them again.  The counter is
+  `allelecounter.AlleleCounter`, looked up at call time: it counts on the device."""
   expanded = utils.expand(region, config.region_expansion_in_bp, ref_reader.n_bases(region.reference_name))
-  counter = (allele_counter_cls or allelecounter.AlleleCounter)(
+  counter = allelecounter.AlleleCounter(
       ref_reader, expanded.reference_name, expanded.start, expanded.end,
       min_mapping_quality=config.min_mapq, min_base_quality=config.min_base_quality,
       keep_legacy_behavior=config.keep_legacy_behavior)
-  if table is not None and allele_counter_cls is None:
+  if table is not None:
     counter.add_table(table)
   else:
     for read in reads:
@@ -213,12 +212,11 @@ def _candidates_to_windows(config: WindowSelectorOptions, candidate_pos: Sequenc
 
 
 def select_windows(config: WindowSelectorOptions, ref_reader, reads: Sequence, region: T.Range,
-                   table=None, allele_counter_cls=None) -> List[T.Range]:
+                   table=None) -> List[T.Range]:
   """window_selector.select_windows (:215-238)."""
   if not reads:
     return []
   if config.realign_all:
     return [region]
-  candidates = _candidates_from_reads(config, ref_reader, reads, region, table=table,
-                                      allele_counter_cls=allele_counter_cls)
+  candidates = _candidates_from_reads(config, ref_reader, reads, region, table=table)
   return _candidates_to_windows(config, candidates, region.reference_name)

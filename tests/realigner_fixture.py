@@ -98,6 +98,10 @@ class OracleAlleleCounter:
   def add(self, read, sample=''):
     self._c.add(read)
 
+  def add_table(self, table):
+    for read in table.to_reads(self._contig):
+      self._c.add(read)
+
   def interval_length(self):
     return len(self._c.counts)
 
@@ -109,3 +113,31 @@ class OracleAlleleCounter:
       a.read_alleles = {k: ac.Allele(v.bases, v.type, 1, v.is_low_quality) for k, v in c.read_alleles.items()}
       out.append(a)
     return out
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def oracle_allele_counter():
+  """CPU tests of the realigner's host logic: `deepvariant_amd.allelecounter.AlleleCounter` (which counts on
+  the device) is swapped for the oracle's counter while the block runs.  The product has no parameter
+  for this; the swap is the test's business."""
+  from deepvariant_amd import allelecounter
+  old = allelecounter.AlleleCounter
+  allelecounter.AlleleCounter = OracleAlleleCounter
+  try:
+    yield
+  finally:
+    allelecounter.AlleleCounter = old
+
+
+def with_oracle_counter(fn):
+  """Decorator form of oracle_allele_counter() for a whole CPU test."""
+  import functools
+
+  @functools.wraps(fn)
+  def wrapped(*args, **kwargs):
+    with oracle_allele_counter():
+      return fn(*args, **kwargs)
+  return wrapped

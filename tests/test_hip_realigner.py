@@ -43,7 +43,8 @@ def test_example_regions_device_counts(name, lo, hi, window, use_model):
   config = R.realigner_config(ws_use_window_selector_model=use_model)
   region = T.Range('chr20', lo, hi)
   got_w, got_r = R.Realigner(config, ref).realign_reads(sets[name], region)
-  want_w, want_r = R.Realigner(config, ref, allele_counter_cls=RF.OracleAlleleCounter).realign_reads(sets[name], region)
+  with RF.oracle_allele_counter():
+    want_w, want_r = R.Realigner(config, ref).realign_reads(sets[name], region)
   assert got_w == want_w and got_r == want_r
   assert len(got_r) == len(sets[name])
   if use_model:

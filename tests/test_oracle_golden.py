@@ -256,7 +256,16 @@ def test_golden_candidates_from_raw_reads():
 # images bit-exact.
 # ---------------------------------------------------------------------------
 def run_golden_chain(make_counter, realigner_counter_cls, build_image):
-  """-> (found calls by (start, ref, alts), images by example index)."""
+  """-> (found calls by (start, ref, alts), images by example index).  `realigner_counter_cls`: not None =
+  the realigner's window selector counts with the oracle's counter (swapped in for the device one while
+  the chain runs: no GPU in the CPU suite)."""
+  import contextlib
+  from tests import realigner_fixture as RF
+  with (RF.oracle_allele_counter() if realigner_counter_cls is not None else contextlib.nullcontext()):
+    return _run_golden_chain(make_counter, build_image)
+
+
+def _run_golden_chain(make_counter, build_image):
   from deepvariant_amd import variant_calling as vc
   from deepvariant_amd.realigner import realigner as R
   from deepvariant_amd.realigner import utils as U
@@ -265,7 +274,7 @@ def run_golden_chain(make_counter, realigner_counter_cls, build_image):
   ref, sets = RF.load()
   _, examples, _ = golden_io.load(FIXTURE)
   opts = MG.wgs_options()
-  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=realigner_counter_cls)
+  rl = R.Realigner(R.realigner_config(), ref)
   caller = vc.VariantCaller(vc.VariantCallerOptions(
       min_count_snps=2, min_count_indels=2, min_fraction_snps=0.12, min_fraction_indels=0.06,
       sample_name='NA12878'))
@@ -465,6 +474,12 @@ def alt_pic_options(mode, with_alt):
 
 @pytest.mark.parametrize('mode', ['rows', 'diff_channels'])
 def test_golden_illumina_alt_aligned_chain(mode):
+  from tests import realigner_fixture as RF
+  with RF.oracle_allele_counter():
+    _golden_illumina_alt_aligned_chain(mode)
+
+
+def _golden_illumina_alt_aligned_chain(mode):
   from deepvariant_amd import allelecounter as ac
   from deepvariant_amd import alt_aligned_pileup_lib as A
   from deepvariant_amd import fast_pass_aligner as fpa
@@ -479,7 +494,7 @@ def test_golden_illumina_alt_aligned_chain(mode):
   pic, enc = alt_pic_options(mode, True), alt_pic_options(mode, False)
   hw = (pic.width - 1) // 2
   n_contig = ref.n_bases('chr20')
-  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=RF.OracleAlleleCounter)
+  rl = R.Realigner(R.realigner_config(), ref)
   caller = vc.VariantCaller(vc.VariantCallerOptions(2, 2, 0.12, 0.06))
   reads = sets['wgs']
   spans = [U.read_range(r) for r in reads]

@@ -37,8 +37,15 @@ def fixture():
   return RF.load()
 
 
+@pytest.fixture(autouse=True)
+def _oracle_counter():
+  """No GPU here: the window selector's allele counts come from the oracle's counter."""
+  with RF.oracle_allele_counter():
+    yield
+
+
 def make_realigner(ref, **flags):
-  return realigner.Realigner(realigner.realigner_config(**flags), ref, allele_counter_cls=RF.OracleAlleleCounter)
+  return realigner.Realigner(realigner.realigner_config(**flags), ref)
 
 
 # ---------------------------------------------------------------- ReadAssignmentTests, :77-194

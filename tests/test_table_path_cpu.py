@@ -58,11 +58,12 @@ def test_with_alignments_equals_repacking_moved_reads():
 
 
 @pytest.mark.timeout(900)
+@RF.with_oracle_counter
 def test_realign_table_equals_realign_reads():
   """The realigner on a table against the realigner on objects, per 1000-base region of the golden
   slice (the goldens themselves pin the object path): same windows, same reads moved, same order."""
   ref, sets = RF.load()
-  rl = R.Realigner(R.realigner_config(), ref, allele_counter_cls=RF.OracleAlleleCounter)
+  rl = R.Realigner(R.realigner_config(), ref)
   reads = sets['wgs']
   spans = [U.read_range(r) for r in reads]
   n_moved = 0

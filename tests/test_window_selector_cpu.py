@@ -51,8 +51,8 @@ def test_candidates_to_windows_distances(d):                   # :505-567
 def test_select_windows():                                     # :569-585
   reads = [V.mk('AGA', 99, '3M', [q] * 3) for q in (64, 63, 62)]
   chrom = reads[0].alignment.position.reference_name
-  got = ws.select_windows(V.threshold_config(), RF.StringRef(chrom, 'A' * 300), reads, T.Range(chrom, 0, 200),
-                          allele_counter_cls=RF.OracleAlleleCounter)
+  with RF.oracle_allele_counter():
+    got = ws.select_windows(V.threshold_config(), RF.StringRef(chrom, 'A' * 300), reads, T.Range(chrom, 0, 200))
   assert got == [T.Range(chrom, 96, 104)]
 
 

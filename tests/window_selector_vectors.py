@@ -30,11 +30,13 @@ def threshold_config():     # WindowSelectorTest.setUp, :177-191
 
 
 def candidates(config, reads, start=0, end=20, ref=None, counter_cls=None):
-  """assertCandidatesFromReadsEquals' left-hand side (:63-84)."""
+  """assertCandidatesFromReadsEquals' left-hand side (:63-84).  `counter_cls` = the oracle's counter
+  (CPU tests): swapped in for allelecounter.AlleleCounter while the call runs; None = the device counter."""
+  import contextlib
   chrom = reads[0].alignment.position.reference_name
   ref = ref if ref is not None else 'A' * (end - start + 512)
-  return ws._candidates_from_reads(config, RF.StringRef(chrom, ref), reads, T.Range(chrom, start, end),
-                                   allele_counter_cls=counter_cls)
+  with (RF.oracle_allele_counter() if counter_cls is not None else contextlib.nullcontext()):
+    return ws._candidates_from_reads(config, RF.StringRef(chrom, ref), reads, T.Range(chrom, start, end))
 
 
 # (config name, reads as argument tuples of mk, expected, kwargs)
