@@ -1568,7 +1568,16 @@ struct dv_model {
     // The default set is a property of the LAYER, not of the kernel that happens to run it: 1x1
     // layers from mixed4 on, 3-tap and 3x3 layers from mixed8 on -- never the factorised-7x7
     // layers, which run as fused chains (and must give the same bits when DV_NO_CHAIN unfuses them).
+    const char* list_env = getenv("DV_SPLIT_LAYERS");   // experiments: an explicit comma list of layers
     auto wanted = [&](const Op& o) {
+      if (list_env != nullptr) {
+        for (const char* q = list_env; *q;) {
+          if (atoi(q) == o.layer) return true;
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+        return false;
+      }
       if (first_layer_env >= 0) return o.layer >= first_layer_env;
       if (o.kh * o.kw == 1) return o.layer >= 30;
       return o.layer >= 70 && std::max(o.kh, o.kw) <= 3;

@@ -20,7 +20,7 @@ def main():
   ap.add_argument('--n', type=int, default=2048)
   ap.add_argument('--seeds', default='17,29')
   ap.add_argument('--split_from', default='94,70,0')
-  ap.add_argument('--env', default='', help='extra settings to sweep instead, e.g. DV_X=1;DV_Y=2')
+  ap.add_argument('--layer_sets', default='', help="';'-separated DV_SPLIT_LAYERS lists to sweep instead")
   args = ap.parse_args()
   import test_hip_precision as T
   print('# HIP forward vs fp32 oracle, %d ILLUMINA30 pileups per seed; max / mean / 99.9th percentile |dp|' % args.n)
@@ -28,12 +28,18 @@ def main():
     ref = R.make_random_model(7, seed=seed)
     x = T._pileups(args.n, seed=1000 + seed)
     want = T._oracle_probs(ref, x)
-    for sf in args.split_from.split(','):
-      m = T._model(ref.export_flat(), args.n, split_from=int(sf))
+    settings = ([('DV_SPLIT_LAYERS', v) for v in args.layer_sets.split(';')] if args.layer_sets else
+                [('DV_SPLIT_FROM', v) for v in args.split_from.split(',')])
+    for key, val in settings:
+      os.environ[key] = val
+      try:
+        m = T._model(ref.export_flat(), args.n, split_from=None if key == 'DV_SPLIT_LAYERS' else int(val))
+      finally:
+        os.environ.pop(key, None)
       got = m(torch.from_numpy(x).cuda()).cpu().numpy()
       del m
       e = np.abs(got - want).max(axis=1)
-      print('seed %d DV_SPLIT_FROM=%-3s  %.3e / %.3e / %.3e' % (seed, sf, e.max(), e.mean(), np.quantile(e, 0.999)),
+      print('seed %d %s=%-3s  %.3e / %.3e / %.3e' % (seed, key, val, e.max(), e.mean(), np.quantile(e, 0.999)),
             flush=True)
 
 
