@@ -2404,7 +2404,7 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   m->build();
   m->stem_a_grid = dv::stem_a_blocks(device);
   m->stem_b_grid = dv::stem_b_blocks(device);
-  m->n_cus = m->stem_b_grid;
+  m->n_cus = dv::stem_a_blocks(device) / 2;   // stem_a runs two workgroups per CU
   // 32-bit index ranges of the kernels at max_batch (see conv_mfma_kernel's prologue)
   for (const Op& op : m->ops) {
     const BufferDesc& ob = m->buffers[op.out_buf];

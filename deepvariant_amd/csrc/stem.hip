@@ -360,29 +360,35 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
 }
 
 // =========================================================================== stem B
-constexpr int B_PH = kStemB_PH, B_PW = kStemB_PW;             // pooled tile 12 x 9
-constexpr int B_C3H = 2 * B_PH + 1, B_C3W = 2 * B_PW + 1;     // conv3 tile 25 x 19
-constexpr int B_C3PX = B_C3H * B_C3W;                         // 475
-constexpr int B_C3FR = (B_C3PX + 31) / 32;                    // 15 fragments
+constexpr int B_PH = kStemB_PH, B_PW = kStemB_PW;             // pooled tile 6 x 9 (wide build: 12 x 9)
+constexpr int B_WAVES = kStemB_Waves;
+constexpr int B_C3H = 2 * B_PH + 1, B_C3W = 2 * B_PW + 1;     // conv3 tile 13 x 19 (25 x 19)
+constexpr int B_C3PX = B_C3H * B_C3W;                         // 247 (475)
+constexpr int B_C3FR = (B_C3PX + 31) / 32;                    // 8 fragments (15)
 // conv3 tile in LDS: 8 planes of 8 channels; the plane stride is an ODD number of pieces so
-// that the max-pool's stride-2 reads of two adjacent planes interleave on the LDS banks
-constexpr int B_C3PLANE = (B_C3FR * 32 + 1) * 16;             // 7696
-constexpr int B_PTH = B_C3H + 2, B_PTW = B_C3W + 2;           // input patch 27 x 21
-constexpr int B_PTPX = B_PTH * B_PTW;                         // 567
-constexpr int B_PTPLANE = B_PTPX * 16;                        // 9072
+// that the max-pool's stride-2 reads of two adjacent planes interleave on the LDS banks.  Only
+// the tile's own pixels are stored (the last fragment's surplus lanes are predicated off), so
+// the stride is the pixel count rounded up to odd.
+constexpr int B_C3PLANE = (B_C3PX | 1) * 16;                  // 3952 (7600)
+constexpr int B_PTH = B_C3H + 2, B_PTW = B_C3W + 2;           // input patch 15 x 21 (27 x 21)
+constexpr int B_PTPX = B_PTH * B_PTW;                         // 315 (567)
+constexpr int B_PTPLANE = B_PTPX * 16;                        // 5040 (9072)
 constexpr int B_PT_BYTES = (4 * B_PTPLANE + 1023) / 1024 * 1024;  // 32 channels, padded to the 1 KB DMA granule
-constexpr int B_PT_PIECES = 4 * B_PTPX;                       // 2268
-constexpr int B_PPX = B_PH * B_PW;                            // 108 pooled pixels
-constexpr int B_PFR = (B_PPX + 31) / 32;                      // 4 fragments
-constexpr int B_PPLANE = B_PFR * 32 * 16;                     // 2048
-constexpr int B_THREADS = 512;
+constexpr int B_PT_PIECES = 4 * B_PTPX;                       // 1260 (2268)
+constexpr int B_PPX = B_PH * B_PW;                            // 54 (108) pooled pixels
+constexpr int B_PFR = (B_PPX + 31) / 32;                      // 2 (4) fragments
+constexpr int B_PPLANE = B_PFR * 32 * 16;                     // 1024 (2048)
+constexpr int B_THREADS = B_WAVES * 64;
 constexpr int B_PASSES = (B_PT_PIECES + B_THREADS - 1) / B_THREADS;  // 5
+constexpr int B_POOL_ROUNDS = (8 * B_PPX + B_THREADS - 1) / B_THREADS;  // 2
 constexpr int B_OFF_C3 = 2 * B_PT_BYTES;                      // LDS map: patch x2 | conv3 | pooled | shifts
-constexpr int B_OFF_P = B_OFF_C3 + 8 * B_C3PLANE;
+constexpr int B_OFF_P = (B_OFF_C3 + 8 * B_C3PLANE + 15) / 16 * 16;
 constexpr int B_OFF_SH = B_OFF_P + 8 * B_PPLANE;
 constexpr int B_LDS = B_OFF_SH + (64 + 96) * 4;
-static_assert(B_LDS <= 160 * 1024, "one workgroup per CU");
-static_assert(B_PFR == 4, "1x1 work split assumes four pooled fragments");
+constexpr int B_BLOCKS_PER_CU = B_WAVES == 4 ? 2 : 1;
+static_assert(B_LDS * B_BLOCKS_PER_CU <= 160 * 1024, "workgroups per CU");
+static_assert(2 * B_PFR == B_WAVES, "1x1 work split: (pooled fragment, subtiles {0,1}) and (fragment, subtile 2)");
+static_assert(B_C3FR <= 2 * B_WAVES, "two conv3 fragments per wave");
 
 __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -399,10 +405,10 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     a3lo[kc] = *reinterpret_cast<const half8_t*>(p.w3 + (((0 * 18 + kc) * 2 + hi) * 32 + l31) * 8);
     a3up[kc] = *reinterpret_cast<const half8_t*>(p.w3 + (((1 * 18 + kc) * 2 + hi) * 32 + l31) * 8);
   }
-  // 1x1: waves 0-3 own output subtiles 0 and 1 of pooled fragment `wave`, waves 4-7 subtile 2;
-  // its weights (12 fragments, L2 resident) are fetched per tile, not held
-  const int s0 = wave < 4 ? 0 : 2;
-  const int nsub = wave < 4 ? 2 : 1;
+  // 1x1: the first half of the waves own output subtiles 0 and 1 of pooled fragment `wave`, the
+  // second half subtile 2; its weights (12 fragments, L2 resident) are fetched per tile, not held
+  const int s0 = wave < B_PFR ? 0 : 2;
+  const int nsub = wave < B_PFR ? 2 : 1;
 #pragma unroll
   for (int kc = 0; kc < 18; ++kc) {  // loads retire here (see stem A)
     asm volatile("" : "+v"(a3lo[kc]));
@@ -431,19 +437,21 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
                    ? static_cast<unsigned>(((g * p.ig.hp + row) * p.ig.wp + col) * 16)
                    : 0x80000000u;
   }
-  // conv3: fragments wave and wave + 8 of the 25 x 19 tile
+  // conv3: fragments wave and wave + B_WAVES of the tile
   unsigned b3[2], c3dst[2];
+  bool c3ok[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const int i = (wave + 8 * m) * 32 + l31;
+    const int i = (wave + B_WAVES * m) * 32 + l31;
+    c3ok[m] = i < B_C3PX;
     const int ii = min(i, B_C3PX - 1);
     const int cy = ii / B_C3W, cx = ii - cy * B_C3W;
     b3[m] = static_cast<unsigned>(hi * B_PTPLANE + (cy * B_PTW + cx) * 16);
     // conv3 output channel 32h + 16rh + {0-3, 8-11} + 4hi  ->  plane (2h + rh)*2 + hi
     c3dst[m] = static_cast<unsigned>(B_OFF_C3 + hi * B_C3PLANE + i * 16);
   }
-  // 1x1: pooled fragment wave & 3
-  const int pp = (wave & 3) * 32 + l31;
+  // 1x1: pooled fragment wave % B_PFR
+  const int pp = (wave % B_PFR) * 32 + l31;
   const int ppc = min(pp, B_PPX - 1);
   const int ppy = ppc / B_PW, ppx = ppc - ppy * B_PW;
   const unsigned b4 = static_cast<unsigned>(B_OFF_P + hi * B_PPLANE + pp * 16);
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     return static_cast<unsigned>(((2 * py0 - 1 + p.ig.halo) * p.ig.wp + 2 * px0 - 1 + p.ig.halo) * 16);
   };
   auto dma_round = [&](int ps, const __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned buf_off) {
-    const unsigned g0 = static_cast<unsigned>((ps * 8 + wave_u) * 1024);
+    const unsigned g0 = static_cast<unsigned>((ps * B_WAVES + wave_u) * 1024);
     if (g0 < static_cast<unsigned>(B_PT_BYTES)) {  // wave-uniform
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsrc, (__attribute__((address_space(3))) void*)(smem + buf_off + g0), 16, prel[ps], soff, 0, 0);
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     // ---- conv3 (3x3 'same', 32 -> 64) on this wave's two fragments -> LDS ---------------------
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (wave + 8 * m < B_C3FR) {  // wave-uniform: fragment 15 does not exist
+      if (wave + B_WAVES * m < B_C3FR) {  // wave-uniform (wide build: fragment 15 does not exist)
         float16_t acc_lo = acc_init(lsh + hi * 16), acc_up = acc_init(lsh + 32 + hi * 16);
         mfma_sweep_pair<18, 4>(
             a3lo, a3up, smem,
@@ -533,10 +541,12 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
                 dma_round(sI / 3, rn, son, buf ^ B_PT_BYTES);
               }
             });
-        *reinterpret_cast<uint4_t*>(smem + c3dst[m]) = relu_piece(acc_lo, 0);
-        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 2 * B_C3PLANE) = relu_piece(acc_lo, 1);
-        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 4 * B_C3PLANE) = relu_piece(acc_up, 0);
-        *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 6 * B_C3PLANE) = relu_piece(acc_up, 1);
+        if (c3ok[m]) {   // the last fragment's surplus lanes have no slot in the tile
+          *reinterpret_cast<uint4_t*>(smem + c3dst[m]) = relu_piece(acc_lo, 0);
+          *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 2 * B_C3PLANE) = relu_piece(acc_lo, 1);
+          *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 4 * B_C3PLANE) = relu_piece(acc_up, 0);
+          *reinterpret_cast<uint4_t*>(smem + c3dst[m] + 6 * B_C3PLANE) = relu_piece(acc_up, 1);
+        }
       }
     }
     // this wave's 1x1 weight fragments start their trip now (used after the pool)
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     // 16-byte reads fall on 32 consecutive even/odd LDS slots -- no bank conflicts (they cost
     // 2x on 124 KB of reads per tile when a wave walked one plane with stride 2)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < B_POOL_ROUNDS; ++k) {
       const int e = k * B_THREADS + tid;
       if (e < 8 * B_PPX) {
         const int j = e >> 1;
@@ -630,9 +640,9 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     buf ^= B_PT_BYTES;
   }
 #undef DV_PHASE
-  if (p.prof && lane == 0 && (wave == 0 || wave == 7)) {
+  if (p.prof && lane == 0 && (wave == 0 || wave == B_WAVES - 1)) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) p.prof[(blockIdx.x * 2 + (wave == 7)) * 8 + i] = ph[i];
+    for (int i = 0; i < 7; ++i) p.prof[(blockIdx.x * 2 + (wave == B_WAVES - 1)) * 8 + i] = ph[i];
   }
 }
 
@@ -645,7 +655,7 @@ int cu_count(int device) {
 }  // namespace
 
 int stem_a_blocks(int device) { return 2 * cu_count(device); }
-int stem_b_blocks(int device) { return cu_count(device); }
+int stem_b_blocks(int device) { return B_BLOCKS_PER_CU * cu_count(device); }
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream) {
   static const bool attr = [] {

@@ -44,7 +44,15 @@ struct StemAArgs {
 // ---- stem B: conv 3x3 'same' 32 -> 64, max-pool 3x3/2, conv 1x1 64 -> 80 -----------------
 // One workgroup produces a PH x PW tile of the 1x1's output; the conv3 tile
 // ((2PH+1) x (2PW+1) x 64) and its pooled image live in LDS only.
-constexpr int kStemB_PH = 12, kStemB_PW = 9;
+// Round 4: tiles of 6 x 9 pooled pixels on FOUR waves, two workgroups per CU (80 KB of LDS each): the
+// eight waves of the round-2/3 kernel moved in lockstep, so every phase's tail (DMA wait, two
+// barriers, the MFMA-free pool) was exposed -- 46 % MFMA-busy; two independent workgroups cover
+// each other's.  -DDV_STEM_B_WIDE builds the old 12 x 9 / eight-wave shape for A/B runs.
+#ifdef DV_STEM_B_WIDE
+constexpr int kStemB_PH = 12, kStemB_PW = 9, kStemB_Waves = 8;
+#else
+constexpr int kStemB_PH = 6, kStemB_PW = 9, kStemB_Waves = 4;
+#endif
 constexpr int kStemB_W3Halfs = 2 * 18 * 2 * 32 * 8;  // [cout half][9 taps x 2 chunks]
 constexpr int kStemB_W4Halfs = 3 * 4 * 2 * 32 * 8;   // [cout subtile][4 chunks]
 
