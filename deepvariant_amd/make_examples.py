@@ -670,6 +670,14 @@ def main(argv=None) -> int:
   except (ValueError, KeyError, IOError, OSError) as e:
     print('make_examples: %s' % e, file=sys.stderr)
     return 1
+  except Exception as e:  # pylint: disable=broad-except
+    # a spawned rank's ValueError / IOError comes back wrapped (torch.multiprocessing.ProcessRaisedException):
+    # same message and exit code as the single-process route, not a traceback
+    if type(e).__name__ not in ('ProcessRaisedException', 'ProcessExitedException'):
+      raise
+    lines = [ln for ln in str(e).strip().splitlines() if ln.strip()]
+    print('make_examples: %s' % (lines[-1] if lines else e), file=sys.stderr)
+    return 1
   return 0
 
 

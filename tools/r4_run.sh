@@ -24,7 +24,12 @@ for step in "$@"; do
        python $R/profiles/summarize_rocpd.py $(find $R/$O/stats -name '*.db' | head -1) > $R/$O/kernel_stats.txt
        rm -rf $R/$O/stats; cd $R; head -20 $O/kernel_stats.txt ;;
     bam) timeout 300 python bench.py --mode bam > $O/bench_bam.json 2> $O/bench_bam.err; cat $O/bench_bam.json ;;
-    workloads) for w in hifi35 ont50; do timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; cat $O/bench_$w.json; done ;;
+    workloads) for w in hifi35 ont50; do
+         timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; cat $O/bench_$w.json
+         DV_OP_TRACE=1 timeout 300 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/op_trace_$w.txt
+         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_$w -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $R/$O/stats_$w.log 2>&1
+           python $R/profiles/summarize_rocpd.py $(find $R/$O/stats_$w -name '*.db' | head -1) > $R/$O/kernel_stats_$w.txt; rm -rf $R/$O/stats_$w )
+       done ;;
     ab:*) kv=${step#ab:}; for r in 1 2; do bench_line default; bench_line "$kv" "$kv"; done ;;
     *) echo "unknown step $step" ;;
   esac
