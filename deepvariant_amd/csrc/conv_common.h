@@ -88,7 +88,11 @@ struct ConvArgs {
   const _Float16* blank_src;
   // Split weights (model.hip): the packed image holds every K chunk twice, W_hi then
   // W_lo = fp16(W - W_hi); n_chunks counts both, the pixel operand advances once per pair.
+  // split_tiles: the leading cout tiles of the launch that carry such pairs (= n_tiles when every
+  // branch is split); the tiles behind them hold plain weights in the first half of their slot
+  // (sibling 1x1 heads of which only some are split).
   int split;
+  int split_tiles;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));

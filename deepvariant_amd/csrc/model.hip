@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -312,7 +313,6 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
   // ---- weight slabs: global -> registers -> LDS ---------------------------
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
                       static_cast<size_t>(band_r * p.n_tiles + n_tile) * p.n_slabs * (kSlabChunks * BN * 2);
-  const int n_slabs = (p.n_chunks + SLAB - 1) / SLAB;   // (the packed image is laid out in kSlabChunks units)
   uint4_t wreg[W_PER_THREAD];
 #define DV_LOAD_SLAB(s_)                                                                   \
   {                                                                                        \
@@ -366,36 +366,53 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
     copy_blank_wave<NB, PT>(p, n_tile, pn, poh, pow_, mvalid, lane);
     return;
   }
+  // The K loop of one cout tile over `n_chunks` weight chunks, with (S = true) or without the
+  // (hi, lo) pairing of split weights.  A split launch may mix both kinds of tile: the leading
+  // ConvArgs::split_tiles cout tiles carry W_hi + W_lo (2 K chunks), the others plain weights
+  // (K chunks, the first half of their slot in the packed image) -- block-uniform choice.
+  auto k_loop = [&](auto split_tag, const int n_chunks) {
+    constexpr bool S = decltype(split_tag)::value;
+    const int tile_slabs = (n_chunks + SLAB - 1) / SLAB;
 #ifdef DV_ABLATE_LOOP
-  const int n_full = p.n_chunks < 0 ? 1 : 0;
-  const int rem = 0;
+    const int n_full = n_chunks < 0 ? 1 : 0;
+    const int rem = 0;
 #else
-  const int n_full = p.n_chunks / SLAB;
-  const int rem = p.n_chunks - n_full * SLAB;
+    const int n_full = n_chunks / SLAB;
+    const int rem = n_chunks - n_full * SLAB;
 #endif
-  for (int s = 0; s < n_full; ++s) {
-    // The next slab's global loads are UNCONDITIONAL (the last trip re-reads its own slab
-    // into the idle buffer): behind an `if` the compiler has to assume at the first
-    // pixel-fragment wait that they were not issued and emits vmcnt(7) -- which, when they
-    // were, drains the whole four-chunk prefetch queue at every slab start.
-    const int next = s + 1 < n_slabs ? s + 1 : s;
-    DV_LOAD_SLAB(next)
-    conv_slab<NB, PT, SLAB, 0, SPLIT>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc);
-    DV_STORE_SLAB((s + 1) & 1)
-    __syncthreads();
-  }
-  // Tail slab (n_chunks % 8 chunks), in straight-line groups of 4: K is padded
-  // to a multiple of 4 chunks with zero weights (the slab image is zero there),
-  // so no chunk count ever needs a branch or a register rotation inside the
-  // load pipeline.  (A rolled one-chunk loop had to rotate the prefetch slots and
-  // drained vmcnt(0) every chunk; per-count unrolled variants behind a switch
-  // made the register allocator clone the accumulators.)
-  if (rem) {
-    const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
-    conv_slab<NB, PT, 4, 0, SPLIT>(p, rsrc, wslab, walk, base, xf, acc);
-    if constexpr (SLAB > 4) {
-      if (rem > 4) conv_slab<NB, PT, 4, 4, SPLIT>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+    for (int s = 0; s < n_full; ++s) {
+      // The next slab's global loads are UNCONDITIONAL (the last trip re-reads its own slab
+      // into the idle buffer): behind an `if` the compiler has to assume at the first
+      // pixel-fragment wait that they were not issued and emits vmcnt(7) -- which, when they
+      // were, drains the whole four-chunk prefetch queue at every slab start.
+      const int next = s + 1 < tile_slabs ? s + 1 : s;
+      DV_LOAD_SLAB(next)
+      conv_slab<NB, PT, SLAB, 0, S>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc);
+      DV_STORE_SLAB((s + 1) & 1)
+      __syncthreads();
     }
+    // Tail slab (n_chunks % 8 chunks), in straight-line groups of 4: K is padded
+    // to a multiple of 4 chunks with zero weights (the slab image is zero there),
+    // so no chunk count ever needs a branch or a register rotation inside the
+    // load pipeline.  (A rolled one-chunk loop had to rotate the prefetch slots and
+    // drained vmcnt(0) every chunk; per-count unrolled variants behind a switch
+    // made the register allocator clone the accumulators.)
+    if (rem) {
+      const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
+      conv_slab<NB, PT, 4, 0, S>(p, rsrc, wslab, walk, base, xf, acc);
+      if constexpr (SLAB > 4) {
+        if (rem > 4) conv_slab<NB, PT, 4, 4, S>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+      }
+    }
+  };
+  if constexpr (SPLIT) {
+    if (n_tile < p.split_tiles) {
+      k_loop(std::true_type{}, p.n_chunks);
+    } else {
+      k_loop(std::false_type{}, p.n_chunks >> 1);
+    }
+  } else {
+    k_loop(std::false_type{}, p.n_chunks);
   }
 #undef DV_LOAD_SLAB
 #undef DV_STORE_SLAB
@@ -1246,7 +1263,9 @@ struct Op {
   // follows it as ONE launch; the tensor between them is never materialised.
   // imgconv.hip: whole-map tiles, both operands through LDS (set on the launch's leader op)
   int band = 0;                  // conv_mfma_kernel's row-band mode: map rows (= taps kept), 0 = off
-  bool split = false;            // W_hi + W_lo weight image, two MFMAs per product (choose_split)
+  bool split = false;            // the LAUNCH carries W_hi + W_lo weight images (choose_split) ...
+  bool split_rows = false;       // ... and this op's couts are among them (siblings of a group may not be)
+  int split_tiles = 0;           // leader: leading cout tiles of the launch that hold (hi, lo) pairs
   bool v2 = false;
   int v2_g = 0;                  // images per tile
   int v2_steps = 0;              // K steps (KC channel chunks each)
@@ -1579,21 +1598,43 @@ struct dv_model {
         return false;
       }
       if (first_layer_env >= 0) return o.layer >= first_layer_env;
-      if (o.kh * o.kw == 1) return o.layer >= 30;
+      // 17x17 stage: the two 1x1 layers of a block whose output IS block output -- the b1 branch
+      // (written into the concat buffer) and the pooled projection (raw) -- not the heads of the
+      // factorised-7x7 branches (measured: profiles/r04_precision_sweep.txt)
+      if (o.kh * o.kw == 1 && o.layer >= 30 && o.layer < 70) return o.raw || buffers[o.out_buf].c > o.cout;
       return o.layer >= 70 && std::max(o.kh, o.kw) <= 3;
     };
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& op = ops[i];
       if (op.type != kOpConv) continue;
       const int followers = op.group_followers;
-      bool ok = !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b && !op.v2 && op.chain_len == 0 &&
-                !op.in_chain && !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.nb <= 4 &&
-                static_cast<int>(i) != blank_conv4_op;
-      for (int gi = 0; gi <= followers; ++gi) ok = ok && wanted(ops[i + gi]);
-      if (ok) {
+      const bool eligible = !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b && !op.v2 &&
+                            op.chain_len == 0 && !op.in_chain && !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) &&
+                            op.nb <= 4 && static_cast<int>(i) != blank_conv4_op;
+      int n_wanted = 0;
+      for (int gi = 0; gi <= followers; ++gi) n_wanted += wanted(ops[i + gi]) ? 1 : 0;
+      if (eligible && n_wanted > 0) {
+        // Siblings of which only some are wanted: the wanted ones go to the front of the launch's
+        // cout space, and if they fill whole cout tiles only those tiles carry (hi, lo) pairs
+        // (ConvArgs::split_tiles); otherwise -- or when the leader itself is not wanted -- the whole
+        // launch is split.
+        int split_subs = 0, all_subs = 0;
+        bool partial = n_wanted <= followers && wanted(op);
+        if (partial) {
+          std::stable_partition(ops.begin() + i + 1, ops.begin() + i + 1 + followers,
+                                [&](const Op& o) { return wanted(o); });
+          for (int gi = 0; gi <= followers; ++gi) {
+            if (wanted(ops[i + gi])) split_subs += (ops[i + gi].cout + 31) / 32;
+          }
+          partial = split_subs % ops[i].nb == 0;
+        }
+        for (int gi = 0; gi <= followers; ++gi) all_subs += (ops[i + gi].cout + 31) / 32;
+        Op& lead = ops[i];   // (stable_partition leaves the leader in place)
+        lead.split_tiles = partial ? split_subs / lead.nb : (all_subs + lead.nb - 1) / lead.nb;
         for (int gi = 0; gi <= followers; ++gi) {
           Op& o = ops[i + gi];
           o.split = true;
+          o.split_rows = !partial || wanted(o);
           o.n_chunks *= 2;
           o.n_steps = (o.n_chunks + kSlabChunks - 1) / kSlabChunks;
         }
@@ -2235,6 +2276,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.n_chunks = op.n_chunks;
       a.n_slabs = op.n_steps;
       a.split = op.split ? 1 : 0;
+      a.split_tiles = op.split_tiles;
       a.in_bytes = static_cast<size_t>(n) * ib.bytes_per_example();
       a.img_bytes = static_cast<unsigned>(ib.bytes_per_example());
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
@@ -2280,7 +2322,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (op.pool_in) tr_label += " <- maxpool3s2";
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
-      if (op.split) tr_label += " [split W]";
+      if (op.split) tr_label += " [split W: " + std::to_string(op.split_tiles) + " of " + std::to_string(tiles) + " tiles]";
       const bool resident = !op.v2 && !op.pool_in && !op.pool_out && resident_ok(m, op, a);
       if (resident) tr_label += " [weights resident in LDS]";
       if (op.pool_out) tr_label += " [weights resident in LDS] -> maxpool3s2";
@@ -2661,9 +2703,12 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
     // kh = pad_h - band_r + 0..band-1 that meet map rows 0..band-1
     const int eff_taps = op.band ? op.band * op.kw : taps;
     const int n_tiles_op = ((op.cout + 31) / 32 + op.nb - 1) / op.nb;   // band ops are never grouped
-    const int parts = op.split ? 2 : 1;   // split: chunk 2q = W_hi, chunk 2q + 1 = W_lo of pixel chunk q
+    // split rows: chunk 2q = W_hi, chunk 2q + 1 = W_lo of pixel chunk q; plain rows of a split launch
+    // (siblings that are not split) use the first half of the launch's chunk slots
+    const int parts = op.split_rows ? 2 : 1;
+    const int op_chunks = op.split && !op.split_rows ? op.n_chunks / 2 : op.n_chunks;
     for (int band_r = 0; band_r < (op.band ? op.band : 1); ++band_r)
-    for (int kc = 0; kc < op.n_chunks; ++kc) {
+    for (int kc = 0; kc < op_chunks; ++kc) {
       const int sl = kc / kSlabChunks, j = kc % kSlabChunks;
       const int q = kc / parts, part = kc % parts;
       const int cc = q / eff_taps, tap = q % eff_taps;  // chunk-major, tap-minor (ChunkWalk)
