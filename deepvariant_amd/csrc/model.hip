@@ -864,11 +864,15 @@ struct FirstConvArgs {
   int M, n_chunks;
   unsigned in_bytes;
   float rcp_ow, rcp_ohow;
+  // C in 9..16 (the long-read channel sets: 9 = ONT_R104, 10 = PACBIO): a K chunk is ONE tap x 16
+  // "channels" -- k-group 0 = bytes 0..7 of the pixel, k-group 1 = bytes 8..15 (bytes C.. belong to the
+  // next pixel and meet zero weights) -- instead of two taps x 8
+  int wide;
 };
 
-constexpr int kFirstMaxChunks = 13;  // up to 5x5 taps
+constexpr int kFirstMaxChunks = 13;  // up to 5x5 taps (C <= 8) / 3x3 taps (C <= 16)
 
-template <int PT>
+template <int PT, int UNROLL = kFirstUnroll>
 __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvArgs p) {
   __shared__ __attribute__((aligned(16))) _Float16 wl[kFirstMaxChunks * 32 * kChunk];
   const int tid = threadIdx.x;
@@ -925,15 +929,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
     return half8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
   };
   typedef unsigned uint3_t __attribute__((ext_vector_type(3)));
-  if (p.n_chunks <= kFirstUnroll) {
+  if (p.n_chunks <= UNROLL) {
     // every fragment of the tile is requested before the first one is used
-    uint3_t d[kFirstUnroll][PT];
-    unsigned sh[kFirstUnroll][PT];
+    uint3_t d[UNROLL][PT];
+    unsigned sh[UNROLL][PT];
 #pragma unroll
-    for (int kc = 0; kc < kFirstUnroll; ++kc) {
-      const int t = min(2 * kc + hi, taps - 1);
+    for (int kc = 0; kc < UNROLL; ++kc) {
+      const int t = min(p.wide ? kc : 2 * kc + hi, taps - 1);
       const int kh = t / p.KW, kw = t - kh * p.KW;
-      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
+      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C + (p.wide ? 8 * hi : 0));
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const unsigned a = base[pt] + toff;
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
       }
     }
 #pragma unroll
-    for (int kc = 0; kc < kFirstUnroll; ++kc) {
+    for (int kc = 0; kc < UNROLL; ++kc) {
       if (kc < p.n_chunks) {
         const half8_t wf = *reinterpret_cast<const half8_t*>(
             wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
@@ -957,10 +961,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_first_u8_kernel(FirstConvAr
     }
   } else {
     for (int kc = 0; kc < p.n_chunks; ++kc) {
-      // this lane-half's tap; past the last tap the weights are zero
-      const int t = min(2 * kc + hi, taps - 1);
+      // this lane-half's tap (wide: its half of the tap's channels); past the last tap the weights are zero
+      const int t = min(p.wide ? kc : 2 * kc + hi, taps - 1);
       const int kh = t / p.KW, kw = t - kh * p.KW;
-      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C);
+      const unsigned toff = static_cast<unsigned>((kh * p.W + kw) * p.C + (p.wide ? 8 * hi : 0));
       const half8_t wf = *reinterpret_cast<const half8_t*>(
           wl + kc * 32 * kChunk + hi * (32 * 8) + (lane & 31) * 8);
 #pragma unroll
@@ -1722,11 +1726,12 @@ struct dv_model {
     const int in_buf = new_buffer(desc.height, desc.width, 16);
     TensorRef x = full(in_buf);
     x = conv(x, 32, 3, 3, 2, false, -1, 0, desc.channels);
-    if (desc.channels <= 8 && getenv("DV_NO_U8_CONV1") == nullptr) {
+    if (desc.channels <= 16 && getenv("DV_NO_U8_CONV1") == nullptr &&
+        (desc.channels <= 8 || getenv("DV_NO_U8_CONV1_WIDE") == nullptr)) {
       Op& f = ops.back();
-      f.first_u8 = true;  // conv_first_u8_kernel: K chunk = 2 taps x 8 channels
+      f.first_u8 = true;  // conv_first_u8_kernel: K chunk = 2 taps x 8 channels (C <= 8), 1 tap x 16 (C <= 16)
       f.nb = 1;
-      f.n_chunks = (f.kh * f.kw + 1) / 2;
+      f.n_chunks = desc.channels <= 8 ? (f.kh * f.kw + 1) / 2 : f.kh * f.kw;
       f.n_steps = 1;
       buffers[in_buf] = {1, 1, 16, 0};  // the fp16 staging image is never materialised
     }
@@ -1750,12 +1755,18 @@ struct dv_model {
     // Fused stem kernels (stem.hip): conv1+conv2 and conv3+maxpool+1x1 as two persistent
     // launches whose intermediates stay in LDS.  DV_NO_STEM_FUSE keeps the per-layer path
     // (also used for inputs with more than 8 channels).
-    if (ops[0].first_u8 && ops[3].pool_in && getenv("DV_NO_STEM_FUSE") == nullptr &&
-        ops[3].cout <= 96) {
-      ops[0].stem_a = true;
-      ops[2].stem_b = true;
-      buffers[ops[0].out_buf] = {1, 1, 32, 0};  // conv1 output: LDS only
-      buffers[ops[2].out_buf] = {1, 1, 64, 0};  // conv3 output: LDS only
+    if (getenv("DV_NO_STEM_FUSE") == nullptr) {
+      // stem_a reads the uint8 image with two taps x 8 channels per chunk: C <= 8 only.  stem_b
+      // (conv3 + max-pool + 1x1) reads conv2's fp16 output whatever produced it, so the long-read
+      // channel sets (C = 9, 10) get it too -- behind conv_first_u8 (wide) + a per-layer conv2.
+      if (ops[0].first_u8 && desc.channels <= 8 && ops[3].pool_in && ops[3].cout <= 96) {
+        ops[0].stem_a = true;
+        buffers[ops[0].out_buf] = {1, 1, 32, 0};  // conv1 output: LDS only
+      }
+      if (ops[3].pool_in && ops[3].cout <= 96 && (ops[0].stem_a || getenv("DV_NO_STEM_B_ALONE") == nullptr)) {
+        ops[2].stem_b = true;
+        buffers[ops[2].out_buf] = {1, 1, 64, 0};  // conv3 output: LDS only
+      }
     }
     x = conv(x, 192, 3, 3, 1, false);
     blank_conv4_op = static_cast<int>(ops.size()) - 1;
@@ -2237,6 +2248,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       f.stride = op.stride;
       f.M = n * op.oh * op.ow;
       f.n_chunks = op.n_chunks;
+      f.wide = op.cin_real > 8 ? 1 : 0;
       f.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin_real);
       f.rcp_ow = 1.0f / static_cast<float>(op.ow);
       f.rcp_ohow = 1.0f / static_cast<float>(op.oh * op.ow);
@@ -2247,7 +2259,10 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       // four pixel fragments per wave: 20 outstanding 12-byte loads per lane (+1.7 % end to end
       // over two on MI355X); DV_FIRST_PT2 restores the smaller tile for tuning.
       static const bool first4 = getenv("DV_FIRST_PT2") == nullptr;
-      if (first4) {
+      if (f.wide) {   // nine one-tap chunks, all requested before the first MFMA
+        hipLaunchKernelGGL((conv_first_u8_kernel<2, 9>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
+                           stream, f);
+      } else if (first4) {
         hipLaunchKernelGGL((conv_first_u8_kernel<4>), dim3((f.M + 511) / 512), dim3(kConvThreads), 0,
                            stream, f);
       } else {
@@ -2611,8 +2626,8 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       inv[co] = 1.0f / std::sqrt(var[co] + 1e-3f);
       shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
     }
-    if (m->ops[0].stem_a && oi < 4) {  // fused stem: stem.hip's own fragment images
-      _Float16* dst = packed.data() + op.w_off;
+    if ((m->ops[0].stem_a && oi < 2) || (m->ops[2].stem_b && (oi == 2 || oi == 3))) {
+      _Float16* dst = packed.data() + op.w_off;   // fused stem: stem.hip's own fragment images
       if (oi == 0) dv::pack_stem_a_w1(w, inv.data(), l.cin, dst);
       if (oi == 1) dv::pack_stem_a_w2(w, inv.data(), dst);
       if (oi == 2) dv::pack_stem_b_w3(w, inv.data(), dst);
@@ -2620,16 +2635,18 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       continue;
     }
     if (op.first_u8) {
-      // [chunk kc][k-group g = tap 2kc+g][cout][8]: channel c < cin_real, else zero
+      // C <= 8:  [chunk kc][k-group g = tap 2kc+g][cout][8]: channel c < cin_real, else zero
+      // C <= 16: [chunk kc = tap][k-group g = channels 8g..8g+7][cout][8]
+      const bool wide = l.cin > 8;
       for (int kc = 0; kc < op.n_chunks; ++kc)
         for (int g = 0; g < 2; ++g) {
-          const int tap = 2 * kc + g;
+          const int tap = wide ? kc : 2 * kc + g;
           if (tap >= op.kh * op.kw) continue;
           const int kh = tap / op.kw, kw = tap % op.kw;
           for (int co = 0; co < op.cout; ++co)
-            for (int ci = 0; ci < l.cin; ++ci) {
+            for (int ci = wide ? 8 * g : 0; ci < (wide ? std::min(l.cin, 8 * g + 8) : l.cin); ++ci) {
               const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co];
-              packed[op.w_off + ((static_cast<size_t>(kc) * 2 + g) * 32 + co) * 8 + ci] =
+              packed[op.w_off + ((static_cast<size_t>(kc) * 2 + g) * 32 + co) * 8 + (ci & 7)] =
                   static_cast<_Float16>(v * inv[co]);
             }
         }

@@ -66,9 +66,15 @@ def test_blank_skip_is_bit_identical(shape):
   xd = torch.from_numpy(x).cuda()
   want = plain(xd).cpu().numpy()
   got = skip(xd).cpu().numpy()
-  # the stem's last tensor (3x3 80->192 output) is where the copies land
+  # the stem's last tensor (3x3 80->192 output) is where the copies land.  Round 4: the default path
+  # pools that tensor inside the convolution (10 x 25), the blank-skipping path keeps the unpooled
+  # one (21 x 51) for its copies -- pool it here before comparing (max is exact)
   idx = -2
-  np.testing.assert_array_equal(skip.debug_tensor(idx, n), plain.debug_tensor(idx, n))
+  a, b = skip.debug_tensor(idx, n), plain.debug_tensor(idx, n)
+  if a.shape != b.shape:
+    a = torch.nn.functional.max_pool2d(torch.from_numpy(a.astype(np.float32)).permute(0, 3, 1, 2), 3, 2
+                                       ).permute(0, 2, 3, 1).numpy().astype(np.float16)
+  np.testing.assert_array_equal(a, b)
   np.testing.assert_array_equal(got, want)
   # a second forward through the captured graph, different images in the same buffer
   xd.copy_(torch.from_numpy(x[::-1].copy()).cuda())

@@ -5,6 +5,8 @@ The reference pins no CNN numerics ("parity unpinned"), so the
 oracle is the fp32 torch restatement with seeded random weights, exactly like
 deepvariant/call_variants_test.py:109-127.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,8 +152,13 @@ def test_preprocess_known_answer_all_byte_values():
   from deepvariant_amd.inception_v3 import InceptionV3
   want = ((np.arange(256, dtype=np.float32) - 128.0) / 128.0)
   assert want[0] == -1.0 and want[128] == 0.0 and want[255] == 0.9921875
-  # (a) staging kernel
-  model = InceptionV3((75, 75, 9), max_batch=1)
+  # (a) staging kernel (round 4: inputs with 9..16 channels read the uint8 image directly too --
+  # part (d); DV_NO_U8_CONV1_WIDE keeps the staging path for them)
+  os.environ['DV_NO_U8_CONV1_WIDE'] = '1'
+  try:
+    model = InceptionV3((75, 75, 9), max_batch=1)
+  finally:
+    os.environ.pop('DV_NO_U8_CONV1_WIDE', None)
   model.init_random(seed=1)
   x = np.zeros((1, 75, 75, 9), np.uint8)
   x[0, 0, :, 0] = np.arange(75)
@@ -205,7 +212,28 @@ def test_preprocess_known_answer_all_byte_values():
                    for i in range(256) if i // 37 >= 1 and 1 <= i % 37 <= 35]) - 2.0
   want2 = np.array([want[i] for i in range(256) if i // 37 >= 1 and 1 <= i % 37 <= 35])
   np.testing.assert_array_equal(got2, want2)
-
+  # (d) the wide uint8 first conv (9..16 channels: one tap x 16 channels per K chunk): channel 8 sits in
+  # the SECOND k-group (bytes 8..15 of the pixel), channel 0 in the first; a one-hot filter on either
+  # recovers every byte value
+  for ch in (0, 8):
+    ref9 = R.make_random_model(9, seed=2)
+    flat9 = ref9.export_flat()
+    k9 = np.zeros((3, 3, 9, 32), np.float32)
+    k9[1, 1, ch, 0] = 1.0
+    flat9[:k9.size] = k9.reshape(-1)
+    flat9[k9.size:k9.size + 32] = 2.0
+    flat9[k9.size + 32:k9.size + 64] = 0.0
+    flat9[k9.size + 64:k9.size + 96] = 1.0 - 1e-3
+    model9 = _per_layer_model((75, 75, 9), 1)
+    model9.load_flat_weights(flat9)
+    x9 = np.random.default_rng(ch).integers(0, 256, (1, 75, 75, 9), dtype=np.uint8)
+    for i, v in enumerate(vals):
+      x9[0, 2 * (i // 37) + 1, 2 * (i % 37) + 1, ch] = v
+    model9(torch.from_numpy(x9).cuda())
+    out9 = model9.debug_tensor(1, 1).astype(np.float32)[0, :, :, 0]
+    got9 = np.array([out9[i // 37, i % 37] for i in range(256)]) - 2.0
+    np.testing.assert_allclose(got9, want, atol=2e-3)
+    assert got9[128] == 0.0 and got9[0] == -1.0
 
 def test_conv_macs_match_the_architecture_count():
   """dv_model_conv_macs (what bench.py prices the conv kernels with) equals the count of
