@@ -1577,14 +1577,15 @@ struct dv_model {
   // Split weights.  The fp16 rounding of the BN-folded weights is ~3/4 of the variance
   // of the CNN's error against the fp32 reference (tools/r4_layer_sensitivity.py: a flat budget, no
   // layer above 3.5 %), and it is the half that a kernel can remove without touching its pixel
-  // operand.  conv_mfma_kernel launches from the 17x17 stage on (the 1x1 heads of mixed4..7, all of
-  // mixed8..10 outside the fused chain: 40 % of the variance in 17 % of the run time) therefore
-  // carry W as W_hi + W_lo (both fp16, W_lo = fp16(W - W_hi)): the packed image holds every K chunk
-  // twice and the kernel multiplies the same pixel fragment by both -- products are exact, the sum
-  // is fp32, so those layers compute with 22-bit weights.  Measured on 2048 pileups x seeds 17 / 29
-  // (profiles/r04_precision_sweep.txt): max |dp| 1.15e-3 / 1.55e-3 without, 8.5e-4 / 8.1e-4 with.
-  // DV_SPLIT_FROM=<layer> moves the first split layer (construction order; 94 = none, 0 = every
-  // conv_mfma layer) for A/B runs.
+  // operand.  Selected conv_mfma_kernel launches therefore carry W as W_hi + W_lo (both fp16,
+  // W_lo = fp16(W - W_hi)): the packed image holds every K chunk twice and the kernel multiplies the
+  // same pixel fragment by both -- products are exact, the sum is fp32, so those layers compute
+  // with 22-bit weights.  Which: in the 17x17 blocks the two 1x1 layers whose output is block
+  // output (b1, pooled projection -- the leading cout tiles of the grouped heads launch), in
+  // mixed8..10 every 1x1 / 3-tap / 3x3 layer.  Measured on 2048 pileups x seeds 17 / 29
+  // (profiles/r04_precision_sweep.txt): max |dp| 1.15e-3 / 1.55e-3 without, 7.8e-4 / 8.6e-4 with.
+  // DV_SPLIT_FROM=<layer> (construction order; 94 = none, 0 = every conv_mfma layer) and
+  // DV_SPLIT_LAYERS=<list> override the set for A/B runs.
   void choose_split() {
     const int first_layer_env = getenv("DV_SPLIT_FROM") ? atoi(getenv("DV_SPLIT_FROM")) : -1;  // per model (tests)
     // mixed4 (the 17x17 stage) starts at conv layer 30 of the 94 (5 stem + 3 x 7 + 4), mixed8 at 70.

@@ -108,7 +108,7 @@ def test_split_weights_move_the_features_towards_the_fp32_oracle():
   """With ordinary weights the split layers compute with W_hi + W_lo: the 2048 pooled features of
   an all-split model are measurably closer to the fp32 oracle than those of an unsplit one
   (the weight rounding is ~3/4 of the error variance, tools/r4_layer_sensitivity.py; conv_mfma
-  launches are about half of the layers), and the default (17x17 heads + mixed8..10) lies in between."""
+  launches are about half of the layers), and the default (two heads per 17x17 block + mixed8..10) lies in between."""
   from oracle import inception_ref as R
   n = 256
   ref = R.make_random_model(7, seed=17)
