@@ -940,11 +940,37 @@ def pmc_traffic(args, n_items):
   return conv, enc, 'STALE (round-2 kernels) bytes per launch, separate rocprofv3 --pmc passes: ' + t['source']
 
 
+def usable_cores():
+  """Cores this process may actually use: the scheduler affinity mask, cut by the cgroup CPU quota
+  (a container on a 256-core host is often given far fewer)."""
+  n = os.cpu_count() or 1
+  try:
+    n = min(n, len(os.sched_getaffinity(0)))
+  except (AttributeError, OSError):
+    pass
+  for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    try:
+      with open(path) as f:
+        fields = f.read().split()
+      if path.endswith('cpu.max'):
+        if fields[0] != 'max':
+          n = min(n, max(1, int(float(fields[0]) / float(fields[1]) + 0.5)))
+      else:
+        quota = int(fields[0])
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+          period = int(f.read().split()[0])
+        if quota > 0:
+          n = min(n, max(1, int(quota / period + 0.5)))
+    except (OSError, ValueError, IndexError):
+      continue
+  return n
+
+
 def cpu_baseline(host_batch, opts, C, sample):
   """The oracle (a port: C++ encoder restatement + fp32 torch Inception)
   timed on this host's cores on a bounded sample of the same workload."""
   from oracle import inception_ref, oracle as O
-  cores = os.cpu_count() or 1
+  cores = usable_cores()
   n_enc = sample or min(host_batch.n_items, 2048)
   # sub-batch = the first n_enc items (lists index the shared read table)
   t0 = time.perf_counter()
@@ -987,6 +1013,7 @@ def cpu_baseline(host_batch, opts, C, sample):
       'value': 1.0 / per_item,
       'unit': 'candidates/s',
       'cores': cores,
+      'host_logical_cpus': os.cpu_count(),
       'cores_used': used * best_threads if node_rate >= one_rate else best_threads,
       'kind': 'port',
       'sample': '%d candidates encoded by the C++ oracle on %d threads (%.2f s) '

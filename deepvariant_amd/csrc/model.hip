@@ -1462,13 +1462,15 @@ struct dv_model {
       // as pick_nb: tiles x (nb MFMA columns + 1 pixel-fragment stream)
       int subs = (lead.cout + 31) / 32;
       for (size_t j : sib) subs += (ops[j].cout + 31) / 32;
-      // measured (8 K examples): 128-cout tiles win from 16 subtiles up (17x17 and 8x8 heads,
-      // -20..-26 %); the 7-subtile 35x35 heads and the 12-subtile 768->192+192 head are
-      // faster as 96-cout tiles (two blocks per CU) than as 128 (one block per CU).
-      // heads that max-pool their input on the fly (mixed0): ONE tile of all 7 subtiles, so
-      // that every 3x3 window is fetched and reduced once (three 96-cout tiles: 1.55 ms
-      // against 0.84 + 0.47 ms for the separate pool + heads)
-      const int nb = lead.pool_in && subs == 7 && getenv("DV_POOL2_NB3") == nullptr ? 7 : subs >= 16 ? 4 : 3;
+      // 128-cout tiles (<4,2>, two blocks per CU since round 2) for every grouped head from 7
+      // subtiles up: the 35x35 heads (7-8 subtiles) then take 2 tiles instead of 3 -- the input is
+      // re-read twice instead of three times and no padding subtile is multiplied: 495 / 556 / 583
+      // -> 448 / 522 / 567 us, +0.8 % end to end (round 4, tools/r4_run.sh ab:DV_HEADS_NB4_MIN=7;
+      // round 2 had measured 96-cout tiles faster when <4,2> still ran one block per CU).
+      // heads that max-pool their input on the fly (DV_NO_POOL2_IN_CONV): ONE tile of all 7 subtiles, so
+      // that every 3x3 window is fetched and reduced once
+      static const int nb4_min = getenv("DV_HEADS_NB4_MIN") ? atoi(getenv("DV_HEADS_NB4_MIN")) : 7;  // tuning knob
+      const int nb = lead.pool_in && subs == 7 && getenv("DV_POOL2_NB3") == nullptr ? 7 : subs >= nb4_min ? 4 : 3;
       std::vector<Op> moved;
       for (size_t j : sib) moved.push_back(ops[j]);
       for (size_t k = sib.size(); k-- > 0;) ops.erase(ops.begin() + sib[k]);
