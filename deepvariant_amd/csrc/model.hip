@@ -1949,7 +1949,8 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
   // to one when that would leave CUs without a block.
   const long blocks2 = blocks(256);
   if (a.split) {  // W_hi + W_lo images: the same two tile shapes, SPLIT slab code
-    if (blocks2 >= 512) {
+    static const long pt2_min = getenv("DV_SPLIT_PT2_MIN") ? atol(getenv("DV_SPLIT_PT2_MIN")) : 256;  // split layers carry twice the weight bytes per pixel: two fragments per wave from 256 blocks up (1x3 / 3x1 / 3x3 of mixed9-10: -12...-15 %, tools/r4_run.sh ab:DV_SPLIT_PT2_MIN=256)
+    if (blocks2 >= pt2_min) {
       hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2, kSlabChunks, 4, true>), dim3(static_cast<unsigned>(blocks2)),
                          dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
     } else {
