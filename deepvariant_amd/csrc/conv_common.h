@@ -93,6 +93,13 @@ struct ConvArgs {
   // (sibling 1x1 heads of which only some are split).
   int split;
   int split_tiles;
+  // Side max-pool (model.hip choose_side_pool): a 3x3 / stride-2 'valid' convolution
+  // loads, per 16-channel chunk, exactly the nine pieces of the 3x3 / stride-2 max-pool window of
+  // each of its output pixels.  The workgroups of cout tile 0 keep their running maximum and store
+  // it -- the sibling MaxPooling2D(3, 2) of the reduction block without its own launch.
+  _Float16* side_pool_out;   // NULL = off
+  TensorGeom side_pool_og;
+  int side_pool_goff;        // first destination group (channel offset / 8) in the concat buffer
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));

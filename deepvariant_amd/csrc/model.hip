@@ -94,12 +94,27 @@ struct ChunkWalk {
 // that multiply the SAME pixel fragment: chunk j of the slab uses pixel slot (S0 + j) / 2 and
 // the slot is refilled after the lo half.  The products are exact and the accumulator is fp32,
 // so the layer sees 22-bit weights for one extra MFMA and one extra ds_read per fragment.
-template <int NB, int PT, int R, int S0 = 0, bool SPLIT = false>
+// State of the side max-pool (ConvArgs::side_pool_out) of one wave: the running maximum of the
+// current 16-channel chunk's window pieces and where the finished ones go.
+template <int PT>
+struct SidePool {
+  half8_t best[PT];
+  int tap, cc;          // position in the K walk (wave-uniform): tap of the chunk, channel chunk
+  int cc_mod;           // cc % n_tiles: the cout tiles of a pixel block load the same fragments and share
+  int n_tiles, my_tile; // the pool's chunks round robin (tile t stores the chunks with cc % n_tiles == t)
+  int taps, n_cc;
+  unsigned at[PT];      // piece index of (n, group side_pool_goff + hi, oh, ow) in the pooled tensor
+  bool ok[PT];
+  unsigned gstride2;    // two channel groups (one chunk) further
+  uint4_t* out;
+};
+
+template <int NB, int PT, int R, int S0 = 0, bool SPLIT = false, bool POOL = false>
 __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
                                           const _Float16* wslab, ChunkWalk& walk,
                                           const unsigned (&base)[PT],
                                           uint4_t (&xf)[prefetch_depth(NB, PT)][PT],
-                                          float16_t (&acc)[NB][PT]) {
+                                          float16_t (&acc)[NB][PT], SidePool<PT>* sp = nullptr) {
   constexpr int BN = NB * 32;
   constexpr int kPrefetch = prefetch_depth(NB, PT);
   // Weight fragments are double buffered in registers: the ds_reads of chunk
@@ -141,6 +156,33 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
       for (int pt = 0; pt < PT; ++pt) {
         acc[nb][pt] =
             __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j & 1][nb], xh[pt], acc[nb][pt], 0, 0, 0);
+      }
+    }
+    if constexpr (POOL) {
+      // this step's fragments ARE window pieces of the sibling max-pool (K order: channel chunk
+      // major, tap minor); exact, so the result equals the separate max-pool kernel's bit for bit.
+      // The cout tiles of a pixel block see the same fragments: tile t keeps the chunks with
+      // cc % n_tiles == t (wave-uniform), the running maximum restarts from the lowest fp16 number.
+      if (sp->cc_mod == sp->my_tile) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) sp->best[pt] = __builtin_elementwise_max(sp->best[pt], xh[pt]);
+      }
+      if (sp->tap == sp->taps - 1) {   // wave-uniform
+        if (sp->cc < sp->n_cc && sp->cc_mod == sp->my_tile) {
+          const _Float16 lowest = static_cast<_Float16>(-65504.f);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            if (sp->ok[pt]) sp->out[sp->at[pt]] = __builtin_bit_cast(uint4_t, sp->best[pt]);
+            sp->best[pt] = half8_t{lowest, lowest, lowest, lowest, lowest, lowest, lowest, lowest};
+          }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) sp->at[pt] += sp->gstride2;
+        sp->tap = 0;
+        ++sp->cc;
+        sp->cc_mod = sp->cc_mod + 1 == sp->n_tiles ? 0 : sp->cc_mod + 1;
+      } else {
+        ++sp->tap;
       }
     }
     // refill the slot just consumed with chunk (current + kPrefetch)
@@ -207,7 +249,7 @@ __device__ __forceinline__ void copy_blank_wave(const ConvArgs& p, int n_tile, c
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
 template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks, int WAVES = 4,
-          bool SPLIT = false>
+          bool SPLIT = false, bool SIDE_POOL = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8)
@@ -370,8 +412,11 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
   // (hi, lo) pairing of split weights.  A split launch may mix both kinds of tile: the leading
   // ConvArgs::split_tiles cout tiles carry W_hi + W_lo (2 K chunks), the others plain weights
   // (K chunks, the first half of their slot in the packed image) -- block-uniform choice.
-  auto k_loop = [&](auto split_tag, const int n_chunks) {
+  SidePool<PT> side;
+  auto k_loop = [&](auto split_tag, auto pool_tag, const int n_chunks) {
     constexpr bool S = decltype(split_tag)::value;
+    constexpr bool P = decltype(pool_tag)::value;
+    SidePool<PT>* const sp = P ? &side : nullptr;
     const int tile_slabs = (n_chunks + SLAB - 1) / SLAB;
 #ifdef DV_ABLATE_LOOP
     const int n_full = n_chunks < 0 ? 1 : 0;
@@ -387,7 +432,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
       // were, drains the whole four-chunk prefetch queue at every slab start.
       const int next = s + 1 < tile_slabs ? s + 1 : s;
       DV_LOAD_SLAB(next)
-      conv_slab<NB, PT, SLAB, 0, S>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc);
+      conv_slab<NB, PT, SLAB, 0, S, P>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc, sp);
       DV_STORE_SLAB((s + 1) & 1)
       __syncthreads();
     }
@@ -399,20 +444,40 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
     // made the register allocator clone the accumulators.)
     if (rem) {
       const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
-      conv_slab<NB, PT, 4, 0, S>(p, rsrc, wslab, walk, base, xf, acc);
+      conv_slab<NB, PT, 4, 0, S, P>(p, rsrc, wslab, walk, base, xf, acc, sp);
       if constexpr (SLAB > 4) {
-        if (rem > 4) conv_slab<NB, PT, 4, 4, S>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+        if (rem > 4) conv_slab<NB, PT, 4, 4, S, P>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc, sp);
       }
     }
   };
   if constexpr (SPLIT) {
     if (n_tile < p.split_tiles) {
-      k_loop(std::true_type{}, p.n_chunks);
+      k_loop(std::true_type{}, std::false_type{}, p.n_chunks);
     } else {
-      k_loop(std::false_type{}, p.n_chunks >> 1);
+      k_loop(std::false_type{}, std::false_type{}, p.n_chunks >> 1);
     }
+  } else if constexpr (SIDE_POOL) {   // the reduction block's 3x3 / 2 with its sibling max-pool on the side
+    side.tap = 0;
+    side.cc = 0;
+    side.cc_mod = 0;
+    side.n_tiles = p.n_tiles;
+    side.my_tile = n_tile;
+    side.taps = p.KH * p.KW;
+    side.n_cc = p.Cin / kChunk;
+    side.gstride2 = 2u * static_cast<unsigned>(p.side_pool_og.hp * p.side_pool_og.wp);
+    side.out = reinterpret_cast<uint4_t*>(p.side_pool_out);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const _Float16 lowest = static_cast<_Float16>(-65504.f);
+      side.best[pt] = half8_t{lowest, lowest, lowest, lowest, lowest, lowest, lowest, lowest};
+      side.ok[pt] = mvalid[pt];
+      side.at[pt] = static_cast<unsigned>(
+          ((pn[pt] * p.side_pool_og.groups + p.side_pool_goff + (lane >> 5)) * p.side_pool_og.hp + poh[pt] +
+           p.side_pool_og.halo) * p.side_pool_og.wp + pow_[pt] + p.side_pool_og.halo);
+    }
+    k_loop(std::false_type{}, std::true_type{}, p.n_chunks);
   } else {
-    k_loop(std::false_type{}, p.n_chunks);
+    k_loop(std::false_type{}, std::false_type{}, p.n_chunks);
   }
 #undef DV_LOAD_SLAB
 #undef DV_STORE_SLAB
@@ -1261,6 +1326,7 @@ struct Op {
   bool first_u8 = false;         // conv: reads the uint8 image directly (fused preprocess)
   bool pool_shift_relu = false;  // avgpool: add shift[c] and ReLU after averaging
   bool pool_in = false;          // 1x1 conv that max-pools (3x3, stride 2) its input on the fly
+  int side_pool_partner = -1;    // 3x3 / 2 conv <-> the sibling max-pool it computes on the side (choose_side_pool)
   bool pool_out = false;         // conv whose output is max-pooled (3x3, stride 2) before it is stored
                                  // (conv_pool_resident_kernel; oh / ow stay the conv's, the buffer is pooled)
   // Fused stem (stem.hip): the op marked stem_a / stem_b runs together with the op that
@@ -1573,6 +1639,32 @@ struct dv_model {
       if (op.cout > 128 && op.cout <= 192 && op.nb == 3 && getenv("DV_NO_BAND_NB6") == nullptr) op.nb = 6;
       op.n_chunks = h * op.kw * (op.cin / kChunk);
       op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;
+    }
+  }
+
+  // The reduction block mixed3 runs MaxPooling2D(3, 2) next to a 3x3 / stride-2 'valid' convolution of the
+  // SAME tensor: per 16-channel chunk the convolution's nine tap fragments are exactly the pool's
+  // window pieces, so the workgroups of its cout tile 0 take the maximum on the side (SidePool) and the
+  // pool's own launch (0.27 ms, a full re-read of the block input) disappears.  mixed8's pool has no
+  // such sibling (its stride-2 convolutions read the 1x1 outputs).  DV_NO_SIDE_POOL keeps the launch.
+  void choose_side_pool() {
+    if (getenv("DV_NO_SIDE_POOL") != nullptr) return;
+    for (size_t pi = 0; pi < ops.size(); ++pi) {
+      Op& pl = ops[pi];
+      if (pl.type != kOpMaxPool) continue;
+      for (size_t ci = 0; ci < ops.size(); ++ci) {
+        Op& cv = ops[ci];
+        if (cv.type != kOpConv || cv.in_buf != pl.in_buf || cv.stride != 2 || cv.kh != 3 || cv.kw != 3 ||
+            cv.pad_h != 0 || cv.pad_w != 0 || cv.nb != 4 || cv.group_followers != 0 || cv.first_u8 || cv.pool_in ||
+            cv.pool_out || cv.stem_a || cv.stem_b || cv.v2 || cv.band || cv.split || cv.chain_len != 0 || cv.in_chain ||
+            cv.raw || cv.cin != pl.cin || cv.cin % kChunk != 0 || cv.cin != buffers[cv.in_buf].c ||
+            cv.oh != pl.oh || cv.ow != pl.ow || cv.side_pool_partner >= 0) {
+          continue;
+        }
+        cv.side_pool_partner = static_cast<int>(pi);
+        pl.side_pool_partner = static_cast<int>(ci);
+        break;
+      }
     }
   }
 
@@ -1903,6 +1995,7 @@ struct dv_model {
     choose_imgconv();
     choose_band();
     choose_split();
+    choose_side_pool();
     for (size_t i = 0; i < ops.size(); ++i) {  // packed-weight image per LAUNCH (after grouping)
       Op& op = ops[i];
       if (op.type != kOpConv) continue;
@@ -1948,6 +2041,18 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
   // Two pixel tiles per wave halve the LDS weight traffic per MFMA; fall back
   // to one when that would leave CUs without a block.
   const long blocks2 = blocks(256);
+  if constexpr (NB == 4) {
+    if (a.side_pool_out != nullptr) {   // its own instantiations: the side pool costs registers the other launches keep
+      if (blocks2 >= 512) {
+        hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2, kSlabChunks, 4, false, true>), dim3(static_cast<unsigned>(blocks2)),
+                           dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+      } else {
+        hipLaunchKernelGGL((conv_mfma_kernel<NB, 1, 2, kSlabChunks, 4, false, true>), dim3(static_cast<unsigned>(blocks(128))),
+                           dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+      }
+      return;
+    }
+  }
   if (a.split) {  // W_hi + W_lo images: the same two tile shapes, SPLIT slab code
     static const long pt2_min = getenv("DV_SPLIT_PT2_MIN") ? atol(getenv("DV_SPLIT_PT2_MIN")) : 256;  // split layers carry twice the weight bytes per pixel: two fragments per wave from 256 blocks up (1x3 / 3x1 / 3x3 of mixed9-10: -12...-15 %, tools/r4_run.sh ab:DV_SPLIT_PT2_MIN=256)
     if (blocks2 >= pt2_min) {
@@ -2066,8 +2171,10 @@ bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
 
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
             int shifted_buf = -1, int out_example_off = 0, size_t images_off = 0) {
+  std::vector<char> side_pooled(m->ops.size(), 0);   // max-pools a convolution of this pass has taken on the side
   for (int oi = first; oi < last; ++oi) {
     const Op& op = m->ops[oi];
+    if (side_pooled[oi]) continue;
     const BufferDesc& ob = m->buffers[op.out_buf];
     const size_t out_shift_halfs =
         op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
@@ -2342,6 +2449,15 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
       if (op.split) tr_label += " [split W: " + std::to_string(op.split_tiles) + " of " + std::to_string(tiles) + " tiles]";
+      if (op.side_pool_partner > oi && op.side_pool_partner < last && op.nb == 4 && !resident_ok(m, op, a)) {
+        const Op& pl = m->ops[op.side_pool_partner];
+        a.side_pool_out = static_cast<_Float16*>(m->dbuf[pl.out_buf].ptr);
+        a.side_pool_og = m->buffers[pl.out_buf].geom();
+        a.side_pool_goff = pl.out_coff / 8;
+        side_pooled[op.side_pool_partner] = 1;
+        tr_label += " + maxpool3s2 on the side";
+        tr_bytes += 2.0 * n * pl.oh * pl.ow * pl.cin;
+      }
       const bool resident = !op.v2 && !op.pool_in && !op.pool_out && resident_ok(m, op, a);
       if (resident) tr_label += " [weights resident in LDS]";
       if (op.pool_out) tr_label += " [weights resident in LDS] -> maxpool3s2";

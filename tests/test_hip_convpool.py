@@ -78,3 +78,39 @@ def test_pooled_tensor_against_the_fp32_oracle():
   assert s1.shape == want.shape == (n, 10, 25, 192)
   rel = np.abs(s1.astype(np.float32) - want).max() / np.abs(want).max()
   assert rel <= 1e-2, rel
+
+
+def _forward_env(shape, weights, x, env):
+  from deepvariant_amd.inception_v3 import InceptionV3
+  for k in env:
+    os.environ[k] = '1'
+  try:
+    m = InceptionV3(shape, max_batch=x.shape[0])
+    m.load_flat_weights(weights)
+    probs = m(x).cpu().numpy()
+    feat = m.debug_tensor(-1, x.shape[0])
+  finally:
+    for k in env:
+      os.environ.pop(k, None)
+  return probs, feat
+
+
+@pytest.mark.parametrize('shape,n', [((100, 221, 7), 5), ((100, 221, 7), 300), ((100, 147, 10), 64),
+                                     ((100, 199, 9), 40), ((75, 75, 1), 9), ((120, 301, 5), 6)])
+def test_side_max_pool_of_mixed3_is_bit_identical(shape, n):
+  """mixed3's MaxPooling2D(3, 2) taken on the side by the 3x3 / stride-2 convolution of the same tensor
+  (model.hip choose_side_pool: the convolution's nine tap fragments of a channel chunk ARE the pool's window)
+  against the separate max-pool launch (DV_NO_SIDE_POOL=1): the maximum is exact, so the 2048 features and
+  the probabilities must agree bit for bit -- for the <4,1> tile shape of small batches and the <4,2> shape
+  of large ones, and for map sizes whose last pixel block is partial."""
+  from oracle import inception_ref as R
+  h, w, c = shape
+  ref = R.make_random_model(c, seed=37)
+  weights = ref.export_flat()
+  x = np.random.default_rng(n + w).integers(0, 256, (n, h, w, c), dtype=np.uint8)
+  x[: n // 2, 45:] = 0
+  xd = torch.from_numpy(x).cuda()
+  p0, f0 = _forward_env(shape, weights, xd, ['DV_NO_SIDE_POOL'])
+  p1, f1 = _forward_env(shape, weights, xd, [])
+  np.testing.assert_array_equal(f1, f0)
+  np.testing.assert_array_equal(p1, p0)
