@@ -1256,14 +1256,21 @@ __global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const flo
   float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const _Float16* x = in + static_cast<size_t>(n) * g.groups * plane;
   const float invP = 1.0f / static_cast<float>(g.h * g.w);
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f;
-    const _Float16* xc = x + static_cast<size_t>(c >> 3) * plane + (c & 7);
+  // one thread per 8-channel group: the map's pixels come in as whole 16-byte pieces
+  for (int grp = tid; grp * 8 < C; grp += 256) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const half8_t* xg = reinterpret_cast<const half8_t*>(x + static_cast<size_t>(grp) * plane);
     for (int y = 0; y < g.h; ++y)
-      for (int xx = 0; xx < g.w; ++xx)
-        s += static_cast<float>(xc[((y + g.halo) * g.wp + xx + g.halo) * 8]);
-    s *= invP;
-    for (int k = 0; k < K; ++k) part[k] += s * w[static_cast<size_t>(c) * K + k];
+      for (int xx = 0; xx < g.w; ++xx) {
+        const half8_t v = xg[(y + g.halo) * g.wp + xx + g.halo];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m = s[j] * invP;
+      for (int k = 0; k < K; ++k) part[k] += m * w[static_cast<size_t>(grp * 8 + j) * K + k];
+    }
   }
   for (int k = 0; k < K; ++k) {
     float v = part[k];
