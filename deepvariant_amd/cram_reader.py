@@ -573,6 +573,11 @@ class CramFile:
     n_blocks, k = _itf8(d, k)
     _, k = _itf8_array(d, k)
     embedded_id, k = _itf8(d, k)
+    ref_md5 = bytes(d[k:k + 16])
+    # a slice that cannot overlap the query is skipped BEFORE its blocks are inflated (the rANS decoder is
+    # pure Python: decoding and then dropping every non-overlapping slice of a container dominated region queries)
+    if want_ref is not None and s_ref >= 0 and (s_ref != want_ref or s_start - 1 >= hi or s_start - 1 + s_span <= lo):
+      return []
     external: Dict[int, _Block] = {}
     core = _Bits(b'')
     for _ in range(n_blocks):
@@ -581,8 +586,6 @@ class CramFile:
         core = _Bits(blk.data)
       elif blk.content_type == 4:
         external[blk.content_id] = blk
-    if want_ref is not None and s_ref >= 0 and (s_ref != want_ref or s_start - 1 >= hi or s_start - 1 + s_span <= lo):
-      return []
     codecs = _Codecs(external, core)
     S = ch.series
 
@@ -617,6 +620,14 @@ class CramFile:
       if s_ref >= 0 and ref_id == s_ref:
         o = max(0, s_start - 1)
         text = self.fetch_reference(name, o, o + s_span + 1)
+        # the slice header carries the MD5 of the reference stretch it was encoded against (CRAM 3.0
+        # section 8.5; all zero = not recorded): htslib refuses a mismatching FASTA, and decoding
+        # against the wrong one would silently produce wrong read bases
+        if ref_md5 != bytes(16) and len(ref_md5) == 16 and s_span > 0 and len(text) >= s_span:
+          import hashlib
+          if hashlib.md5(text[:s_span].upper().encode('latin-1')).digest() != ref_md5:
+            raise ValueError('Failed to parse BAM/CRAM file. %s: the reference MD5 of the slice at %s:%d does not '
+                             'match --ref' % (self.path, name, s_start))
         if start >= o and start + n <= o + len(text):
           ref_cache[ref_id] = (o, text)
           return text[start - o:start - o + n]

@@ -126,6 +126,24 @@ def test_cram_without_its_reference_fails_like_the_reference(files):
     cram_reader.read_cram(files['na12878_cram'], None, 'chr20', 10_000_000, 10_000_500)
 
 
+def test_cram_against_the_wrong_reference_is_refused(files):
+  """htslib refuses to decode a slice whose header MD5 does not match the reference it is given
+  (a mismatching --ref would otherwise yield wrong read bases silently): one changed base inside the
+  first slice's span is enough."""
+  ref = genomics_io.FastaReader(files['fasta'])
+
+  def tampered(contig, start, end):
+    text = ref.get_bases(contig, start, end)
+    if start <= 10_000_100 < end:
+      k = 10_000_100 - start
+      text = text[:k] + ('A' if text[k] != 'A' else 'C') + text[k + 1:]
+    return text
+  with pytest.raises(ValueError, match='MD5'):
+    cram_reader.read_cram(files['na12878_cram'], tampered, 'chr20', 10_000_000, 10_001_000)
+  # the untouched reference decodes
+  assert cram_reader.read_cram(files['na12878_cram'], ref.get_bases, 'chr20', 10_000_000, 10_001_000)[1]
+
+
 def test_rans_round_trip_on_synthetic_streams():
   """The order-0 / order-1 rANS 4x8 decoder against a straightforward encoder written here from the
   same published description (the real files above exercise it on 300 KB quality streams)."""
