@@ -568,7 +568,7 @@ def bam_mode(args, log=sys.stderr):
       proc.candidates_in_region = timed('allele counts (device) + candidate caller', proc.candidates_in_region)
       proc.generator.call_variants_in_region = timed(
           'pack + encode + classify (device) + CallVariantsOutput protos', proc.generator.call_variants_in_region)
-      proc.realign_table = timed('realign (window selection on the device, assembly, alignment)', proc.realign_table)
+      proc.realign_tables = timed('realign (window selection on the device, assembly, alignment)', proc.realign_tables)
       proc.generator.encode_region_on_device = timed('pack + encode (device)', proc.generator.encode_region_on_device)
       proc.flush_queue = timed('classify (device, several regions per forward) + CallVariantsOutput protos',
                                proc.flush_queue)

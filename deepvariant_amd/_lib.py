@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     'dv_aligner_score_threshold', 'dv_aligner_kmer_occurrences', 'dv_positions_map',
     'dv_merge_cigar_op', 'dv_local_align', 'dv_local_align_many',
     'dv_debruijn_build', 'dv_debruijn_destroy', 'dv_debruijn_kmer_size', 'dv_debruijn_haplotypes',
-    'dv_debruijn_graphviz', 'dv_phase_reads',
+    'dv_debruijn_graphviz', 'dv_realign_regions', 'dv_realign_result_free', 'dv_phase_reads',
     'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
 
@@ -169,6 +169,28 @@ class DvLocalAlignment(C.Structure):
 class DvDebruijnOptions(C.Structure):
   _fields_ = [(n, C.c_int32) for n in ('min_k', 'max_k', 'step_k', 'min_mapq', 'min_base_quality',
                                        'min_edge_weight', 'max_num_paths', 'disable_graph_pruning')]
+
+
+class DvRealignRegion(C.Structure):
+  _fields_ = [('bases', C.c_void_p), ('quals', C.c_void_p), ('n_bases', C.c_int64), ('read_seq_off', C.c_void_p),
+              ('read_mapq', C.c_void_p), ('read_start', C.c_void_p), ('read_end', C.c_void_p),
+              ('n_reads', C.c_int32), ('n_windows', C.c_int32), ('window_start', C.c_void_p),
+              ('window_end', C.c_void_p), ('ref', C.c_char_p), ('ref_start', C.c_int64), ('ref_len', C.c_int64),
+              ('contig_len', C.c_int64)]
+
+
+class DvRealignOptions(C.Structure):
+  _fields_ = [('dbg', DvDebruijnOptions), ('aln', DvAlignerOptions), ('ref_align_margin', C.c_int32),
+              ('n_threads', C.c_int32)]
+
+
+class DvRealignOutput(C.Structure):
+  _fields_ = [('region_row_off', C.POINTER(C.c_int64)), ('order', C.POINTER(C.c_int32)),
+              ('status', C.POINTER(C.c_int32)), ('position', C.POINTER(C.c_int64)),
+              ('cigar_off', C.POINTER(C.c_int64)), ('cigar', C.POINTER(C.c_uint32)),
+              ('region_assembled_off', C.POINTER(C.c_int32)), ('assembled_window', C.POINTER(C.c_int32)),
+              ('assembled_hap_off', C.POINTER(C.c_int32)), ('hap_text_off', C.POINTER(C.c_int64)),
+              ('hap_text', C.POINTER(C.c_char))]
 
 
 class DvPhasingAllele(C.Structure):
@@ -298,6 +320,9 @@ def lib():
     l.dv_debruijn_kmer_size.argtypes = [C.c_void_p]
     l.dv_debruijn_haplotypes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.dv_debruijn_graphviz.argtypes = [C.c_void_p, C.c_void_p]
+    l.dv_realign_regions.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_realign_result_free.argtypes = [C.c_void_p]
+    l.dv_realign_result_free.restype = None
     l.dv_phase_reads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int32]

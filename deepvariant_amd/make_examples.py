@@ -34,6 +34,7 @@ from deepvariant_amd.realigner import utils
 
 _RANDOM_SEED = 609314161            # make_examples_options.py:981
 _CLASSIFY_AT = 256                  # fused route, table path: examples collected on the device per CNN forward
+_REGION_BATCH = 64                  # table path: calling regions whose realigner work goes through one native call
 _REALIGNER_FLAGS = {k: v for k, v in realigner_module._FLAG_DEFAULTS.items()   # pylint: disable=protected-access
                     if k.startswith(('ws_', 'dbg_', 'aln_')) or k in (
                         'max_num_mismatches', 'realignment_similarity_threshold', 'kmer_size', 'split_skip_reads')}
@@ -494,30 +495,36 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   t_loop = time.perf_counter()
   stats['setup_s'] = t_loop - t_start        # flags, region list, processor, model + weights
   try:
-    for region in pieces:
-      if use_tables:
+    # the table path walks the regions in batches: the realigner's native work of a whole batch
+    # (every window's assembly and alignment) is ONE threaded call, the rest stays per region
+    for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
+      batch = pieces[at:at + _REGION_BATCH]
+      tables = []
+      for region in batch:
         in_table = reads_for.table(region)
         if 0 < args.max_reads_per_partition < in_table.n_reads:     # the same draws on row numbers
           in_table = in_table.take(np.array(reservoir_sample(range(in_table.n_reads), args.max_reads_per_partition,
                                                              np.random.RandomState(_RANDOM_SEED)), np.int64))
+        tables.append(in_table)
+      for region, in_table, realigned in zip(batch, tables, proc.realign_tables(tables, batch)):
         stats['n_regions'] += 1
         stats['n_reads'] += in_table.n_reads
         if model is not None:
           # drawn on the device now, classified with the regions around it (one CNN forward per
           # _CLASSIFY_AT examples); records leave in region order
-          stats['n_candidates'] += len(proc.queue_region_table(region, in_table, model))
+          stats['n_candidates'] += len(proc.queue_region_table(region, in_table, model, realigned=realigned))
           if proc.n_queued_examples >= _CLASSIFY_AT:
             for records in proc.flush_queue(model):
               for rec in records:
                 writer.write(rec)
               stats['n_examples'] += len(records)
           continue
-        candidates, records = proc.examples_in_region_table(region, in_table)
+        candidates, records = proc.examples_in_region_table(region, in_table, realigned=realigned)
         for rec in records:
           writer.write(rec)
         stats['n_candidates'] += len(candidates)
         stats['n_examples'] += len(records)
-        continue
+    for region in ([] if use_tables else pieces):
       in_reads = reads_for(region)
       if args.max_reads_per_partition > 0:
         in_reads = reservoir_sample(in_reads, args.max_reads_per_partition, np.random.RandomState(_RANDOM_SEED))

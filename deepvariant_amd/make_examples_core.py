@@ -305,20 +305,34 @@ class RegionProcessor:
   def realign_table(self, table, region: T.Range):
     """realign_reads on a table: reads longer than max_read_length_to_realign bypass the
     realigner and come first."""
-    if self.realigner is None or table.n_reads == 0:
-      return table
-    limit = self.processor_options.max_read_length_to_realign
-    if limit == 0:
-      return self.realigner.realign_table(table, region)[1]
-    lengths = np.diff(table.read_seq_off.astype(np.int64))
-    long_rows = np.nonzero(lengths > limit)[0]
-    if not len(long_rows):
-      return self.realigner.realign_table(table, region)[1]
-    short = self.realigner.realign_table(table.take(np.nonzero(lengths <= limit)[0]), region)[1]
-    return packing.concat_tables([table.take(long_rows), short])
+    return self.realign_tables([table], [region])[0]
 
-  def process_table(self, region: T.Range, table) -> Tuple[List[T.DeepVariantCall], 'packing.ReadTable']:
-    realigned = self.realign_table(table, region)
+  def realign_tables(self, tables: Sequence, regions: Sequence[T.Range]) -> List:
+    """`realign_table` for a batch of calling regions: the realigner's assembly and alignment
+    work of all of them goes through one native, threaded call (Realigner.realign_tables)."""
+    tables = list(tables)
+    if self.realigner is None:
+      return tables
+    limit = self.processor_options.max_read_length_to_realign
+    long_parts = [None] * len(tables)
+    short = tables
+    if limit:
+      short = []
+      for k, table in enumerate(tables):
+        lengths = np.diff(table.read_seq_off.astype(np.int64))
+        long_rows = np.nonzero(lengths > limit)[0]
+        if len(long_rows):
+          long_parts[k] = table.take(long_rows)
+          table = table.take(np.nonzero(lengths <= limit)[0])
+        short.append(table)
+    out = [t for _, t in self.realigner.realign_tables(short, regions, want_haplotypes=False)]
+    return [t if lp is None else packing.concat_tables([lp, t]) for lp, t in zip(long_parts, out)]
+
+  def process_table(self, region: T.Range, table, realigned=None) -> Tuple[List[T.DeepVariantCall], 'packing.ReadTable']:
+    """`realigned`: the region's table as `realign_tables` returned it (the runner realigns a
+    batch of regions ahead); None = realign here."""
+    if realigned is None:
+      realigned = self.realign_table(table, region)
     rows = np.nonzero((realigned.read_end > region.start) & (region.end > realigned.read_pos.astype(np.int64)))[0]
     if not len(rows):
       return [], realigned
@@ -330,9 +344,9 @@ class RegionProcessor:
     candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(region, in_region, positions))
     return candidates, realigned
 
-  def examples_in_region_table(self, region: T.Range, table, stats: Optional[dict] = None
+  def examples_in_region_table(self, region: T.Range, table, stats: Optional[dict] = None, realigned=None
                                ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
-    candidates, realigned = self.process_table(region, table)
+    candidates, realigned = self.process_table(region, table, realigned)
     if not candidates:
       return candidates, []
     examples, _ = self.generator.encode_region(candidates, [realigned], [0], [0.0], stats if stats is not None else {})
@@ -346,8 +360,8 @@ class RegionProcessor:
 
   # ---- deferred classification (table path, fused route): regions are drawn on the device one by
   # one, their tensors wait there, and ONE CNN forward classifies a few hundred examples
-  def queue_region_table(self, region: T.Range, table, model) -> List[T.DeepVariantCall]:
-    candidates, realigned = self.process_table(region, table)
+  def queue_region_table(self, region: T.Range, table, model, realigned=None) -> List[T.DeepVariantCall]:
+    candidates, realigned = self.process_table(region, table, realigned)
     images, plan = (None, [])
     if candidates:
       images, plan = self.generator.encode_region_on_device(candidates, [realigned], [0], [0.0], model.input_shape)

@@ -524,15 +524,27 @@ class ReadTable:
     everything else is shared with `self`."""
     if not len(rows):
       return self
+    off = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum([len(w) for w in cigars], out=off[1:])
+    words = np.concatenate([np.asarray(w, np.uint32) for w in cigars]) if off[-1] else np.zeros(0, np.uint32)
+    return self.with_alignments_csr(rows, positions, off, words)
+
+  def with_alignments_csr(self, rows, positions, cigar_off, words) -> 'ReadTable':
+    """`with_alignments` with the new CIGARs as one array: row rows[k] gets words[cigar_off[k]:cigar_off[k + 1]]
+    (the form dv_realign_regions returns them in).  Array operations only."""
     rows = np.asarray(rows, np.int64)
-    off = self.read_cigar_off.astype(np.int64)
-    lengths = np.diff(off)
+    if not len(rows):
+      return self
+    cigar_off = np.asarray(cigar_off, np.int64)
+    words = np.asarray(words, np.uint32)
+    lengths = np.diff(self.read_cigar_off.astype(np.int64))
+    in_len = np.diff(cigar_off)
     new_len = lengths.copy()
-    new_len[rows] = [len(w) for w in cigars]
+    new_len[rows] = in_len
     new_off = np.zeros(self.n_reads + 1, np.int64)
     np.cumsum(new_len, out=new_off[1:])
     cigar = np.zeros(int(new_off[-1]), np.uint32)
-    # unchanged rows: one vectorised segment copy; changed rows: their new words
+    # unchanged rows: one segment copy out of the old array; changed rows: one out of `words`
     same = np.ones(self.n_reads, bool)
     same[rows] = False
     same_rows = np.nonzero(same)[0]
@@ -540,14 +552,19 @@ class ReadTable:
     dst = np.arange(len(src), dtype=np.int64) + np.repeat(
         new_off[same_rows] - (np.cumsum(lengths[same_rows]) - lengths[same_rows]), lengths[same_rows])
     cigar[dst] = self.cigar[src]
+    total = int(cigar_off[-1] - cigar_off[0])
+    src_w = np.arange(total, dtype=np.int64) + cigar_off[0]
+    dst_w = np.arange(total, dtype=np.int64) + np.repeat(new_off[rows] - (cigar_off[:-1] - cigar_off[0]), in_len)
+    cigar[dst_w] = words[src_w]
     pos = self.read_pos.copy()
     end = self.read_end.copy()
-    for r, p, words in zip(rows.tolist(), np.asarray(positions).tolist(), cigars):
-      words = np.asarray(words, np.uint32)
-      cigar[new_off[r]:new_off[r + 1]] = words
-      pos[r] = p
-      ops = words & 15
-      end[r] = p + int((words >> 4)[(ops == 1) | (ops == 8) | (ops == 9) | (ops == 3) | (ops == 4)].sum())
+    pos[rows] = np.asarray(positions).astype(pos.dtype)
+    # alignment end = start + the reference bases its operations consume (M, =, X, D, N)
+    w = words[src_w]
+    ops = w & 15
+    on_ref = np.where((ops == 1) | (ops == 8) | (ops == 9) | (ops == 3) | (ops == 4), (w >> 4).astype(np.int64), 0)
+    span = np.bincount(np.repeat(np.arange(len(rows)), in_len), weights=on_ref, minlength=len(rows)).astype(np.int64)
+    end[rows] = (np.asarray(positions, np.int64) + span).astype(end.dtype)
     return dataclasses.replace(self, read_pos=pos, read_end=end, read_cigar_off=new_off.astype(np.uint32), cigar=cigar)
 
   def query(self, start: int, end: int) -> np.ndarray:

@@ -16,12 +16,14 @@ csrc/fast_pass_aligner.cpp + local_align.cpp.  A region's reads are packed ONCE
 from __future__ import annotations
 
 import concurrent.futures
+import ctypes as C
 import dataclasses
 import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from deepvariant_amd import _lib
 from deepvariant_amd import alt_aligned_pileup_lib
 from deepvariant_amd import dv_types as T
 from deepvariant_amd import fast_pass_aligner
@@ -37,6 +39,9 @@ from deepvariant_amd.realigner.window_selector import (
 # Windows of a region are independent: their assembly and alignment calls (native, the GIL is
 # released inside ctypes) run on a small thread pool; results are collected in window order.
 _THREADS = max(1, int(os.environ.get('DV_REALIGN_THREADS', '4')))
+# The table path hands all windows of a batch of regions to one native call (dv_realign_regions),
+# which runs them on its own host threads: DV_REALIGN_THREADS, or one per hardware thread up to 16.
+_NATIVE_THREADS = max(0, int(os.environ.get('DV_REALIGN_THREADS', '0')))
 _pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
 
 
@@ -381,81 +386,119 @@ class Realigner:
       realigned.extend(aligned)
     return candidate_haplotypes, realigned
 
-  # ---- the same procedure on a packed table (make_examples' table path): no Read objects
+  # ---- the same procedure on packed tables (make_examples' table path): no Read objects, and the
+  # assembly + alignment of ALL windows of ALL regions handed over in one native, threaded call
   def realign_table(self, table: 'packing.ReadTable', region: T.Range):
     """`realign_reads` for the reads of a packed table: -> (candidate haplotypes per assembled window,
     the table of ALL input reads -- first the ones no window claimed, then window by window, in
-    the order realign_reads returns them -- with the new alignment starts and CIGARs in place).
-    Window selection counts on the device from the table, assembly takes row indices, read to
-    window assignment and the write-back are array operations; only the read sequences of the
-    windows go to the aligner as strings."""
-    n = table.n_reads
-    if n == 0:
-      return [], table
+    the order realign_reads returns them -- with the new alignment starts and CIGARs in place)."""
+    return self.realign_tables([table], [region])[0]
+
+  def _native_options(self) -> '_lib.DvRealignOptions':
+    d, a = self.config.dbg_config, self.config.aln_config
+    return _lib.DvRealignOptions(
+        _lib.DvDebruijnOptions(d.min_k, d.max_k, d.step_k, d.min_mapq, d.min_base_quality, d.min_edge_weight,
+                               d.max_num_paths, int(bool(d.disable_graph_pruning))),
+        _lib.DvAlignerOptions(a.match, a.mismatch, a.gap_open, a.gap_extend, a.kmer_size, 0, a.max_num_of_mismatches,
+                              a.realignment_similarity_threshold, 0, int(bool(self.config.normalize_reads)), 0, 0),
+        _REF_ALIGN_MARGIN, _NATIVE_THREADS)
+
+  def realign_tables(self, tables: Sequence['packing.ReadTable'], regions: Sequence[T.Range],
+                     want_haplotypes: bool = True) -> List[Tuple[List[CandidateHaplotypes], 'packing.ReadTable']]:
+    """`realign_table` for several calling regions at once: window selection per region (device
+    counts from the table, window_selector.py), then ONE dv_realign_regions call in which every
+    (region, window) assembly and alignment task of the batch runs on a pool of host threads
+    (csrc/region_realigner.cpp), then the new starts and CIGARs written back as array operations.
+    Results per region are those of the region-by-region procedure (tests/test_table_path_cpu.py).
+    Without `want_haplotypes` the CandidateHaplotypes lists come back empty (make_examples only
+    uses the reads)."""
     if self.config.split_skip_reads:
       raise NotImplementedError('split_skip_reads works on Read objects (realign_reads)')
-    windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, range(n), region, table=table)
-    starts = table.read_pos.astype(np.int64)
-    ends = table.read_end.astype(np.int64)
-    usable = [w for w in windows
-              if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
-
-    def assemble(window):
-      ref = self._query(window)
-      window_reads = np.nonzero((ends > window.start) & (window.end > starts))[0].tolist()
-      graph = debruijn_graph.build_from_table(ref, table, window_reads, self.config.dbg_config)
-      haplotypes = [ref] if graph is None else graph.candidate_haplotypes()
-      if haplotypes and haplotypes != [ref]:
-        return CandidateHaplotypes(span=window, haplotypes=haplotypes)
-      return None
-
-    candidate_haplotypes = [ch for ch in _map_in_order(assemble, usable) if ch is not None]
-    if not candidate_haplotypes:
-      return candidate_haplotypes, table
-    # every read joins the window it shares most bases with (first on ties); the rest pass through
-    w_lo = np.array([ch.span.start for ch in candidate_haplotypes], np.int64)
-    w_hi = np.array([ch.span.end for ch in candidate_haplotypes], np.int64)
-    shared = np.maximum(np.minimum(ends[:, None], w_hi[None, :]) - np.maximum(starts[:, None], w_lo[None, :]), 0)
-    best = shared.argmax(axis=1)
-    claimed = shared[np.arange(n), best] > 0
-    groups = [np.nonzero(claimed & (best == w))[0] for w in range(len(candidate_haplotypes))]
-    seq_off = table.read_seq_off.astype(np.int64)
-    bases = table.bases.tobytes()
-
-    def align(w):
-      rows = groups[w]
-      if not len(rows):
-        return None
-      ch = candidate_haplotypes[w]
-      window = ch.span
-      contig = window.reference_name
-      lo, hi = int(starts[rows].min()), int(ends[rows].max())
-      ref_start = max(0, min(lo, window.start) - _REF_ALIGN_MARGIN)
-      ref_end = min(self.ref_reader.n_bases(contig), max(hi, window.end) + _REF_ALIGN_MARGIN)
-      if ref_end <= window.end:      # no room for a suffix: keep the original alignments
-        return None
-      ref_prefix = self._query(utils.make_range(contig, ref_start, window.start))
-      ref = self._query(window)
-      ref_suffix = self._query(utils.make_range(contig, window.end, ref_end))
-      sequences = [bases[seq_off[r]:seq_off[r + 1]] for r in rows.tolist()]
-      aligner = self._aligner(len(sequences[0]), False, len(ref_prefix), len(ref_suffix))
-      aligner.set_reference(ref_prefix + ref + ref_suffix, ref_start)
-      aligner.set_haplotypes([ref_prefix + target + ref_suffix for target in ch.haplotypes])
-      return aligner.align_reads_arrays(sequences)
-
-    changed_rows, changed_pos, changed_cigars = [], [], []
-    for w, res in enumerate(_map_in_order(align, list(range(len(candidate_haplotypes))))):
-      if res is None:
+    results: List = [None] * len(tables)
+    jobs = []        # (slot, table, region, usable windows, int64 starts / ends, window arrays, reference bytes)
+    for slot, (table, region) in enumerate(zip(tables, regions)):
+      n = table.n_reads
+      if n == 0:
+        results[slot] = ([], table)
         continue
-      status, position, off, words = res
-      rows = groups[w]
-      for k in np.nonzero(status == 1)[0].tolist():
-        changed_rows.append(int(rows[k]))
-        changed_pos.append(int(position[k]))
-        changed_cigars.append(words[off[k]:off[k + 1]])
-    realigned = table.with_alignments(changed_rows, changed_pos, changed_cigars)
-    order = np.concatenate([np.nonzero(~claimed)[0]] + groups)
-    return candidate_haplotypes, realigned.take(order)
+      windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, range(n), region, table=table)
+      usable = [w for w in windows
+                if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
+      if not usable:
+        results[slot] = ([], table)
+        continue
+      starts = np.ascontiguousarray(table.read_pos, np.int64)
+      ends = np.ascontiguousarray(table.read_end, np.int64)
+      w_lo = np.array([w.start for w in usable], np.int64)
+      w_hi = np.array([w.end for w in usable], np.int64)
+      contig = region.reference_name
+      n_contig = self.ref_reader.n_bases(contig)
+      ref_lo = max(0, min(int(starts.min()), int(w_lo.min())) - _REF_ALIGN_MARGIN)
+      ref_hi = min(n_contig, max(int(ends.max()), int(w_hi.max())) + _REF_ALIGN_MARGIN)
+      ref = self.ref_reader.get_bases(contig, ref_lo, ref_hi).encode()
+      jobs.append((slot, table, usable, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig))
+    if not jobs:
+      return results
+    descs = (_lib.DvRealignRegion * len(jobs))()
+    keep = []
+    for d, (slot, table, usable, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig) in zip(descs, jobs):
+      bases = np.ascontiguousarray(table.bases, np.uint8)
+      quals = np.ascontiguousarray(table.quals, np.uint8)
+      seq_off = np.ascontiguousarray(table.read_seq_off, np.uint32)
+      mapq = np.ascontiguousarray(table.read_mapq, np.uint8)
+      keep.append((bases, quals, seq_off, mapq))
+      d.bases, d.quals, d.n_bases = bases.ctypes.data, quals.ctypes.data, len(bases)
+      d.read_seq_off, d.read_mapq = seq_off.ctypes.data, mapq.ctypes.data
+      d.read_start, d.read_end = starts.ctypes.data, ends.ctypes.data
+      d.n_reads, d.n_windows = table.n_reads, len(usable)
+      d.window_start, d.window_end = w_lo.ctypes.data, w_hi.ctypes.data
+      d.ref, d.ref_start, d.ref_len, d.contig_len = ref, ref_lo, len(ref), n_contig
+    opt = self._native_options()
+    handle = C.c_void_p()
+    out = _lib.DvRealignOutput()
+    lib = _lib.lib()
+    _lib.check(lib.dv_realign_regions(descs, len(jobs), C.byref(opt), C.byref(handle), C.byref(out)))
+    try:
+      n_jobs = len(jobs)
+      row_off = np.ctypeslib.as_array(out.region_row_off, shape=(n_jobs + 1,))
+      total = int(row_off[-1])
+      view = lambda ptr, n, dtype: np.ctypeslib.as_array(ptr, shape=(n,)) if n else np.zeros(0, dtype)   # noqa: E731
+      order = view(out.order, total, np.int32)
+      status = view(out.status, total, np.int32)
+      position = view(out.position, total, np.int64)
+      cigar_off = np.ctypeslib.as_array(out.cigar_off, shape=(total + 1,))
+      words = view(out.cigar, int(cigar_off[-1]), np.uint32)
+      asm_off = np.ctypeslib.as_array(out.region_assembled_off, shape=(n_jobs + 1,))
+      n_asm = int(asm_off[-1])
+      asm_window = view(out.assembled_window, n_asm, np.int32)
+      hap_off = np.ctypeslib.as_array(out.assembled_hap_off, shape=(n_asm + 1,))
+      n_haps = int(hap_off[-1])
+      text_off = np.ctypeslib.as_array(out.hap_text_off, shape=(n_haps + 1,))
+      text = C.string_at(out.hap_text, int(text_off[-1])) if want_haplotypes and n_haps else b''
+      for g, (slot, table, usable, *_rest) in enumerate(jobs):
+        a0, a1 = int(asm_off[g]), int(asm_off[g + 1])
+        if a0 == a1:                       # no window assembled: the table passes through as it is
+          results[slot] = ([], table)
+          continue
+        haplotypes = []
+        if want_haplotypes:
+          for a in range(a0, a1):
+            haps = [text[int(text_off[h]):int(text_off[h + 1])].decode() for h in range(int(hap_off[a]), int(hap_off[a + 1]))]
+            haplotypes.append(CandidateHaplotypes(span=usable[int(asm_window[a])], haplotypes=haps))
+        r0, r1 = int(row_off[g]), int(row_off[g + 1])
+        changed = np.nonzero(status[r0:r1] == 1)[0]
+        realigned = table
+        if len(changed):
+          c_off = cigar_off[r0:r1 + 1]
+          # the changed rows' words are consecutive runs of `words`; rows in between are empty
+          realigned = table.with_alignments_csr(
+              changed, position[r0:r1][changed],
+              np.concatenate([c_off[changed], c_off[changed[-1] + 1:changed[-1] + 2]]), words)
+        results[slot] = (haplotypes, realigned.take(order[r0:r1].astype(np.int64)))
+    finally:
+      lib.dv_realign_result_free(handle)
+    del keep
+    return results
 
   def align_to_haplotype(self, this_haplotype: str, haplotypes: Sequence[str], prefix: str, suffix: str,
                          reads: Sequence, contig: str, ref_start: int) -> List:

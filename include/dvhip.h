@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 3
+#define DV_ABI_VERSION 4
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -466,6 +466,64 @@ int dv_debruijn_kmer_size(const dv_debruijn_graph* g);                          
 /* candidate_haplotypes(): sorted; strings owned by the graph until its next call. */
 int dv_debruijn_haplotypes(dv_debruijn_graph* g, int32_t* n, const char* const** haplotypes);
 int dv_debruijn_graphviz(dv_debruijn_graph* g, const char** text);                     /* graphviz */
+
+/* ---- the window realigner over many regions in one call (host only, threaded) -----
+ * Replaces the body of Realigner.realign_reads (deepvariant/realigner/realigner.py:795-855) for a
+ * BATCH of calling regions whose candidate windows are already selected: per window the reads
+ * that overlap it are assembled (call_debruijn_graph, :703-738; windows whose only haplotype is
+ * the reference are dropped), every read joins the assembled window it shares most bases with
+ * (assign_reads_to_assembled_regions, :596-619; the first such window on ties), and each
+ * window's reads are realigned against its haplotypes padded with the reference out to the
+ * reads' span + ref_align_margin (call_fast_pass_aligner, :740-793; FastPassAligner::AlignReads,
+ * deepvariant/realigner/fast_pass_aligner.cc:131-177).  The reference runs this window by
+ * window from Python, one make_examples process per core; here the (region, window) tasks of
+ * the whole batch are spread over `n_threads` host threads inside one call, and nothing but
+ * arrays crosses the boundary.  Results are those of the per-window entry points above. */
+typedef struct dv_realign_region {
+  /* the region's reads: dv_batch's arrays (one row per read, in the caller's order) */
+  const uint8_t* bases;
+  const uint8_t* quals;
+  int64_t n_bases;
+  const uint32_t* read_seq_off;    /* [n_reads + 1] */
+  const uint8_t* read_mapq;        /* [n_reads] */
+  const int64_t* read_start;       /* [n_reads] alignment start */
+  const int64_t* read_end;         /* [n_reads] alignment end, exclusive (ReadRange) */
+  int32_t n_reads;
+  int32_t n_windows;               /* candidate windows, sorted; each inside the contig and */
+  const int64_t* window_start;     /*   no longer than ws_config.max_window_size (the caller's */
+  const int64_t* window_end;       /*   filter, realigner.py:717-722) */
+  const char* ref;                 /* reference bases [ref_start, ref_start + ref_len): must cover */
+  int64_t ref_start;               /*   every read and window +- ref_align_margin, clipped to */
+  int64_t ref_len;                 /*   [0, contig_len) */
+  int64_t contig_len;
+} dv_realign_region;
+
+typedef struct dv_realign_options {
+  dv_debruijn_options dbg;
+  dv_aligner_options aln;          /* read_size, ref_prefix_len, ref_suffix_len are set per window */
+  int32_t ref_align_margin;        /* _REF_ALIGN_MARGIN, realigner.py:263 (20) */
+  int32_t n_threads;               /* <= 0: one per hardware thread, at most 16 */
+} dv_realign_options;
+
+typedef struct dv_realign_output {   /* views into the result; valid until dv_realign_result_free */
+  const int64_t* region_row_off;     /* [n_regions + 1]: region g's rows are [off[g], off[g + 1]) below */
+  const int32_t* order;              /* rows of the region in the order realign_reads returns its reads:
+                                        first the ones no window claimed, then window by window */
+  const int32_t* status;             /* per row (input order): 0 alignment kept, 1 new alignment */
+  const int64_t* position;           /* new alignment start, status 1 */
+  const int64_t* cigar_off;          /* [rows + 1] into `cigar`; empty unless status 1 */
+  const uint32_t* cigar;             /* (length << 4 | op) words */
+  const int32_t* region_assembled_off;   /* [n_regions + 1] into the assembled-window arrays */
+  const int32_t* assembled_window;   /* index in the region's window list */
+  const int32_t* assembled_hap_off;  /* [n_assembled + 1] into the haplotype list */
+  const int64_t* hap_text_off;       /* [n_haplotypes + 1] into hap_text */
+  const char* hap_text;              /* CandidateHaplotypes.haplotypes, sorted per window */
+} dv_realign_output;
+
+typedef struct dv_realign_result dv_realign_result;
+int dv_realign_regions(const dv_realign_region* regions, int32_t n_regions, const dv_realign_options* options,
+                       dv_realign_result** out, dv_realign_output* arrays);
+void dv_realign_result_free(dv_realign_result* r);
 
 /* ---- read phasing for the long-read path (host only) ---------------------------
  * Replaces deepvariant/direct_phasing.{h,cc} (DirectPhasing::PhaseReads / GetPhasedVariants;

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
   for sym in declared:
     assert hasattr(l, sym), sym
   assert sorted(_lib.ABI_SYMBOLS) == declared
-  assert l.dv_abi_version() == 3   # 3: dv_allele_event.length_type (28-bit lengths), dv_model_graph_stats
+  assert l.dv_abi_version() == 4   # 4: dv_realign_regions (the window realigner over a batch of regions)
 
 
 def test_host_helpers_need_no_gpu():

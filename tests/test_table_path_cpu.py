@@ -78,3 +78,55 @@ def test_realign_table_equals_realign_reads():
     _same(realigned_table, want)
     n_moved += int((np.sort(want.read_pos) != np.sort(table.read_pos)).sum())
   assert n_moved > 50
+
+
+@pytest.mark.timeout(900)
+@RF.with_oracle_counter
+def test_realign_tables_batch_equals_region_by_region():
+  """One dv_realign_regions call over every region of the golden slice (the make_examples runner's
+  form: all windows of the batch on the native thread pool) against one call per region, with one
+  and with several threads: same assembled windows, same haplotypes, same tables."""
+  ref, sets = RF.load()
+  rl = R.Realigner(R.realigner_config(), ref)
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  regions, tables = [], []
+  for start in range(9_999_999, 10_010_000, 1000):
+    region = T.Range('chr20', start, min(start + 1000, 10_010_000))
+    regions.append(region)
+    tables.append(packing.ReadTable.from_reads([r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)]))
+  regions.append(T.Range('chr20', 10_020_000, 10_021_000))          # a region without reads rides along
+  tables.append(packing.ReadTable.from_reads([]))
+  one_by_one = [rl.realign_table(t, r) for t, r in zip(tables, regions)]
+  assert sum(len(ch) for ch, _ in one_by_one) > 5
+  for threads in (1, 5):
+    old, R._NATIVE_THREADS = R._NATIVE_THREADS, threads
+    try:
+      batch = rl.realign_tables(tables, regions)
+      bare = rl.realign_tables(tables, regions, want_haplotypes=False)
+    finally:
+      R._NATIVE_THREADS = old
+    assert len(batch) == len(one_by_one)
+    for (ch_a, t_a), (ch_b, t_b), (ch_c, t_c) in zip(one_by_one, batch, bare):
+      assert [(c.span, c.haplotypes) for c in ch_a] == [(c.span, c.haplotypes) for c in ch_b]
+      _same(t_a, t_b, ranks_as_order=False)
+      _same(t_a, t_c, ranks_as_order=False)
+      assert ch_c == []
+
+
+def test_with_alignments_csr_handles_runs_and_empty_input():
+  _, sets = RF.load()
+  reads = sets['wgs'][:40]
+  table = packing.ReadTable.from_reads(reads)
+  assert table.with_alignments_csr([], [], np.zeros(1, np.int64), np.zeros(0, np.uint32)) is table
+  rows = np.array([0, 1, 39])
+  words = np.array([(50 << 4) | 1, (3 << 4) | 3, (51 << 4) | 1, (101 << 4) | 1, (7 << 4) | 5, (94 << 4) | 1], np.uint32)
+  off = np.array([0, 3, 4, 6])
+  positions = np.array([100, 200, 300])
+  got = table.with_alignments_csr(rows, positions, off, words)
+  want = table.with_alignments(rows.tolist(), positions.tolist(), [words[0:3], words[3:4], words[4:6]])
+  _same(got, want, ranks_as_order=False)
+  assert got.read_end[0] == 100 + 104 and got.read_end[1] == 200 + 101 and got.read_end[39] == 300 + 94
+  assert np.array_equal(got.cigar[got.read_cigar_off[39]:got.read_cigar_off[40]], words[4:6])
+  assert np.array_equal(got.cigar[got.read_cigar_off[2]:got.read_cigar_off[3]],
+                        table.cigar[table.read_cigar_off[2]:table.read_cigar_off[3]])
