@@ -582,14 +582,52 @@ def bam_mode(args, log=sys.stderr):
     me.RegionReads.__call__ = timed('BAM decode (native) + reads of the region', me.RegionReads.__call__)
     me.RegionReads.table = timed('BAM decode (native) + rows of the region', me.RegionReads.table)
     tfrecord.Writer.write = timed('TFRecord(GZIP) write', tfrecord.Writer.write)
+    weights = os.path.join(tmp, 'weights.f32')
+
+    class WarmHooks(Hooks):
+      def make_model(self, args, options):      # the timed run reads its weights from a file, as a real run does
+        model = super().make_model(args, options)
+        model.flat_weights.tofile(weights)
+        return model
+
     warm = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm.cvo.tfrecord.gz')
-    me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=Hooks())     # kernels loaded, graphs captured
+    me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=WarmHooks())     # kernels loaded, graphs captured
     stage.clear()
     timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'cvo.tfrecord.gz')
+    timed_args.checkpoint = weights
     t0 = time.perf_counter()
     stats = me.make_examples_runner(timed_args, log=open(os.devnull, 'w'), hooks=Hooks())
     elapsed = time.perf_counter() - t0
     n_written = sum(1 for _ in tfrecord.read_tfrecords(os.path.join(tmp, 'cvo.tfrecord.gz')))
+    if os.environ.get('DV_BAM_CPROFILE'):       # where the host time of the loop goes: one more run under cProfile
+      import cProfile
+      import io
+      import pstats
+      prof_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'prof.cvo.tfrecord.gz')
+      prof_args.checkpoint = weights
+      pr = cProfile.Profile()
+      pr.enable()
+      me.make_examples_runner(prof_args, log=open(os.devnull, 'w'), hooks=me.RunnerHooks())
+      pr.disable()
+      text = io.StringIO()
+      pstats.Stats(pr, stream=text).sort_stats('tottime').print_stats(45)
+      pstats.Stats(pr, stream=text).sort_stats('cumulative').print_stats(60)
+      with open(os.environ['DV_BAM_CPROFILE'], 'w') as f:
+        f.write(text.getvalue())
+    # the same run once more with a HIP event pair around every kernel launch (eager launches):
+    # how long the GPU computes for this slice, against the wall time of the timed run
+    timed_stage = dict(stage)
+    from deepvariant_amd import _lib
+    lib = _lib.lib()
+    lib.dv_set_profiling(1)
+    again = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'again.cvo.tfrecord.gz')
+    again.checkpoint = weights
+    me.make_examples_runner(again, log=open(os.devnull, 'w'), hooks=Hooks())
+    torch.cuda.synchronize()
+    kernel_ms = {'encoder': lib.dv_profile_ms(0), 'cnn': lib.dv_profile_ms(1), 'other (allele counts, pools, head)': lib.dv_profile_ms(2)}
+    lib.dv_set_profiling(0)
+    stage.clear()
+    stage.update(timed_stage)
   assert n_written == stats['n_examples']
   print(json.dumps({
       'metric': 'examples/sec, BAM + FASTA -> CallVariantsOutput (make_examples fused route), one host process',
@@ -603,8 +641,11 @@ def bam_mode(args, log=sys.stderr):
       'examples': stats['n_examples'], 'table_path': stats.get('table_path'),
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
       'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
-      'host_cores': os.cpu_count(),
-      'note': 'not the contract metric: inputs start in files on the host, one Python process drives the region loop',
+      'gpu_kernel_ms': kernel_ms, 'gpu_busy_frac': sum(kernel_ms.values()) / (1e3 * elapsed),
+      'host_cores': os.cpu_count(), 'realigner_threads': os.environ.get('DV_REALIGN_THREADS', 'auto (<= 16)'),
+      'note': 'not the contract metric: inputs start in files on the host, one Python process drives the region loop '
+              '(the realigner of a batch of regions on native host threads, the model set up on a worker thread); '
+              'gpu_busy_frac = kernel time of an instrumented repeat of the run / wall time of the timed run',
   }))
 
 

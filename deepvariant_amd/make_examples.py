@@ -425,6 +425,44 @@ class RegionReads:
     return out
 
 
+class _BackgroundModel:
+  """The classifier of the fused route, built on a worker thread (device allocations, the
+  checkpoint read, BN folding + fp16 packing + upload: native code, the GIL is free) while the
+  region loop decodes its first block of reads and realigns its first batch of regions.  The
+  loop only needs the input shape until the first batch of examples is classified."""
+
+  def __init__(self, build, input_shape):
+    import threading
+    self.input_shape = tuple(input_shape)
+    self._model, self._error = None, None
+    self._thread = threading.Thread(target=self._run, args=(build,), name='dv-model-setup', daemon=True)
+    self._thread.start()
+
+  def _run(self, build):
+    try:
+      self._model = build()
+    except BaseException as e:      # pylint: disable=broad-except   (re-raised on the main thread)
+      self._error = e
+
+  def get(self):
+    if self._thread is not None:
+      self._thread.join()
+      self._thread = None
+    if self._error is not None:
+      raise self._error
+    built = getattr(self._model, 'input_shape', None)
+    if built is not None and tuple(built) != self.input_shape:
+      raise ValueError('model shape %s != example shape %s' % (tuple(built), self.input_shape))
+    return self._model
+
+  @property
+  def max_batch(self) -> int:
+    return self.get().max_batch
+
+  def __call__(self, images):
+    return self.get()(images)
+
+
 class RunnerHooks:
   """What the runner builds per task.  The product uses these defaults; the multi-process CPU
   tests substitute a processor / model that need no GPU (tests/test_make_examples_dist_cpu.py)."""
@@ -463,7 +501,11 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   pieces = calling_regions(args, ref_reader, contig_names, num_shards)
   reads_for = RegionReads(args)
   proc = hooks.make_processor(options, ref_reader, po, args.device)
-  model = hooks.make_model(args, options) if args.call_variants_outfile else None
+  model = None
+  if args.call_variants_outfile:
+    shape = (make_examples_native.calculate_pileup_image_height(options), options.pic_options.width,
+             len(options.pic_options.channels))
+    model = _BackgroundModel(lambda: hooks.make_model(args, options), shape)
   stats = dict(n_regions=0, n_reads=0, n_candidates=0, n_examples=0)
   if sweep:
     # int32 positions per calling region, END_OF_PARTITION after each, END_OF_REGION where a
@@ -493,7 +535,7 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   use_tables = os.environ.get('DV_REGION_OBJECTS') is None and getattr(proc, 'table_path_ok', lambda: False)()
   stats['table_path'] = bool(use_tables)
   t_loop = time.perf_counter()
-  stats['setup_s'] = t_loop - t_start        # flags, region list, processor, model + weights
+  stats['setup_s'] = t_loop - t_start        # flags, region list, processor (the model is set up on a worker thread)
   try:
     # the table path walks the regions in batches: the realigner's native work of a whole batch
     # (every window's assembly and alignment) is ONE threaded call, the rest stays per region
@@ -531,7 +573,7 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
       stats['n_regions'] += 1
       stats['n_reads'] += len(in_reads)
       if model is not None:
-        candidates, records = proc.call_variants_in_region(region, in_reads, model)
+        candidates, records = proc.call_variants_in_region(region, in_reads, model.get())
       else:
         candidates, records = proc.examples_in_region(region, in_reads)
       for rec in records:
@@ -543,6 +585,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
         for rec in records:
           writer.write(rec)
         stats['n_examples'] += len(records)
+    if model is not None:
+      model.get()                 # a failed model set-up is an error even when no example asked for it
   finally:
     writer.close()
   stats['loop_s'] = time.perf_counter() - t_loop   # the region loop proper (BAM decode to the last record written)
