@@ -470,7 +470,7 @@ def _bam_fixture(tmp):
       f.write(z['bai'].tobytes())
     fasta = os.path.join(tmp, 'ref.fa')
     lo = int(z['ref_start'][0])
-    genomics_io.write_fasta(fasta, [('chr20', 'N' * lo + z['ref_bases'].tobytes().decode())])
+    genomics_io.write_fasta(fasta, [('chr20', 'N' * lo + z['ref_bases'].tobytes().decode())], index=True)
   return bam, fasta
 
 
@@ -568,7 +568,12 @@ def bam_mode(args, log=sys.stderr):
       proc.candidates_in_region = timed('allele counts (device) + candidate caller', proc.candidates_in_region)
       proc.generator.call_variants_in_region = timed(
           'pack + encode + classify (device) + CallVariantsOutput protos', proc.generator.call_variants_in_region)
-      proc.realign_tables = timed('realign (window selection on the device, assembly, alignment)', proc.realign_tables)
+      start_batch = proc.start_realign_tables
+
+      def start_realign_tables(*a, **k):      # the native call of batch k + 1 runs while batch k is called and drawn
+        finish = timed('realign: window selection (device counts) + marshalling', start_batch)(*a, **k)
+        return timed('realign: wait for the assembly / alignment threads + write-back', finish)
+      proc.start_realign_tables = start_realign_tables
       proc.generator.encode_region_on_device = timed('pack + encode (device)', proc.generator.encode_region_on_device)
       proc.flush_queue = timed('classify (device, several regions per forward) + CallVariantsOutput protos',
                                proc.flush_queue)

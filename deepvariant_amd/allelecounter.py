@@ -136,6 +136,39 @@ class AlleleCounter:
     self._build_alleles()
     return [self._count_at(i) for i in sorted(self._alleles)]
 
+  def counts_with_alt_support(self, min_count: int) -> List[AlleleCount]:
+    """The positions at which at least `min_count` reads left a good-quality allele that is
+    neither the reference nor a soft clip, in order.  An alternate allele's count is at most that
+    number, so a candidate caller whose thresholds ask for `min_count` reads per allele
+    (IsGoodAltAllele, variant_calling_multisample.cc:232-238) finds every candidate among them --
+    one position in twenty of the ones `counts_with_read_alleles` returns on 30x Illumina data,
+    where most read alleles are lone sequencing errors.  The AlleleCounts are complete (all read
+    alleles of the position, low-quality ones included); only those positions' Allele objects
+    are built."""
+    self._ensure()
+    ev = self._events
+    if not len(ev):
+      return []
+    packed = ev['length_type']
+    kind = (packed >> 28) & 7
+    n = self._end - self._start
+    good = ((packed >> 31) == 0) & (kind != REFERENCE) & (kind != SOFT_CLIP) & (ev['position'] >= 0) & (ev['position'] < n)
+    per_position = np.bincount(ev['position'][good], minlength=n) if good.any() else np.zeros(n, np.int64)
+    wanted = np.nonzero(per_position >= max(1, int(min_count)))[0]
+    if not len(wanted):
+      return []
+    if self._alleles is not None:
+      return [self._count_at(int(i)) for i in wanted.tolist()]
+    alleles = self._alleles_of(np.nonzero(np.isin(ev['position'], wanted))[0])
+    out = []
+    for i in wanted.tolist():
+      c = AlleleCount(self._contig, self._start + i, self._interval_ref[i])
+      c.ref_supporting_read_count = int(self._ref_counts[i])
+      c.track_ref_reads = self._track_ref_reads
+      c.read_alleles = alleles.get(i, {})
+      out.append(c)
+    return out
+
   def ref_supporting_read_counts(self) -> np.ndarray:
     self._ensure()
     return self._ref_counts
@@ -195,29 +228,32 @@ class AlleleCounter:
   def _build_alleles(self):
     if self._alleles is not None:
       return
-    ev = self._events
+    self._alleles, self._counts = self._alleles_of(None), None
+
+  def _alleles_of(self, rows) -> Dict[int, Dict[str, Allele]]:
+    """{position offset: {read key: Allele}} of the events `rows` (indices, ascending; None = all)."""
+    ev = self._events if rows is None else self._events[rows]
     table, window, w0 = self._event_ctx
-    if True:
-      seq_off = table.read_seq_off
-      bases = table.bases
-      keys = table.keys
-      s0_all = seq_off[ev['read']].astype(np.int64) + ev['read_offset']
-      alleles: Dict[int, Dict[str, Allele]] = {}
-      for k, (position, read, read_offset, packed) in enumerate(ev.tolist()):
-        length_k, type_k, low = packed & 0x0fffffff, (packed >> 28) & 7, packed >> 31
-        s0 = int(s0_all[k])
-        if type_k == SUBSTITUTION or type_k == REFERENCE:
-          text = chr(bases[s0])
+    seq_off = table.read_seq_off
+    bases = table.bases
+    keys = table.keys
+    s0_all = seq_off[ev['read']].astype(np.int64) + ev['read_offset']
+    alleles: Dict[int, Dict[str, Allele]] = {}
+    for k, (position, read, read_offset, packed) in enumerate(ev.tolist()):
+      length_k, type_k, low = packed & 0x0fffffff, (packed >> 28) & 7, packed >> 31
+      s0 = int(s0_all[k])
+      if type_k == SUBSTITUTION or type_k == REFERENCE:
+        text = chr(bases[s0])
+      else:
+        anchor = self._start + position - w0              # the base the indel is anchored on
+        prev = chr(bases[s0 - 1]) if read_offset > 0 else window[anchor:anchor + 1].decode()
+        if type_k == DELETION:
+          text = prev + window[anchor + 1:anchor + 1 + length_k].decode()
         else:
-          anchor = self._start + position - w0              # the base the indel is anchored on
-          prev = chr(bases[s0 - 1]) if read_offset > 0 else window[anchor:anchor + 1].decode()
-          if type_k == DELETION:
-            text = prev + window[anchor + 1:anchor + 1 + length_k].decode()
-          else:
-            text = prev + bytes(bases[s0:s0 + length_k]).decode()
-        # a later read with the same key overwrites (read_alleles is a map keyed by ReadKey)
-        alleles.setdefault(position, {})[keys[read]] = Allele(text, type_k, 1, bool(low))
-      self._alleles, self._counts = alleles, None
+          text = prev + bytes(bases[s0:s0 + length_k]).decode()
+      # a later read with the same key overwrites (read_alleles is a map keyed by ReadKey)
+      alleles.setdefault(position, {})[keys[read]] = Allele(text, type_k, 1, bool(low))
+    return alleles
 
   def variant_read_window_counts(self, min_allele_support: int = 0, strict_insertion_filter: bool = False):
     """VariantReadsWindowSelectorCandidates (window_selector.cc:101-141) straight from the events:

@@ -30,8 +30,10 @@ std::vector<int8_t> translate(const std::string& s) {
 // walk their sequences with a step of +1 or -1 (the reverse pass), shorter ones are padded with
 // symbols that match nothing: a padded cell is always strictly below a real cell that was seen
 // earlier, so it can neither start a new maximum nor be picked as its row.
-constexpr int kLanes = 16;
-typedef int16_t Lanes __attribute__((vector_size(2 * kLanes)));
+// 16 lanes fill an AVX2 register, 32 an AVX-512 one; which one runs is a property of the host
+// (sweep_width), the result per pair is the same either way.
+constexpr int kMaxLanes = 32;
+template <int L> struct LaneVector { typedef int16_t type __attribute__((vector_size(2 * L))); };
 
 struct SweepLane {
   const int8_t* ref = nullptr;
@@ -46,7 +48,9 @@ struct SweepParams {
   int match, mismatch, gap_open, gap_extend;
 };
 
+template <int kLanes>
 static inline __attribute__((always_inline)) void sweep_lanes_body(SweepLane* lanes, const SweepParams& p) {
+  typedef typename LaneVector<kLanes>::type Lanes;
   int n = 0, columns = 0;
   for (int l = 0; l < kLanes; ++l) {
     n = std::max(n, lanes[l].q_len);
@@ -115,14 +119,29 @@ static inline __attribute__((always_inline)) void sweep_lanes_body(SweepLane* la
   }
 }
 
-__attribute__((target("avx2"))) void sweep_lanes_avx2(SweepLane* lanes, const SweepParams& p) {
-  sweep_lanes_body(lanes, p);
+__attribute__((target("avx512bw,avx512vl,avx512f"))) void sweep_lanes_avx512(SweepLane* lanes, const SweepParams& p) {
+  sweep_lanes_body<32>(lanes, p);
 }
-void sweep_lanes_generic(SweepLane* lanes, const SweepParams& p) { sweep_lanes_body(lanes, p); }
+__attribute__((target("avx2"))) void sweep_lanes_avx2(SweepLane* lanes, const SweepParams& p) {
+  sweep_lanes_body<16>(lanes, p);
+}
+void sweep_lanes_generic(SweepLane* lanes, const SweepParams& p) { sweep_lanes_body<16>(lanes, p); }
 
-void sweep_lanes(SweepLane* lanes, const SweepParams& p) {
+// pairs per sweep on this host: 32 with AVX-512BW, else 16 (DV_SWEEP_LANES=16 forces the narrow form)
+int sweep_width() {
+  static const int width = [] {
+    const char* forced = getenv("DV_SWEEP_LANES");
+    if (forced && std::atoi(forced) == 16) return 16;
+    return __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") ? 32 : 16;
+  }();
+  return width;
+}
+
+void sweep_lanes(SweepLane* lanes, const SweepParams& p, int width) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  if (avx2) {
+  if (width == 32) {
+    sweep_lanes_avx512(lanes, p);
+  } else if (avx2) {
     sweep_lanes_avx2(lanes, p);
   } else {
     sweep_lanes_generic(lanes, p);
@@ -312,8 +331,12 @@ void LocalAligner::align_pairs(const std::vector<const CodedSequence*>& referenc
   out->assign(m, LocalAlignment());
   ok->assign(m, 0);
   const SweepParams params{match_, mismatch_, gap_open_, gap_extend_};
-  for (size_t base = 0; base < m; base += kLanes) {
-    const size_t count = std::min<size_t>(kLanes, m - base);
+  const int host_width = sweep_width();
+  size_t count = 0;
+  for (size_t base = 0; base < m; base += count) {
+    // a tail of at most 16 pairs goes through the narrow sweep: half the work per column
+    const int width = m - base > 16 ? host_width : 16;
+    count = std::min<size_t>(width, m - base);
     // int16 lanes: scores and column indices must fit
     bool lanes_fit = count > 1 && gap_open_ < 16000 && mismatch_ < 16000 && match_ < 16000;
     for (size_t l = 0; l < count; ++l) {
@@ -331,7 +354,7 @@ void LocalAligner::align_pairs(const std::vector<const CodedSequence*>& referenc
       }
       continue;
     }
-    SweepLane fwd[kLanes], rev[kLanes];
+    SweepLane fwd[kMaxLanes], rev[kMaxLanes];
     for (size_t l = 0; l < count; ++l) {
       const CodedSequence& ref = *references[base + l];
       const CodedSequence& q = *queries[base + l];
@@ -341,7 +364,7 @@ void LocalAligner::align_pairs(const std::vector<const CodedSequence*>& referenc
       fwd[l].q = q.data();
       fwd[l].q_len = static_cast<int>(q.size());
     }
-    sweep_lanes(fwd, params);
+    sweep_lanes(fwd, params, width);
     bool any_reverse = false;
     for (size_t l = 0; l < count; ++l) {
       if (fwd[l].ref_len == 0) continue;
@@ -360,7 +383,7 @@ void LocalAligner::align_pairs(const std::vector<const CodedSequence*>& referenc
       any_reverse = true;
     }
     if (!any_reverse) continue;
-    sweep_lanes(rev, params);
+    sweep_lanes(rev, params, width);
     for (size_t l = 0; l < count; ++l) {
       if (rev[l].ref_len == 0 || rev[l].best != fwd[l].best) continue;      // ok stays 0, as in finish()
       const int ref_end = fwd[l].best_ref, q_end = fwd[l].best_q;

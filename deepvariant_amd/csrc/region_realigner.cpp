@@ -15,6 +15,8 @@
 // thread_local), so a phase is a parallel loop over a task list ordered longest first.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -45,27 +47,81 @@ struct Window {            // one candidate window of one region
   std::vector<dv::RealignedRead> aligned;   // parallel to rows; empty: alignments kept
 };
 
-template <class F>
-void parallel_tasks(const std::vector<int>& tasks, int n_threads, F&& fn) {
-  const int n = static_cast<int>(tasks.size());
-  if (n_threads <= 1 || n <= 1) {
-    for (int t : tasks) fn(t);
-    return;
+// The worker threads live as long as the library: no thread creation per call, and the aligner's
+// thread_local scratch tables (MBs for a heavy window) stay allocated from one call to the next.
+// One job at a time; the calling thread works too.
+class WorkerPool {
+ public:
+  static WorkerPool& get() {
+    static WorkerPool* pool = new WorkerPool();      // never destroyed: workers may outlive main()'s statics
+    return *pool;
   }
-  std::atomic<int> next{0};
-  auto work = [&]() {
-    for (;;) {
-      const int i = next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= n) return;
-      fn(tasks[i]);
+
+  void run(const std::vector<int>& tasks, int n_threads, const std::function<void(int)>& fn) {
+    const int n = static_cast<int>(tasks.size());
+    if (n_threads <= 1 || n <= 1) {
+      for (int t : tasks) fn(t);
+      return;
     }
-  };
-  std::vector<std::thread> threads;
-  const int extra = std::min(n_threads, n) - 1;
-  threads.reserve(extra);
-  for (int t = 0; t < extra; ++t) threads.emplace_back(work);
-  work();
-  for (std::thread& t : threads) t.join();
+    std::lock_guard<std::mutex> one_job(job_lock_);
+    const int helpers = std::min(n_threads, n) - 1;
+    {
+      std::lock_guard<std::mutex> hold(lock_);
+      while (static_cast<int>(threads_.size()) < helpers) threads_.emplace_back([this] { worker(); });
+      tasks_ = &tasks;
+      fn_ = &fn;
+      next_.store(0, std::memory_order_relaxed);
+      wanted_ = helpers;
+      busy_ = helpers;
+      ++generation_;
+    }
+    wake_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> hold(lock_);
+    done_.wait(hold, [this] { return busy_ == 0; });
+    tasks_ = nullptr;
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    const int n = static_cast<int>(tasks_->size());
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) return;
+      (*fn_)((*tasks_)[i]);
+    }
+  }
+
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> hold(lock_);
+        wake_.wait(hold, [&] { return generation_ != seen && wanted_ > 0; });
+        seen = generation_;
+        --wanted_;
+      }
+      drain();
+      {
+        std::lock_guard<std::mutex> hold(lock_);
+        if (--busy_ == 0) done_.notify_one();
+      }
+    }
+  }
+
+  std::mutex job_lock_, lock_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> threads_;
+  const std::vector<int>* tasks_ = nullptr;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int wanted_ = 0, busy_ = 0;
+  uint64_t generation_ = 0;
+};
+
+void parallel_tasks(const std::vector<int>& tasks, int n_threads, const std::function<void(int)>& fn) {
+  WorkerPool::get().run(tasks, n_threads, fn);
 }
 
 std::vector<int> longest_first(const std::vector<int64_t>& cost) {

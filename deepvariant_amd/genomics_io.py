@@ -14,6 +14,7 @@ generator and by make_examples_native when it is handed file names.
 from __future__ import annotations
 
 import gzip
+import os
 import struct
 import zlib
 from typing import Dict, Iterator, List, Optional, Tuple
@@ -274,33 +275,64 @@ def _find_u32_array_tag(aux, tag: bytes) -> Optional[List[int]]:
 
 
 class FastaReader:
-  """Whole-file FASTA (plain, gzip or bgzip) reader; bases upper-cased."""
+  """FASTA reader (plain, gzip or bgzip); bases upper-cased.  The interface the region chain uses
+  of nucleus' IndexedFastaReader (third_party/nucleus/io/reference.h: contig names in file order,
+  n_bases, get_bases).
+
+  A plain file with a samtools `.fai` next to it is mapped and read on demand -- a query costs the
+  bytes it returns, and a process holds no copy of the genome (R ranks on a GPU share the page
+  cache).  Anything else (compressed, no index) is parsed once into memory, record by record with
+  bulk byte operations."""
 
   def __init__(self, path: str):
-    opener = gzip.open if open(path, 'rb').read(2) == b'\x1f\x8b' else open
     self._contigs: Dict[str, str] = {}
-    name, chunks = None, []
-    with opener(path, 'rt') as f:
-      for line in f:
-        if line.startswith('>'):
-          if name is not None:
-            self._contigs[name] = ''.join(chunks).upper()
-          name = line[1:].split()[0]
-          chunks = []
-        else:
-          chunks.append(line.strip())
-    if name is not None:
-      self._contigs[name] = ''.join(chunks).upper()
+    self._index: Dict[str, Tuple[int, int, int, int]] = {}       # name -> (length, offset, line bases, line bytes)
+    self._map = None
+    with open(path, 'rb') as f:
+      compressed = f.read(2) == b'\x1f\x8b'
+    fai = path + '.fai'
+    if not compressed and os.path.exists(fai):
+      import mmap
+      with open(fai) as f:
+        for line in f:
+          parts = line.rstrip('\n').split('\t')
+          if len(parts) >= 5:
+            self._index[parts[0]] = (int(parts[1]), int(parts[2]), int(parts[3]), int(parts[4]))
+      self._file = open(path, 'rb')
+      self._map = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
+      return
+    with (gzip.open if compressed else open)(path, 'rb') as f:
+      data = f.read()
+    at = data.find(b'>')
+    while at >= 0:
+      eol = data.find(b'\n', at)
+      eol = len(data) if eol < 0 else eol
+      nxt = data.find(b'\n>', eol)
+      end = len(data) if nxt < 0 else nxt
+      header = data[at + 1:eol].split()
+      name = header[0].decode() if header else ''
+      self._contigs[name] = data[eol + 1:end].translate(None, b'\n\r \t').upper().decode()
+      at = -1 if nxt < 0 else nxt + 1
 
   def n_bases(self, contig: str) -> int:
+    if self._map is not None:
+      return self._index[contig][0]
     return len(self._contigs[contig])
 
   def contig_names(self) -> List[str]:
     """Contig names in file order (the order the reference's regions are processed in)."""
-    return list(self._contigs)
+    return list(self._index if self._map is not None else self._contigs)
 
   def get_bases(self, contig: str, start: int, end: int) -> str:
-    return self._contigs[contig][start:end]
+    if self._map is None:
+      return self._contigs[contig][start:end]
+    length, offset, line_bases, line_bytes = self._index[contig]
+    start, end = max(start, 0), min(end, length)
+    if end <= start:
+      return ''
+    first = offset + (start // line_bases) * line_bytes + start % line_bases
+    last = offset + (end // line_bases) * line_bytes + end % line_bases
+    return self._map[first:last].translate(None, b'\n\r').upper().decode()
 
 
 def read_satisfies_requirements(read, min_mapping_quality: int = 0,
@@ -395,11 +427,21 @@ def _reg2bin(beg: int, end: int) -> int:
   return 0
 
 
-def write_fasta(path: str, contigs) -> None:
-  """contigs: [(name, bases)]; 60 bases a line, gzip if the path ends in .gz."""
+def write_fasta(path: str, contigs, index: bool = False) -> None:
+  """contigs: [(name, bases)]; 60 bases a line, gzip if the path ends in .gz; `index` also writes
+  the samtools .fai of a plain file (name, length, offset of the first base, 60, 61)."""
   opener = gzip.open if path.endswith('.gz') else open
-  with opener(path, 'wt') as f:
+  fai = []
+  at = 0
+  with opener(path, 'wb') as f:
     for name, bases in contigs:
-      f.write('>%s\n' % name)
-      for i in range(0, len(bases), 60):
-        f.write(bases[i:i + 60] + '\n')
+      header = ('>%s\n' % name).encode()
+      raw = bases.encode() if isinstance(bases, str) else bytes(bases)
+      body = b'\n'.join(raw[i:i + 60] for i in range(0, len(raw), 60)) + (b'\n' if raw else b'')
+      f.write(header)
+      f.write(body)
+      fai.append('%s\t%d\t%d\t60\t61\n' % (name, len(raw), at + len(header)))
+      at += len(header) + len(body)
+  if index and not path.endswith('.gz'):
+    with open(path + '.fai', 'w') as f:
+      f.writelines(fai)

@@ -34,7 +34,7 @@ from deepvariant_amd.realigner import utils
 
 _RANDOM_SEED = 609314161            # make_examples_options.py:981
 _CLASSIFY_AT = 256                  # fused route, table path: examples collected on the device per CNN forward
-_REGION_BATCH = 64                  # table path: calling regions whose realigner work goes through one native call
+_REGION_BATCH = 32                  # table path: calling regions whose realigner work goes through one native call
 _REALIGNER_FLAGS = {k: v for k, v in realigner_module._FLAG_DEFAULTS.items()   # pylint: disable=protected-access
                     if k.startswith(('ws_', 'dbg_', 'aln_')) or k in (
                         'max_num_mismatches', 'realignment_similarity_threshold', 'kmer_size', 'split_skip_reads')}
@@ -538,8 +538,9 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   stats['setup_s'] = t_loop - t_start        # flags, region list, processor (the model is set up on a worker thread)
   try:
     # the table path walks the regions in batches: the realigner's native work of a whole batch
-    # (every window's assembly and alignment) is ONE threaded call, the rest stays per region
-    for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
+    # (every window's assembly and alignment) is ONE threaded call, started for batch k + 1
+    # before the candidates of batch k are called and drawn -- the rest stays per region
+    def start_batch(at):
       batch = pieces[at:at + _REGION_BATCH]
       tables = []
       for region in batch:
@@ -548,7 +549,17 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
           in_table = in_table.take(np.array(reservoir_sample(range(in_table.n_reads), args.max_reads_per_partition,
                                                              np.random.RandomState(_RANDOM_SEED)), np.int64))
         tables.append(in_table)
-      for region, in_table, realigned in zip(batch, tables, proc.realign_tables(tables, batch)):
+      return batch, tables, proc.start_realign_tables(tables, batch, executor=realign_thread)
+
+    realign_thread = None
+    if use_tables and len(pieces) > _REGION_BATCH:
+      import concurrent.futures
+      realign_thread = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-realign-batch')
+    pending = start_batch(0) if use_tables and pieces else None
+    for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
+      batch, tables, realigned_tables = pending
+      pending = start_batch(at + _REGION_BATCH) if at + _REGION_BATCH < len(pieces) else None
+      for region, in_table, realigned in zip(batch, tables, realigned_tables()):
         stats['n_regions'] += 1
         stats['n_reads'] += in_table.n_reads
         if model is not None:
@@ -566,6 +577,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
           writer.write(rec)
         stats['n_candidates'] += len(candidates)
         stats['n_examples'] += len(records)
+    if realign_thread is not None:
+      realign_thread.shutdown()
     for region in ([] if use_tables else pieces):
       in_reads = reads_for(region)
       if args.max_reads_per_partition > 0:

@@ -310,9 +310,15 @@ class RegionProcessor:
   def realign_tables(self, tables: Sequence, regions: Sequence[T.Range]) -> List:
     """`realign_table` for a batch of calling regions: the realigner's assembly and alignment
     work of all of them goes through one native, threaded call (Realigner.realign_tables)."""
+    return self.start_realign_tables(tables, regions)()
+
+  def start_realign_tables(self, tables: Sequence, regions: Sequence[T.Range], executor=None):
+    """-> a callable that returns the realigned tables.  The regions' windows are selected now;
+    with an `executor` the native call is already running on one of its threads when this
+    returns (Realigner.start_realign_tables)."""
     tables = list(tables)
     if self.realigner is None:
-      return tables
+      return lambda: tables
     limit = self.processor_options.max_read_length_to_realign
     long_parts = [None] * len(tables)
     short = tables
@@ -325,8 +331,12 @@ class RegionProcessor:
           long_parts[k] = table.take(long_rows)
           table = table.take(np.nonzero(lengths <= limit)[0])
         short.append(table)
-    out = [t for _, t in self.realigner.realign_tables(short, regions, want_haplotypes=False)]
-    return [t if lp is None else packing.concat_tables([lp, t]) for lp, t in zip(long_parts, out)]
+    job = self.realigner.start_realign_tables(short, regions, want_haplotypes=False, executor=executor)
+
+    def finish():
+      return [t if lp is None else packing.concat_tables([lp, t])
+              for lp, (_, t) in zip(long_parts, job.result())]
+    return finish
 
   def process_table(self, region: T.Range, table, realigned=None) -> Tuple[List[T.DeepVariantCall], 'packing.ReadTable']:
     """`realigned`: the region's table as `realign_tables` returned it (the runner realigns a

@@ -299,6 +299,110 @@ def split_reads(reads: Sequence) -> List:
   return out
 
 
+class RealignJob:
+  """One dv_realign_regions call over a batch of regions: arguments marshalled by `add`, the native
+  call in `start` (optionally on an executor thread), the write-back in `result`."""
+
+  def __init__(self, n_slots: int, want_haplotypes: bool, options: '_lib.DvRealignOptions'):
+    self.results: List = [None] * n_slots
+    self._want_haplotypes = want_haplotypes
+    self._options = options
+    self._jobs: List = []          # (slot, table, usable windows)
+    self._keep: List = []          # the arrays the region descriptors point into
+    self._future = None
+    self._output = None            # (handle, DvRealignOutput) once the native call has run
+
+  def add(self, slot: int, table: 'packing.ReadTable', usable: Sequence[T.Range], ref_reader, contig: str,
+          n_contig: int) -> None:
+    starts = np.ascontiguousarray(table.read_pos, np.int64)
+    ends = np.ascontiguousarray(table.read_end, np.int64)
+    w_lo = np.array([w.start for w in usable], np.int64)
+    w_hi = np.array([w.end for w in usable], np.int64)
+    ref_lo = max(0, min(int(starts.min()), int(w_lo.min())) - _REF_ALIGN_MARGIN)
+    ref_hi = min(n_contig, max(int(ends.max()), int(w_hi.max())) + _REF_ALIGN_MARGIN)
+    ref = ref_reader.get_bases(contig, ref_lo, ref_hi).encode()
+    bases = np.ascontiguousarray(table.bases, np.uint8)
+    quals = np.ascontiguousarray(table.quals, np.uint8)
+    seq_off = np.ascontiguousarray(table.read_seq_off, np.uint32)
+    mapq = np.ascontiguousarray(table.read_mapq, np.uint8)
+    self._jobs.append((slot, table, list(usable)))
+    self._keep.append((bases, quals, seq_off, mapq, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig))
+
+  def _call(self):
+    descs = (_lib.DvRealignRegion * len(self._jobs))()
+    for d, (slot, table, usable), k in zip(descs, self._jobs, self._keep):
+      bases, quals, seq_off, mapq, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig = k
+      d.bases, d.quals, d.n_bases = bases.ctypes.data, quals.ctypes.data, len(bases)
+      d.read_seq_off, d.read_mapq = seq_off.ctypes.data, mapq.ctypes.data
+      d.read_start, d.read_end = starts.ctypes.data, ends.ctypes.data
+      d.n_reads, d.n_windows = table.n_reads, len(usable)
+      d.window_start, d.window_end = w_lo.ctypes.data, w_hi.ctypes.data
+      d.ref, d.ref_start, d.ref_len, d.contig_len = ref, ref_lo, len(ref), n_contig
+    handle = C.c_void_p()
+    out = _lib.DvRealignOutput()
+    _lib.check(_lib.lib().dv_realign_regions(descs, len(self._jobs), C.byref(self._options), C.byref(handle),
+                                             C.byref(out)))
+    return handle, out
+
+  def start(self, executor=None) -> None:
+    if self._jobs and executor is not None:
+      self._future = executor.submit(self._call)
+
+  def result(self) -> List:
+    """-> [(candidate haplotypes per assembled window, realigned table)] per region of the batch."""
+    if not self._jobs:
+      return self.results
+    if self._output is None:
+      self._output = self._future.result() if self._future is not None else self._call()
+      self._future = None
+      self._write_back()
+    return self.results
+
+  def _write_back(self) -> None:
+    handle, out = self._output
+    jobs, results, want_haplotypes = self._jobs, self.results, self._want_haplotypes
+    try:
+      n_jobs = len(jobs)
+      row_off = np.ctypeslib.as_array(out.region_row_off, shape=(n_jobs + 1,))
+      total = int(row_off[-1])
+      view = lambda ptr, n, dtype: np.ctypeslib.as_array(ptr, shape=(n,)) if n else np.zeros(0, dtype)   # noqa: E731
+      order = view(out.order, total, np.int32)
+      status = view(out.status, total, np.int32)
+      position = view(out.position, total, np.int64)
+      cigar_off = np.ctypeslib.as_array(out.cigar_off, shape=(total + 1,))
+      words = view(out.cigar, int(cigar_off[-1]), np.uint32)
+      asm_off = np.ctypeslib.as_array(out.region_assembled_off, shape=(n_jobs + 1,))
+      n_asm = int(asm_off[-1])
+      asm_window = view(out.assembled_window, n_asm, np.int32)
+      hap_off = np.ctypeslib.as_array(out.assembled_hap_off, shape=(n_asm + 1,))
+      n_haps = int(hap_off[-1])
+      text_off = np.ctypeslib.as_array(out.hap_text_off, shape=(n_haps + 1,))
+      text = C.string_at(out.hap_text, int(text_off[-1])) if want_haplotypes and n_haps else b''
+      for g, (slot, table, usable) in enumerate(jobs):
+        a0, a1 = int(asm_off[g]), int(asm_off[g + 1])
+        if a0 == a1:                       # no window assembled: the table passes through as it is
+          results[slot] = ([], table)
+          continue
+        haplotypes = []
+        if want_haplotypes:
+          for a in range(a0, a1):
+            haps = [text[int(text_off[h]):int(text_off[h + 1])].decode() for h in range(int(hap_off[a]), int(hap_off[a + 1]))]
+            haplotypes.append(CandidateHaplotypes(span=usable[int(asm_window[a])], haplotypes=haps))
+        r0, r1 = int(row_off[g]), int(row_off[g + 1])
+        changed = np.nonzero(status[r0:r1] == 1)[0]
+        realigned = table
+        if len(changed):
+          c_off = cigar_off[r0:r1 + 1]
+          # the changed rows' words are consecutive runs of `words`; rows in between are empty
+          realigned = table.with_alignments_csr(
+              changed, position[r0:r1][changed],
+              np.concatenate([c_off[changed], c_off[changed[-1] + 1:changed[-1] + 2]]), words)
+        results[slot] = (haplotypes, realigned.take(order[r0:r1].astype(np.int64)))
+    finally:
+      _lib.lib().dv_realign_result_free(handle)
+      self._keep = []
+
+
 class Realigner:
   """Realigner(config, ref_reader) (:675-893).  `ref_reader`: n_bases(contig) /
   get_bases(contig, start, end), as everywhere in this package."""
@@ -412,93 +516,34 @@ class Realigner:
     Results per region are those of the region-by-region procedure (tests/test_table_path_cpu.py).
     Without `want_haplotypes` the CandidateHaplotypes lists come back empty (make_examples only
     uses the reads)."""
+    return self.start_realign_tables(tables, regions, want_haplotypes).result()
+
+  def start_realign_tables(self, tables: Sequence['packing.ReadTable'], regions: Sequence[T.Range],
+                           want_haplotypes: bool = True, executor=None) -> 'RealignJob':
+    """The same in two steps: the windows of every region are selected now (on the calling thread:
+    it launches on the device), the native call runs on `executor` (a concurrent.futures executor;
+    None = inside .result()), and `.result()` writes the alignments back.  A region driver starts
+    the next batch before it calls candidates and draws pileups for the current one, so the
+    assembly and alignment threads work while the main thread is busy elsewhere (the native call
+    holds no Python lock)."""
     if self.config.split_skip_reads:
       raise NotImplementedError('split_skip_reads works on Read objects (realign_reads)')
-    results: List = [None] * len(tables)
-    jobs = []        # (slot, table, region, usable windows, int64 starts / ends, window arrays, reference bytes)
+    job = RealignJob(len(tables), want_haplotypes, self._native_options())
     for slot, (table, region) in enumerate(zip(tables, regions)):
       n = table.n_reads
       if n == 0:
-        results[slot] = ([], table)
+        job.results[slot] = ([], table)
         continue
       windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, range(n), region, table=table)
       usable = [w for w in windows
                 if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
       if not usable:
-        results[slot] = ([], table)
+        job.results[slot] = ([], table)
         continue
-      starts = np.ascontiguousarray(table.read_pos, np.int64)
-      ends = np.ascontiguousarray(table.read_end, np.int64)
-      w_lo = np.array([w.start for w in usable], np.int64)
-      w_hi = np.array([w.end for w in usable], np.int64)
       contig = region.reference_name
-      n_contig = self.ref_reader.n_bases(contig)
-      ref_lo = max(0, min(int(starts.min()), int(w_lo.min())) - _REF_ALIGN_MARGIN)
-      ref_hi = min(n_contig, max(int(ends.max()), int(w_hi.max())) + _REF_ALIGN_MARGIN)
-      ref = self.ref_reader.get_bases(contig, ref_lo, ref_hi).encode()
-      jobs.append((slot, table, usable, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig))
-    if not jobs:
-      return results
-    descs = (_lib.DvRealignRegion * len(jobs))()
-    keep = []
-    for d, (slot, table, usable, starts, ends, w_lo, w_hi, ref, ref_lo, n_contig) in zip(descs, jobs):
-      bases = np.ascontiguousarray(table.bases, np.uint8)
-      quals = np.ascontiguousarray(table.quals, np.uint8)
-      seq_off = np.ascontiguousarray(table.read_seq_off, np.uint32)
-      mapq = np.ascontiguousarray(table.read_mapq, np.uint8)
-      keep.append((bases, quals, seq_off, mapq))
-      d.bases, d.quals, d.n_bases = bases.ctypes.data, quals.ctypes.data, len(bases)
-      d.read_seq_off, d.read_mapq = seq_off.ctypes.data, mapq.ctypes.data
-      d.read_start, d.read_end = starts.ctypes.data, ends.ctypes.data
-      d.n_reads, d.n_windows = table.n_reads, len(usable)
-      d.window_start, d.window_end = w_lo.ctypes.data, w_hi.ctypes.data
-      d.ref, d.ref_start, d.ref_len, d.contig_len = ref, ref_lo, len(ref), n_contig
-    opt = self._native_options()
-    handle = C.c_void_p()
-    out = _lib.DvRealignOutput()
-    lib = _lib.lib()
-    _lib.check(lib.dv_realign_regions(descs, len(jobs), C.byref(opt), C.byref(handle), C.byref(out)))
-    try:
-      n_jobs = len(jobs)
-      row_off = np.ctypeslib.as_array(out.region_row_off, shape=(n_jobs + 1,))
-      total = int(row_off[-1])
-      view = lambda ptr, n, dtype: np.ctypeslib.as_array(ptr, shape=(n,)) if n else np.zeros(0, dtype)   # noqa: E731
-      order = view(out.order, total, np.int32)
-      status = view(out.status, total, np.int32)
-      position = view(out.position, total, np.int64)
-      cigar_off = np.ctypeslib.as_array(out.cigar_off, shape=(total + 1,))
-      words = view(out.cigar, int(cigar_off[-1]), np.uint32)
-      asm_off = np.ctypeslib.as_array(out.region_assembled_off, shape=(n_jobs + 1,))
-      n_asm = int(asm_off[-1])
-      asm_window = view(out.assembled_window, n_asm, np.int32)
-      hap_off = np.ctypeslib.as_array(out.assembled_hap_off, shape=(n_asm + 1,))
-      n_haps = int(hap_off[-1])
-      text_off = np.ctypeslib.as_array(out.hap_text_off, shape=(n_haps + 1,))
-      text = C.string_at(out.hap_text, int(text_off[-1])) if want_haplotypes and n_haps else b''
-      for g, (slot, table, usable, *_rest) in enumerate(jobs):
-        a0, a1 = int(asm_off[g]), int(asm_off[g + 1])
-        if a0 == a1:                       # no window assembled: the table passes through as it is
-          results[slot] = ([], table)
-          continue
-        haplotypes = []
-        if want_haplotypes:
-          for a in range(a0, a1):
-            haps = [text[int(text_off[h]):int(text_off[h + 1])].decode() for h in range(int(hap_off[a]), int(hap_off[a + 1]))]
-            haplotypes.append(CandidateHaplotypes(span=usable[int(asm_window[a])], haplotypes=haps))
-        r0, r1 = int(row_off[g]), int(row_off[g + 1])
-        changed = np.nonzero(status[r0:r1] == 1)[0]
-        realigned = table
-        if len(changed):
-          c_off = cigar_off[r0:r1 + 1]
-          # the changed rows' words are consecutive runs of `words`; rows in between are empty
-          realigned = table.with_alignments_csr(
-              changed, position[r0:r1][changed],
-              np.concatenate([c_off[changed], c_off[changed[-1] + 1:changed[-1] + 2]]), words)
-        results[slot] = (haplotypes, realigned.take(order[r0:r1].astype(np.int64)))
-    finally:
-      lib.dv_realign_result_free(handle)
-    del keep
-    return results
+      job.add(slot, table, usable, self.ref_reader, contig, self.ref_reader.n_bases(contig))
+    job.start(executor)
+    return job
 
   def align_to_haplotype(self, this_haplotype: str, haplotypes: Sequence[str], prefix: str, suffix: str,
                          reads: Sequence, contig: str, ref_start: int) -> List:

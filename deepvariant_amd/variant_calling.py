@@ -93,8 +93,13 @@ def _simplify_ref_alt(ref: str, alt: str) -> str:
   return '%s->%s' % (ref[:len(ref) - n], alt[:len(alt) - n])
 
 
-def _worth_looking_at(allele_counter):
-  """The AlleleCounts a caller has to visit: without read alleles there is no alternate allele."""
+def _worth_looking_at(allele_counter, min_count: int = 0):
+  """The AlleleCounts a caller has to visit: without read alleles there is no alternate allele,
+  and with fewer than `min_count` reads carrying one no allele reaches the caller's count
+  threshold (the device counter answers both from its event arrays)."""
+  narrowed = getattr(allele_counter, 'counts_with_alt_support', None)
+  if narrowed is not None and min_count > 1:
+    return narrowed(min_count)
   sparse = getattr(allele_counter, 'counts_with_read_alleles', None)
   return sparse() if sparse is not None else allele_counter.counts()
 
@@ -155,11 +160,14 @@ class VariantCaller:
         out.append(call)
     return out
 
+  def _least_allele_count(self) -> int:
+    return min(self._options.min_count_snps, self._options.min_count_indels)
+
   def calls_from_allele_counter(self, allele_counter) -> List[T.DeepVariantCall]:
-    return self.calls_from_allele_counts(_worth_looking_at(allele_counter))
+    return self.calls_from_allele_counts(_worth_looking_at(allele_counter, self._least_allele_count()))
 
   def call_positions_from_allele_counter(self, allele_counter) -> List[int]:
-    return self.call_positions_from_allele_counts(_worth_looking_at(allele_counter))
+    return self.call_positions_from_allele_counts(_worth_looking_at(allele_counter, self._least_allele_count()))
 
   def call_positions_from_allele_counts(self, allele_counts: Sequence) -> List[int]:
     """CallPositionsFromAlleleCounts / CallVariantPosition (variant_calling_multisample.cc:940-1004):

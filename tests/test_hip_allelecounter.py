@@ -262,3 +262,49 @@ def test_window_counts_from_events_equal_the_allele_walk(seed, long_reads):
       assert fast == slow, support
       assert support > 1 or sum(slow) > 0
     assert counter.variant_read_window_counts(2, True) is None      # the strict filter needs allele totals
+
+
+@pytest.mark.parametrize('seed,long_reads,track', [(31, False, False), (32, True, False), (33, False, True)])
+def test_narrowed_visit_gives_the_same_candidates(seed, long_reads, track):
+  """VariantCaller on AlleleCounter.counts_with_alt_support (the positions where enough reads carry
+  a good non-reference allele for ANY allele to reach the caller's count threshold, taken from the
+  event arrays) against the caller on every position with read alleles: same calls, same allele
+  support, on the fuzz reads (duplicate keys, low-quality alleles, soft clips, tracked reference reads)."""
+  from deepvariant_amd import variant_calling as V
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000))
+  ref = _Ref(seq)
+
+  class _Unnarrowed:
+    def __init__(self, counter):
+      self._c = counter
+    def __getattr__(self, name):
+      if name == 'counts_with_alt_support':
+        raise AttributeError(name)
+      return getattr(self._c, name)
+
+  n_calls = 0
+  for (start, end), (lo, hi) in (((1000, 2000), (700, 2100)), ((0, 400), (0, 420)), ((5600, 6000), (5300, 5990))):
+    reads = _fuzz_reads(rng, ref, 700 if not long_reads else 200, lo, hi, long_reads)
+    reads += reads[:40]
+    for min_snps, min_indels in ((2, 2), (3, 2), (2, 4)):
+      caller = V.VariantCaller(V.VariantCallerOptions(min_snps, min_indels, 0.12, 0.06, sample_name='s', track_ref_reads=track))
+
+      def counter_for(positions=()):
+        c = A.AlleleCounter(ref, 'c', start, end, candidate_positions=positions, min_mapping_quality=10,
+                            min_base_quality=20, track_ref_reads=track)
+        for r in reads:
+          c.add(r)
+        return c
+
+      positions = caller.call_positions_from_allele_counter(counter_for())
+      assert positions == caller.call_positions_from_allele_counter(_Unnarrowed(counter_for()))
+      marked = positions if track else ()
+      fast = caller.calls_from_allele_counter(counter_for(marked))
+      slow = caller.calls_from_allele_counter(_Unnarrowed(counter_for(marked)))
+      assert fast == slow                    # dataclasses: variant, allele_support, *_ext, field by field
+      assert [c.variant.start for c in fast] == positions
+      narrowed = counter_for().counts_with_alt_support(min(min_snps, min_indels))
+      assert len(narrowed) < len(counter_for().counts_with_read_alleles())
+      n_calls += len(fast)
+  assert n_calls > 30

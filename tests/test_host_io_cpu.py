@@ -145,3 +145,33 @@ def test_sharded_output_name_detection():
   assert cv.is_sharded_filename('cvo-3-of-16')
   assert not cv.is_sharded_filename('/x/cvo.tfrecord.gz')
   assert not cv.is_sharded_filename('/x/cvo-00000-of-00000.tfrecord.gz')
+
+
+def test_fasta_reader_indexed_and_whole_file_forms_agree(tmp_path):
+  """FastaReader on a plain file with a .fai (mapped, read on demand), without one and on gzip
+  (parsed once): same contig order, lengths and bases for queries that cross line ends, run past
+  the contig end or are empty; lower case is upper-cased, header descriptions and CR LF are ignored."""
+  import os
+  from deepvariant_amd import genomics_io as G
+  rng = np.random.default_rng(1)
+  c1 = 'N' * 1000 + ''.join('acgtN'[i] for i in rng.integers(0, 5, size=12345))
+  c2 = ''.join('ACGT'[i] for i in rng.integers(0, 4, size=120))
+  for suffix in ('', '.gz'):
+    for index in (False, True):
+      path = os.path.join(str(tmp_path), 'r%d.fa%s' % (index, suffix))
+      G.write_fasta(path, [('chrA', c1), ('chrB', c2)], index=index)
+      r = G.FastaReader(path)
+      assert (r._map is not None) == (index and not suffix)          # pylint: disable=protected-access
+      assert r.contig_names() == ['chrA', 'chrB']
+      assert r.n_bases('chrA') == len(c1) and r.n_bases('chrB') == 120
+      for a, b in ((0, 10), (990, 1100), (59, 61), (60, 120), (0, len(c1)), (13000, 14000), (len(c1) - 1, len(c1) + 5),
+                   (500, 500)):
+        assert r.get_bases('chrA', a, b) == c1.upper()[a:b], (suffix, index, a, b)
+      assert r.get_bases('chrB', 0, 120) == c2 and r.get_bases('chrB', 100, 500) == c2[100:]
+      with pytest.raises(KeyError):
+        r.n_bases('chrZ')
+  path = os.path.join(str(tmp_path), 'x.fa')
+  with open(path, 'wb') as f:
+    f.write(b'>c1 some description\r\nacgt\r\nNN\r\n>c2\nTT\n')
+  r = G.FastaReader(path)
+  assert r.contig_names() == ['c1', 'c2'] and r.get_bases('c1', 0, 10) == 'ACGTNN' and r.get_bases('c2', 0, 5) == 'TT'
