@@ -551,14 +551,17 @@ def bam_mode(args, log=sys.stderr):
       mp.spawn(_bam_rank, args=(args.procs, port, tmp, bam, fasta), nprocs=args.procs, join=True)
     return
   stage = {}
+  setup = {}            # the model's set-up runs on a worker thread, beside the region loop
 
-  def timed(label, fn):
+  def timed(label, fn, store=None):
+    store = stage if store is None else store
+
     def wrapper(*a, **k):
       t0 = time.perf_counter()
       try:
         return fn(*a, **k)
       finally:
-        stage[label] = stage.get(label, 0.0) + time.perf_counter() - t0
+        store[label] = store.get(label, 0.0) + time.perf_counter() - t0
     return wrapper
 
   class Hooks(me.RunnerHooks):
@@ -587,6 +590,11 @@ def bam_mode(args, log=sys.stderr):
     me.RegionReads.__call__ = timed('BAM decode (native) + reads of the region', me.RegionReads.__call__)
     me.RegionReads.table = timed('BAM decode (native) + rows of the region', me.RegionReads.table)
     tfrecord.Writer.write = timed('TFRecord(GZIP) write', tfrecord.Writer.write)
+    from deepvariant_amd import call_variants as cv_mod
+    from deepvariant_amd.inception_v3 import InceptionV3
+    InceptionV3.__init__ = timed('dv_model_create (activations for max_batch examples)', InceptionV3.__init__, setup)
+    InceptionV3.load_flat_weights = timed('dv_model_load_weights (BN fold, fp16 pack, upload)', InceptionV3.load_flat_weights, setup)
+    cv_mod.load_flat_checkpoint = timed('checkpoint read + load', cv_mod.load_flat_checkpoint, setup)
     weights = os.path.join(tmp, 'weights.f32')
 
     class WarmHooks(Hooks):
@@ -598,6 +606,7 @@ def bam_mode(args, log=sys.stderr):
     warm = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm.cvo.tfrecord.gz')
     me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=WarmHooks())     # kernels loaded, graphs captured
     stage.clear()
+    setup.clear()
     timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'cvo.tfrecord.gz')
     timed_args.checkpoint = weights
     t0 = time.perf_counter()
@@ -621,7 +630,7 @@ def bam_mode(args, log=sys.stderr):
         f.write(text.getvalue())
     # the same run once more with a HIP event pair around every kernel launch (eager launches):
     # how long the GPU computes for this slice, against the wall time of the timed run
-    timed_stage = dict(stage)
+    timed_stage, timed_setup = dict(stage), dict(setup)
     from deepvariant_amd import _lib
     lib = _lib.lib()
     lib.dv_set_profiling(1)
@@ -646,6 +655,7 @@ def bam_mode(args, log=sys.stderr):
       'examples': stats['n_examples'], 'table_path': stats.get('table_path'),
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
       'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
+      'model_setup_ms_on_worker_thread': {k: 1e3 * v for k, v in timed_setup.items()},
       'gpu_kernel_ms': kernel_ms, 'gpu_busy_frac': sum(kernel_ms.values()) / (1e3 * elapsed),
       'host_cores': os.cpu_count(), 'realigner_threads': os.environ.get('DV_REALIGN_THREADS', 'auto (<= 16)'),
       'note': 'not the contract metric: inputs start in files on the host, one Python process drives the region loop '

@@ -457,8 +457,18 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   // not superseded, the deletion is added after it); read offsets order them as the CIGAR
   // does, so the consumer's "later entry overwrites" matches read_alleles[key] = allele.
   // LSD radix sort on (position << 32 | read), 16 bits a pass, then the rare ties by offset.
-  {
-    const size_t n_ev = ctr[0];
+  const size_t n_ev = ctr[0];
+  if (n_ev < (1u << 15)) {
+    // a calling region's few hundred events: a comparison sort on (position, read, read_offset);
+    // the radix passes below cost 65536-entry histograms each, more than the whole launch
+    res->events.assign(res->raw.ptr, res->raw.ptr + n_ev);
+    std::stable_sort(res->events.begin(), res->events.end(), [](const dv_allele_event& x, const dv_allele_event& y) {
+      if (x.position != y.position) return static_cast<uint32_t>(x.position) < static_cast<uint32_t>(y.position);
+      if (x.read != y.read) return x.read < y.read;
+      return x.read_offset < y.read_offset;
+    });
+    res->raw.release();
+  } else {
     std::vector<uint64_t> key(n_ev), key2(n_ev);
     std::vector<uint32_t> idx(n_ev), idx2(n_ev);
     uint64_t all = 0;
@@ -467,9 +477,10 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
       idx[i] = static_cast<uint32_t>(i);
       all |= key[i];
     }
+    std::vector<size_t> count(65537);
     for (int shift = 0; shift < 64; shift += 16) {
       if (((all >> shift) & 0xffffu) == 0) continue;      // these 16 bits are zero everywhere
-      size_t count[65537] = {0};
+      std::fill(count.begin(), count.end(), size_t{0});
       for (size_t i = 0; i < n_ev; ++i) ++count[((key[i] >> shift) & 0xffffu) + 1];
       for (int c = 0; c < 65536; ++c) count[c + 1] += count[c];
       for (size_t i = 0; i < n_ev; ++i) {
@@ -486,8 +497,8 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
       size_t j = i + 1;
       while (j < n_ev && key[j] == key[i]) ++j;
       if (j - i > 1) {
-        std::sort(res->events.begin() + i, res->events.begin() + j,
-                  [](const dv_allele_event& x, const dv_allele_event& y) { return x.read_offset < y.read_offset; });
+        std::stable_sort(res->events.begin() + i, res->events.begin() + j,
+                         [](const dv_allele_event& x, const dv_allele_event& y) { return x.read_offset < y.read_offset; });
       }
       i = j;
     }

@@ -28,10 +28,12 @@
 //   maxpool3s2_kernel / avgpool3s1_kernel   (avg excludes padding, optional shift + ReLU)
 //   head_kernel               global average pool + Dense(3) + softmax in fp32
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <type_traits>
 
 #include <hip/hip_fp16.h>
@@ -2736,9 +2738,21 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
   DV_HIP_CHECK(hipSetDevice(m->device));
   std::vector<_Float16> packed(m->packed_halfs, static_cast<_Float16>(0.f));
   std::vector<float> shift(m->shift_floats, 0.f);
-  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
-    const Op& op = m->ops[oi];
+  for (const Op& op : m->ops) {
     if (op.type != kOpConv) continue;
+    const LayerInfo& l = m->layers[op.layer];
+    const float* var = weights + l.param_off + static_cast<size_t>(l.kh) * l.kw * l.cin * l.cout + 2 * l.cout;
+    for (int co = 0; co < l.cout; ++co) {
+      if (!(var[co] + 1e-3f > 0.f)) return dv::fail(DV_ERR_BAD_INPUT, "non-positive BatchNorm variance");
+    }
+  }
+  // One conv layer's weights -> its fragment image.  Layers write disjoint parts of `packed` and
+  // `shift` (the siblings of a grouped launch share a region but own different cout rows), so
+  // they are packed on a few host threads: the 22 M weights are read with a stride of cout and
+  // one thread needs 0.2-0.3 s for them -- as long as a 100 kb make_examples run takes.
+  auto pack_op = [&](size_t oi) {
+    const Op& op = m->ops[oi];
+    if (op.type != kOpConv) return;
     const LayerInfo& l = m->layers[op.layer];
     const float* w = weights + l.param_off;  // HWIO
     const size_t wn = static_cast<size_t>(l.kh) * l.kw * l.cin * l.cout;
@@ -2747,9 +2761,6 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
     const float* var = mean + l.cout;
     std::vector<float> inv(l.cout);
     for (int co = 0; co < l.cout; ++co) {
-      if (!(var[co] + 1e-3f > 0.f)) {
-        return dv::fail(DV_ERR_BAD_INPUT, "non-positive BatchNorm variance");
-      }
       inv[co] = 1.0f / std::sqrt(var[co] + 1e-3f);
       shift[op.shift_off + co] = beta[co] - mean[co] * inv[co];
     }
@@ -2759,7 +2770,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
       if (oi == 1) dv::pack_stem_a_w2(w, inv.data(), dst);
       if (oi == 2) dv::pack_stem_b_w3(w, inv.data(), dst);
       if (oi == 3) dv::pack_stem_b_w4(w, inv.data(), l.cout, dst);
-      continue;
+      return;
     }
     if (op.first_u8) {
       // C <= 8:  [chunk kc][k-group g = tap 2kc+g][cout][8]: channel c < cin_real, else zero
@@ -2777,7 +2788,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
                   static_cast<_Float16>(v * inv[co]);
             }
         }
-      continue;
+      return;
     }
     if (op.chain_len > 0 || op.in_chain) {
       // chain.hip: [channel chunk][tap][k-group][cout_pad][8]
@@ -2794,7 +2805,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
                   static_cast<_Float16>(v * inv[co]);
             }
         }
-      continue;
+      return;
     }
     // Row of this op's cout `co` in the launch's concatenated cout space: the siblings
     // grouped before it (leader first) each occupy whole 32-cout subtiles.
@@ -2840,7 +2851,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
             }
           }
         }
-        continue;
+        return;
       }
     }
     // row-band mode: one image per output row `band_r`, holding the op.band tap rows
@@ -2873,6 +2884,17 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         }
       }
     }
+  };
+  {
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (size_t oi = next.fetch_add(1); oi < m->ops.size(); oi = next.fetch_add(1)) pack_op(oi);
+    };
+    const unsigned helpers = std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1);
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < helpers; ++t) threads.emplace_back(work);
+    work();
+    for (std::thread& t : threads) t.join();
   }
   const LayerInfo& dl = m->layers.back();
   const float* dw = weights + dl.param_off;

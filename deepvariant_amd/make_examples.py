@@ -477,7 +477,7 @@ class RunnerHooks:
              len(options.pic_options.channels))
     # activations are allocated for max_batch examples (6 MB each); R processes sharing a GPU
     # each own a model, and a 1 kb region rarely yields more than a few dozen examples
-    model = InceptionV3(shape, max_batch=1024 if args.ranks_per_gpu == 1 else 256, device=args.device)
+    model = InceptionV3(shape, max_batch=512 if args.ranks_per_gpu == 1 else 256, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
     return model
 
