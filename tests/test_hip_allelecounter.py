@@ -307,4 +307,4 @@ def test_narrowed_visit_gives_the_same_candidates(seed, long_reads, track):
       narrowed = counter_for().counts_with_alt_support(min(min_snps, min_indels))
       assert len(narrowed) < len(counter_for().counts_with_read_alleles())
       n_calls += len(fast)
-  assert n_calls > 30 or long_reads      # (random long reads rarely agree on an allele: the equalities above are the test)
+  assert n_calls > 20 or long_reads      # (random long reads rarely agree on an allele: the equalities above are the test)
