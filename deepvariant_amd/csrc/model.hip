@@ -1395,10 +1395,6 @@ struct dv_model {
   };
   std::vector<GraphEntry> graphs;  // captured forwards, see dv_model_infer
   int64_t graph_captures = 0, graph_replays = 0;
-  // DV_POOL_STREAM=1: the average pools of the pooled projections run on a second stream, forked
-  // behind the heads launch that produces their input and joined where they stood (run_ops)
-  hipStream_t pool_stream = nullptr;
-  std::vector<hipEvent_t> pool_fork, pool_done;   // per op
 
   // ---- builder ------------------------------------------------------------
   int new_buffer(int h, int w, int c) {
@@ -2185,68 +2181,9 @@ bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
 int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
             int shifted_buf = -1, int out_example_off = 0, size_t images_off = 0) {
   std::vector<char> side_pooled(m->ops.size(), 0);   // max-pools a convolution of this pass has taken on the side
-  // pools: one launch each (max-pool 3x3 / 2 'valid', average pool 3x3 / 1 'same' with optional shift + ReLU)
-  auto launch_pool = [&](const Op& op, hipStream_t s, size_t out_shift_halfs) {
-    const BufferDesc& ob = m->buffers[op.out_buf];
-    PoolArgs p{};
-    p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
-    p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
-    p.ig = m->buffers[op.in_buf].geom();
-    p.og = ob.geom();
-    p.N = n;
-    p.C = op.cin;
-    p.OH = op.oh;
-    p.OW = op.ow;
-    p.out_goff = op.out_coff / 8;
-    p.shift = op.pool_shift_relu
-                  ? static_cast<const float*>(m->d_shift.ptr) + op.shift_off
-                  : nullptr;
-    const size_t total = static_cast<size_t>(n) * op.oh *
-                         (op.type == kOpAvgPool ? (op.ow + 1) / 2 : op.ow) * (op.cin / 8);
-    const dim3 grid(static_cast<unsigned>((total + 255) / 256));
-    TraceScope tr(s, std::string(op.type == kOpMaxPool ? "maxpool3s2 " : "avgpool3s1 ") +
-                         std::to_string(op.cin) + " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow),
-                  0.0, 2.0 * n * op.cin * (static_cast<double>(op.ih) * op.iw + op.oh * op.ow));
-    dv::ProfileScope prof(dv::kProfOther, s);
-    if (op.type == kOpMaxPool) {
-      hipLaunchKernelGGL(maxpool3s2_kernel, grid, dim3(256), 0, s, p);
-    } else {
-      hipLaunchKernelGGL(avgpool3s1_kernel, grid, dim3(256), 0, s, p);
-    }
-  };
-  // DV_POOL_STREAM=1: an average pool whose input is complete (its producer, the block's heads launch,
-  // is queued) and that stands later in the list is started now on the pool stream; the main stream
-  // waits for it where it stood.  Its neighbours in between (the block's chains) touch neither its
-  // input nor its slice of the concat buffer.
-  std::vector<char> forked(m->ops.size(), 0);
-  std::vector<int> producer(m->ops.size(), -1);
-  const bool fork_pools = m->pool_stream != nullptr && stream != nullptr;
-  if (fork_pools) {
-    for (int j = first; j < last; ++j) {
-      if (m->ops[j].type != kOpAvgPool) continue;
-      for (int i = j - 1; i >= first; --i) {
-        if (m->ops[i].type == kOpConv && m->ops[i].out_buf == m->ops[j].in_buf) {
-          producer[j] = i;
-          break;
-        }
-      }
-    }
-  }
   for (int oi = first; oi < last; ++oi) {
     const Op& op = m->ops[oi];
     if (side_pooled[oi]) continue;
-    if (fork_pools) {
-      for (int j = oi + 1; j < last; ++j) {
-        if (forked[j] || producer[j] < 0 || producer[j] >= oi) continue;
-        // every op before `oi` is queued (the loop steps over the followers of a grouped launch, so a
-        // producer that is one of them is behind us only once its launch is)
-        DV_HIP_CHECK(hipEventRecord(m->pool_fork[j], stream));
-        DV_HIP_CHECK(hipStreamWaitEvent(m->pool_stream, m->pool_fork[j], 0));
-        launch_pool(m->ops[j], m->pool_stream, 0);
-        DV_HIP_CHECK(hipEventRecord(m->pool_done[j], m->pool_stream));
-        forked[j] = 1;
-      }
-    }
     const BufferDesc& ob = m->buffers[op.out_buf];
     const size_t out_shift_halfs =
         op.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * ob.bytes_per_example() / 2
@@ -2595,11 +2532,31 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         default: launch_conv<4>(a, stream); break;
       }
     } else {
-      if (forked[oi]) {        // ran on the pool stream behind its producer: everything after this point waits for it
-        DV_HIP_CHECK(hipStreamWaitEvent(stream, m->pool_done[oi], 0));
-        continue;
+      PoolArgs p{};
+      p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
+      p.ig = m->buffers[op.in_buf].geom();
+      p.og = ob.geom();
+      p.N = n;
+      p.C = op.cin;
+      p.OH = op.oh;
+      p.OW = op.ow;
+      p.out_goff = op.out_coff / 8;
+      p.shift = op.pool_shift_relu
+                    ? static_cast<const float*>(m->d_shift.ptr) + op.shift_off
+                    : nullptr;
+      const size_t total = static_cast<size_t>(n) * op.oh *
+                           (op.type == kOpAvgPool ? (op.ow + 1) / 2 : op.ow) * (op.cin / 8);
+      const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+      TraceScope tr(stream, std::string(op.type == kOpMaxPool ? "maxpool3s2 " : "avgpool3s1 ") +
+                                std::to_string(op.cin) + " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow),
+                    0.0, 2.0 * n * op.cin * (static_cast<double>(op.ih) * op.iw + op.oh * op.ow));
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      if (op.type == kOpMaxPool) {
+        hipLaunchKernelGGL(maxpool3s2_kernel, grid, dim3(256), 0, stream, p);
+      } else {
+        hipLaunchKernelGGL(avgpool3s1_kernel, grid, dim3(256), 0, stream, p);
       }
-      launch_pool(op, stream, out_shift_halfs);
     }
   }
   DV_HIP_CHECK(hipGetLastError());
@@ -2669,16 +2626,6 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
   if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
   if (int rc = m->d_ext.reserve(sizeof(ExtPtrs))) return rc;
-  if (getenv("DV_POOL_STREAM") != nullptr && atoi(getenv("DV_POOL_STREAM")) != 0) {
-    DV_HIP_CHECK(hipStreamCreateWithFlags(&m->pool_stream, hipStreamNonBlocking));
-    m->pool_fork.assign(m->ops.size(), nullptr);
-    m->pool_done.assign(m->ops.size(), nullptr);
-    for (size_t i = 0; i < m->ops.size(); ++i) {
-      if (m->ops[i].type != kOpAvgPool) continue;
-      DV_HIP_CHECK(hipEventCreateWithFlags(&m->pool_fork[i], hipEventDisableTiming));
-      DV_HIP_CHECK(hipEventCreateWithFlags(&m->pool_done[i], hipEventDisableTiming));
-    }
-  }
   // opt-in: skip the stem work that only sees the zero rows below the pile-up;
   // needs the uint8 front end, a single-branch 3x3 80->192 and whole dwords per image
   if (getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0 &&
@@ -2705,9 +2652,6 @@ void dv_model_destroy(dv_model* m) {
   m->d_ext.release();
   m->d_blank_conv4.release();
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-  for (hipEvent_t e : m->pool_fork) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : m->pool_done) if (e) (void)hipEventDestroy(e);
-  if (m->pool_stream) (void)hipStreamDestroy(m->pool_stream);
   delete m;
 }
 
