@@ -580,9 +580,9 @@ def bam_mode(args, log=sys.stderr):
       proc.generator.encode_region_on_device = timed('pack + encode (device)', proc.generator.encode_region_on_device)
       proc.flush_queue = timed('classify (device, several regions per forward) + CallVariantsOutput protos',
                                proc.flush_queue)
-      if os.environ.get('DV_REGION_OBJECTS') is None:   # (nested inside candidates_in_region on the object path)
-        proc.variant_caller.calls_from_allele_counter = timed(
-            'allele counts (device) + candidate caller', proc.variant_caller.calls_from_allele_counter)
+      if os.environ.get('DV_REGION_OBJECTS') is None:   # the table path: a batch's counts in one device call
+        proc.process_tables = timed('allele counts (device, one call per batch of regions) + candidate caller',
+                                    proc.process_tables)
       return proc
 
   with tempfile.TemporaryDirectory() as tmp:

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     'dv_merge_cigar_op', 'dv_local_align', 'dv_local_align_many',
     'dv_debruijn_build', 'dv_debruijn_destroy', 'dv_debruijn_kmer_size', 'dv_debruijn_haplotypes',
     'dv_debruijn_graphviz', 'dv_realign_regions', 'dv_realign_result_free', 'dv_phase_reads',
-    'dv_count_alleles', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
+    'dv_count_alleles', 'dv_count_alleles_batch', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
 
 
@@ -327,6 +327,7 @@ def lib():
                                  C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int32]
     l.dv_count_alleles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.dv_count_alleles_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     l.dv_allele_counts_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     l.dv_allele_counts_free.argtypes = [C.c_void_p]
     l.dv_allele_counts_free.restype = None

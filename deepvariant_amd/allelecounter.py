@@ -187,7 +187,8 @@ class AlleleCounter:
             for c in counts[left_padding:len(counts) - right_padding]]
 
   # ---- the launch
-  def _run(self):
+  def _request(self):
+    """-> (packed batch, options struct, the objects they point into, (table, window, w0, interval_ref))."""
     table = self._table if self._table is not None else packing.ReadTable.from_reads(self._reads)
     n_contig = self._ref.n_bases(self._contig)
     # reference window: the reads interval plus room for the longest deletion anchored inside it
@@ -203,10 +204,12 @@ class AlleleCounter:
         self._candidate_positions.ctypes.data if len(self._candidate_positions) else None,
         len(self._candidate_positions))
     b, keep = packing.PackedBatch(table=table, width=3).to_ctypes()
-    handle = C.c_void_p()
+    return b, opt, keep, (table, window, w0, interval_ref)
+
+  def _take(self, handle, ctx) -> None:
+    """Copies the result out of a dv_allele_counts handle and frees it."""
+    table, window, w0, interval_ref = ctx
     lib = _lib.lib()
-    _lib.check(lib.dv_count_alleles(C.byref(b), C.byref(opt), C.byref(handle), None))
-    del keep
     try:
       refc = C.POINTER(C.c_int32)()
       events = C.POINTER(_lib.DvAlleleEvent)()
@@ -224,6 +227,33 @@ class AlleleCounter:
       self._alleles, self._counts, self._n_counted = None, None, int(n_counted.value)
     finally:
       lib.dv_allele_counts_free(handle)
+
+  def _run(self):
+    b, opt, keep, ctx = self._request()
+    handle = C.c_void_p()
+    _lib.check(_lib.lib().dv_count_alleles(C.byref(b), C.byref(opt), C.byref(handle), None))
+    del keep
+    self._take(handle, ctx)
+
+  @staticmethod
+  def run_batch(counters: Sequence['AlleleCounter']) -> None:
+    """Counts for several counters (a batch of calling regions, each with its reads added) in ONE
+    dv_count_alleles_batch call: one upload, kernels back to back, two synchronisations for the
+    whole batch.  Afterwards every counter answers as if it had counted alone."""
+    todo = [c for c in counters if c._events is None]      # pylint: disable=protected-access
+    if not todo:
+      return
+    if len(todo) == 1:
+      todo[0]._run()                                       # pylint: disable=protected-access
+      return
+    requests = [c._request() for c in todo]                # pylint: disable=protected-access
+    n = len(todo)
+    batches = (C.c_void_p * n)(*[C.addressof(r[0]) for r in requests])
+    options = (C.c_void_p * n)(*[C.addressof(r[1]) for r in requests])
+    handles = (C.c_void_p * n)()
+    _lib.check(_lib.lib().dv_count_alleles_batch(n, batches, options, handles, None))
+    for c, r, h in zip(todo, requests, handles):
+      c._take(C.c_void_p(h), r[3])                         # pylint: disable=protected-access
 
   def _build_alleles(self):
     if self._alleles is not None:

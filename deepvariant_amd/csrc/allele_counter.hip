@@ -64,6 +64,25 @@ struct PinnedArray {
   ~PinnedArray() { release(); }
 };
 
+// Grow-only pinned staging for the batch entry point (one per host thread and direction).
+struct PinnedBytes {
+  uint8_t* ptr = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return DV_OK;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 20);
+    if (hipHostMalloc(reinterpret_cast<void**>(&ptr), want, hipHostMallocDefault) != hipSuccess) {
+      ptr = nullptr;
+      return dv::fail(DV_ERR_OUT_OF_MEMORY, "hipHostMalloc (allele counter staging)");
+    }
+    cap = want;
+    return DV_OK;
+  }
+};
+
 struct dv_allele_counts {
   PinnedArray<int32_t> ref_count;
   PinnedArray<dv_allele_event> raw;      // as the kernel left them
@@ -318,19 +337,71 @@ int to_device(dv::DeviceBuffer& buf, const T* src, size_t count, int memory, con
   return DV_OK;
 }
 
-}  // namespace
+// Order: (position, read, read_offset).  One read can leave two alleles at one position when
+// a skipped allele sits between them (1I 4S 2D with an unusable soft clip: the insertion is
+// not superseded, the deletion is added after it); read offsets order them as the CIGAR
+// does, so the consumer's "later entry overwrites" matches read_alleles[key] = allele.
+// Large lists: LSD radix sort on (position << 32 | read), 16 bits a pass, then the rare ties by offset.
+void order_events(dv_allele_counts* res, size_t n_ev) {
+  if (n_ev < (1u << 15)) {
+    // a calling region's few hundred events: a comparison sort on (position, read, read_offset);
+    // the radix passes below cost 65536-entry histograms each, more than the whole launch
+    res->events.assign(res->raw.ptr, res->raw.ptr + n_ev);
+    std::stable_sort(res->events.begin(), res->events.end(), [](const dv_allele_event& x, const dv_allele_event& y) {
+      if (x.position != y.position) return static_cast<uint32_t>(x.position) < static_cast<uint32_t>(y.position);
+      if (x.read != y.read) return x.read < y.read;
+      return x.read_offset < y.read_offset;
+    });
+    res->raw.release();
+  } else {
+    std::vector<uint64_t> key(n_ev), key2(n_ev);
+    std::vector<uint32_t> idx(n_ev), idx2(n_ev);
+    uint64_t all = 0;
+    for (size_t i = 0; i < n_ev; ++i) {
+      key[i] = (static_cast<uint64_t>(static_cast<uint32_t>(res->raw.ptr[i].position)) << 32) | res->raw.ptr[i].read;
+      idx[i] = static_cast<uint32_t>(i);
+      all |= key[i];
+    }
+    std::vector<size_t> count(65537);
+    for (int shift = 0; shift < 64; shift += 16) {
+      if (((all >> shift) & 0xffffu) == 0) continue;      // these 16 bits are zero everywhere
+      std::fill(count.begin(), count.end(), size_t{0});
+      for (size_t i = 0; i < n_ev; ++i) ++count[((key[i] >> shift) & 0xffffu) + 1];
+      for (int c = 0; c < 65536; ++c) count[c + 1] += count[c];
+      for (size_t i = 0; i < n_ev; ++i) {
+        const size_t d = count[(key[i] >> shift) & 0xffffu]++;
+        key2[d] = key[i];
+        idx2[d] = idx[i];
+      }
+      key.swap(key2);
+      idx.swap(idx2);
+    }
+    res->events.resize(n_ev);
+    for (size_t i = 0; i < n_ev; ++i) res->events[i] = res->raw.ptr[idx[i]];
+    for (size_t i = 0; i + 1 < n_ev;) {
+      size_t j = i + 1;
+      while (j < n_ev && key[j] == key[i]) ++j;
+      if (j - i > 1) {
+        std::stable_sort(res->events.begin() + i, res->events.begin() + j,
+                         [](const dv_allele_event& x, const dv_allele_event& y) { return x.read_offset < y.read_offset; });
+      }
+      i = j;
+    }
+    res->raw.release();
+  }
+}
 
-extern "C" {
-
-int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_allele_counts** out, void* stream_v) {
-  if (!b || !o || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: null");
+// Argument and read-table checks shared by the one-region and the batch entry point.
+int check_request(const dv_batch* b, const dv_allele_counter_options* o, dv_allele_counts** out, const char* who) {
+  const std::string name(who);
+  if (!b || !o || !out) return dv::fail(DV_ERR_INVALID_ARGUMENT, name + ": null");
   if (b->n_reads < 0 || o->interval_end < o->interval_start || !o->ref_bases || o->n_ref_bases <= 0 ||
       o->min_base_quality < 0 || o->min_mapping_quality < 0) {
-    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: bad argument");
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, name + ": bad argument");
   }
   if (b->n_reads && (!b->read_pos || !b->read_seq_off || !b->read_cigar_off || !b->read_mapq || !b->bases ||
                      !b->quals || !b->cigar)) {
-    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: read table field missing");
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, name + ": read table field missing");
   }
   if (b->memory == DV_MEM_HOST) {
     // the same read-table checks dv_validate_batch applies (a device-resident table is the
@@ -354,12 +425,23 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   const int64_t reads_start = std::min(o->interval_start, o->reads_interval_start);
   const int64_t reads_end = std::max(o->interval_end, o->reads_interval_end);
   if (o->ref_start > reads_start || o->ref_start + o->n_ref_bases < reads_end) {
-    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles: the reference window must cover the reads interval");
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, name + ": the reference window must cover the reads interval");
   }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
-    return dv::fail(DV_ERR_NO_DEVICE, "dv_count_alleles: no HIP device (there is no CPU fallback)");
+    return dv::fail(DV_ERR_NO_DEVICE, name + ": no HIP device (there is no CPU fallback)");
   }
+  return DV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_allele_counts** out, void* stream_v) {
+  if (int rc = check_request(b, o, out, "dv_count_alleles")) return rc;
+  const int64_t reads_start = std::min(o->interval_start, o->reads_interval_start);
+  const int64_t reads_end = std::max(o->interval_end, o->reads_interval_end);
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const int64_t len = o->interval_end - o->interval_start;
   auto res = std::make_unique<dv_allele_counts>();
@@ -452,59 +534,206 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
                                 hipMemcpyDeviceToHost, stream));
   }
   DV_HIP_CHECK(hipStreamSynchronize(stream));
-  // Order: (position, read, read_offset).  One read can leave two alleles at one position when
-  // a skipped allele sits between them (1I 4S 2D with an unusable soft clip: the insertion is
-  // not superseded, the deletion is added after it); read offsets order them as the CIGAR
-  // does, so the consumer's "later entry overwrites" matches read_alleles[key] = allele.
-  // LSD radix sort on (position << 32 | read), 16 bits a pass, then the rare ties by offset.
-  const size_t n_ev = ctr[0];
-  if (n_ev < (1u << 15)) {
-    // a calling region's few hundred events: a comparison sort on (position, read, read_offset);
-    // the radix passes below cost 65536-entry histograms each, more than the whole launch
-    res->events.assign(res->raw.ptr, res->raw.ptr + n_ev);
-    std::stable_sort(res->events.begin(), res->events.end(), [](const dv_allele_event& x, const dv_allele_event& y) {
-      if (x.position != y.position) return static_cast<uint32_t>(x.position) < static_cast<uint32_t>(y.position);
-      if (x.read != y.read) return x.read < y.read;
-      return x.read_offset < y.read_offset;
-    });
-    res->raw.release();
-  } else {
-    std::vector<uint64_t> key(n_ev), key2(n_ev);
-    std::vector<uint32_t> idx(n_ev), idx2(n_ev);
-    uint64_t all = 0;
-    for (size_t i = 0; i < n_ev; ++i) {
-      key[i] = (static_cast<uint64_t>(static_cast<uint32_t>(res->raw.ptr[i].position)) << 32) | res->raw.ptr[i].read;
-      idx[i] = static_cast<uint32_t>(i);
-      all |= key[i];
-    }
-    std::vector<size_t> count(65537);
-    for (int shift = 0; shift < 64; shift += 16) {
-      if (((all >> shift) & 0xffffu) == 0) continue;      // these 16 bits are zero everywhere
-      std::fill(count.begin(), count.end(), size_t{0});
-      for (size_t i = 0; i < n_ev; ++i) ++count[((key[i] >> shift) & 0xffffu) + 1];
-      for (int c = 0; c < 65536; ++c) count[c + 1] += count[c];
-      for (size_t i = 0; i < n_ev; ++i) {
-        const size_t d = count[(key[i] >> shift) & 0xffffu]++;
-        key2[d] = key[i];
-        idx2[d] = idx[i];
-      }
-      key.swap(key2);
-      idx.swap(idx2);
-    }
-    res->events.resize(n_ev);
-    for (size_t i = 0; i < n_ev; ++i) res->events[i] = res->raw.ptr[idx[i]];
-    for (size_t i = 0; i + 1 < n_ev;) {
-      size_t j = i + 1;
-      while (j < n_ev && key[j] == key[i]) ++j;
-      if (j - i > 1) {
-        std::stable_sort(res->events.begin() + i, res->events.begin() + j,
-                         [](const dv_allele_event& x, const dv_allele_event& y) { return x.read_offset < y.read_offset; });
-      }
-      i = j;
-    }
-    res->raw.release();
-  }
+  order_events(res.get(), ctr[0]);
   *out = res.release();
+  return DV_OK;
+}
+
+// Several regions in one go (a region driver's batch of 1 kb calling regions: window selection of
+// all of them, then their candidate counts).  What a one-region call spends is not the kernel (a few
+// microseconds) but ~10 small pageable uploads, two stream synchronisations and two small
+// downloads; here every region's arrays travel in ONE pinned staging image, the kernels are queued
+// back to back, and the stream is synchronised twice for the whole batch.  Results per region are
+// those of dv_count_alleles (the same kernel on the same arguments).  Regions whose tables are
+// device-resident, and the rare region whose events overflow the first guess, take the one-region path.
+int dv_count_alleles_batch(int32_t n, const dv_batch* const* reads, const dv_allele_counter_options* const* options,
+                           dv_allele_counts** out, void* stream_v) {
+  if (n < 0 || (n > 0 && (!reads || !options || !out))) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles_batch: null");
+  for (int32_t k = 0; k < n; ++k) out[k] = nullptr;
+  auto fail_all = [&](int rc) {
+    for (int32_t k = 0; k < n; ++k) {
+      delete out[k];
+      out[k] = nullptr;
+    }
+    return rc;
+  };
+  for (int32_t k = 0; k < n; ++k) {
+    if (int rc = check_request(reads[k], options[k], &out[k], "dv_count_alleles_batch")) return rc;
+    if (options[k]->track_ref_reads && options[k]->n_candidate_positions > 0 && !options[k]->candidate_positions) {
+      return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_count_alleles_batch: candidate_positions is null");
+    }
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  struct Plan {
+    bool batched = false;
+    size_t up[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // staging offsets: read_pos, seq_off, cigar_off, mapq, bases, quals, cigar, ref, mask
+    size_t cnt_off = 0, ev_off = 0;              // in ints / events
+    int64_t len = 0;
+    uint32_t cap = 0;
+    size_t mask_words = 0;
+  };
+  std::vector<Plan> plan(static_cast<size_t>(n));
+  auto align16 = [](size_t x) { return (x + 15) & ~static_cast<size_t>(15); };
+  size_t up_bytes = 0, cnt_ints = 0, ev_total = 0;
+  int n_batched = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    const dv_batch* b = reads[k];
+    const dv_allele_counter_options* o = options[k];
+    Plan& p = plan[k];
+    p.len = o->interval_end - o->interval_start;
+    if (b->n_reads == 0 || p.len == 0 || b->memory != DV_MEM_HOST) continue;     // one-region path below
+    p.batched = true;
+    ++n_batched;
+    const size_t nr = static_cast<size_t>(b->n_reads);
+    const size_t sizes[9] = {nr * 4, (nr + 1) * 4, (nr + 1) * 4, nr, b->n_bases, b->n_bases,
+                             static_cast<size_t>(b->n_cigar) * 4, static_cast<size_t>(o->n_ref_bases), 0};
+    for (int f = 0; f < 8; ++f) {
+      p.up[f] = up_bytes;
+      up_bytes += align16(std::max<size_t>(sizes[f], 1));
+    }
+    size_t n_candidate_refs = 0;
+    if (o->track_ref_reads && o->n_candidate_positions > 0) {
+      p.mask_words = static_cast<size_t>((p.len + 31) / 32);
+      p.up[8] = up_bytes;
+      up_bytes += align16(p.mask_words * 4);
+      n_candidate_refs = static_cast<size_t>(o->n_candidate_positions);
+    }
+    p.cnt_off = cnt_ints;
+    cnt_ints += static_cast<size_t>(p.len);
+    p.cap = b->n_cigar + b->n_bases / 16 + 4096 + static_cast<uint32_t>(std::min<size_t>(n_candidate_refs * 64, 1u << 24));
+    p.ev_off = ev_total;
+    ev_total += p.cap;
+  }
+  if (n_batched > 0) {
+    // grow-only scratch per host thread: pinned staging both ways, device images
+    static thread_local PinnedBytes h_up, h_down;
+    static thread_local dv::DeviceBuffer d_up, d_res, d_ev;
+    const size_t ctr_bytes = align16(static_cast<size_t>(n) * 4 * sizeof(uint32_t));
+    const size_t res_bytes = ctr_bytes + cnt_ints * sizeof(int32_t);
+    if (int rc = h_up.reserve(up_bytes)) return rc;
+    if (int rc = d_up.reserve(up_bytes)) return rc;
+    if (int rc = d_res.reserve(res_bytes)) return rc;
+    if (int rc = d_ev.reserve(std::max<size_t>(ev_total, 1) * sizeof(dv_allele_event))) return rc;
+    for (int32_t k = 0; k < n; ++k) {
+      const Plan& p = plan[k];
+      if (!p.batched) continue;
+      const dv_batch* b = reads[k];
+      const dv_allele_counter_options* o = options[k];
+      const size_t nr = static_cast<size_t>(b->n_reads);
+      uint8_t* base = h_up.ptr;
+      std::memcpy(base + p.up[0], b->read_pos, nr * 4);
+      std::memcpy(base + p.up[1], b->read_seq_off, (nr + 1) * 4);
+      std::memcpy(base + p.up[2], b->read_cigar_off, (nr + 1) * 4);
+      std::memcpy(base + p.up[3], b->read_mapq, nr);
+      std::memcpy(base + p.up[4], b->bases, b->n_bases);
+      std::memcpy(base + p.up[5], b->quals, b->n_bases);
+      std::memcpy(base + p.up[6], b->cigar, static_cast<size_t>(b->n_cigar) * 4);
+      std::memcpy(base + p.up[7], o->ref_bases, static_cast<size_t>(o->n_ref_bases));
+      if (p.mask_words) {
+        uint32_t* mask = reinterpret_cast<uint32_t*>(base + p.up[8]);
+        std::memset(mask, 0, p.mask_words * 4);
+        for (int32_t c = 0; c < o->n_candidate_positions; ++c) {
+          const int64_t q = o->candidate_positions[c] - o->interval_start;
+          if (q >= 0 && q < p.len) mask[static_cast<size_t>(q >> 5)] |= 1u << (q & 31);
+        }
+      }
+    }
+    DV_HIP_CHECK(hipMemcpyAsync(d_up.ptr, h_up.ptr, up_bytes, hipMemcpyHostToDevice, stream));
+    DV_HIP_CHECK(hipMemsetAsync(d_res.ptr, 0, res_bytes, stream));
+    uint8_t* dres = static_cast<uint8_t*>(d_res.ptr);
+    const uint8_t* dup = static_cast<const uint8_t*>(d_up.ptr);
+    for (int32_t k = 0; k < n; ++k) {
+      const Plan& p = plan[k];
+      if (!p.batched) continue;
+      const dv_batch* b = reads[k];
+      const dv_allele_counter_options* o = options[k];
+      CountArgs a{};
+      a.n_reads = b->n_reads;
+      a.read_pos = reinterpret_cast<const int32_t*>(dup + p.up[0]);
+      a.seq_off = reinterpret_cast<const uint32_t*>(dup + p.up[1]);
+      a.cigar_off = reinterpret_cast<const uint32_t*>(dup + p.up[2]);
+      a.mapq = dup + p.up[3];
+      a.bases = dup + p.up[4];
+      a.quals = dup + p.up[5];
+      a.cigar = reinterpret_cast<const uint32_t*>(dup + p.up[6]);
+      a.ref = dup + p.up[7];
+      a.ref_start = o->ref_start;
+      a.n_ref = o->n_ref_bases;
+      a.reads_start = std::min(o->interval_start, o->reads_interval_start);
+      a.reads_end = std::max(o->interval_end, o->reads_interval_end);
+      a.interval_start = o->interval_start;
+      a.interval_len = p.len;
+      a.contig_len = o->contig_n_bases > 0 ? o->contig_n_bases : o->ref_start + o->n_ref_bases;
+      a.min_mapq = o->min_mapping_quality;
+      a.min_bq = o->min_base_quality;
+      a.legacy = o->keep_legacy_behavior ? 1 : 0;
+      a.candidate_mask = p.mask_words ? reinterpret_cast<const uint32_t*>(dup + p.up[8]) : nullptr;
+      a.counters = reinterpret_cast<uint32_t*>(dres) + static_cast<size_t>(k) * 4;
+      a.ref_count = reinterpret_cast<int32_t*>(dres + ctr_bytes) + p.cnt_off;
+      a.events = static_cast<dv_allele_event*>(d_ev.ptr) + p.ev_off;
+      a.event_cap = p.cap;
+      dv::ProfileScope prof(dv::kProfOther, stream);
+      hipLaunchKernelGGL(count_alleles_kernel, dim3((b->n_reads + 4 * kReadsPerWave - 1) / (4 * kReadsPerWave)),
+                         dim3(256), 0, stream, a);
+    }
+    DV_HIP_CHECK(hipGetLastError());
+    // counters and counts come back together; the events follow once their numbers are known
+    if (int rc = h_down.reserve(res_bytes)) return rc;
+    DV_HIP_CHECK(hipMemcpyAsync(h_down.ptr, d_res.ptr, res_bytes, hipMemcpyDeviceToHost, stream));
+    DV_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t* ctrs = reinterpret_cast<const uint32_t*>(h_down.ptr);
+    const int32_t* cnts = reinterpret_cast<const int32_t*>(h_down.ptr + ctr_bytes);
+    size_t ev_bytes = 0;
+    for (int32_t k = 0; k < n; ++k) {
+      Plan& p = plan[k];
+      if (!p.batched) continue;
+      const uint32_t* ctr = ctrs + static_cast<size_t>(k) * 4;
+      if (ctr[2] != 0) {
+        return fail_all(dv::fail(DV_ERR_BAD_INPUT,
+                                 "dv_count_alleles: an indel reaches outside the reference window (pass more margin)"));
+      }
+      if (ctr[0] > p.cap) {          // the first guess was too small: this region goes alone (two passes there)
+        p.batched = false;
+        continue;
+      }
+      auto res = std::make_unique<dv_allele_counts>();
+      res->length = p.len;
+      res->n_reads_counted = static_cast<int32_t>(ctr[1]);
+      if (int rc = res->ref_count.reserve(static_cast<size_t>(p.len))) return fail_all(rc);
+      std::memcpy(res->ref_count.ptr, cnts + p.cnt_off, static_cast<size_t>(p.len) * sizeof(int32_t));
+      if (int rc = res->raw.reserve(ctr[0])) return fail_all(rc);
+      out[k] = res.release();
+      ev_bytes += static_cast<size_t>(ctr[0]) * sizeof(dv_allele_event);
+    }
+    // the events of every region into one pinned image, one synchronisation
+    static thread_local PinnedBytes h_ev;
+    if (int rc = h_ev.reserve(ev_bytes)) return fail_all(rc);
+    size_t at = 0;
+    for (int32_t k = 0; k < n; ++k) {
+      const Plan& p = plan[k];
+      if (!p.batched || !out[k]) continue;
+      const size_t bytes = static_cast<size_t>(ctrs[static_cast<size_t>(k) * 4]) * sizeof(dv_allele_event);
+      if (bytes) {
+        DV_HIP_CHECK(hipMemcpyAsync(h_ev.ptr + at, static_cast<const dv_allele_event*>(d_ev.ptr) + p.ev_off, bytes,
+                                    hipMemcpyDeviceToHost, stream));
+      }
+      at += bytes;
+    }
+    DV_HIP_CHECK(hipStreamSynchronize(stream));
+    at = 0;
+    for (int32_t k = 0; k < n; ++k) {
+      const Plan& p = plan[k];
+      if (!p.batched || !out[k]) continue;
+      const size_t n_ev = ctrs[static_cast<size_t>(k) * 4];
+      if (n_ev) std::memcpy(out[k]->raw.ptr, h_ev.ptr + at, n_ev * sizeof(dv_allele_event));
+      at += n_ev * sizeof(dv_allele_event);
+      order_events(out[k], n_ev);
+    }
+  }
+  for (int32_t k = 0; k < n; ++k) {
+    if (out[k]) continue;
+    if (int rc = dv_count_alleles(reads[k], options[k], &out[k], stream_v)) return fail_all(rc);
+  }
   return DV_OK;
 }
 

@@ -559,23 +559,24 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
     for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
       batch, tables, realigned_tables = pending
       pending = start_batch(at + _REGION_BATCH) if at + _REGION_BATCH < len(pieces) else None
-      for region, in_table, realigned in zip(batch, tables, realigned_tables()):
+      called = proc.process_tables(batch, tables, realigned_tables())     # the batch's allele counts: one device call
+      for region, in_table, (candidates, realigned) in zip(batch, tables, called):
         stats['n_regions'] += 1
         stats['n_reads'] += in_table.n_reads
+        stats['n_candidates'] += len(candidates)
         if model is not None:
           # drawn on the device now, classified with the regions around it (one CNN forward per
           # _CLASSIFY_AT examples); records leave in region order
-          stats['n_candidates'] += len(proc.queue_region_table(region, in_table, model, realigned=realigned))
+          proc.queue_region_candidates(candidates, realigned, model)
           if proc.n_queued_examples >= _CLASSIFY_AT:
             for records in proc.flush_queue(model):
               for rec in records:
                 writer.write(rec)
               stats['n_examples'] += len(records)
           continue
-        candidates, records = proc.examples_in_region_table(region, in_table, realigned=realigned)
+        _, records = proc.examples_in_region_table(region, in_table, called=(candidates, realigned))
         for rec in records:
           writer.write(rec)
-        stats['n_candidates'] += len(candidates)
         stats['n_examples'] += len(records)
     if realign_thread is not None:
       realign_thread.shutdown()

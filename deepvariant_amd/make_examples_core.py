@@ -341,22 +341,39 @@ class RegionProcessor:
   def process_table(self, region: T.Range, table, realigned=None) -> Tuple[List[T.DeepVariantCall], 'packing.ReadTable']:
     """`realigned`: the region's table as `realign_tables` returned it (the runner realigns a
     batch of regions ahead); None = realign here."""
-    if realigned is None:
-      realigned = self.realign_table(table, region)
-    rows = np.nonzero((realigned.read_end > region.start) & (region.end > realigned.read_pos.astype(np.int64)))[0]
-    if not len(rows):
-      return [], realigned
-    in_region = realigned.take(rows)
-    positions = ()
-    if self.processor_options.track_ref_reads:
-      first_pass = self._allele_counter(region, in_region)
-      positions = self.variant_caller.call_positions_from_allele_counter(first_pass)
-    candidates = self.variant_caller.calls_from_allele_counter(self._allele_counter(region, in_region, positions))
-    return candidates, realigned
+    return self.process_tables([region], [table], None if realigned is None else [realigned])[0]
 
-  def examples_in_region_table(self, region: T.Range, table, stats: Optional[dict] = None, realigned=None
-                               ) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
-    candidates, realigned = self.process_table(region, table, realigned)
+  def process_tables(self, regions: Sequence[T.Range], tables: Sequence, realigned_tables: Optional[Sequence] = None
+                     ) -> List[Tuple[List[T.DeepVariantCall], 'packing.ReadTable']]:
+    """Candidates of a batch of calling regions: -> [(candidates, realigned table)] per region.  The
+    regions' allele counters are filled in one device call per pass (AlleleCounter.run_batch: one
+    upload, kernels back to back -- two passes with track_ref_reads), the caller then reads each
+    region's counts on its own."""
+    if realigned_tables is None:
+      realigned_tables = self.realign_tables(tables, regions)
+    out = [([], realigned) for realigned in realigned_tables]
+    slots, in_region = [], []
+    for k, (region, realigned) in enumerate(zip(regions, realigned_tables)):
+      rows = np.nonzero((realigned.read_end > region.start) & (region.end > realigned.read_pos.astype(np.int64)))[0]
+      if len(rows):
+        slots.append(k)
+        in_region.append(realigned.take(rows))
+    run_batch = getattr(allelecounter.AlleleCounter, 'run_batch', None) or (lambda counters: None)
+    positions = [()] * len(slots)
+    if self.processor_options.track_ref_reads:
+      first_pass = [self._allele_counter(regions[k], t) for k, t in zip(slots, in_region)]
+      run_batch(first_pass)
+      positions = [self.variant_caller.call_positions_from_allele_counter(c) for c in first_pass]
+    counters = [self._allele_counter(regions[k], t, p) for k, t, p in zip(slots, in_region, positions)]
+    run_batch(counters)
+    for k, counter in zip(slots, counters):
+      out[k] = (self.variant_caller.calls_from_allele_counter(counter), realigned_tables[k])
+    return out
+
+  def examples_in_region_table(self, region: T.Range, table, stats: Optional[dict] = None, realigned=None,
+                               called=None) -> Tuple[List[T.DeepVariantCall], List[bytes]]:
+    """`called`: (candidates, realigned table) of this region out of `process_tables`."""
+    candidates, realigned = called if called is not None else self.process_table(region, table, realigned)
     if not candidates:
       return candidates, []
     examples, _ = self.generator.encode_region(candidates, [realigned], [0], [0.0], stats if stats is not None else {})
@@ -372,6 +389,11 @@ class RegionProcessor:
   # one, their tensors wait there, and ONE CNN forward classifies a few hundred examples
   def queue_region_table(self, region: T.Range, table, model, realigned=None) -> List[T.DeepVariantCall]:
     candidates, realigned = self.process_table(region, table, realigned)
+    return self.queue_region_candidates(candidates, realigned, model)
+
+  def queue_region_candidates(self, candidates, realigned, model) -> List[T.DeepVariantCall]:
+    """The drawing half of queue_region_table, for a driver that called the candidates of a batch
+    of regions at once (process_tables)."""
     images, plan = (None, [])
     if candidates:
       images, plan = self.generator.encode_region_on_device(candidates, [realigned], [0], [0.0], model.input_shape)

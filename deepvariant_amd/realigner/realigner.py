@@ -529,12 +529,12 @@ class Realigner:
     if self.config.split_skip_reads:
       raise NotImplementedError('split_skip_reads works on Read objects (realign_reads)')
     job = RealignJob(len(tables), want_haplotypes, self._native_options())
-    for slot, (table, region) in enumerate(zip(tables, regions)):
-      n = table.n_reads
-      if n == 0:
+    tables, regions = list(tables), list(regions)
+    all_windows = window_selector.select_windows_of_tables(self.config.ws_config, self.ref_reader, tables, regions)
+    for slot, (table, region, windows) in enumerate(zip(tables, regions, all_windows)):
+      if table.n_reads == 0:
         job.results[slot] = ([], table)
         continue
-      windows = window_selector.select_windows(self.config.ws_config, self.ref_reader, range(n), region, table=table)
       usable = [w for w in windows
                 if w.end - w.start <= self.config.ws_config.max_window_size and self._is_valid(w)]
       if not usable:

@@ -161,11 +161,11 @@ def allele_count_linear_candidates_from_allele_counter(allele_counter, model: Al
   return scores
 
 
-def _candidates_from_reads(config: WindowSelectorOptions, ref_reader, reads: Sequence, region: T.Range,
-                           table=None) -> List[int]:
-  """window_selector._candidates_from_reads (:40-86).  `table`: the reads already packed
-  (packing.ReadTable), so the counter does not pack them again.  The counter is
-  `allelecounter.AlleleCounter`, looked up at call time: it counts on the device."""
+def _make_counter(config: WindowSelectorOptions, ref_reader, reads: Sequence, region: T.Range, table=None):
+  """The allele counter of the region expanded by region_expansion_in_bp, with its reads added
+  (window_selector.py:40-66).  `table`: the reads already packed (packing.ReadTable), so the counter
+  does not pack them again.  The counter is `allelecounter.AlleleCounter`, looked up at call time:
+  it counts on the device."""
   expanded = utils.expand(region, config.region_expansion_in_bp, ref_reader.n_bases(region.reference_name))
   counter = allelecounter.AlleleCounter(
       ref_reader, expanded.reference_name, expanded.start, expanded.end,
@@ -176,6 +176,11 @@ def _candidates_from_reads(config: WindowSelectorOptions, ref_reader, reads: Seq
   else:
     for read in reads:
       counter.add(read, 'placeholder_sample_id')
+  return counter, expanded
+
+
+def _candidates_from_counter(config: WindowSelectorOptions, counter, expanded: T.Range) -> List[int]:
+  """The positions the model selects, from a counter that holds the region's reads (:68-86)."""
   model_type = config.window_selector_model.model_type
   if model_type == VARIANT_READS:
     conf = config.window_selector_model.variant_reads_model
@@ -187,6 +192,13 @@ def _candidates_from_reads(config: WindowSelectorOptions, ref_reader, reads: Seq
     scores = allele_count_linear_candidates_from_allele_counter(counter, conf)
     return [expanded.start + i for i, score in enumerate(scores) if float(score) > conf.decision_boundary]
   raise ValueError('Unknown enum option "{}" for WindowSelectorModel.model_type'.format(model_type))
+
+
+def _candidates_from_reads(config: WindowSelectorOptions, ref_reader, reads: Sequence, region: T.Range,
+                           table=None) -> List[int]:
+  """window_selector._candidates_from_reads (:40-86)."""
+  counter, expanded = _make_counter(config, ref_reader, reads, region, table=table)
+  return _candidates_from_counter(config, counter, expanded)
 
 
 def _candidates_to_windows(config: WindowSelectorOptions, candidate_pos: Sequence[int], ref_name: str) -> List[T.Range]:
@@ -220,3 +232,23 @@ def select_windows(config: WindowSelectorOptions, ref_reader, reads: Sequence, r
     return [region]
   candidates = _candidates_from_reads(config, ref_reader, reads, region, table=table)
   return _candidates_to_windows(config, candidates, region.reference_name)
+
+
+def select_windows_of_tables(config: WindowSelectorOptions, ref_reader, tables: Sequence, regions: Sequence[T.Range]
+                             ) -> List[List[T.Range]]:
+  """`select_windows` for the packed read tables of several calling regions: the regions' allele
+  counters are filled in ONE device call (AlleleCounter.run_batch: one upload, the kernels back to
+  back) before each region's candidates are read off its counter."""
+  out: List[List[T.Range]] = [[] for _ in tables]
+  if config.realign_all:
+    return [[region] if table.n_reads else [] for table, region in zip(tables, regions)]
+  jobs = []
+  for k, (table, region) in enumerate(zip(tables, regions)):
+    if table.n_reads:
+      jobs.append((k, region) + _make_counter(config, ref_reader, (), region, table=table))
+  run_batch = getattr(allelecounter.AlleleCounter, 'run_batch', None)
+  if run_batch is not None:
+    run_batch([job[2] for job in jobs])
+  for k, region, counter, expanded in jobs:
+    out[k] = _candidates_to_windows(config, _candidates_from_counter(config, counter, expanded), region.reference_name)
+  return out

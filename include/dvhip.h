@@ -615,6 +615,13 @@ typedef struct dv_allele_counts dv_allele_counts;  /* owns the host copies of th
 
 int dv_count_alleles(const dv_batch* reads, const dv_allele_counter_options* options, dv_allele_counts** out,
                      void* stream);
+/* The same for n regions (a region driver's batch of calling regions, each with its own read
+ * table and options): every region's arrays travel in one pinned staging image, the kernels are
+ * queued back to back and the stream is synchronised twice for the whole batch instead of twice
+ * per region.  out[k] receives region k's result (each freed with dv_allele_counts_free); on an
+ * error no result is left allocated. */
+int dv_count_alleles_batch(int32_t n, const dv_batch* const* reads, const dv_allele_counter_options* const* options,
+                           dv_allele_counts** out, void* stream);
 /* Events are sorted by (position, read, read_offset) = the order AddReadAlleles stores them
  * for one position.  Returns the interval length. */
 int dv_allele_counts_arrays(const dv_allele_counts* c, const int32_t** ref_supporting_read_count,

@@ -308,3 +308,43 @@ def test_narrowed_visit_gives_the_same_candidates(seed, long_reads, track):
       assert len(narrowed) < len(counter_for().counts_with_read_alleles())
       n_calls += len(fast)
   assert n_calls > 20 or long_reads      # (random long reads rarely agree on an allele: the equalities above are the test)
+
+
+@pytest.mark.parametrize('seed,long_reads', [(41, False), (42, True)])
+def test_batch_call_equals_one_call_per_region(seed, long_reads):
+  """AlleleCounter.run_batch (dv_count_alleles_batch: the regions' arrays in one staging image, kernels
+  back to back, two synchronisations for the batch) against every counter counting alone: the same
+  reference-supporting counts, the same events in the same order, the same number of counted reads --
+  regions of different sizes, one without reads, one with tracked reference reads at candidate
+  positions, one counter that has already run."""
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=6000))
+  ref = _Ref(seq[:700] + 'NN' + seq[702:])
+  spans = [((1000, 2000), (700, 2100)), ((0, 400), (0, 420)), ((5600, 6000), (5300, 5990)), ((2500, 2600), (2300, 2650)),
+           ((3000, 3500), (2900, 3600))]
+  read_sets = [_fuzz_reads(rng, ref, 500 if not long_reads else 150, lo, hi, long_reads) for _, (lo, hi) in spans]
+  read_sets[3] = []                                                   # a region without reads
+
+  def make(k, **kw):
+    (start, end), _ = spans[k]
+    c = A.AlleleCounter(ref, 'c', start, end, min_mapping_quality=10, min_base_quality=20, **kw)
+    for r in read_sets[k]:
+      c.add(r)
+    return c
+
+  marked = [1100, 1101, 1500, 1999]
+  specs = [dict(), dict(keep_legacy_behavior=True), dict(), dict(), dict(track_ref_reads=True, candidate_positions=marked)]
+  specs[0] = dict(track_ref_reads=True, candidate_positions=marked)
+  alone = [make(k, **specs[k]) for k in range(len(spans))]
+  together = [make(k, **specs[k]) for k in range(len(spans))]
+  together[2].n_counted_reads()                                       # already ran: run_batch leaves it alone
+  A.AlleleCounter.run_batch(together)
+  for a, b in zip(alone, together):
+    assert a.n_counted_reads() == b.n_counted_reads()
+    assert np.array_equal(a.ref_supporting_read_counts(), b.ref_supporting_read_counts())
+    assert np.array_equal(a._events, b._events)                       # pylint: disable=protected-access
+    assert a.interval_length() == b.interval_length()
+  assert sum(len(c._events) for c in together) > 300                  # pylint: disable=protected-access
+  assert (((together[0]._events['length_type'] >> 28) & 7) == A.REFERENCE).any()   # pylint: disable=protected-access
+  A.AlleleCounter.run_batch([])                                       # nothing to do
+  A.AlleleCounter.run_batch(together)                                 # everything has run
