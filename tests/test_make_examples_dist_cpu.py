@@ -114,3 +114,40 @@ def test_flag_checks():
     me.check_flags(ap.parse_args(['--ref', 'r', '--reads', 'b', '--examples', 'e@2.gz', '--ranks_per_gpu', '2']))
   with pytest.raises(ValueError, match='ranks_per_gpu'):
     me.check_flags(ap.parse_args(['--ref', 'r', '--reads', 'b', '--examples', 'e.gz', '--ranks_per_gpu', '0']))
+
+
+def test_background_model_hands_over_the_model_or_its_error():
+  """make_examples._BackgroundModel: the classifier set up on a worker thread -- the input shape is
+  known at once, the first use waits for the thread, a failed set-up is raised on the calling
+  thread (every time it is asked for), a model of another shape is refused."""
+  import threading
+
+  class _Model:
+    input_shape = (100, 221, 7)
+    max_batch = 64
+
+    def __call__(self, images):
+      return ('classified', images)
+
+  started = threading.Event()
+
+  def build():
+    started.wait(5)
+    return _Model()
+
+  bg = me._BackgroundModel(build, (100, 221, 7))              # pylint: disable=protected-access
+  assert bg.input_shape == (100, 221, 7)
+  started.set()
+  assert bg.max_batch == 64 and bg('x') == ('classified', 'x') and isinstance(bg.get(), _Model)
+
+  def broken():
+    raise ValueError('no such checkpoint')
+  bad = me._BackgroundModel(broken, (100, 221, 7))            # pylint: disable=protected-access
+  for _ in range(2):
+    with pytest.raises(ValueError, match='no such checkpoint'):
+      bad.get()
+  with pytest.raises(ValueError, match='no such checkpoint'):
+    bad('x')
+  other = me._BackgroundModel(_Model, (100, 147, 10))         # pylint: disable=protected-access
+  with pytest.raises(ValueError, match='model shape'):
+    other.get()

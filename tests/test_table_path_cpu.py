@@ -130,3 +130,66 @@ def test_with_alignments_csr_handles_runs_and_empty_input():
   assert np.array_equal(got.cigar[got.read_cigar_off[39]:got.read_cigar_off[40]], words[4:6])
   assert np.array_equal(got.cigar[got.read_cigar_off[2]:got.read_cigar_off[3]],
                         table.cigar[table.read_cigar_off[2]:table.read_cigar_off[3]])
+
+
+@pytest.mark.timeout(900)
+@RF.with_oracle_counter
+def test_realign_job_on_an_executor_thread_gives_the_same_tables():
+  """start_realign_tables with an executor (the make_examples runner's form: the native call of the
+  next batch runs on a worker thread while the current batch is processed) against the blocking call;
+  two jobs in flight at once."""
+  import concurrent.futures
+  ref, sets = RF.load()
+  rl = R.Realigner(R.realigner_config(), ref)
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  regions = [T.Range('chr20', s, s + 1000) for s in range(9_999_999, 10_005_999, 1000)]
+  tables = [packing.ReadTable.from_reads([r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)])
+            for region in regions]
+  want = rl.realign_tables(tables, regions)
+  with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+    first = rl.start_realign_tables(tables[:3], regions[:3], executor=pool)
+    second = rl.start_realign_tables(tables[3:], regions[3:], executor=pool)
+    got = first.result() + second.result()
+    assert first.result() is first.results                    # a second call does not run anything again
+  assert len(got) == len(want)
+  for (ch_a, t_a), (ch_b, t_b) in zip(want, got):
+    assert [(c.span, c.haplotypes) for c in ch_a] == [(c.span, c.haplotypes) for c in ch_b]
+    _same(t_a, t_b, ranks_as_order=False)
+
+
+@pytest.mark.timeout(900)
+@RF.with_oracle_counter
+def test_process_tables_equals_process_table_region_by_region():
+  """RegionProcessor.process_tables (the runner's form: a batch of regions realigned in one native call,
+  their candidates called from counters filled together) against process_table per region."""
+  from deepvariant_amd import make_examples_core as mec
+  from tests.golden.make_golden import wgs_options
+  ref, sets = RF.load()
+  options = T.MakeExamplesOptions(pic_options=wgs_options(), sample_options=[T.SampleOptions(name='s')])
+  po = mec.RegionProcessorOptions()
+
+  class _NoGenerator(mec.RegionProcessor):        # the candidate half only: no encoder, no device
+    def __init__(self):
+      from deepvariant_amd import variant_calling
+      from deepvariant_amd.realigner import realigner as realigner_module
+      self.options, self.ref_reader, self.processor_options = options, ref, po
+      self.realigner = realigner_module.Realigner(realigner_module.realigner_config(), ref)
+      self.variant_caller = variant_calling.VariantCaller(variant_calling.VariantCallerOptions(
+          po.vsc_min_count_snps, po.vsc_min_count_indels, po.vsc_min_fraction_snps, po.vsc_min_fraction_indels,
+          sample_name='s', track_ref_reads=po.track_ref_reads))
+
+  proc = _NoGenerator()
+  reads = sets['wgs']
+  spans = [U.read_range(r) for r in reads]
+  regions = [T.Range('chr20', s, s + 1000) for s in range(9_999_999, 10_004_999, 1000)]
+  tables = [packing.ReadTable.from_reads([r for r, s in zip(reads, spans) if U.ranges_overlap(s, region)])
+            for region in regions]
+  together = proc.process_tables(regions, tables)
+  n_candidates = 0
+  for region, table, (candidates, realigned) in zip(regions, tables, together):
+    alone_candidates, alone_table = proc.process_table(region, table)
+    assert candidates == alone_candidates
+    _same(realigned, alone_table, ranks_as_order=False)
+    n_candidates += len(candidates)
+  assert n_candidates > 10
