@@ -537,10 +537,14 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   t_loop = time.perf_counter()
   stats['setup_s'] = t_loop - t_start        # flags, region list, processor (the model is set up on a worker thread)
   try:
-    # the table path walks the regions in batches: the realigner's native work of a whole batch
-    # (every window's assembly and alignment) is ONE threaded call, started for batch k + 1
-    # before the candidates of batch k are called and drawn -- the rest stays per region
-    def start_batch(at):
+    # the table path walks the regions in batches of _REGION_BATCH.  A batch is PREPARED -- its reads
+    # cut out of the decoded block, its windows selected (allele counts of the batch: one device call),
+    # every window assembled and its reads aligned (one native call on host threads), the alignments
+    # written back -- on a worker thread, one batch ahead of the main thread, which calls the
+    # candidates of the current batch, draws and classifies them.  Most of either side's time is
+    # spent in native calls that hold no Python lock.  DV_PREPARE_ON_MAIN=1: only the realigner's
+    # native call goes to the worker (A/B).
+    def batch_tables(at):
       batch = pieces[at:at + _REGION_BATCH]
       tables = []
       for region in batch:
@@ -549,17 +553,44 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
           in_table = in_table.take(np.array(reservoir_sample(range(in_table.n_reads), args.max_reads_per_partition,
                                                              np.random.RandomState(_RANDOM_SEED)), np.int64))
         tables.append(in_table)
-      return batch, tables, proc.start_realign_tables(tables, batch, executor=realign_thread)
+      return batch, tables
 
-    realign_thread = None
+    def prepare(at):                     # everything of a batch up to the realigned tables
+      batch, tables = batch_tables(at)
+      return batch, tables, proc.start_realign_tables(tables, batch)()
+
+    def on_worker_device():              # HIP's current device is per thread
+      if args.call_variants_outfile or getattr(proc, 'table_path_ok', None) is not None:
+        try:
+          import torch
+          if torch.cuda.is_available():
+            torch.cuda.set_device(args.device)
+        except ImportError:
+          pass
+
+    worker = None
+    prepare_on_main = os.environ.get('DV_PREPARE_ON_MAIN') is not None
     if use_tables and len(pieces) > _REGION_BATCH:
       import concurrent.futures
-      realign_thread = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-realign-batch')
+      worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-region-batch',
+                                                     initializer=on_worker_device)
+
+    def start_batch(at):                 # -> a callable that returns (batch, tables, realigned tables)
+      if worker is None:
+        return lambda: prepare(at)
+      if prepare_on_main:
+        batch, tables = batch_tables(at)
+        finish = proc.start_realign_tables(tables, batch, executor=worker)
+        return lambda: (batch, tables, finish())
+      return worker.submit(prepare, at).result
+
     pending = start_batch(0) if use_tables and pieces else None
     for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
-      batch, tables, realigned_tables = pending
+      t_wait = time.perf_counter()
+      batch, tables, realigned_tables = pending()
+      stats['wait_for_prepared_batches_s'] = stats.get('wait_for_prepared_batches_s', 0.0) + time.perf_counter() - t_wait
       pending = start_batch(at + _REGION_BATCH) if at + _REGION_BATCH < len(pieces) else None
-      called = proc.process_tables(batch, tables, realigned_tables())     # the batch's allele counts: one device call
+      called = proc.process_tables(batch, tables, realigned_tables)       # the batch's allele counts: one device call
       for region, in_table, (candidates, realigned) in zip(batch, tables, called):
         stats['n_regions'] += 1
         stats['n_reads'] += in_table.n_reads
@@ -578,8 +609,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
         for rec in records:
           writer.write(rec)
         stats['n_examples'] += len(records)
-    if realign_thread is not None:
-      realign_thread.shutdown()
+    if worker is not None:
+      worker.shutdown()
     for region in ([] if use_tables else pieces):
       in_reads = reads_for(region)
       if args.max_reads_per_partition > 0:
