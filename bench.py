@@ -655,10 +655,7 @@ def bam_mode(args, log=sys.stderr):
       'examples': stats['n_examples'], 'table_path': stats.get('table_path'),
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
       'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
-      'stage_note': 'BAM rows, window selection, the realigner call and its write-back run on a worker thread one batch of '
-                    'regions ahead of the main thread (candidates, drawing, classification): the stages overlap and do not '
-                    'add up to the wall time; main_thread_wait_for_prepared_batches_ms is what the main thread waits for them',
-      'main_thread_wait_for_prepared_batches_ms': 1e3 * stats.get('wait_for_prepared_batches_s', 0.0),
+      'main_thread_wait_for_realigned_batches_ms': 1e3 * stats.get('wait_for_prepared_batches_s', 0.0),
       'model_setup_ms_on_worker_thread': {k: 1e3 * v for k, v in timed_setup.items()},
       'gpu_kernel_ms': kernel_ms, 'gpu_busy_frac': sum(kernel_ms.values()) / (1e3 * elapsed),
       'host_cores': os.cpu_count(), 'realigner_threads': os.environ.get('DV_REALIGN_THREADS', 'auto (<= 16)'),

@@ -537,13 +537,13 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   t_loop = time.perf_counter()
   stats['setup_s'] = t_loop - t_start        # flags, region list, processor (the model is set up on a worker thread)
   try:
-    # the table path walks the regions in batches of _REGION_BATCH.  A batch is PREPARED -- its reads
-    # cut out of the decoded block, its windows selected (allele counts of the batch: one device call),
-    # every window assembled and its reads aligned (one native call on host threads), the alignments
-    # written back -- on a worker thread, one batch ahead of the main thread, which calls the
-    # candidates of the current batch, draws and classifies them.  Most of either side's time is
-    # spent in native calls that hold no Python lock.  DV_PREPARE_ON_MAIN=1: only the realigner's
-    # native call goes to the worker (A/B).
+    # the table path walks the regions in batches of _REGION_BATCH: the realigner's native work of a
+    # whole batch (every window's assembly and alignment) is ONE threaded call, handed to a worker
+    # thread for batch k + 1 before the candidates of batch k are called, drawn and classified on
+    # the main thread -- the native call holds no Python lock.  (Moving the REST of a batch's
+    # preparation -- rows, window selection, write-back -- to the worker as well was measured and
+    # is slower: those are Python / numpy steps that contend for the interpreter lock, 900-918
+    # against 973-997 examples/s on the NA12878 slice, same box.)
     def batch_tables(at):
       batch = pieces[at:at + _REGION_BATCH]
       tables = []
@@ -555,34 +555,15 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
         tables.append(in_table)
       return batch, tables
 
-    def prepare(at):                     # everything of a batch up to the realigned tables
-      batch, tables = batch_tables(at)
-      return batch, tables, proc.start_realign_tables(tables, batch)()
-
-    def on_worker_device():              # HIP's current device is per thread
-      if args.call_variants_outfile or getattr(proc, 'table_path_ok', None) is not None:
-        try:
-          import torch
-          if torch.cuda.is_available():
-            torch.cuda.set_device(args.device)
-        except ImportError:
-          pass
-
     worker = None
-    prepare_on_main = os.environ.get('DV_PREPARE_ON_MAIN') is not None
     if use_tables and len(pieces) > _REGION_BATCH:
       import concurrent.futures
-      worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-region-batch',
-                                                     initializer=on_worker_device)
+      worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-realign-batch')
 
     def start_batch(at):                 # -> a callable that returns (batch, tables, realigned tables)
-      if worker is None:
-        return lambda: prepare(at)
-      if prepare_on_main:
-        batch, tables = batch_tables(at)
-        finish = proc.start_realign_tables(tables, batch, executor=worker)
-        return lambda: (batch, tables, finish())
-      return worker.submit(prepare, at).result
+      batch, tables = batch_tables(at)
+      finish = proc.start_realign_tables(tables, batch, executor=worker)
+      return lambda: (batch, tables, finish())
 
     pending = start_batch(0) if use_tables and pieces else None
     for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
