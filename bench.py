@@ -489,8 +489,8 @@ def _bam_rank(rank, world, port, tmp, bam, fasta):
   alone, then the product's distributed runner over the whole slice between two barriers."""
   import torch.distributed as dist
   from deepvariant_amd import make_examples as me, tfrecord
-  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                    MASTER_PORT=str(port))
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   devnull = open(os.devnull, 'w')
   try:

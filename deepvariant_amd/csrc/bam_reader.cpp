@@ -48,25 +48,35 @@ struct Block {
   size_t out_off, out_len;
 };
 
-// Whole file -> one inflated buffer.  Block boundaries come from the BC extra field
-// (SAMv1 4.1), sizes from ISIZE, so blocks inflate independently.
-int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<uint8_t>* out) {
+// A run of BGZF members -> one inflated buffer.  Block boundaries come from the BC extra field
+// (SAMv1 4.1), sizes from ISIZE, so blocks inflate independently on `n_threads` threads.  With
+// `cut_tail_ok` the run may end inside a member (a byte range read ahead of an indexed query): the
+// complete members are inflated, `*consumed` tells how many input bytes they span.  `members`
+// (optional) receives (offset in the input, offset in the output) per member.
+int inflate_members(const uint8_t* file, size_t size, int n_threads, bool cut_tail_ok, std::vector<uint8_t>* out,
+                    size_t* consumed, std::vector<std::pair<size_t, size_t>>* members) {
   std::vector<Block> blocks;
   size_t pos = 0, total = 0;
-  while (pos < file.size()) {
-    if (pos + 18 > file.size() || file[pos] != 31 || file[pos + 1] != 139) {
+  while (pos < size) {
+    if (pos + 18 > size) {
+      if (cut_tail_ok) break;
+      return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF file (bad gzip member header)");
+    }
+    if (file[pos] != 31 || file[pos + 1] != 139) {
       return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF file (bad gzip member header)");
     }
     const unsigned xlen = le16(&file[pos + 10]);
     size_t p = pos + 12;
     const size_t xend = p + xlen;
+    if (xend > size && cut_tail_ok) break;
     long bsize = -1;
-    while (p + 4 <= xend && xend <= file.size()) {
+    while (p + 4 <= xend && xend <= size) {
       const unsigned slen = le16(&file[p + 2]);
       if (file[p] == 66 && file[p + 1] == 67 && slen == 2) bsize = le16(&file[p + 4]) + 1L;
       p += 4 + slen;
     }
-    if (bsize < 0 || pos + bsize > file.size() || static_cast<size_t>(bsize) < 12u + xlen + 8u) {
+    if (bsize >= 0 && pos + bsize > size && cut_tail_ok) break;
+    if (bsize < 0 || pos + bsize > size || static_cast<size_t>(bsize) < 12u + xlen + 8u) {
       return dv::fail(DV_ERR_BAD_INPUT, "not a BGZF file (no BC subfield / truncated block)");
     }
     Block b;
@@ -75,10 +85,12 @@ int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<ui
     b.out_len = le32(&file[pos + bsize - 4]);
     if (b.out_len > 65536) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block larger than 64 KiB (ISIZE)");
     b.out_off = total;
+    if (members) members->emplace_back(pos, total);
     total += b.out_len;
     blocks.push_back(b);
     pos += bsize;
   }
+  if (consumed) *consumed = pos;
   out->resize(total);
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
@@ -110,6 +122,11 @@ int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<ui
   for (auto& t : pool) t.join();
   if (failed.load()) return dv::fail(DV_ERR_BAD_INPUT, "BGZF block failed to inflate");
   return DV_OK;
+}
+
+// Whole file -> one inflated buffer.
+int inflate_bgzf(const std::vector<uint8_t>& file, int n_threads, std::vector<uint8_t>* out) {
+  return inflate_members(file.data(), file.size(), n_threads, false, out, nullptr, nullptr);
 }
 
 // Integer value of a 2-letter aux tag (c C s S i I), or false.
@@ -625,7 +642,7 @@ int csi_chunks(const std::string& csi_path, int32_t ref, int64_t start, int64_t 
 
 // Indexed read: only the BGZF members the .bai (or .csi) points at are read and inflated.
 int read_indexed(const char* path, const std::string& bai, const char* contig, RegionFilter f,
-                 dv_read_table* t) {
+                 dv_read_table* t, int n_threads) {
   FILE* fp = std::fopen(path, "rb");
   if (!fp) return dv::fail(DV_ERR_BAD_INPUT, std::string("cannot open ") + path);
   struct Closer {
@@ -651,6 +668,7 @@ int read_indexed(const char* path, const std::string& bai, const char* contig, R
                       : bai_chunks(bai, f.want_ref, f.start, f.end, &chunks)) {
     return rc;
   }
+  std::vector<uint8_t> range;
   for (const Chunk& c : chunks) {
     buf.clear();
     uint64_t next = c.beg >> 16;                 // file offset of the next member to inflate
@@ -658,6 +676,27 @@ int read_indexed(const char* path, const std::string& bai, const char* contig, R
     size_t end_limit = static_cast<size_t>(-1);  // buffer offset matching the chunk's end
     size_t p = c.beg & 0xFFFF;
     bool past = false, eof = false;
+    // The chunk's members -- through the one its end lies in, plus room for a record that runs on
+    // into the next ones -- are read in one go and inflated on n_threads threads; the loop below
+    // then finds its records in memory and only falls back to member-by-member reads for what a
+    // record needs beyond that.
+    if (end_coff >= next) {
+      const size_t want = static_cast<size_t>(end_coff - next) + 3 * 65536;
+      range.resize(want);
+      size_t got = 0;
+      if (fseeko(fp, static_cast<off_t>(next), SEEK_SET) == 0) got = std::fread(range.data(), 1, want, fp);
+      std::vector<std::pair<size_t, size_t>> members;
+      size_t consumed = 0;
+      if (got > 0) {
+        if (int rc = inflate_members(range.data(), got, n_threads, true, &buf, &consumed, &members)) return rc;
+      }
+      for (const auto& m : members) {
+        if (next + m.first == end_coff) end_limit = m.second + (c.end & 0xFFFF);
+      }
+      if (end_limit == static_cast<size_t>(-1) && next + consumed > end_coff) end_limit = buf.size();
+      next += consumed;
+      if (consumed == 0 && got == 0) eof = true;
+    }
     for (;;) {
       // make sure the record at p is complete in buf
       while (!eof && (buf.size() < p + 4 || buf.size() < p + 4 + le32(&buf[p]))) {
@@ -714,7 +753,7 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
     }
   }
   if (!bai.empty()) {
-    if (int rc = read_indexed(path, bai, contig, flt, t.get())) return rc;
+    if (int rc = read_indexed(path, bai, contig, flt, t.get(), n_threads)) return rc;
     t1 = std::chrono::steady_clock::now();
   } else {
     std::vector<uint8_t> file;

@@ -368,6 +368,10 @@ class RegionReads:
     self._starts = np.zeros(0, np.int64)
     self._ends = np.zeros(0, np.int64)
     self._max_span = 0
+    # BGZF members of a block inflate on a few host threads (this rank's share of the node's cores)
+    import os
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    self._threads = max(1, min(8, cores // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))))
 
   def _load(self, contig: str, lo: int, hi: int) -> None:
     a = self._args
@@ -385,7 +389,7 @@ class RegionReads:
         fetch = self._ref.get_bases
       table = packing.ReadTable.from_cram(a.reads, fetch, contig, lo, hi, **requirements)
     else:
-      table = packing.ReadTable.from_bam(a.reads, contig, lo, hi, **requirements)
+      table = packing.ReadTable.from_bam(a.reads, contig, lo, hi, n_threads=self._threads, **requirements)
     # Read objects are built on demand (a task of N touches 1/N of the block's reads) and kept
     # for the neighbouring region, which shares the reads that straddle the boundary
     self._make = table.read_factory(contig)
@@ -658,6 +662,14 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
   if on_gpu:
     args.device = (rank // max(getattr(args, 'ranks_per_gpu', 1), 1)) % torch.cuda.device_count()
     torch.cuda.set_device(args.device)
+  # the ranks of a node share its cores: each rank's realigner pool gets its share (16 threads per
+  # rank, the single-process default, would oversubscribe a node that runs 8 or 16 ranks)
+  import os
+  if os.environ.get('DV_REALIGN_THREADS') is None:
+    from deepvariant_amd.realigner import realigner as realigner_module
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    on_node = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    realigner_module._NATIVE_THREADS = max(1, min(16, cores // on_node))      # pylint: disable=protected-access
   sink = _MemorySink()
   stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
   # RCCL wants one rank per GPU; ranks that share a GPU exchange their (host) records over gloo
@@ -685,8 +697,8 @@ def _backend(args) -> str:
 def _spawned_rank(rank: int, args, world: int, port: int) -> None:
   import os
   import torch.distributed as dist
-  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                    MASTER_PORT=str(port))
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   dist.init_process_group(_backend(args), rank=rank, world_size=world)
   try:
     distributed_runner(args, rank, world)
