@@ -548,15 +548,8 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
     # preparation -- rows, window selection, write-back -- to the worker as well was measured and
     # is slower: those are Python / numpy steps that contend for the interpreter lock, 900-918
     # against 973-997 examples/s on the NA12878 slice, same box.)
-    # batch sizes ramp up (8, 16, 32, 32, ...): nothing hides the first batch's native call, so it is
-    # kept short and the pipeline fills early
-    bounds, size = [0], max(1, _REGION_BATCH // 4)
-    while bounds[-1] < len(pieces):
-      bounds.append(min(len(pieces), bounds[-1] + size))
-      size = min(_REGION_BATCH, 2 * size)
-
-    def batch_tables(k):
-      batch = pieces[bounds[k]:bounds[k + 1]]
+    def batch_tables(at):
+      batch = pieces[at:at + _REGION_BATCH]
       tables = []
       for region in batch:
         in_table = reads_for.table(region)
@@ -567,21 +560,21 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
       return batch, tables
 
     worker = None
-    if use_tables and len(bounds) > 2:
+    if use_tables and len(pieces) > _REGION_BATCH:
       import concurrent.futures
       worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dv-realign-batch')
 
-    def start_batch(k):                  # -> a callable that returns (batch, tables, realigned tables)
-      batch, tables = batch_tables(k)
+    def start_batch(at):                 # -> a callable that returns (batch, tables, realigned tables)
+      batch, tables = batch_tables(at)
       finish = proc.start_realign_tables(tables, batch, executor=worker)
       return lambda: (batch, tables, finish())
 
     pending = start_batch(0) if use_tables and pieces else None
-    for k in range(len(bounds) - 1 if use_tables else 0):
+    for at in range(0, len(pieces) if use_tables else 0, _REGION_BATCH):
       t_wait = time.perf_counter()
       batch, tables, realigned_tables = pending()
       stats['wait_for_prepared_batches_s'] = stats.get('wait_for_prepared_batches_s', 0.0) + time.perf_counter() - t_wait
-      pending = start_batch(k + 1) if k + 2 < len(bounds) else None
+      pending = start_batch(at + _REGION_BATCH) if at + _REGION_BATCH < len(pieces) else None
       called = proc.process_tables(batch, tables, realigned_tables)       # the batch's allele counts: one device call
       for region, in_table, (candidates, realigned) in zip(batch, tables, called):
         stats['n_regions'] += 1
