@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     'dv_last_profile_count',
     'dv_bam_read_region', 'dv_read_table_fill_batch', 'dv_read_table_name',
     'dv_read_table_names', 'dv_read_table_ends', 'dv_read_table_free',
+    'dv_cram_read_region', 'dv_cram_header',
     'dv_pack_region', 'dv_packed_region_fill_batch', 'dv_packed_region_items',
     'dv_packed_region_free',
     'dv_aligner_create', 'dv_aligner_destroy', 'dv_aligner_set_reference',
@@ -52,6 +53,11 @@ ABI_SYMBOLS = [
     'dv_debruijn_graphviz', 'dv_realign_regions', 'dv_realign_result_free', 'dv_phase_reads',
     'dv_count_alleles', 'dv_count_alleles_batch', 'dv_allele_counts_arrays', 'dv_allele_counts_free', 'dv_merge_alt_channels',
 ]
+
+
+# dv_ref_fetch_fn (include/dvhip.h): the reference bases a CRAM written against an external FASTA leaves out
+REF_FETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_char),
+                           C.POINTER(C.c_int64))
 
 
 class DvError(RuntimeError):
@@ -282,6 +288,9 @@ def lib():
     l.dv_model_layer_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     l.dv_bam_read_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_int, C.c_void_p]
+    l.dv_cram_read_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, REF_FETCH_FN,
+                                      C.c_void_p, C.c_int, C.c_void_p]
+    l.dv_cram_header.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
     l.dv_read_table_fill_batch.argtypes = [C.c_void_p, C.c_void_p]
     l.dv_read_table_name.restype = C.c_char_p
     l.dv_read_table_name.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -337,9 +346,13 @@ def lib():
   return _lib
 
 
+def last_error() -> str:
+  return lib().dv_last_error().decode()
+
+
 def check(status: int):
   if status != DV_OK:
-    raise DvError(status, lib().dv_last_error().decode())
+    raise DvError(status, last_error())
 
 
 def try_crc32c(data: bytes) -> Optional[int]:

@@ -1,5 +1,10 @@
 """CRAM 3.0 -> Read objects (host side, pure Python + zlib / bz2 / lzma).
 
+The packed-table path (make_examples' default: packing.ReadTable.from_cram) goes through the NATIVE
+decoder, deepvariant_amd/csrc/cram_reader.cpp (dv_cram_read_region); this module is its Python twin:
+it yields Read OBJECTS for the object path (phasing, trimmed / alt-aligned pileups), lists contigs, and
+tests/test_cram_native_cpu.py holds the two against each other.
+
 The reference opens CRAM through htslib (third_party/nucleus/io/sam_reader.cc:560-640: `hts_open`,
 `--use_ref_for_cram`, `hts_set_opt(CRAM_OPT_REFERENCE)`); htslib is not in this image, so this is a
 restatement of the published format (CRAM format specification v3.0, samtools/hts-specs) at the
@@ -544,6 +549,10 @@ class CramFile:
     index = self._index()
     if index is None:
       for h, blocks in self.containers():
+        # a single-reference container of another contig or interval, or the unmapped tail (-1), cannot hold
+        # a read of the query; multi-reference containers (-2) are looked into
+        if h['ref_id'] == -1:
+          continue
         if h['ref_id'] >= 0 and (h['ref_id'] != want_ref or h['start'] - 1 >= end or h['start'] - 1 + h['span'] <= start):
           continue
         yield h, blocks
@@ -569,7 +578,7 @@ class CramFile:
     s_start, k = _itf8(d, k)
     s_span, k = _itf8(d, k)
     n_records, k = _itf8(d, k)
-    _, k = _ltf8(d, k)
+    record_counter, k = _ltf8(d, k)      # index of the slice's first record in the file
     n_blocks, k = _itf8(d, k)
     _, k = _itf8_array(d, k)
     embedded_id, k = _itf8(d, k)
@@ -806,6 +815,10 @@ class CramFile:
             rc.tlen = tlen
           else:
             rc.tlen = -tlen
+        # lossy names (RN = false): one generated name for the whole template -- htslib gives both mates
+        # of a pair the same generated name, and allele_support matches reads by name + read number
+        if not recs[chain[0]].name:
+          recs[chain[0]].name = b'%d' % (record_counter + chain[0])
         for a, c in enumerate(chain):      # mate of chain[a] is the next in the chain, the last one's is the first
           m = recs[chain[(a + 1) % len(chain)]]
           rc = recs[c]
@@ -819,8 +832,8 @@ class CramFile:
     for idx, r in enumerate(recs):
       if r.tlen is None:
         r.tlen = 0
-      if not r.name:
-        r.name = b'%d' % idx
+      if not r.name:      # generated from the record's index in the FILE, so names differ across slices
+        r.name = b'%d' % (record_counter + idx)
     return recs
 
   def records(self, contig: Optional[str] = None, start: int = 0, end: int = 1 << 62) -> List[CramRecord]:

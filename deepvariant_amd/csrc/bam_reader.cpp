@@ -27,14 +27,7 @@
 #include <vector>
 
 #include "dv_internal.h"
-
-struct dv_read_table {
-  std::vector<int32_t> pos, frag_len, hp;
-  std::vector<uint32_t> seq_off, cigar_off, cigar, name_rank, name_off;
-  std::vector<uint8_t> mapq, flags, read_number, bases, quals;
-  std::vector<int64_t> end;
-  std::vector<char> names;  // NUL-terminated, concatenated
-};
+#include "read_table.h"
 
 namespace {
 
@@ -796,19 +789,7 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   const auto t2 = std::chrono::steady_clock::now();
   // dense rank under the reference's tuple<string, int> ordering (fragment_name, read_number)
   const size_t n = t->pos.size();
-  std::vector<uint32_t> order(n);
-  std::iota(order.begin(), order.end(), 0u);
-  auto key_less = [&](uint32_t a, uint32_t b) {
-    const int c = std::strcmp(&t->names[t->name_off[a]], &t->names[t->name_off[b]]);
-    return c != 0 ? c < 0 : t->read_number[a] < t->read_number[b];
-  };
-  std::sort(order.begin(), order.end(), key_less);
-  t->name_rank.assign(n, 0);
-  uint32_t rank = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (i && key_less(order[i - 1], order[i])) ++rank;
-    t->name_rank[order[i]] = rank;
-  }
+  dv::rank_read_names(t.get());
   if (getenv("DV_BAM_TIMING")) {
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -66,22 +66,33 @@ def gather_call_outputs(probs: torch.Tensor, ids: torch.Tensor, group=None,
   return torch.cat(out_p), torch.cat(out_i)
 
 
+class PeerFailed(RuntimeError):
+  """Another rank reported a failure at the record exchange (its own exception is raised there)."""
+
+
 def gather_records(records: Sequence[bytes], device=None, group=None,
-                   max_chunk_bytes: int = 1 << 28) -> List[List[bytes]]:
+                   max_chunk_bytes: int = 1 << 28, failed: bool = False) -> List[List[bytes]]:
   """All ranks receive every rank's list of serialised records (CallVariantsOutput protos of the
   fused route), rank by rank in the order they were produced.
 
   Record lengths and bytes travel as two padded all-gathers (lengths int64, payload uint8; the
   payload in chunks of at most `max_chunk_bytes` per rank so that the staging buffers stay
   bounded whatever the run's size).  `device`: where the staging tensors live -- a CUDA device
-  under RCCL, None (CPU) under gloo."""
+  under RCCL, None (CPU) under gloo.
+
+  `failed=True`: this rank could not produce its records.  The first exchange (counts) carries the
+  flag, so every rank leaves the collective at once with `PeerFailed` naming the ranks -- instead of the
+  healthy ranks waiting in an all-gather the failed one never joins until the backend's timeout."""
   world = dist.get_world_size(group)
   lengths = torch.tensor([len(r) for r in records], dtype=torch.int64)
   total = int(lengths.sum()) if len(records) else 0
-  mine = torch.tensor([len(records), total], dtype=torch.int64, device=device)
+  mine = torch.tensor([-1 if failed else len(records), total], dtype=torch.int64, device=device)
   sizes = torch.zeros((world, 2), dtype=torch.int64, device=device)
   dist.all_gather_into_tensor(sizes.view(-1), mine, group=group)
   sizes = sizes.cpu().tolist()
+  bad = [r for r in range(world) if sizes[r][0] < 0]
+  if bad:
+    raise PeerFailed('rank%s %s failed before the record exchange' % ('s' if len(bad) > 1 else '', ', '.join(map(str, bad))))
   max_n = max(s[0] for s in sizes)
   max_total = max(s[1] for s in sizes)
   if max_n == 0:

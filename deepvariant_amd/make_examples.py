@@ -358,12 +358,12 @@ class RegionReads:
 
   BLOCK_BASES = 1 << 20
 
-  def __init__(self, args):
+  def __init__(self, args, ref_reader=None):
     self._args = args
     self._contig = None
     self._lo = self._hi = 0
     self._make = None
-    self._ref = None
+    self._ref = ref_reader      # the runner's FastaReader (CRAM decoding shares it: one reference per process)
     self._reads = {}
     self._starts = np.zeros(0, np.int64)
     self._ends = np.zeros(0, np.int64)
@@ -387,7 +387,8 @@ class RegionReads:
         if self._ref is None:
           self._ref = genomics_io.FastaReader(a.ref)
         fetch = self._ref.get_bases
-      table = packing.ReadTable.from_cram(a.reads, fetch, contig, lo, hi, **requirements)
+      # native decoder (dv_cram_read_region): the slices of the block decode on this rank's host threads
+      table = packing.ReadTable.from_cram(a.reads, fetch, contig, lo, hi, n_threads=self._threads, **requirements)
     else:
       table = packing.ReadTable.from_bam(a.reads, contig, lo, hi, n_threads=self._threads, **requirements)
     # Read objects are built on demand (a task of N touches 1/N of the block's reads) and kept
@@ -503,7 +504,7 @@ def make_examples_runner(args, log=sys.stderr, hooks: Optional[RunnerHooks] = No
   out_path, num_shards = _shard(out_spec, args.task)
   contig_names = genomics_io.bam_contig_names(args.reads)
   pieces = calling_regions(args, ref_reader, contig_names, num_shards)
-  reads_for = RegionReads(args)
+  reads_for = RegionReads(args, ref_reader)
   proc = hooks.make_processor(options, ref_reader, po, args.device)
   model = None
   if args.call_variants_outfile:
@@ -671,9 +672,17 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
     on_node = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     realigner_module._NATIVE_THREADS = max(1, min(16, cores // on_node))      # pylint: disable=protected-access
   sink = _MemorySink()
-  stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
   # RCCL wants one rank per GPU; ranks that share a GPU exchange their (host) records over gloo
   device = torch.device('cuda', args.device) if on_gpu and dist.get_backend() == 'nccl' else None
+  try:
+    stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
+  except BaseException:
+    # tell the peers before leaving: they would otherwise sit in the all-gather until the backend's timeout
+    try:
+      dvd.gather_records([], device=device, failed=True)
+    except dvd.PeerFailed:
+      pass
+    raise
   per_rank = dvd.gather_records(sink.records, device=device)
   if rank == 0:
     for r, records in enumerate(per_rank):

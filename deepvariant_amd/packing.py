@@ -358,20 +358,43 @@ class ReadTable:
   def from_cram(cls, path: str, fetch_reference, contig: Optional[str] = None, start: int = 0,
                 end: int = 1 << 62, min_mapping_quality: int = 0, keep_duplicates: bool = False,
                 keep_supplementary: bool = False, keep_secondary: bool = False, keep_failed_qc: bool = False,
-                keep_improperly_placed: bool = False, use_original_quality_scores: bool = False) -> 'ReadTable':
-    """CRAM 3.0 -> packed table: the same reads, in the same order, `from_bam` yields for the BAM
-    of the same alignments (deepvariant_amd/cram_reader.py decodes on the host;
-    `fetch_reference(contig, start, end)` supplies the bases a CRAM written against an external
-    reference leaves out -- the reference's --use_ref_for_cram)."""
-    from deepvariant_amd import cram_reader
-    from deepvariant_amd import genomics_io
-    _, reads = cram_reader.read_cram(path, fetch_reference, contig, start, min(end, 1 << 62),
-                                     use_original_quality_scores=use_original_quality_scores)
-    kept = [r for r in reads if genomics_io.read_satisfies_requirements(
-        r, min_mapping_quality=min_mapping_quality, keep_duplicates=keep_duplicates, keep_failed_qc=keep_failed_qc,
-        keep_secondary=keep_secondary, keep_supplementary=keep_supplementary,
-        keep_improperly_placed=keep_improperly_placed)]
-    return cls.from_reads(kept)
+                keep_improperly_placed: bool = False, use_original_quality_scores: bool = False,
+                n_threads: int = 4) -> 'ReadTable':
+    """Native CRAM 3.0 -> packed table (dv_cram_read_region, include/dvhip.h;
+    deepvariant_amd/csrc/cram_reader.cpp): the same reads, in the same order, `from_bam` yields for
+    the BAM of the same alignments.  `fetch_reference(contig, start, end) -> bases` supplies what a
+    CRAM written against an external reference leaves out (the reference's --use_ref_for_cram);
+    None = embedded references only."""
+    import ctypes as C
+    lib = _lib.lib()
+    req = _lib.DvReadRequirements(int(keep_duplicates), int(keep_failed_qc), int(keep_secondary),
+                                  int(keep_supplementary), int(keep_improperly_placed),
+                                  int(min_mapping_quality), int(use_original_quality_scores))
+    raised = []
+
+    def fetch(_ctx, name, lo, hi, out, n_out):
+      try:
+        bases = fetch_reference(name.decode(), int(lo), int(hi)).encode('latin-1')[:max(0, hi - lo)]
+        C.memmove(out, bases, len(bases))
+        n_out[0] = len(bases)
+        return 0
+      except BaseException as e:      # pylint: disable=broad-except   (re-raised below, on the caller's thread)
+        raised.append(e)
+        return 1
+    callback = _lib.REF_FETCH_FN(fetch) if fetch_reference is not None else C.cast(None, _lib.REF_FETCH_FN)
+    handle = C.c_void_p()
+    status = lib.dv_cram_read_region(
+        path.encode(), contig.encode() if contig is not None else None, int(start), int(min(end, (1 << 62))),
+        C.byref(req), callback, None, int(n_threads), C.byref(handle))
+    if raised:
+      raise raised[0]
+    if status in (_lib.DV_ERR_BAD_INPUT, _lib.DV_ERR_UNSUPPORTED):      # what the Python decoder raises for the same files
+      raise ValueError(_lib.last_error())
+    _lib.check(status)
+    try:
+      return cls._from_native_table(handle)
+    finally:
+      lib.dv_read_table_free(handle)
 
   @classmethod
   def from_bam(cls, path: str, contig: Optional[str] = None, start: int = 0,
@@ -392,35 +415,42 @@ class ReadTable:
         path.encode(), contig.encode() if contig is not None else None, int(start),
         int(min(end, (1 << 62))), C.byref(req), int(n_threads), C.byref(handle)))
     try:
-      b = _lib.DvBatch()
-      _lib.check(lib.dv_read_table_fill_batch(handle, C.byref(b)))
-      n = b.n_reads
-
-      def arr(ptr, dtype, count):
-        if not count:
-          return np.zeros(0, dtype)
-        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-        return np.frombuffer(buf, dtype=dtype, count=count).copy()
-
-      ends = arr(lib.dv_read_table_ends(handle), np.int64, n)
-      blob, offs, rns, nbytes = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
-      _lib.check(lib.dv_read_table_names(handle, C.byref(blob), C.byref(offs), C.byref(rns),
-                                         C.byref(nbytes)))
-      names = bytes(arr(blob.value, np.uint8, nbytes.value)).decode().split('\0')[:n]
-      read_numbers = arr(rns.value, np.uint8, n)
-      keys = ['%s/%d' % (nm, rn) for nm, rn in zip(names, read_numbers.tolist())]
-      return cls(
-          n_reads=n, read_pos=arr(b.read_pos, np.int32, n), read_sort_pos=None,
-          read_seq_off=arr(b.read_seq_off, np.uint32, n + 1),
-          read_cigar_off=arr(b.read_cigar_off, np.uint32, n + 1),
-          read_mapq=arr(b.read_mapq, np.uint8, n), read_flags=arr(b.read_flags, np.uint8, n),
-          read_frag_len=arr(b.read_frag_len, np.int32, n), read_hp=arr(b.read_hp, np.int32, n),
-          read_name_rank=arr(b.read_name_rank, np.uint32, n), read_aux=None,
-          bases=arr(b.bases, np.uint8, b.n_bases), quals=arr(b.quals, np.uint8, b.n_bases),
-          mod_5mc=None, mod_6ma=None, cigar=arr(b.cigar, np.uint32, b.n_cigar), keys=keys,
-          read_end=ends)
+      return cls._from_native_table(handle)
     finally:
       lib.dv_read_table_free(handle)
+
+  @classmethod
+  def _from_native_table(cls, handle) -> 'ReadTable':
+    """Copies a dv_read_table (what the native BAM / CRAM decoders return) into numpy arrays."""
+    import ctypes as C
+    lib = _lib.lib()
+    b = _lib.DvBatch()
+    _lib.check(lib.dv_read_table_fill_batch(handle, C.byref(b)))
+    n = b.n_reads
+
+    def arr(ptr, dtype, count):
+      if not count:
+        return np.zeros(0, dtype)
+      buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+      return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+    ends = arr(lib.dv_read_table_ends(handle), np.int64, n)
+    blob, offs, rns, nbytes = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    _lib.check(lib.dv_read_table_names(handle, C.byref(blob), C.byref(offs), C.byref(rns),
+                                       C.byref(nbytes)))
+    names = bytes(arr(blob.value, np.uint8, nbytes.value)).decode().split('\0')[:n]
+    read_numbers = arr(rns.value, np.uint8, n)
+    keys = ['%s/%d' % (nm, rn) for nm, rn in zip(names, read_numbers.tolist())]
+    return cls(
+        n_reads=n, read_pos=arr(b.read_pos, np.int32, n), read_sort_pos=None,
+        read_seq_off=arr(b.read_seq_off, np.uint32, n + 1),
+        read_cigar_off=arr(b.read_cigar_off, np.uint32, n + 1),
+        read_mapq=arr(b.read_mapq, np.uint8, n), read_flags=arr(b.read_flags, np.uint8, n),
+        read_frag_len=arr(b.read_frag_len, np.int32, n), read_hp=arr(b.read_hp, np.int32, n),
+        read_name_rank=arr(b.read_name_rank, np.uint32, n), read_aux=None,
+        bases=arr(b.bases, np.uint8, b.n_bases), quals=arr(b.quals, np.uint8, b.n_bases),
+        mod_5mc=None, mod_6ma=None, cigar=arr(b.cigar, np.uint32, b.n_cigar), keys=keys,
+        read_end=ends)
 
   def to_reads(self, reference_name: str) -> List:
     """Read objects (dv_types.Read) back from the packed table -- what the region chain's host

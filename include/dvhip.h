@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 4
+#define DV_ABI_VERSION 5
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -291,6 +291,26 @@ typedef struct dv_read_table dv_read_table; /* owns host arrays in dv_batch's re
  * optional, mapq >= 0), in file order. */
 int dv_bam_read_region(const char* path, const char* contig, int64_t start, int64_t end,
                        const dv_read_requirements* req, int n_threads, dv_read_table** out);
+/* ---- CRAM 3.0 -> the same packed read table (host only) ------------------------
+ * Replaces the CRAM side of SamReader (third_party/nucleus/io/sam_reader.cc:560-640: hts_open +
+ * hts_set_opt(CRAM_OPT_REFERENCE) for SamReaderOptions.ref_path / --use_ref_for_cram, :1022-1035
+ * the query iterator, :734-840 ConvertToPb).  `fetch` supplies the bases of the FASTA the file
+ * was written against: it is asked for [start, end) of `contig` (0-based, half open), writes up to
+ * end - start bases into `out` (fewer at a contig's end: *n_out), returns 0 on success; it may be
+ * entered from a worker thread of the call, one thread at a time.  NULL = decode from the slices'
+ * embedded references only (--nouse_ref_for_cram); a slice that needs the external reference is
+ * then DV_ERR_BAD_INPUT, as is a FASTA whose MD5 differs from the slice header's.  With
+ * `<path>.crai` present and a contig given, only the containers the index lists are decoded
+ * (without one the container headers are walked); slices decode on `n_threads` threads.  Same
+ * rows, in the same order, dv_bam_read_region returns for the BAM of the same alignments. */
+typedef int (*dv_ref_fetch_fn)(void* ctx, const char* contig, int64_t start, int64_t end,
+                               char* out, int64_t* n_out);
+int dv_cram_read_region(const char* path, const char* contig, int64_t start, int64_t end,
+                        const dv_read_requirements* req, dv_ref_fetch_fn fetch, void* fetch_ctx,
+                        int n_threads, dv_read_table** out);
+/* The SAM header text of a CRAM (its first container): `needed` = its length; up to
+ * `capacity` bytes are copied to `text` (may be NULL). */
+int dv_cram_header(const char* path, char* text, uint64_t capacity, uint64_t* needed);
 /* Points the read-table fields of `b` (n_reads, read_*, bases, quals, cigar, n_bases,
  * n_cigar; memory = DV_MEM_HOST) at the table's arrays; item / list fields are left
  * alone.  The table must outlive the batch. */

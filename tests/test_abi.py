@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
   for sym in declared:
     assert hasattr(l, sym), sym
   assert sorted(_lib.ABI_SYMBOLS) == declared
-  assert l.dv_abi_version() == 4   # 4: dv_realign_regions (the window realigner over a batch of regions)
+  assert l.dv_abi_version() == 5   # 4: dv_realign_regions; 5: dv_cram_read_region (native CRAM 3.0 decoder)
 
 
 def test_host_helpers_need_no_gpu():

@@ -88,3 +88,33 @@ def test_gather_records_world2():
   for _, got, empty in results:
     assert got == [want0, want1]
     assert empty == [[], []]
+
+
+def _failing_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from deepvariant_amd import dist as dvd
+  try:
+    dvd.gather_records([b'x'] * (rank + 1), failed=(rank == 1))
+    q.put((rank, 'returned'))
+  except dvd.PeerFailed as e:
+    q.put((rank, str(e)))
+  dist.destroy_process_group()
+
+
+def test_a_failed_rank_releases_its_peers_at_the_record_exchange():
+  """make_examples --gpus N: a rank whose region loop raised joins the first exchange with a failure flag, so
+  the healthy ranks leave with PeerFailed at once instead of waiting for the backend's timeout."""
+  world = 2
+  port = _free_port()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = dict(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert results[0] == results[1] == 'rank 1 failed before the record exchange'
