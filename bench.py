@@ -1033,7 +1033,24 @@ def cpu_baseline(host_batch, opts, C, sample):
   t0 = time.perf_counter()
   sub = _first_items(host_batch, n_enc)
   imgs, _ = O.encode_packed(opts, sub, C, n_threads=cores)
-  t_enc = time.perf_counter() - t0
+  t_enc = t_enc_port = time.perf_counter() - t0
+  # The encoder leg on the REFERENCE's own code where its build travelled with the repo (oracle/_ref/libdvref.so:
+  # deepvariant/pileup_image_native.cc, pileup_channel_lib.cc, channels/*.cc compiled unmodified, oracle/ref_build/):
+  # same packed sample re-expanded into Read / DeepVariantCall objects, BuildPileupForOneSample per candidate, on
+  # the same threads.  Its pixels must equal the oracle's; its time is the encoder time of the baseline.
+  encoder_kind, ref_note = 'port', 'reference encoder build not present (oracle/_ref/libdvref.so)'
+  try:
+    if O.reference_available():
+      with O.reference_backend():
+        t0 = time.perf_counter()
+        ref_imgs, _ = O.encode_packed(opts, sub, C, n_threads=cores)
+        t_ref = time.perf_counter() - t0
+      if not np.array_equal(ref_imgs, imgs):
+        raise RuntimeError('the reference build and the oracle restatement drew different pileups')
+      t_enc, encoder_kind = t_ref, 'reference'
+      ref_note = 'pixels equal the oracle restatement\'s on all %d candidates' % n_enc
+  except Exception as e:      # pylint: disable=broad-except   (the baseline is context: never fail the bench on it)
+    ref_note = 'reference encoder leg failed: %s' % e
   n_cnn = min(n_enc, 256)
   ref = inception_ref.make_random_model(C, seed=1)
   x = torch.from_numpy(imgs.reshape(-1, opts.height, opts.width, C)[:n_cnn])
@@ -1073,11 +1090,14 @@ def cpu_baseline(host_batch, opts, C, sample):
       'host_logical_cpus': os.cpu_count(),
       'cores_used': used * best_threads if node_rate >= one_rate else best_threads,
       'kind': 'port',
-      'sample': '%d candidates encoded by the C++ oracle on %d threads (%.2f s) '
-                '+ fp32 torch-CPU Inception-v3: %d processes x %d threads, each classifying the same %d '
-                'candidates in one batch, concurrently (node rate %.0f/s; one process alone %.0f/s); '
-                'reference binaries cannot be built here (DESIGN.md)' %
-                (n_enc, cores, t_enc, used, best_threads, n_cnn, node_rate, one_rate),
+      'sample': '%d candidates encoded by %s on %d threads (%.2f s; %s) '
+                '+ fp32 torch-CPU Inception-v3 (a port: tf_keras cannot run here): %d processes x %d threads, each '
+                'classifying the same %d candidates in one batch, concurrently (node rate %.0f/s; one process alone '
+                '%.0f/s)' %
+                (n_enc, "the reference's own encoder sources (oracle/_ref)" if encoder_kind == 'reference' else
+                 'the C++ oracle restatement', cores, t_enc, ref_note, used, best_threads, n_cnn, node_rate, one_rate),
+      'encoder_kind': encoder_kind,
+      'encoder_candidates_per_s_port': n_enc / t_enc_port,
       'cnn_threads': best_threads,
       'cnn_processes': used,
       'cnn_channels_last': best_cl,

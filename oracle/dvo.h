@@ -14,9 +14,11 @@
  *                                         CalculateRefRows)
  *   deepvariant/channels/ *.cc            (per-channel FillReadBase / FillRefBase)
  *   deepvariant/pileup_image_native.h    (FillPileupArray: CHW rows -> HWC bytes)
- * The reference itself cannot be compiled here (needs protoc-generated headers,
- * abseil, bazel), so parity is pinned by the reference's own
- * known-answer vectors and golden TFRecords (tests/test_oracle_*.py).
+ * Parity is pinned by the reference's own known-answer vectors and golden
+ * TFRecords (tests/test_oracle_*.py) AND by the reference itself: its encoder
+ * sources compile here, unmodified, against generated structs and small abseil
+ * stand-ins (oracle/ref_build/ -> oracle/_ref/libdvref.so, which exports this same
+ * interface); tests/test_reference_encoder_cpu.py holds the two against each other.
  *
  * Inputs are proto-shaped (names as strings, allele_support as string lists):
  * the oracle does the reference's string matching itself, it does not consume

@@ -12,6 +12,7 @@
 // the reference's static_cast<int>(254.0f * x)).
 
 #include "dvo.h"
+#include "packed_adapter.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1115,105 +1116,27 @@ int dvo_read_overlaps(const dvo_read* read, int64_t start, int64_t end) {
   return ReadOverlaps(*read, start, end);
 }
 
-// Re-expand one packed item into proto-shaped inputs and run BuildPileup.
+// Re-expand one packed item into proto-shaped inputs (oracle/packed_adapter.h) and run BuildPileup.
 static int EncodePackedItem(const dvo_options& opt, const dvo_packed_batch& b,
                             int item, int out_channels, uint8_t* out,
                             int32_t* out_rows) {
-  const uint32_t l0 = b.item_list_off[item], l1 = b.item_list_off[item + 1];
-  const int n = static_cast<int>(l1 - l0);
-  std::vector<dvo_read> reads(n);
-  std::vector<std::string> names(n);
-  std::vector<std::vector<int32_t>> ops(n);
-  std::vector<std::vector<int64_t>> lens(n);
-  std::vector<int64_t> sort_pos(n);
-  // A synthetic DeepVariantCall whose allele_support reproduces the codes:
-  // "ALT_IN" is in alt_alleles (code 1), "ALT_OTHER" is not (code 2).
-  std::vector<std::string> in_names, other_names;
-  for (int i = 0; i < n; ++i) {
-    const uint32_t r = b.list_read[l0 + i];
-    char buf[16];
-    snprintf(buf, sizeof(buf), "%010u", b.read_name_rank[r]);
-    names[i] = buf;
-    dvo_read& rd = reads[i];
-    memset(&rd, 0, sizeof(rd));
-    rd.fragment_name = names[i].c_str();
-    rd.read_number = 0;
-    rd.position = b.read_pos[r];
-    sort_pos[i] = b.read_sort_pos ? b.read_sort_pos[r] : b.read_pos[r];
-    rd.mapping_quality = b.read_mapq[r];
-    rd.reverse_strand = b.read_flags[r] & 1;
-    rd.supplementary = (b.read_flags[r] >> 1) & 1;
-    rd.fragment_length = b.read_frag_len[r];
-    const uint32_t s0 = b.read_seq_off[r], s1 = b.read_seq_off[r + 1];
-    rd.seq = reinterpret_cast<const char*>(b.bases + s0);
-    rd.seq_len = s1 - s0;
-    rd.qual = b.quals + s0;
-    rd.qual_len = s1 - s0;
-    for (uint32_t c = b.read_cigar_off[r]; c < b.read_cigar_off[r + 1]; ++c) {
-      ops[i].push_back(b.cigar[c] & 0xF);
-      lens[i].push_back(b.cigar[c] >> 4);
-    }
-    rd.cigar_ops = ops[i].data();
-    rd.cigar_lens = lens[i].data();
-    rd.n_cigar = ops[i].size();
-    if (b.read_hp[r] != INT32_MIN) {
-      rd.hp_present = 1;
-      rd.hp_n_values = 1;
-      rd.hp_is_int = 1;
-      rd.hp_value = b.read_hp[r];
-    }
-    if (b.mod_5mc && (b.read_flags[r] & 4)) {
-      rd.mod_5mc = b.mod_5mc + s0;
-      rd.mod_5mc_len = s1 - s0;
-    }
-    if (b.mod_6ma && (b.read_flags[r] & 8)) {
-      rd.mod_6ma = b.mod_6ma + s0;
-      rd.mod_6ma_len = s1 - s0;
-    }
-    const std::string key = names[i] + "/0";
-    if (b.list_code[l0 + i] == 1) in_names.push_back(key);
-    if (b.list_code[l0 + i] == 2) other_names.push_back(key);
-  }
-  if (b.list_group != nullptr && opt.sort_by_alt_allele_support) {
-    g_error = "packed adapter: sort_by_alt_allele_support not supported";
+  std::string error;
+  const int kept = dvo_adapter::ExpandPackedItem(
+      opt, b, item, &error,
+      [&](const dvo_call& call, const std::string& ref, const dvo_read* reads, int n, int image_start,
+          const char* const* alt_alleles, int n_alt_alleles, int h, float mean_cov, const int64_t* sort_pos,
+          const int32_t* blank, int n_blank) {
+        std::vector<Row> rows;
+        std::vector<int> row_read;
+        const int k = BuildPileup(opt, call, ref, reads, n, image_start, alt_alleles, n_alt_alleles, h, mean_cov,
+                                  sort_pos, blank, n_blank, &rows, &row_read);
+        if (k >= 0) FillPileupArray(rows, out_channels, out + b.item_out_off[item]);
+        return k;
+      });
+  if (kept < 0) {
+    if (!error.empty()) g_error = error;
     return -1;
   }
-  const char* alts[2] = {"ALT_IN", "ALT_OTHER"};
-  std::vector<const char*> support_names;
-  for (auto& s : in_names) support_names.push_back(s.c_str());
-  for (auto& s : other_names) support_names.push_back(s.c_str());
-  int32_t support_offsets[3] = {0, static_cast<int32_t>(in_names.size()),
-                                static_cast<int32_t>(support_names.size())};
-  dvo_call call;
-  memset(&call, 0, sizeof(call));
-  call.variant_start = b.item_variant_start[item];
-  call.n_alts = 2;
-  call.alts = alts;
-  call.n_support = 2;
-  call.support_alleles = alts;
-  call.support_offsets = support_offsets;
-  call.support_names = support_names.data();
-  const char* alt_alleles[1] = {"ALT_IN"};
-
-  const int h = b.item_height[item];
-  std::vector<Row> rows;
-  std::vector<int> row_read;
-  std::string ref(reinterpret_cast<const char*>(b.ref_windows) +
-                      static_cast<size_t>(b.item_ref_idx[item]) * opt.width,
-                  opt.width);
-  std::vector<int32_t> blank;
-  if (b.item_blank_mask != nullptr) {
-    for (int c = 0; c < opt.n_channels; ++c) {
-      if ((b.item_blank_mask[item] >> c) & 1u) blank.push_back(opt.channels[c]);
-    }
-  }
-  const float mean_cov = b.item_mean_coverage ? b.item_mean_coverage[item] : 0.0f;
-  int kept = BuildPileup(opt, call, ref, reads.data(), n,
-                         b.item_image_start[item], alt_alleles, 1, h, mean_cov,
-                         sort_pos.data(), blank.data(),
-                         static_cast<int>(blank.size()), &rows, &row_read);
-  if (kept < 0) return -1;
-  FillPileupArray(rows, out_channels, out + b.item_out_off[item]);
   if (out_rows) out_rows[item] = kept;
   return 0;
 }

@@ -9,6 +9,7 @@ restatement in encoder_oracle.cpp.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -18,17 +19,32 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'libdvoracle.so')
+# The REFERENCE's own encoder sources, compiled from where they lie by oracle/ref_build/Makefile (only where
+# /root/reference exists; the built library travels to the GPU box): same C interface, same symbols.
+_REF_LIB_PATH = os.path.join(_HERE, '_ref', 'libdvref.so')
+_REFERENCE_ROOT = os.environ.get('DV_REFERENCE_ROOT', '/root/reference')
 DVO_MAX_CHANNELS = 32
 
 
 def build(force: bool = False) -> str:
   """Compiles the oracle with the committed Makefile (g++)."""
-  src = os.path.join(_HERE, 'encoder_oracle.cpp')
+  srcs = [os.path.join(_HERE, f) for f in ('encoder_oracle.cpp', 'dvo.h', 'packed_adapter.h')]
   if (force or not os.path.exists(_LIB_PATH) or
-      os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+      os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)):
     subprocess.check_call(['make', '-C', _HERE, 'libdvoracle.so'],
                           stdout=subprocess.DEVNULL)
   return _LIB_PATH
+
+
+def build_reference() -> Optional[str]:
+  """oracle/_ref/libdvref.so: the reference's own pileup_image_native.cc / pileup_channel_lib.cc / channels/*.cc,
+  unmodified, behind dvo.h (oracle/ref_build/: mini_protoc.py + shims + dvref_capi.cc).  Built where the
+  reference tree is present (make decides what is stale); elsewhere the prebuilt file is used.  None when
+  neither exists."""
+  if os.path.isdir(os.path.join(_REFERENCE_ROOT, 'deepvariant', 'channels')):
+    subprocess.check_call(['make', '-C', os.path.join(_HERE, 'ref_build'), '-j8', 'REF=' + _REFERENCE_ROOT],
+                          stdout=subprocess.DEVNULL)
+  return _REF_LIB_PATH if os.path.exists(_REF_LIB_PATH) else None
 
 
 class DvoOptions(C.Structure):
@@ -122,14 +138,49 @@ class DvoPackedBatch(C.Structure):
 _lib = None
 
 
+_ref_lib = None
+
+
+def _load(path):
+  l = C.CDLL(path)
+  l.dvo_last_error.restype = C.c_char_p
+  l.dvo_channel_str_to_enum.argtypes = [C.c_char_p]
+  return l
+
+
 def lib():
   global _lib
   if _lib is None:
     build()
-    _lib = C.CDLL(_LIB_PATH)
-    _lib.dvo_last_error.restype = C.c_char_p
-    _lib.dvo_channel_str_to_enum.argtypes = [C.c_char_p]
+    _lib = _load(_LIB_PATH)
   return _lib
+
+
+def reference_available() -> bool:
+  return build_reference() is not None
+
+
+def is_reference_backend() -> bool:
+  return hasattr(lib(), 'dvo_is_reference')
+
+
+@contextlib.contextmanager
+def reference_backend():
+  """Inside the block every function of this module (encode_read, build_pileup, encode_packed, ...) runs the
+  REFERENCE's own encoder (oracle/_ref/libdvref.so) instead of the restatement.  `row_read` results are -2 for
+  read rows there (the reference does not say which read a row shows)."""
+  global _lib, _ref_lib
+  if _ref_lib is None:
+    path = build_reference()
+    if path is None:
+      raise OracleError('oracle/_ref/libdvref.so is not built and %s is not here to build it from' % _REFERENCE_ROOT)
+    _ref_lib = _load(path)
+  lib()
+  saved, _lib = _lib, _ref_lib
+  try:
+    yield
+  finally:
+    _lib = saved
 
 
 class OracleError(RuntimeError):

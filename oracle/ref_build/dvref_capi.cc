@@ -1,0 +1,386 @@
+// dvref_capi.cc -- the REFERENCE's own pileup encoder behind the oracle's C interface (oracle/dvo.h).
+//
+// TEST INFRASTRUCTURE.  oracle/ref_build/Makefile compiles, from where they lie under /root/reference and
+// UNMODIFIED, deepvariant/pileup_image_native.cc, deepvariant/pileup_channel_lib.cc and deepvariant/channels/*.cc
+// (against headers mini_protoc.py generates from the reference's .proto files and the small abseil / protobuf
+// stand-ins under shims/) and links them with this file into oracle/_ref/libdvref.so.  This file is the only
+// code of ours in that library: it turns the proto-shaped C inputs of dvo.h into the message objects the
+// reference's classes take and copies their ImageRows out with the reference's own FillPileupArray.
+//
+// The library exports the SAME symbols as libdvoracle.so (dvo_*), so oracle/oracle.py drives either with the
+// same ctypes code: tests/test_reference_encoder_cpu.py holds the restatement (encoder_oracle.cpp) against the
+// reference itself on the known-answer vectors, the golden pileups and seeded fuzz inputs, and bench.py's
+// cpu_baseline times this library ("kind": "reference").
+//
+// Differences from a bazel build of the same sources, all outside what is compared: LOG(FATAL) / CHECK failures
+// throw (returned as an error code) instead of aborting; google::protobuf::Map iterates in key order;
+// absl::Uniform (non-uniform downsampling only) draws from the standard library.
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "deepvariant/channels/read_supports_variant_fuzzy_channel.h"
+#include "deepvariant/pileup_channel_lib.h"
+#include "deepvariant/pileup_image_native.h"
+#include "deepvariant/protos/deepvariant.pb.h"
+#include "dvo.h"
+#include "packed_adapter.h"
+#include "third_party/nucleus/protos/range.pb.h"
+#include "third_party/nucleus/protos/reads.pb.h"
+#include "third_party/nucleus/util/utils.h"
+
+namespace learning {
+namespace genomics {
+namespace deepvariant {
+// defined in pileup_image_native.cc:153 (not declared in its header)
+std::vector<int> DownsampleReadIndices(const std::vector<const ::nucleus::genomics::v1::Read*>& reads, int max_reads,
+                                       std::mt19937_64 gen);
+}  // namespace deepvariant
+}  // namespace genomics
+}  // namespace learning
+
+namespace {
+
+namespace dv = learning::genomics::deepvariant;
+using nucleus::genomics::v1::CigarUnit;
+using nucleus::genomics::v1::Read;
+
+thread_local std::string g_error;
+
+int fail(const std::string& m) {
+  g_error = m;
+  return -1;
+}
+
+// channel names the reference's ChannelStrToEnum knows (pileup_channel_lib.h:60-101), for the way back from
+// dvo_options.channels (enum values) to PileupImageOptions.channels (names)
+const char* const kChannelNames[] = {
+    "read_base", "base_quality", "mapping_quality", "strand", "read_supports_variant", "read_supports_variant_fuzzy",
+    "base_differs_from_ref", "read_mapping_percent", "haplotype", "allele_frequency", "avg_base_quality", "identity",
+    "gap_compressed_identity", "gc_content", "is_homopolymer", "homopolymer_weighted", "blank", "insert_size",
+    "mean_coverage", "base_methylation", "base_6ma", "supplementary_alignment", "allele_sample_probability",
+};
+
+const char* ChannelName(int channel_enum) {
+  for (const char* name : kChannelNames) {
+    if (static_cast<int>(dv::Channels::ChannelStrToEnum(name)) == channel_enum) return name;
+  }
+  return nullptr;
+}
+
+bool MakeOptions(const dvo_options& o, dv::PileupImageOptions* p) {
+  p->set_width(o.width);
+  p->set_height(o.height);
+  p->set_reference_band_height(o.reference_band_height);
+  p->set_base_color_offset_a_and_g(o.base_color_offset_a_and_g);
+  p->set_base_color_offset_t_and_c(o.base_color_offset_t_and_c);
+  p->set_base_color_stride(o.base_color_stride);
+  p->set_allele_supporting_read_alpha(o.allele_supporting_read_alpha);
+  p->set_allele_unsupporting_read_alpha(o.allele_unsupporting_read_alpha);
+  p->set_other_allele_supporting_read_alpha(o.other_allele_supporting_read_alpha);
+  p->set_reference_matching_read_alpha(o.reference_matching_read_alpha);
+  p->set_reference_mismatching_read_alpha(o.reference_mismatching_read_alpha);
+  if (o.indel_anchoring_base_char) p->set_indel_anchoring_base_char(std::string(1, static_cast<char>(o.indel_anchoring_base_char)));
+  p->set_reference_base_quality(o.reference_base_quality);
+  p->set_positive_strand_color(o.positive_strand_color);
+  p->set_negative_strand_color(o.negative_strand_color);
+  p->set_base_quality_cap(o.base_quality_cap);
+  p->set_mapping_quality_cap(o.mapping_quality_cap);
+  p->mutable_read_requirements()->set_min_base_quality(o.min_base_quality);
+  p->mutable_read_requirements()->set_min_mapping_quality(o.min_mapping_quality);
+  p->set_random_seed(o.random_seed);
+  p->set_sort_by_haplotypes(o.sort_by_haplotypes != 0);
+  p->set_hp_tag_for_assembly_polishing(o.hp_tag_for_assembly_polishing);
+  p->set_sort_by_alt_allele_support(o.sort_by_alt_allele_support != 0);
+  p->set_min_non_zero_allele_frequency(o.min_non_zero_allele_frequency);
+  p->set_num_channels(o.n_channels);
+  for (int c = 0; c < o.n_channels; ++c) {
+    const char* name = ChannelName(o.channels[c]);
+    if (!name) return false;
+    p->add_channels(name);
+  }
+  return true;
+}
+
+void MakeRead(const dvo_read& r, Read* read) {
+  read->set_fragment_name(r.fragment_name ? r.fragment_name : "");
+  read->set_read_number(r.read_number);
+  auto* aln = read->mutable_alignment();
+  aln->mutable_position()->set_reference_name("contig");
+  aln->mutable_position()->set_position(r.position);
+  aln->mutable_position()->set_reverse_strand(r.reverse_strand != 0);
+  aln->set_mapping_quality(r.mapping_quality);
+  for (int i = 0; i < r.n_cigar; ++i) {
+    auto* cu = aln->add_cigar();
+    cu->set_operation(static_cast<CigarUnit::Operation>(r.cigar_ops[i]));
+    cu->set_operation_length(r.cigar_lens[i]);
+  }
+  read->set_supplementary_alignment(r.supplementary != 0);
+  read->set_fragment_length(r.fragment_length);
+  read->set_aligned_sequence(std::string(r.seq ? r.seq : "", static_cast<size_t>(r.seq_len)));
+  read->set_aligned_quality(std::string(reinterpret_cast<const char*>(r.qual), static_cast<size_t>(r.qual_len)));
+  if (r.hp_present) {
+    auto& hp = (*read->mutable_info())["HP"];
+    for (int i = 0; i < r.hp_n_values; ++i) {
+      auto* v = hp.add_values();
+      if (i == 0 && !r.hp_is_int) {
+        v->set_string_value("1");
+      } else {
+        v->set_int_value(i == 0 ? r.hp_value : 0);
+      }
+    }
+  }
+  if (r.mod_5mc) {
+    (*read->mutable_base_modifications())["5mC"] = std::string(reinterpret_cast<const char*>(r.mod_5mc), static_cast<size_t>(r.mod_5mc_len));
+  }
+  if (r.mod_6ma) {
+    (*read->mutable_base_modifications())["6mA"] = std::string(reinterpret_cast<const char*>(r.mod_6ma), static_cast<size_t>(r.mod_6ma_len));
+  }
+}
+
+void MakeCall(const dvo_call& c, dv::DeepVariantCall* call) {
+  auto* v = call->mutable_variant();
+  v->set_start(c.variant_start);
+  if (c.reference_bases) v->set_reference_bases(c.reference_bases);
+  for (int i = 0; i < c.n_alts; ++i) v->add_alternate_bases(c.alts[i]);
+  for (int i = 0; i < c.n_rejected_alts; ++i) v->add_alternate_bases_rejected(c.rejected_alts[i]);
+  for (int s = 0; s < c.n_support; ++s) {
+    auto& sr = (*call->mutable_allele_support())[c.support_alleles[s]];
+    for (int n = c.support_offsets[s]; n < c.support_offsets[s + 1]; ++n) sr.add_read_names(c.support_names[n]);
+  }
+  for (int s = 0; s < c.n_rejected_support; ++s) {
+    auto& sr = (*call->mutable_rejected_allele_support())[c.rejected_support_alleles[s]];
+    for (int n = c.rejected_support_offsets[s]; n < c.rejected_support_offsets[s + 1]; ++n) {
+      sr.add_read_names(c.rejected_support_names[n]);
+    }
+  }
+  for (int i = 0; i < c.n_af; ++i) (*call->mutable_allele_frequency())[c.af_alleles[i]] = c.af_values[i];
+  for (int i = 0; i < c.n_ref_support; ++i) {
+    call->add_ref_support(c.ref_support_names ? c.ref_support_names[i] : "");
+  }
+  if (c.alt_ps_present) {
+    auto& ps = (*v->mutable_info())["ALT_PS"];
+    for (int i = 0; i < c.n_alt_ps; ++i) ps.add_values()->set_int_value(c.alt_ps[i]);
+  }
+}
+
+absl::flat_hash_set<dv::DeepVariantChannelEnum> BlankSet(const int32_t* blank, int n) {
+  absl::flat_hash_set<dv::DeepVariantChannelEnum> out;
+  for (int i = 0; i < n; ++i) out.insert(static_cast<dv::DeepVariantChannelEnum>(blank[i]));
+  return out;
+}
+
+std::vector<std::string> Strings(const char* const* a, int n) {
+  std::vector<std::string> out;
+  for (int i = 0; i < n; ++i) out.emplace_back(a[i]);
+  return out;
+}
+
+// FillPileupArray of the reference (pileup_image_native.h:214-335, AltAlignedPileup::kNone), then widened to
+// c_total channels per pixel when the caller's tensor has more (the oracle pads the same way).
+void CopyOut(const std::vector<std::unique_ptr<dv::ImageRow>>& rows, int n_channels, int c_total, uint8_t* out) {
+  if (rows.empty()) return;
+  const size_t w = static_cast<size_t>(rows[0]->Width());
+  std::vector<uint8_t> dense(rows.size() * w * static_cast<size_t>(n_channels));
+  dv::FillPileupArray(absl::MakeConstSpan(rows), absl::Span<const std::vector<std::unique_ptr<dv::ImageRow>>>(),
+                      dv::AltAlignedPileup::kNone, &dense, static_cast<int>(dense.size()), 0);
+  if (c_total == n_channels) {
+    std::memcpy(out, dense.data(), dense.size());
+    return;
+  }
+  size_t src = 0, dst = 0;
+  for (size_t px = 0; px < rows.size() * w; ++px) {
+    for (int c = 0; c < n_channels; ++c) out[dst++] = dense[src++];
+    for (int c = n_channels; c < c_total; ++c) out[dst++] = 0;
+  }
+}
+
+int BuildPileup(const dvo_options& opt, const dvo_call& call, const std::string& ref_bases, const dvo_read* reads,
+                int n_reads, int image_start_pos, const char* const* alt_alleles, int n_alt_alleles, int pileup_height,
+                float mean_coverage, const int64_t* alignment_positions, const int32_t* blank, int n_blank, int c_total,
+                uint8_t* out, int32_t* row_read = nullptr) {
+  dv::PileupImageOptions options;
+  if (!MakeOptions(opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
+  dv::PileupImageEncoderNative encoder(options);
+  dv::DeepVariantCall dv_call;
+  MakeCall(call, &dv_call);
+  std::vector<Read> protos(static_cast<size_t>(n_reads));
+  std::vector<const Read*> ptrs;
+  for (int i = 0; i < n_reads; ++i) {
+    MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+    ptrs.push_back(&protos[static_cast<size_t>(i)]);
+  }
+  dv::SampleOptions sample;
+  sample.set_pileup_height(pileup_height);
+  std::vector<int64_t> positions;
+  if (alignment_positions) positions.assign(alignment_positions, alignment_positions + n_reads);
+  auto rows = encoder.BuildPileupForOneSample(dv_call, ref_bases, ptrs, image_start_pos, Strings(alt_alleles, n_alt_alleles),
+                                              sample, mean_coverage, alignment_positions ? &positions : nullptr,
+                                              BlankSet(blank, n_blank));
+  CopyOut(rows, opt.n_channels, c_total, out);
+  // The reference does not say how many reads it drew: rows below the band that hold any nonzero byte
+  int kept = 0;
+  const size_t row_bytes = ref_bases.size() * static_cast<size_t>(c_total);
+  for (size_t r = static_cast<size_t>(opt.reference_band_height); r < rows.size(); ++r) {
+    bool any = false;
+    for (size_t k = 0; k < row_bytes && !any; ++k) any = out[r * row_bytes + k] != 0;
+    if (row_read) row_read[r] = any ? -2 : -1;
+    kept += any ? 1 : 0;
+  }
+  if (row_read) {
+    for (int r = 0; r < opt.reference_band_height && r < static_cast<int>(rows.size()); ++r) row_read[r] = -1;
+  }
+  return kept;
+}
+
+template <class F>
+int Guard(F f) {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    return fail(e.what());
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dvo_last_error(void) { return g_error.c_str(); }
+
+int dvo_is_reference(void) { return 1; }
+
+int dvo_channel_str_to_enum(const char* name) {
+  return Guard([&] { return static_cast<int>(dv::Channels::ChannelStrToEnum(name)); });
+}
+
+int dvo_encode_reference(const dvo_options* opt, const char* ref_bases, int w, uint8_t* out_hwc) {
+  return Guard([&] {
+    dv::PileupImageOptions options;
+    if (!MakeOptions(*opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
+    dv::PileupImageEncoderNative encoder(options);
+    std::vector<std::unique_ptr<dv::ImageRow>> rows;
+    rows.push_back(encoder.EncodeReference(std::string(ref_bases, static_cast<size_t>(w))));
+    CopyOut(rows, opt->n_channels, opt->n_channels, out_hwc);
+    return 0;
+  });
+}
+
+int dvo_encode_read(const dvo_options* opt, const dvo_call* call, const char* ref_bases, int w, const dvo_read* read,
+                    int32_t image_start_pos, const char* const* alt_alleles, int n_alt_alleles,
+                    const int32_t* channels_to_blank, int n_blank, uint8_t* out_hwc) {
+  return Guard([&] {
+    dv::PileupImageOptions options;
+    if (!MakeOptions(*opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
+    dv::PileupImageEncoderNative encoder(options);
+    dv::DeepVariantCall dv_call;
+    MakeCall(*call, &dv_call);
+    Read proto;
+    MakeRead(*read, &proto);
+    std::vector<std::unique_ptr<dv::ImageRow>> rows;
+    rows.push_back(encoder.EncodeRead(dv_call, std::string(ref_bases, static_cast<size_t>(w)), proto, image_start_pos,
+                                      Strings(alt_alleles, n_alt_alleles), BlankSet(channels_to_blank, n_blank)));
+    if (!rows[0]) return 0;
+    CopyOut(rows, opt->n_channels, opt->n_channels, out_hwc);
+    return 1;
+  });
+}
+
+/* out_row_read: the reference does not say which read a row shows; read rows come back as -2, the others -1,
+ * and the return value counts the rows below the band that hold any nonzero byte. */
+int dvo_build_pileup(const dvo_options* opt, const dvo_call* call, const char* ref_bases, int w, const dvo_read* reads,
+                     int n_reads, int32_t image_start_pos, const char* const* alt_alleles, int n_alt_alleles,
+                     int pileup_height, float mean_coverage, const int64_t* alignment_positions,
+                     const int32_t* channels_to_blank, int n_blank, uint8_t* out_hwc, int32_t* out_row_read) {
+  return Guard([&] {
+    return BuildPileup(*opt, *call, std::string(ref_bases, static_cast<size_t>(w)), reads, n_reads, image_start_pos,
+                       alt_alleles, n_alt_alleles, pileup_height, mean_coverage, alignment_positions, channels_to_blank,
+                       n_blank, opt->n_channels, out_hwc, out_row_read);
+  });
+}
+
+int dvo_fuzzy_read_supports_alt(const dvo_call* call, const dvo_read* read, const char* const* alt_alleles,
+                                int n_alt_alleles) {
+  return Guard([&] {
+    dv::PileupImageOptions options;
+    options.set_width(221);
+    dv::ReadSupportsVariantFuzzyChannel channel(221, options);
+    dv::DeepVariantCall dv_call;
+    MakeCall(*call, &dv_call);
+    Read proto;
+    MakeRead(*read, &proto);
+    const std::vector<std::string> alts = Strings(alt_alleles, n_alt_alleles);
+    return channel.ReadSupportsAlt(dv_call, proto, alts);
+  });
+}
+
+int dvo_downsample_indices(int n, int max_reads, uint32_t seed, int32_t* out) {
+  return Guard([&] {
+    std::vector<const Read*> reads(static_cast<size_t>(n), nullptr);   // only the count is looked at
+    const std::vector<int> idx = dv::DownsampleReadIndices(reads, max_reads, std::mt19937_64(seed));
+    for (int i = 0; i < n; ++i) out[i] = idx[static_cast<size_t>(i)];
+    return 0;
+  });
+}
+
+/* nucleus::ReadOverlapsRegion (third_party/nucleus/util/utils.cc:172-240) on one contig. */
+int dvo_read_overlaps(const dvo_read* read, int64_t start, int64_t end) {
+  return Guard([&] {
+    Read proto;
+    MakeRead(*read, &proto);
+    nucleus::genomics::v1::Range range;
+    range.set_reference_name("contig");
+    range.set_start(start);
+    range.set_end(end);
+    return nucleus::ReadOverlapsRegion(proto, range) ? 1 : 0;
+  });
+}
+
+int dvo_encode_packed(const dvo_options* opt, const dvo_packed_batch* b, int out_channels, uint8_t* out,
+                      int32_t* out_rows, int n_threads) {
+  if (out_channels < opt->n_channels) return fail("out_channels too small");
+  auto one = [&](int item) -> int {
+    return Guard([&] {
+      std::string error;
+      const int rc = dvo_adapter::ExpandPackedItem(
+          *opt, *b, item, &error,
+          [&](const dvo_call& call, const std::string& ref, const dvo_read* reads, int n, int image_start,
+              const char* const* alt_alleles, int n_alt_alleles, int h, float mean_cov, const int64_t* sort_pos,
+              const int32_t* blank, int n_blank) {
+            return BuildPileup(*opt, call, ref, reads, n, image_start, alt_alleles, n_alt_alleles, h, mean_cov, sort_pos,
+                               blank, n_blank, out_channels, out + b->item_out_off[item]);
+          });
+      if (rc < 0 && !error.empty()) return fail(error);
+      if (rc >= 0 && out_rows) out_rows[item] = rc;
+      return rc < 0 ? -1 : 0;
+    });
+  };
+  if (n_threads <= 1) {
+    for (int i = 0; i < b->n_items; ++i) {
+      if (one(i) != 0) return -1;
+    }
+    return 0;
+  }
+  std::vector<std::thread> threads;
+  std::vector<std::string> errors(static_cast<size_t>(n_threads));
+  for (int t = 0; t < n_threads; ++t) {
+    threads.emplace_back([&, t]() {
+      for (int i = t; i < b->n_items; i += n_threads) {
+        if (one(i) != 0) {
+          errors[static_cast<size_t>(t)] = g_error.empty() ? "worker failed" : g_error;
+          return;
+        }
+      }
+    });
+  }
+  for (auto& th : threads) th.join();
+  for (const std::string& e : errors) {
+    if (!e.empty()) return fail("dvo_encode_packed (reference): " + e);
+  }
+  return 0;
+}
+
+}  // extern "C"

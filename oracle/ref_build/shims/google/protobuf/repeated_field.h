@@ -1,0 +1,2 @@
+// TEST INFRASTRUCTURE: see mini_runtime.h
+#include "google/protobuf/mini_runtime.h"

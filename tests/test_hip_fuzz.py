@@ -42,6 +42,36 @@ def test_fuzz_build_pileup(name, channels, width, height, okw, ckw):
     np.testing.assert_array_equal(got, want, err_msg='%s trial %d' % (name, trial))
 
 
+@pytest.mark.parametrize('name,channels,width,height,okw,ckw', CONFIGS)
+def test_fuzz_build_pileup_against_the_reference_build(name, channels, width, height, okw, ckw):
+  """The same shapes against the REFERENCE's own encoder (oracle/_ref/libdvref.so: its pileup_image_native.cc /
+  pileup_channel_lib.cc / channels/*.cc compiled unmodified, oracle/ref_build/) instead of the restatement: the HIP
+  kernel's pixels equal the reference's, with nothing of ours in between but the input marshalling."""
+  from deepvariant_amd.pileup_image_native import PileupImageEncoderNative
+  from oracle import oracle as O
+  if not O.reference_available():
+    pytest.skip('oracle/_ref/libdvref.so was not built (no reference tree where build() ran)')
+  rng = np.random.default_rng(zlib.crc32(name.encode()) ^ 0x5bd1e995)
+  opts = _options(channels, width, height, **dict(okw))
+  enc = PileupImageEncoderNative(opts)
+  so = T.SampleOptions(pileup_height=height)
+  for trial in range(8):
+    n_reads = int(rng.choice([0, 2, 10, height, height + 30, 3 * height]))
+    call, ref, reads, start, combo = F.make_case(rng, width, n_reads, **dict(ckw))
+    if 'avg_base_quality' in channels:  # reference aborts on quals > 93
+      for r in reads:
+        r.aligned_quality = bytes(min(q, 93) for q in r.aligned_quality)
+    mc = float(rng.integers(0, height + 5)) if 'mean_coverage' in channels else 0.0
+    blank = [int(T.CHANNEL_STR_TO_ENUM[channels[int(rng.integers(0, len(channels)))]])] \
+        if trial % 3 == 0 else None
+    got = enc.build_pileup_for_one_sample(call, ref, reads, start, combo, so,
+                                          mean_coverage=mc, channels_to_blank=blank)
+    with O.reference_backend():
+      want = O.build_pileup(opts, call, ref, reads, start, combo, pileup_height=height,
+                            mean_coverage=mc, channels_to_blank=blank)
+    np.testing.assert_array_equal(got, want, err_msg='%s trial %d' % (name, trial))
+
+
 def test_empty_batch_and_bad_arguments():
   import ctypes as C
   from deepvariant_amd import _lib, packing, synth
