@@ -113,13 +113,19 @@ class VariantCaller:
     if options.fraction_reference_sites_to_emit > 0:
       raise NotImplementedError('fraction_reference_sites_to_emit (reference-site sampling)')
     self._options = options
+    import numpy as np
+    self._min_fraction_f32 = (float(np.float32(options.min_fraction_indels)), float(np.float32(options.min_fraction_snps)))
 
   # ---- thresholds
   def _min_count(self, allele) -> int:
     return self._options.min_count_snps if allele.type == ac.SUBSTITUTION else self._options.min_count_indels
 
   def _min_fraction(self, allele) -> float:
-    return self._options.min_fraction_snps if allele.type == ac.SUBSTITUTION else self._options.min_fraction_indels
+    # VariantCallerOptions.min_fraction_* are proto `float` fields: the reference compares the double ratio
+    # count / total with the threshold ROUNDED TO FLOAT32 (variant_calling_multisample.cc:250-254).  float32(0.1) is
+    # above 0.1, so an allele at exactly 10 % is rejected there; comparing with the Python double would keep it
+    # (found by tests/test_reference_calling_cpu.py, which runs the reference's own caller).
+    return self._min_fraction_f32[allele.type == ac.SUBSTITUTION]
 
   def is_good_alt_allele(self, allele, total_count: int) -> bool:
     """IsGoodAltAllele (:232-238)."""

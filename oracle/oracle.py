@@ -507,3 +507,105 @@ def encode_packed(pic_options, batch, out_channels=None, n_threads=1):
   if rc != 0:
     raise _err()
   return out, rows[:batch.n_items]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Candidate generation on the REFERENCE's own code (oracle/_ref/libdvref.so: deepvariant/allelecounter.cc +
+# deepvariant/variant_calling_multisample.cc compiled unmodified, one sample): the checker of
+# oracle/allelecounter_ref.py and deepvariant_amd/variant_calling.py.  tests/ only.
+# ---------------------------------------------------------------------------------------------------------------
+class DvrCallingOptions(C.Structure):
+  _fields_ = [
+      ('partition_size', C.c_int32), ('min_mapping_quality', C.c_int32), ('min_base_quality', C.c_int32),
+      ('track_ref_reads', C.c_int32), ('normalize_reads', C.c_int32), ('keep_legacy_behavior', C.c_int32),
+      ('call_variants', C.c_int32), ('min_count_snps', C.c_int32), ('min_count_indels', C.c_int32),
+      ('min_fraction_snps', C.c_float), ('min_fraction_indels', C.c_float), ('min_fraction_multiplier', C.c_float),
+      ('p_error', C.c_float), ('max_gq', C.c_int32), ('gq_resolution', C.c_int32), ('ploidy', C.c_int32),
+      ('call_positions_only', C.c_int32),
+  ]
+
+
+def reference_count_and_call(ref_reader, contig: str, start: int, end: int, reads, sample: str = 'sample',
+                             candidate_positions=(), full_range=None, min_mapping_quality=0, min_base_quality=0,
+                             track_ref_reads=False, normalize_reads=False, keep_legacy_behavior=False,
+                             caller: Optional[dict] = None, call_positions_only=False, contig_length: int = 1 << 40,
+                             ref_margin: int = 2000):
+  """The reference's AlleleCounter over [start, end) of `contig`, fed with `reads` in order, and -- with `caller`
+  = dict(min_count_snps=, min_count_indels=, min_fraction_snps=, min_fraction_indels=, ...) -- its multi-sample
+  VariantCaller with this one sample as the target.
+
+  -> (counts, calls, positions): counts = {position: (ref_base, ref_supporting_read_count, {read key: (bases,
+  type, is_low_quality)})} for the positions that hold anything; calls = list of dicts (start, end,
+  reference_bases, alternate_bases, allele_support, ref_support, allele_support_ext, ref_support_ext, info,
+  call_set_name, genotype); positions = CallPositionsFromAlleleCounts when asked for."""
+  if not reference_available():
+    raise OracleError('oracle/_ref/libdvref.so is not available')
+  global _ref_lib
+  if _ref_lib is None:
+    _ref_lib = _load(_REF_LIB_PATH)
+  L = _ref_lib
+  keep = _Keep()
+  arr = (DvoRead * max(len(reads), 1))()
+  for i, rd in enumerate(reads):
+    _fill_read(arr[i], rd, keep)
+  lo = max(0, min(start, full_range[0] if full_range else start) - ref_margin)
+  hi = min(contig_length, max(end, full_range[1] if full_range else end) + ref_margin)
+  bases = ref_reader.get_bases(contig, lo, hi).encode()
+  o = DvrCallingOptions()
+  o.partition_size = max(1, end - start)
+  o.min_mapping_quality, o.min_base_quality = int(min_mapping_quality), int(min_base_quality)
+  o.track_ref_reads, o.normalize_reads = int(bool(track_ref_reads)), int(bool(normalize_reads))
+  o.keep_legacy_behavior = int(bool(keep_legacy_behavior))
+  o.call_variants = int(caller is not None)
+  c = dict(min_count_snps=2, min_count_indels=2, min_fraction_snps=0.12, min_fraction_indels=0.06,
+           min_fraction_multiplier=1.0, p_error=0.001, max_gq=50, gq_resolution=1, ploidy=2)
+  c.update(caller or {})
+  for k, v in c.items():
+    setattr(o, k, v)
+  o.call_positions_only = int(bool(call_positions_only))
+  cand = keep(np.array(list(candidate_positions) or [0], dtype=np.int32))
+  out, n = C.c_char_p(), C.c_uint64()
+  L.dvr_count_and_call.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+  fs, fe = full_range if full_range else (0, 0)
+  out_p = C.c_void_p()
+  rc = L.dvr_count_and_call(contig.encode(), contig_length, lo, bases, len(bases), start, end, fs, fe, arr, len(reads),
+                            sample.encode(), cand.ctypes.data, len(candidate_positions), C.byref(o), C.byref(out_p),
+                            C.byref(n))
+  if rc != 0:
+    raise OracleError(L.dvo_last_error().decode())
+  text = C.string_at(out_p.value, n.value).decode()
+  L.dvr_free.argtypes = [C.c_void_p]
+  L.dvr_free(out_p)
+  counts, calls, positions = {}, [], []
+  cur = None
+  for line in text.split('\n'):
+    if not line:
+      continue
+    f = line.split('\t')
+    if f[0] == 'C':
+      cur = {}
+      counts[int(f[1])] = (f[2], int(f[3]), cur)
+    elif f[0] == 'A':
+      cur[f[1]] = (f[2], int(f[3]), bool(int(f[4])))
+    elif f[0] == 'V':
+      calls.append(dict(start=int(f[1]), end=int(f[2]), reference_bases=f[3], alternate_bases=f[4].split(',') if f[4] else [],
+                        allele_support={}, ref_support=[], allele_support_ext={}, ref_support_ext=[], info={},
+                        call_set_name=None, genotype=None))
+    elif f[0] == 'S':
+      calls[-1]['allele_support'][f[1]] = f[2].split(',') if f[2] else []
+    elif f[0] == 'R':
+      calls[-1]['ref_support'] = f[1].split(',') if f[1] else []
+    elif f[0] == 'E':
+      calls[-1]['allele_support_ext'][f[1]] = [(x.rsplit(':', 1)[0], bool(int(x.rsplit(':', 1)[1]))) for x in f[2].split(',') if x]
+    elif f[0] == 'F':
+      calls[-1]['ref_support_ext'] = [(x.rsplit(':', 1)[0], bool(int(x.rsplit(':', 1)[1]))) for x in f[1].split(',') if x]
+    elif f[0] == 'G':
+      calls[-1]['call_set_name'] = f[1]
+      calls[-1]['genotype'] = [int(x) for x in f[2].split(',')] if f[2] else []
+    elif f[0] == 'I':
+      calls[-1]['info'][f[1]] = [float(x) if ('.' in x or 'e' in x or 'n' in x) else int(x) for x in f[2].split(',')] if f[2] else []
+    elif f[0] == 'P':
+      positions.append(int(f[1]))
+  return counts, calls, positions

@@ -384,3 +384,209 @@ int dvo_encode_packed(const dvo_options* opt, const dvo_packed_batch* b, int out
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Candidate generation: the reference's AlleleCounter (deepvariant/allelecounter.cc) and its multi-sample
+// VariantCaller (deepvariant/variant_calling_multisample.cc, what make_examples runs -- with ONE sample here),
+// compiled unmodified like the encoder above.  SURVEY.md 8f row f2.  One call counts a region and, if asked,
+// calls its candidates; results come back as tab-separated text (oracle/oracle.py parses it).
+// ---------------------------------------------------------------------------------------------------------------
+#include <sstream>
+#include <unordered_map>
+
+#include "deepvariant/allelecounter.h"
+#include "deepvariant/variant_calling_multisample.h"
+#include "third_party/nucleus/io/reference.h"
+
+namespace {
+
+// nucleus::GenomeReference over one stretch of one contig handed in by the test
+class WindowReference : public nucleus::GenomeReference {
+ public:
+  WindowReference(const std::string& contig, int64_t contig_length, int64_t start, std::string bases)
+      : start_(start), bases_(std::move(bases)) {
+    contigs_.emplace_back();
+    contigs_.back().set_name(contig);
+    contigs_.back().set_n_bases(contig_length);
+  }
+  const std::vector<nucleus::genomics::v1::ContigInfo>& Contigs() const override { return contigs_; }
+  nucleus::StatusOr<std::string> GetBases(const nucleus::genomics::v1::Range& range) const override {
+    if (!IsValidInterval(range)) return nucleus::InvalidArgument("Invalid interval");
+    if (range.start() < start_ || range.end() > start_ + static_cast<int64_t>(bases_.size())) {
+      return nucleus::OutOfRange("the test handed in no reference bases for this interval");
+    }
+    return bases_.substr(static_cast<size_t>(range.start() - start_), static_cast<size_t>(range.end() - range.start()));
+  }
+
+ private:
+  int64_t start_;
+  std::string bases_;
+  std::vector<nucleus::genomics::v1::ContigInfo> contigs_;
+};
+
+std::string Join(const google::protobuf::RepeatedPtrField<std::string>& v) {
+  std::string out;
+  for (int i = 0; i < v.size(); ++i) {
+    if (i) out += ',';
+    out += v[i];
+  }
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+typedef struct dvr_calling_options {
+  /* AlleleCounterOptions (deepvariant.proto) */
+  int32_t partition_size;
+  int32_t min_mapping_quality;
+  int32_t min_base_quality;
+  int32_t track_ref_reads;
+  int32_t normalize_reads;
+  int32_t keep_legacy_behavior;
+  /* VariantCallerOptions; call_variants = 0 -> counts only */
+  int32_t call_variants;
+  int32_t min_count_snps;
+  int32_t min_count_indels;
+  float min_fraction_snps;
+  float min_fraction_indels;
+  float min_fraction_multiplier;
+  float p_error;
+  int32_t max_gq;
+  int32_t gq_resolution;
+  int32_t ploidy;
+  int32_t call_positions_only; /* CallPositionsFromAlleleCounts instead of CallsFromAlleleCounts */
+} dvr_calling_options;
+
+void dvr_free(char* p) { std::free(p); }
+
+/* Lines:  C <position> <ref_base> <ref_supporting_read_count>      one per position that holds anything
+ *         A <read key> <bases> <type> <is_low_quality>             the read alleles of the position above, key order
+ *         V <start> <end> <reference_bases> <alt,alt,...>          one per DeepVariantCall
+ *         S <allele> <read name,read name,...>                     allele_support of the call above (key order)
+ *         R <read name,...>                                        ref_support
+ *         E <allele> <name:is_low_quality,...>                     allele_support_ext
+ *         F <name:is_low_quality,...>                              ref_support_ext
+ *         I <key> <v,v,...>                                        calls(0).info of the variant (AD, DP, VAF, ...)
+ *         G <sample name> <genotype,...>                           calls(0)
+ *         P <position>                                             (call_positions_only) */
+int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_start, const char* ref_bases,
+                       int64_t n_ref_bases, int64_t start, int64_t end, int64_t full_start, int64_t full_end,
+                       const dvo_read* reads, int n_reads, const char* sample, const int32_t* candidate_positions,
+                       int n_candidate_positions, const dvr_calling_options* o, char** out, uint64_t* out_len) {
+  return Guard([&] {
+    WindowReference ref(contig, contig_length, ref_start, std::string(ref_bases, static_cast<size_t>(n_ref_bases)));
+    dv::AlleleCounterOptions co;
+    co.set_partition_size(o->partition_size);
+    co.mutable_read_requirements()->set_min_mapping_quality(o->min_mapping_quality);
+    co.mutable_read_requirements()->set_min_base_quality(o->min_base_quality);
+    co.set_track_ref_reads(o->track_ref_reads != 0);
+    co.set_normalize_reads(o->normalize_reads != 0);
+    co.set_keep_legacy_behavior(o->keep_legacy_behavior != 0);
+    nucleus::genomics::v1::Range range, full;
+    range.set_reference_name(contig);
+    range.set_start(start);
+    range.set_end(end);
+    full.set_reference_name(contig);
+    full.set_start(full_start);
+    full.set_end(full_end);
+    const std::vector<int> positions(candidate_positions, candidate_positions + n_candidate_positions);
+    std::unique_ptr<dv::AlleleCounter> counter(
+        full_end > full_start ? new dv::AlleleCounter(&ref, range, full, positions, co)
+                              : new dv::AlleleCounter(&ref, range, positions, co));
+    for (int i = 0; i < n_reads; ++i) {
+      Read proto;
+      MakeRead(reads[i], &proto);
+      proto.mutable_alignment()->mutable_position()->set_reference_name(contig);
+      if (o->normalize_reads) {
+        std::unique_ptr<std::vector<CigarUnit>> norm_cigar(new std::vector<CigarUnit>());
+        int shift = 0;
+        counter->NormalizeAndAdd(proto, sample, norm_cigar, shift);
+      } else {
+        counter->Add(proto, sample);
+      }
+    }
+    std::ostringstream text;
+    for (const dv::AlleleCount& c : counter->Counts()) {
+      if (c.ref_supporting_read_count() == 0 && c.read_alleles().empty()) continue;
+      text << "C\t" << c.position().position() << '\t' << c.ref_base() << '\t' << c.ref_supporting_read_count() << '\n';
+      for (const auto& kv : c.read_alleles()) {
+        text << "A\t" << kv.first << '\t' << kv.second.bases() << '\t' << static_cast<int>(kv.second.type()) << '\t'
+             << (kv.second.is_low_quality() ? 1 : 0) << '\n';
+      }
+    }
+    if (o->call_variants) {
+      dv::VariantCallerOptions vo;
+      vo.set_min_count_snps(o->min_count_snps);
+      vo.set_min_count_indels(o->min_count_indels);
+      vo.set_min_fraction_snps(o->min_fraction_snps);
+      vo.set_min_fraction_indels(o->min_fraction_indels);
+      vo.set_min_fraction_multiplier(o->min_fraction_multiplier);
+      vo.set_sample_name(sample);
+      vo.set_p_error(o->p_error);
+      vo.set_max_gq(o->max_gq);
+      vo.set_gq_resolution(o->gq_resolution);
+      vo.set_ploidy(o->ploidy);
+      vo.set_track_ref_reads(o->track_ref_reads != 0);
+      dv::multi_sample::VariantCaller caller(vo);
+      std::unordered_map<std::string, dv::AlleleCounter*> counters{{sample, counter.get()}};
+      if (o->call_positions_only) {
+        for (int p : caller.CallPositionsFromAlleleCounts(counters, sample)) text << "P\t" << p << '\n';
+      } else {
+        for (const dv::DeepVariantCall& call : caller.CallsFromAlleleCounts(counters, sample)) {
+          const auto& v = call.variant();
+          text << "V\t" << v.start() << '\t' << v.end() << '\t' << v.reference_bases() << '\t' << Join(v.alternate_bases()) << '\n';
+          for (const auto& kv : call.allele_support()) text << "S\t" << kv.first << '\t' << Join(kv.second.read_names()) << '\n';
+          if (call.ref_support_size()) text << "R\t" << Join(call.ref_support()) << '\n';
+          for (const auto& kv : call.allele_support_ext()) {
+            text << "E\t" << kv.first << '\t';
+            for (int i = 0; i < kv.second.read_infos_size(); ++i) {
+              text << (i ? "," : "") << kv.second.read_infos(i).read_name() << ':' << (kv.second.read_infos(i).is_low_quality() ? 1 : 0);
+            }
+            text << '\n';
+          }
+          if (call.ref_support_ext().read_infos_size()) {
+            text << "F\t";
+            for (int i = 0; i < call.ref_support_ext().read_infos_size(); ++i) {
+              text << (i ? "," : "") << call.ref_support_ext().read_infos(i).read_name() << ':'
+                   << (call.ref_support_ext().read_infos(i).is_low_quality() ? 1 : 0);
+            }
+            text << '\n';
+          }
+          if (v.calls_size()) {
+            const auto& vc = v.calls(0);
+            text << "G\t" << vc.call_set_name() << '\t';
+            for (int i = 0; i < vc.genotype_size(); ++i) text << (i ? "," : "") << vc.genotype(i);
+            text << '\n';
+            for (const auto& kv : vc.info()) {
+              text << "I\t" << kv.first << '\t';
+              for (int i = 0; i < kv.second.values_size(); ++i) {
+                const auto& val = kv.second.values(i);
+                text << (i ? "," : "");
+                if (val.kind_case() == nucleus::genomics::v1::Value::kIntValue) {
+                  text << val.int_value();
+                } else if (val.kind_case() == nucleus::genomics::v1::Value::kNumberValue) {
+                  char buf[64];
+                  std::snprintf(buf, sizeof(buf), "%.17g", val.number_value());
+                  text << buf;
+                } else {
+                  text << val.string_value();
+                }
+              }
+              text << '\n';
+            }
+          }
+        }
+      }
+    }
+    const std::string s = text.str();
+    *out = static_cast<char*>(std::malloc(s.size() + 1));
+    std::memcpy(*out, s.data(), s.size());
+    (*out)[s.size()] = 0;
+    *out_len = s.size();
+    return 0;
+  });
+}
+
+}  // extern "C"

@@ -445,6 +445,9 @@ class Generator:
           bodies.append('inline %s* %s::mutable_%s() { %sreturn %s_.mutable_get(); }' % (ct, cls, n, guard_set, n))
           bodies.append('inline void %s::clear_%s() { %s_.reset(); }' % (cls, n, n))
           members.append('  ::google::protobuf::mini::Box<%s> %s_;' % (ct, n))
+      # (text format is only ever used inside the reference's log / CHECK messages)
+      w('  std::string DebugString() const { return "<%s>"; }' % cls)
+      w('  std::string ShortDebugString() const { return "<%s>"; }' % cls)
       w('  void Clear() { *this = %s(); }' % cls)
       w('  void CopyFrom(const %s& other) { *this = other; }' % cls)
       w(' private:')

@@ -2,10 +2,11 @@
 #ifndef DVREF_ABSL_FLAT_HASH_SET_H_
 #define DVREF_ABSL_FLAT_HASH_SET_H_
 #include <unordered_set>
+#include "absl/hash/hash.h"
 namespace absl {
-template <class T, class H = std::hash<T>, class E = std::equal_to<T>>
+template <class T, class H = absl::Hash<T>, class E = absl::dvref_hash::DefaultEq<T>>
 using flat_hash_set = std::unordered_set<T, H, E>;
-template <class T, class H = std::hash<T>, class E = std::equal_to<T>>
+template <class T, class H = absl::Hash<T>, class E = absl::dvref_hash::DefaultEq<T>>
 using node_hash_set = std::unordered_set<T, H, E>;
 }
 #endif

@@ -6,7 +6,11 @@
 #define GOOGLE_PROTOBUF_MINI_RUNTIME_H_
 
 #include <stdexcept>
+#include <cstddef>
+#include <initializer_list>
+#include <iterator>
 #include <map>
+#include <type_traits>
 #include <memory>
 #include <string>
 #include <string_view>
@@ -29,21 +33,148 @@ class RepeatedField : public std::vector<T> {
   T* mutable_data() { return this->data(); }
 };
 
+// Elements are held through pointers, as in libprotobuf: pointer_begin() / pointer_end() expose the pointer array
+// (the reference sorts alternate_bases through it), everything else sees T&.
 template <class T>
-class RepeatedPtrField : public std::vector<T> {
+class RepeatedPtrField {
+  template <bool Const>
+  class Iter {
+   public:
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = T;
+    using difference_type = std::ptrdiff_t;
+    using pointer = std::conditional_t<Const, const T*, T*>;
+    using reference = std::conditional_t<Const, const T&, T&>;
+    Iter() : p_(nullptr) {}
+    explicit Iter(T* const* p) : p_(p) {}
+    template <bool C = Const, class = std::enable_if_t<C>>
+    Iter(const Iter<false>& o) : p_(o.raw()) {}
+    reference operator*() const { return **p_; }
+    pointer operator->() const { return *p_; }
+    reference operator[](difference_type n) const { return *p_[n]; }
+    Iter& operator++() { ++p_; return *this; }
+    Iter operator++(int) { Iter t = *this; ++p_; return t; }
+    Iter& operator--() { --p_; return *this; }
+    Iter operator--(int) { Iter t = *this; --p_; return t; }
+    Iter& operator+=(difference_type n) { p_ += n; return *this; }
+    Iter& operator-=(difference_type n) { p_ -= n; return *this; }
+    friend Iter operator+(Iter a, difference_type n) { return a += n; }
+    friend Iter operator+(difference_type n, Iter a) { return a += n; }
+    friend Iter operator-(Iter a, difference_type n) { return a -= n; }
+    friend difference_type operator-(const Iter& a, const Iter& b) { return a.p_ - b.p_; }
+    friend bool operator==(const Iter& a, const Iter& b) { return a.p_ == b.p_; }
+    friend bool operator!=(const Iter& a, const Iter& b) { return a.p_ != b.p_; }
+    friend bool operator<(const Iter& a, const Iter& b) { return a.p_ < b.p_; }
+    friend bool operator>(const Iter& a, const Iter& b) { return a.p_ > b.p_; }
+    friend bool operator<=(const Iter& a, const Iter& b) { return a.p_ <= b.p_; }
+    friend bool operator>=(const Iter& a, const Iter& b) { return a.p_ >= b.p_; }
+    T* const* raw() const { return p_; }
+   private:
+    T* const* p_;
+  };
+
  public:
-  using std::vector<T>::vector;
-  int size() const { return static_cast<int>(std::vector<T>::size()); }
-  const T& Get(int i) const { return (*this)[i]; }
-  T* Mutable(int i) { return &(*this)[i]; }
-  T* Add() {
-    this->emplace_back();
-    return &this->back();
+  using value_type = T;
+  using iterator = Iter<false>;
+  using const_iterator = Iter<true>;
+  using pointer_iterator = T**;
+  using const_pointer_iterator = const T* const*;
+  using size_type = int;
+  using reference = T&;
+  using const_reference = const T&;
+  RepeatedPtrField() = default;
+  RepeatedPtrField(const RepeatedPtrField& o) { for (const T* e : o.v_) v_.push_back(new T(*e)); }
+  RepeatedPtrField(RepeatedPtrField&& o) noexcept : v_(std::move(o.v_)) { o.v_.clear(); }
+  template <class It>
+  RepeatedPtrField(It b, It e) { for (; b != e; ++b) v_.push_back(new T(*b)); }
+  RepeatedPtrField(std::initializer_list<T> l) { for (const T& e : l) v_.push_back(new T(e)); }
+  ~RepeatedPtrField() { Clear(); }
+  RepeatedPtrField& operator=(const RepeatedPtrField& o) {
+    if (this != &o) {
+      Clear();
+      for (const T* e : o.v_) v_.push_back(new T(*e));
+    }
+    return *this;
   }
-  void Add(T&& v) { this->push_back(std::move(v)); }
-  void Add(const T& v) { this->push_back(v); }
-  void Clear() { this->clear(); }
-  void Reserve(int n) { this->reserve(n); }
+  RepeatedPtrField& operator=(RepeatedPtrField&& o) noexcept {
+    if (this != &o) {
+      Clear();
+      v_ = std::move(o.v_);
+      o.v_.clear();
+    }
+    return *this;
+  }
+  int size() const { return static_cast<int>(v_.size()); }
+  bool empty() const { return v_.empty(); }
+  const T& Get(int i) const { return *v_[static_cast<size_t>(i)]; }
+  T* Mutable(int i) { return v_[static_cast<size_t>(i)]; }
+  const T& operator[](int i) const { return *v_[static_cast<size_t>(i)]; }
+  T& operator[](int i) { return *v_[static_cast<size_t>(i)]; }
+  const T& at(int i) const { return *v_.at(static_cast<size_t>(i)); }
+  T& at(int i) { return *v_.at(static_cast<size_t>(i)); }
+  T* Add() {
+    v_.push_back(new T());
+    return v_.back();
+  }
+  void Add(T&& v) { v_.push_back(new T(std::move(v))); }
+  void Add(const T& v) { v_.push_back(new T(v)); }
+  template <class It>
+  void Add(It b, It e) { for (; b != e; ++b) v_.push_back(new T(*b)); }
+  void push_back(const T& v) { v_.push_back(new T(v)); }
+  void push_back(T&& v) { v_.push_back(new T(std::move(v))); }
+  template <class... A>
+  T& emplace_back(A&&... a) {
+    v_.push_back(new T(std::forward<A>(a)...));
+    return *v_.back();
+  }
+  T& back() { return *v_.back(); }
+  const T& back() const { return *v_.back(); }
+  T& front() { return *v_.front(); }
+  const T& front() const { return *v_.front(); }
+  void RemoveLast() {
+    delete v_.back();
+    v_.pop_back();
+  }
+  void DeleteSubrange(int start, int num) {
+    for (int i = start; i < start + num; ++i) delete v_[static_cast<size_t>(i)];
+    v_.erase(v_.begin() + start, v_.begin() + start + num);
+  }
+  iterator erase(const_iterator pos) {
+    const std::ptrdiff_t i = pos.raw() - v_.data();
+    DeleteSubrange(static_cast<int>(i), 1);
+    return iterator(v_.data() + i);
+  }
+  void SwapElements(int a, int b) { std::swap(v_[static_cast<size_t>(a)], v_[static_cast<size_t>(b)]); }
+  void Clear() {
+    for (T* e : v_) delete e;
+    v_.clear();
+  }
+  void clear() { Clear(); }
+  void Reserve(int n) { v_.reserve(static_cast<size_t>(n)); }
+  void reserve(size_t n) { v_.reserve(n); }
+  void Swap(RepeatedPtrField* o) { v_.swap(o->v_); }
+  void CopyFrom(const RepeatedPtrField& o) { *this = o; }
+  void MergeFrom(const RepeatedPtrField& o) { for (const T* e : o.v_) v_.push_back(new T(*e)); }
+  iterator begin() { return iterator(v_.data()); }
+  iterator end() { return iterator(v_.data() + v_.size()); }
+  const_iterator begin() const { return const_iterator(v_.data()); }
+  const_iterator end() const { return const_iterator(v_.data() + v_.size()); }
+  const_iterator cbegin() const { return begin(); }
+  const_iterator cend() const { return end(); }
+  pointer_iterator pointer_begin() { return v_.data(); }
+  pointer_iterator pointer_end() { return v_.data() + v_.size(); }
+  const_pointer_iterator pointer_begin() const { return v_.data(); }
+  const_pointer_iterator pointer_end() const { return v_.data() + v_.size(); }
+  friend bool operator==(const RepeatedPtrField& a, const RepeatedPtrField& b) {
+    if (a.size() != b.size()) return false;
+    for (int i = 0; i < a.size(); ++i) {
+      if (!(a[i] == b[i])) return false;
+    }
+    return true;
+  }
+
+ private:
+  std::vector<T*> v_;
 };
 
 // google::protobuf::Map iterates in an unspecified (hash) order; code whose output depends on that order has no

@@ -94,6 +94,17 @@ def test_min_fraction():
   _check('A', c, [('A', REF, n * 100), ('C', SUB, n), ('G', SUB, n)])
 
 
+def test_min_fraction_is_a_float32_threshold():
+  """VariantCallerOptions.min_fraction_* are proto `float`s: the reference compares the double ratio with the
+  threshold rounded to float32 (variant_calling_multisample.cc:250-254).  float32(0.1) > 0.1, so exactly 10 % is
+  rejected; float32(0.12) < 0.12, so exactly 12 % is kept.  (Found by running the reference's own caller:
+  tests/test_reference_calling_cpu.py.)"""
+  _check('A', _caller(2, 0.1), [('A', REF, 27), ('C', SUB, 3)])                                # 3 / 30 == 0.1
+  _check('A', _caller(2, 0.1), [('A', REF, 26), ('C', SUB, 3)], 'A', ['C'], [26, 3])           # 3 / 29 > 0.1
+  _check('A', _caller(2, 0.12), [('A', REF, 22), ('C', SUB, 3)], 'A', ['C'], [22, 3])          # 3 / 25 == 0.12
+  _check('A', _caller(2, findels=0.1), [('A', REF, 45), ('AC', INS, 5)])                       # 5 / 50 == 0.1
+
+
 def test_min_snp_indel_separately():
   c = _caller(snps=5, indels=10, fsnps=0.1, findels=0.5)
   _check('A', c, [('A', REF, 8), ('C', SUB, 8)], 'A', ['C'], [8, 8])
