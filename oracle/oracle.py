@@ -609,3 +609,37 @@ def reference_count_and_call(ref_reader, contig: str, start: int, end: int, read
     elif f[0] == 'P':
       positions.append(int(f[1]))
   return counts, calls, positions
+
+
+def reference_window_candidates(ref_reader, contig: str, start: int, end: int, reads, min_mapq=20, min_base_quality=20,
+                                keep_legacy_behavior=False, min_allele_support=0, enable_strict_insertion_filter=False,
+                                linear_model=None, contig_length: int = 1 << 40, ref_margin: int = 2000):
+  """deepvariant/realigner/window_selector.cc on the reference's own AlleleCounter over `reads`:
+  -> (reads supporting a variant at every position of [start, end), int32; the linear model's float32 scores, or
+  None).  `linear_model` = (bias, coeff_soft_clip, coeff_substitution, coeff_insertion, coeff_deletion,
+  coeff_reference, decision_boundary)."""
+  if not reference_available():
+    raise OracleError('oracle/_ref/libdvref.so is not available')
+  global _ref_lib
+  if _ref_lib is None:
+    _ref_lib = _load(_REF_LIB_PATH)
+  L = _ref_lib
+  keep = _Keep()
+  arr = (DvoRead * max(len(reads), 1))()
+  for i, rd in enumerate(reads):
+    _fill_read(arr[i], rd, keep)
+  lo, hi = max(0, start - ref_margin), min(contig_length, end + ref_margin)
+  bases = ref_reader.get_bases(contig, lo, hi).encode()
+  counts = np.zeros(end - start, np.int32)
+  scores = np.zeros(end - start, np.float32)
+  lin = keep(np.array(linear_model, np.float32)) if linear_model is not None else None
+  L.dvr_window_candidates.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+  rc = L.dvr_window_candidates(contig.encode(), contig_length, lo, bases, len(bases), start, end, arr, len(reads),
+                               int(min_mapq), int(min_base_quality), int(bool(keep_legacy_behavior)), int(min_allele_support),
+                               int(bool(enable_strict_insertion_filter)), lin.ctypes.data if lin is not None else None,
+                               counts.ctypes.data, scores.ctypes.data)
+  if rc < 0:
+    raise OracleError(L.dvo_last_error().decode())
+  return counts, (scores if linear_model is not None else None)

@@ -590,3 +590,62 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The realigner's window selector (deepvariant/realigner/window_selector.cc, compiled unmodified): per position
+// of [start, end) the number of reads supporting a variant there (VariantReadsWindowSelectorCandidates) and the
+// linear model's score (AlleleCountLinearWindowSelectorCandidates, float32), from the reference's AlleleCounter
+// over the same reads.  SURVEY.md 8f row f4.
+// ---------------------------------------------------------------------------------------------------------------
+#include "deepvariant/protos/realigner.pb.h"
+#include "deepvariant/realigner/window_selector.h"
+
+extern "C" {
+
+/* linear: bias, coeff_soft_clip, coeff_substitution, coeff_insertion, coeff_deletion, coeff_reference,
+ * decision_boundary -- or NULL (out_scores is then left alone). */
+int dvr_window_candidates(const char* contig, int64_t contig_length, int64_t ref_start, const char* ref_bases,
+                          int64_t n_ref_bases, int64_t start, int64_t end, const dvo_read* reads, int n_reads,
+                          int32_t min_mapq, int32_t min_base_quality, int32_t keep_legacy_behavior,
+                          int32_t min_allele_support, int32_t enable_strict_insertion_filter, const float* linear,
+                          int32_t* out_counts, float* out_scores) {
+  return Guard([&] {
+    WindowReference ref(contig, contig_length, ref_start, std::string(ref_bases, static_cast<size_t>(n_ref_bases)));
+    dv::AlleleCounterOptions co;
+    co.set_partition_size(static_cast<int32_t>(end - start));
+    co.mutable_read_requirements()->set_min_mapping_quality(min_mapq);
+    co.mutable_read_requirements()->set_min_base_quality(min_base_quality);
+    co.set_keep_legacy_behavior(keep_legacy_behavior != 0);
+    nucleus::genomics::v1::Range range;
+    range.set_reference_name(contig);
+    range.set_start(start);
+    range.set_end(end);
+    dv::AlleleCounter counter(&ref, range, {}, co);
+    for (int i = 0; i < n_reads; ++i) {
+      Read proto;
+      MakeRead(reads[i], &proto);
+      proto.mutable_alignment()->mutable_position()->set_reference_name(contig);
+      counter.Add(proto, "placeholder_sample_id");
+    }
+    dv::WindowSelectorOptions config;
+    config.set_min_allele_support(min_allele_support);
+    config.set_enable_strict_insertion_filter(enable_strict_insertion_filter != 0);
+    const std::vector<int> counts = dv::VariantReadsWindowSelectorCandidates(counter, config);
+    for (size_t i = 0; i < counts.size(); ++i) out_counts[i] = counts[i];
+    if (linear && out_scores) {
+      dv::WindowSelectorModel::AlleleCountLinearModel model;
+      model.set_bias(linear[0]);
+      model.set_coeff_soft_clip(linear[1]);
+      model.set_coeff_substitution(linear[2]);
+      model.set_coeff_insertion(linear[3]);
+      model.set_coeff_deletion(linear[4]);
+      model.set_coeff_reference(linear[5]);
+      model.set_decision_boundary(linear[6]);
+      const std::vector<float> scores = dv::AlleleCountLinearWindowSelectorCandidates(counter, model);
+      for (size_t i = 0; i < scores.size(); ++i) out_scores[i] = scores[i];
+    }
+    return static_cast<int>(counts.size());
+  });
+}
+
+}  // extern "C"

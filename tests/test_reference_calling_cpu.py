@@ -151,3 +151,38 @@ def test_track_ref_reads_two_pass(seed, long_reads):
   caller = vc.VariantCaller(vc.VariantCallerOptions(sample_name='s', track_ref_reads=True, **caller_kw))
   _check_calls(caller.calls_from_allele_counts(_product_counts(counter, 'c', True)), calls, 's', track_ref_reads=True)
   assert any(c['ref_support'] for c in calls)
+
+
+@pytest.mark.parametrize('seed,long_reads,legacy', [(21, False, False), (22, False, True), (23, True, False)])
+def test_window_selector_models(seed, long_reads, legacy):
+  """deepvariant/realigner/window_selector.cc (compiled unmodified) on the reference's AlleleCounter, against
+  the product's window selector (deepvariant_amd/realigner/window_selector.py) on the oracle's counts: the
+  per-position read-support profile of the VARIANT_READS model -- with and without min_allele_support and the
+  strict insertion filter -- exactly, and the ALLELE_COUNT_LINEAR scores to float32 rounding."""
+  from deepvariant_amd.realigner import window_selector as WS
+  from tests import realigner_fixture as RF
+  rng = np.random.default_rng(seed)
+  seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=5000))
+  ref = _Ref(seq[:1800] + 'N' + seq[1801:])
+  start, end = 1000, 2200
+  reads = _fuzz_reads(rng, ref, 700 if not long_reads else 180, 700, 2300, long_reads)
+  linear = (-0.68, 0.081, 0.073, 0.41, 0.29, -0.012, 3.0)
+  for support, strict in ((0, False), (2, False), (2, True), (3, True)):
+    counts, scores = O.reference_window_candidates(ref, 'c', start, end, reads, min_mapq=20, min_base_quality=20,
+                                                   keep_legacy_behavior=legacy, min_allele_support=support,
+                                                   enable_strict_insertion_filter=strict, linear_model=linear,
+                                                   contig_length=len(seq))
+    counter = RF.OracleAlleleCounter(ref, 'c', start, end, min_mapping_quality=20, min_base_quality=20,
+                                     keep_legacy_behavior=legacy)
+    for r in reads:
+      counter.add(r)
+    config = WS.WindowSelectorOptions(min_allele_support=support, enable_strict_insertion_filter=strict)
+    mine = WS.variant_reads_candidates_from_allele_counter(counter, config)
+    assert mine == counts.tolist() and (support > 0 or max(mine) > 3)
+    model = WS.AlleleCountLinearModel(*linear)
+    got = WS.allele_count_linear_candidates_from_allele_counter(counter, model)
+    # float32 sums: the reference adds a position's read alleles in the iteration order of a protobuf Map -- hash
+    # order there, key order in this build, arrival order in the product -- so the last bit is not defined by the
+    # reference itself; everything above it is
+    assert got.dtype == np.float32 and np.abs(got - scores).max() <= 2e-6, np.abs(got - scores).max()
+    assert ((got > linear[6]) == (scores > linear[6])).mean() > 0.999
