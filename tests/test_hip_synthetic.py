@@ -125,3 +125,31 @@ def test_pileups_deeper_than_the_dense_shuffle_table():
   torch.cuda.synchronize()
   np.testing.assert_array_equal(rows2.cpu().numpy(), want_rows2)
   np.testing.assert_array_equal(out2.cpu().numpy(), want2)
+
+
+@pytest.mark.parametrize('kind,n', [('illumina30', 7700), ('hifi35', 4096), ('ont50', 2048)])
+def test_bench_sized_batches_equal_the_reference_build(kind, n):
+  """BASELINE.json's full sizes against the REFERENCE's own encoder (oracle/_ref/libdvref.so: its sources
+  compiled unmodified, oracle/ref_build/): the 7700-site ILLUMINA30 step of bench.py (about 8100 pileups, 1.25 GB of
+  pixels) and the two long-read workloads, every byte of every pileup and every row count."""
+  import os
+  from deepvariant_amd import synth
+  from deepvariant_amd.pileup_image_native import _Encoder
+  from oracle import oracle as O
+  if not O.reference_available():
+    pytest.skip('oracle/_ref/libdvref.so was not built (no reference tree where build() ran)')
+  if kind == 'illumina30':
+    opts = synth.illumina_options(7)
+    batch = synth.make_illumina_batch(n, options=opts)
+  else:
+    lr = 'hifi' if kind == 'hifi35' else 'ont'
+    opts = synth.longread_options(lr)
+    batch = synth.make_longread_batch(n, lr, options=opts)
+  C = len(opts.channels)
+  out, rows = _Encoder(opts, opts.width).encode(batch, C)
+  threads = max(1, min(32, len(os.sched_getaffinity(0))))
+  with O.reference_backend():
+    want, want_rows = O.encode_packed(opts, batch, C, n_threads=threads)
+  np.testing.assert_array_equal(rows, want_rows)
+  assert out.size == want.size > n * 100 * opts.width * C - 1
+  assert np.array_equal(out, want), 'first differing byte: %d' % int(np.flatnonzero(out != want)[0])
