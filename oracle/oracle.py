@@ -643,3 +643,112 @@ def reference_window_candidates(ref_reader, contig: str, start: int, end: int, r
   if rc < 0:
     raise OracleError(L.dvo_last_error().decode())
   return counts, (scores if linear_model is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The read realigner and the trimmed-read helpers on the reference's own sources (fast_pass_aligner.cc,
+# alt_aligned_pileup_lib.cc in oracle/_ref/libdvref.so; the local aligner under them is the product's libssw
+# restatement, see oracle/ref_build/shims/src/ssw_cpp.h).  tests/ only.
+# ---------------------------------------------------------------------------------------------------------------
+def _ref_text_call(fn_name, argtypes, *args):
+  if not reference_available():
+    raise OracleError('oracle/_ref/libdvref.so is not available')
+  global _ref_lib
+  if _ref_lib is None:
+    _ref_lib = _load(_REF_LIB_PATH)
+  L = _ref_lib
+  fn = getattr(L, fn_name)
+  fn.argtypes = argtypes + [C.c_void_p, C.c_void_p]
+  out_p, n = C.c_void_p(), C.c_uint64()
+  rc = fn(*args, C.byref(out_p), C.byref(n))
+  if rc != 0:
+    raise OracleError(L.dvo_last_error().decode())
+  text = C.string_at(out_p.value, n.value).decode('latin-1')
+  L.dvr_free.argtypes = [C.c_void_p]
+  L.dvr_free(out_p)
+  return text
+
+
+def _parse_read_lines(text):
+  """-> list of None (the empty Read) or dict(name, read_number, position, cigar [(op, len)], seq, qual, mapq,
+  reverse, mod_5mc, mod_6ma[, original_position])."""
+  out = []
+  for line in text.split('\n'):
+    if not line:
+      continue
+    f = line.split('\t')
+    if f[0] == 'E':
+      out.append(None)
+    elif f[0] == 'R':
+      cigar = [tuple(int(x) for x in u.split(':')) for u in f[4].split(',')] if f[4] else []
+      mods = [None if m == '-' else bytes(int(x) for x in m.split(',')) if m else b'' for m in f[9:11]]
+      out.append(dict(name=f[1], read_number=int(f[2]), position=int(f[3]), cigar=cigar, seq=f[5],
+                      qual=bytes(int(x) for x in f[6].split(',')) if f[6] else b'', mapq=int(f[7]), reverse=bool(int(f[8])),
+                      mod_5mc=mods[0], mod_6ma=mods[1]))
+    elif f[0] == 'P':
+      out[-1]['original_position'] = int(f[1])
+  return out
+
+
+def _aligner_options(cfg):
+  keys = ('match', 'mismatch', 'gap_open', 'gap_extend', 'kmer_size', 'read_size', 'max_num_of_mismatches',
+          'force_alignment', 'normalize_reads', 'ref_prefix_len', 'ref_suffix_len')
+  return (C.c_int32 * len(keys))(*[int(cfg.get(k, 0)) for k in keys]), float(cfg.get('realignment_similarity_threshold', 0.0))
+
+
+def _read_array(reads, keep):
+  arr = (DvoRead * max(len(reads), 1))()
+  for i, rd in enumerate(reads):
+    _fill_read(arr[i], rd, keep)
+  return arr
+
+
+def reference_align_reads(reference: str, contig: str, ref_start: int, haplotypes, reads, **cfg):
+  """FastPassAligner::AlignReads (set_options / set_reference / set_ref_start / set_haplotypes as the window
+  realigner and RealignReadsToHaplotype drive it) -> one entry per read (see _parse_read_lines)."""
+  keep = _Keep()
+  opts, sim = _aligner_options(cfg)
+  haps = _str_array(list(haplotypes), keep)
+  text = _ref_text_call('dvr_align_reads', [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_double],
+                        reference.encode(), contig.encode(), int(ref_start), haps, len(haplotypes), _read_array(reads, keep),
+                        len(reads), opts, sim)
+  return _parse_read_lines(text)
+
+
+def reference_trim_reads(reads, contig: str, region_start: int, region_end: int, min_overlap: int = 15):
+  """TrimReads (alt_aligned_pileup_lib.cc:231-248) -> kept reads with `original_position`."""
+  keep = _Keep()
+  text = _ref_text_call('dvr_trim_reads', [C.c_void_p, C.c_int, C.c_char_p, C.c_int64, C.c_int64, C.c_int],
+                        _read_array(reads, keep), len(reads), contig.encode(), int(region_start), int(region_end),
+                        int(min_overlap))
+  return _parse_read_lines(text)
+
+
+def reference_realign_reads_to_haplotype(haplotype: str, reads, contig: str, ref_start: int, ref_end: int, ref_reader,
+                                         contig_length: int, **cfg):
+  """RealignReadsToHaplotype (alt_aligned_pileup_lib.cc:278-313)."""
+  keep = _Keep()
+  opts, sim = _aligner_options(cfg)
+  lo, hi = max(0, ref_start - 100), min(contig_length, ref_end + 100)
+  bases = ref_reader.get_bases(contig, lo, hi).encode()
+  text = _ref_text_call('dvr_realign_reads_to_haplotype',
+                        [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p,
+                         C.c_int64, C.c_void_p, C.c_double],
+                        haplotype.encode(), _read_array(reads, keep), len(reads), contig.encode(), int(ref_start), int(ref_end),
+                        int(contig_length), lo, bases, len(bases), opts, sim)
+  return _parse_read_lines(text)
+
+
+def reference_calculate_alignment_region(contig_length: int, variant_start: int, n_reference_bases: int, half_width: int):
+  if not reference_available():
+    raise OracleError('oracle/_ref/libdvref.so is not available')
+  global _ref_lib
+  if _ref_lib is None:
+    _ref_lib = _load(_REF_LIB_PATH)
+  out = (C.c_int64 * 2)()
+  _ref_lib.dvr_calculate_alignment_region.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+  if _ref_lib.dvr_calculate_alignment_region(b'contig', int(contig_length), int(variant_start), int(n_reference_bases),
+                                             int(half_width), out) != 0:
+    raise OracleError(_ref_lib.dvo_last_error().decode())
+  return int(out[0]), int(out[1])

@@ -44,7 +44,7 @@ std::vector<int> DownsampleReadIndices(const std::vector<const ::nucleus::genomi
 
 namespace {
 
-namespace dv = learning::genomics::deepvariant;
+namespace refdv = learning::genomics::deepvariant;
 using nucleus::genomics::v1::CigarUnit;
 using nucleus::genomics::v1::Read;
 
@@ -66,12 +66,12 @@ const char* const kChannelNames[] = {
 
 const char* ChannelName(int channel_enum) {
   for (const char* name : kChannelNames) {
-    if (static_cast<int>(dv::Channels::ChannelStrToEnum(name)) == channel_enum) return name;
+    if (static_cast<int>(refdv::Channels::ChannelStrToEnum(name)) == channel_enum) return name;
   }
   return nullptr;
 }
 
-bool MakeOptions(const dvo_options& o, dv::PileupImageOptions* p) {
+bool MakeOptions(const dvo_options& o, refdv::PileupImageOptions* p) {
   p->set_width(o.width);
   p->set_height(o.height);
   p->set_reference_band_height(o.reference_band_height);
@@ -141,7 +141,7 @@ void MakeRead(const dvo_read& r, Read* read) {
   }
 }
 
-void MakeCall(const dvo_call& c, dv::DeepVariantCall* call) {
+void MakeCall(const dvo_call& c, refdv::DeepVariantCall* call) {
   auto* v = call->mutable_variant();
   v->set_start(c.variant_start);
   if (c.reference_bases) v->set_reference_bases(c.reference_bases);
@@ -167,9 +167,9 @@ void MakeCall(const dvo_call& c, dv::DeepVariantCall* call) {
   }
 }
 
-absl::flat_hash_set<dv::DeepVariantChannelEnum> BlankSet(const int32_t* blank, int n) {
-  absl::flat_hash_set<dv::DeepVariantChannelEnum> out;
-  for (int i = 0; i < n; ++i) out.insert(static_cast<dv::DeepVariantChannelEnum>(blank[i]));
+absl::flat_hash_set<refdv::DeepVariantChannelEnum> BlankSet(const int32_t* blank, int n) {
+  absl::flat_hash_set<refdv::DeepVariantChannelEnum> out;
+  for (int i = 0; i < n; ++i) out.insert(static_cast<refdv::DeepVariantChannelEnum>(blank[i]));
   return out;
 }
 
@@ -181,12 +181,12 @@ std::vector<std::string> Strings(const char* const* a, int n) {
 
 // FillPileupArray of the reference (pileup_image_native.h:214-335, AltAlignedPileup::kNone), then widened to
 // c_total channels per pixel when the caller's tensor has more (the oracle pads the same way).
-void CopyOut(const std::vector<std::unique_ptr<dv::ImageRow>>& rows, int n_channels, int c_total, uint8_t* out) {
+void CopyOut(const std::vector<std::unique_ptr<refdv::ImageRow>>& rows, int n_channels, int c_total, uint8_t* out) {
   if (rows.empty()) return;
   const size_t w = static_cast<size_t>(rows[0]->Width());
   std::vector<uint8_t> dense(rows.size() * w * static_cast<size_t>(n_channels));
-  dv::FillPileupArray(absl::MakeConstSpan(rows), absl::Span<const std::vector<std::unique_ptr<dv::ImageRow>>>(),
-                      dv::AltAlignedPileup::kNone, &dense, static_cast<int>(dense.size()), 0);
+  refdv::FillPileupArray(absl::MakeConstSpan(rows), absl::Span<const std::vector<std::unique_ptr<refdv::ImageRow>>>(),
+                      refdv::AltAlignedPileup::kNone, &dense, static_cast<int>(dense.size()), 0);
   if (c_total == n_channels) {
     std::memcpy(out, dense.data(), dense.size());
     return;
@@ -202,10 +202,10 @@ int BuildPileup(const dvo_options& opt, const dvo_call& call, const std::string&
                 int n_reads, int image_start_pos, const char* const* alt_alleles, int n_alt_alleles, int pileup_height,
                 float mean_coverage, const int64_t* alignment_positions, const int32_t* blank, int n_blank, int c_total,
                 uint8_t* out, int32_t* row_read = nullptr) {
-  dv::PileupImageOptions options;
+  refdv::PileupImageOptions options;
   if (!MakeOptions(opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
-  dv::PileupImageEncoderNative encoder(options);
-  dv::DeepVariantCall dv_call;
+  refdv::PileupImageEncoderNative encoder(options);
+  refdv::DeepVariantCall dv_call;
   MakeCall(call, &dv_call);
   std::vector<Read> protos(static_cast<size_t>(n_reads));
   std::vector<const Read*> ptrs;
@@ -213,7 +213,7 @@ int BuildPileup(const dvo_options& opt, const dvo_call& call, const std::string&
     MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
     ptrs.push_back(&protos[static_cast<size_t>(i)]);
   }
-  dv::SampleOptions sample;
+  refdv::SampleOptions sample;
   sample.set_pileup_height(pileup_height);
   std::vector<int64_t> positions;
   if (alignment_positions) positions.assign(alignment_positions, alignment_positions + n_reads);
@@ -254,15 +254,15 @@ const char* dvo_last_error(void) { return g_error.c_str(); }
 int dvo_is_reference(void) { return 1; }
 
 int dvo_channel_str_to_enum(const char* name) {
-  return Guard([&] { return static_cast<int>(dv::Channels::ChannelStrToEnum(name)); });
+  return Guard([&] { return static_cast<int>(refdv::Channels::ChannelStrToEnum(name)); });
 }
 
 int dvo_encode_reference(const dvo_options* opt, const char* ref_bases, int w, uint8_t* out_hwc) {
   return Guard([&] {
-    dv::PileupImageOptions options;
+    refdv::PileupImageOptions options;
     if (!MakeOptions(*opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
-    dv::PileupImageEncoderNative encoder(options);
-    std::vector<std::unique_ptr<dv::ImageRow>> rows;
+    refdv::PileupImageEncoderNative encoder(options);
+    std::vector<std::unique_ptr<refdv::ImageRow>> rows;
     rows.push_back(encoder.EncodeReference(std::string(ref_bases, static_cast<size_t>(w))));
     CopyOut(rows, opt->n_channels, opt->n_channels, out_hwc);
     return 0;
@@ -273,14 +273,14 @@ int dvo_encode_read(const dvo_options* opt, const dvo_call* call, const char* re
                     int32_t image_start_pos, const char* const* alt_alleles, int n_alt_alleles,
                     const int32_t* channels_to_blank, int n_blank, uint8_t* out_hwc) {
   return Guard([&] {
-    dv::PileupImageOptions options;
+    refdv::PileupImageOptions options;
     if (!MakeOptions(*opt, &options)) return fail("a channel of dvo_options has no name the reference knows");
-    dv::PileupImageEncoderNative encoder(options);
-    dv::DeepVariantCall dv_call;
+    refdv::PileupImageEncoderNative encoder(options);
+    refdv::DeepVariantCall dv_call;
     MakeCall(*call, &dv_call);
     Read proto;
     MakeRead(*read, &proto);
-    std::vector<std::unique_ptr<dv::ImageRow>> rows;
+    std::vector<std::unique_ptr<refdv::ImageRow>> rows;
     rows.push_back(encoder.EncodeRead(dv_call, std::string(ref_bases, static_cast<size_t>(w)), proto, image_start_pos,
                                       Strings(alt_alleles, n_alt_alleles), BlankSet(channels_to_blank, n_blank)));
     if (!rows[0]) return 0;
@@ -305,10 +305,10 @@ int dvo_build_pileup(const dvo_options* opt, const dvo_call* call, const char* r
 int dvo_fuzzy_read_supports_alt(const dvo_call* call, const dvo_read* read, const char* const* alt_alleles,
                                 int n_alt_alleles) {
   return Guard([&] {
-    dv::PileupImageOptions options;
+    refdv::PileupImageOptions options;
     options.set_width(221);
-    dv::ReadSupportsVariantFuzzyChannel channel(221, options);
-    dv::DeepVariantCall dv_call;
+    refdv::ReadSupportsVariantFuzzyChannel channel(221, options);
+    refdv::DeepVariantCall dv_call;
     MakeCall(*call, &dv_call);
     Read proto;
     MakeRead(*read, &proto);
@@ -320,7 +320,7 @@ int dvo_fuzzy_read_supports_alt(const dvo_call* call, const dvo_read* read, cons
 int dvo_downsample_indices(int n, int max_reads, uint32_t seed, int32_t* out) {
   return Guard([&] {
     std::vector<const Read*> reads(static_cast<size_t>(n), nullptr);   // only the count is looked at
-    const std::vector<int> idx = dv::DownsampleReadIndices(reads, max_reads, std::mt19937_64(seed));
+    const std::vector<int> idx = refdv::DownsampleReadIndices(reads, max_reads, std::mt19937_64(seed));
     for (int i = 0; i < n; ++i) out[i] = idx[static_cast<size_t>(i)];
     return 0;
   });
@@ -477,7 +477,7 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
                        int n_candidate_positions, const dvr_calling_options* o, char** out, uint64_t* out_len) {
   return Guard([&] {
     WindowReference ref(contig, contig_length, ref_start, std::string(ref_bases, static_cast<size_t>(n_ref_bases)));
-    dv::AlleleCounterOptions co;
+    refdv::AlleleCounterOptions co;
     co.set_partition_size(o->partition_size);
     co.mutable_read_requirements()->set_min_mapping_quality(o->min_mapping_quality);
     co.mutable_read_requirements()->set_min_base_quality(o->min_base_quality);
@@ -492,9 +492,9 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
     full.set_start(full_start);
     full.set_end(full_end);
     const std::vector<int> positions(candidate_positions, candidate_positions + n_candidate_positions);
-    std::unique_ptr<dv::AlleleCounter> counter(
-        full_end > full_start ? new dv::AlleleCounter(&ref, range, full, positions, co)
-                              : new dv::AlleleCounter(&ref, range, positions, co));
+    std::unique_ptr<refdv::AlleleCounter> counter(
+        full_end > full_start ? new refdv::AlleleCounter(&ref, range, full, positions, co)
+                              : new refdv::AlleleCounter(&ref, range, positions, co));
     for (int i = 0; i < n_reads; ++i) {
       Read proto;
       MakeRead(reads[i], &proto);
@@ -508,7 +508,7 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
       }
     }
     std::ostringstream text;
-    for (const dv::AlleleCount& c : counter->Counts()) {
+    for (const refdv::AlleleCount& c : counter->Counts()) {
       if (c.ref_supporting_read_count() == 0 && c.read_alleles().empty()) continue;
       text << "C\t" << c.position().position() << '\t' << c.ref_base() << '\t' << c.ref_supporting_read_count() << '\n';
       for (const auto& kv : c.read_alleles()) {
@@ -517,7 +517,7 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
       }
     }
     if (o->call_variants) {
-      dv::VariantCallerOptions vo;
+      refdv::VariantCallerOptions vo;
       vo.set_min_count_snps(o->min_count_snps);
       vo.set_min_count_indels(o->min_count_indels);
       vo.set_min_fraction_snps(o->min_fraction_snps);
@@ -529,12 +529,12 @@ int dvr_count_and_call(const char* contig, int64_t contig_length, int64_t ref_st
       vo.set_gq_resolution(o->gq_resolution);
       vo.set_ploidy(o->ploidy);
       vo.set_track_ref_reads(o->track_ref_reads != 0);
-      dv::multi_sample::VariantCaller caller(vo);
-      std::unordered_map<std::string, dv::AlleleCounter*> counters{{sample, counter.get()}};
+      refdv::multi_sample::VariantCaller caller(vo);
+      std::unordered_map<std::string, refdv::AlleleCounter*> counters{{sample, counter.get()}};
       if (o->call_positions_only) {
         for (int p : caller.CallPositionsFromAlleleCounts(counters, sample)) text << "P\t" << p << '\n';
       } else {
-        for (const dv::DeepVariantCall& call : caller.CallsFromAlleleCounts(counters, sample)) {
+        for (const refdv::DeepVariantCall& call : caller.CallsFromAlleleCounts(counters, sample)) {
           const auto& v = call.variant();
           text << "V\t" << v.start() << '\t' << v.end() << '\t' << v.reference_bases() << '\t' << Join(v.alternate_bases()) << '\n';
           for (const auto& kv : call.allele_support()) text << "S\t" << kv.first << '\t' << Join(kv.second.read_names()) << '\n';
@@ -611,7 +611,7 @@ int dvr_window_candidates(const char* contig, int64_t contig_length, int64_t ref
                           int32_t* out_counts, float* out_scores) {
   return Guard([&] {
     WindowReference ref(contig, contig_length, ref_start, std::string(ref_bases, static_cast<size_t>(n_ref_bases)));
-    dv::AlleleCounterOptions co;
+    refdv::AlleleCounterOptions co;
     co.set_partition_size(static_cast<int32_t>(end - start));
     co.mutable_read_requirements()->set_min_mapping_quality(min_mapq);
     co.mutable_read_requirements()->set_min_base_quality(min_base_quality);
@@ -620,20 +620,20 @@ int dvr_window_candidates(const char* contig, int64_t contig_length, int64_t ref
     range.set_reference_name(contig);
     range.set_start(start);
     range.set_end(end);
-    dv::AlleleCounter counter(&ref, range, {}, co);
+    refdv::AlleleCounter counter(&ref, range, {}, co);
     for (int i = 0; i < n_reads; ++i) {
       Read proto;
       MakeRead(reads[i], &proto);
       proto.mutable_alignment()->mutable_position()->set_reference_name(contig);
       counter.Add(proto, "placeholder_sample_id");
     }
-    dv::WindowSelectorOptions config;
+    refdv::WindowSelectorOptions config;
     config.set_min_allele_support(min_allele_support);
     config.set_enable_strict_insertion_filter(enable_strict_insertion_filter != 0);
-    const std::vector<int> counts = dv::VariantReadsWindowSelectorCandidates(counter, config);
+    const std::vector<int> counts = refdv::VariantReadsWindowSelectorCandidates(counter, config);
     for (size_t i = 0; i < counts.size(); ++i) out_counts[i] = counts[i];
     if (linear && out_scores) {
-      dv::WindowSelectorModel::AlleleCountLinearModel model;
+      refdv::WindowSelectorModel::AlleleCountLinearModel model;
       model.set_bias(linear[0]);
       model.set_coeff_soft_clip(linear[1]);
       model.set_coeff_substitution(linear[2]);
@@ -641,10 +641,218 @@ int dvr_window_candidates(const char* contig, int64_t contig_length, int64_t ref
       model.set_coeff_deletion(linear[4]);
       model.set_coeff_reference(linear[5]);
       model.set_decision_boundary(linear[6]);
-      const std::vector<float> scores = dv::AlleleCountLinearWindowSelectorCandidates(counter, model);
+      const std::vector<float> scores = refdv::AlleleCountLinearWindowSelectorCandidates(counter, model);
       for (size_t i = 0; i < scores.size(); ++i) out_scores[i] = scores[i];
     }
     return static_cast<int>(counts.size());
+  });
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The read realigner (deepvariant/realigner/fast_pass_aligner.cc, ssw.cc) and the trimmed-read / alt-haplotype
+// helpers (deepvariant/alt_aligned_pileup_lib.cc), compiled unmodified.  The one thing underneath them that is
+// NOT the reference's is the local aligner: libssw is not vendored, so `src/ssw_cpp.h` here is the library's C++
+// interface implemented on the product's restatement (deepvariant_amd/csrc/local_align.cpp) -- see
+// shims/src/ssw_cpp.h.  SURVEY.md 8(a) row a16 and 8f row f4.
+// ---------------------------------------------------------------------------------------------------------------
+// (dvr_align_reads_state below runs the aligner's stages one by one, two of which are private members)
+#define private public
+#include "deepvariant/realigner/fast_pass_aligner.h"
+#undef private
+#include "deepvariant/alt_aligned_pileup_lib.h"
+
+namespace {
+
+void ReadLine(std::ostringstream& text, const Read& r) {
+  // E = the empty Read the aligner returns under force_alignment when nothing was found
+  if (r.aligned_sequence().empty() && r.fragment_name().empty() && r.alignment().cigar_size() == 0) {
+    text << "E\n";
+    return;
+  }
+  text << "R\t" << r.fragment_name() << '\t' << r.read_number() << '\t' << r.alignment().position().position() << '\t';
+  for (int i = 0; i < r.alignment().cigar_size(); ++i) {
+    text << (i ? "," : "") << static_cast<int>(r.alignment().cigar(i).operation()) << ':' << r.alignment().cigar(i).operation_length();
+  }
+  text << '\t' << r.aligned_sequence() << '\t';
+  for (size_t i = 0; i < r.aligned_quality().size(); ++i) {
+    text << (i ? "," : "") << static_cast<int>(static_cast<unsigned char>(r.aligned_quality()[i]));
+  }
+  text << '\t' << r.alignment().mapping_quality() << '\t' << (r.alignment().position().reverse_strand() ? 1 : 0);
+  for (const char* key : {"5mC", "6mA"}) {
+    text << '\t';
+    auto it = r.base_modifications().find(key);
+    if (it != r.base_modifications().end()) {
+      for (size_t i = 0; i < it->second.size(); ++i) text << (i ? "," : "") << static_cast<int>(static_cast<unsigned char>(it->second[i]));
+    } else {
+      text << '-';
+    }
+  }
+  text << '\n';
+}
+
+int TextOut(const std::ostringstream& text, char** out, uint64_t* out_len) {
+  const std::string s = text.str();
+  *out = static_cast<char*>(std::malloc(s.size() + 1));
+  std::memcpy(*out, s.data(), s.size());
+  (*out)[s.size()] = 0;
+  *out_len = s.size();
+  return 0;
+}
+
+void SetAlignerOptions(const int32_t* o, double similarity, refdv::AlignerOptions* a) {
+  a->set_match(o[0]);
+  a->set_mismatch(o[1]);
+  a->set_gap_open(o[2]);
+  a->set_gap_extend(o[3]);
+  a->set_kmer_size(o[4]);
+  a->set_read_size(o[5]);
+  a->set_max_num_of_mismatches(o[6]);
+  a->set_realignment_similarity_threshold(similarity);
+  a->set_force_alignment(o[7] != 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* FastPassAligner::AlignReads as the window realigner drives it (realigner.py:740-790).
+ * options: match, mismatch, gap_open, gap_extend, kmer_size, read_size, max_num_of_mismatches, force_alignment,
+ * normalize_reads, ref_prefix_len, ref_suffix_len.  One line per read (ReadLine above). */
+int dvr_align_reads(const char* reference, const char* contig, int64_t ref_start, const char* const* haplotypes,
+                    int n_haplotypes, const dvo_read* reads, int n_reads, const int32_t* options, double similarity,
+                    char** out, uint64_t* out_len) {
+  return Guard([&] {
+    refdv::FastPassAligner aligner;
+    refdv::AlignerOptions a;
+    SetAlignerOptions(options, similarity, &a);
+    aligner.set_options(a);
+    aligner.set_normalize_reads(options[8] != 0);
+    aligner.set_reference(reference);
+    aligner.set_ref_start(contig, static_cast<uint64_t>(ref_start));
+    aligner.set_ref_prefix_len(options[9]);
+    aligner.set_ref_suffix_len(options[10]);
+    aligner.set_haplotypes(Strings(haplotypes, n_haplotypes));
+    std::vector<Read> protos(static_cast<size_t>(n_reads));
+    for (int i = 0; i < n_reads; ++i) {
+      MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+      protos[static_cast<size_t>(i)].mutable_alignment()->mutable_position()->set_reference_name(contig);
+    }
+    auto realigned = aligner.AlignReads(protos);
+    std::ostringstream text;
+    for (const Read& r : *realigned) ReadLine(text, r);
+    return TextOut(text, out, out_len);
+  });
+}
+
+/* TrimReads (alt_aligned_pileup_lib.cc:231-248): one R line per kept read, followed by "P <original position>". */
+int dvr_trim_reads(const dvo_read* reads, int n_reads, const char* contig, int64_t region_start, int64_t region_end,
+                   int min_overlap, char** out, uint64_t* out_len) {
+  return Guard([&] {
+    std::vector<Read> protos(static_cast<size_t>(n_reads));
+    std::vector<const Read*> ptrs;
+    for (int i = 0; i < n_reads; ++i) {
+      MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+      protos[static_cast<size_t>(i)].mutable_alignment()->mutable_position()->set_reference_name(contig);
+      ptrs.push_back(&protos[static_cast<size_t>(i)]);
+    }
+    nucleus::genomics::v1::Range region;
+    region.set_reference_name(contig);
+    region.set_start(region_start);
+    region.set_end(region_end);
+    std::vector<int64_t> original;
+    const std::vector<Read> trimmed = refdv::TrimReads(ptrs, region, original, min_overlap);
+    std::ostringstream text;
+    for (size_t i = 0; i < trimmed.size(); ++i) {
+      ReadLine(text, trimmed[i]);
+      text << "P\t" << (i < original.size() ? original[i] : -1) << '\n';
+    }
+    return TextOut(text, out, out_len);
+  });
+}
+
+/* RealignReadsToHaplotype (alt_aligned_pileup_lib.cc:278-313) over a reference handed in as one stretch, and
+ * CalculateAlignmentRegion (:218-231) for a variant (start, reference_bases length) -> region_out[2]. */
+int dvr_realign_reads_to_haplotype(const char* haplotype, const dvo_read* reads, int n_reads, const char* contig,
+                                   int64_t ref_start, int64_t ref_end, int64_t contig_length, int64_t window_start,
+                                   const char* window_bases, int64_t n_window_bases, const int32_t* options,
+                                   double similarity, char** out, uint64_t* out_len) {
+  return Guard([&] {
+    WindowReference ref(contig, contig_length, window_start, std::string(window_bases, static_cast<size_t>(n_window_bases)));
+    refdv::MakeExamplesOptions opts;
+    SetAlignerOptions(options, similarity, opts.mutable_realigner_options()->mutable_aln_config());
+    std::vector<Read> protos(static_cast<size_t>(n_reads));
+    for (int i = 0; i < n_reads; ++i) {
+      MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+      protos[static_cast<size_t>(i)].mutable_alignment()->mutable_position()->set_reference_name(contig);
+    }
+    const std::vector<Read> realigned = refdv::RealignReadsToHaplotype(haplotype, protos, contig, ref_start, ref_end, ref, opts);
+    std::ostringstream text;
+    for (const Read& r : realigned) ReadLine(text, r);
+    return TextOut(text, out, out_len);
+  });
+}
+
+int dvr_calculate_alignment_region(const char* contig, int64_t contig_length, int64_t variant_start,
+                                   int64_t n_reference_bases, int half_width, int64_t* region_out) {
+  return Guard([&] {
+    WindowReference ref(contig, contig_length, 0, "");
+    nucleus::genomics::v1::Variant v;
+    v.set_reference_name(contig);
+    v.set_start(variant_start);
+    v.set_end(variant_start + n_reference_bases);
+    v.set_reference_bases(std::string(static_cast<size_t>(n_reference_bases), 'A'));
+    const nucleus::genomics::v1::Range r = refdv::CalculateAlignmentRegion(v, half_width, ref);
+    region_out[0] = r.start();
+    region_out[1] = r.end();
+    return 0;
+  });
+}
+
+}  // extern "C"
+
+extern "C" {
+
+/* The stages of FastPassAligner::AlignReads up to (not including) RealignReadsToReference, then the state:
+ *   H <haplotype index> <haplotype score> <ref_pos> <is_reference> <cigar>   per haplotype, in sorted order
+ *   A <read> <position or -1> <score> <cigar>                               its read alignments */
+int dvr_align_reads_state(const char* reference, const char* contig, int64_t ref_start, const char* const* haplotypes,
+                          int n_haplotypes, const dvo_read* reads, int n_reads, const int32_t* options, double similarity,
+                          char** out, uint64_t* out_len) {
+  return Guard([&] {
+    refdv::FastPassAligner aligner;
+    refdv::AlignerOptions a;
+    SetAlignerOptions(options, similarity, &a);
+    aligner.set_options(a);
+    aligner.set_normalize_reads(options[8] != 0);
+    aligner.set_reference(reference);
+    aligner.set_ref_start(contig, static_cast<uint64_t>(ref_start));
+    aligner.set_ref_prefix_len(options[9]);
+    aligner.set_ref_suffix_len(options[10]);
+    aligner.set_haplotypes(Strings(haplotypes, n_haplotypes));
+    std::vector<std::string> seqs;
+    for (int i = 0; i < n_reads; ++i) seqs.emplace_back(reads[i].seq, static_cast<size_t>(reads[i].seq_len));
+    aligner.set_reads(seqs);
+    aligner.CalculateSswAlignmentScoreThreshold();
+    aligner.BuildIndex();
+    aligner.FastAlignReadsToHaplotypes();
+    aligner.InitSswLib();
+    aligner.AlignHaplotypesToReference();
+    aligner.CalculatePositionMaps();
+    aligner.SswAlignReadsToHaplotypes(static_cast<uint16_t>(aligner.get_ssw_alignment_score_threshold()));
+    std::ostringstream text;
+    text << "T\t" << aligner.get_ssw_alignment_score_threshold() << '\n';
+    for (const auto& h : aligner.GetReadToHaplotypeAlignments()) {
+      text << "H\t" << h.haplotype_index << '\t' << h.haplotype_score << '\t' << h.ref_pos << '\t' << (h.is_reference ? 1 : 0)
+           << '\t' << h.cigar << '\n';
+      for (size_t r = 0; r < h.read_alignment_scores.size(); ++r) {
+        const auto& ra = h.read_alignment_scores[r];
+        text << "A\t" << r << '\t' << (ra.position == refdv::ReadAlignment::kNotAligned ? -1 : static_cast<int>(ra.position))
+             << '\t' << ra.score << '\t' << ra.cigar << '\n';
+      }
+    }
+    return TextOut(text, out, out_len);
   });
 }
 

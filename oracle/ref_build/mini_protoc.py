@@ -357,6 +357,7 @@ class Generator:
         w('  %sCase %s_case() const { return static_cast<%sCase>(_oneof_%s_); }' % (camel(oneof), oneof, camel(oneof), oneof))
         w('  void clear_%s() { _oneof_%s_ = 0; }' % (oneof, oneof))
       members = []
+      merges = []      # statements of MergeFrom(const cls& o)
       for fld in m.fields:
         n = fld.name
         guard_get = guard_set = ''
@@ -373,6 +374,7 @@ class Generator:
           w('  int %s_size() const { return static_cast<int>(%s_.size()); }' % (n, n))
           w('  void clear_%s() { %s_.clear(); }' % (n, n))
           members.append('  %s %s_;' % (mt, n))
+          merges.append('for (const auto& kv : o.%s_) %s_[kv.first] = kv.second;' % (n, n))
           continue
         kind, ct = self.cpp_type(f, scope, fld.type)
         if fld.label == 'repeated':
@@ -402,6 +404,7 @@ class Generator:
           w('  int %s_size() const { return static_cast<int>(%s_.size()); }' % (n, n))
           w('  void clear_%s() { %s_.clear(); }' % (n, n))
           members.append('  %s %s_;' % (rt, n))
+          merges.append('for (const auto& e : o.%s_) %s_.push_back(e);' % (n, n))
         elif kind in ('scalar', 'enum'):
           zero = 'static_cast<%s>(0)' % ct
           if fld.oneof:
@@ -415,6 +418,12 @@ class Generator:
             w('  bool has_%s() const { return _has_%s_; }' % (n, n))
             members.append('  bool _has_%s_ = false;' % n)
           members.append('  %s %s_ = %s;' % (ct, n, zero))
+          if fld.oneof:
+            merges.append('if (o.%s) set_%s(o.%s_);' % (guard_get, n, n))
+          elif fld.optional:
+            merges.append('if (o._has_%s_) set_%s(o.%s_);' % (n, n, n))
+          else:
+            merges.append('if (o.%s_ != %s) %s_ = o.%s_;' % (n, zero, n, n))
         elif kind == 'string':
           if fld.oneof:
             w('  const std::string& %s() const { return %s ? %s_ : ::google::protobuf::mini::EmptyString(); }' % (n, guard_get, n))
@@ -432,6 +441,12 @@ class Generator:
             w('  bool has_%s() const { return _has_%s_; }' % (n, n))
             members.append('  bool _has_%s_ = false;' % n)
           members.append('  std::string %s_;' % n)
+          if fld.oneof:
+            merges.append('if (o.%s) set_%s(o.%s_);' % (guard_get, n, n))
+          elif fld.optional:
+            merges.append('if (o._has_%s_) set_%s(o.%s_);' % (n, n, n))
+          else:
+            merges.append('if (!o.%s_.empty()) %s_ = o.%s_;' % (n, n, n))
         else:     # singular message: held through a copying pointer (the type may still be incomplete here)
           w('  const %s& %s() const;' % (ct, n))
           w('  %s* mutable_%s();' % (ct, n))
@@ -444,12 +459,22 @@ class Generator:
             bodies.append('inline const %s& %s::%s() const { return %s_.get(); }' % (ct, cls, n, n))
           bodies.append('inline %s* %s::mutable_%s() { %sreturn %s_.mutable_get(); }' % (ct, cls, n, guard_set, n))
           bodies.append('inline void %s::clear_%s() { %s_.reset(); }' % (cls, n, n))
+          w('  void set_allocated_%s(%s* p);' % (n, ct))
+          w('  %s* release_%s();' % (ct, n))
+          bodies.append('inline void %s::set_allocated_%s(%s* p) { %s%s_.adopt(p); }' % (cls, n, ct, guard_set, n))
+          bodies.append('inline %s* %s::release_%s() { return %s_.release(); }' % (ct, cls, n, n))
           members.append('  ::google::protobuf::mini::Box<%s> %s_;' % (ct, n))
+          if fld.oneof:
+            merges.append('if (o.%s) mutable_%s()->MergeFrom(o.%s_.get());' % (guard_get, n, n))
+          else:
+            merges.append('if (o.%s_.has()) mutable_%s()->MergeFrom(o.%s_.get());' % (n, n, n))
       # (text format is only ever used inside the reference's log / CHECK messages)
       w('  std::string DebugString() const { return "<%s>"; }' % cls)
       w('  std::string ShortDebugString() const { return "<%s>"; }' % cls)
       w('  void Clear() { *this = %s(); }' % cls)
       w('  void CopyFrom(const %s& other) { *this = other; }' % cls)
+      w('  void MergeFrom(const %s& o);' % cls)
+      bodies.append('inline void %s::MergeFrom(const %s& o) {\n  %s\n}' % (cls, cls, '\n  '.join(merges) or '(void)o;'))
       w(' private:')
       for oneof in m.oneofs:
         members.append('  int _oneof_%s_ = 0;' % oneof)

@@ -245,6 +245,8 @@ class Box {
     return p_.get();
   }
   void reset() { p_.reset(); }
+  void adopt(T* p) { p_.reset(p); }      // set_allocated_*: takes ownership
+  T* release() { return p_.release(); }
 
  private:
   std::unique_ptr<T> p_;
