@@ -752,3 +752,89 @@ def reference_calculate_alignment_region(contig_length: int, variant_start: int,
                                              int(half_width), out) != 0:
     raise OracleError(_ref_lib.dvo_last_error().decode())
   return int(out[0]), int(out[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The top of the hot path on the reference's own code: ExamplesGenerator::WriteExamplesInRegion
+# (deepvariant/make_examples_native.cc in oracle/_ref/libdvref.so).  tests/ only.
+# ---------------------------------------------------------------------------------------------------------------
+def reference_write_examples_in_region(options, ref_reader, contig: str, contig_length: int, candidates,
+                                       reads_per_sample, sample_order, role: str, mean_coverage_per_sample,
+                                       aln_config: Optional[dict] = None, ref_margin: int = 600):
+  """`options`: MakeExamplesOptions-shaped (pic_options, sample_options, trim_reads_for_pileup).
+  -> (serialized tf.Examples in the order the reference wrote them, image_shape)."""
+  if not reference_available():
+    raise OracleError('oracle/_ref/libdvref.so is not available')
+  global _ref_lib
+  if _ref_lib is None:
+    _ref_lib = _load(_REF_LIB_PATH)
+  L = _ref_lib
+  pic = options.pic_options
+  lines = []
+  for k in ('width', 'height', 'reference_band_height', 'base_color_offset_a_and_g', 'base_color_offset_t_and_c',
+            'base_color_stride', 'allele_supporting_read_alpha', 'allele_unsupporting_read_alpha',
+            'other_allele_supporting_read_alpha', 'reference_matching_read_alpha', 'reference_mismatching_read_alpha',
+            'indel_anchoring_base_char', 'reference_base_quality', 'positive_strand_color', 'negative_strand_color',
+            'base_quality_cap', 'mapping_quality_cap', 'read_overlap_buffer_bp', 'multi_allelic_mode', 'random_seed',
+            'num_channels', 'sequencing_type', 'alt_aligned_pileup', 'types_to_alt_align', 'hp_tag_for_assembly_polishing',
+            'min_non_zero_allele_frequency'):
+    v = getattr(pic, k)
+    lines.append('O\tpic.%s\t%s' % (k, repr(float(v)) if isinstance(v, float) else (int(v) if not isinstance(v, str) else v)))
+  lines.append('O\tpic.sort_by_haplotypes\t%d' % int(bool(pic.sort_by_haplotypes)))
+  lines.append('O\tpic.sort_by_alt_allele_support\t%d' % int(bool(getattr(pic, 'sort_by_alt_allele_support', False))))
+  lines.append('O\tpic.min_base_quality\t%d' % pic.read_requirements.min_base_quality)
+  lines.append('O\tpic.min_mapping_quality\t%d' % pic.read_requirements.min_mapping_quality)
+  lines.append('O\tpic.channels\t%s' % ','.join(pic.channels))
+  lines.append('O\ttrim_reads_for_pileup\t%d' % int(bool(options.trim_reads_for_pileup)))
+  for k, v in (aln_config or {}).items():
+    lines.append('O\taln.%s\t%s' % (k, v))
+  for so in options.sample_options:
+    lines.append('M\t%s\t%s\t%d\t%s\t%s\t%s\t%d' % (so.role, so.name, so.pileup_height, ','.join(map(str, so.order)),
+                                                     so.alt_aligned_pileup, ','.join(str(int(c)) for c in so.channels_enum_to_blank),
+                                                     int(bool(so.keep_only_window_spanning_reads))))
+  lo, hi = contig_length, 0
+  for c in candidates:
+    v = c.variant
+    call = v.calls[0] if v.calls else None
+    lines.append('C\t%d\t%d\t%s\t%s\t%s\t%s' % (v.start, v.end, v.reference_bases, ','.join(v.alternate_bases),
+                                                call.call_set_name if call else '', ','.join(map(str, call.genotype)) if call else ''))
+    for allele, support in c.allele_support.items():
+      lines.append('S\t%s\t%s' % (allele, ','.join(support.read_names)))
+    if getattr(c, 'make_examples_alt_allele_indices', None):
+      lines.append('A\t%s' % ';'.join(','.join(map(str, idx.indices if hasattr(idx, 'indices') else idx))
+                                      for idx in c.make_examples_alt_allele_indices))
+    if call:
+      for key, lv in call.info.items():
+        vals = lv.values
+        if vals and getattr(vals[0], 'number_value', None) not in (None, 0.0) or key == 'VAF':
+          lines.append('I\t%s\tfloat\t%s' % (key, ','.join(repr(float(x.number_value)) for x in vals)))
+        else:
+          lines.append('I\t%s\tint\t%s' % (key, ','.join(str(int(x.int_value)) for x in vals)))
+    lo, hi = min(lo, v.start), max(hi, v.end)
+  lo, hi = max(0, lo - pic.width - ref_margin), min(contig_length, hi + pic.width + ref_margin)
+  bases = ref_reader.get_bases(contig, lo, hi).encode() if hi > lo else b''
+  keep = _Keep()
+  flat = [r for sample in reads_per_sample for r in sample]
+  arr = _read_array(flat, keep)
+  n_per = (C.c_int32 * max(len(reads_per_sample), 1))(*[len(s) for s in reads_per_sample])
+  order = (C.c_int32 * max(len(sample_order), 1))(*[int(x) for x in sample_order])
+  cov = (C.c_float * max(len(reads_per_sample), 1))(*[float(x) for x in mean_coverage_per_sample])
+  shape = (C.c_int32 * 3)()
+  out_p, n = C.c_void_p(), C.c_uint64()
+  L.dvr_write_examples_in_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+  rc = L.dvr_write_examples_in_region('\n'.join(lines).encode(), contig.encode(), int(contig_length), lo, bases, len(bases), arr,
+                                      n_per, len(reads_per_sample), order, len(sample_order), role.encode(), cov, shape,
+                                      C.byref(out_p), C.byref(n))
+  if rc != 0:
+    raise OracleError(L.dvo_last_error().decode())
+  blob = C.string_at(out_p.value, n.value)
+  L.dvr_free.argtypes = [C.c_void_p]
+  L.dvr_free(out_p)
+  examples, at = [], 0
+  while at < len(blob):
+    ln = int.from_bytes(blob[at:at + 4], 'little')
+    examples.append(blob[at + 4:at + 4 + ln])
+    at += 4 + ln
+  return examples, [int(x) for x in shape]

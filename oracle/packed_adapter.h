@@ -6,6 +6,7 @@
 #ifndef DVO_PACKED_ADAPTER_H_
 #define DVO_PACKED_ADAPTER_H_
 
+#include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -27,9 +28,6 @@ int ExpandPackedItem(const dvo_options& opt, const dvo_packed_batch& b, int item
   std::vector<std::vector<int32_t>> ops(n);
   std::vector<std::vector<int64_t>> lens(n);
   std::vector<int64_t> sort_pos(n);
-  // A synthetic DeepVariantCall whose allele_support reproduces the codes:
-  // "ALT_IN" is in alt_alleles (code 1), "ALT_OTHER" is not (code 2).
-  std::vector<std::string> in_names, other_names;
   for (int i = 0; i < n; ++i) {
     const uint32_t r = b.list_read[l0 + i];
     char buf[16];
@@ -71,30 +69,79 @@ int ExpandPackedItem(const dvo_options& opt, const dvo_packed_batch& b, int item
       rd.mod_6ma = b.mod_6ma + s0;
       rd.mod_6ma_len = s1 - s0;
     }
-    const std::string key = names[i] + "/0";
-    if (b.list_code[l0 + i] == 1) in_names.push_back(key);
-    if (b.list_code[l0 + i] == 2) other_names.push_back(key);
   }
-  if (b.list_group != nullptr && opt.sort_by_alt_allele_support) {
-    *error = "packed adapter: sort_by_alt_allele_support not supported";
-    return -1;
+  // A synthetic DeepVariantCall whose allele_support reproduces the packed codes (and, under
+  // sort_by_alt_allele_support, the packed allele groups: alt number g of the variant is "ALT_G<g>", supported by the
+  // reads of group g; the alt combination is the set of groups that hold a code-1 read).
+  const bool grouped = b.list_group != nullptr && opt.sort_by_alt_allele_support;
+  int n_groups = 0;
+  if (grouped) {
+    for (int i = 0; i < n; ++i) {
+      if (b.list_code[l0 + i] != 0) n_groups = std::max(n_groups, static_cast<int>(b.list_group[l0 + i]) + 1);
+    }
   }
-  const char* alts[2] = {"ALT_IN", "ALT_OTHER"};
-  std::vector<const char*> support_names;
-  for (auto& s : in_names) support_names.push_back(s.c_str());
-  for (auto& s : other_names) support_names.push_back(s.c_str());
-  int32_t support_offsets[3] = {0, static_cast<int32_t>(in_names.size()),
-                                static_cast<int32_t>(support_names.size())};
+  std::vector<std::string> alt_names;
+  std::vector<std::vector<std::string>> alt_support;
+  std::vector<char> in_combo;
+  if (grouped && n_groups > 0) {
+    alt_names.resize(static_cast<size_t>(n_groups));
+    alt_support.resize(static_cast<size_t>(n_groups));
+    in_combo.assign(static_cast<size_t>(n_groups), 0);
+    for (int g = 0; g < n_groups; ++g) alt_names[static_cast<size_t>(g)] = "ALT_G" + std::to_string(g);
+    // A group is in the combination when its reads all carry code 1 (a read listed under an alt of the combination
+    // supports it: code 1; a group outside it holds code-2 reads -- and possibly reads that are ALSO listed under
+    // an alt of the combination: code 1 with the group of their last listing, pileup_image_native.cc:346-361).
+    std::vector<char> has1(static_cast<size_t>(n_groups), 0), has2(static_cast<size_t>(n_groups), 0);
+    for (int i = 0; i < n; ++i) {
+      const int code = b.list_code[l0 + i];
+      if (code == 1) has1[b.list_group[l0 + i]] = 1;
+      if (code == 2) has2[b.list_group[l0 + i]] = 1;
+    }
+    for (int g = 0; g < n_groups; ++g) in_combo[static_cast<size_t>(g)] = has1[static_cast<size_t>(g)] && !has2[static_cast<size_t>(g)];
+    // Reads that carry code 1 inside a group outside the combination are ALSO listed under an alt of the
+    // combination (their group is that of their last listing).  They join a synthetic alt of the combination placed
+    // in FRONT of all groups: every real group moves up by one, so the groups' order -- all that row sorting uses --
+    // is unchanged, and "last listing wins" still gives such a read its own group.
+    std::vector<std::string> doubly;
+    for (int i = 0; i < n; ++i) {
+      const int code = b.list_code[l0 + i];
+      if (code == 0) continue;
+      const int g = b.list_group[l0 + i];
+      alt_support[static_cast<size_t>(g)].push_back(names[i] + "/0");
+      if (code == 1 && !in_combo[static_cast<size_t>(g)]) doubly.push_back(names[i] + "/0");
+    }
+    if (!doubly.empty()) {
+      alt_names.insert(alt_names.begin(), "ALT_OF_THE_COMBINATION");
+      alt_support.insert(alt_support.begin(), doubly);
+      in_combo.insert(in_combo.begin(), 1);
+    }
+  } else {
+    alt_names = {"ALT_IN", "ALT_OTHER"};
+    alt_support.resize(2);
+    in_combo = {1, 0};
+    for (int i = 0; i < n; ++i) {
+      if (b.list_code[l0 + i] == 1) alt_support[0].push_back(names[i] + "/0");
+      if (b.list_code[l0 + i] == 2) alt_support[1].push_back(names[i] + "/0");
+    }
+  }
+  std::vector<const char*> alts, support_names, combo;
+  std::vector<int32_t> support_offsets{0};
+  for (size_t g = 0; g < alt_names.size(); ++g) {
+    alts.push_back(alt_names[g].c_str());
+    for (const std::string& s : alt_support[g]) support_names.push_back(s.c_str());
+    support_offsets.push_back(static_cast<int32_t>(support_names.size()));
+    if (in_combo[g]) combo.push_back(alt_names[g].c_str());
+  }
+  if (combo.empty()) combo.push_back("ALT_NOT_IN_THE_VARIANT");
   dvo_call call;
   memset(&call, 0, sizeof(call));
   call.variant_start = b.item_variant_start[item];
-  call.n_alts = 2;
-  call.alts = alts;
-  call.n_support = 2;
-  call.support_alleles = alts;
-  call.support_offsets = support_offsets;
+  call.n_alts = static_cast<int32_t>(alts.size());
+  call.alts = alts.data();
+  call.n_support = static_cast<int32_t>(alts.size());
+  call.support_alleles = alts.data();
+  call.support_offsets = support_offsets.data();
   call.support_names = support_names.data();
-  const char* alt_alleles[1] = {"ALT_IN"};
 
   const int h = b.item_height[item];
   std::string ref(reinterpret_cast<const char*>(b.ref_windows) +
@@ -107,8 +154,8 @@ int ExpandPackedItem(const dvo_options& opt, const dvo_packed_batch& b, int item
     }
   }
   const float mean_cov = b.item_mean_coverage ? b.item_mean_coverage[item] : 0.0f;
-  return build(call, ref, reads.data(), n, b.item_image_start[item], alt_alleles, 1, h, mean_cov, sort_pos.data(),
-               blank.data(), static_cast<int>(blank.size()));
+  return build(call, ref, reads.data(), n, b.item_image_start[item], combo.data(), static_cast<int>(combo.size()), h, mean_cov,
+               sort_pos.data(), blank.data(), static_cast<int>(blank.size()));
 }
 
 }  // namespace dvo_adapter

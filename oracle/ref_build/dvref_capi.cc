@@ -857,3 +857,211 @@ int dvr_align_reads_state(const char* reference, const char* contig, int64_t ref
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The top of the hot path: ExamplesGenerator::WriteExamplesInRegion (deepvariant/make_examples_native.cc, compiled
+// unmodified) -- InMemoryReader::Query per candidate, alt-allele combinations, one pileup per sample stacked,
+// alt-aligned images, EncodeExample.  SURVEY.md 8(a) rows a1-a3, a12-a16.  Its tf.Examples are written through the
+// ExampleWriter stand-in (kept in memory) and handed back as they are, length-prefixed.
+// ---------------------------------------------------------------------------------------------------------------
+#include "deepvariant/make_examples_native.h"
+
+namespace {
+
+std::vector<std::string> SplitTabs(const std::string& line) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  for (;;) {
+    const size_t t = line.find('\t', i);
+    out.push_back(line.substr(i, t == std::string::npos ? std::string::npos : t - i));
+    if (t == std::string::npos) break;
+    i = t + 1;
+  }
+  return out;
+}
+
+std::vector<std::string> SplitCommas(const std::string& s) {
+  std::vector<std::string> out;
+  if (s.empty()) return out;
+  size_t i = 0;
+  for (;;) {
+    const size_t t = s.find(',', i);
+    out.push_back(s.substr(i, t == std::string::npos ? std::string::npos : t - i));
+    if (t == std::string::npos) break;
+    i = t + 1;
+  }
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* `spec`: tab-separated lines.
+ *   O <key> <value>        option: pic.<field> (PileupImageOptions), trim_reads_for_pileup, aln.<field> (AlignerOptions)
+ *   M <role> <name> <pileup_height> <order,order,..> <alt_aligned_pileup> <blank enums,> <keep_only_window_spanning_reads>
+ *                          one SampleOptions per line, in order
+ *   C <start> <end> <reference_bases> <alt,alt,...> <call_set_name> <genotype,..>   one candidate
+ *   S <allele> <read key,read key,...>                                              allele_support of the last C
+ *   A <i,j;i;...>                                                                    make_examples_alt_allele_indices
+ *   I <key> <int|float> <v,v,...>                                                    calls(0).info of the last C
+ * reads: all samples' reads back to back, reads_per_sample[k] of them for sample k; sample_order and role as
+ * WriteExamplesInRegion takes them.  out: per example a little-endian uint32 length + the serialized tf.Example;
+ * image_shape_out[3]. */
+int dvr_write_examples_in_region(const char* spec, const char* contig, int64_t contig_length, int64_t window_start,
+                                 const char* window_bases, int64_t n_window_bases, const dvo_read* reads,
+                                 const int32_t* reads_per_sample, int n_samples, const int32_t* sample_order,
+                                 int n_sample_order, const char* role, const float* mean_coverage_per_sample,
+                                 int32_t* image_shape_out, char** out, uint64_t* out_len) {
+  return Guard([&] {
+    refdv::MakeExamplesOptions options;
+    auto* pic = options.mutable_pic_options();
+    std::vector<refdv::DeepVariantCall> candidates;
+    std::istringstream in(spec);
+    std::string line;
+    while (std::getline(in, line)) {
+      if (line.empty()) continue;
+      const std::vector<std::string> f = SplitTabs(line);
+      if (f[0] == "O") {
+        const std::string& k = f[1];
+        const std::string& v = f[2];
+        const int iv = std::atoi(v.c_str());
+        const float fv = static_cast<float>(std::atof(v.c_str()));
+        if (k == "pic.width") pic->set_width(iv);
+        else if (k == "pic.height") pic->set_height(iv);
+        else if (k == "pic.reference_band_height") pic->set_reference_band_height(iv);
+        else if (k == "pic.base_color_offset_a_and_g") pic->set_base_color_offset_a_and_g(iv);
+        else if (k == "pic.base_color_offset_t_and_c") pic->set_base_color_offset_t_and_c(iv);
+        else if (k == "pic.base_color_stride") pic->set_base_color_stride(iv);
+        else if (k == "pic.allele_supporting_read_alpha") pic->set_allele_supporting_read_alpha(fv);
+        else if (k == "pic.allele_unsupporting_read_alpha") pic->set_allele_unsupporting_read_alpha(fv);
+        else if (k == "pic.other_allele_supporting_read_alpha") pic->set_other_allele_supporting_read_alpha(fv);
+        else if (k == "pic.reference_matching_read_alpha") pic->set_reference_matching_read_alpha(fv);
+        else if (k == "pic.reference_mismatching_read_alpha") pic->set_reference_mismatching_read_alpha(fv);
+        else if (k == "pic.indel_anchoring_base_char") pic->set_indel_anchoring_base_char(v);
+        else if (k == "pic.reference_base_quality") pic->set_reference_base_quality(iv);
+        else if (k == "pic.positive_strand_color") pic->set_positive_strand_color(iv);
+        else if (k == "pic.negative_strand_color") pic->set_negative_strand_color(iv);
+        else if (k == "pic.base_quality_cap") pic->set_base_quality_cap(iv);
+        else if (k == "pic.mapping_quality_cap") pic->set_mapping_quality_cap(iv);
+        else if (k == "pic.read_overlap_buffer_bp") pic->set_read_overlap_buffer_bp(iv);
+        else if (k == "pic.min_base_quality") pic->mutable_read_requirements()->set_min_base_quality(iv);
+        else if (k == "pic.min_mapping_quality") pic->mutable_read_requirements()->set_min_mapping_quality(iv);
+        else if (k == "pic.multi_allelic_mode") pic->set_multi_allelic_mode(static_cast<refdv::PileupImageOptions::MultiAllelicMode>(iv));
+        else if (k == "pic.random_seed") pic->set_random_seed(static_cast<uint32_t>(std::strtoul(v.c_str(), nullptr, 10)));
+        else if (k == "pic.num_channels") pic->set_num_channels(iv);
+        else if (k == "pic.sequencing_type") pic->set_sequencing_type(static_cast<refdv::PileupImageOptions::SequencingType>(iv));
+        else if (k == "pic.alt_aligned_pileup") pic->set_alt_aligned_pileup(v);
+        else if (k == "pic.types_to_alt_align") pic->set_types_to_alt_align(v);
+        else if (k == "pic.sort_by_haplotypes") pic->set_sort_by_haplotypes(iv != 0);
+        else if (k == "pic.hp_tag_for_assembly_polishing") pic->set_hp_tag_for_assembly_polishing(iv);
+        else if (k == "pic.sort_by_alt_allele_support") pic->set_sort_by_alt_allele_support(iv != 0);
+        else if (k == "pic.min_non_zero_allele_frequency") pic->set_min_non_zero_allele_frequency(fv);
+        else if (k == "pic.channels") { for (const std::string& c : SplitCommas(v)) pic->add_channels(c); }
+        else if (k == "trim_reads_for_pileup") options.set_trim_reads_for_pileup(iv != 0);
+        else if (k.rfind("aln.", 0) == 0) {
+          auto* a = options.mutable_realigner_options()->mutable_aln_config();
+          if (k == "aln.match") a->set_match(iv);
+          else if (k == "aln.mismatch") a->set_mismatch(iv);
+          else if (k == "aln.gap_open") a->set_gap_open(iv);
+          else if (k == "aln.gap_extend") a->set_gap_extend(iv);
+          else if (k == "aln.kmer_size") a->set_kmer_size(iv);
+          else if (k == "aln.max_num_of_mismatches") a->set_max_num_of_mismatches(iv);
+          else if (k == "aln.realignment_similarity_threshold") a->set_realignment_similarity_threshold(std::atof(v.c_str()));
+          else return fail("unknown option " + k);
+        } else {
+          return fail("unknown option " + k);
+        }
+      } else if (f[0] == "M") {
+        auto* so = options.add_sample_options();
+        so->set_role(f[1]);
+        so->set_name(f[2]);
+        so->set_pileup_height(std::atoi(f[3].c_str()));
+        for (const std::string& x : SplitCommas(f[4])) so->add_order(std::atoi(x.c_str()));
+        so->set_alt_aligned_pileup(f[5]);
+        for (const std::string& x : SplitCommas(f[6])) so->add_channels_enum_to_blank(static_cast<refdv::DeepVariantChannelEnum>(std::atoi(x.c_str())));
+        so->set_keep_only_window_spanning_reads(std::atoi(f[7].c_str()) != 0);
+      } else if (f[0] == "C") {
+        candidates.emplace_back();
+        auto* v = candidates.back().mutable_variant();
+        v->set_reference_name(contig);
+        v->set_start(std::atoll(f[1].c_str()));
+        v->set_end(std::atoll(f[2].c_str()));
+        v->set_reference_bases(f[3]);
+        for (const std::string& a : SplitCommas(f[4])) v->add_alternate_bases(a);
+        if (!f[5].empty() || !f[6].empty()) {      // (a candidate without a VariantCall stays without one)
+          auto* vc = v->add_calls();
+          vc->set_call_set_name(f[5]);
+          for (const std::string& g : SplitCommas(f[6])) vc->add_genotype(std::atoi(g.c_str()));
+        }
+      } else if (f[0] == "S") {
+        auto& sr = (*candidates.back().mutable_allele_support())[f[1]];
+        for (const std::string& name : SplitCommas(f[2])) sr.add_read_names(name);
+      } else if (f[0] == "A") {
+        size_t i = 0;
+        const std::string& s = f[1];
+        for (;;) {
+          const size_t t = s.find(';', i);
+          auto* idx = candidates.back().add_make_examples_alt_allele_indices();
+          for (const std::string& x : SplitCommas(s.substr(i, t == std::string::npos ? std::string::npos : t - i))) idx->add_indices(std::atoi(x.c_str()));
+          if (t == std::string::npos) break;
+          i = t + 1;
+        }
+      } else if (f[0] == "I") {
+        auto& lv = (*candidates.back().mutable_variant()->mutable_calls(0)->mutable_info())[f[1]];
+        for (const std::string& x : SplitCommas(f[3])) {
+          if (f[2] == "int") lv.add_values()->set_int_value(std::atoi(x.c_str()));
+          else lv.add_values()->set_number_value(std::atof(x.c_str()));
+        }
+      } else {
+        return fail("unknown line kind " + f[0]);
+      }
+    }
+    options.set_mode(refdv::MakeExamplesOptions::CALLING);
+    const std::string fasta = "dvref://reference", examples = "dvref://examples";
+    options.set_reference_filename(fasta);
+    options.set_examples_filename(examples);
+    nucleus::IndexedFastaReader::Registered reg;
+    reg.contig = contig;
+    reg.contig_length = contig_length;
+    reg.start = window_start;
+    reg.bases.assign(window_bases, static_cast<size_t>(n_window_bases));
+    nucleus::IndexedFastaReader::Registry()[fasta] = reg;
+    nucleus::CapturedExamples::Store()[examples].clear();
+    std::vector<int> image_shape;
+    {
+      refdv::ExamplesGenerator generator(options, {{role, examples}});
+      std::vector<Read> protos;
+      size_t total = 0;
+      for (int s = 0; s < n_samples; ++s) total += static_cast<size_t>(reads_per_sample[s]);
+      protos.resize(total);
+      for (size_t i = 0; i < total; ++i) {
+        MakeRead(reads[i], &protos[i]);
+        protos[i].mutable_alignment()->mutable_position()->set_reference_name(contig);
+      }
+      std::vector<std::vector<nucleus::ConstProtoPtr<Read>>> per_sample(static_cast<size_t>(n_samples));
+      size_t at = 0;
+      for (int s = 0; s < n_samples; ++s) {
+        for (int i = 0; i < reads_per_sample[s]; ++i) per_sample[static_cast<size_t>(s)].emplace_back(&protos[at++]);
+      }
+      std::vector<nucleus::ConstProtoPtr<refdv::DeepVariantCall>> cands;
+      for (auto& c : candidates) cands.emplace_back(&c);
+      const std::vector<int> order(sample_order, sample_order + n_sample_order);
+      const std::vector<float> coverage(mean_coverage_per_sample, mean_coverage_per_sample + n_samples);
+      generator.WriteExamplesInRegion(cands, per_sample, order, role, coverage, &image_shape);
+    }
+    for (size_t i = 0; i < 3; ++i) image_shape_out[i] = i < image_shape.size() ? image_shape[i] : 0;
+    std::string blob;
+    for (const std::string& ex : nucleus::CapturedExamples::Store()[examples]) {
+      const uint32_t n = static_cast<uint32_t>(ex.size());
+      blob.append(reinterpret_cast<const char*>(&n), 4);
+      blob.append(ex);
+    }
+    *out = static_cast<char*>(std::malloc(blob.size() + 1));
+    std::memcpy(*out, blob.data(), blob.size());
+    *out_len = blob.size();
+    return 0;
+  });
+}
+
+}  // extern "C"

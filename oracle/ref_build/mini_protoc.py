@@ -207,20 +207,40 @@ class Parser:
     return m
 
 
+
+def wire_scalar(t):
+  """proto scalar type -> (wire type, C++ expression template writing value `v` into *out)."""
+  W = '::google::protobuf::mini::'
+  if t in ('int32', 'int64', 'uint32', 'uint64', 'bool'):
+    return 0, W + 'PutVarint(out, static_cast<uint64_t>(static_cast<int64_t>(%s)))' if t in ('int32', 'int64') else W + 'PutVarint(out, static_cast<uint64_t>(%s))'
+  if t in ('sint32', 'sint64'):
+    return 0, W + 'PutVarint(out, ' + W + 'ZigZag(static_cast<int64_t>(%s)))'
+  if t in ('fixed32', 'sfixed32', 'float'):
+    return 5, W + 'PutFixed(out, %s)'
+  if t in ('fixed64', 'sfixed64', 'double'):
+    return 1, W + 'PutFixed(out, %s)'
+  raise KeyError(t)
+
+
 def camel(name):
   return ''.join(p[:1].upper() + p[1:] for p in name.split('_'))
 
 
 class Generator:
   def __init__(self, root):
-    self.root = root
+    self.roots = root if isinstance(root, (list, tuple)) else [root]
     self.files = {}           # path -> File
     self.types = {}           # fully qualified proto name -> ('message' | 'enum', cpp namespace, cpp class name)
 
   def load(self, path):
     if path in self.files:
       return
-    with open(os.path.join(self.root, path)) as fh:
+    for root in self.roots:
+      if os.path.exists(os.path.join(root, path)):
+        break
+    else:
+      raise FileNotFoundError(path)
+    with open(os.path.join(root, path)) as fh:
       f = Parser(tokenize(fh.read())).file(path)
     self.files[path] = f
     ns = '::'.join(f.package.split('.')) if f.package else ''
@@ -304,6 +324,10 @@ class Generator:
         w('  if (v == %d) { static const std::string s = "%s"; return s; }' % (num, name))
       w('  return kUnknown;\n}')
       w('inline bool %s_IsValid(int v) { return %s; }' % (cls, ' || '.join('v == %d' % n for n in sorted({n for _, n in e.values})) or 'false'))
+      w('inline const ::google::protobuf::mini::EnumDescriptor* %s_descriptor() {' % cls)
+      w('  static const ::google::protobuf::mini::EnumDescriptor* d = new ::google::protobuf::mini::EnumDescriptor({%s});'
+        % ', '.join('{"%s", %d}' % (name, num) for name, num in e.values))
+      w('  return d;\n}')
     # forward declarations
     for m in all_msgs:
       w('class %s;' % '_'.join(m.scope + [m.name]))
@@ -336,6 +360,29 @@ class Generator:
       visit(name)
 
     bodies = []
+    W = '::google::protobuf::mini::'
+
+    def put_value(scope, t, expr):
+      """statement(s) writing one value of proto type t (no tag) -- scalars, strings, enums, messages."""
+      if t in SCALARS:
+        return wire_scalar(t)[1] % expr + ';'
+      if t in STRINGS:
+        return W + 'PutBytes(out, %s);' % expr
+      kind, _ = self.resolve(f, scope, t)
+      if kind == 'enum':
+        return W + 'PutVarint(out, static_cast<uint64_t>(static_cast<int64_t>(%s)));' % expr
+      return '{ std::string sub; (%s).AppendTo(&sub); %sPutBytes(out, sub); }' % (expr, W)
+
+    def wire_type(scope, t):
+      if t in SCALARS:
+        return wire_scalar(t)[0]
+      if t in STRINGS:
+        return 2
+      kind, _ = self.resolve(f, scope, t)
+      return 0 if kind == 'enum' else 2
+
+    def tag(number, wt):
+      return W + 'PutVarint(out, %du);' % ((number << 3) | wt)
     for m in ordered:
       cls = '_'.join(m.scope + [m.name])
       scope = m.scope + [m.name]
@@ -358,6 +405,7 @@ class Generator:
         w('  void clear_%s() { _oneof_%s_ = 0; }' % (oneof, oneof))
       members = []
       merges = []      # statements of MergeFrom(const cls& o)
+      writes = []      # (field number, statement of AppendTo(std::string* out))
       for fld in m.fields:
         n = fld.name
         guard_get = guard_set = ''
@@ -375,6 +423,9 @@ class Generator:
           w('  void clear_%s() { %s_.clear(); }' % (n, n))
           members.append('  %s %s_;' % (mt, n))
           merges.append('for (const auto& kv : o.%s_) %s_[kv.first] = kv.second;' % (n, n))
+          writes.append((fld.number, 'for (const auto& kv : %s_) { std::string e; { std::string* out = &e; %s %s %s %s } %s %sPutBytes(out, e); }' % (
+              n, tag(1, wire_type(scope, fld.map_key)), put_value(scope, fld.map_key, 'kv.first'),
+              tag(2, wire_type(scope, fld.map_value)), put_value(scope, fld.map_value, 'kv.second'), tag(fld.number, 2), W)))
           continue
         kind, ct = self.cpp_type(f, scope, fld.type)
         if fld.label == 'repeated':
@@ -388,6 +439,8 @@ class Generator:
             w('  const std::string& %s(int i) const { return %s_[i]; }' % (n, n))
             w('  void add_%s(const std::string& v) { %s_.push_back(v); }' % (n, n))
             w('  void add_%s(const char* v) { %s_.emplace_back(v); }' % (n, n))
+            w('  void add_%s(const void* v, size_t len) { %s_.emplace_back(static_cast<const char*>(v), len); }' % (n, n))
+            w('  void add_%s(std::string&& v) { %s_.push_back(std::move(v)); }' % (n, n))
             w('  std::string* add_%s() { %s_.emplace_back(); return &%s_.back(); }' % (n, n, n))
             w('  std::string* mutable_%s(int i) { return &%s_[i]; }' % (n, n))
             w('  void set_%s(int i, const std::string& v) { %s_[i] = v; }' % (n, n))
@@ -405,6 +458,11 @@ class Generator:
           w('  void clear_%s() { %s_.clear(); }' % (n, n))
           members.append('  %s %s_;' % (rt, n))
           merges.append('for (const auto& e : o.%s_) %s_.push_back(e);' % (n, n))
+          if kind in ('scalar', 'enum'):      # packed (proto3)
+            writes.append((fld.number, 'if (!%s_.empty()) { std::string p; { std::string* out = &p; for (const auto& e : %s_) { %s } } %s %sPutBytes(out, p); }' % (
+                n, n, put_value(scope, fld.type, 'e'), tag(fld.number, 2), W)))
+          else:
+            writes.append((fld.number, 'for (const auto& e : %s_) { %s %s }' % (n, tag(fld.number, 2), put_value(scope, fld.type, 'e'))))
         elif kind in ('scalar', 'enum'):
           zero = 'static_cast<%s>(0)' % ct
           if fld.oneof:
@@ -420,10 +478,14 @@ class Generator:
           members.append('  %s %s_ = %s;' % (ct, n, zero))
           if fld.oneof:
             merges.append('if (o.%s) set_%s(o.%s_);' % (guard_get, n, n))
+            cond = guard_get
           elif fld.optional:
             merges.append('if (o._has_%s_) set_%s(o.%s_);' % (n, n, n))
+            cond = '_has_%s_' % n
           else:
             merges.append('if (o.%s_ != %s) %s_ = o.%s_;' % (n, zero, n, n))
+            cond = '%s_ != %s' % (n, zero)
+          writes.append((fld.number, 'if (%s) { %s %s }' % (cond, tag(fld.number, wire_type(scope, fld.type)), put_value(scope, fld.type, n + '_'))))
         elif kind == 'string':
           if fld.oneof:
             w('  const std::string& %s() const { return %s ? %s_ : ::google::protobuf::mini::EmptyString(); }' % (n, guard_get, n))
@@ -443,10 +505,14 @@ class Generator:
           members.append('  std::string %s_;' % n)
           if fld.oneof:
             merges.append('if (o.%s) set_%s(o.%s_);' % (guard_get, n, n))
+            cond = guard_get
           elif fld.optional:
             merges.append('if (o._has_%s_) set_%s(o.%s_);' % (n, n, n))
+            cond = '_has_%s_' % n
           else:
             merges.append('if (!o.%s_.empty()) %s_ = o.%s_;' % (n, n, n))
+            cond = '!%s_.empty()' % n
+          writes.append((fld.number, 'if (%s) { %s %sPutBytes(out, %s_); }' % (cond, tag(fld.number, 2), W, n)))
         else:     # singular message: held through a copying pointer (the type may still be incomplete here)
           w('  const %s& %s() const;' % (ct, n))
           w('  %s* mutable_%s();' % (ct, n))
@@ -466,14 +532,25 @@ class Generator:
           members.append('  ::google::protobuf::mini::Box<%s> %s_;' % (ct, n))
           if fld.oneof:
             merges.append('if (o.%s) mutable_%s()->MergeFrom(o.%s_.get());' % (guard_get, n, n))
+            cond = guard_get
           else:
             merges.append('if (o.%s_.has()) mutable_%s()->MergeFrom(o.%s_.get());' % (n, n, n))
+            cond = '%s_.has()' % n
+          writes.append((fld.number, 'if (%s) { %s %s }' % (cond, tag(fld.number, 2), put_value(scope, fld.type, n + '_.get()'))))
       # (text format is only ever used inside the reference's log / CHECK messages)
       w('  std::string DebugString() const { return "<%s>"; }' % cls)
       w('  std::string ShortDebugString() const { return "<%s>"; }' % cls)
       w('  void Clear() { *this = %s(); }' % cls)
       w('  void CopyFrom(const %s& other) { *this = other; }' % cls)
       w('  void MergeFrom(const %s& o);' % cls)
+      # wire format (fields in number order, packed repeated scalars, map entries in key order): what the
+      # reference's EncodeExample hands to its TFRecord writer
+      w('  void AppendTo(std::string* out) const;')
+      w('  bool SerializeToString(std::string* out) const { out->clear(); AppendTo(out); return true; }')
+      w('  std::string SerializeAsString() const { std::string s; AppendTo(&s); return s; }')
+      w('  size_t ByteSizeLong() const { return SerializeAsString().size(); }')
+      bodies.append('inline void %s::AppendTo(std::string* out) const {\n  %s\n}' % (
+          cls, '\n  '.join(stmt for _, stmt in sorted(writes, key=lambda t: t[0])) or '(void)out;'))
       bodies.append('inline void %s::MergeFrom(const %s& o) {\n  %s\n}' % (cls, cls, '\n  '.join(merges) or '(void)o;'))
       w(' private:')
       for oneof in m.oneofs:
@@ -493,7 +570,7 @@ class Generator:
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--root', required=True)
+  ap.add_argument('--root', required=True, action='append')
   ap.add_argument('--out', required=True)
   ap.add_argument('protos', nargs='+')
   a = ap.parse_args()

@@ -7,6 +7,8 @@
 
 #include <stdexcept>
 #include <cstddef>
+#include <cstdint>
+#include <cstring>
 #include <initializer_list>
 #include <iterator>
 #include <map>
@@ -214,6 +216,45 @@ class Map : public std::map<K, V> {
 };
 
 namespace mini {
+
+// wire-format primitives for the generated AppendTo()
+inline void PutVarint(std::string* out, uint64_t v) {
+  while (v >= 0x80) {
+    out->push_back(static_cast<char>((v & 0x7F) | 0x80));
+    v >>= 7;
+  }
+  out->push_back(static_cast<char>(v));
+}
+inline uint64_t ZigZag(int64_t v) { return (static_cast<uint64_t>(v) << 1) ^ static_cast<uint64_t>(v >> 63); }
+template <class T>
+inline void PutFixed(std::string* out, T v) {
+  char b[sizeof(T)];
+  std::memcpy(b, &v, sizeof(T));      // little-endian hosts only (x86-64)
+  out->append(b, sizeof(T));
+}
+inline void PutBytes(std::string* out, const std::string& v) {
+  PutVarint(out, v.size());
+  out->append(v);
+}
+
+// what the reference asks an enum's descriptor: value_count(), value(i)->number() / ->name()
+class EnumValueDescriptor {
+ public:
+  EnumValueDescriptor(const char* name, int number) : name_(name), number_(number) {}
+  int number() const { return number_; }
+  const std::string& name() const { return name_; }
+ private:
+  std::string name_;
+  int number_;
+};
+class EnumDescriptor {
+ public:
+  EnumDescriptor(std::initializer_list<EnumValueDescriptor> v) : values_(v) {}
+  int value_count() const { return static_cast<int>(values_.size()); }
+  const EnumValueDescriptor* value(int i) const { return &values_[static_cast<size_t>(i)]; }
+ private:
+  std::vector<EnumValueDescriptor> values_;
+};
 
 inline const std::string& EmptyString() {
   static const std::string s;

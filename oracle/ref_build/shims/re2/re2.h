@@ -25,6 +25,13 @@ class RE2 {
     input->remove_prefix(static_cast<size_t>(m.length(0)));
     return true;
   }
+  // Replaces the first match of `re` in *str with `rewrite` (no backreferences used by the callers).
+  static bool Replace(std::string* str, const RE2& re, std::string_view rewrite) {
+    std::smatch m;
+    if (!std::regex_search(*str, m, re.re_)) return false;
+    str->replace(static_cast<size_t>(m.position(0)), static_cast<size_t>(m.length(0)), rewrite);
+    return true;
+  }
  private:
   static bool Store(const std::cmatch& m, size_t k, int* out) {
     if (k >= m.size()) return false;
