@@ -838,3 +838,77 @@ def reference_write_examples_in_region(options, ref_reader, contig: str, contig_
     examples.append(blob[at + 4:at + 4 + ln])
     at += 4 + ln
   return examples, [int(x) for x in shape]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Local assembly and read phasing on the reference's own sources (realigner/debruijn_graph.cc, direct_phasing.cc in
+# oracle/_ref/libdvref.so, over the Boost-Graph stand-in of oracle/ref_build/shims/boost/graph/).  tests/ only.
+# ---------------------------------------------------------------------------------------------------------------
+class ReferenceDeBruijnGraph:
+  """What deepvariant_amd.realigner.debruijn_graph.DeBruijnGraph offers, answered by the reference build."""
+
+  def __init__(self, kmer_size, haplotypes, dot):
+    self.kmer_size, self._haplotypes, self._dot = kmer_size, haplotypes, dot
+
+  def candidate_haplotypes(self):
+    return list(self._haplotypes)
+
+  def graphviz(self):
+    return self._dot
+
+
+def reference_debruijn(ref: str, reads, options):
+  """DeBruijnGraph::Build(ref, reads, options) -> ReferenceDeBruijnGraph, or None where the reference returns
+  nullptr (no k without a cycle)."""
+  keep = _Keep()
+  opts = (C.c_int32 * 8)(options.min_k, options.max_k, options.step_k, options.min_mapq, options.min_base_quality,
+                         options.min_edge_weight, options.max_num_paths, int(bool(options.disable_graph_pruning)))
+  text = _ref_text_call('dvr_debruijn', [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p], ref.encode(), _read_array(reads, keep),
+                        len(reads), opts)
+  if text.startswith('N'):
+    return None
+  head, _, dot = text.partition('#GRAPHVIZ\n')
+  k, haplotypes = 0, []
+  for line in head.split('\n'):
+    f = line.split('\t')
+    if f[0] == 'K':
+      k = int(f[1])
+    elif f[0] == 'H':
+      haplotypes.append(f[1])
+  return ReferenceDeBruijnGraph(k, haplotypes, dot)
+
+
+class ReferenceDirectPhasing:
+  """deepvariant_amd.direct_phasing.DirectPhasing's interface on the reference's DirectPhasing."""
+
+  def __init__(self, min_alleles_to_phase: int = 1):
+    self._min = int(min_alleles_to_phase)
+    self._variants, self._dot = [], ''
+
+  def phase(self, candidates, reads):
+    lines = []
+    for c in candidates:
+      v = c.variant
+      lines.append('C\t%d\t%d\t%s\t%s' % (v.start, v.end, v.reference_bases, ','.join(v.alternate_bases)))
+      for allele, infos in c.allele_support_ext.items():
+        lines.append('E\t%s\t%s' % (allele, ','.join('%s:%d' % (i.read_name, int(bool(i.is_low_quality))) for i in infos)))
+      if c.ref_support_ext:
+        lines.append('F\t%s' % ','.join('%s:%d' % (i.read_name, int(bool(i.is_low_quality))) for i in c.ref_support_ext))
+    keep = _Keep()
+    phases = np.zeros(max(len(reads), 1), np.int32)
+    text = _ref_text_call('dvr_phase_reads', [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], '\n'.join(lines).encode(),
+                          _read_array(reads, keep), len(reads), self._min, phases.ctypes.data)
+    head, _, self._dot = text.partition('#GRAPHVIZ\n')
+    self._variants = []
+    for line in head.split('\n'):
+      f = line.split('\t')
+      if f[0] == 'V':
+        self._variants.append((int(f[1]), f[2], f[3], bool(int(f[4]))))
+    return [int(p) for p in phases[:len(reads)]]
+
+  def get_phased_variants(self):
+    from deepvariant_amd import direct_phasing
+    return [direct_phasing.PhasedVariant(*v) for v in self._variants]
+
+  def graphviz(self):
+    return self._dot

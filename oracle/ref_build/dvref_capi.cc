@@ -1065,3 +1065,106 @@ int dvr_write_examples_in_region(const char* spec, const char* contig, int64_t c
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The realigner's local assembly (deepvariant/realigner/debruijn_graph.cc) and the long-read chain's read phasing
+// (deepvariant/direct_phasing.cc), compiled unmodified over a small Boost-Graph stand-in (shims/boost/graph/).
+// SURVEY.md 8f row f4 and the phasing of section 13.
+// ---------------------------------------------------------------------------------------------------------------
+#include "deepvariant/direct_phasing.h"
+#include "deepvariant/realigner/debruijn_graph.h"
+
+extern "C" {
+
+/* options: min_k, max_k, step_k, min_mapq, min_base_quality, min_edge_weight, max_num_paths, disable_graph_pruning.
+ * Lines: "N" (no graph: no acyclic k), or "K <kmer size>", "H <haplotype>" (sorted), then "G" followed by the
+ * graphviz dump on the remaining lines. */
+int dvr_debruijn(const char* ref, const dvo_read* reads, int n_reads, const int32_t* options, char** out, uint64_t* out_len) {
+  return Guard([&] {
+    refdv::DeBruijnGraphOptions o;
+    o.set_min_k(options[0]);
+    o.set_max_k(options[1]);
+    o.set_step_k(options[2]);
+    o.set_min_mapq(options[3]);
+    o.set_min_base_quality(options[4]);
+    o.set_min_edge_weight(options[5]);
+    o.set_max_num_paths(options[6]);
+    o.set_disable_graph_pruning(options[7] != 0);
+    std::vector<Read> protos(static_cast<size_t>(n_reads));
+    std::vector<nucleus::ConstProtoPtr<const Read>> ptrs;
+    for (int i = 0; i < n_reads; ++i) {
+      MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+      ptrs.emplace_back(&protos[static_cast<size_t>(i)]);
+    }
+    std::unique_ptr<refdv::DeBruijnGraph> graph = refdv::DeBruijnGraph::Build(ref, ptrs, o);
+    std::ostringstream text;
+    if (!graph) {
+      text << "N\n";
+    } else {
+      text << "K\t" << graph->KmerSize() << '\n';
+      for (const std::string& h : graph->CandidateHaplotypes()) text << "H\t" << h << '\n';
+      text << "#GRAPHVIZ\n" << graph->GraphViz();
+    }
+    return TextOut(text, out, out_len);
+  });
+}
+
+/* spec lines:  C <start> <end> <reference_bases> <alt,alt>   a candidate (strictly ordered by start)
+ *              E <allele> <read name:is_low_quality,...>     its allele_support_ext
+ *              F <read name:is_low_quality,...>              its ref_support_ext
+ * phases_out[n_reads]; text: "V <position> <phase 1 bases> <phase 2 bases> <is_first_in_block>" per phased variant,
+ * then "G" and the graphviz dump on the remaining lines. */
+int dvr_phase_reads(const char* spec, const dvo_read* reads, int n_reads, int min_alleles_to_phase, int32_t* phases_out,
+                    char** out, uint64_t* out_len) {
+  return Guard([&] {
+    std::vector<refdv::DeepVariantCall> candidates;
+    std::istringstream in(spec);
+    std::string line;
+    auto fill = [](const std::string& list, refdv::DeepVariantCall::SupportingReadsExt* dst) {
+      for (const std::string& item : SplitCommas(list)) {
+        const size_t c = item.rfind(':');
+        auto* info = dst->add_read_infos();
+        info->set_read_name(item.substr(0, c));
+        info->set_is_low_quality(item.substr(c + 1) == "1");
+      }
+    };
+    while (std::getline(in, line)) {
+      if (line.empty()) continue;
+      const std::vector<std::string> f = SplitTabs(line);
+      if (f[0] == "C") {
+        candidates.emplace_back();
+        auto* v = candidates.back().mutable_variant();
+        v->set_reference_name("contig");
+        v->set_start(std::atoll(f[1].c_str()));
+        v->set_end(std::atoll(f[2].c_str()));
+        v->set_reference_bases(f[3]);
+        for (const std::string& a : SplitCommas(f[4])) v->add_alternate_bases(a);
+      } else if (f[0] == "E") {
+        fill(f.size() > 2 ? f[2] : "", &(*candidates.back().mutable_allele_support_ext())[f[1]]);
+      } else if (f[0] == "F") {
+        fill(f.size() > 1 ? f[1] : "", candidates.back().mutable_ref_support_ext());
+      }
+    }
+    std::vector<Read> protos(static_cast<size_t>(n_reads));
+    std::vector<nucleus::ConstProtoPtr<const Read>> ptrs;
+    for (int i = 0; i < n_reads; ++i) {
+      MakeRead(reads[i], &protos[static_cast<size_t>(i)]);
+      ptrs.emplace_back(&protos[static_cast<size_t>(i)]);
+    }
+    refdv::DirectPhasingOptions o;
+    o.set_min_alleles_to_phase(min_alleles_to_phase);
+    refdv::DirectPhasing phasing(o);
+    auto phases = phasing.PhaseReads(candidates, ptrs);
+    if (!phases.ok()) return fail(std::string(phases.status().message()));
+    const std::vector<int>& p = phases.ValueOrDie();
+    for (int i = 0; i < n_reads; ++i) phases_out[i] = i < static_cast<int>(p.size()) ? p[static_cast<size_t>(i)] : 0;
+    std::ostringstream text;
+    for (const refdv::PhasedVariant& pv : phasing.GetPhasedVariants()) {
+      text << "V\t" << pv.position << '\t' << pv.phase_1_bases << '\t' << pv.phase_2_bases << '\t' << (pv.is_first_in_block ? 1 : 0) << '\n';
+    }
+    text << "#GRAPHVIZ\n" << phasing.GraphViz();
+    return TextOut(text, out, out_len);
+  });
+}
+
+}  // extern "C"

@@ -55,6 +55,19 @@ struct H<std::vector<T>, void> {
     return seed;
   }
 };
+// types that hash themselves the abseil way: friend H AbslHashValue(H h, const T&) { return H::combine(std::move(h), ...); }
+struct HashState {
+  size_t v = 0;
+  template <class... A>
+  static HashState combine(HashState h, const A&... a) {
+    ((h.v = Mix(h.v, H<A>()(a))), ...);
+    return h;
+  }
+};
+template <class T>
+struct H<T, std::void_t<decltype(AbslHashValue(std::declval<HashState>(), std::declval<const T&>()))>> {
+  size_t operator()(const T& v) const { return AbslHashValue(HashState{}, v).v; }
+};
 }  // namespace dvref_hash
 template <class T>
 using Hash = dvref_hash::H<T>;
