@@ -912,3 +912,22 @@ class ReferenceDirectPhasing:
 
   def graphviz(self):
     return self._dot
+
+
+def reference_normalize_cigars(ref_reader, contig: str, start: int, end: int, reads, contig_length: int = 1 << 40,
+                               ref_margin: int = 2000):
+  """AlleleCounter::NormalizeAndAdd per read (a counter over [start, end) of `contig`, normalize_reads on)
+  -> [(is_modified, read_shift, [(op, length), ...])]."""
+  keep = _Keep()
+  lo, hi = max(0, start - ref_margin), min(contig_length, end + ref_margin)
+  bases = ref_reader.get_bases(contig, lo, hi).encode()
+  text = _ref_text_call('dvr_normalize_cigars', [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_int64, C.c_int64,
+                                                 C.c_void_p, C.c_int],
+                        contig.encode(), int(contig_length), lo, bases, len(bases), int(start), int(end), _read_array(reads, keep),
+                        len(reads))
+  out = []
+  for line in text.split('\n'):
+    f = line.split('\t')
+    if f[0] == 'N':
+      out.append((bool(int(f[1])), int(f[2]), [tuple(int(x) for x in u.split(':')) for u in f[3].split(',')] if f[3] else []))
+  return out

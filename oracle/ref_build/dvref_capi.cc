@@ -1168,3 +1168,46 @@ int dvr_phase_reads(const char* spec, const dvo_read* reads, int n_reads, int mi
 }
 
 }  // extern "C"
+
+extern "C" {
+
+/* AlleleCounter::NormalizeAndAdd (allelecounter.cc:847-871) for every read, against a counter over [start, end):
+ * per read one line "N <is_modified> <read_shift> <op:len,...>" (the normalised CIGAR, or the input one when it was
+ * left alone). */
+int dvr_normalize_cigars(const char* contig, int64_t contig_length, int64_t ref_start, const char* ref_bases,
+                         int64_t n_ref_bases, int64_t start, int64_t end, const dvo_read* reads, int n_reads, char** out,
+                         uint64_t* out_len) {
+  return Guard([&] {
+    WindowReference ref(contig, contig_length, ref_start, std::string(ref_bases, static_cast<size_t>(n_ref_bases)));
+    refdv::AlleleCounterOptions co;
+    co.set_partition_size(static_cast<int32_t>(end - start));
+    co.set_normalize_reads(true);
+    nucleus::genomics::v1::Range range;
+    range.set_reference_name(contig);
+    range.set_start(start);
+    range.set_end(end);
+    refdv::AlleleCounter counter(&ref, range, {}, co);
+    std::ostringstream text;
+    for (int i = 0; i < n_reads; ++i) {
+      Read proto;
+      MakeRead(reads[i], &proto);
+      proto.mutable_alignment()->mutable_position()->set_reference_name(contig);
+      std::unique_ptr<std::vector<CigarUnit>> norm(new std::vector<CigarUnit>());
+      int shift = 0;
+      counter.NormalizeAndAdd(proto, "s", norm, shift);
+      const bool modified = !norm->empty();
+      text << "N\t" << (modified ? 1 : 0) << '\t' << shift << '\t';
+      if (modified) {
+        for (size_t k = 0; k < norm->size(); ++k) text << (k ? "," : "") << static_cast<int>((*norm)[k].operation()) << ':' << (*norm)[k].operation_length();
+      } else {
+        for (int k = 0; k < proto.alignment().cigar_size(); ++k) {
+          text << (k ? "," : "") << static_cast<int>(proto.alignment().cigar(k).operation()) << ':' << proto.alignment().cigar(k).operation_length();
+        }
+      }
+      text << '\n';
+    }
+    return TextOut(text, out, out_len);
+  });
+}
+
+}  // extern "C"

@@ -186,3 +186,69 @@ def test_window_selector_models(seed, long_reads, legacy):
     # reference itself; everything above it is
     assert got.dtype == np.float32 and np.abs(got - scores).max() <= 2e-6, np.abs(got - scores).max()
     assert ((got > linear[6]) == (scores > linear[6])).mean() > 0.999
+
+
+@pytest.mark.parametrize('seed', [51, 52, 53])
+def test_normalize_cigar(seed):
+  """AlleleCounter::NormalizeCigar (--normalize_reads): indels left-aligned against the reference, adjacent
+  operations merged, a leading indel folded into the start -- deepvariant_amd.allelecounter.normalize_cigar against
+  the reference's NormalizeAndAdd on reads whose indels sit in homopolymers and tandem repeats."""
+  rng = np.random.default_rng(seed)
+  seq = []
+  while len(seq) < 4000:      # a reference rich in repeats: where left-alignment has something to do
+    u = rng.random()
+    if u < 0.35:
+      seq += ['ACGT'[int(rng.integers(0, 4))]] * int(rng.integers(2, 9))
+    elif u < 0.55:
+      unit = ['ACGT'[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(2, 4)))]
+      seq += unit * int(rng.integers(2, 7))
+    else:
+      seq += ['ACGT'[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 12)))]
+  ref = _Ref(''.join(seq[:4000]))
+  start, end = 500, 3500
+  reads = []
+  for i in range(400):
+    pos = int(rng.integers(start + 5, end - 400))
+    cigar, bases, p = [], [], pos
+    for k in range(int(rng.integers(1, 6))):
+      n = int(rng.integers(5, 60))
+      cigar.append(T.CigarUnit(1, n))
+      bases.append(ref.seq[p:p + n])
+      p += n
+      u = rng.random()
+      m = int(rng.integers(1, 7))
+      if u < 0.4:      # an insertion that repeats the bases in front of it: shiftable
+        cigar.append(T.CigarUnit(2, m))
+        bases.append(ref.seq[p - m:p] if rng.random() < 0.7 else ''.join('ACGT'[int(j)] for j in rng.integers(0, 4, size=m)))
+      elif u < 0.8:
+        cigar.append(T.CigarUnit(3, m))
+        p += m
+      elif u < 0.9:
+        cigar.append(T.CigarUnit(1, 3))      # adjacent matches: merged
+        bases.append(ref.seq[p:p + 3])
+        p += 3
+    if cigar[-1].operation != 1:
+      cigar.append(T.CigarUnit(1, 12))
+      bases.append(ref.seq[p:p + 12])
+    # (no soft clips here: the reference CHECK-fails -- allelecounter.cc:664 -- when an indel shifts left until it
+    # meets one, e.g. 4S5M2I in a repeat; the reference's NormalizeCigar vectors cover clipped reads)
+    if rng.random() < 0.1:      # a read that starts with an indel
+      cigar.insert(0, T.CigarUnit(int(rng.choice([2, 3])), 2))
+      if cigar[0].operation == 2:
+        bases.insert(0, 'GG')
+    s = ''.join(bases)
+    reads.append(T.Read(fragment_name='n%d' % i, read_number=0, number_reads=1, aligned_sequence=s,
+                        aligned_quality=bytes([30] * len(s)),
+                        alignment=T.LinearAlignment(position=T.Position('c', pos, False), mapping_quality=60, cigar=cigar)))
+  theirs = O.reference_normalize_cigars(ref, 'c', start, end, reads, contig_length=len(ref.seq))
+  # the counter's reads interval is the counting interval itself here (no full_range): its reference bases
+  window = ref.seq[start:end]
+  changed = 0
+  for r, (modified, shift, cigar) in zip(reads, theirs):
+    got_modified, got_cigar, got_shift = ac.normalize_cigar(r.aligned_sequence, r.alignment.position.position - start,
+                                                            r.alignment.cigar, window)
+    assert got_modified == modified and got_shift == shift, (r.fragment_name, modified, shift, got_modified, got_shift)
+    if modified:
+      assert [(c.operation, c.operation_length) for c in got_cigar] == cigar, r.fragment_name
+      changed += 1
+  assert changed > 60
