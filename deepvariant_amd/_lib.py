@@ -32,7 +32,7 @@ DV_ERR_BAD_INPUT = -6
 # Every symbol include/dvhip.h declares (checked by tests/test_abi.py).
 ABI_SYMBOLS = [
     'dv_last_error', 'dv_abi_version', 'dv_device_count',
-    'dv_encoder_create', 'dv_encoder_destroy', 'dv_encode_batch',
+    'dv_encoder_create', 'dv_encoder_destroy', 'dv_encode_batch', 'dv_base_aux_plane', 'dv_flow_channel_pixels',
     'dv_downsample_indices', 'dv_validate_batch', 'dv_query_reads', 'dv_crc32c',
     'dv_model_create', 'dv_model_destroy', 'dv_model_num_params', 'dv_model_conv_macs',
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
@@ -119,6 +119,7 @@ class DvBatch(C.Structure):
       ('n_list', C.c_uint32), ('max_list_len', C.c_uint32),
       ('base_aux0', C.c_void_p), ('base_aux1', C.c_void_p),
       ('ref_aux0', C.c_void_p), ('ref_aux1', C.c_void_p), ('ref_aux2', C.c_void_p),
+      ('base_aux2', C.c_void_p),        # ABI v6
   ]
 
 
@@ -291,6 +292,9 @@ def lib():
     l.dv_cram_read_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, REF_FETCH_FN,
                                       C.c_void_p, C.c_int, C.c_void_p]
     l.dv_cram_header.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    l.dv_base_aux_plane.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    l.dv_flow_channel_pixels.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p]
     l.dv_read_table_fill_batch.argtypes = [C.c_void_p, C.c_void_p]
     l.dv_read_table_name.restype = C.c_char_p
     l.dv_read_table_name.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]

@@ -67,6 +67,7 @@ enum ChannelKind : uint8_t {
   kAuxList,       // host-computed per-(item,read) pixel, list_aux
   kBaseAux0,      // host-computed per-base pixel (is_homopolymer); reference row: ref_aux0
   kBaseAux1,      // host-computed per-base pixel (homopolymer_weighted); reference row: ref_aux1
+  kBaseAux2,      // host-computed per-base pixel, third plane (flow-space channels; these may also sit in planes 0 / 1)
 };
 
 // Everything the kernel needs besides the batch; copied into LDS per workgroup.
@@ -135,6 +136,7 @@ struct EncArgs {
   const uint8_t* list_aux;
   const uint8_t* base_aux0;
   const uint8_t* base_aux1;
+  const uint8_t* base_aux2;
   const uint8_t* ref_aux0;
   const uint8_t* ref_aux1;
   const uint8_t* ref_aux2;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         case kAuxList: v = a.list_aux ? a.list_aux[le] : 0; break;
         case kBaseAux0: if (a.base_aux0) dyn_b = 1; break;
         case kBaseAux1: if (a.base_aux1) dyn_b = 2; break;
+        case kBaseAux2: if (a.base_aux2) dyn_b = 3; break;
         default: break;  // kZero
       }
       konst[d] |= v << sh;
@@ -671,6 +674,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
           if ((flags & DV_READ_HAS_6MA) && a.mod_6ma) dyn_b = c->lut_mod[a.mod_6ma[s0 + in.ri[q]]];
           if (a.base_aux0) dyn_b |= static_cast<uint32_t>(a.base_aux0[s0 + in.ri[q]]) << 8;
           if (a.base_aux1) dyn_b |= static_cast<uint32_t>(a.base_aux1[s0 + in.ri[q]]) << 16;
+          if (a.base_aux2) dyn_b |= static_cast<uint32_t>(a.base_aux2[s0 + in.ri[q]]) << 24;
 #pragma unroll
           for (int d = 0; d < kPixDw; ++d) {
             if (d < n_pix_dw) o[d] = __builtin_amdgcn_perm(dyn_b, o[d], sel_b[d]);
@@ -909,6 +913,16 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
         ref = static_cast<uint8_t>(o.allele_unsupporting_read_alpha);  // sic (:61-65)
         break;
       case DV_CH_ALLELE_SAMPLE_PROBABILITY: kind = kAuxList; ref = 0; break;
+      case DV_CH_HOMOPOLYMER_INSERTION_QUALITY:
+      case DV_CH_HOMOPOLYMER_DELETION_QUALITY:
+      case DV_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY: {
+        // per-base pixels from the host; the plane follows dv_base_aux_plane's rule; the reference row is 0
+        // (homopolymer_insertion_quality_channel.cc:63-67 and its siblings)
+        const int plane = dv_base_aux_plane(o.channels, o.n_channels, c);
+        if (plane < 0 || plane > 2) return plane < 0 ? plane : DV_ERR_INVALID_ARGUMENT;
+        kind = static_cast<uint8_t>(kBaseAux0 + plane);
+        break;
+      }
       case DV_CH_READ_SUPPORTS_VARIANT_FUZZY:  // read_supports_variant_fuzzy_channel.cc:115-119
         kind = kAuxList;
         ref = k->lut_support[0];
@@ -936,8 +950,9 @@ int build_const(const dv_encoder_options& o, EncConst* k) {
   }
   for (int c = 0; c < o.n_channels; ++c) {
     const int d = c >> 2, sh = (c & 3) * 8;
-    const int dyn = k->kind[c] == kBase ? 4 : k->kind[c] == kBaseAux0 ? 5
-                    : k->kind[c] == kBaseAux1 ? 6 : k->kind[c] == kAuxRead4 ? 7 : -1;
+    // (a flow-space channel may sit in plane 0 / 1 too: its reference row is the constant 0, not ref_aux0 / ref_aux1)
+    const int dyn = k->kind[c] == kBase ? 4 : o.channels[c] == DV_CH_IS_HOMOPOLYMER ? 5
+                    : o.channels[c] == DV_CH_HOMOPOLYMER_WEIGHTED ? 6 : k->kind[c] == kAuxRead4 ? 7 : -1;
     if (dyn >= 0) {  // reference-row byte taken from {base colour, ref_aux0, ref_aux1, ref_aux2}
       k->ref_sel[d] = (k->ref_sel[d] & ~(0xFFu << sh)) | (static_cast<uint32_t>(dyn) << sh);
     } else {
@@ -1056,6 +1071,36 @@ int stage(dv_encoder* enc, size_t slot, const T* host, size_t count,
 }  // namespace
 
 extern "C" {
+
+int dv_base_aux_plane(const int32_t* channels, int32_t n_channels, int32_t channel_index) {
+  if (!channels || channel_index < 0 || channel_index >= n_channels) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_base_aux_plane: bad channel index");
+  }
+  bool used[3] = {false, false, false};
+  for (int c = 0; c < n_channels; ++c) {
+    if (channels[c] == DV_CH_IS_HOMOPOLYMER) used[0] = true;
+    if (channels[c] == DV_CH_HOMOPOLYMER_WEIGHTED) used[1] = true;
+  }
+  if (channels[channel_index] == DV_CH_IS_HOMOPOLYMER) return 0;
+  if (channels[channel_index] == DV_CH_HOMOPOLYMER_WEIGHTED) return 1;
+  for (int c = 0; c <= channel_index; ++c) {
+    const int ch = channels[c];
+    if (ch != DV_CH_HOMOPOLYMER_INSERTION_QUALITY && ch != DV_CH_HOMOPOLYMER_DELETION_QUALITY &&
+        ch != DV_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY) {
+      continue;
+    }
+    int plane = 2;
+    while (plane >= 0 && used[plane]) --plane;
+    if (plane < 0) {
+      return dv::fail(DV_ERR_UNSUPPORTED,
+                      "more than three per-base host-computed channels (is_homopolymer, homopolymer_weighted and "
+                      "the flow-space channels) in one channel list");
+    }
+    used[plane] = true;
+    if (c == channel_index) return plane;
+  }
+  return DV_BASE_AUX_NONE;
+}
 
 int dv_encoder_create(const dv_encoder_options* options, int device,
                       dv_encoder** out) {
@@ -1234,6 +1279,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     DV_STAGE(list_aux, b->n_list)
     DV_STAGE(base_aux0, b->n_bases)
     DV_STAGE(base_aux1, b->n_bases)
+    DV_STAGE(base_aux2, b->n_bases)
     DV_STAGE(ref_aux0, static_cast<size_t>(b->n_ref_windows) * W)
     DV_STAGE(ref_aux1, static_cast<size_t>(b->n_ref_windows) * W)
     DV_STAGE(ref_aux2, static_cast<size_t>(b->n_ref_windows) * W)
@@ -1249,7 +1295,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     DV_PASS(item_height) DV_PASS(item_out_off) DV_PASS(item_blank_mask)
     DV_PASS(item_mean_coverage) DV_PASS(ref_windows) DV_PASS(list_read)
     DV_PASS(list_code) DV_PASS(list_group) DV_PASS(list_aux)
-    DV_PASS(base_aux0) DV_PASS(base_aux1) DV_PASS(ref_aux0) DV_PASS(ref_aux1) DV_PASS(ref_aux2)
+    DV_PASS(base_aux0) DV_PASS(base_aux1) DV_PASS(base_aux2) DV_PASS(ref_aux0) DV_PASS(ref_aux1) DV_PASS(ref_aux2)
 #undef DV_PASS
   }
 

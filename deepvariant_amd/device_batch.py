@@ -27,7 +27,7 @@ _FIELDS = [
     ('item_blank_mask', np.uint32), ('item_mean_coverage', np.float32),
     ('ref_windows', np.uint8), ('list_read', np.uint32),
     ('list_code', np.uint8), ('list_group', np.uint8), ('list_aux', np.uint8),
-    ('base_aux0', np.uint8), ('base_aux1', np.uint8),
+    ('base_aux0', np.uint8), ('base_aux1', np.uint8), ('base_aux2', np.uint8),
     ('ref_aux0', np.uint8), ('ref_aux1', np.uint8), ('ref_aux2', np.uint8),
 ]
 

@@ -314,7 +314,8 @@ class ExamplesGenerator:
     for reads in reads_per_sample:
       if isinstance(reads, packing.ReadTable):
         if ((self._encoder_api._need_aux and reads.read_aux is None) or
-            (self._encoder_api._need_seq_aux and reads.base_aux0 is None)):
+            any(ch and getattr(reads, 'base_aux%d' % k) is None
+                for k, ch in enumerate(self._encoder_api._need_seq_aux))):
           raise ValueError('this channel set needs per-read aux pixels; pack the reads with '
                            'ReadTable.from_reads(need_aux=True)')
         tables.append(reads)
@@ -682,7 +683,7 @@ def _concat_tables(tables: List[packing.ReadTable]):
       mod_5mc=opt('mod_5mc'), mod_6ma=opt('mod_6ma'), cigar=cat('cigar', np.uint32),
       keys=[k for t in tables for k in t.keys],
       read_end=cat('read_end', np.int64),
-      base_aux0=opt('base_aux0'), base_aux1=opt('base_aux1'))
+      base_aux0=opt('base_aux0'), base_aux1=opt('base_aux1'), base_aux2=opt('base_aux2'))
   return merged, base
 
 

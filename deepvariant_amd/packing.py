@@ -11,6 +11,7 @@ cross to the device (include/dvhip.h, `dv_batch`).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import dataclasses
@@ -27,7 +28,8 @@ DV_READ_REVERSE, DV_READ_SUPPLEMENTARY, DV_READ_HAS_5MC, DV_READ_HAS_6MA = 1, 2,
 # Channels whose pixel the device computes itself / which need host-computed
 # aux bytes (include/dvhip.h DV_CH_*).
 _READ_AUX_SLOT = {11: 0, 12: 1, 13: 2, 14: 3, 15: 4}
-_SEQ_AUX_CHANNELS = (16, 17)        # is_homopolymer, homopolymer_weighted: per-base pixels
+_SEQ_AUX_CHANNELS = (16, 17, 28, 29, 30)  # is_homopolymer, homopolymer_weighted, the three Ultima flow-space channels: per-base pixels
+_FLOW_CHANNELS = (28, 29, 30)       # homopolymer_{insertion,deletion}_quality (tp tag), inter_homopolymer_insertion_quality (t0)
 _REF_AUX_CHANNELS = (15, 16, 17)    # ... and gc_content: per-window reference-row pixels
 _LIST_AUX_CHANNELS = (8, 25, 27)   # one pixel per (item, read), computed on the host
 
@@ -114,6 +116,63 @@ def homopolymer_weighted_pixels(seq: bytes) -> np.ndarray:
   starts = np.concatenate([[0], change])
   lens = np.diff(np.concatenate([starts, [b.size]]))
   return _HW_LUT[np.repeat(lens, lens) & 0xFF]
+
+
+def seq_aux_planes(enums: Sequence[int]) -> tuple:
+  """(channel of base_aux0, of base_aux1, of base_aux2), 0 = plane unused, () if the channel list has no per-base
+  host-computed channel: include/dvhip.h's rule, asked of the library (dv_base_aux_plane) so that the host fills the
+  plane the device reads."""
+  enums = [int(e) for e in enums]
+  if not any(e in _SEQ_AUX_CHANNELS for e in enums):
+    return ()
+  arr = (C.c_int32 * len(enums))(*enums)
+  planes = [0, 0, 0]
+  for i, e in enumerate(enums):
+    if e in _SEQ_AUX_CHANNELS:
+      plane = int(_lib.lib().dv_base_aux_plane(arr, len(enums), i))
+      if plane < 0:
+        _lib.check(plane)
+      planes[plane] = e
+  return tuple(planes)
+
+
+def _flow_tags(channel: int, reads: Sequence, seq_off: np.ndarray) -> np.ndarray:
+  """The `tags` plane of dv_flow_channel_pixels: tp values (int8, 0 where a read has no tag or a shorter one) /
+  t0 characters - 33 (homopolymer_indel_quality_channel.cc:68-84, inter_homopolymer_insertion_quality_channel.cc:
+  76-112)."""
+  tags = np.zeros(int(seq_off[-1]), np.int8)
+  for i, r in enumerate(reads):
+    info = getattr(r, 'info', None) or {}
+    s0, n = int(seq_off[i]), int(seq_off[i + 1]) - int(seq_off[i])
+    if channel in (28, 29):
+      if 'tp' in info and info['tp'].values:
+        vals = np.array([int(v.int_value or 0) for v in info['tp'].values[:n]], np.int64)
+        tags[s0:s0 + len(vals)] = vals.astype(np.int8)
+    elif 't0' in info and info['t0'].values:
+      raw = np.frombuffer((info['t0'].values[0].string_value or '').encode('latin-1')[:n], np.uint8)
+      tags[s0:s0 + len(raw)] = (raw.astype(np.int16) - 33).astype(np.uint8).view(np.int8)
+  return tags
+
+
+def seq_aux_plane(channel: int, reads: Sequence, seqs: Sequence[bytes], bases: np.ndarray, quals: np.ndarray,
+                  seq_off: np.ndarray) -> np.ndarray:
+  """The per-base pixels of one host-computed channel for the reads of a table."""
+  if channel == 16:
+    return np.concatenate([is_homopolymer_pixels(x) for x in seqs] or [np.zeros(0, np.uint8)])
+  if channel == 17:
+    return np.concatenate([homopolymer_weighted_pixels(x) for x in seqs] or [np.zeros(0, np.uint8)])
+  if channel not in _FLOW_CHANNELS:
+    raise ValueError('channel %d has no per-base plane' % channel)
+  tags = _flow_tags(channel, reads, seq_off)
+  out = np.zeros(int(seq_off[-1]), np.uint8)
+  bases = np.ascontiguousarray(bases, np.uint8)
+  quals = np.ascontiguousarray(quals, np.uint8)
+  off = np.ascontiguousarray(seq_off, np.uint32)
+  _lib.check(_lib.lib().dv_flow_channel_pixels(
+      int(channel), bases.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p),
+      tags.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(off) - 1,
+      out.ctypes.data_as(C.c_void_p)))
+  return out
 
 
 def gc_content_pixel(seq: bytes) -> int:
@@ -216,6 +275,7 @@ class ReadTable:
   read_end: np.ndarray
   base_aux0: Optional[np.ndarray] = None  # is_homopolymer pixel per base
   base_aux1: Optional[np.ndarray] = None  # homopolymer_weighted pixel per base
+  base_aux2: Optional[np.ndarray] = None  # third per-base plane (flow-space channels; include/dvhip.h's rule)
 
   @staticmethod
   def _pack_read(r, need_aux: bool) -> tuple:
@@ -299,8 +359,11 @@ class ReadTable:
 
   @classmethod
   def from_reads(cls, reads: Sequence, alignment_positions=None,
-                 need_aux: bool = False, need_seq_aux: bool = False) -> 'ReadTable':
+                 need_aux: bool = False, need_seq_aux=False) -> 'ReadTable':
+    """`need_seq_aux`: seq_aux_planes(channel enums) -- the channel each base_aux plane carries -- or True for
+    is_homopolymer + homopolymer_weighted in planes 0 / 1."""
     n = len(reads)
+    planes = (16, 17, 0) if need_seq_aux is True else tuple(need_seq_aux or ())
     recs = []
     for r in reads:
       rec = packed_record(r)
@@ -340,19 +403,20 @@ class ReadTable:
       if len(alignment_positions) != n:
         raise ValueError('alignment_positions must match reads')
       sort_pos = np.array(alignment_positions, np.int64).astype(np.int32)
+    bases_arr = np.frombuffer(b''.join(seqs), np.uint8)
+    quals_arr = np.frombuffer(b''.join(quals), np.uint8)
+    aux_planes = [seq_aux_plane(ch, reads, seqs, bases_arr, quals_arr, seq_off) if ch else None
+                  for ch in (planes + (0, 0, 0))[:3]]
     return cls(
         n_reads=n, read_pos=pos, read_sort_pos=sort_pos, read_seq_off=seq_off,
         read_cigar_off=cig_off, read_mapq=mapq, read_flags=flags,
         read_frag_len=frag, read_hp=hp, read_name_rank=ranks, read_aux=aux,
-        bases=np.frombuffer(b''.join(seqs), np.uint8),
-        quals=np.frombuffer(b''.join(quals), np.uint8),
+        bases=bases_arr,
+        quals=quals_arr,
         mod_5mc=np.frombuffer(b''.join(m5), np.uint8) if any5 else None,
         mod_6ma=np.frombuffer(b''.join(m6), np.uint8) if any6 else None,
         cigar=np.array(cig, np.uint32), keys=keys, read_end=read_end,
-        base_aux0=(np.concatenate([is_homopolymer_pixels(x) for x in seqs] or
-                                  [np.zeros(0, np.uint8)]) if need_seq_aux else None),
-        base_aux1=(np.concatenate([homopolymer_weighted_pixels(x) for x in seqs] or
-                                  [np.zeros(0, np.uint8)]) if need_seq_aux else None))
+        base_aux0=aux_planes[0], base_aux1=aux_planes[1], base_aux2=aux_planes[2])
 
   @classmethod
   def from_cram(cls, path: str, fetch_reference, contig: Optional[str] = None, start: int = 0,
@@ -546,7 +610,8 @@ class ReadTable:
         read_aux=None if self.read_aux is None else self.read_aux[rows],
         bases=self.bases[seq_idx], quals=self.quals[seq_idx], mod_5mc=per_base(self.mod_5mc),
         mod_6ma=per_base(self.mod_6ma), cigar=self.cigar[cig_idx], keys=[keys[i] for i in rows.tolist()],
-        read_end=self.read_end[rows], base_aux0=per_base(self.base_aux0), base_aux1=per_base(self.base_aux1))
+        read_end=self.read_end[rows], base_aux0=per_base(self.base_aux0), base_aux1=per_base(self.base_aux1),
+        base_aux2=per_base(self.base_aux2))
 
   def with_alignments(self, rows, positions, cigars: Sequence[np.ndarray]) -> 'ReadTable':
     """A copy in which row rows[k] starts at positions[k] with the CIGAR words cigars[k]
@@ -629,7 +694,8 @@ def concat_tables(tables: Sequence[ReadTable]) -> ReadTable:
       read_seq_off=offsets('read_seq_off'), read_cigar_off=offsets('read_cigar_off'), read_mapq=cat('read_mapq'),
       read_flags=cat('read_flags'), read_frag_len=cat('read_frag_len'), read_hp=cat('read_hp'), read_name_rank=ranks,
       read_aux=cat('read_aux'), bases=cat('bases'), quals=cat('quals'), mod_5mc=cat('mod_5mc'), mod_6ma=cat('mod_6ma'),
-      cigar=cat('cigar'), keys=keys, read_end=cat('read_end'), base_aux0=cat('base_aux0'), base_aux1=cat('base_aux1'))
+      cigar=cat('cigar'), keys=keys, read_end=cat('read_end'), base_aux0=cat('base_aux0'), base_aux1=cat('base_aux1'),
+      base_aux2=cat('base_aux2'))
 
 
 def support_codes(dv_call, alt_alleles: Sequence[str], table: ReadTable,
@@ -1074,6 +1140,7 @@ class PackedBatch:
     b.list_aux = ptr(fz['list_aux'], np.uint8) if self.use_list_aux else None
     b.base_aux0 = ptr(t.base_aux0, np.uint8)
     b.base_aux1 = ptr(t.base_aux1, np.uint8)
+    b.base_aux2 = ptr(t.base_aux2, np.uint8)
     for name in ('ref_aux0', 'ref_aux1', 'ref_aux2'):
       setattr(b, name, ptr(fz.get(name), np.uint8))
     b.n_list = int(fz['item_list_off'][-1])

@@ -67,7 +67,8 @@ class PileupImageEncoderNative:
                          for e in self._channel_enums)
     self._need_list_aux = any(e in packing._LIST_AUX_CHANNELS
                               for e in self._channel_enums)
-    self._need_seq_aux = any(e in packing._SEQ_AUX_CHANNELS for e in self._channel_enums)
+    # (channel of base_aux0, base_aux1, base_aux2) or (): the per-base host-computed channels and the plane each reads
+    self._need_seq_aux = packing.seq_aux_planes(self._channel_enums)
     self._need_ref_aux = any(e in packing._REF_AUX_CHANNELS for e in self._channel_enums)
     if 27 in self._channel_enums:
       raise NotImplementedError(

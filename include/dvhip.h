@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 5
+#define DV_ABI_VERSION 6
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -71,6 +71,12 @@ enum {
   DV_CH_READ_SUPPORTS_VARIANT_FUZZY = 25, /* pixel supplied in list_aux */
   DV_CH_SUPPLEMENTARY_ALIGNMENT = 26,
   DV_CH_ALLELE_SAMPLE_PROBABILITY = 27, /* pixel supplied in list_aux */
+  /* Ultima flow-space channels (channels/homopolymer_{insertion,deletion}_quality_channel.cc,
+   * channels/inter_homopolymer_insertion_quality_channel.cc): per-base pixels the host computes from the tp / t0
+   * aux tags (dv_flow_channel_pixels) and passes in the base_aux planes, see dv_batch */
+  DV_CH_HOMOPOLYMER_INSERTION_QUALITY = 28,
+  DV_CH_HOMOPOLYMER_DELETION_QUALITY = 29,
+  DV_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY = 30,
 };
 
 /* CIGAR op codes = nucleus CigarUnit::Operation
@@ -204,10 +210,31 @@ typedef struct dv_batch {
   const uint8_t* ref_aux0;  /* [n_ref_windows][width]: is_homopolymer pixel of the window */
   const uint8_t* ref_aux1;  /* [n_ref_windows][width]: homopolymer_weighted pixel */
   const uint8_t* ref_aux2;  /* [n_ref_windows][width]: gc_content pixel of the window, repeated */
+  /* ABI v6.  A third per-base plane, and the rule that assigns planes: is_homopolymer always reads base_aux0 and
+   * homopolymer_weighted base_aux1; each flow-space channel (DV_CH_HOMOPOLYMER_INSERTION_QUALITY, _DELETION_QUALITY,
+   * DV_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY), in the order of the channel list, takes the first plane of
+   * base_aux2, base_aux1, base_aux0 that no other channel of the list reads (dv_base_aux_plane answers for a given
+   * list).  Their reference-row pixel is 0.  More than three per-base channels in one list: DV_ERR_UNSUPPORTED. */
+  const uint8_t* base_aux2;
 } dv_batch;
 
 typedef struct dv_encoder dv_encoder;
 typedef struct dv_model dv_model;
+
+/* Which base_aux plane (0, 1, 2) the channel at index `channel_index` of `channels[n_channels]` (DV_CH_* values)
+ * reads; DV_BASE_AUX_NONE if it reads none; a dv_status (< 0) otherwise: DV_ERR_UNSUPPORTED if the list needs more
+ * planes than there are. */
+#define DV_BASE_AUX_NONE 3
+int dv_base_aux_plane(const int32_t* channels, int32_t n_channels, int32_t channel_index);
+
+/* Per-base pixels of a flow-space channel for every read of a table, to be passed as the base_aux plane the channel
+ * reads (channels/homopolymer_indel_quality_channel.cc:68-183, channels/inter_homopolymer_insertion_quality_channel.cc:
+ * 76-125, channels/channel_utils.cc:41-44).  `tags` is parallel to bases:
+ *   DV_CH_HOMOPOLYMER_INSERTION_QUALITY / _DELETION_QUALITY   the tp tag's values (0 where a read has none or fewer)
+ *   DV_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY                 the t0 tag's characters - 33 (0 where a read has none)
+ * Host arithmetic as in the reference (double pow, float sum, float log10); no device work. */
+int dv_flow_channel_pixels(int channel, const uint8_t* bases, const uint8_t* quals, const int8_t* tags,
+                           const uint32_t* read_seq_off, int32_t n_reads, uint8_t* out);
 
 const char* dv_last_error(void);
 int dv_abi_version(void);

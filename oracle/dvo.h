@@ -66,6 +66,9 @@ enum {
   DVO_CH_READ_SUPPORTS_VARIANT_FUZZY = 25,
   DVO_CH_SUPPLEMENTARY_ALIGNMENT = 26,
   DVO_CH_ALLELE_SAMPLE_PROBABILITY = 27,
+  DVO_CH_HOMOPOLYMER_INSERTION_QUALITY = 28,       /* Ultima: tp tag */
+  DVO_CH_HOMOPOLYMER_DELETION_QUALITY = 29,        /* Ultima: tp tag */
+  DVO_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY = 30, /* Ultima: t0 tag */
 };
 
 /* CigarUnit::Operation, third_party/nucleus/protos/cigar.proto:38-82 */
@@ -138,6 +141,10 @@ typedef struct dvo_read {
   int32_t mod_5mc_len;
   const uint8_t* mod_6ma;
   int32_t mod_6ma_len;
+  const int8_t* tp; /* read.info["tp"].values(i).int_value(), NULL if the tag is absent */
+  int32_t tp_len;
+  const char* t0;   /* read.info["t0"].values(0).string_value(), NULL if the tag is absent */
+  int32_t t0_len;
 } dvo_read;
 
 /* DeepVariantCall (deepvariant.proto:262-317), the fields the encoder touches. */

@@ -97,6 +97,9 @@ struct ReadChannels {
   std::optional<std::vector<std::uint8_t>> homopolymer_weighted;
   std::optional<std::vector<std::uint8_t>> methylation;
   std::optional<std::vector<std::uint8_t>> m6a;
+  std::optional<std::vector<std::uint8_t>> hmer_insertion_quality;
+  std::optional<std::vector<std::uint8_t>> hmer_deletion_quality;
+  std::optional<std::vector<std::uint8_t>> t0_quality;
   bool error = false;
 
   // channels/read_base_channel.cc:56-73
@@ -561,6 +564,21 @@ struct ReadChannels {
         }
         if (!m6a->empty()) data[col] = m6a->at(read_index);
         return true;
+      case DVO_CH_HOMOPOLYMER_INSERTION_QUALITY:  // homopolymer_insertion_quality_channel.cc:46-61
+        if (!hmer_insertion_quality.has_value()) hmer_insertion_quality = HomoPolymerInDelQuality(false);
+        data[col] = read_index >= 0 && read_index < static_cast<int>(hmer_insertion_quality->size())
+                        ? (*hmer_insertion_quality)[read_index] : 0;
+        return true;
+      case DVO_CH_HOMOPOLYMER_DELETION_QUALITY:  // homopolymer_deletion_quality_channel.cc:46-61
+        if (!hmer_deletion_quality.has_value()) hmer_deletion_quality = HomoPolymerInDelQuality(true);
+        data[col] = read_index >= 0 && read_index < static_cast<int>(hmer_deletion_quality->size())
+                        ? (*hmer_deletion_quality)[read_index] : 0;
+        return true;
+      case DVO_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY:  // inter_homopolymer_insertion_quality_channel.cc:53-68
+        if (!t0_quality.has_value()) t0_quality = T0QualityValues();
+        data[col] = read_index >= 0 && read_index < static_cast<int>(t0_quality->size())
+                        ? (*t0_quality)[read_index] : 0;
+        return true;
       case DVO_CH_SUPPLEMENTARY_ALIGNMENT: {  // supplementary_alignment_channel.cc:49-59
         float alpha = read->supplementary ? opt.allele_supporting_read_alpha
                                           : opt.allele_unsupporting_read_alpha;
@@ -597,6 +615,64 @@ struct ReadChannels {
       default:
         return false;
     }
+  }
+
+  // channels/channel_utils.cc:41-44 with channel_utils.h:44-49's OWN constants: the maximum pixel is 255.0 there
+  // (254.0 everywhere else in the encoder), the maximum quality the float 93.0
+  static std::uint8_t BaseQualityColor(int base_qual) {
+    return static_cast<std::uint8_t>(255.0f * base_qual / 93.0f);
+  }
+
+  // HomopolymerInDelQualityChannel::HomoPolymerInDelQuality with GetTPValues and HomoPolymerWeighted,
+  // homopolymer_indel_quality_channel.cc:68-183 (Ultima: QUAL[i] is the phred score of the homopolymer being
+  // tp[i] longer / shorter than called; the errors of one direction are summed over the homopolymer).
+  std::vector<std::uint8_t> HomoPolymerInDelQuality(bool is_deletion) const {
+    const int kMaxQScore = 93;  // homopolymer_indel_quality_channel.h:65
+    const size_t n = static_cast<size_t>(read->seq_len);
+    std::vector<std::uint8_t> out(n, BaseQualityColor(kMaxQScore));
+    std::vector<std::uint8_t> hmer(n, 1);  // :86-120, run length of the homopolymer a base belongs to, capped at 255
+    for (size_t i = 0; i < n;) {
+      size_t j = i + 1;
+      while (j < n && read->seq[j] == read->seq[i]) ++j;
+      for (size_t k = i; k < j; ++k) hmer[k] = static_cast<std::uint8_t>(std::min<size_t>(j - i, 255));
+      i = j;
+    }
+    std::vector<int8_t> tps(n, 0);  // :68-84
+    if (read->tp != nullptr) {
+      for (size_t i = 0; i < static_cast<size_t>(read->tp_len) && i < n; ++i) tps[i] = read->tp[i];
+    }
+    if (tps.empty()) return out;  // :137-139 (the sizes are equal by construction)
+    size_t i = 0;
+    while (i < n) {
+      const int len = hmer[i];
+      float err = 0;
+      for (int j = 0; j < len; ++j) {
+        if (tps[i + j] == 0) continue;
+        if ((tps[i + j] < 0) == is_deletion) {
+          const std::uint8_t q = read->qual[i + j];
+          const float e = std::pow(10, (q / -10.0));
+          err += e;
+        }
+      }
+      int hq = err == 0 ? kMaxQScore : static_cast<int>(-10 * std::log10(err));
+      if (hq > kMaxQScore) hq = kMaxQScore;
+      for (int j = 0; j < len; ++j) out[i + j] = BaseQualityColor(hq);
+      i += static_cast<size_t>(len);
+    }
+    return out;
+  }
+
+  // InterHomopolymerInsertionQualityChannel::GetT0QualityValues / GetT0Values,
+  // inter_homopolymer_insertion_quality_channel.cc:76-125.
+  std::vector<std::uint8_t> T0QualityValues() const {
+    std::vector<std::uint8_t> out(static_cast<size_t>(read->seq_len), 0);
+    if (read->t0 != nullptr) {
+      for (size_t i = 0; i < static_cast<size_t>(read->t0_len) && i < out.size(); ++i) {
+        out[i] = static_cast<std::uint8_t>(read->t0[i] - 33);
+      }
+    }
+    for (std::uint8_t& v : out) v = BaseQualityColor(v);
+    return out;
   }
 
   // allele_sample_probability_channel.cc:84-98
@@ -679,6 +755,11 @@ bool FillRefBase(const dvo_options& opt, int ch,
     case DVO_CH_ALLELE_SAMPLE_PROBABILITY:  // allele_sample_probability_channel.cc:77-81
     case DVO_CH_BASE_METHYLATION:  // base_methylation_channel.cc:68-72
     case DVO_CH_BASE_6MA:          // base_6ma_channel.cc:68-72
+    // the three Ultima channels push_back(0) behind the `width` zeros the row starts with
+    // (homopolymer_insertion_quality_channel.cc:63-67 and its two siblings): column `col` stays 0
+    case DVO_CH_HOMOPOLYMER_INSERTION_QUALITY:
+    case DVO_CH_HOMOPOLYMER_DELETION_QUALITY:
+    case DVO_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY:
       ref_data[col] = 0;
       return true;
     case DVO_CH_SUPPLEMENTARY_ALIGNMENT:  // supplementary_alignment_channel.cc:61-65
@@ -1047,6 +1128,9 @@ int dvo_channel_str_to_enum(const char* name) {
       {"base_6ma", DVO_CH_BASE_6MA},
       {"supplementary_alignment", DVO_CH_SUPPLEMENTARY_ALIGNMENT},
       {"allele_sample_probability", DVO_CH_ALLELE_SAMPLE_PROBABILITY},
+      {"homopolymer_insertion_quality", DVO_CH_HOMOPOLYMER_INSERTION_QUALITY},
+      {"homopolymer_deletion_quality", DVO_CH_HOMOPOLYMER_DELETION_QUALITY},
+      {"inter_homopolymer_insertion_quality", DVO_CH_INTER_HOMOPOLYMER_INSERTION_QUALITY},
   };
   auto it = kMap.find(name);
   return it == kMap.end() ? -1 : it->second;

@@ -88,6 +88,8 @@ class DvoRead(C.Structure):
       ('hp_is_int', C.c_int32), ('hp_value', C.c_int32),
       ('mod_5mc', C.POINTER(C.c_uint8)), ('mod_5mc_len', C.c_int32),
       ('mod_6ma', C.POINTER(C.c_uint8)), ('mod_6ma_len', C.c_int32),
+      ('tp', C.POINTER(C.c_int8)), ('tp_len', C.c_int32),
+      ('t0', C.c_char_p), ('t0_len', C.c_int32),
   ]
 
 
@@ -290,6 +292,19 @@ def _fill_read(dst: DvoRead, read, keep: _Keep):
     else:
       setattr(dst, pfield, None)
       setattr(dst, lfield, -1)
+
+
+  # Ultima's per-base aux tags (read.info["tp"]: int values; read.info["t0"]: one string)
+  info = getattr(read, 'info', None) or {}
+  dst.tp, dst.tp_len, dst.t0, dst.t0_len = None, 0, None, 0
+  if 'tp' in info:
+    arr = keep(np.array([int(v.int_value or 0) for v in info['tp'].values] or [0], np.int8))
+    dst.tp = arr.ctypes.data_as(C.POINTER(C.c_int8))
+    dst.tp_len = len(info['tp'].values)
+  if 't0' in info and info['t0'].values:
+    raw = keep((info['t0'].values[0].string_value or '').encode('latin-1'))
+    dst.t0 = raw
+    dst.t0_len = len(raw)
 
 
 def _str_array(strings: Sequence[str], keep: _Keep):

@@ -62,6 +62,7 @@ const char* const kChannelNames[] = {
     "base_differs_from_ref", "read_mapping_percent", "haplotype", "allele_frequency", "avg_base_quality", "identity",
     "gap_compressed_identity", "gc_content", "is_homopolymer", "homopolymer_weighted", "blank", "insert_size",
     "mean_coverage", "base_methylation", "base_6ma", "supplementary_alignment", "allele_sample_probability",
+    "homopolymer_insertion_quality", "homopolymer_deletion_quality", "inter_homopolymer_insertion_quality",
 };
 
 const char* ChannelName(int channel_enum) {
@@ -132,6 +133,13 @@ void MakeRead(const dvo_read& r, Read* read) {
         v->set_int_value(i == 0 ? r.hp_value : 0);
       }
     }
+  }
+  if (r.tp) {
+    auto& tp = (*read->mutable_info())["tp"];
+    for (int i = 0; i < r.tp_len; ++i) tp.add_values()->set_int_value(r.tp[i]);
+  }
+  if (r.t0) {
+    (*read->mutable_info())["t0"].add_values()->set_string_value(std::string(r.t0, static_cast<size_t>(r.t0_len)));
   }
   if (r.mod_5mc) {
     (*read->mutable_base_modifications())["5mC"] = std::string(reinterpret_cast<const char*>(r.mod_5mc), static_cast<size_t>(r.mod_5mc_len));

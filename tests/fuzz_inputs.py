@@ -23,7 +23,7 @@ def query_len(cigar):
 
 
 def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
-              with_mods=False, n_alts=2, fuzzy=False):
+              with_mods=False, n_alts=2, fuzzy=False, with_ultima=False):
   hw = (width - 1) // 2
   ref_window = ''.join('ACGTN'[int(i)] for i in rng.choice(5, size=width,
                                                            p=[.24, .24, .24, .24, .04]))
@@ -52,6 +52,22 @@ def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
       r.base_modifications[T.K5MC] = bytes(rng.integers(0, 256, size=qlen).astype(np.uint8))
     if with_mods and rng.random() < 0.5:
       r.base_modifications[T.K6MA] = bytes(rng.integers(0, 256, size=qlen).astype(np.uint8))
+    if with_ultima:
+      # Ultima flow-space tags: tp (per base, the direction / size of the homopolymer error QUAL prices) and t0
+      # (per base, phred + 33).  Qualities stay >= 10 so that a homopolymer's summed error stays below 1 (above it the
+      # reference casts a negative float to uint8); some reads carry no tag, a short one or a long one.
+      runs = rng.integers(1, 7, size=qlen)
+      seq = ''.join('ACGT'[int(b)] * int(k) for b, k in zip(rng.integers(0, 4, size=qlen), runs))[:qlen]
+      r.aligned_sequence = seq
+      r.aligned_quality = bytes(rng.integers(10, 60, size=qlen).astype(np.uint8))
+      kind = rng.random()
+      n_tag = qlen if kind < 0.7 else max(qlen - 3, 0) if kind < 0.8 else qlen + 2 if kind < 0.9 else -1
+      if n_tag >= 0:
+        tp = rng.choice([0, 0, 0, 1, -1, 2, -2], size=n_tag)
+        r.info['tp'] = T.ListValue(values=[T.Value(int_value=int(v)) for v in tp])
+      if n_tag >= 0 or rng.random() < 0.5:
+        r.info['t0'] = T.ListValue(values=[T.Value(string_value=''.join(
+            chr(33 + int(v)) for v in rng.integers(0, 61, size=max(n_tag, 0) or qlen)))])
     reads.append(r)
   keys = ['%s/%d' % (r.fragment_name, r.read_number) for r in reads]
   support = {}
@@ -109,3 +125,15 @@ CONFIGS = [
      61, 40, dict(sort_by_haplotypes=True, other_allele_supporting_read_alpha=0.3),
      dict(with_hp=True, fuzzy=True)),
 ]
+
+# Channel sets added in round 4 (the three Ultima flow-space channels, channels/homopolymer_*_quality_channel.cc and
+# channels/inter_homopolymer_insertion_quality_channel.cc); kept apart from CONFIGS so that the GPU tests of the two
+# lists can be told apart.
+ULTIMA_CONFIGS = [
+    ('ultima', T.PILEUP_DEFAULT_CHANNELS + ['homopolymer_insertion_quality', 'homopolymer_deletion_quality',
+                                            'inter_homopolymer_insertion_quality'], 71, 36, {}, dict(with_ultima=True)),
+    ('ultima_with_sequence_context', ['read_base', 'is_homopolymer', 'homopolymer_deletion_quality', 'base_quality',
+                                      'inter_homopolymer_insertion_quality'], 33, 20, {}, dict(with_ultima=True)),
+    ('ultima_one_channel', ['homopolymer_insertion_quality', 'read_base'], 21, 12, {}, dict(with_ultima=True)),
+]
+

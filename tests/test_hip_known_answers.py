@@ -87,7 +87,9 @@ def test_build_pileup(name):
 def test_unsupported_channel_fails_loudly():
   from deepvariant_amd import _lib
   with pytest.raises(_lib.DvError) as e:
-    make(KA.default_options(['homopolymer_insertion_quality'])).encode_reference('ACGTA')
+    # four per-base host-computed channels: one more than dv_batch has planes for (include/dvhip.h, ABI v6)
+    make(KA.default_options(['is_homopolymer', 'homopolymer_weighted', 'homopolymer_insertion_quality',
+                             'homopolymer_deletion_quality'])).encode_reference('ACGTA')
   assert e.value.status == _lib.DV_ERR_UNSUPPORTED
 
 
