@@ -221,10 +221,10 @@ def _haplotype_reads(rng, ref_seq, variants, n, lo, hi):
   return reads
 
 
-def _alt_region(mode, types, pacbio):
+def _alt_region(mode, types, pacbio, seed=101):
   """Reference, haplotype-carrying reads and candidates (SNPs, insertions, deletions, some
   with two alts) for the alt-aligned tests."""
-  rng = np.random.default_rng(101)
+  rng = np.random.default_rng(seed)
   # pacbio: exactly the released PacBio model's tensor (deepvariant/json/deepvariant.pacbio.savedmodel/
   # model.example_info.json: shape [100, 147, 10], channels [1..7, 26, 9, 10], diff_channels, indels)
   width, height = (147, 100) if pacbio else (99, 40)
