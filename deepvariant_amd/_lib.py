@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     'dv_last_profile_count',
     'dv_bam_read_region', 'dv_read_table_fill_batch', 'dv_read_table_name',
     'dv_read_table_names', 'dv_read_table_ends', 'dv_read_table_free',
-    'dv_cram_read_region', 'dv_cram_header',
+    'dv_cram_read_region', 'dv_cram_header', 'dv_read_table_aux_planes',
     'dv_pack_region', 'dv_packed_region_fill_batch', 'dv_packed_region_items',
     'dv_packed_region_free',
     'dv_aligner_create', 'dv_aligner_destroy', 'dv_aligner_set_reference',
@@ -130,7 +130,9 @@ class DvReadRequirements(C.Structure):
               ('keep_supplementary_alignments', C.c_int32),
               ('keep_improperly_placed', C.c_int32),
               ('min_mapping_quality', C.c_int32),
-              ('use_original_base_quality_scores', C.c_int32)]
+              ('use_original_base_quality_scores', C.c_int32),
+              ('parse_base_modifications', C.c_int32),      # ABI v6: MM / ML / MN -> 5mC / 6mA planes
+              ('parse_flow_tags', C.c_int32)]               # ABI v6: tp / t0 planes
 
 
 class DvPackReads(C.Structure):
@@ -292,6 +294,7 @@ def lib():
     l.dv_cram_read_region.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, REF_FETCH_FN,
                                       C.c_void_p, C.c_int, C.c_void_p]
     l.dv_cram_header.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    l.dv_read_table_aux_planes.argtypes = [C.c_void_p] * 6
     l.dv_base_aux_plane.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     l.dv_flow_channel_pixels.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p]

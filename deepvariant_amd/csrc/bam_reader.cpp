@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "dv_internal.h"
+#include "aux_planes.h"
 #include "read_table.h"
 
 namespace {
@@ -384,6 +385,13 @@ int decode_record(const uint8_t* r, uint32_t block_size, const RegionFilter& f, 
     }
   }
   t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
+  if (t->with_mods || t->with_flow) {   // per-base planes from MM / ML / MN and tp / t0 (aux_planes.h)
+    dv::AuxFields aux;
+    dv::scan_bam_aux(qual + l_seq, r + block_size, &aux);
+    if (!dv::append_aux_planes(t, t->bases.data() + b0, l_seq, (flag & 0x10) != 0, aux)) {
+      return dv::fail(DV_ERR_BAD_INPUT, "MM tag: a position that is not a number");
+    }
+  }
   t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
   t->names.insert(t->names.end(), name, name + l_read_name);  // includes the NUL
   if (t->names.back() != '\0') t->names.back() = '\0';
@@ -728,6 +736,8 @@ int dv_bam_read_region(const char* path, const char* contig, int64_t start, int6
   flt.start = start;
   flt.end = end;
   std::unique_ptr<dv_read_table> t(new dv_read_table());
+  t->with_mods = flt.rq.parse_base_modifications != 0;
+  t->with_flow = flt.rq.parse_flow_tags != 0;
   t->seq_off.push_back(0);
   t->cigar_off.push_back(0);
   const auto t0 = std::chrono::steady_clock::now();
@@ -817,8 +827,8 @@ int dv_read_table_fill_batch(const dv_read_table* t, dv_batch* b) {
   b->read_aux = nullptr;
   b->bases = t->bases.data();
   b->quals = t->quals.data();
-  b->mod_5mc = nullptr;
-  b->mod_6ma = nullptr;
+  b->mod_5mc = t->with_mods ? t->mod_5mc.data() : nullptr;   // (read_flags carry DV_READ_HAS_5MC / _6MA per read)
+  b->mod_6ma = t->with_mods ? t->mod_6ma.data() : nullptr;
   b->cigar = t->cigar.data();
   b->n_bases = static_cast<uint32_t>(t->bases.size());
   b->n_cigar = static_cast<uint32_t>(t->cigar.size());
@@ -840,6 +850,17 @@ int dv_read_table_names(const dv_read_table* t, const char** blob, const uint32_
   if (offsets) *offsets = t->name_off.data();
   if (read_numbers) *read_numbers = t->read_number.data();
   if (blob_bytes) *blob_bytes = t->names.size();
+  return DV_OK;
+}
+
+int dv_read_table_aux_planes(const dv_read_table* t, const uint8_t** mod_5mc, const uint8_t** mod_6ma,
+                             const int8_t** tp, const uint8_t** t0, const uint8_t** flow_present) {
+  if (!t) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_read_table_aux_planes: null");
+  if (mod_5mc) *mod_5mc = t->with_mods ? t->mod_5mc.data() : nullptr;
+  if (mod_6ma) *mod_6ma = t->with_mods ? t->mod_6ma.data() : nullptr;
+  if (tp) *tp = t->with_flow ? t->tp.data() : nullptr;
+  if (t0) *t0 = t->with_flow ? t->t0.data() : nullptr;
+  if (flow_present) *flow_present = t->with_flow ? t->flow_present.data() : nullptr;
   return DV_OK;
 }
 

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "dv_internal.h"
+#include "aux_planes.h"
 #include "read_table.h"
 
 namespace {
@@ -882,12 +883,16 @@ struct Rec {
           mate_pos = 0, tlen = 0, next_fragment = -1, mapq = 0, ref_len = 0, mate_line = -1, hp = 0;
   bool tlen_known = false, has_hp = false, has_oq = false;
   uint32_t name_off = 0, name_len = 0, seq_off = 0, cig_off = 0, cig_n = 0, oq_off = 0, oq_len = 0;
+  // the BAM-encoded values of MM, ML, MN, tp, t0 in SliceOut::aux (kept only when the requirements ask for planes)
+  uint32_t aux_off[5] = {0, 0, 0, 0, 0}, aux_len[5] = {0, 0, 0, 0, 0};
+  char aux_type[5] = {0, 0, 0, 0, 0};
 };
 
 struct SliceOut {
   std::vector<Rec> recs;
-  std::vector<uint8_t> bases, quals, names, oq;
+  std::vector<uint8_t> bases, quals, names, oq, aux;
   std::vector<uint32_t> cigar;   // BAM words (len << 4 | op), ops M I D N S H P = 0..6
+  bool keep_aux = false;
 };
 
 using FetchFn = dv_ref_fetch_fn;
@@ -1105,6 +1110,17 @@ bool decode_slice(const CramFile& f, const CompressionHeader& ch, size_t at, int
         r.oq_len = static_cast<uint32_t>(n);
         r.has_oq = true;
         out->oq.insert(out->oq.end(), tmp.begin(), tmp.begin() + static_cast<long>(n));
+      } else if (out->keep_aux) {
+        static const char kKeep[5][3] = {"MM", "ML", "MN", "tp", "t0"};
+        for (int k = 0; k < 5; ++k) {
+          if (key3[0] == static_cast<uint8_t>(kKeep[k][0]) && key3[1] == static_cast<uint8_t>(kKeep[k][1]) &&
+              r.aux_type[k] == 0) {
+            r.aux_type[k] = static_cast<char>(key3[2]);
+            r.aux_off[k] = static_cast<uint32_t>(out->aux.size());
+            r.aux_len[k] = static_cast<uint32_t>(tmp.size());
+            out->aux.insert(out->aux.end(), tmp.begin(), tmp.end());
+          }
+        }
       }
     }
     const size_t L = static_cast<size_t>(r.read_length);
@@ -1378,6 +1394,30 @@ void append_rows(const SliceOut& s, int32_t want, int64_t start, int64_t end, co
       for (size_t i = q0; i < t->quals.size(); ++i) t->quals[i] = static_cast<uint8_t>(t->quals[i] - qsub);
     }
     t->seq_off.push_back(static_cast<uint32_t>(t->bases.size()));
+    if (t->with_mods || t->with_flow) {   // per-base planes from MM / ML / MN and tp / t0 (aux_planes.h)
+      dv::AuxFields aux;
+      dv::AuxField* slots[5] = {&aux.mm, &aux.ml, &aux.mn, &aux.tp, &aux.t0};
+      bool ok = true;
+      for (int k = 0; k < 5; ++k) {
+        if (!r.aux_type[k]) continue;
+        slots[k]->type = r.aux_type[k];
+        slots[k]->data = s.aux.data() + r.aux_off[k];
+        slots[k]->size = r.aux_len[k];
+        // a B value must hold its header and the elements it announces
+        if (r.aux_type[k] == 'B') {
+          uint32_t n = 0;
+          const int sub = r.aux_len[k] >= 5 ? dv::aux_scalar_size(slots[k]->data[0]) : 0;
+          if (sub) std::memcpy(&n, slots[k]->data + 1, 4);
+          ok = ok && sub && static_cast<uint64_t>(r.aux_len[k]) >= 5 + static_cast<uint64_t>(n) * sub;
+        } else if (dv::aux_scalar_size(static_cast<uint8_t>(r.aux_type[k]))) {
+          ok = ok && r.aux_len[k] >= static_cast<uint32_t>(dv::aux_scalar_size(static_cast<uint8_t>(r.aux_type[k])));
+        }
+      }
+      if (!ok) throw CramError(DV_ERR_BAD_INPUT, "malformed aux tag value in a CRAM record");
+      if (!dv::append_aux_planes(t, t->bases.data() + t->bases.size() - L, L, (flag & 0x10) != 0, aux)) {
+        throw CramError(DV_ERR_BAD_INPUT, "MM tag: a position that is not a number");
+      }
+    }
     t->name_off.push_back(static_cast<uint32_t>(t->names.size()));
     t->names.insert(t->names.end(), s.names.begin() + r.name_off, s.names.begin() + r.name_off + r.name_len);
     t->names.push_back('\0');
@@ -1427,6 +1467,7 @@ int dv_cram_read_region(const char* path, const char* contig, int64_t start, int
         Job j;
         j.ch = ch;
         j.at = h.blocks + static_cast<size_t>(lm);
+        j.out.keep_aux = rq.parse_base_modifications != 0 || rq.parse_flow_tags != 0;
         jobs.push_back(std::move(j));
       }
     }
@@ -1455,6 +1496,8 @@ int dv_cram_read_region(const char* path, const char* contig, int64_t start, int
     work();
     for (auto& t : pool) t.join();
     std::unique_ptr<dv_read_table> t(new dv_read_table());
+    t->with_mods = rq.parse_base_modifications != 0;
+    t->with_flow = rq.parse_flow_tags != 0;
     t->seq_off.push_back(0);
     t->cigar_off.push_back(0);
     for (Job& j : jobs) {

@@ -15,6 +15,12 @@ struct dv_read_table {
   std::vector<uint8_t> mapq, flags, read_number, bases, quals;
   std::vector<int64_t> end;
   std::vector<char> names;  // NUL-terminated, concatenated
+  // Optional per-base planes, parallel to `bases`, derived from aux tags (aux_planes.h) when the read requirements
+  // ask for them: base modifications (MM / ML / MN; flags carry DV_READ_HAS_5MC / _6MA per read) and the Ultima
+  // flow-space tags (tp values; t0 characters - 33; flow_present: bit 0 = the read has tp, bit 1 = it has t0).
+  bool with_mods = false, with_flow = false;
+  std::vector<uint8_t> mod_5mc, mod_6ma, t0, flow_present;
+  std::vector<int8_t> tp;
 };
 
 namespace dv {

@@ -17,7 +17,7 @@ import gzip
 import os
 import struct
 import zlib
-from typing import Dict, Iterator, List, Optional, Tuple
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 from deepvariant_amd import dv_types as T
 
@@ -93,8 +93,8 @@ def bam_contig_names(path: str) -> List[str]:
 
 
 def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
-             end: int = 1 << 62, use_original_quality_scores: bool = False
-             ) -> Tuple[List[str], List[T.Read]]:
+             end: int = 1 << 62, use_original_quality_scores: bool = False,
+             aux_fields: Sequence[str] = ()) -> Tuple[List[str], List[T.Read]]:
   """Reads a whole (small) BAM; returns (contig names, reads overlapping).  With
   `use_original_quality_scores` the qualities are the OQ:Z tag's characters - 33
   (sam_reader.cc:722-740); a read without the tag is an error here (nucleus leaves its
@@ -167,6 +167,10 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
     hp = _find_int_tag(aux, b'HP')
     if hp is not None:
       info['HP'] = T.ListValue(values=[T.Value(int_value=hp)])
+    if aux_fields:      # SamReaderOptions.aux_fields_to_keep (sam_reader.cc:294-470): the listed tags, as info values
+      for tag, value in parse_aux_fields(aux).items():
+        if tag in aux_fields and tag != 'HP':
+          info[tag] = value
     paired = bool(flag & 0x1)
     read_number = 0 if (not paired or (flag & 0x40)) else 1
     reads.append(T.Read(
@@ -186,6 +190,8 @@ def read_bam(path: str, contig: Optional[str] = None, start: int = 0,
                                 reverse_strand=bool(flag & 0x10)),
             mapping_quality=mapq, cigar=cigar),
         info=info))
+    if aux_fields:
+      reads[-1].base_modifications = parse_base_modifications(reads[-1])      # sam_reader.cc:855-862
     reads[-1]._flag = flag  # pylint: disable=protected-access
     # next_mate_position exists only for a paired read whose mate is mapped with a valid
     # reference id (sam_reader.cc:829-837); without it the read counts as properly placed
@@ -198,6 +204,140 @@ _AUX_SIZES = {b'A': 1, b'c': 1, b'C': 1, b's': 2, b'S': 2, b'i': 4, b'I': 4,
               b'f': 4}
 _AUX_FMT = {b'c': '<b', b'C': '<B', b's': '<h', b'S': '<H', b'i': '<i',
             b'I': '<I'}
+
+
+def parse_aux_fields(aux) -> Dict[str, T.ListValue]:
+  """ParseAuxFields (third_party/nucleus/io/sam_reader.cc:294-470) on a BAM record's aux block: every tag as the
+  info value nucleus stores -- 'A' and 'Z' strings, integers, floats, B arrays element by element (a B:C array without
+  elements is not stored, :394-397); 'H' strings are skipped; a malformed block ends the walk."""
+  out: Dict[str, T.ListValue] = {}
+  aux = bytes(aux)
+  p, n = 0, len(aux)
+  while n - p >= 4:
+    tag, ty = aux[p:p + 2].decode('latin-1'), aux[p + 2:p + 3]
+    p += 3
+    if ty == b'A':
+      out[tag] = T.ListValue(values=[T.Value(string_value=aux[p:p + 1].decode('latin-1'))])
+      p += 1
+    elif ty in _AUX_FMT:
+      size = _AUX_SIZES[ty]
+      if n - p < size:
+        break
+      out[tag] = T.ListValue(values=[T.Value(int_value=struct.unpack_from(_AUX_FMT[ty], aux, p)[0])])
+      p += size
+    elif ty == b'f':
+      if n - p < 4:
+        break
+      out[tag] = T.ListValue(values=[T.Value(number_value=struct.unpack_from('<f', aux, p)[0])])
+      p += 4
+    elif ty in (b'Z', b'H'):
+      q = aux.find(b'\0', p)
+      if q < 0:
+        break
+      if ty == b'Z':
+        out[tag] = T.ListValue(values=[T.Value(string_value=aux[p:q].decode('latin-1'))])
+      p = q + 1
+    elif ty == b'B':
+      if n - p < 5:
+        break
+      sub = aux[p:p + 1]
+      count = struct.unpack_from('<I', aux, p + 1)[0]
+      size = _AUX_SIZES.get(sub, 0) if sub != b'A' else 0
+      if not size or n - (p + 5) < count * size:
+        break
+      p += 5
+      if sub == b'f':
+        vals = [T.Value(number_value=v) for v in struct.unpack_from('<%df' % count, aux, p)]
+      else:
+        vals = [T.Value(int_value=v) for v in struct.unpack_from('<%d%s' % (count, _AUX_FMT[sub][1]), aux, p)]
+      if not (sub == b'C' and count == 0):
+        out[tag] = T.ListValue(values=vals)
+      p += count * size
+    else:
+      break
+  return out
+
+
+_COMPLEMENT = str.maketrans('ACGTacgt', 'TGCAtgca')
+_MOD_SPEC = None
+
+
+def parse_base_modifications(read) -> Dict[str, bytes]:
+  """ParseBaseModifications (third_party/nucleus/io/sam_reader.cc:521-719): the read's MM / ML (/ MN) info values ->
+  {'5mC': bytes, '6mA': bytes}, one probability per base in the read's aligned orientation.  A second restatement,
+  next to the native readers' csrc/aux_planes.h, of the function and of its quirks: unsupported specifications still
+  consume their ML values; a specification whose positions run past the read leaves no entry and does not advance
+  the ML offset; the two strands of one modification are merged with a SIGNED char maximum; a mismatching MN or an ML
+  that is too short drops everything."""
+  global _MOD_SPEC
+  import re
+  if _MOD_SPEC is None:
+    _MOD_SPEC = re.compile(r'([ACGTUN])([-+])([a-z]+|[0-9]+)([.?]?)')
+  info = read.info
+  if 'MM' not in info or 'ML' not in info or not info['MM'].values:
+    return {}
+  seq = read.aligned_sequence
+  mn = info['MN'].values[0].int_value or 0 if 'MN' in info and info['MN'].values else len(seq)
+  if mn != len(seq):
+    return {}
+  reverse = bool(read.alignment.position.reverse_strand)
+  if reverse:
+    seq = seq[::-1].translate(_COMPLEMENT)
+  ml = [v.int_value or 0 for v in info['ML'].values]
+  mm = info['MM'].values[0].string_value or ''
+  if mm.endswith(';'):
+    mm = mm[:-1]
+  result: Dict[str, bytes] = {}
+  ml_offset = 0
+  for mod in mm.split(';'):
+    parts = mod.split(',')
+    if len(parts) <= 1:
+      continue
+    m = _MOD_SPEC.fullmatch(parts[0])
+    spec = None
+    if m:
+      base, strand, code = m.group(1), m.group(2), m.group(3)
+      if (base, strand, code) == ('C', '+', 'm'):
+        spec = T.K5MC
+      elif (base, strand, code) in (('A', '+', 'a'), ('T', '-', 'a')):
+        spec = T.K6MA
+    if spec is None:
+      ml_offset += len(parts) - 1
+      continue
+    deltas = parts[1:]
+    plane = bytearray(len(seq))
+    idx = base_count = 0
+    delta = _stoi(deltas[0])
+    for pos, here in enumerate(seq):
+      if here != base:
+        continue
+      if base_count != delta:
+        base_count += 1
+        continue
+      if ml_offset + idx >= len(ml):
+        return {}
+      plane[pos] = ml[idx + ml_offset] & 0xFF
+      base_count = 0
+      idx += 1
+      if idx >= len(deltas):
+        ml_offset += idx
+        done = bytes(plane[::-1] if reverse else plane)
+        if spec in result:
+          signed = lambda b: b - 256 if b > 127 else b      # noqa: E731   (std::max on chars)
+          done = bytes(a if signed(a) >= signed(b) else b for a, b in zip(result[spec], done))
+        result[spec] = done
+        break
+      delta = _stoi(deltas[idx])
+  return result
+
+
+def _stoi(text: str) -> int:
+  """std::stoi: optional blanks and sign, then digits; what follows is ignored; no digits is an error."""
+  import re
+  m = re.match(r'\s*([-+]?\d+)', text)
+  if not m:
+    raise ValueError('MM tag: %r is not a number' % text)
+  return int(m.group(1))
 
 
 def _find_int_tag(aux, tag: bytes) -> Optional[int]:
@@ -407,6 +547,20 @@ def write_bam(path: str, contigs, reads, sample_name: str = 'sample') -> None:
     aux = b''
     if 'HP' in r.info and r.info['HP'].values and r.info['HP'].values[0].int_value is not None:
       aux = b'HPi' + struct.pack('<i', r.info['HP'].values[0].int_value)
+    # base-modification and flow-space tags, in the types the instruments' files use
+    for tag, kind in (('MM', 'Z'), ('ML', 'BC'), ('MN', 'i'), ('tp', 'Bc'), ('t0', 'Z')):
+      if tag not in r.info:
+        continue
+      vals = r.info[tag].values
+      if kind == 'Z':
+        aux += tag.encode() + b'Z' + (vals[0].string_value or '').encode('latin-1') + b'\0'
+      elif kind == 'i':
+        aux += tag.encode() + b'i' + struct.pack('<i', int(vals[0].int_value or 0))
+      else:
+        ints = [int(v.int_value or 0) for v in vals]
+        aux += (tag.encode() + b'B' + kind[1].encode() + struct.pack('<I', len(ints)) +
+                struct.pack('<%d%s' % (len(ints), kind[1].replace('C', 'B').replace('c', 'b')), *ints))
+    aux += getattr(r, '_aux_raw', b'')       # tests: any further BAM-encoded tags, verbatim
     body = (struct.pack('<iiBBHHHiiii', rid, aln.position.position, len(name), aln.mapping_quality,
                         _reg2bin(aln.position.position, end), len(aln.cigar), flag, len(seq), rid if flag & 1 else -1,
                         aln.position.position if flag & 1 else -1, r.fragment_length) +

@@ -379,6 +379,13 @@ class RegionReads:
         min_mapping_quality=a.min_mapping_quality, keep_duplicates=_true(a.keep_duplicates),
         keep_supplementary=_true(a.keep_supplementary_alignments), keep_secondary=_true(a.keep_secondary_alignments),
         use_original_quality_scores=_true(a.use_original_quality_scores))
+    # resolve_sam_aux_fields (make_examples_core.py:288-373): the aux tags the channel list needs -- MM / ML / MN for the
+    # base-modification channels, tp / t0 for the Ultima flow-space channels; the native decoders turn them into
+    # per-base planes (csrc/aux_planes.h)
+    channels = set(getattr(a, 'model_channels', None) or re.split('[, ]+', getattr(a, 'channel_list', '') or ''))
+    requirements['parse_base_modifications'] = bool(channels & {'base_methylation', 'base_6ma'})
+    requirements['parse_flow_tags'] = bool(channels & {'homopolymer_insertion_quality', 'homopolymer_deletion_quality',
+                                                       'inter_homopolymer_insertion_quality'})
     if genomics_io.is_cram(a.reads):
       # sam_reader.cc:560-640: htslib decodes against --ref (use_ref_for_cram) or the slices' own
       # embedded reference; without either the file cannot be parsed

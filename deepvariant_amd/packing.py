@@ -276,6 +276,11 @@ class ReadTable:
   base_aux0: Optional[np.ndarray] = None  # is_homopolymer pixel per base
   base_aux1: Optional[np.ndarray] = None  # homopolymer_weighted pixel per base
   base_aux2: Optional[np.ndarray] = None  # third per-base plane (flow-space channels; include/dvhip.h's rule)
+  # the Ultima flow-space tags as the native decoders deliver them (parse_flow_tags): tp values / t0 characters - 33
+  # per base, and per read bit 0 = has tp, bit 1 = has t0
+  flow_tp: Optional[np.ndarray] = None
+  flow_t0: Optional[np.ndarray] = None
+  flow_present: Optional[np.ndarray] = None
 
   @staticmethod
   def _pack_read(r, need_aux: bool) -> tuple:
@@ -423,7 +428,8 @@ class ReadTable:
                 end: int = 1 << 62, min_mapping_quality: int = 0, keep_duplicates: bool = False,
                 keep_supplementary: bool = False, keep_secondary: bool = False, keep_failed_qc: bool = False,
                 keep_improperly_placed: bool = False, use_original_quality_scores: bool = False,
-                n_threads: int = 4) -> 'ReadTable':
+                n_threads: int = 4, parse_base_modifications: bool = False,
+                parse_flow_tags: bool = False) -> 'ReadTable':
     """Native CRAM 3.0 -> packed table (dv_cram_read_region, include/dvhip.h;
     deepvariant_amd/csrc/cram_reader.cpp): the same reads, in the same order, `from_bam` yields for
     the BAM of the same alignments.  `fetch_reference(contig, start, end) -> bases` supplies what a
@@ -433,7 +439,8 @@ class ReadTable:
     lib = _lib.lib()
     req = _lib.DvReadRequirements(int(keep_duplicates), int(keep_failed_qc), int(keep_secondary),
                                   int(keep_supplementary), int(keep_improperly_placed),
-                                  int(min_mapping_quality), int(use_original_quality_scores))
+                                  int(min_mapping_quality), int(use_original_quality_scores),
+                                  int(parse_base_modifications), int(parse_flow_tags))
     raised = []
 
     def fetch(_ctx, name, lo, hi, out, n_out):
@@ -466,14 +473,18 @@ class ReadTable:
                keep_duplicates: bool = False, keep_supplementary: bool = False,
                keep_secondary: bool = False, keep_failed_qc: bool = False,
                keep_improperly_placed: bool = False, n_threads: int = 4,
-               use_original_quality_scores: bool = False) -> 'ReadTable':
+               use_original_quality_scores: bool = False, parse_base_modifications: bool = False,
+               parse_flow_tags: bool = False) -> 'ReadTable':
     """Native BAM -> packed table (dv_bam_read_region, include/dvhip.h): the reads of
-    `contig` overlapping [start, end) that pass nucleus' ReadRequirements, in file order."""
+    `contig` overlapping [start, end) that pass nucleus' ReadRequirements, in file order.
+    `parse_base_modifications`: the MM / ML / MN tags become the 5mC / 6mA planes (nucleus' ParseBaseModifications);
+    `parse_flow_tags`: the Ultima tp / t0 tags become per-base planes (flow_tp / flow_t0)."""
     import ctypes as C
     lib = _lib.lib()
     req = _lib.DvReadRequirements(int(keep_duplicates), int(keep_failed_qc), int(keep_secondary),
                                   int(keep_supplementary), int(keep_improperly_placed),
-                                  int(min_mapping_quality), int(use_original_quality_scores))
+                                  int(min_mapping_quality), int(use_original_quality_scores),
+                                  int(parse_base_modifications), int(parse_flow_tags))
     handle = C.c_void_p()
     _lib.check(lib.dv_bam_read_region(
         path.encode(), contig.encode() if contig is not None else None, int(start),
@@ -505,6 +516,9 @@ class ReadTable:
     names = bytes(arr(blob.value, np.uint8, nbytes.value)).decode().split('\0')[:n]
     read_numbers = arr(rns.value, np.uint8, n)
     keys = ['%s/%d' % (nm, rn) for nm, rn in zip(names, read_numbers.tolist())]
+    m5, m6, tp, t0, present = (C.c_void_p() for _ in range(5))
+    _lib.check(lib.dv_read_table_aux_planes(handle, C.byref(m5), C.byref(m6), C.byref(tp), C.byref(t0),
+                                            C.byref(present)))
     return cls(
         n_reads=n, read_pos=arr(b.read_pos, np.int32, n), read_sort_pos=None,
         read_seq_off=arr(b.read_seq_off, np.uint32, n + 1),
@@ -513,8 +527,12 @@ class ReadTable:
         read_frag_len=arr(b.read_frag_len, np.int32, n), read_hp=arr(b.read_hp, np.int32, n),
         read_name_rank=arr(b.read_name_rank, np.uint32, n), read_aux=None,
         bases=arr(b.bases, np.uint8, b.n_bases), quals=arr(b.quals, np.uint8, b.n_bases),
-        mod_5mc=None, mod_6ma=None, cigar=arr(b.cigar, np.uint32, b.n_cigar), keys=keys,
-        read_end=ends)
+        mod_5mc=arr(m5.value, np.uint8, b.n_bases) if m5.value else None,
+        mod_6ma=arr(m6.value, np.uint8, b.n_bases) if m6.value else None,
+        cigar=arr(b.cigar, np.uint32, b.n_cigar), keys=keys, read_end=ends,
+        flow_tp=arr(tp.value, np.int8, b.n_bases) if tp.value else None,
+        flow_t0=arr(t0.value, np.uint8, b.n_bases) if t0.value else None,
+        flow_present=arr(present.value, np.uint8, n) if present.value else None)
 
   def to_reads(self, reference_name: str) -> List:
     """Read objects (dv_types.Read) back from the packed table -- what the region chain's host
@@ -543,8 +561,12 @@ class ReadTable:
     raw = self.bases.tobytes()
     words = self.cigar.tolist()
     ends = self.read_end.tolist()
-    plain = self.mod_5mc is None and self.mod_6ma is None
+    plain = self.mod_5mc is None and self.mod_6ma is None and self.flow_tp is None
     strand_bits = DV_READ_REVERSE | DV_READ_SUPPLEMENTARY
+    m5 = self.mod_5mc.tobytes() if self.mod_5mc is not None else None
+    m6 = self.mod_6ma.tobytes() if self.mod_6ma is not None else None
+    flow_tp, flow_t0 = self.flow_tp, self.flow_t0
+    flow_present = self.flow_present.tolist() if self.flow_present is not None else None
 
     def make_alignment(i: int):
       return T.LinearAlignment(
@@ -559,10 +581,22 @@ class ReadTable:
         info['HP'] = T.ListValue(values=[T.Value(int_value=hp[i])])
       s0, s1 = seq_off[i], seq_off[i + 1]
       if not plain:
+        # base modifications / flow-space tags: an ordinary Read carrying what nucleus' reader would have parsed
+        # (Read.base_modifications, sam_reader.cc:855-862; info['tp'] a list of ints, info['t0'] one string)
+        mods = {}
+        if m5 is not None and flags[i] & DV_READ_HAS_5MC:
+          mods[T.K5MC] = m5[s0:s1]
+        if m6 is not None and flags[i] & DV_READ_HAS_6MA:
+          mods[T.K6MA] = m6[s0:s1]
+        if flow_present is not None and flow_present[i] & 1:
+          info['tp'] = T.ListValue(values=[T.Value(int_value=int(v)) for v in flow_tp[s0:s1]])
+        if flow_present is not None and flow_present[i] & 2:
+          info['t0'] = T.ListValue(values=[T.Value(string_value=(flow_t0[s0:s1] + 33).tobytes().decode('latin-1'))])
         return T.Read(
             fragment_name=name, read_number=int(number), number_reads=2,
             supplementary_alignment=bool(flags[i] & DV_READ_SUPPLEMENTARY), fragment_length=frag[i],
-            aligned_sequence=seq[s0:s1], aligned_quality=quals[s0:s1], alignment=make_alignment(i), info=info)
+            aligned_sequence=seq[s0:s1], aligned_quality=quals[s0:s1], alignment=make_alignment(i), info=info,
+            base_modifications=mods)
       # the row this Read is made from IS its packed form (ReadTable._pack_read's record, alignment
       # slot empty until the object exists): from_reads on a list that contains it copies the row
       read = object.__new__(LazyRead)
@@ -611,7 +645,8 @@ class ReadTable:
         bases=self.bases[seq_idx], quals=self.quals[seq_idx], mod_5mc=per_base(self.mod_5mc),
         mod_6ma=per_base(self.mod_6ma), cigar=self.cigar[cig_idx], keys=[keys[i] for i in rows.tolist()],
         read_end=self.read_end[rows], base_aux0=per_base(self.base_aux0), base_aux1=per_base(self.base_aux1),
-        base_aux2=per_base(self.base_aux2))
+        base_aux2=per_base(self.base_aux2), flow_tp=per_base(self.flow_tp), flow_t0=per_base(self.flow_t0),
+        flow_present=None if self.flow_present is None else self.flow_present[rows])
 
   def with_alignments(self, rows, positions, cigars: Sequence[np.ndarray]) -> 'ReadTable':
     """A copy in which row rows[k] starts at positions[k] with the CIGAR words cigars[k]
@@ -695,7 +730,7 @@ def concat_tables(tables: Sequence[ReadTable]) -> ReadTable:
       read_flags=cat('read_flags'), read_frag_len=cat('read_frag_len'), read_hp=cat('read_hp'), read_name_rank=ranks,
       read_aux=cat('read_aux'), bases=cat('bases'), quals=cat('quals'), mod_5mc=cat('mod_5mc'), mod_6ma=cat('mod_6ma'),
       cigar=cat('cigar'), keys=keys, read_end=cat('read_end'), base_aux0=cat('base_aux0'), base_aux1=cat('base_aux1'),
-      base_aux2=cat('base_aux2'))
+      base_aux2=cat('base_aux2'), flow_tp=cat('flow_tp'), flow_t0=cat('flow_t0'), flow_present=cat('flow_present'))
 
 
 def support_codes(dv_call, alt_alleles: Sequence[str], table: ReadTable,

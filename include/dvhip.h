@@ -307,6 +307,15 @@ typedef struct dv_read_requirements {
    * aligned_quality EMPTY for a read without the tag -- which the encoder cannot draw -- so
    * here such a read is an error (DV_ERR_BAD_INPUT). */
   int32_t use_original_base_quality_scores;
+  /* ABI v6: per-base planes from aux tags, what make_examples asks SamReader to parse when the channel list needs
+   * them (deepvariant/make_examples_core.py:288-373 resolve_sam_aux_fields).
+   * parse_base_modifications: MM / ML / MN -> 5mC and 6mA planes = Read.base_modifications
+   * (third_party/nucleus/io/sam_reader.cc:521-719 ParseBaseModifications, :855-862); dv_read_table_fill_batch then
+   * sets dv_batch::mod_5mc / mod_6ma, and read_flags carry DV_READ_HAS_5MC / DV_READ_HAS_6MA per read.
+   * parse_flow_tags: the Ultima tp (B array) and t0 (Z) tags -> dv_read_table_aux_planes' tp / t0 planes, the
+   * `tags` input of dv_flow_channel_pixels. */
+  int32_t parse_base_modifications;
+  int32_t parse_flow_tags;
 } dv_read_requirements;
 
 typedef struct dv_read_table dv_read_table; /* owns host arrays in dv_batch's read layout */
@@ -335,6 +344,11 @@ typedef int (*dv_ref_fetch_fn)(void* ctx, const char* contig, int64_t start, int
 int dv_cram_read_region(const char* path, const char* contig, int64_t start, int64_t end,
                         const dv_read_requirements* req, dv_ref_fetch_fn fetch, void* fetch_ctx,
                         int n_threads, dv_read_table** out);
+/* The optional per-base planes of a table, parallel to its bases (NULL where the requirements did not ask for them):
+ * 5mC / 6mA modification probabilities; tp values (0 where a read has no tag or a shorter one); t0 characters - 33;
+ * flow_present[read]: bit 0 = the read has a tp tag, bit 1 = a t0 tag.  Any output pointer may be NULL. */
+int dv_read_table_aux_planes(const dv_read_table* table, const uint8_t** mod_5mc, const uint8_t** mod_6ma,
+                             const int8_t** tp, const uint8_t** t0, const uint8_t** flow_present);
 /* The SAM header text of a CRAM (its first container): `needed` = its length; up to
  * `capacity` bytes are copied to `text` (may be NULL). */
 int dv_cram_header(const char* path, char* text, uint64_t capacity, uint64_t* needed);
