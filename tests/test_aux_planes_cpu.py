@@ -232,3 +232,51 @@ def test_make_examples_asks_for_the_tags_its_channels_need(tmp_path):
   c, keep = batch.to_ctypes()
   assert c.mod_5mc and c.mod_6ma
   del keep
+
+
+def test_malformed_aux_blocks_do_not_break_the_decoder(tmp_path):
+  """Aux blocks come from untrusted files: random bytes, truncated values, arrays that announce more elements than the
+  record holds, MM strings without numbers.  The reader keeps what it parsed before the damage (as ParseAuxFields
+  does), refuses what the reference aborts on (a position that is not a number: BAD_INPUT), and never reads outside
+  the record -- every read comes back with planes of its own length."""
+  import struct
+  rng = np.random.default_rng(99)
+  reads = []
+  for k in range(400):
+    n = int(rng.integers(1, 40))
+    r = _read(''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=n)), name='m%03d' % k, start=5 + 45 * k,
+              reverse=bool(rng.integers(0, 2)))
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+      raw = bytes(rng.integers(0, 256, size=int(rng.integers(0, 40))).astype(np.uint8))
+    elif kind == 1:      # an array that announces far more elements than follow
+      raw = b'MLBC' + struct.pack('<I', int(rng.integers(5, 1 << 31))) + b'\x01\x02'
+    elif kind == 2:      # a string without its terminator, at the end of the record
+      raw = b'MMZC+m?,0,0'
+    elif kind == 3:      # valid MM, ML of another array type, MN of a small type
+      raw = b'MMZC+m?,0;\0' + b'MLBs' + struct.pack('<Ih', 1, 300) + b'MNC' + bytes([n & 0xFF])
+    elif kind == 4:      # tp as 32-bit integers (cut to int8), t0 longer than the read
+      raw = b'tpBi' + struct.pack('<I3i', 3, 1, -2, 300) + b't0Z' + b'5' * (n + 7) + b'\0'
+    elif kind == 5:      # unknown array subtype
+      raw = b'MLBZ' + struct.pack('<I', 2) + b'ab'
+    else:                # float array where integers are expected, hex string where a string is expected
+      raw = b'MLBf' + struct.pack('<I2f', 2, 1.5, 2.5) + b'MMH4142\0'
+    r._aux_raw = raw       # pylint: disable=protected-access
+    reads.append(r)
+  path = str(tmp_path / 'bad_aux.bam')
+  gio.write_bam(path, [('chr1', 40000)], reads)
+  table = packing.ReadTable.from_bam(path, 'chr1', 0, 40000, parse_base_modifications=True, parse_flow_tags=True)
+  assert table.n_reads == len(reads)
+  total = int(table.read_seq_off[-1])
+  assert table.mod_5mc.size == table.mod_6ma.size == table.flow_tp.size == table.flow_t0.size == total
+  # kind 4: values cut to a byte, the rest of the read zero; the long t0 cut to the read
+  i = next(k for k, r in enumerate(reads) if r._aux_raw.startswith(b'tpBi') and len(r.aligned_sequence) >= 4)      # pylint: disable=protected-access
+  s0, s1 = int(table.read_seq_off[i]), int(table.read_seq_off[i + 1])
+  assert table.flow_tp[s0:s0 + 4].tolist() == [1, -2, 300 - 256, 0] and table.flow_present[i] == 3
+  assert set(table.flow_t0[s0:s1].tolist()) == {ord('5') - 33}
+  # what the reference aborts on is refused, with a message
+  bad = _read('ACGTCC', name='bad', info={'MM': 'C+m?,x', 'ML': [1]})
+  gio.write_bam(path, [('chr1', 40000)], [bad])
+  with pytest.raises(Exception, match='not a number'):
+    packing.ReadTable.from_bam(path, 'chr1', 0, 40000, parse_base_modifications=True)
+  assert packing.ReadTable.from_bam(path, 'chr1', 0, 40000).n_reads == 1      # (not asked for: not looked at)
