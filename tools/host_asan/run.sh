@@ -6,10 +6,11 @@
 #   tools/host_asan/run.sh [pytest arguments...]      (default: the host-native test files)
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
-WORK=${DV_ASAN_WORK:-/tmp/dv_host_asan}
+SAN=${DV_SANITIZER:-address,undefined}      # DV_SANITIZER=thread: ThreadSanitizer (the decoders' and the realigner's host threads)
+WORK=${DV_ASAN_WORK:-/tmp/dv_host_san_${SAN//,/_}}
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 mkdir -p "$WORK"
-FLAGS="-std=c++17 -O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/include -I$ROOT/deepvariant_amd/csrc"
+FLAGS="-std=c++17 -O1 -g -fPIC -fsanitize=$SAN -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/include -I$ROOT/deepvariant_amd/csrc"
 OBJS=""
 for src in bam_reader cram_reader region_packer local_align fast_pass_aligner debruijn_graph direct_phasing aligner_abi region_realigner flow_channels; do
   $CLANG $FLAGS -x c++ -c "$ROOT/deepvariant_amd/csrc/$src.cpp" -o "$WORK/$src.o"
@@ -17,13 +18,13 @@ for src in bam_reader cram_reader region_packer local_align fast_pass_aligner de
 done
 $CLANG $FLAGS -x c++ -c "$ROOT/tools/host_asan/stubs.cc" -o "$WORK/stubs.o"
 $CLANG $FLAGS -x c++ -c "$ROOT/tools/host_asan/device_stubs.cc" -o "$WORK/device_stubs.o"
-$CLANG -shared -fsanitize=address,undefined -shared-libsan $OBJS "$WORK/stubs.o" "$WORK/device_stubs.o" -o "$WORK/libdvhost_asan.so" -lz -ldl -lpthread
-RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
+$CLANG -shared -fsanitize=$SAN -shared-libsan $OBJS "$WORK/stubs.o" "$WORK/device_stubs.o" -o "$WORK/libdvhost_asan.so" -lz -ldl -lpthread
+RT=$($CLANG -print-file-name=libclang_rt.$([ "$SAN" = thread ] && echo tsan || echo asan)-x86_64.so)
 cd "$ROOT"
 TESTS=${@:-tests/test_bam_native_cpu.py tests/test_bam_reference_vectors_cpu.py tests/test_cram_native_cpu.py tests/test_aux_planes_cpu.py tests/test_fast_pass_aligner_cpu.py tests/test_reference_realigner_cpu.py tests/test_reference_graphs_cpu.py tests/test_realigner_cpu.py tests/test_host_io_cpu.py tests/test_make_examples_cli_cpu.py tests/test_reference_examples_fuzz_cpu.py tests/test_reference_examples_cpu.py}
-DV_LIB_PATH="$WORK/libdvhost_asan.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0 \
+DV_LIB_PATH="$WORK/libdvhost_asan.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 TSAN_OPTIONS=report_signal_unsafe=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0 \
   python -m pytest $TESTS -q -p no:cacheprovider 2>&1 | tee "$WORK/log.txt" | tail -25
-echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer' "$WORK/log.txt" || true)"
+echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer\|ThreadSanitizer' "$WORK/log.txt" || true)"
 echo "failed tests (expected here: the ones that reach a host helper living in a .hip translation unit --"
 echo "dv_query_reads, dv_base_aux_plane, dv_crc32c -- which this build answers with a stand-in):"
 grep -E "^(FAILED|ERROR)" "$WORK/log.txt" | cut -c1-110 || echo "  none"
