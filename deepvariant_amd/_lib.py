@@ -33,6 +33,7 @@ DV_ERR_BAD_INPUT = -6
 ABI_SYMBOLS = [
     'dv_last_error', 'dv_abi_version', 'dv_device_count',
     'dv_encoder_create', 'dv_encoder_destroy', 'dv_encode_batch', 'dv_base_aux_plane', 'dv_flow_channel_pixels',
+    'dv_downsample_with_partition_mins',
     'dv_downsample_indices', 'dv_validate_batch', 'dv_query_reads', 'dv_crc32c',
     'dv_model_create', 'dv_model_destroy', 'dv_model_num_params', 'dv_model_conv_macs',
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights',
@@ -295,6 +296,8 @@ def lib():
                                       C.c_void_p, C.c_int, C.c_void_p]
     l.dv_cram_header.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
     l.dv_read_table_aux_planes.argtypes = [C.c_void_p] * 6
+    l.dv_downsample_with_partition_mins.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                    C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     l.dv_base_aux_plane.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     l.dv_flow_channel_pixels.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p]

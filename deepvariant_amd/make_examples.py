@@ -102,6 +102,9 @@ def build_arg_parser() -> argparse.ArgumentParser:
   ap.add_argument('--vsc_min_fraction_indels', type=float, default=0.06)
   ap.add_argument('--pileup_image_width', type=int, default=221)
   ap.add_argument('--pileup_image_height', type=int, default=100)
+  # make_examples_options.py:866-883: every allele keeps at least this many of its supporting reads in the image
+  ap.add_argument('--use_non_uniform_downsampling', default='false', **boolean)
+  ap.add_argument('--non_uniform_downsampling_threshold', type=int, default=3)
   ap.add_argument('--sort_by_haplotypes', default='false', **boolean)
   ap.add_argument('--reverse_haplotypes', default='false', **boolean)
   ap.add_argument('--phase_reads', default='false', **boolean)
@@ -290,7 +293,9 @@ def options_from_flags(args):
   options = T.MakeExamplesOptions(
       pic_options=pic, trim_reads_for_pileup=_true(args.trim_reads_for_pileup),
       sample_options=[T.SampleOptions(role='main', name=args.sample_name or 'default',
-                                      pileup_height=args.pileup_image_height)])
+                                      pileup_height=args.pileup_image_height,
+                                      use_non_uniform_downsampling=_true(args.use_non_uniform_downsampling),
+                                      non_uniform_downsampling_threshold=args.non_uniform_downsampling_threshold)])
   realigner_flags = {}
   for name, default in _REALIGNER_FLAGS.items():
     v = getattr(args, name)

@@ -159,8 +159,6 @@ class ExamplesGenerator:
     self._samples = {so.role: so for so in options.sample_options}
     for so in options.sample_options:
       aap.get_alt_aligned_pileup(so.alt_aligned_pileup or aap.NONE)   # unknown names are fatal
-      if so.use_non_uniform_downsampling:
-        raise NotImplementedError('use_non_uniform_downsampling')
     self._height = calculate_pileup_image_height(options)
     self._labels: List[Optional[VariantLabel]] = []
     self._writers: Dict[str, tfrecord.Writer] = {}
@@ -243,6 +241,17 @@ class ExamplesGenerator:
     new_tables = [self._table_of(trimmed[s], starts[s]) for s in range(len(reads_per_sample))]
     self._trimmed_reads, self._trimmed_starts = trimmed, starts
     return new_tables, ranges
+
+  def _non_uniform(self, cand, table, idx_local, so):
+    """SampleOptions.use_non_uniform_downsampling: the reads of one image that stay (every BuildPileupForOneSample
+    call of the sample -- reference image and alt-aligned images alike -- samples its own read list,
+    pileup_image_native.cc:326-341)."""
+    if not so.use_non_uniform_downsampling:
+      return idx_local
+    pic = self._options.pic_options
+    kept = packing.non_uniform_sample(cand, table, idx_local, so.pileup_height - pic.reference_band_height,
+                                      so.non_uniform_downsampling_threshold, pic.random_seed)
+    return idx_local if kept is None else np.asarray(idx_local)[kept]
 
   def _table_of(self, reads, sort_positions):
     t = packing.ReadTable.from_reads(
@@ -352,7 +361,7 @@ class ExamplesGenerator:
     if (trim_ranges is None and len(sample_order) == 1 and len(tables) == 1 and
         not self._encoder_api._need_list_aux and os.environ.get('DV_PY_PACKER') is None):
       so = self._options.sample_options[sample_order[0]]
-      if not so.channels_enum_to_blank and not so.variant_types_to_blank:
+      if not so.channels_enum_to_blank and not so.variant_types_to_blank and not so.use_non_uniform_downsampling:
         windows = [get_reference_bases_for_pileup(self._ref, c.variant, width) for c in candidates]
         combos = [list(alt_allele_combinations(c, pic.multi_allelic_mode)) if w else []
                   for c, w in zip(candidates, windows)]
@@ -393,6 +402,7 @@ class ExamplesGenerator:
           else:
             table, base = tables[s], sample_base[s]
             idx_local = table.query(q0, q1)
+          idx_local = self._non_uniform(cand, table, idx_local, so)
           blank = list(so.channels_enum_to_blank)
           if vtype in _types_to_blank(so):
             blank = list(T.DeepVariantChannelEnum)
@@ -445,6 +455,7 @@ class ExamplesGenerator:
       for target in ([out_off] + ([item['in_place']] if item['scratch'] is not None and
                                   item['in_place'] is not None else [])):
         idx_local, table = item['idx'], item['table']
+        idx_local = self._non_uniform(item['cand'], table, idx_local, so)
         batch.add_item(
             item['variant'].start, item['variant'].start - self._half_width,
             batch.add_ref_window(item['window']), idx_local + item['base'],

@@ -175,6 +175,43 @@ def seq_aux_plane(channel: int, reads: Sequence, seqs: Sequence[bytes], bases: n
   return out
 
 
+def non_uniform_sample(dv_call, table, idx: np.ndarray, max_reads: int, min_per_allele: int, random_seed: int,
+                       forced_draws=None) -> Optional[np.ndarray]:
+  """SampleOptions.use_non_uniform_downsampling for one pile-up whose reads are the table rows `idx`
+  (DownsampleReadIndicesWithMinsPerAllele, pileup_image_native.cc:242-294): -> positions in `idx` (ascending) of the
+  reads that stay, or None where the reference falls back to the uniform shuffle (then the whole list goes to the
+  encoder as usual).  Alleles are taken in key order (the reference walks a hash map: for a read listed under two
+  alleles its own result depends on hash order).  The sampler is native (dv_downsample_with_partition_mins)."""
+  n = len(idx)
+  position = {}
+  keys = table.keys
+  for k, row in enumerate(np.asarray(idx).tolist()):
+    position[keys[row]] = k          # a later read replaces an earlier one of the same key (:251-256)
+  off, flat = [0], []
+  for allele in sorted(dv_call.allele_support):
+    for name in dv_call.allele_support[allele].read_names:
+      k = position.get(name)
+      if k is not None:
+        flat.append(k)
+    off.append(len(flat))
+  listed = set(flat)
+  flat += sorted(k for k in position.values() if k not in listed)      # the reads no allele lists: the last element
+  off.append(len(flat))
+  part_off = np.array(off, np.int32)
+  part_idx = np.array(flat or [0], np.int32)
+  out = np.zeros(max(n, 1), np.int32)
+  n_out = C.c_int32(0)
+  forced = None if forced_draws is None else np.ascontiguousarray(forced_draws, np.uint64)
+  _lib.check(_lib.lib().dv_downsample_with_partition_mins(
+      n, part_off.ctypes.data_as(C.c_void_p), part_idx.ctypes.data_as(C.c_void_p), len(off) - 1, int(max_reads),
+      int(min_per_allele), int(random_seed) & 0xFFFFFFFF,
+      None if forced is None else forced.ctypes.data_as(C.c_void_p), 0 if forced is None else len(forced),
+      out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
+  if n_out.value < 0:
+    return None
+  return out[:n_out.value].astype(np.int64)
+
+
 def gc_content_pixel(seq: bytes) -> int:
   """GcContentChannel::GcContent + ScaleColor(.., 100) (channels/gc_content_channel.cc:78-101)."""
   if not seq:

@@ -110,7 +110,7 @@ class PileupImageEncoderNative:
   def _one_item(self, dv_call, ref_bases: str, reads: Sequence,
                 image_start_pos: int, alt_alleles: Sequence[str], height: int,
                 mean_coverage: float = 0.0, alignment_positions=None,
-                channels_to_blank=None):
+                channels_to_blank=None, non_uniform_threshold=None):
     width = len(ref_bases)
     table = packing.ReadTable.from_reads(
         reads, alignment_positions=alignment_positions,
@@ -118,6 +118,11 @@ class PileupImageEncoderNative:
     batch = packing.PackedBatch(table=table, width=width, use_ref_aux=self._need_ref_aux)
     ref_idx = batch.add_ref_window(ref_bases)
     idx = np.arange(len(reads), dtype=np.uint32)
+    if non_uniform_threshold is not None:
+      kept = packing.non_uniform_sample(dv_call, table, idx, height - self._options.reference_band_height,
+                                        non_uniform_threshold, self._options.random_seed)
+      if kept is not None:
+        idx = idx[kept]
     codes = packing.support_codes(dv_call, alt_alleles, table, idx)
     groups = (packing.allele_groups(dv_call, table, idx)
               if getattr(self._options, 'sort_by_alt_allele_support', False)
@@ -164,13 +169,14 @@ class PileupImageEncoderNative:
     pileup_image_native.cc:297-447, in FillPileupArray's HWC order)."""
     if len(ref_bases) != self._options.width:
       raise ValueError('ref_bases.size() != width')  # CHECK_EQ, :308
-    if getattr(sample_options, 'use_non_uniform_downsampling', False):
-      raise NotImplementedError(
-          'use_non_uniform_downsampling draws from absl::Uniform; unsupported')
     height = sample_options.pileup_height or self._options.height
+    non_uniform = None
+    if getattr(sample_options, 'use_non_uniform_downsampling', False):
+      # every allele keeps a minimum of its supporters (:326-341); sampled on the host, see packing.non_uniform_sample
+      non_uniform = int(sample_options.non_uniform_downsampling_threshold)
     img, _ = self._one_item(
         dv_call, ref_bases, list(reads), image_start_pos, list(alt_alleles),
         height=height, mean_coverage=mean_coverage,
         alignment_positions=alignment_positions,
-        channels_to_blank=channels_to_blank)
+        channels_to_blank=channels_to_blank, non_uniform_threshold=non_uniform)
     return img

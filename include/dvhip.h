@@ -227,6 +227,24 @@ typedef struct dv_model dv_model;
 #define DV_BASE_AUX_NONE 3
 int dv_base_aux_plane(const int32_t* channels, int32_t n_channels, int32_t channel_index);
 
+/* SampleOptions.use_non_uniform_downsampling (deepvariant/pileup_image_native.cc:242-294,326-341;
+ * deepvariant/sampling_util.h:57-155): the reads of one pile-up that survive when every allele keeps at least
+ * `min_per_partition` of its supporters.  part_off[n_parts + 1] / part_idx: for every allele of
+ * DeepVariantCall.allele_support, in the order the map yields them, the indices (into the pile-up's read list,
+ * 0 .. n_reads - 1) of the reads it lists, and as the LAST element the reads no allele lists (GetReadIndicesAllelePartition
+ * finds reads by their "fragment_name/read_number" key: of several reads with one key only the last takes part -- the
+ * others appear in no element and are never drawn).  A read listed twice belongs to the first element that lists it.
+ * out[<= n_reads] receives the sample in ascending order, *n_out its size -- or -1 where the reference's
+ * sampler fails (the thresholds alone exceed max_reads) and BuildPileupForOneSample falls back to the uniform
+ * shuffle: the caller then passes the whole list to dv_encode_batch as usual.  With a sample in hand the caller passes
+ * only those reads (the list is then no longer than max_reads and the device draws them all, in that order).
+ * Draws: absl::Uniform over std::mt19937_64(random_seed), restated (csrc/sampling.cpp: parity UNPINNED for the bit
+ * stream alone).  forced_draws (tests; NULL otherwise) replaces the draws, one per Uniform(0, index) call. */
+int dv_downsample_with_partition_mins(int32_t n_reads, const int32_t* part_off, const int32_t* part_idx,
+                                      int32_t n_parts, int32_t max_reads, int32_t min_per_partition,
+                                      uint32_t random_seed, const uint64_t* forced_draws, int64_t n_forced,
+                                      int32_t* out, int32_t* n_out);
+
 /* Per-base pixels of a flow-space channel for every read of a table, to be passed as the base_aux plane the channel
  * reads (channels/homopolymer_indel_quality_channel.cc:68-183, channels/inter_homopolymer_insertion_quality_channel.cc:
  * 76-125, channels/channel_utils.cc:41-44).  `tags` is parallel to bases:

@@ -115,6 +115,9 @@ typedef struct dvo_options {
   int32_t hp_tag_for_assembly_polishing;
   int32_t sort_by_alt_allele_support;
   float min_non_zero_allele_frequency;
+  /* SampleOptions.use_non_uniform_downsampling / non_uniform_downsampling_threshold (deepvariant.proto:715-720) */
+  int32_t use_non_uniform_downsampling;
+  int32_t non_uniform_downsampling_threshold;
 } dvo_options;
 
 /* nucleus.genomics.v1.Read, the fields the encoder touches. */

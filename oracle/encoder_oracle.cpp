@@ -11,6 +11,7 @@
 // float->int truncations below must be evaluated in IEEE fp32 exactly like
 // the reference's static_cast<int>(254.0f * x)).
 
+#include "absl_uniform_restated.h"
 #include "dvo.h"
 #include "packed_adapter.h"
 
@@ -22,6 +23,7 @@
 #include <numeric>
 #include <optional>
 #include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -937,6 +939,68 @@ std::vector<int> DownsampleReadIndices(int n, int max_reads, uint32_t seed) {
   return idx;
 }
 
+// GetReadIndicesAllelePartition + DownsampleReadIndicesWithMinsPerAllele (pileup_image_native.cc:242-294) over
+// sampling::SampleWithPartitionMins / ReservoirSample (deepvariant/sampling_util.h:57-155): at least `min_per_allele`
+// reads of every allele's supporters (and of the reads that support no allele) survive, the rest of the image is filled
+// from what is left.  -> the kept read indices in ascending order (the reference returns a btree_set), or false where
+// the reference returns an error (the thresholds alone exceed the image) and falls back to the uniform shuffle.
+// A read listed under two alleles belongs to the one the proto map yields first: hash order in the reference, KEY order
+// here and in the reference build (oracle/ref_build).  The draws follow oracle/absl_uniform_restated.h.
+bool DownsampleWithMinsPerAllele(const dvo_call& call, const dvo_read* reads, int n_reads, int max_reads,
+                                 int min_per_allele, uint32_t seed, std::vector<int>* out) {
+  std::map<std::string, int> name_to_index;
+  for (int i = 0; i < n_reads; ++i) name_to_index[ReadKey(reads[i])] = i;
+  std::vector<int> order(static_cast<size_t>(call.n_support));
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    return std::string(call.support_alleles[a]) < call.support_alleles[b];
+  });
+  std::set<std::set<int>> partition;
+  for (int s : order) {
+    std::set<int> idx;
+    for (int n = call.support_offsets[s]; n < call.support_offsets[s + 1]; ++n) {
+      auto it = name_to_index.find(call.support_names[n]);
+      if (it != name_to_index.end()) {
+        idx.insert(it->second);
+        name_to_index.erase(it);
+      }
+    }
+    partition.insert(idx);
+  }
+  std::set<int> ref_idx;
+  for (const auto& kv : name_to_index) ref_idx.insert(kv.second);
+  partition.insert(ref_idx);
+
+  std::mt19937_64 gen(seed);
+  auto reservoir = [&gen](const std::set<int>& population, size_t sample_size_in) {
+    const int sample_size = static_cast<int>(sample_size_in);   // ReservoirSample(int sample_size, ...)
+    if (population.size() < static_cast<size_t>(sample_size)) return population;
+    std::vector<int> sampled(static_cast<size_t>(sample_size));
+    size_t index = 0;
+    auto it = population.begin();
+    for (; index < static_cast<size_t>(sample_size); ++it, ++index) sampled[index] = *it;
+    for (; it != population.end(); ++it, ++index) {
+      const size_t swap_index = dvo_absl::UniformClosed64(gen, 0, index);
+      if (swap_index < static_cast<size_t>(sample_size)) sampled[swap_index] = *it;
+    }
+    return std::set<int>(sampled.begin(), sampled.end());
+  };
+  std::set<int> sampled, unsampled;
+  for (const std::set<int>& part : partition) {
+    const std::set<int> chosen = reservoir(part, static_cast<size_t>(min_per_allele));
+    for (int e : part) {
+      if (!chosen.count(e)) unsampled.insert(e);
+    }
+    sampled.insert(chosen.begin(), chosen.end());
+  }
+  const int remaining = max_reads - static_cast<int>(sampled.size());
+  if (remaining < 0) return false;
+  const std::set<int> rest = reservoir(unsampled, static_cast<size_t>(remaining));
+  sampled.insert(rest.begin(), rest.end());
+  out->assign(sampled.begin(), sampled.end());
+  return true;
+}
+
 struct PileupRow {
   int hap_idx;
   int allele_group;
@@ -981,8 +1045,12 @@ int BuildPileup(const dvo_options& opt, const dvo_call& call,
     row_read.push_back(-1);
   }
 
-  std::vector<int> sampled =
-      DownsampleReadIndices(n_reads, max_reads, opt.random_seed);
+  std::vector<int> sampled;
+  if (!opt.use_non_uniform_downsampling ||
+      !DownsampleWithMinsPerAllele(call, reads, n_reads, max_reads, opt.non_uniform_downsampling_threshold,
+                                   opt.random_seed, &sampled)) {
+    sampled = DownsampleReadIndices(n_reads, max_reads, opt.random_seed);
+  }
 
   // read name -> allele group (pileup_image_native.cc:346-361)
   std::map<std::string, int> read_name_to_allele_group;

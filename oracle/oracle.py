@@ -71,6 +71,7 @@ class DvoOptions(C.Structure):
       ('hp_tag_for_assembly_polishing', C.c_int32),
       ('sort_by_alt_allele_support', C.c_int32),
       ('min_non_zero_allele_frequency', C.c_float),
+      ('use_non_uniform_downsampling', C.c_int32), ('non_uniform_downsampling_threshold', C.c_int32),
   ]
 
 
@@ -408,10 +409,14 @@ def encode_read(pic_options, dv_call, ref_bases: str, read, image_start_pos,
 def build_pileup(pic_options, dv_call, ref_bases: str, reads, image_start_pos,
                  alt_alleles, pileup_height=0, mean_coverage=0.0,
                  alignment_positions=None, channels_to_blank=None,
-                 return_row_reads=False):
-  """BuildPileupForOneSample + FillPileupArray -> uint8 [H, W, C]."""
+                 return_row_reads=False, non_uniform_downsampling_threshold=None):
+  """BuildPileupForOneSample + FillPileupArray -> uint8 [H, W, C].  `non_uniform_downsampling_threshold`: the
+  sample's use_non_uniform_downsampling with that many reads kept per allele (pileup_image_native.cc:326-341)."""
   keep = _Keep()
   o = make_options(pic_options)
+  if non_uniform_downsampling_threshold is not None:
+    o.use_non_uniform_downsampling = 1
+    o.non_uniform_downsampling_threshold = int(non_uniform_downsampling_threshold)
   w = len(ref_bases)
   h = pileup_height or pic_options.height
   out = np.zeros((h, w, o.n_channels), dtype=np.uint8)
@@ -804,9 +809,11 @@ def reference_write_examples_in_region(options, ref_reader, contig: str, contig_
   for k, v in (aln_config or {}).items():
     lines.append('O\taln.%s\t%s' % (k, v))
   for so in options.sample_options:
-    lines.append('M\t%s\t%s\t%d\t%s\t%s\t%s\t%d' % (so.role, so.name, so.pileup_height, ','.join(map(str, so.order)),
-                                                     so.alt_aligned_pileup, ','.join(str(int(c)) for c in so.channels_enum_to_blank),
-                                                     int(bool(so.keep_only_window_spanning_reads))))
+    lines.append('M\t%s\t%s\t%d\t%s\t%s\t%s\t%d\t%d\t%d' % (
+        so.role, so.name, so.pileup_height, ','.join(map(str, so.order)), so.alt_aligned_pileup,
+        ','.join(str(int(c)) for c in so.channels_enum_to_blank), int(bool(so.keep_only_window_spanning_reads)),
+        int(bool(getattr(so, 'use_non_uniform_downsampling', False))),
+        int(getattr(so, 'non_uniform_downsampling_threshold', 0))))
   lo, hi = contig_length, 0
   for c in candidates:
     v = c.variant

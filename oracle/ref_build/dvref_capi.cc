@@ -223,6 +223,8 @@ int BuildPileup(const dvo_options& opt, const dvo_call& call, const std::string&
   }
   refdv::SampleOptions sample;
   sample.set_pileup_height(pileup_height);
+  sample.set_use_non_uniform_downsampling(opt.use_non_uniform_downsampling != 0);
+  sample.set_non_uniform_downsampling_threshold(opt.non_uniform_downsampling_threshold);
   std::vector<int64_t> positions;
   if (alignment_positions) positions.assign(alignment_positions, alignment_positions + n_reads);
   auto rows = encoder.BuildPileupForOneSample(dv_call, ref_bases, ptrs, image_start_pos, Strings(alt_alleles, n_alt_alleles),
@@ -989,6 +991,10 @@ int dvr_write_examples_in_region(const char* spec, const char* contig, int64_t c
         so->set_alt_aligned_pileup(f[5]);
         for (const std::string& x : SplitCommas(f[6])) so->add_channels_enum_to_blank(static_cast<refdv::DeepVariantChannelEnum>(std::atoi(x.c_str())));
         so->set_keep_only_window_spanning_reads(std::atoi(f[7].c_str()) != 0);
+        if (f.size() > 9) {
+          so->set_use_non_uniform_downsampling(std::atoi(f[8].c_str()) != 0);
+          so->set_non_uniform_downsampling_threshold(std::atoi(f[9].c_str()));
+        }
       } else if (f[0] == "C") {
         candidates.emplace_back();
         auto* v = candidates.back().mutable_variant();

@@ -125,3 +125,41 @@ def test_packed_batches_of_the_bench_workloads(kind):
   (ref, ref_rows), (mine, mine_rows) = _both(lambda: O.encode_packed(opts, batch, n_threads=2))
   assert ref.size == mine.size > 0 and np.array_equal(ref, mine)
   assert np.array_equal(ref_rows, mine_rows) and int(mine_rows.max()) > 20
+
+
+@pytest.mark.parametrize('threshold', [0, 1, 3, 8, 40])
+def test_non_uniform_downsampling_equals_the_reference(threshold):
+  """SampleOptions.use_non_uniform_downsampling (pileup_image_native.cc:242-294,326-341; deepvariant/sampling_util.h):
+  the allele partition, the per-allele minimum, the reservoir samples and the fall-back to the uniform shuffle when
+  the thresholds alone exceed the image -- the oracle restatement == the reference's own code, rows and pixels.  Both
+  draw through the same restatement of absl::Uniform (oracle/absl_uniform_restated.h; abseil is not in the image), so
+  this pins everything around the bit stream, not the bit stream."""
+  name, channels, width, height, okw, ckw = FZ.CONFIGS[0]
+  height = 30
+  opts = FZ.options(channels, width, height, **dict(okw))
+  n_sampled = n_fallback = 0
+  for seed in range(10):
+    rng = np.random.default_rng(4000 + 17 * threshold + seed)
+    depth = int(rng.choice([5, 24, 26, 60, 140]))
+    call, ref_window, reads, image_start, combo = FZ.make_case(rng, width, depth, n_alts=int(rng.integers(1, 4)), **dict(ckw))
+    for k, r in enumerate(reads):       # every read usable, distinct keys: the sample decides the image
+      r.fragment_name, r.read_number = 'f%03d' % k, 0
+      r.alignment.mapping_quality = 60
+    keys = ['%s/0' % r.fragment_name for r in reads]
+    for allele in list(call.allele_support):
+      pick = rng.choice(len(keys), size=int(rng.integers(0, max(len(keys) // 3, 1) + 1)), replace=False) if keys else []
+      call.allele_support[allele] = T.SupportingReads([keys[int(j)] for j in pick])
+    kw = dict(pileup_height=height, non_uniform_downsampling_threshold=threshold, return_row_reads=True)
+    (ref, _, _), (mine, n_mine, rows_mine) = _both(
+        lambda: O.build_pileup(opts, call, ref_window, reads, image_start, combo, **kw))
+    # (the reference does not report which read a row shows: the pixels say it -- random reads, no two rows alike)
+    assert np.array_equal(ref, mine), (threshold, seed)
+    _, (uniform, _, rows_uniform) = _both(lambda: O.build_pileup(opts, call, ref_window, reads, image_start, combo,
+                                                                 pileup_height=height, return_row_reads=True))
+    if depth > height - 5:
+      same_as_uniform = rows_uniform.tolist() == rows_mine.tolist()
+      n_fallback += same_as_uniform
+      n_sampled += not same_as_uniform
+  assert n_sampled + n_fallback >= 4
+  assert (n_sampled >= 3) if threshold <= 3 else True
+  assert (n_fallback >= 3) if threshold == 40 else True       # 40 reads per allele cannot fit 25 rows: uniform again

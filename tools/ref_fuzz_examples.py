@@ -7,7 +7,7 @@ tests/test_hip_reference_examples.py).  TEST INFRASTRUCTURE.
   python tools/ref_fuzz_examples.py [n_cases] [first_seed] [alt]     -> a summary line; failures are printed with their seed
 
 What varies per case: window width, 1-3 samples with their own heights / read sets / channels_enum_to_blank /
-keep_only_window_spanning_reads, the sample order and the role, the channel list (insert_size, haplotype + HP tags with
+keep_only_window_spanning_reads / use_non_uniform_downsampling, the sample order and the role, the channel list (insert_size, haplotype + HP tags with
 sort_by_haplotypes, mean_coverage, blank, is_homopolymer ...), sort_by_alt_allele_support, multi_allelic_mode,
 read_overlap_buffer_bp, trim_reads_for_pileup, SNP / insertion / deletion candidates with 1-3 alts (some with explicit
 make_examples_alt_allele_indices), candidates at both ends of the contig (N padding), reads listed under several
@@ -56,6 +56,9 @@ def make_case(seed):
     if rng.random() < 0.25:
       so.channels_enum_to_blank = sorted(set(int(enums[int(i)]) for i in rng.integers(0, len(enums), size=int(rng.integers(1, 3)))))
     so.keep_only_window_spanning_reads = bool(rng.random() < 0.15)
+    if rng.random() < 0.2:      # every allele keeps a minimum of its supporters (a threshold too high: uniform again)
+      so.use_non_uniform_downsampling = True
+      so.non_uniform_downsampling_threshold = int(rng.choice([0, 1, 2, 5, 30]))
     samples.append(so)
   order = [int(x) for x in rng.permutation(n_samples)] if rng.random() < 0.5 else list(range(n_samples))
   for so in samples:
