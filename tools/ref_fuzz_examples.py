@@ -126,6 +126,10 @@ def make_alt_case(seed):
   g = _alt_region(mode, ['all', 'indels'][int(rng.integers(0, 2))], bool(rng.random() < 0.3), seed=seed)
   for so in g['options'].sample_options:
     so.order = [0]
+    if rng.random() < 0.3:      # the alt-aligned images sample their own (realigned) read lists
+      so.use_non_uniform_downsampling = True
+      so.non_uniform_downsampling_threshold = int(rng.choice([1, 3, 8]))
+      so.pileup_height = int(rng.choice([so.pileup_height, 12, 20]))
   g['options'].pic_options.multi_allelic_mode = int(rng.choice([T.MultiAllelicMode.ADD_HET_ALT_IMAGES,
                                                                T.MultiAllelicMode.NO_HET_ALT_IMAGES]))
   return dict(options=g['options'], ref=g['ref'], reads=[g['reads']], cands=g['cands'], order=[0], role='main',
