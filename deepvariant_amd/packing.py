@@ -829,6 +829,39 @@ def allele_frequency_pixels(pic_options, dv_call, alt_alleles, table, read_idx
   return out
 
 
+def allele_sample_probability_pixels(dv_call, table, read_idx) -> np.ndarray:
+  """AlleleSampleProbabilityChannel (channels/allele_sample_probability_channel.cc:43-98): the share of the site's
+  reads that support the read's own allele (the reference allele for a read no allele lists), square-rooted.  The
+  reference counts `total_reads` while it walks allele_support -- a proto map -- up to the read's allele, so for a
+  read of any but the first allele its value depends on the map's iteration order, which protobuf leaves
+  unspecified.  Here the alleles are walked in KEY order: what the reference's code does when compiled against an
+  ordered map (oracle/_ref)."""
+  out = np.zeros(len(read_idx), np.uint8)
+  support = dv_call.allele_support
+  alleles = sorted(support)
+  n_ref = len(dv_call.ref_support)
+  for j, r in enumerate(read_idx):
+    key = table.keys[r]
+    total = mine = 0
+    found = False
+    for allele in alleles:
+      names = support[allele].read_names
+      total += len(names)
+      if key in names:
+        mine = len(names)
+        found = True
+        break
+    if not found:
+      mine = n_ref
+    total += n_ref
+    if total == 0:
+      continue
+    value = np.float32(min(max(np.float32(mine), np.float32(0.0)), np.float32(total)))
+    probability = float(np.float32(value) / np.float32(total))       # float division, then double
+    out[j] = int(np.float32(254.0) * np.sqrt(np.float64(probability))) & 0xFF
+  return out
+
+
 def fuzzy_read_supports_alt(dv_call, alt_alleles: Sequence[str], key: str, hp_value: int) -> int:
   """ReadSupportsVariantFuzzyChannel::ReadSupportsAlt
   (channels/read_supports_variant_fuzzy_channel.cc:119-288) for the read `key` with HP tag

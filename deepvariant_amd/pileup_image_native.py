@@ -70,14 +70,10 @@ class PileupImageEncoderNative:
     # (channel of base_aux0, base_aux1, base_aux2) or (): the per-base host-computed channels and the plane each reads
     self._need_seq_aux = packing.seq_aux_planes(self._channel_enums)
     self._need_ref_aux = any(e in packing._REF_AUX_CHANNELS for e in self._channel_enums)
-    if 27 in self._channel_enums:
-      raise NotImplementedError(
-          'allele_sample_probability iterates a proto map in hash order in the '
-          'reference; not reproduced')
     if sum(e in packing._LIST_AUX_CHANNELS for e in self._channel_enums) > 1:
       raise NotImplementedError(
-          'allele_frequency and read_supports_variant_fuzzy in one channel set: the packed '
-          'batch carries one host-computed pixel per (candidate, read)')
+          'allele_frequency / read_supports_variant_fuzzy / allele_sample_probability together in one channel '
+          'set: the packed batch carries one host-computed pixel per (candidate, read)')
     self._encoders: Dict[int, _Encoder] = {}
 
   # ------------------------------------------------------------------ helpers
@@ -104,6 +100,8 @@ class PileupImageEncoderNative:
       return None
     if 25 in self._channel_enums:
       return packing.fuzzy_support_pixels(self._options, dv_call, alt_alleles, table, idx)
+    if 27 in self._channel_enums:      # allele_sample_probability (alleles in key order, see packing)
+      return packing.allele_sample_probability_pixels(dv_call, table, idx)
     return packing.allele_frequency_pixels(self._options, dv_call, alt_alleles,
                                            table, idx)
 

@@ -589,14 +589,22 @@ struct ReadChannels {
       }
       case DVO_CH_ALLELE_SAMPLE_PROBABILITY: {
         // allele_sample_probability_channel.cc:43-75.  NOTE: the reference
-        // iterates a proto map (hash order); the oracle iterates the order it
-        // was given, which is only equivalent when the early `break` cannot
-        // change `total_reads` (single allele, or read in no allele).
+        // iterates a proto map (hash order, unspecified); the oracle walks the
+        // alleles in KEY order -- what the same code does over an ordered map
+        // (the reference build of oracle/ref_build).  The two only have to
+        // agree where the early `break` cannot change `total_reads` (a single
+        // allele, or a read in no allele).
         int total_reads = 0;
         int total_reads_supporting_allele = 0;
         const std::string read_key = ReadKey(*read);
         bool found = false;
-        for (int s = 0; s < call->n_support && !found; ++s) {
+        std::vector<int> order(static_cast<size_t>(call->n_support));
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+          return std::string(call->support_alleles[a]) < call->support_alleles[b];
+        });
+        for (int oi = 0; oi < call->n_support && !found; ++oi) {
+          const int s = order[static_cast<size_t>(oi)];
           const int n0 = call->support_offsets[s];
           const int n1 = call->support_offsets[s + 1];
           total_reads += n1 - n0;

@@ -23,7 +23,7 @@ def query_len(cigar):
 
 
 def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
-              with_mods=False, n_alts=2, fuzzy=False, with_ultima=False):
+              with_mods=False, n_alts=2, fuzzy=False, with_ultima=False, with_ref_support=False):
   hw = (width - 1) // 2
   ref_window = ''.join('ACGTN'[int(i)] for i in rng.choice(5, size=width,
                                                            p=[.24, .24, .24, .24, .04]))
@@ -89,6 +89,8 @@ def make_case(rng, width, n_reads, variant_start=1000, with_hp=False,
     call.rejected_allele_support = {'ACCC': T.SupportingReads(pick(3)),
                                     'ACCCCCCC': T.SupportingReads(pick(2))}
     call.ref_support = pick(4)
+  if with_ref_support and n_reads:
+    call.ref_support = [keys[int(j)] for j in rng.integers(0, n_reads, size=int(rng.integers(0, 9)))]
   combo = [alts[int(j)] for j in sorted(set(rng.integers(0, n_alts, size=int(rng.integers(1, 3))).tolist()))]
   return call, ref_window, reads, variant_start - hw, combo
 
@@ -135,5 +137,12 @@ ULTIMA_CONFIGS = [
     ('ultima_with_sequence_context', ['read_base', 'is_homopolymer', 'homopolymer_deletion_quality', 'base_quality',
                                       'inter_homopolymer_insertion_quality'], 33, 20, {}, dict(with_ultima=True)),
     ('ultima_one_channel', ['homopolymer_insertion_quality', 'read_base'], 21, 12, {}, dict(with_ultima=True)),
+]
+
+# allele_sample_probability (channels/allele_sample_probability_channel.cc): drawn with the alleles in KEY order --
+# what the reference's code does over an ordered map (oracle/_ref); over protobuf's hash map its own output is not a
+# function of its input.  Kept apart like the list above.
+SAMPLE_PROBABILITY_CONFIGS = [
+    ('allele_sample_probability', T.PILEUP_DEFAULT_CHANNELS + ['allele_sample_probability'], 51, 28, {}, dict(n_alts=3, with_ref_support=True)),
 ]
 

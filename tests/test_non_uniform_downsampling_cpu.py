@@ -127,3 +127,31 @@ def test_product_pileups_equal_the_oracle_and_the_reference_build(oracle_drawn_e
     uniform = O.build_pileup(opts, call, ref_window, reads, image_start, combo, pileup_height=height)
     differs_from_uniform += not np.array_equal(got, uniform)
   assert (differs_from_uniform >= 3) if threshold < 40 else (differs_from_uniform == 0)
+
+
+def test_allele_sample_probability_pixels():
+  """channels/allele_sample_probability_channel.cc: the host pixel (packing.allele_sample_probability_pixels, alleles
+  in key order; it travels to the device in list_aux like the allele-frequency pixel) is what the oracle and the
+  reference build draw along the read.  (tests/test_hip_sampling.py compares whole pile-ups on the device.)"""
+  name, channels, width, height, okw, ckw = FZ.SAMPLE_PROBABILITY_CONFIGS[0]
+  opts = FZ.options(channels, width, height, min_bq=0, min_mapq=0)
+  seen = set()
+  n = 0
+  for seed in range(10):
+    rng = np.random.default_rng(300 + seed)
+    call, ref_window, reads, image_start, combo = FZ.make_case(rng, width, int(rng.choice([3, 12, 40])), **dict(ckw))
+    table = packing.ReadTable.from_reads(reads)
+    mine = packing.allele_sample_probability_pixels(call, table, np.arange(len(reads)))
+    for i, r in enumerate(reads):
+      rows = [O.encode_read(opts, call, ref_window, r, image_start, combo, None)]
+      if O.reference_available():
+        with O.reference_backend():
+          rows.append(O.encode_read(opts, call, ref_window, r, image_start, combo, None))
+      for row in rows:
+        if row is None or not row[0, :, 0].any():
+          continue                                         # rejected, or no base inside the window
+        drawn = row[0, :, len(channels) - 1][row[0, :, 0] > 0]
+        assert set(drawn.tolist()) == {int(mine[i])}, (seed, i, drawn.tolist(), int(mine[i]))
+        n += 1
+    seen.update(mine.tolist())
+  assert n > 200 and len(seen) > 8

@@ -67,8 +67,8 @@ def _both(fn):
   return ref, mine
 
 
-@pytest.mark.parametrize('name,channels,width,height,okw,ckw', FZ.CONFIGS + FZ.ULTIMA_CONFIGS,
-                         ids=[c[0] for c in FZ.CONFIGS + FZ.ULTIMA_CONFIGS])
+@pytest.mark.parametrize('name,channels,width,height,okw,ckw', FZ.CONFIGS + FZ.ULTIMA_CONFIGS + FZ.SAMPLE_PROBABILITY_CONFIGS,
+                         ids=[c[0] for c in FZ.CONFIGS + FZ.ULTIMA_CONFIGS + FZ.SAMPLE_PROBABILITY_CONFIGS])
 def test_oracle_equals_the_reference_on_fuzz_inputs(name, channels, width, height, okw, ckw):
   opts = FZ.options(channels, width, height, **dict(okw))
   enums = [O.channel_str_to_enum(c) for c in channels]
