@@ -1,6 +1,6 @@
 """Long differential fuzz: oracle/encoder_oracle.cpp (the restatement) against oracle/_ref/libdvref.so (the reference's
 own encoder sources, compiled unmodified: oracle/ref_build/) over every channel set of tests/fuzz_inputs.py.
-TEST INFRASTRUCTURE, CPU only, needs /root/reference (or a prebuilt oracle/_ref).  `python tools/ref_fuzz.py [seeds]`;
+TEST INFRASTRUCTURE, CPU only, needs /root/reference (or a prebuilt oracle/_ref).  `python tools/ref_fuzz.py [seeds] [config,config...]`;
 the committed test (tests/test_reference_encoder_cpu.py) runs 12 seeds per set, this runs thousands.
 Round 4: 6000 seeds x 8 channel sets = 48,000 pile-ups, 0 differing (profiles/r04_reference_fuzz.txt)."""
 import sys, time
@@ -16,7 +16,11 @@ def both(fn):
   with O.reference_backend():
     r = fn()
   return r, fn()
-for (name, channels, width, height, okw, ckw) in FZ.CONFIGS:
+ALL = FZ.CONFIGS + FZ.ULTIMA_CONFIGS + FZ.SAMPLE_PROBABILITY_CONFIGS      # (the last two lists: round 4)
+ONLY = sys.argv[2].split(',') if len(sys.argv) > 2 else None
+for (name, channels, width, height, okw, ckw) in ALL:
+  if ONLY and name not in ONLY:
+    continue
   opts = FZ.options(channels, width, height, **dict(okw))
   enums = [O.channel_str_to_enum(c) for c in channels]
   for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6000):
@@ -29,6 +33,8 @@ for (name, channels, width, height, okw, ckw) in FZ.CONFIGS:
     blank = [enums[int(rng.integers(0, len(enums)))]] if seed % 4 == 3 else None
     positions = [int(r.alignment.position.position) - int(rng.integers(0, 30)) for r in reads] if seed % 5 == 4 else None
     kw = dict(pileup_height=(height if seed % 3 else 0), mean_coverage=float(rng.integers(0, 60)), alignment_positions=positions, channels_to_blank=blank)
+    if seed % 7 == 6:      # SampleOptions.use_non_uniform_downsampling, thresholds that fit and thresholds that fall back
+      kw['non_uniform_downsampling_threshold'] = int(rng.choice([0, 1, 3, 12, 60]))
     try:
       a, b = both(lambda: O.build_pileup(opts, call, ref_window, reads, image_start, combo, **kw))
     except Exception as e:
