@@ -280,3 +280,84 @@ def test_malformed_aux_blocks_do_not_break_the_decoder(tmp_path):
   with pytest.raises(Exception, match='not a number'):
     packing.ReadTable.from_bam(path, 'chr1', 0, 40000, parse_base_modifications=True)
   assert packing.ReadTable.from_bam(path, 'chr1', 0, 40000).n_reads == 1      # (not asked for: not looked at)
+
+
+def test_methylation_from_a_bam_reaches_the_pixels(tmp_path):
+  """End to end on the CPU: MM / ML tags in a BAM -> the native decoder's 5mC plane -> the packed batch of a calling
+  region (table path: no Read objects) -> pile-ups with the base_methylation channel.  The device encoder is replaced
+  by the oracle's packed adapter (no GPU here); the expectation is drawn by the oracle -- and by the reference build --
+  from Read objects whose base_modifications the PYTHON restatement parsed."""
+  from deepvariant_amd import make_examples_native as men
+  from oracle import oracle as O
+  from tests import fuzz_inputs as FZ
+  from tests.test_reference_examples_cpu import OracleDeviceEncoder
+  rng = np.random.default_rng(12)
+  L = 600
+  ref_seq = ''.join('ACGT'[int(i)] for i in rng.integers(0, 4, size=L))
+
+  class Ref:
+    def n_bases(self, contig):
+      return L
+
+    def get_bases(self, contig, start, end):
+      return ref_seq[start:end]
+
+  reads = []
+  for k in range(90):
+    n = int(rng.integers(60, 140))
+    start = int(rng.integers(150, 330))
+    seq = list(ref_seq[start:start + n])
+    for _ in range(3):
+      seq[int(rng.integers(0, n))] = 'ACGT'[int(rng.integers(0, 4))]
+    seq = ''.join(seq)
+    reverse = bool(rng.integers(0, 2))
+    strand_seq = seq[::-1].translate(str.maketrans('ACGT', 'TGCA')) if reverse else seq
+    n_c = strand_seq.count('C')
+    info = {}
+    if n_c >= 2 and rng.random() < 0.8:
+      cnt = int(rng.integers(1, n_c + 1))
+      info['MM'] = 'C+m?,' + ','.join('0' for _ in range(cnt)) + ';'
+      info['ML'] = [int(v) for v in rng.integers(1, 256, size=cnt)]
+    r = _read(seq, name='m%03d' % k, start=start, reverse=reverse, info=info)
+    r.aligned_quality = bytes(rng.integers(20, 41, size=n).astype(np.uint8))
+    reads.append(r)
+  path = str(tmp_path / 'meth.bam')
+  gio.write_bam(path, [('chr1', L)], reads)
+  channels = list(T.PILEUP_DEFAULT_CHANNELS) + ['base_methylation']
+  width, height = 41, 40
+  pic = FZ.options(channels, width, height, min_mapq=0)
+  pic.num_channels = len(channels)
+  options = T.MakeExamplesOptions(pic_options=pic, sample_options=[
+      T.SampleOptions(role='main', name='s', pileup_height=height, order=[0])])
+  table = packing.ReadTable.from_bam(path, 'chr1', 0, L, parse_base_modifications=True)
+  assert table.n_reads == len(reads) and (table.read_flags & packing.DV_READ_HAS_5MC).sum() > 40
+  _, py_reads = gio.read_bam(path, 'chr1', aux_fields=('MM', 'ML', 'MN'))
+  cands = []
+  for pos in (230, 260, 290, 320):
+    refb = ref_seq[pos]
+    alt = [b for b in 'ACGT' if b != refb][0]
+    near = [r for r in reads if r.alignment.position.position <= pos < r.alignment.position.position + len(r.aligned_sequence)]
+    cands.append(T.DeepVariantCall(variant=T.Variant('chr1', pos, pos + 1, refb, [alt]),
+                                   allele_support={alt: T.SupportingReads(['%s/0' % r.fragment_name for r in near[::3]])}))
+  gen = men.ExamplesGenerator(options, {}, test_mode=True, ref_reader=Ref())
+  gen._device_encoder = OracleDeviceEncoder(pic)       # pylint: disable=protected-access
+  examples, shape = gen.encode_region(cands, [table], [0], [0.0], {}, role='main')
+  assert shape == [height, width, len(channels)] and len(examples) == len(cands)
+  from deepvariant_amd import protowire as pw
+  hw = (width - 1) // 2
+  meth = 0
+  for ex, cand in zip(examples, cands):
+    img = np.frombuffer(pw.decode_example(ex)['image/encoded'][0], np.uint8).reshape(shape)
+    v = cand.variant
+    overlapping = [r for r in py_reads                      # (file order: what InMemoryReader::Query yields)
+                   if r.alignment.position.position < v.end + 5 and
+                   r.alignment.position.position + len(r.aligned_sequence) > v.start - 5]
+    window = ref_seq[v.start - hw:v.start + hw + 1]
+    want = O.build_pileup(pic, cand, window, overlapping, v.start - hw, list(v.alternate_bases), pileup_height=height)
+    assert np.array_equal(img, want), v.start
+    if O.reference_available():
+      with O.reference_backend():
+        assert np.array_equal(img, O.build_pileup(pic, cand, window, overlapping, v.start - hw, list(v.alternate_bases),
+                                                  pileup_height=height)), v.start
+    meth += int((img[5:, :, len(channels) - 1] > 0).sum())
+  assert meth > 200
