@@ -8,7 +8,7 @@ tests/test_hip_reference_examples.py).  TEST INFRASTRUCTURE.
 
 What varies per case: window width, 1-3 samples with their own heights / read sets / channels_enum_to_blank /
 keep_only_window_spanning_reads / use_non_uniform_downsampling, the sample order and the role, the channel list (insert_size, haplotype + HP tags with
-sort_by_haplotypes, mean_coverage, blank, is_homopolymer ...), sort_by_alt_allele_support, multi_allelic_mode,
+sort_by_haplotypes, mean_coverage, blank, is_homopolymer, base_methylation / base_6ma with per-base modification bytes ...), sort_by_alt_allele_support, multi_allelic_mode,
 read_overlap_buffer_bp, trim_reads_for_pileup, SNP / insertion / deletion candidates with 1-3 alts (some with explicit
 make_examples_alt_allele_indices), candidates at both ends of the contig (N padding), reads listed under several
 alleles, under none, under alleles of other candidates.
@@ -35,7 +35,8 @@ def make_case(seed):
   with_hp = False
   for extra, p in (('insert_size', .5), ('haplotype', .3), ('mean_coverage', .3), ('blank', .15),
                    ('is_homopolymer', .15), ('homopolymer_weighted', .15), ('gc_content', .15),
-                   ('supplementary_alignment', .2), ('read_mapping_percent', .15), ('avg_base_quality', .15)):
+                   ('supplementary_alignment', .2), ('read_mapping_percent', .15), ('avg_base_quality', .15),
+                   ('base_methylation', .15), ('base_6ma', .1)):
     if rng.random() < p and len(channels) < 12:
       channels.append(extra)
       with_hp |= extra == 'haplotype'
@@ -72,6 +73,10 @@ def make_case(seed):
     for r in rs:
       if 'avg_base_quality' in channels:
         r.aligned_quality = bytes(min(q, 93) for q in r.aligned_quality)
+      if 'base_methylation' in channels and rng.random() < 0.6:
+        r.base_modifications[T.K5MC] = bytes(rng.integers(0, 256, size=len(r.aligned_sequence)).astype(np.uint8))
+      if 'base_6ma' in channels and rng.random() < 0.6:
+        r.base_modifications[T.K6MA] = bytes(rng.integers(0, 256, size=len(r.aligned_sequence)).astype(np.uint8))
       if with_hp and rng.random() < 0.6:
         r.info['HP'] = T.ListValue(values=[T.Value(int_value=int(rng.integers(0, 3)))])
       r.alignment.position.position = max(0, r.alignment.position.position)
