@@ -55,6 +55,8 @@ def parse_args():
   ap.add_argument('--procs', type=int, default=1,
                   help="--mode bam: host processes sharing the GPU (make_examples --ranks_per_gpu)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-workloads', action='store_true',
+                  help='skip the hifi35 / ont50 lines the default 1-GPU run attaches as "workloads"')
   ap.add_argument('--parity-sites', type=int, default=4096,
                   help='sites of the timed batch checked against the oracle after the timed region')
   ap.add_argument('--cpu-sample', type=int, default=0,

@@ -43,6 +43,7 @@
 #include "imgconv.h"
 #include "chain.h"
 #include "stem_fused.h"
+#include "calib.h"
 
 using namespace dv::convk;
 
@@ -1387,6 +1388,7 @@ struct dv_model {
   dv::DeviceBuffer d_blank_thr;   // int32 [4][max_batch], blank_rows_kernel
   dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output for the all-blank image (one example)
   bool loaded = false;
+  std::vector<float> h_shift, h_dense_b;   // as computed by dv_model_load_weights (before any calibration)
   dv::DeviceBuffer d_ext;         // ExtPtrs: the caller's image / probability pointers of the running forward
   struct GraphEntry {
     int n;
@@ -2904,7 +2906,92 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
                          hipMemcpyHostToDevice));
   DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dw + static_cast<size_t>(dl.cin) * dl.cout,
                          dl.cout * 4, hipMemcpyHostToDevice));
+  m->h_shift = shift;
+  m->h_dense_b.assign(dw + static_cast<size_t>(dl.cin) * dl.cout, dw + static_cast<size_t>(dl.cin) * dl.cout + dl.cout);
   m->loaded = true;
+  return prepare_blank_responses(m);
+}
+
+// Shift calibration (include/dvhip.h, csrc/calib.h): the op list as a plan of plain NHWC tensors --
+// fused pools unfolded (pool_in / pool_out), LDS-only tensors given their real size -- run through
+// the two fp32 pipelines; shifts and the Dense bias move by the mean differences.
+int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images, int n_images,
+                       float* corrections, int64_t capacity) {
+  if (!m || !weights || !images) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: null");
+  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: load weights first");
+  if (n_weights != m->n_params) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: wrong number of weights");
+  if (n_images < 1 || n_images > 4096) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: 1..4096 images");
+  dv::CalibPlan plan;
+  plan.bufs.resize(m->buffers.size());
+  for (size_t b = 0; b < m->buffers.size(); ++b) plan.bufs[b] = {m->buffers[b].h, m->buffers[b].w, m->buffers[b].c};
+  plan.bufs[0] = {m->desc.height, m->desc.width, m->desc.channels};
+  for (const Op& op : m->ops) {
+    dv::CalibOp c{};
+    c.type = op.type == kOpConv ? 0 : op.type == kOpMaxPool ? 1 : 2;
+    c.in_buf = op.in_buf;
+    c.out_buf = op.out_buf;
+    c.out_coff = op.out_coff;
+    c.shift_off = -1;
+    int oh = op.oh, ow = op.ow;
+    if (op.type == kOpConv) {
+      c.pool_in = op.pool_in;
+      c.pool_out = op.pool_out;
+      c.kh = op.kh;
+      c.kw = op.kw;
+      c.stride = op.stride;
+      c.pad_h = op.pad_h;
+      c.pad_w = op.pad_w;
+      c.cin = op.cin_real;
+      c.cout = op.cout;
+      c.w_off = m->layers[op.layer].param_off;
+      c.raw = op.raw;
+      c.shift_off = static_cast<int64_t>(op.shift_off);
+      c.split = op.split_rows;
+      if (op.pool_in) {   // op.ih / op.iw: the tensor as stored, before the on-the-fly pool
+        plan.bufs[op.in_buf].h = op.ih;
+        plan.bufs[op.in_buf].w = op.iw;
+      }
+      if (op.pool_out) {
+        oh = (oh - 3) / 2 + 1;
+        ow = (ow - 3) / 2 + 1;
+      }
+    } else if (op.type == kOpAvgPool) {
+      c.shift_relu = op.pool_shift_relu;
+      if (op.pool_shift_relu) c.shift_off = static_cast<int64_t>(op.shift_off);
+      c.cout = op.cout;
+    } else {
+      c.cout = op.cout;
+    }
+    plan.bufs[op.out_buf].h = oh;   // LDS-only tensors of the fused kernels are 1 x 1 in `buffers`
+    plan.bufs[op.out_buf].w = ow;
+    plan.ops.push_back(c);
+  }
+  plan.feat_buf = m->feat_buf;
+  plan.num_classes = m->desc.num_classes;
+  plan.dense_off = m->layers.back().param_off;
+  std::vector<float> corr, dense_corr;
+  if (int rc = dv::run_calibration(plan, m->device, weights, n_weights, m->h_shift, images, n_images, &corr,
+                                   &dense_corr)) {
+    return rc;
+  }
+  std::vector<float> shift = m->h_shift, dense_b = m->h_dense_b;
+  for (size_t i = 0; i < shift.size(); ++i) shift[i] -= corr[i];
+  for (size_t k = 0; k < dense_b.size(); ++k) dense_b[k] -= dense_corr[k];
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  DV_HIP_CHECK(hipDeviceSynchronize());
+  DV_HIP_CHECK(hipMemcpy(m->d_shift.ptr, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dense_b.data(), dense_b.size() * 4, hipMemcpyHostToDevice));
+  if (corrections != nullptr) {
+    int64_t at = 0;
+    std::vector<const Op*> by_layer(m->layers.size(), nullptr);
+    for (const Op& op : m->ops) {
+      if (op.type == kOpConv) by_layer[op.layer] = &op;
+    }
+    for (size_t l = 0; l + 1 < m->layers.size(); ++l) {
+      for (int co = 0; co < by_layer[l]->cout && at < capacity; ++co) corrections[at++] = corr[by_layer[l]->shift_off + co];
+    }
+    for (size_t k = 0; k < dense_corr.size() && at < capacity; ++k) corrections[at++] = dense_corr[k];
+  }
   return prepare_blank_responses(m);
 }
 

@@ -61,6 +61,24 @@ class InceptionV3(torch.nn.Module):
                                                 flat.size))
     self.flat_weights = flat
 
+  def calibrate(self, images: torch.Tensor) -> np.ndarray:
+    """dv_model_calibrate: moves every layer's fp32 shift by the per-channel mean of the fp16
+    pipeline's error on `images` (CUDA uint8 [N,H,W,C], a few hundred examples drawn like the inputs
+    the model will see).  Needs the weights given to load_flat_weights.  Returns the corrections
+    (cout values per conv layer in layer order, then the logit corrections)."""
+    if self.flat_weights is None:
+      raise ValueError('calibrate() needs load_flat_weights() first')
+    if images.dtype != torch.uint8 or not images.is_cuda or tuple(images.shape[1:]) != self.input_shape:
+      raise ValueError('images must be a CUDA uint8 tensor [N, %d, %d, %d]' % self.input_shape)
+    images = images.contiguous()
+    n_corr = sum(co for _, _, _, co, _ in self.layer_table())
+    corr = np.zeros(n_corr, np.float32)
+    torch.cuda.synchronize(images.device)
+    _lib.check(_lib.lib().dv_model_calibrate(
+        self._handle, self.flat_weights.ctypes.data, self.flat_weights.size, images.data_ptr(),
+        images.shape[0], corr.ctypes.data, corr.size))
+    return corr
+
   def init_random(self, seed: int = 0):
     """Seeded He-normal kernels / randomised BN statistics (no checkpoint is
     available offline; the reference's own tests do the same,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 6
+#define DV_ABI_VERSION 7
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -750,6 +750,24 @@ int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
  * fp16 in the MFMA fragment layout and uploads.  `weights` is host memory.
  * Replaces model.load_weights (deepvariant/call_variants.py:759-762). */
 int dv_model_load_weights(dv_model* m, const float* weights, int64_t n);
+
+/* Shift calibration (ABI v7; optional, after dv_model_load_weights with the SAME `weights`).
+ * The classifier multiplies fp16 weights by fp16 activations where the reference computes in float32
+ * (deepvariant/call_variants.py:913-918).  Both roundings have a per-channel MEAN (the weight
+ * error is one fixed draw multiplying activations that are far from zero-mean; constant map regions
+ * round identically everywhere); this call measures it on `n_images` example images -- two fp32
+ * pipelines on the device, one exact, one with the MFMA kernels' roundings, walked layer by layer
+ * (csrc/calib.h) -- and moves each layer's fp32 shift (and the Dense bias) by the difference of the
+ * per-channel pre-activation means.  No run-time cost; deterministic for given weights and images;
+ * calling it again replaces the previous correction.  Any batch drawn like the inputs the model
+ * will see serves (a few hundred pile-ups; tests use OTHER images than the ones they check).
+ *   weights  host, the array given to dv_model_load_weights
+ *   images   device uint8 [n_images, height, width, channels]
+ *   corrections  optional host array [capacity]: the shift corrections in layer order (cout values per
+ *                convolution), then num_classes logit corrections; for tests and reports
+ * The reference has no counterpart: it keeps float32 end to end. */
+int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images,
+                       int n_images, float* corrections, int64_t capacity);
 
 /* preprocess_images ((x-128)/128, deepvariant/dv_utils.py:343-366) + model
  * forward + softmax (deepvariant/call_variants.py:904-932).

@@ -53,7 +53,33 @@ class ConvBN(nn.Module):
     nn.init.ones_(self.bn.weight)
 
   def forward(self, x):
+    if ConvBN.as_gemm:
+      return self._forward_gemm(x)
     return F.relu(self.bn(self.conv(x)))
+
+  # The same fp32 arithmetic written as im2col + matmul and an explicit BN: what the large-N
+  # tests run on the GPU (tests/cnn_tail.py).  torch's conv2d on ROCm goes through MIOpen,
+  # which compiles its solvers on first use on a fresh box (minutes); unfold / matmul / pooling
+  # are precompiled ATen + rocBLAS kernels.  Checked against forward() above by
+  # tests/test_cnn_oracle_gemm_cpu.py (CPU) and tests/test_hip_cnn_tail.py (GPU vs CPU).
+  as_gemm = False
+
+  def _forward_gemm(self, x):
+    n, c, h, w = x.shape
+    co, ci, kh, kw = self.conv.weight.shape
+    sh, sw = self.conv.stride
+    ph, pw = self.conv.padding
+    oh = (h + 2 * ph - kh) // sh + 1
+    ow = (w + 2 * pw - kw) // sw + 1
+    if kh == 1 and kw == 1 and sh == 1 and sw == 1:
+      cols = x.reshape(n, c, h * w)
+    else:
+      cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))
+    y = torch.matmul(self.conv.weight.reshape(co, ci * kh * kw), cols).reshape(n, co, oh, ow)
+    inv = 1.0 / torch.sqrt(self.bn.running_var + self.bn.eps)
+    y = (y - self.bn.running_mean[None, :, None, None]) * (inv * self.bn.weight)[None, :, None, None] \
+        + self.bn.bias[None, :, None, None]
+    return F.relu(y)
 
 
 def _avgpool(x):

@@ -1,0 +1,104 @@
+"""dv_model_calibrate (include/dvhip.h, deepvariant_amd/csrc/calib.hip) on the GPU: the native two-pipeline
+walk against its torch restatement (tests/calib_emulation.py), determinism, and what it buys against the fp32
+oracle on pileups it was NOT calibrated on."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(shape, n, seed):
+  import cnn_tail as T
+  if shape == (100, 221, 7):
+    return T.illumina_pileups_gpu(n, seed=seed, chunk=4096)
+  return T.longread_images_gpu('hifi' if shape[2] == 10 else 'ont', n, seed=seed)
+
+
+def _model(shape, weights, max_batch):
+  from deepvariant_amd.inception_v3 import InceptionV3
+  m = InceptionV3(shape, max_batch=max_batch)
+  m.load_flat_weights(weights)
+  return m
+
+
+@pytest.mark.parametrize('shape', [(100, 221, 7), (100, 147, 10)])
+def test_native_corrections_equal_the_torch_restatement(shape):
+  import calib_emulation as E
+  from oracle import inception_ref as R
+  ref = R.make_random_model(shape[2], seed=23)
+  x = _images(shape, 48, seed=515)
+  m = _model(shape, ref.export_flat(), 64)
+  got = m.calibrate(x)
+  torch.set_num_threads(min(64, os.cpu_count() or 1))
+  want = E.corrections(ref, x.cpu())
+  assert got.shape == want.shape
+  rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+  print('%s: |corr| rms %.3g, max %.3g; native vs torch restatement: relative L2 difference %.3g, max abs %.3g' % (
+      shape, float(np.sqrt((want ** 2).mean())), float(np.abs(want).max()), rel, float(np.abs(got - want).max())))
+  assert np.isfinite(got).all()
+  assert rel <= 0.05, rel
+
+
+def test_calibration_is_deterministic_and_replaces_the_previous_one():
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  ref = R.make_random_model(7, seed=31)
+  x = _images(shape, 96, seed=616)
+  m = _model(shape, ref.export_flat(), 96)
+  p0 = m(x).cpu().numpy()
+  a = m.calibrate(x[:64])
+  p1 = m(x).cpu().numpy()
+  b = m.calibrate(x[:64])
+  p2 = m(x).cpu().numpy()
+  assert np.array_equal(a, b)
+  assert np.array_equal(p1, p2)          # a second calibration starts from the loaded shifts again
+  assert not np.array_equal(p0, p1)
+  assert np.abs(p0 - p1).max() < 5e-3
+
+
+@pytest.mark.parametrize('seed', [17, 404])
+def test_calibrated_model_is_closer_to_the_fp32_oracle_on_other_pileups(seed):
+  import cnn_tail as T
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  n = 4096
+  ref = R.make_random_model(7, seed=seed)
+  ref_gpu = R.make_random_model(7, seed=seed).cuda()
+  x = _images(shape, n, seed=7000 + seed)
+  want = T.oracle_probs_gpu(ref_gpu, x)
+  old = os.environ.get('DV_SPLIT_FROM')
+  os.environ['DV_SPLIT_FROM'] = '94'     # plain fp16 weights in every layer
+  try:
+    m = _model(shape, ref.export_flat(), n)
+  finally:
+    os.environ.pop('DV_SPLIT_FROM', None)
+    if old is not None:
+      os.environ['DV_SPLIT_FROM'] = old
+  before = T.tail_stats(m(x).cpu().numpy(), want)
+  m.calibrate(_images(shape, 256, seed=880000 + seed))
+  after = T.tail_stats(m(x).cpu().numpy(), want)
+  print('seed %d uncalibrated: %s' % (seed, T.fmt(before)))
+  print('seed %d calibrated:   %s' % (seed, T.fmt(after)))
+  assert after['mean_abs_dp'] <= 0.9 * before['mean_abs_dp'], (before, after)
+  assert after['max_abs_dp'] <= 1e-3, after
+
+
+def test_calibrate_argument_errors():
+  import ctypes as C
+  from deepvariant_amd import _lib
+  from deepvariant_amd.inception_v3 import InceptionV3
+  m = InceptionV3((100, 221, 7), max_batch=8)
+  x = torch.zeros((4, 100, 221, 7), dtype=torch.uint8, device='cuda')
+  with pytest.raises(ValueError):
+    m.calibrate(x)                        # no weights yet
+  w = np.zeros(m.num_params, np.float32)
+  rc = _lib.lib().dv_model_calibrate(m._handle, w.ctypes.data, w.size, x.data_ptr(), 4, None, 0)
+  assert rc == _lib.DV_ERR_INVALID_ARGUMENT and b'load weights first' in _lib.lib().dv_last_error()
+  m.init_random(seed=3)
+  rc = _lib.lib().dv_model_calibrate(m._handle, w.ctypes.data, w.size - 1, x.data_ptr(), 4, None, 0)
+  assert rc == _lib.DV_ERR_INVALID_ARGUMENT
+  with pytest.raises(ValueError):
+    m.calibrate(x.cpu())
