@@ -55,6 +55,8 @@ def parse_args():
   ap.add_argument('--procs', type=int, default=1,
                   help="--mode bam: host processes sharing the GPU (make_examples --ranks_per_gpu)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--calibration-images', type=int, default=256,
+                  help='examples (of another synthetic seed) dv_model_calibrate sees before the timed region; 0 = off')
   ap.add_argument('--no-workloads', action='store_true',
                   help='skip the hifi35 / ont50 lines the default 1-GPU run attaches as "workloads"')
   ap.add_argument('--parity-sites', type=int, default=4096,
@@ -203,6 +205,7 @@ def run_rank(args, rank, local_rank, world):
   model = InceptionV3((H, W, C), max_batch=min(n_items, 8192),
                       device=local_rank)
   model.init_random(seed=1234)          # same weights on every rank
+  calibration = calibrate_model(model, args, lambda n, seed: illumina_calibration_images(n, seed, opts, enc, C, dev))
   images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)
   rows = torch.empty(n_items, dtype=torch.int32, device=dev)
   ids = (torch.arange(n_items, device=dev, dtype=torch.int64) +
@@ -323,9 +326,22 @@ def run_rank(args, rank, local_rank, world):
         },
         'other_kernels_ms_per_step': other_ms / args.steps,
     }
+    out['calibration'] = calibration
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(host_batch, opts, C, args.cpu_sample)
       out['parity'] = parity_sample(region, opts, C, model, images, probs, n=args.parity_sites)
+      out['parity'].update(cnn_tail_parity(model, C, images, probs))
+    if world == 1 and not args.no_workloads:
+      # BASELINE configs[3], configs[4]: the long-read shapes, timed after the headline with the same
+      # K / W, attached to the ONE line (the headline `value` / `config` stay ILLUMINA30)
+      out['workloads'] = {}
+      for w in ('hifi35', 'ont50'):
+        sub = argparse.Namespace(**vars(args))
+        sub.workload = w
+        full = longread_bench(sub, dev, local_rank, emit=False)
+        out['workloads'][w] = {k: full[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline',
+                                                    'roofline_encoder', 'other_kernels_ms_per_step', 'calibration',
+                                                    'parity') if k in full}
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
@@ -695,7 +711,7 @@ def make_longread_workload(kind, n, seed=None):
   return opts, batch, with_alt, c_enc, Ct
 
 
-def longread_bench(args, dev, local_rank):
+def longread_bench(args, dev, local_rank, emit=True):
   """`--workload hifi35 | ont50`: the long-read shapes of SURVEY.md 8(d) / BASELINE configs[3], [4] through
   the same two entry points, one JSON line each (never the contract's `value`).
 
@@ -724,6 +740,7 @@ def longread_bench(args, dev, local_rank):
   enc = _Encoder(opts, W, device=local_rank)
   model = InceptionV3((H, W, Ct), max_batch=n, device=local_rank)
   model.init_random(seed=1234)
+  calibration = calibrate_model(model, args, lambda m, seed: longread_calibration_images(kind, m, seed, dev))
   flat = torch.zeros(n_images * img_bytes, dtype=torch.uint8, device=dev)
   images = flat[:n * img_bytes].view(n, H, W, Ct)
   rows = torch.empty(n_images, dtype=torch.int32, device=dev)
@@ -794,9 +811,13 @@ def longread_bench(args, dev, local_rank):
       },
       'other_kernels_ms_per_step': other_ms / args.steps,
   }
+  out['calibration'] = calibration
   if not args.no_cpu_baseline:
     out['parity'] = longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs)
-  print(json.dumps(out))
+    out['parity'].update(cnn_tail_parity(model, Ct, images, probs))
+  if emit:
+    print(json.dumps(out))
+  return out
 
 
 def longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs, sample=192):
@@ -914,6 +935,69 @@ def parity_sample(region, opts, C, model, images, probs, n=512):
   }
 
 
+def illumina_calibration_images(n, seed, opts, enc, C, dev):
+  """n ILLUMINA30 pileups drawn by the HIP encoder from ANOTHER synthetic seed than the timed batch."""
+  from deepvariant_amd import synth
+  batch = synth.make_illumina_batch(n, seed=seed, options=opts, multi_allelic=False)
+  img, _ = enc.encode(batch, C)
+  return torch.from_numpy(np.ascontiguousarray(img.reshape(-1, opts.height, opts.width, C)[:n])).to(dev)
+
+
+def longread_calibration_images(kind, n, seed, dev):
+  """n examples of the long-read workload from another seed: encoder + dv_merge_alt_channels, as in the step."""
+  import ctypes as CT
+  from deepvariant_amd import _lib
+  from deepvariant_amd.device_batch import DeviceBatch
+  from deepvariant_amd.pileup_image_native import _Encoder
+  opts, batch, with_alt, c_enc, Ct = make_longread_workload(kind, n, seed=seed)
+  H, W = opts.height, opts.width
+  img_bytes = H * W * Ct
+  entries = (_lib.DvAltMergeEntry * max(len(with_alt), 1))()
+  for k, i in enumerate(with_alt):
+    entries[k].example, entries[k].first_row, entries[k].rows = i, 0, H
+    entries[k].scratch_alt1, entries[k].scratch_alt2 = 2 * k, 2 * k + 1
+  flat = torch.zeros(batch.n_items * img_bytes, dtype=torch.uint8, device=dev)
+  rows = torch.empty(batch.n_items, dtype=torch.int32, device=dev)
+  DeviceBatch(batch, dev).encode(_Encoder(opts, W, device=dev.index or 0), Ct, flat, rows)
+  _lib.check(_lib.lib().dv_merge_alt_channels(flat.data_ptr(), n * img_bytes, img_bytes, img_bytes, W, Ct, c_enc, 5,
+                                              entries, len(with_alt),
+                                              CT.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+  torch.cuda.synchronize(dev)
+  return flat[:n * img_bytes].view(n, H, W, Ct).clone()
+
+
+def calibrate_model(model, args, draw):
+  """dv_model_calibrate on `--calibration-images` examples of another synthetic seed (model preparation, once per
+  set of weights, before the timed region; --calibration-images 0 = the uncalibrated fp16 model)."""
+  n = args.calibration_images
+  if n <= 0:
+    return {'images': 0}
+  t0 = time.perf_counter()
+  x = draw(n, 515151)
+  t1 = time.perf_counter()
+  corr = model.calibrate(x)
+  return {'images': n, 'seed': 515151, 'seconds': time.perf_counter() - t1, 'draw_seconds': t1 - t0,
+          'max_abs_shift_correction': float(np.abs(corr).max()),
+          'what': 'per-channel mean of the fp16 pipeline error moved into the fp32 shifts (dv_model_calibrate)'}
+
+
+def cnn_tail_parity(model, C, images, probs, check=64):
+  """|dp| over EVERY candidate of the timed batch: the fp32 oracle run on the GPU through torch-ROCm (its im2col +
+  matmul form, oracle/inception_gpu.py), after that run has been compared with the CPU oracle on `check` images."""
+  from oracle import inception_gpu as G, inception_ref
+  ref = inception_ref.InceptionV3(C)
+  ref.load_flat(model.flat_weights)
+  ref_gpu = inception_ref.InceptionV3(C)
+  ref_gpu.load_flat(model.flat_weights)
+  ref_gpu = ref_gpu.to(images.device)
+  agree = G.check_gpu_oracle(ref, ref_gpu, images, n=check)
+  st = G.tail_stats(probs.cpu().numpy(), G.oracle_probs_gpu(ref_gpu, images))
+  return {'all_candidates': st['n'], 'max_abs_dp_all': st['max_abs_dp'], 'mean_abs_dp_all': st['mean_abs_dp'],
+          'p999_abs_dp': st['p999_abs_dp'], 'p9999_abs_dp': st['p9999_abs_dp'], 'n_over_tol': st['n_over_tol'],
+          'gpu_oracle_vs_cpu_oracle_max_abs_dp': agree, 'gpu_oracle_checked_on': check,
+          'ok_all': bool(st['max_abs_dp'] <= 1e-3)}
+
+
 CONV_KERNELS = ('conv_mfma_kernel', 'conv_resident_kernel', 'conv_pool1x1_kernel', 'conv_first_u8_kernel',
                 'stem_a_kernel', 'stem_b_kernel', 'imgconv_kernel', 'chain_kernel')
 
@@ -931,8 +1015,8 @@ def _pmc_pass(counter, args, timeout_s=300):
   try:
     env = dict(os.environ, TMPDIR='/tmp', DV_BENCH_NO_PMC='1')
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '--', sys.executable,
-           os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
-           '--batch', str(args.batch), '--channels', str(args.channels)]
+           os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-workloads',
+           '--calibration-images', '0', '--batch', str(args.batch), '--channels', str(args.channels)]
     subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dbs = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)

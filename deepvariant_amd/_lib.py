@@ -121,6 +121,7 @@ class DvBatch(C.Structure):
       ('base_aux0', C.c_void_p), ('base_aux1', C.c_void_p),
       ('ref_aux0', C.c_void_p), ('ref_aux1', C.c_void_p), ('ref_aux2', C.c_void_p),
       ('base_aux2', C.c_void_p),        # ABI v6
+      ('max_cigar_ops', C.c_uint32), ('max_item_height', C.c_uint32),   # ABI v7: LDS sizing hints, 0 = unknown
   ]
 
 

@@ -9,6 +9,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "wave_prio.h"
+
 namespace dv {
 namespace convk {
 
@@ -40,6 +42,9 @@ struct ConvBranch {
   int Cout;
   int relu;
   int sub0;               // first 32-cout subtile of this branch in the launch's cout space
+  // AveragePooling2D(3, 1, 'same') of this branch's RAW outputs in the launch's epilogue (ConvArgs::tile_g):
+  // out / og / out_goff / shift / relu then describe the POOLED tensor (model.hip choose_avg_epilogue)
+  int avgpool;
 };
 
 constexpr int kMaxBranches = 4;
@@ -100,6 +105,15 @@ struct ConvArgs {
   _Float16* side_pool_out;   // NULL = off
   TensorGeom side_pool_og;
   int side_pool_goff;        // first destination group (channel offset / 8) in the concat buffer
+  // Image-aligned pixel tiles (tile_g > 0; conv_mfma_kernel<..., AVG>): a 256-pixel block holds tile_g WHOLE
+  // maps of tile_p = OH*OW pixels (slots past tile_g * tile_p idle), so that a branch's 3x3 average pool
+  // (ConvBranch::avgpool: the pooled projection of an Inception block, evaluated as conv -> pool) never
+  // leaves the block: raw outputs go to LDS as fp16, are averaged there, shifted, clamped and stored --
+  // the raw tensor and the avg-pool launch disappear.  grid = ceil(N / tile_g) * n_tiles.
+  int tile_g, tile_p;
+  float rcp_tile_p;
+  // wave_prio.h: 0 = off, else the asymmetric-priority mode the kernel starts with (set by the launchers)
+  int prio;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
@@ -119,6 +133,15 @@ __device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, in
     r -= d;
     ++q;
   }
+}
+
+// The arithmetic of one average-pool output channel, shared by avgpool3s1_kernel (model.hip) and the
+// pooling epilogue below so that both round alike: three column sums (each top + middle + bottom, zeros
+// outside the map), left to right, times 1 / (cells inside), then shift + ReLU when the pool carries them.
+__device__ __forceinline__ _Float16 avg_finish(float c0, float c1, float c2, float inv, float sh, bool shift_relu) {
+#pragma clang fp contract(off)   // never (sum * inv + sh) as one fma in one kernel and two roundings in the other
+  const float v = (c0 + c1 + c2) * inv;
+  return static_cast<_Float16>(shift_relu ? fmaxf(v + sh, 0.f) : v);
 }
 
 // Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
@@ -196,6 +219,145 @@ __device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], co
           outp[obase + static_cast<unsigned>(group) * gstride] = piece;
         }
       }
+    }
+  }
+}
+
+// Epilogue of conv_mfma_kernel<..., AVG>: branches without `avgpool` store as conv_epilogue does; the others
+// leave their RAW fp16 outputs in LDS (the weight slabs' space: NB*32 couts x 256 pixel slots x 2 bytes =
+// both slabs exactly), [subtile nb][8-cout group q][pixel slot][8 halfs], and after one barrier every thread
+// averages the 3x3 neighbourhood of ITS pixel slot (the block holds whole maps, ConvArgs::tile_g) for
+// the 4 groups of each pooled subtile: avgpool3s1_kernel's arithmetic (avg_finish), shift, ReLU, one
+// 16-byte store per group into the pooled tensor.  Bit-identical to conv -> avgpool3s1_kernel.
+template <int NB, int PT>
+__device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT], const ConvArgs& p, int n_tile,
+                                                  int pix_block, const int (&pn)[PT], const int (&poh)[PT],
+                                                  const int (&pow_)[PT], const bool (&mvalid)[PT], int lane,
+                                                  int wave, _Float16* smem) {
+  static_assert(PT == 2, "256-pixel blocks");
+  const int hi = lane >> 5;
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+  uint4_t* tile = reinterpret_cast<uint4_t*>(smem);
+  __syncthreads();   // every wave has read its last weight fragment: the slabs become the pooling tile
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int sub = n_tile * NB + nb;
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
+    const ConvBranch& b = p.br[bi];
+    const int cbase = (sub - b.sub0) * 32;
+    if (cbase >= b.Cout) continue;
+    const bool pooled = b.avgpool != 0;   // block-uniform
+    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+    float2_t shv[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+      if (b.shift != nullptr && !pooled) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(b.shift + (cbase + 8 * q)));
+        const f4_t l4 = sp[0], u4 = sp[1];
+        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
+      }
+      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
+      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const float16_t a = acc[nb][pt];
+      const unsigned obase = static_cast<unsigned>(
+          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp + pow_[pt] + b.og.halo);
+      const int slot = (wave * PT + pt) * 32 + (lane & 31);
+      unsigned pk[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
+          half2_t h = __builtin_convertvector(v, half2_t);
+          if (b.relu && !pooled) h = __builtin_elementwise_max(h, zero2);
+          pk[q][hq] = __builtin_bit_cast(unsigned, h);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+        const int q8 = 2 * t + hi;            // 8-cout group within the subtile
+        const int group = cbase / 8 + q8;
+        if (pooled) {
+          tile[(nb * 4 + q8) * 256 + slot] = piece;   // idle slots too: never read
+        } else if (mvalid[pt] && group * 8 < b.Cout) {
+          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pooling pass: thread = pixel slot
+  const int slot = wave * 64 + lane;
+  int il, pix, y, x;
+  divmod_small(slot, p.tile_p, p.rcp_tile_p, il, pix);
+  divmod_small(pix, p.OW, p.rcp_ow, y, x);
+  const int n = pix_block * p.tile_g + il;
+  const bool live = il < p.tile_g && n < p.N;
+  const int H = p.OH, W = p.OW;
+  const int map0 = il * p.tile_p;
+  const float inv = 1.0f / static_cast<float>(((y > 0) + (y < H - 1) + 1) * ((x > 0) + (x < W - 1) + 1));
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int sub = n_tile * NB + nb;
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
+    const ConvBranch& b = p.br[bi];
+    const int cbase = (sub - b.sub0) * 32;
+    if (cbase >= b.Cout || !b.avgpool || !live) continue;
+    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+    const unsigned obase = static_cast<unsigned>(
+        ((n * b.og.groups + b.out_goff) * b.og.hp + y + b.og.halo) * b.og.wp + x + b.og.halo);
+    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+    for (int q8 = 0; q8 < 4; ++q8) {
+      const int group = cbase / 8 + q8;
+      if (group * 8 >= b.Cout) break;
+      const half8_t* src = reinterpret_cast<const half8_t*>(tile) + (nb * 4 + q8) * 256 + map0;
+      float col[3][8];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        const bool cx = xx >= 0 && xx < W;
+        half8_t r[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yy = y + dy - 1;
+          const bool ok = cx && yy >= 0 && yy < H;
+          r[dy] = src[ok ? yy * W + xx : pix];
+          if (!ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[dy][j] = static_cast<_Float16>(0.f);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          col[dx][j] = static_cast<float>(r[0][j]) + static_cast<float>(r[1][j]) + static_cast<float>(r[2][j]);
+        }
+      }
+      float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (b.shift != nullptr) {
+        const float4 s0 = *reinterpret_cast<const float4*>(b.shift + group * 8);
+        const float4 s1 = *reinterpret_cast<const float4*>(b.shift + group * 8 + 4);
+        sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
+        sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
+      }
+      half8_t o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = avg_finish(col[0][j], col[1][j], col[2][j], inv, sh[j], b.shift != nullptr);
+      outp[obase + static_cast<unsigned>(group) * gstride] = __builtin_bit_cast(uint4_t, o);
     }
   }
 }

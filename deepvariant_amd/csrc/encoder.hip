@@ -42,7 +42,9 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kColsPerLane = 4;  // a row is rendered in passes of 256 columns, 4 per lane
 constexpr int kMaxKept = 256;
-constexpr int kCigCache = 8;     // CIGAR words per kept read cached in LDS (power of two; longer CIGARs are read from global)
+constexpr int kCigCache = 8;     // CIGAR words per kept read cached in LDS when the batch gives no hint (EncArgs::cig_cache:
+                                 // a power of two, 8..64, from dv_batch::max_cigar_ops; longer CIGARs are read from global)
+constexpr int kCigCacheMax = 64; // one coalesced wave load per read
 constexpr int kPixDw = DV_MAX_CHANNELS / 4;  // dwords of one pixel's channel bytes
 constexpr int kInsertLutSize = 1008;
 
@@ -144,6 +146,8 @@ struct EncArgs {
   int32_t n_channels;     // = EncConst::n_channels (sizes the LDS layout)
   int32_t out_channels;
   int32_t row_buf_bytes;  // per-wave LDS row buffer, multiple of 16
+  int32_t cig_cache;      // CIGAR words per kept read in LDS: power of two in [kCigCache, kCigCacheMax]
+  int32_t kept_cap;       // rows of the CIGAR cache: max (item_height - band) of the batch, <= kMaxKept
   uint8_t* out;
   int32_t* out_rows;
 };
@@ -256,8 +260,9 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   uint32_t* m_const = wave_tot + 8;                // [kMaxKept][pdw]
   uint32_t* m_sel_a = m_const + kMaxKept * pdw;    // dynamic bytes {base, qual, diff, 5mC}
   uint32_t* m_sel_b = m_sel_a + kMaxKept * pdw;    // dynamic byte  {6mA}
-  uint32_t* m_cig = m_sel_b + kMaxKept * pdw;      // [kMaxKept][kCigCache]: the first CIGAR words of each kept read
-  uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_cig + kMaxKept * kCigCache);
+  const int cig_cache = a.cig_cache;
+  uint32_t* m_cig = m_sel_b + kMaxKept * pdw;      // [kept_cap][cig_cache]: the first CIGAR words of each kept read
+  uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_cig + a.kept_cap * cig_cache);
   // after the sort the key arrays are dead: they become the per-read metadata
   uint32_t* m_c0 = reinterpret_cast<uint32_t*>(key_hap);
   uint32_t* m_s0 = reinterpret_cast<uint32_t*>(key_pos);
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   const int H = a.item_height[item];
   // host batches are validated (height - band <= kMaxKept); device batches are clamped so
   // that a bad height can never run past the LDS tables
-  const int max_reads = min(H - band, kMaxKept);
+  const int max_reads = min(H - band, a.kept_cap);
   const uint32_t l0 = a.item_list_off[item];
   const int n = static_cast<int>(a.item_list_off[item + 1] - l0);
   const int vstart = a.item_variant_start[item];
@@ -422,16 +427,19 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         m_sel_b[tid * pdw + d] = sel_b[d];
       }
     }
-#pragma unroll
-    for (int k = 0; k < kCigCache; ++k) {
-      m_cig[tid * kCigCache + k] = rc0 + k < rc1 ? a.cigar[rc0 + k] : 0u;
-    }
-    if (rc1 - rc0 > static_cast<uint32_t>(kCigCache)) atomicOr(&wave_tot[kWaves], 1u);
+    if (rc1 - rc0 > static_cast<uint32_t>(cig_cache)) atomicOr(&wave_tot[kWaves], 1u);
     m_c0[tid] = rc0;   // (key_* / kept_* of this slot are dead from here on)
     m_s0[tid] = rs0;
     m_rpos[tid] = rp;
     m_c1[tid] = rc1;
     m_flags[tid] = flags;
+  }
+  __syncthreads();
+  // the CIGAR cache: a wave per kept read, its first cig_cache words with ONE coalesced load
+  // (cig_cache <= 64 lanes), zero past the read's own operations
+  for (int slot = wave; slot < kept; slot += kWaves) {
+    const uint32_t rc0 = m_c0[slot], rc1 = m_c1[slot];
+    if (lane < cig_cache) m_cig[slot * cig_cache + lane] = rc0 + lane < rc1 ? a.cigar[rc0 + lane] : 0u;
   }
   __syncthreads();
 
@@ -529,8 +537,8 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
     const int n_ops = static_cast<int>(c1 - c0);
     for (int kb = 0; kb < n_ops; kb += 64) {
       uint32_t cg_v;
-      if (kLdsOnly || n_ops <= kCigCache) {   // wave-uniform
-        cg_v = m_cig[slot * kCigCache + (lane & (kCigCache - 1))];
+      if (kLdsOnly || n_ops <= cig_cache) {   // wave-uniform
+        cg_v = m_cig[slot * cig_cache + (lane & (cig_cache - 1))];
       } else {
         cg_v = (kb + lane < n_ops) ? a.cigar[c0 + kb + lane] : 0u;
       }
@@ -1323,9 +1331,28 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
   a.out = d_out;
   a.out_rows = d_rows;
 
+  // CIGAR cache geometry (EncArgs::cig_cache, kept_cap): from the batch itself when it is host memory, from its
+  // ABI v7 hints when it is not; without either the round-4 shape (8 words x kMaxKept reads).  The cache may
+  // take up to 24 KB (64 words x 96 reads: the ONT shape), which still leaves three workgroups per CU.
+  {
+    uint32_t ops = b->max_cigar_ops, height = b->max_item_height;
+    if (b->memory == DV_MEM_HOST) {
+      ops = 0;
+      height = 0;
+      for (int r = 0; r < b->n_reads; ++r) ops = std::max(ops, b->read_cigar_off[r + 1] - b->read_cigar_off[r]);
+      for (int i = 0; i < b->n_items; ++i) height = std::max<uint32_t>(height, b->item_height[i]);
+    }
+    const int band = enc->opt.reference_band_height;
+    a.kept_cap = height > static_cast<uint32_t>(band) ? std::min<int>(kMaxKept, static_cast<int>(height) - band) : kMaxKept;
+    a.kept_cap = (a.kept_cap + 3) & ~3;
+    int cache = kCigCache;
+    while (cache < kCigCacheMax && static_cast<uint32_t>(cache) < ops) cache *= 2;
+    while (cache > kCigCache && static_cast<size_t>(cache) * a.kept_cap * 4 > 24 * 1024) cache /= 2;
+    a.cig_cache = ops == 0 ? kCigCache : cache;
+  }
   const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
                      3 * static_cast<size_t>(kMaxKept) * ((a.n_channels + 3) / 4) * 4 +
-                     static_cast<size_t>(kMaxKept) * kCigCache * 4 +
+                     static_cast<size_t>(a.kept_cap) * a.cig_cache * 4 +
                      static_cast<size_t>(kWaves) * a.row_buf_bytes;
   {
     dv::ProfileScope prof(dv::kProfEncoder, stream);

@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "stem_fused.h"
+#include "wave_prio.h"
 
 namespace dv {
 namespace {
@@ -172,6 +173,7 @@ __device__ __forceinline__ uint4_t normalise8(unsigned lo, unsigned up) {
 
 __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  asym_priority(p.prio);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -392,6 +394,7 @@ static_assert(B_C3FR <= 2 * B_WAVES, "two conv3 fragments per wave");
 
 __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  asym_priority(p.prio);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -665,7 +668,9 @@ void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream) {
   }();
   (void)attr;
   const int grid = std::max(1, std::min(blocks, a.total_tiles));
-  hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, a);
+  StemAArgs b = a;
+  b.prio = prio_mode(kPrioStemA);
+  hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, b);
 }
 
 void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
@@ -676,7 +681,9 @@ void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
   }();
   (void)attr;
   const int grid = std::max(1, std::min(blocks, a.total_tiles));
-  hipLaunchKernelGGL(stem_b_kernel, dim3(grid), dim3(B_THREADS), B_LDS, stream, a);
+  StemBArgs b = a;
+  b.prio = prio_mode(kPrioStemB);
+  hipLaunchKernelGGL(stem_b_kernel, dim3(grid), dim3(B_THREADS), B_LDS, stream, b);
 }
 
 // ---------------------------------------------------------------------------- weight packing

@@ -79,6 +79,7 @@ class DeviceBatch:
     self.c.n_ref_windows = len(batch.ref_windows_list)
     self.c.n_list = int(batch.item_list_off[-1])
     self.c.max_list_len = batch.max_list_len
+    self.c.max_cigar_ops, self.c.max_item_height = host_c.max_cigar_ops, host_c.max_item_height
     self.input_bytes = int(self.storage.numel())
 
   def encode(self, encoder, out_channels: int, out: torch.Tensor,

@@ -1250,7 +1250,16 @@ class PackedBatch:
       setattr(b, name, ptr(fz.get(name), np.uint8))
     b.n_list = int(fz['item_list_off'][-1])
     b.max_list_len = self.max_list_len
+    b.max_cigar_ops, b.max_item_height = self.size_hints()
     return b, keep
+
+  def size_hints(self):
+    """(max CIGAR operations of any read, max item height): dv_batch's ABI v7 hints."""
+    t = self.table
+    off = np.asarray(t.read_cigar_off, np.int64)
+    ops = int((off[1:] - off[:-1]).max()) if off.size > 1 else 0
+    heights = np.asarray(self._freeze()['item_height'])
+    return ops, int(heights.max()) if heights.size else 0
 
 
 def blank_mask_for(chan_enums: Sequence[int], channels_enum_to_blank) -> int:

@@ -216,6 +216,13 @@ typedef struct dv_batch {
    * base_aux2, base_aux1, base_aux0 that no other channel of the list reads (dv_base_aux_plane answers for a given
    * list).  Their reference-row pixel is 0.  More than three per-base channels in one list: DV_ERR_UNSUPPORTED. */
   const uint8_t* base_aux2;
+  /* ABI v7.  Optional hints (0 = unknown) that size the encoder's per-item LDS tables: an upper bound on the
+   * CIGAR operations of any read and on any item_height.  With them the row pipeline keeps up to 64 operations
+   * per kept read in LDS (8 without: reads with more take the row-at-a-time path -- every ONT read).  A host
+   * batch is measured by dv_encode_batch itself; a DV_MEM_DEVICE batch relies on the hints, and a hint that
+   * is too small is a caller error (items are clamped to it, never read out of bounds). */
+  uint32_t max_cigar_ops;
+  uint32_t max_item_height;
 } dv_batch;
 
 typedef struct dv_encoder dv_encoder;

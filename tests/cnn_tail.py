@@ -1,11 +1,8 @@
 """Large-N CNN parity helpers (GPU box; test infrastructure, never imported by the product).
 
-The fp32 oracle (oracle/inception_ref.py) takes minutes per 2048 images on host cores; a genome is
-10^6-10^7 candidates and the largest |dp| grows with the sample.  Here the SAME oracle module runs on
-the GPU through torch-ROCm in fp32 (its im2col + matmul formulation, `ConvBN.as_gemm`: rocBLAS and
-ATen kernels only -- MIOpen would compile its solvers for minutes on a fresh box), after it has been
-checked against its own CPU conv2d form on the same images (`check_gpu_oracle`).  Used by
-tests/test_hip_cnn_tail.py, tools/r5_cnn_tail.py and bench.py's parity leg.
+Images for the large-N tests drawn by the HIP encoder and kept on the GPU; the fp32 oracle on the GPU and the
+tail statistics live in oracle/inception_gpu.py (re-exported here).  Used by tests/test_hip_cnn_tail.py,
+tests/test_hip_calibration.py and tools/r5_cnn_tail.py.
 """
 import os
 import sys
@@ -17,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-from oracle import inception_ref as R   # noqa: E402  (checker)
+from oracle import inception_ref as R   # noqa: E402,F401  (checker)
+from oracle.inception_gpu import (check_gpu_oracle, fmt, oracle_probs_cpu, oracle_probs_gpu,   # noqa: E402,F401
+                                  tail_stats)
 
 
 def illumina_pileups_gpu(n, seed, chunk=8192, device='cuda'):
@@ -67,38 +66,6 @@ def longread_images_gpu(kind, n, seed=None, device='cuda'):
   return flat[:n * img_bytes].view(n, h, w, ct).clone()
 
 
-def oracle_probs_gpu(ref_gpu, images, batch=256):
-  """fp32 oracle on the GPU: images uint8 [N,H,W,C] (cuda) -> float32 probabilities [N,3] (numpy)."""
-  outs = []
-  R.ConvBN.as_gemm = True
-  try:
-    with torch.no_grad():
-      for i in range(0, images.shape[0], batch):
-        outs.append(ref_gpu(images[i:i + batch]).cpu())
-  finally:
-    R.ConvBN.as_gemm = False
-  return torch.cat(outs).numpy()
-
-
-def oracle_probs_cpu(ref, images_np, batch=64):
-  torch.set_num_threads(min(128, os.cpu_count() or 1))
-  with torch.no_grad():
-    return torch.cat([ref(torch.from_numpy(images_np[i:i + batch]), channels_last=True)
-                      for i in range(0, len(images_np), batch)]).numpy()
-
-
-def check_gpu_oracle(ref, ref_gpu, images, n=256, tol=5e-6):
-  """The GPU run of the oracle against its CPU conv2d form on the first n images; returns max |dp|.
-  Both are float32 with different summation orders: measured 0.4e-6 .. 1.6e-6 on 256 pileups
-  (profiles/r05_cnn_tail.txt), three orders of magnitude under the bar being checked."""
-  x = images[:n]
-  got = oracle_probs_gpu(ref_gpu, x)
-  want = oracle_probs_cpu(ref, x.cpu().numpy())
-  d = float(np.abs(got - want).max())
-  assert d <= tol, 'GPU fp32 oracle differs from the CPU oracle by %.3g on %d images' % (d, n)
-  return d
-
-
 def hip_probs(model, images, chunk):
   outs = []
   for i in range(0, images.shape[0], chunk):
@@ -106,17 +73,3 @@ def hip_probs(model, images, chunk):
   return torch.cat(outs).numpy()
 
 
-def tail_stats(got, want, tol=1e-3):
-  e = np.abs(got.astype(np.float64) - want.astype(np.float64)).max(axis=1)
-  return {
-      'n': int(e.size), 'max_abs_dp': float(e.max()), 'mean_abs_dp': float(e.mean()),
-      'p999_abs_dp': float(np.quantile(e, 0.999)), 'p9999_abs_dp': float(np.quantile(e, 0.9999)),
-      'n_over_tol': int((e > tol).sum()), 'tol': tol,
-      'prob_spread': float((want.max(0) - want.min(0)).max()),
-  }
-
-
-def fmt(s):
-  return ('n %d  max %.3e  p99.99 %.3e  p99.9 %.3e  mean %.3e  over %.0e: %d (%.2e of the sample)  spread %.2f' % (
-      s['n'], s['max_abs_dp'], s['p9999_abs_dp'], s['p999_abs_dp'], s['mean_abs_dp'], s['tol'], s['n_over_tol'],
-      s['n_over_tol'] / s['n'], s['prob_spread']))

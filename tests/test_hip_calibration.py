@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _images(shape, n, seed):
-  import cnn_tail as T
+  from tests import cnn_tail as T
   if shape == (100, 221, 7):
     return T.illumina_pileups_gpu(n, seed=seed, chunk=4096)
   return T.longread_images_gpu('hifi' if shape[2] == 10 else 'ont', n, seed=seed)
@@ -26,7 +26,7 @@ def _model(shape, weights, max_batch):
 
 @pytest.mark.parametrize('shape', [(100, 221, 7), (100, 147, 10)])
 def test_native_corrections_equal_the_torch_restatement(shape):
-  import calib_emulation as E
+  from tests import calib_emulation as E
   from oracle import inception_ref as R
   ref = R.make_random_model(shape[2], seed=23)
   x = _images(shape, 48, seed=515)
@@ -38,6 +38,16 @@ def test_native_corrections_equal_the_torch_restatement(shape):
   rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
   print('%s: |corr| rms %.3g, max %.3g; native vs torch restatement: relative L2 difference %.3g, max abs %.3g' % (
       shape, float(np.sqrt((want ** 2).mean())), float(np.abs(want).max()), rel, float(np.abs(got - want).max())))
+  off = 0
+  rows = []
+  for i, cb in enumerate(ref.convs):       # where the two walks part: per-layer relative difference
+    c = cb.conv.out_channels
+    g, w = got[off:off + c], want[off:off + c]
+    rows.append((float(np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-12)), i, c, float(np.abs(w).max())))
+    off += c
+  print('  per layer (relative L2, layer, couts, max |corr|): first 6 %s' % (
+      ' '.join('%d:%.3f' % (i, r) for r, i, _, _ in rows[:6])))
+  print('  worst 8: %s' % ' '.join('%d(c%d):%.3f' % (i, c, r) for r, i, c, _ in sorted(rows, reverse=True)[:8]))
   assert np.isfinite(got).all()
   assert rel <= 0.05, rel
 
@@ -61,7 +71,7 @@ def test_calibration_is_deterministic_and_replaces_the_previous_one():
 
 @pytest.mark.parametrize('seed', [17, 404])
 def test_calibrated_model_is_closer_to_the_fp32_oracle_on_other_pileups(seed):
-  import cnn_tail as T
+  from tests import cnn_tail as T
   from oracle import inception_ref as R
   shape = (100, 221, 7)
   n = 4096

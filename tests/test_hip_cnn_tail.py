@@ -24,7 +24,7 @@ _cache = {}
 
 
 def _tail_images():
-  import cnn_tail as T
+  from tests import cnn_tail as T
   if 'x' not in _cache:
     _cache['x'] = T.illumina_pileups_gpu(N_TAIL, seed=424242)
   return _cache['x']
@@ -40,7 +40,7 @@ def _calibrated_model(shape, weights, max_batch, cal_images):
 
 
 def test_gpu_oracle_equals_cpu_oracle_on_256_pileups():
-  import cnn_tail as T
+  from tests import cnn_tail as T
   from oracle import inception_ref as R
   x = _tail_images()
   ref = R.make_random_model(7, seed=HELD_OUT_SEEDS[0])
@@ -51,7 +51,7 @@ def test_gpu_oracle_equals_cpu_oracle_on_256_pileups():
 
 @pytest.mark.parametrize('seed', HELD_OUT_SEEDS)
 def test_illumina30_tail_on_held_out_weight_seeds(seed):
-  import cnn_tail as T
+  from tests import cnn_tail as T
   from oracle import inception_ref as R
   x = _tail_images()
   ref = R.make_random_model(7, seed=seed)
@@ -69,7 +69,7 @@ def test_illumina30_tail_on_held_out_weight_seeds(seed):
 
 @pytest.mark.parametrize('kind,shape', [('hifi', (100, 147, 10)), ('ont', (100, 199, 9))])
 def test_long_read_shapes_on_2048_examples(kind, shape):
-  import cnn_tail as T
+  from tests import cnn_tail as T
   from oracle import inception_ref as R
   n = 2048
   x = T.longread_images_gpu(kind, n)

@@ -28,17 +28,22 @@ def _pileups(n, seed):
   return np.ascontiguousarray(out.reshape(-1, 100, 221, 7)[:n])
 
 
-def _model(weights, max_batch, split_from=None):
+def _model(weights, max_batch, split_from=None, split_default=False):
+  """split_from: DV_SPLIT_FROM (94 = no layer, 0 = every conv_mfma layer); split_default: the round-4 set
+  (DV_SPLIT_DEFAULT=1); neither: the product default -- plain fp16 weights since round 5."""
   from deepvariant_amd.inception_v3 import InceptionV3
-  old = os.environ.pop('DV_SPLIT_FROM', None)
+  old = {k: os.environ.pop(k, None) for k in ('DV_SPLIT_FROM', 'DV_SPLIT_DEFAULT')}
   if split_from is not None:
     os.environ['DV_SPLIT_FROM'] = str(split_from)
+  if split_default:
+    os.environ['DV_SPLIT_DEFAULT'] = '1'
   try:
     m = InceptionV3((100, 221, 7), max_batch=max_batch)
   finally:
-    os.environ.pop('DV_SPLIT_FROM', None)
-    if old is not None:
-      os.environ['DV_SPLIT_FROM'] = old
+    for k, v in old.items():
+      os.environ.pop(k, None)
+      if v is not None:
+        os.environ[k] = v
   m.load_flat_weights(weights)
   return m
 
@@ -52,11 +57,13 @@ def _oracle_probs(ref, x, batch=128):
 
 @pytest.mark.parametrize('seed', [17, 29, 43])
 def test_softmax_within_1e3_on_2048_pileups(seed):
-  """max |dp| <= 1e-3 over 2048 pileups x 3 classes, product defaults (one forward)."""
+  """max |dp| <= 1e-3 over 2048 pileups x 3 classes, product defaults: plain fp16 weights, shifts calibrated
+  (dv_model_calibrate) on 256 OTHER pileups; one forward."""
   from oracle import inception_ref as R
   ref = R.make_random_model(7, seed=seed)
   x = _pileups(N_PILEUPS, seed=1000 + seed)
   model = _model(ref.export_flat(), N_PILEUPS)
+  model.calibrate(torch.from_numpy(_pileups(256, seed=555000 + seed)).cuda())
   got = model(torch.from_numpy(x).cuda()).cpu().numpy()
   want = _oracle_probs(ref, x)
   err = np.abs(got - want).max(axis=1)
@@ -108,7 +115,7 @@ def test_split_weights_move_the_features_towards_the_fp32_oracle():
   """With ordinary weights the split layers compute with W_hi + W_lo: the 2048 pooled features of
   an all-split model are measurably closer to the fp32 oracle than those of an unsplit one
   (the weight rounding is ~3/4 of the error variance, tools/r4_layer_sensitivity.py; conv_mfma
-  launches are about half of the layers), and the default (two heads per 17x17 block + mixed8..10) lies in between."""
+  launches are about half of the layers), and the round-4 set (DV_SPLIT_DEFAULT=1: two heads per 17x17 block + mixed8..10) lies in between."""
   from oracle import inception_ref as R
   n = 256
   ref = R.make_random_model(7, seed=17)
@@ -120,7 +127,7 @@ def test_split_weights_move_the_features_towards_the_fp32_oracle():
     want = ref.features(pre.contiguous(memory_format=torch.channels_last)).numpy()
   rms = {}
   for name, first in (('none', 94), ('default', None), ('all', 0)):
-    m = _model(w, n, split_from=first)
+    m = _model(w, n, split_from=first, split_default=first is None)
     m(torch.from_numpy(x).cuda())
     fmap = m.debug_tensor(-1, n).astype(np.float32)
     halo = (fmap.shape[1] - 1) // 2

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import cnn_tail as T                    # noqa: E402
+from tests import cnn_tail as T   # noqa: E402
 from oracle import inception_ref as R   # noqa: E402
 
 

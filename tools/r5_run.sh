@@ -18,6 +18,12 @@ for step in "$@"; do
     tests:*) timeout 1500 python -m pytest ${step#tests:} -m gpu -q -s > $O/pytest_sel.log 2>&1; echo "rc=$?" >> $O/pytest_sel.log; grep -E "seed|hifi|ont|max|passed|failed|rc=|Error|assert" $O/pytest_sel.log | tail -30 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log ;;
     bench) DV_BENCH_PMC_SAVE=$O/pmc_hbm_traffic.txt timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench.err; cat $O/bench_default.json ;;
+    trace:*) rest=${step#trace:}; label=${rest%%:*}; kvs=${rest#*:}; [ "$kvs" = "$rest" ] && kvs=DV_X=0
+       env ${kvs//,/ } DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-workloads > /dev/null 2> $O/op_trace_$label.txt; grep -c dv-op $O/op_trace_$label.txt ;;
+    wl:*) rest=${step#wl:}; w=${rest%%:*}; rest=${rest#*:}; label=${rest%%:*}; kvs=${rest#*:}; [ "$kvs" = "$rest" ] && kvs=DV_X=0
+       env ${kvs//,/ } DV_BENCH_NO_PMC=1 timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>> $O/ab.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('$w $label', round(d['value']), round(d['ms_per_step'],3), 'conv', round(d['roofline']['ms_per_step'],3), 'other', round(d['other_kernels_ms_per_step'],3), 'enc', round(d['roofline_encoder']['avg_launch_ms'],3), 'enc_frac', round(d['roofline_encoder']['frac'],3))" | tee -a $O/ab.txt ;;
     trace) DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-workloads > /dev/null 2> $O/op_trace_raw.txt; grep -c dv-op $O/op_trace_raw.txt ;;
     stats) cd /tmp && export TMPDIR=/tmp
        DV_BENCH_NO_PMC=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-workloads > $R/$O/stats.log 2>&1
