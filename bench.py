@@ -226,6 +226,9 @@ def run_rank(args, rank, local_rank, world):
     host_inclusive(args, region, opts, C, enc, model, dev)
     return
 
+  # (Measured and removed in round 5: the next step's encoder on a second stream, two pileup buffers, so that it
+  # runs under this step's classifier -- 444 K against 455 K candidates/s same box: the encoder's waves take
+  # issue slots and L2 from the MFMA kernels for longer than its own 0.55 ms.)
   def local_step():
     dbatch.encode(enc, C, images, rows)
     return model(images)

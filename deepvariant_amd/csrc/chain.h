@@ -40,8 +40,6 @@ struct ChainArgs {
   // tuning aid (DV_CHAIN_PROF, eager launches): shader-clock sums [block][computing wave][8] =
   // wait at the chunk barriers, MFMA steps, wait at the layer barrier, LDS epilogue, HBM epilogue, set-up
   unsigned long long* prof;
-  // wave_prio.h (set by launch_chain): 0 = off, 1 = the four computing waves issue first, 2 = the four movers do
-  int prio;
 };
 
 size_t chain_lds_bytes(const ChainArgs& a);

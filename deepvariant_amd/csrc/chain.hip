@@ -568,7 +568,6 @@ __global__ __launch_bounds__(CH_THREADS, 1) void chain_kernel(ChainArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   if (static_cast<int>(blockIdx.x) >= p.n_tiles) return;
-  if (p.prio != 0 && (wave < 4) == (p.prio == 1)) __builtin_amdgcn_s_setprio(3);
   if (wave < 4) {
     chain_compute<PT, PROF>(p, smem, wave, lane);
   } else {
@@ -590,9 +589,7 @@ static void launch_chain_as(const ChainArgs& a, int grid, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  ChainArgs b = a;
-  b.prio = prio_mode(kPrioChain) != 0 ? (getenv("DV_PRIO_CHAIN") ? atoi(getenv("DV_PRIO_CHAIN")) : 1) : 0;
-  hipLaunchKernelGGL((chain_kernel<PT, PROF>), dim3(grid), dim3(CH_THREADS), chain_lds_bytes(a), stream, b);
+  hipLaunchKernelGGL((chain_kernel<PT, PROF>), dim3(grid), dim3(CH_THREADS), chain_lds_bytes(a), stream, a);
 }
 
 void launch_chain(const ChainArgs& a, int blocks, hipStream_t stream) {

@@ -9,8 +9,6 @@
 #include <cstddef>
 #include <cstdint>
 
-#include "wave_prio.h"
-
 namespace dv {
 namespace convk {
 
@@ -112,8 +110,6 @@ struct ConvArgs {
   // the raw tensor and the avg-pool launch disappear.  grid = ceil(N / tile_g) * n_tiles.
   int tile_g, tile_p;
   float rcp_tile_p;
-  // wave_prio.h: 0 = off, else the asymmetric-priority mode the kernel starts with (set by the launchers)
-  int prio;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));

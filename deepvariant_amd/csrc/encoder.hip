@@ -28,6 +28,7 @@
 // candidates share reads.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -44,7 +45,9 @@ constexpr int kColsPerLane = 4;  // a row is rendered in passes of 256 columns, 
 constexpr int kMaxKept = 256;
 constexpr int kCigCache = 8;     // CIGAR words per kept read cached in LDS when the batch gives no hint (EncArgs::cig_cache:
                                  // a power of two, 8..64, from dv_batch::max_cigar_ops; longer CIGARs are read from global)
-constexpr int kCigCacheMax = 64; // one coalesced wave load per read
+constexpr int kCigCacheMax = 16; // by default; up to kCigCacheHardMax words (one coalesced wave load per read) fit the code
+constexpr int kCigCacheHardMax = 64;   // (DV_CIG_CACHE: measured on ont50, 13,654 images: 8 words 1.94 ms, 16: 1.92, 32: 2.00, 64: 2.46 --
+                                       // the LDS the larger tables take costs more occupancy than the cached words save)
 constexpr int kPixDw = DV_MAX_CHANNELS / 4;  // dwords of one pixel's channel bytes
 constexpr int kInsertLutSize = 1008;
 
@@ -1349,6 +1352,11 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     while (cache < kCigCacheMax && static_cast<uint32_t>(cache) < ops) cache *= 2;
     while (cache > kCigCache && static_cast<size_t>(cache) * a.kept_cap * 4 > 24 * 1024) cache /= 2;
     a.cig_cache = ops == 0 ? kCigCache : cache;
+    static const int force_cache = getenv("DV_CIG_CACHE") ? atoi(getenv("DV_CIG_CACHE")) : 0;   // tuning knob: 8..64
+    if (force_cache >= kCigCache && force_cache <= kCigCacheHardMax && (force_cache & (force_cache - 1)) == 0) {
+      a.cig_cache = force_cache;
+      if (getenv("DV_CIG_KEPT_MAX") != nullptr) a.kept_cap = kMaxKept;
+    }
   }
   const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
                      3 * static_cast<size_t>(kMaxKept) * ((a.n_channels + 3) / 4) * 4 +

@@ -53,7 +53,6 @@ __global__ __launch_bounds__(IC_THREADS, 2) void imgconv_kernel(ImgConvArgs p) {
   constexpr int W_ROUNDS = (W_SLAB / 1024 + IC_WAVES - 1) / IC_WAVES;
   constexpr int D = 2;                         // LDS fragment prefetch depth (steps of NB*PT MFMAs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dv::asym_priority(p.c.prio ? 2 : 0);   // one workgroup per CU: between the two waves of a SIMD
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,10 +276,8 @@ void launch_ring(const ImgConvArgs& a, int blocks, size_t lds, hipStream_t strea
   (void)attr;
   const int total = a.n_img_tiles * a.n_cout_tiles;
   const int grid = total < blocks ? total : blocks;
-  ImgConvArgs b = a;
-  b.c.prio = prio_mode(kPrioImgconv);
   hipLaunchKernelGGL((imgconv_kernel<KH, KW, KC, NB, R>), dim3(grid > 0 ? grid : 1), dim3(IC_THREADS), lds,
-                     stream, b);
+                     stream, a);
 }
 
 template <int KH, int KW, int KC, int NB>

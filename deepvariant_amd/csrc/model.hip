@@ -28,6 +28,7 @@
 //   maxpool3s2_kernel / avgpool3s1_kernel   (avg excludes padding, optional shift + ReLU)
 //   head_kernel               global average pool + Dense(3) + softmax in fp32
 #include <algorithm>
+#include <map>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -254,7 +255,6 @@ __device__ __forceinline__ void copy_blank_wave(const ConvArgs& p, int n_tile, c
 template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks, int WAVES = 4,
           bool SPLIT = false, bool SIDE_POOL = false, bool AVG = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p) {
-  dv::asym_priority(p.prio);
   constexpr int BN = NB * 32;
   constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8)
   constexpr int SLAB_HALFS = SLAB * BN * kChunk;
@@ -513,7 +513,6 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
 // cout tiles of the same pixels.
 template <int NB, int PT>
 __global__ __launch_bounds__(512, 1) void conv_resident_kernel(ConvArgs p) {
-  dv::asym_priority(p.prio ? 2 : 0);   // one workgroup per CU: between the two waves of a SIMD
   constexpr int BN = NB * 32;
   constexpr int WAVES = 8, kThreads = WAVES * 64;
   constexpr int SLAB_HALFS = kSlabChunks * BN * kChunk;
@@ -682,7 +681,6 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
 
 template <int NB>
 __global__ __launch_bounds__(512, 1) void conv_pool_resident_kernel(ConvArgs p) {
-  dv::asym_priority(p.prio ? 2 : 0);   // one workgroup per CU: between the two waves of a SIMD
   constexpr int BN = NB * 32;
   constexpr int WAVES = 8, kThreads = WAVES * 64;
   constexpr int kNew = 30;   // positions a fragment owns (the last two belong to the next one)
@@ -1783,6 +1781,7 @@ struct dv_model {
   // heads that pool their input on the fly.  DV_NO_AVG_EPI keeps conv -> avgpool3s1_kernel (same bits).
   void choose_avg_epilogue() {
     if (getenv("DV_NO_AVG_EPI") != nullptr) return;
+    const int min_g = getenv("DV_AVG_EPI_MIN_G") ? atoi(getenv("DV_AVG_EPI_MIN_G")) : 1;   // tuning knob: whole maps per block
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& lead = ops[i];
       if (lead.type != kOpConv) continue;
@@ -1791,7 +1790,7 @@ struct dv_model {
       const bool ok = lead.kh == 1 && lead.kw == 1 && lead.stride == 1 && lead.nb == 4 && !lead.split && !lead.pool_in &&
                       !lead.pool_out && !lead.v2 && !lead.band && lead.chain_len == 0 && !lead.in_chain &&
                       !lead.first_u8 && !lead.stem_a && !lead.stem_b && px >= 5 && px <= 256 &&
-                      (256 / px) * px * 10 >= 256 * 9;
+                      (256 / px) * px * 10 >= 256 * 9 && 256 / px >= min_g;
       if (ok) {
         for (int gi = 0; gi <= followers; ++gi) {
           Op& c = ops[i + gi];
@@ -2102,9 +2101,7 @@ void launch_conv6(const ConvArgs& a, hipStream_t stream) {
 }
 
 template <int NB>
-void launch_conv(const ConvArgs& a_in, hipStream_t stream) {
-  ConvArgs a = a_in;
-  a.prio = dv::prio_mode(dv::kPrioConvMfma);
+void launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int n_tiles = a.n_tiles;
   // pixel blocks of `px` pixels: over all N*OH*OW pixels, or per output row in row-band mode
   const long rows = a.band ? a.band : 1;
@@ -2347,6 +2344,41 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                             "barrierB %.0f conv1x1+store %.0f\n", w ? 7 : 0, sum[0] / tiles, sum[1] / tiles,
                     sum[6] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles);
           }
+          {  // placement: which workgroups share a CU, their TG slots, and the phase sums of the two classes
+            std::map<unsigned long long, std::vector<int>> where;
+            for (int b = 0; b < m->stem_b_grid; ++b) {
+              const unsigned long long v = h[(b * 2) * 8 + 7];
+              const unsigned hw = static_cast<unsigned>(v), xcc = static_cast<unsigned>(v >> 32);
+              where[(static_cast<unsigned long long>(xcc) << 16) | ((hw >> 8) & 0xffu)].push_back(b);
+            }
+            int pairs = 0, same_parity = 0, apart256 = 0;
+            for (const auto& kv : where) {
+              if (kv.second.size() != 2) continue;
+              ++pairs;
+              const unsigned t0 = (static_cast<unsigned>(h[(kv.second[0] * 2) * 8 + 7]) >> 16) & 15u;
+              const unsigned t1 = (static_cast<unsigned>(h[(kv.second[1] * 2) * 8 + 7]) >> 16) & 15u;
+              same_parity += (t0 & 1u) == (t1 & 1u);
+              apart256 += kv.second[1] - kv.second[0] == 256;
+            }
+            fprintf(stderr, "[dv-stem-b placement] %zu places for %d workgroups; %d pairs, %d with TG slots of EQUAL parity, "
+                            "%d pairs are blocks b / b+256\n", where.size(), m->stem_b_grid, pairs, same_parity, apart256);
+            for (int cls = 0; cls < 2; ++cls) {
+              double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+              int nb = 0;
+              for (int b = 0; b < m->stem_b_grid; ++b) {
+                const unsigned tg = (static_cast<unsigned>(h[(b * 2) * 8 + 7]) >> 16) & 15u;
+                if (static_cast<int>(tg & 1u) != cls) continue;
+                ++nb;
+                for (int i = 0; i < 7; ++i) sum[i] += static_cast<double>(h[(b * 2) * 8 + i]);
+              }
+              double tot = 0;
+              for (double v : sum) tot += v;
+              fprintf(stderr, "[dv-stem-b TG parity %d] %d workgroups, share of wave-0 cycles: issue %.3f conv3 %.3f dma-wait %.3f "
+                              "barrierA %.3f pool %.3f barrierB %.3f conv1x1+store %.3f; cycles per workgroup %.0f\n", cls, nb,
+                      sum[0] / tot, sum[1] / tot, sum[6] / tot, sum[2] / tot, sum[3] / tot, sum[4] / tot, sum[5] / tot,
+                      nb ? tot / nb : 0.0);
+            }
+          }
         }
       } else {
         dv::launch_stem_b(a, m->stem_b_grid, stream);
@@ -2562,7 +2594,6 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (op.pool_out) tr_label += " [weights resident in LDS] -> maxpool3s2";
       TraceScope tr(stream, tr_label, tr_flops, tr_bytes);
       dv::ProfileScope prof(dv::kProfConv, stream);
-      if (op.pool_out || resident) a.prio = dv::prio_mode(dv::kPrioResident);
       if (op.pool_out) {
         const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
         static const bool attr = [] {

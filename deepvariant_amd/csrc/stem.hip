@@ -32,7 +32,6 @@
 #include <algorithm>
 
 #include "stem_fused.h"
-#include "wave_prio.h"
 
 namespace dv {
 namespace {
@@ -173,7 +172,6 @@ __device__ __forceinline__ uint4_t normalise8(unsigned lo, unsigned up) {
 
 __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  asym_priority(p.prio);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -394,7 +392,6 @@ static_assert(B_C3FR <= 2 * B_WAVES, "two conv3 fragments per wave");
 
 __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  asym_priority(p.prio);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -646,6 +643,10 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
   if (p.prof && lane == 0 && (wave == 0 || wave == B_WAVES - 1)) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) p.prof[(blockIdx.x * 2 + (wave == B_WAVES - 1)) * 8 + i] = ph[i];
+    // where the workgroup ran: HW_ID (wave / SIMD / CU / SH / SE / TG slot) and XCC_ID
+    p.prof[(blockIdx.x * 2 + (wave == B_WAVES - 1)) * 8 + 7] =
+        static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) |
+        (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u) << 32);
   }
 }
 
@@ -668,9 +669,7 @@ void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream) {
   }();
   (void)attr;
   const int grid = std::max(1, std::min(blocks, a.total_tiles));
-  StemAArgs b = a;
-  b.prio = prio_mode(kPrioStemA);
-  hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, b);
+  hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, a);
 }
 
 void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
@@ -681,9 +680,7 @@ void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
   }();
   (void)attr;
   const int grid = std::max(1, std::min(blocks, a.total_tiles));
-  StemBArgs b = a;
-  b.prio = prio_mode(kPrioStemB);
-  hipLaunchKernelGGL(stem_b_kernel, dim3(grid), dim3(B_THREADS), B_LDS, stream, b);
+  hipLaunchKernelGGL(stem_b_kernel, dim3(grid), dim3(B_THREADS), B_LDS, stream, a);
 }
 
 // ---------------------------------------------------------------------------- weight packing

@@ -39,7 +39,6 @@ struct StemAArgs {
   int tiles_y, tiles_x;
   int total_tiles;        // N * tiles_y * tiles_x
   unsigned in_bytes;      // N*H*W*C (< 2^31)
-  int prio;               // wave_prio.h mode (set by launch_stem_a)
 };
 
 // ---- stem B: conv 3x3 'same' 32 -> 64, max-pool 3x3/2, conv 1x1 64 -> 80 -----------------
@@ -75,7 +74,6 @@ struct StemBArgs {
   unsigned in_img_bytes;
   // tuning aid (DV_STEM_PROF): per-phase shader-clock sums [block][8], or NULL
   unsigned long long* prof;
-  int prio;               // wave_prio.h mode (set by launch_stem_b)
 };
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream);

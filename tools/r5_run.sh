@@ -24,6 +24,8 @@ for step in "$@"; do
        env ${kvs//,/ } DV_BENCH_NO_PMC=1 timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>> $O/ab.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print('$w $label', round(d['value']), round(d['ms_per_step'],3), 'conv', round(d['roofline']['ms_per_step'],3), 'other', round(d['other_kernels_ms_per_step'],3), 'enc', round(d['roofline_encoder']['avg_launch_ms'],3), 'enc_frac', round(d['roofline_encoder']['frac'],3))" | tee -a $O/ab.txt ;;
+    stemprof:*) rest=${step#stemprof:}; label=${rest%%:*}; kvs=${rest#*:}; [ "$kvs" = "$rest" ] && kvs=DV_X=0
+       env ${kvs//,/ } DV_STEM_PROF=1 DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-workloads --calibration-images 0 2>&1 > /dev/null | grep -E "dv-stem-b|stem_b conv" | tail -6 | sed "s/^/$label /" | tee -a $O/stemprof.txt ;;
     trace) DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-workloads > /dev/null 2> $O/op_trace_raw.txt; grep -c dv-op $O/op_trace_raw.txt ;;
     stats) cd /tmp && export TMPDIR=/tmp
        DV_BENCH_NO_PMC=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-workloads > $R/$O/stats.log 2>&1
