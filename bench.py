@@ -54,6 +54,9 @@ def parse_args():
                        'path, double buffered (deepvariant_amd/host_pipeline.py); 1 GPU only')
   ap.add_argument('--procs', type=int, default=1,
                   help="--mode bam: host processes sharing the GPU (make_examples --ranks_per_gpu)")
+  ap.add_argument('--repeat', type=int, default=1,
+                  help='--mode bam: every calling region of the slice this many times (10 = the work of 1 Mb); the '
+                       'decoded BAM block is reused between passes')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--calibration-images', type=int, default=256,
                   help='examples (of another synthetic seed) dv_model_calibrate sees before the timed region; 0 = off')
@@ -505,7 +508,19 @@ def _bam_args(me, tmp, bam, fasta, regions, out, extra=()):
       os.path.join(tmp, out)] + list(extra))
 
 
-def _bam_rank(rank, world, port, tmp, bam, fasta):
+def _repeat_calling_regions(me, k):
+  """Every calling region of the run k times over (a rank's share, in order, pass after pass): the work of a
+  k-times longer interval from the bundled 100 kb slice.  Bench-only: wraps the product's region list."""
+  if k <= 1:
+    return
+  original = me.calling_regions
+
+  def repeated(*a, **kw):
+    return list(original(*a, **kw)) * k
+  me.calling_regions = repeated
+
+
+def _bam_rank(rank, world, port, tmp, bam, fasta, repeat=1):
   """One of `--procs R` host processes sharing GPU 0 (make_examples --ranks_per_gpu R): warm up
   alone, then the product's distributed runner over the whole slice between two barriers."""
   import torch.distributed as dist
@@ -515,20 +530,53 @@ def _bam_rank(rank, world, port, tmp, bam, fasta):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   devnull = open(os.devnull, 'w')
   try:
+    weights = os.path.join(tmp, 'weights.rank%d.f32' % rank)
+
+    class WarmHooks(me.RunnerHooks):
+      def make_model(self, args, options):      # the timed run reads its weights from a file, as a real run does
+        model = super().make_model(args, options)   # ('random:1234' draws 24 M numbers on the host: seconds, and
+        model.flat_weights.tofile(weights)          # eight ranks doing it at once was most of an earlier wall time)
+        return model
+
     me.make_examples_runner(_bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm%d.cvo.tfrecord.gz' % rank),
-                            log=devnull)
+                            log=devnull, hooks=WarmHooks())
     spec = 'cvo.tfrecord@%d.gz' % world
     timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', spec,
                            ['--gpus', '1', '--ranks_per_gpu', str(world)])
+    timed_args.checkpoint = weights
+    _repeat_calling_regions(me, repeat)
+    # gloo opens its pairwise connections on the first all-gather (5.6 s for 8 ranks, 19 s for 16, measured): a
+    # once-per-job cost of the backend, paid here before the timed region like the kernels' first load
+    from deepvariant_amd import dist as dvd
+    dvd.gather_records([b'warm-up'], device=None)
     dist.barrier()
     t0 = time.perf_counter()
     stats = me.distributed_runner(timed_args, rank, world, log=devnull)
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0, float(stats['n_regions']), float(stats['n_reads']),
                             float(stats['n_candidates']), float(stats['n_examples'])], dtype=torch.float64)
-    wall = torch.tensor([elapsed[0], stats['loop_s'], stats['setup_s']], dtype=torch.float64)
+    wall = torch.tensor([elapsed[0], stats['loop_s'], stats['setup_s'], stats['runner_s'], stats['gather_s'],
+                         stats['write_s']], dtype=torch.float64)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     dist.all_reduce(elapsed, op=dist.ReduceOp.SUM)
+    # the same run once more with a HIP event pair around every kernel launch of every rank: how long the GPU
+    # computes (summed over the processes that share it) against the wall time of that run
+    from deepvariant_amd import _lib
+    lib = _lib.lib()
+    lib.dv_set_profiling(1)
+    again = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'again.' + spec,
+                      ['--gpus', '1', '--ranks_per_gpu', str(world)])
+    again.checkpoint = weights
+    dist.barrier()
+    t1 = time.perf_counter()
+    me.distributed_runner(again, rank, world, log=devnull)
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+    kernel = torch.tensor([lib.dv_profile_ms(0), lib.dv_profile_ms(1), lib.dv_profile_ms(2)], dtype=torch.float64)
+    lib.dv_set_profiling(0)
+    dist.all_reduce(wall2, op=dist.ReduceOp.MAX)
+    dist.all_reduce(kernel, op=dist.ReduceOp.SUM)
     if rank == 0:
       from deepvariant_amd import sharded_file_utils
       n_written = sum(sum(1 for _ in tfrecord.read_tfrecords(sharded_file_utils.sharded_filename(os.path.join(tmp, spec), r)))
@@ -539,14 +587,20 @@ def _bam_rank(rank, world, port, tmp, bam, fasta):
                     'processes sharing one GPU (make_examples --gpus 1 --ranks_per_gpu %d)' % (world, world),
           'value': int(elapsed[4]) / float(wall[0]), 'unit': 'examples/s', 'n_gpus': 1, 'host_processes': world,
           'data': _BAM_DATA, 'wall_s': float(wall[0]), 'region_loop_s_max_over_ranks': float(wall[1]),
-          'setup_s_max_over_ranks': float(wall[2]),
+          'setup_s_max_over_ranks': float(wall[2]), 'runner_s_max_over_ranks': float(wall[3]),
+          'record_exchange_s_max_over_ranks': float(wall[4]), 'rank0_shard_files_s': float(wall[5]),
           'examples_per_s_region_loop_only': int(elapsed[4]) / float(wall[1]),
           'regions': int(elapsed[1]), 'reads': int(elapsed[2]),
           'candidates': int(elapsed[3]), 'examples': int(elapsed[4]), 'host_cores': os.cpu_count(),
+          'passes_over_the_slice': repeat,
+          'gpu_kernel_ms_all_ranks': {'encoder': float(kernel[0]), 'cnn': float(kernel[1]),
+                                      'other (allele counts, pools, head)': float(kernel[2])},
+          'gpu_busy_frac': float(kernel.sum()) / (1e3 * float(wall2[0])),
+          'instrumented_wall_s': float(wall2[0]),
           'note': 'not the contract metric: inputs start in files on the host; wall = max over ranks between two '
-                  'barriers, includes every rank building its model and loading weights (setup_s: a fixed cost, '
-                  'large against this 100 kb slice), the final gather of the records and rank 0 writing the %d shard '
-                  'files' % world,
+                  'barriers, includes every rank building its model and loading weights (setup_s: a fixed cost), '
+                  'the final gather of the records and rank 0 writing the %d shard files; gpu_busy_frac = kernel '
+                  'time of an instrumented repeat summed over the ranks / wall time of that repeat' % world,
       }), flush=True)
   finally:
     dist.destroy_process_group()
@@ -569,7 +623,7 @@ def bam_mode(args, log=sys.stderr):
       with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-      mp.spawn(_bam_rank, args=(args.procs, port, tmp, bam, fasta), nprocs=args.procs, join=True)
+      mp.spawn(_bam_rank, args=(args.procs, port, tmp, bam, fasta, args.repeat), nprocs=args.procs, join=True)
     return
   stage = {}
   setup = {}            # the model's set-up runs on a worker thread, beside the region loop
@@ -628,6 +682,7 @@ def bam_mode(args, log=sys.stderr):
     me.make_examples_runner(warm, log=open(os.devnull, 'w'), hooks=WarmHooks())     # kernels loaded, graphs captured
     stage.clear()
     setup.clear()
+    _repeat_calling_regions(me, args.repeat)
     timed_args = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,100,000', 'cvo.tfrecord.gz')
     timed_args.checkpoint = weights
     t0 = time.perf_counter()
@@ -673,7 +728,7 @@ def bam_mode(args, log=sys.stderr):
       'wall_s': elapsed, 'region_loop_s': stats['loop_s'], 'setup_s': stats['setup_s'],
       'examples_per_s_region_loop_only': stats['n_examples'] / stats['loop_s'],
       'regions': stats['n_regions'], 'reads': stats['n_reads'], 'candidates': stats['n_candidates'],
-      'examples': stats['n_examples'], 'table_path': stats.get('table_path'),
+      'examples': stats['n_examples'], 'table_path': stats.get('table_path'), 'passes_over_the_slice': args.repeat,
       'stage_ms': {k: 1e3 * v for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
       'unaccounted_ms': 1e3 * (elapsed - sum(stage.values())),
       'main_thread_wait_for_realigned_batches_ms': 1e3 * stats.get('wait_for_prepared_batches_s', 0.0),
@@ -877,41 +932,11 @@ def parity_sample(region, opts, C, model, images, probs, n=512):
   product packed (support codes, name ranks, read lists) can cancel out.  Pileup tensors must be
   bit-exact; the softmax is checked against the fp32 torch restatement loaded with the same
   weights (bar: 1e-3, BASELINE.json)."""
-  from deepvariant_amd import dv_types as T, synth
-  from oracle import inception_ref, oracle as O
-  table, cands, combos, windows = region
-  n_sites = len(cands)
-  first_item = np.concatenate([[0], np.cumsum([len(c) for c in combos])])
+  from oracle import inception_ref, proto_driver
+  n_sites = len(region[1])
   picks = sorted(set(int(i) for i in np.linspace(0, n_sites - 1, num=min(n, n_sites))))
   H, W = opts.height, opts.width
-  hw = (W - 1) // 2
-  pos, end = np.asarray(table.read_pos, np.int64), np.asarray(table.read_end, np.int64)
-  seq_off, cig_off = table.read_seq_off, table.read_cigar_off
-  bases, quals, cigar = table.bases, table.quals, table.cigar
-
-  def read_object(j):
-    j = int(j)
-    name, _, number = table.keys[j].rpartition('/')
-    s0, s1 = int(seq_off[j]), int(seq_off[j + 1])
-    words = cigar[int(cig_off[j]):int(cig_off[j + 1])]
-    return T.Read(
-        fragment_name=name, read_number=int(number), number_reads=2, fragment_length=int(table.read_frag_len[j]),
-        aligned_sequence=bytes(bases[s0:s1]).decode(), aligned_quality=bytes(quals[s0:s1]),
-        alignment=T.LinearAlignment(
-            position=T.Position('chr1', int(pos[j]), bool(table.read_flags[j] & 1)),
-            mapping_quality=int(table.read_mapq[j]),
-            cigar=[T.CigarUnit(int(w) & 15, int(w) >> 4) for w in words]))
-
-  items, want_imgs = [], []
-  for ci in picks:
-    v = cands[ci].variant
-    # InMemoryReader::Query (make_examples_native.cc:802-810): overlapping reads in input order
-    lo, hi = v.start - opts.read_overlap_buffer_bp, v.end + opts.read_overlap_buffer_bp
-    reads = [read_object(j) for j in np.nonzero((hi > pos) & (lo < end))[0]]
-    for k, combo in enumerate(combos[ci]):
-      items.append(int(first_item[ci]) + k)
-      window = windows[ci] if isinstance(windows[ci], str) else bytes(windows[ci]).decode()
-      want_imgs.append(O.build_pileup(opts, cands[ci], window, reads, v.start - hw, list(combo)))
+  items, want_imgs = proto_driver.pileups_of_sites(opts, region, picks)
   want_img = np.stack(want_imgs).reshape(len(items), -1)
   idx = torch.tensor(items, dtype=torch.long, device=images.device)
   got_img = images.index_select(0, idx).cpu().numpy().reshape(len(items), -1)

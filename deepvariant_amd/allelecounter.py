@@ -252,8 +252,15 @@ class AlleleCounter:
     options = (C.c_void_p * n)(*[C.addressof(r[1]) for r in requests])
     handles = (C.c_void_p * n)()
     _lib.check(_lib.lib().dv_count_alleles_batch(n, batches, options, handles, None))
-    for c, r, h in zip(todo, requests, handles):
-      c._take(C.c_void_p(h), r[3])                         # pylint: disable=protected-access
+    taken = 0
+    try:
+      for c, r, h in zip(todo, requests, handles):
+        taken += 1                                         # _take frees its handle, also when it raises
+        c._take(C.c_void_p(h), r[3])                       # pylint: disable=protected-access
+    finally:
+      for h in list(handles)[taken:]:                      # a failure part-way: the rest is not leaked
+        if h:
+          _lib.lib().dv_allele_counts_free(C.c_void_p(h))
 
   def _build_alleles(self):
     if self._alleles is not None:

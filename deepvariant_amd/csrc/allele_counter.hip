@@ -331,7 +331,7 @@ int to_device(dv::DeviceBuffer& buf, const T* src, size_t count, int memory, con
     *out = src;
     return DV_OK;
   }
-  if (int rc = buf.reserve(std::max<size_t>(count, 1) * sizeof(T))) return rc;
+  if (int rc = buf.reserve_on_current_device(std::max<size_t>(count, 1) * sizeof(T))) return rc;
   DV_HIP_CHECK(hipMemcpyAsync(buf.ptr, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
   *out = static_cast<const T*>(buf.ptr);
   return DV_OK;
@@ -467,7 +467,7 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   if (int rc = to_device(up[4], b->bases, b->n_bases, b->memory, &a.bases, stream)) return rc;
   if (int rc = to_device(up[5], b->quals, b->n_bases, b->memory, &a.quals, stream)) return rc;
   if (int rc = to_device(up[6], b->cigar, b->n_cigar, b->memory, &a.cigar, stream)) return rc;
-  if (int rc = d_ref.reserve(static_cast<size_t>(o->n_ref_bases))) return rc;
+  if (int rc = d_ref.reserve_on_current_device(static_cast<size_t>(o->n_ref_bases))) return rc;
   DV_HIP_CHECK(hipMemcpyAsync(d_ref.ptr, o->ref_bases, static_cast<size_t>(o->n_ref_bases), hipMemcpyHostToDevice,
                               stream));
   a.ref = static_cast<const uint8_t*>(d_ref.ptr);
@@ -489,14 +489,14 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
       const int64_t p = o->candidate_positions[k] - o->interval_start;
       if (p >= 0 && p < len) mask[static_cast<size_t>(p >> 5)] |= 1u << (p & 31);
     }
-    if (int rc = d_mask.reserve(mask.size() * sizeof(uint32_t))) return rc;
+    if (int rc = d_mask.reserve_on_current_device(mask.size() * sizeof(uint32_t))) return rc;
     DV_HIP_CHECK(hipMemcpyAsync(d_mask.ptr, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     DV_HIP_CHECK(hipStreamSynchronize(stream));      // `mask` is a local
     a.candidate_mask = static_cast<const uint32_t*>(d_mask.ptr);
     n_candidate_refs = static_cast<size_t>(o->n_candidate_positions);
   }
-  if (int rc = d_cnt.reserve(static_cast<size_t>(len) * sizeof(int32_t))) return rc;
-  if (int rc = d_ctr.reserve(4 * sizeof(uint32_t))) return rc;
+  if (int rc = d_cnt.reserve_on_current_device(static_cast<size_t>(len) * sizeof(int32_t))) return rc;
+  if (int rc = d_ctr.reserve_on_current_device(4 * sizeof(uint32_t))) return rc;
   a.ref_count = static_cast<int32_t*>(d_cnt.ptr);
   a.counters = static_cast<uint32_t*>(d_ctr.ptr);
   // events: substitutions are a few per cent of the bases, indels at most one per CIGAR op;
@@ -504,7 +504,7 @@ int dv_count_alleles(const dv_batch* b, const dv_allele_counter_options* o, dv_a
   uint32_t cap = b->n_cigar + b->n_bases / 16 + 4096 + static_cast<uint32_t>(std::min<size_t>(n_candidate_refs * 64, 1u << 24));
   uint32_t ctr[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; ++pass) {
-    if (int rc = d_ev.reserve(static_cast<size_t>(cap) * sizeof(dv_allele_event))) return rc;
+    if (int rc = d_ev.reserve_on_current_device(static_cast<size_t>(cap) * sizeof(dv_allele_event))) return rc;
     a.events = static_cast<dv_allele_event*>(d_ev.ptr);
     a.event_cap = cap;
     DV_HIP_CHECK(hipMemsetAsync(d_cnt.ptr, 0, static_cast<size_t>(len) * sizeof(int32_t), stream));
@@ -564,6 +564,9 @@ int dv_count_alleles_batch(int32_t n, const dv_batch* const* reads, const dv_all
     }
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  // Everything from here on may have results in out[]: the body runs as one callable so that EVERY error exit
+  // -- the DV_HIP_CHECK returns included -- passes through fail_all ("on an error no result is left allocated").
+  auto body = [&]() -> int {
   struct Plan {
     bool batched = false;
     size_t up[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // staging offsets: read_pos, seq_off, cigar_off, mapq, bases, quals, cigar, ref, mask
@@ -611,9 +614,9 @@ int dv_count_alleles_batch(int32_t n, const dv_batch* const* reads, const dv_all
     const size_t ctr_bytes = align16(static_cast<size_t>(n) * 4 * sizeof(uint32_t));
     const size_t res_bytes = ctr_bytes + cnt_ints * sizeof(int32_t);
     if (int rc = h_up.reserve(up_bytes)) return rc;
-    if (int rc = d_up.reserve(up_bytes)) return rc;
-    if (int rc = d_res.reserve(res_bytes)) return rc;
-    if (int rc = d_ev.reserve(std::max<size_t>(ev_total, 1) * sizeof(dv_allele_event))) return rc;
+    if (int rc = d_up.reserve_on_current_device(up_bytes)) return rc;
+    if (int rc = d_res.reserve_on_current_device(res_bytes)) return rc;
+    if (int rc = d_ev.reserve_on_current_device(std::max<size_t>(ev_total, 1) * sizeof(dv_allele_event))) return rc;
     for (int32_t k = 0; k < n; ++k) {
       const Plan& p = plan[k];
       if (!p.batched) continue;
@@ -732,9 +735,12 @@ int dv_count_alleles_batch(int32_t n, const dv_batch* const* reads, const dv_all
   }
   for (int32_t k = 0; k < n; ++k) {
     if (out[k]) continue;
-    if (int rc = dv_count_alleles(reads[k], options[k], &out[k], stream_v)) return fail_all(rc);
+    if (int rc = dv_count_alleles(reads[k], options[k], &out[k], stream_v)) return rc;
   }
   return DV_OK;
+  };
+  const int rc = body();
+  return rc == DV_OK ? DV_OK : fail_all(rc);
 }
 
 int dv_allele_counts_arrays(const dv_allele_counts* c, const int32_t** ref_supporting_read_count,

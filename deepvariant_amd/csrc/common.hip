@@ -20,9 +20,19 @@ int fail(int status, const std::string& msg) {
   return status;
 }
 
+// For function-local static / thread_local scratch, which outlives a hipSetDevice: a buffer belongs to the
+// device that was current when it was allocated, and memory of another device must not be handed to a kernel
+// of this one.  (Object-owned buffers -- a model's, an encoder's -- call reserve(): their owner sets the device.)
+int DeviceBuffer::reserve_on_current_device(size_t bytes) {
+  int now = -1;
+  if (ptr != nullptr && hipGetDevice(&now) == hipSuccess && now != device) release();
+  return reserve(bytes);
+}
+
 int DeviceBuffer::reserve(size_t bytes) {
   if (bytes <= cap) return DV_OK;
   release();
+  (void)hipGetDevice(&device);
   size_t want = std::max<size_t>(bytes + bytes / 4, 256);
   hipError_t e = hipMalloc(&ptr, want);
   if (e != hipSuccess) {

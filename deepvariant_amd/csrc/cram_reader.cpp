@@ -296,6 +296,9 @@ void rans_decode(const uint8_t* in, size_t n_in, std::vector<uint8_t>* out) {
   const int order = c.u8();
   c.le32();                       // compressed size
   const uint32_t out_size = c.le32();
+  // rANS 4x8 cannot expand by more than its 12-bit frequency resolution allows per symbol: refuse sizes a few
+  // bytes of input could not have produced before allocating them (a 9-byte block may not ask for 4 GiB)
+  if (static_cast<uint64_t>(out_size) > (static_cast<uint64_t>(n_in) + 16) * 4096) bad("rANS block states an impossible size");
   out->assign(out_size, 0);
   if (out_size == 0) return;
   uint8_t* o = out->data();
@@ -389,6 +392,11 @@ void read_block(Cursor& c, Block* b, bool decode = true) {
   c.take(4);  // CRC32
   b->pos = 0;
   if (!decode) return;
+  // gzip / bzip2 / lzma expand by at most ~1000x / ~50000x (run lengths) in theory, real CRAM blocks by < 100x:
+  // a stated raw size beyond 65536x the payload (+ slack for tiny blocks) is refused before it is allocated
+  if (method != 0 && static_cast<uint64_t>(rsize) > (static_cast<uint64_t>(csize) + 64) * 65536) {
+    bad("CRAM block states an impossible uncompressed size");
+  }
   switch (method) {
     case 0:
       b->data = payload;
@@ -520,10 +528,12 @@ struct Decoder {
       case 6:
         offset = itf8(c);
         nbits = itf8(c);
+        if (nbits < 0 || nbits > 32) bad("bad BETA bit count");
         break;
       case 7:
         offset = itf8(c);
         nbits = itf8(c);   // k
+        if (nbits < 0 || nbits > 32) bad("bad SUBEXP k");
         break;
       case 9:
         offset = itf8(c);
@@ -548,12 +558,13 @@ struct Decoder {
         if (constant) return only;
         // canonical decode: codes of one length are consecutive, the first of a longer length is
         // (last of the shorter + 1) shifted
-        int32_t code = 0, first = 0, index = 0;
+        uint64_t code = 0, first = 0;   // 64-bit unsigned: a 32-bit code shifted once more stays defined
+        int64_t index = 0;
         for (int len = 1; len <= 32; ++len) {
-          code |= static_cast<int32_t>(core->read(1));
-          const int n = count[len];
-          if (code - first < n) return syms[static_cast<size_t>(index + (code - first))];
-          index += n;
+          code |= static_cast<uint64_t>(core->read(1));
+          const uint64_t n = static_cast<uint64_t>(count[len]);
+          if (code >= first && code - first < n) return syms[static_cast<size_t>(index + static_cast<int64_t>(code - first))];
+          index += static_cast<int64_t>(n);
           first += n;
           first <<= 1;
           code <<= 1;
@@ -567,7 +578,7 @@ struct Decoder {
         while (core->read(1)) ++n;
         if (n == 0) return static_cast<int32_t>(core->read(nbits)) - offset;
         const int bits = n + nbits - 1;
-        if (bits > 31) bad("bad SUBEXP value");
+        if (bits < 0 || bits > 31) bad("bad SUBEXP value");
         return static_cast<int32_t>((1u << bits) | core->read(bits)) - offset;
       }
       case 9: {
@@ -782,7 +793,7 @@ struct CramFile {
   }
 
   ContainerHeader container(size_t i) const {
-    if (i + 4 > size) bad("truncated CRAM container");
+    if (i > size || size - i < 4) bad("truncated CRAM container");   // (i + 4 would wrap for an offset near 2^64)
     Cursor c{buf + i, buf + size};
     const int32_t length = static_cast<int32_t>(c.le32());
     if (length < 0) bad("negative CRAM container length");
@@ -852,6 +863,8 @@ struct CramFile {
         if (r[0] != want || r[1] - 1 >= end || r[1] - 1 + r[2] <= start) continue;
         if (std::find(seen.begin(), seen.end(), r[3]) != seen.end()) continue;
         seen.push_back(r[3]);
+        // the offsets come from a text file: never trust them further than the bytes that are there
+        if (r[1] < 0 || r[2] < 0 || r[3] < 0 || static_cast<uint64_t>(r[3]) >= size) bad("CRAM index (.crai) row outside the file");
         ContainerHeader h = container(static_cast<size_t>(r[3]));
         if (h.n_blocks > 0) out.push_back(std::move(h));
       }
@@ -1040,7 +1053,8 @@ bool decode_slice(const CramFile& f, const CompressionHeader& ch, size_t at, int
     return scratch.data();
   };
 
-  out->recs.reserve(static_cast<size_t>(n_records));
+  // (a record count is an itf8 from the file: reserve what a slice can plausibly hold, grow for the rest)
+  out->recs.reserve(static_cast<size_t>(std::min<int32_t>(std::max<int32_t>(n_records, 0), 1 << 20)));
   int32_t prev_pos = s_start;
   std::vector<uint8_t> tmp;
   for (int32_t rec_i = 0; rec_i < n_records; ++rec_i) {

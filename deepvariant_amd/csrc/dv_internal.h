@@ -28,7 +28,9 @@ int fail(int status, const std::string& msg);
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t cap = 0;
+  int device = -1;   // the device `ptr` was allocated on (reserve() re-allocates after a device change)
   int reserve(size_t bytes);
+  int reserve_on_current_device(size_t bytes);
   void release();
 };
 

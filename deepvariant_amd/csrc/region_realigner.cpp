@@ -20,9 +20,13 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "debruijn_graph.h"
 #include "dv_internal.h"
@@ -67,6 +71,15 @@ class WorkerPool {
     const int helpers = std::min(n_threads, n) - 1;
     {
       std::lock_guard<std::mutex> hold(lock_);
+      if (pid_ != getpid()) {
+        // after fork() the helper threads do not exist in the child: forget them (their std::thread objects are
+        // leaked on purpose -- destroying a joinable one terminates) and start over with this process's own
+        pid_ = getpid();
+        (void)new std::vector<std::thread>(std::move(threads_));
+        threads_.clear();
+        wanted_ = busy_ = 0;
+      }
+      error_.clear();
       while (static_cast<int>(threads_.size()) < helpers) threads_.emplace_back([this] { worker(); });
       tasks_ = &tasks;
       fn_ = &fn;
@@ -81,6 +94,7 @@ class WorkerPool {
     done_.wait(hold, [this] { return busy_ == 0; });
     tasks_ = nullptr;
     fn_ = nullptr;
+    if (!error_.empty()) throw std::runtime_error(error_);   // on the CALLING thread, after every helper has let go
   }
 
  private:
@@ -89,8 +103,23 @@ class WorkerPool {
     for (;;) {
       const int i = next_.fetch_add(1, std::memory_order_relaxed);
       if (i >= n) return;
-      (*fn_)((*tasks_)[i]);
+      // an exception (std::bad_alloc, length_error ...) must neither leave a helper thread (std::terminate) nor
+      // unwind the caller while helpers still hold tasks_ / fn_: the first one is kept, the rest of the job is
+      // skipped, run() rethrows it once everybody is done
+      try {
+        (*fn_)((*tasks_)[i]);
+      } catch (const std::exception& e) {
+        fail_job(e.what());
+      } catch (...) {
+        fail_job("unknown exception in a realigner task");
+      }
     }
+  }
+
+  void fail_job(const char* what) {
+    std::lock_guard<std::mutex> hold(lock_);
+    if (error_.empty()) error_ = what;
+    next_.store(1 << 30, std::memory_order_relaxed);
   }
 
   void worker() {
@@ -118,6 +147,8 @@ class WorkerPool {
   std::atomic<int> next_{0};
   int wanted_ = 0, busy_ = 0;
   uint64_t generation_ = 0;
+  std::string error_;
+  pid_t pid_ = getpid();
 };
 
 void parallel_tasks(const std::vector<int>& tasks, int n_threads, const std::function<void(int)>& fn) {
@@ -135,8 +166,25 @@ std::vector<int> longest_first(const std::vector<int64_t>& cost) {
 
 extern "C" {
 
+static int realign_regions_impl(const dv_realign_region* regions, int32_t n_regions, const dv_realign_options* o,
+                                dv_realign_result** out, dv_realign_output* arrays);
+
+// The exception barrier of the entry point: nothing unwinds through extern "C" into ctypes.
 int dv_realign_regions(const dv_realign_region* regions, int32_t n_regions, const dv_realign_options* o,
                        dv_realign_result** out, dv_realign_output* arrays) {
+  try {
+    return realign_regions_impl(regions, n_regions, o, out, arrays);
+  } catch (const std::bad_alloc&) {
+    if (out) *out = nullptr;
+    return dv::fail(DV_ERR_OUT_OF_MEMORY, "dv_realign_regions: out of host memory");
+  } catch (const std::exception& e) {
+    if (out) *out = nullptr;
+    return dv::fail(DV_ERR_BAD_INPUT, std::string("dv_realign_regions: ") + e.what());
+  }
+}
+
+static int realign_regions_impl(const dv_realign_region* regions, int32_t n_regions, const dv_realign_options* o,
+                                dv_realign_result** out, dv_realign_output* arrays) {
   if (!out || !arrays || !o || n_regions < 0 || (n_regions > 0 && !regions)) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_realign_regions: null argument");
   }

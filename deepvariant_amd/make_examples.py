@@ -686,16 +686,27 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
   sink = _MemorySink()
   # RCCL wants one rank per GPU; ranks that share a GPU exchange their (host) records over gloo
   device = torch.device('cuda', args.device) if on_gpu and dist.get_backend() == 'nccl' else None
+  import time
+  t_runner = time.perf_counter()
   try:
     stats = make_examples_runner(args, log=log, hooks=hooks, sink=sink)
-  except BaseException:
-    # tell the peers before leaving: they would otherwise sit in the all-gather until the backend's timeout
-    try:
-      dvd.gather_records([], device=device, failed=True)
-    except dvd.PeerFailed:
-      pass
+  except BaseException as err:
+    # tell the peers before leaving: they would otherwise sit in the all-gather until the backend's timeout.
+    # The notification is itself a collective: it is skipped when there is no process group (any more) or
+    # when the failure CAME from a collective (a second, mismatched all-gather could hang instead of
+    # exiting), and nothing it raises may replace the original error -- the `raise` below always runs.
+    notify = dist.is_available() and dist.is_initialized() and not isinstance(err, dvd.PeerFailed) and \
+        not getattr(err, 'from_collective', False) and 'ProcessGroup' not in type(err).__name__ and \
+        'DistBackendError' not in type(err).__name__
+    if notify:
+      try:
+        dvd.gather_records([], device=device, failed=True)
+      except BaseException:      # pylint: disable=broad-except
+        pass
     raise
+  t_gather = time.perf_counter()
   per_rank = dvd.gather_records(sink.records, device=device)
+  t_write = time.perf_counter()
   if rank == 0:
     for r, records in enumerate(per_rank):
       writer = tfrecord.Writer(sharded_file_utils.sharded_filename(spec, r))
@@ -707,6 +718,9 @@ def distributed_runner(args, rank: int, world: int, log=sys.stderr, hooks: Optio
     print('make_examples --gpus %d: %s CallVariantsOutputs gathered from %d ranks -> %s' % (
         world, '+'.join(str(len(x)) for x in per_rank), world, spec), file=log)
   stats['n_gathered'] = sum(len(x) for x in per_rank)
+  # where this rank's time went: its own region loop (incl. set-up), the record exchange (which also waits for
+  # the slowest rank), rank 0's shard files
+  stats['runner_s'], stats['gather_s'], stats['write_s'] = t_gather - t_runner, t_write - t_gather, time.perf_counter() - t_write
   return stats
 
 

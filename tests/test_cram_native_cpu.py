@@ -474,3 +474,20 @@ def test_template_lengths_of_attached_mates_follow_htslib(files):
   assert t.read_frag_len.tolist() == [220, 0, -220, 321]
   assert [int(f) & 1 for f in t.read_flags] == [0, 0, 1, 0]
   _same_tables(t, _python_table(path, _fetch([contig]), 'c1'))
+
+
+@pytest.mark.parametrize('offset', [-1, -2, -4, -(1 << 40), 1 << 62, (1 << 63) - 1])
+def test_index_rows_that_point_outside_the_file_are_refused(files, offset):
+  """A .crai is gzip text: its container offsets are checked against the file before anything is read through
+  them (an offset of -1 ... -4 used to wrap the bounds check and crash the process)."""
+  import gzip
+  ref = genomics_io.FastaReader(files['fasta'])
+  bad = os.path.join(files['tmp'], 'bad_index_%d.cram' % (offset & 0xffff))
+  shutil.copy(files['na12878_cram'], bad)
+  with gzip.open(files['na12878_crai'], 'rt') as f:
+    rows = [l.rstrip('\n').split('\t') for l in f if l.strip()]
+  rows[len(rows) // 2][3] = str(offset)
+  with gzip.open(bad + '.crai', 'wt') as f:
+    f.write(''.join('\t'.join(r) + '\n' for r in rows))
+  with pytest.raises((ValueError, RuntimeError, _lib.DvError)):
+    packing.ReadTable.from_cram(bad, ref.get_bases, 'chr20', 10_000_000, 10_100_000)

@@ -90,6 +90,42 @@ def test_gather_records_world2():
     assert empty == [[], []]
 
 
+def _big_records_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from deepvariant_amd import dist as dvd
+  mine = [bytes([(rank * 37 + i) % 251]) * (50 + (11 * i) % 200) for i in range(400 + 30 * rank)] + [b'']
+  assert sum(map(len, mine)) > dvd._SHM_MIN_BYTES          # pylint: disable=protected-access
+  import glob
+  before = set(glob.glob('/dev/shm/dvamd-*'))
+  shm = dvd.gather_records(mine)                   # host ranks of one node: through /dev/shm
+  os.environ['DV_NO_SHM_EXCHANGE'] = '1'
+  tcp = dvd.gather_records(mine, max_chunk_bytes=7000)     # the collective, several chunks
+  dist.barrier()
+  left = set(glob.glob('/dev/shm/dvamd-*')) - before
+  q.put((rank, shm == tcp, [len(x) for x in shm], shm[rank] == mine, sorted(left)))
+  dist.destroy_process_group()
+
+
+def test_gather_records_through_shared_memory_equals_the_collective_world3():
+  world = 3
+  port = _free_port()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_big_records_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = sorted(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for _, same, counts, own, left in results:
+    assert same and own
+    assert counts == [401, 431, 461]
+    assert left == []                              # the exchange directory is gone
+
+
 def _failing_worker(rank, world, port, q):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
