@@ -220,6 +220,9 @@ def build_arg_parser():
   ap.add_argument('--stream_examples', **boolean)
   ap.add_argument('--allow_empty_examples', **boolean)
   ap.add_argument('--device', type=int, default=0)
+  # not a reference flag: the fp16 classifier's shifts are calibrated (dv_model_calibrate) on the first examples of
+  # the run -- up to this many, at least 64 -- before they are classified; 0 = the uncalibrated fp16 model
+  ap.add_argument('--calibration_examples', type=int, default=256)
   return ap
 
 
@@ -338,6 +341,8 @@ def main(argv=None) -> int:
   from deepvariant_amd.inception_v3 import InceptionV3
   model = InceptionV3(tuple(shape), max_batch=min(args.batch_size, 8192), device=args.device)
   load_flat_checkpoint(args.checkpoint, model)
+  if args.calibration_examples > 0:
+    model.enable_auto_calibration(max_images=args.calibration_examples)
   n = call_variants(paths, args.outfile, model,
                     batch_size=args.batch_size, max_batches=args.max_batches,
                     writer_shards=max(1, min(args.writer_threads or 1, 16)),

@@ -7,7 +7,7 @@
 // builds the backbone; SURVEY.md App. B has the graph).  Per layer these launches spent about
 // half of their time outside the K loop (prologue, output stores, fill / drain:
 // profiles/r02_conv_ablation.txt) and fetched their pixel operand through the vector L1,
-// which is what bounded them (TA 87-89 % busy).  Here
+// which is what bounded them (TA 87-89 % busy, HISTORY.md 7).  Here
 //   * a workgroup owns a tile of G WHOLE images (G * h * w <= 192 pixels = 6 MFMA fragments)
 //     and walks the whole chain on it: the c-channel intermediate (<= 74 KB) lives in ONE LDS
 //     buffer that is rewritten in place between layers -- a layer's full output sits in the

@@ -82,21 +82,21 @@ struct ConvArgs {
   // neighbouring cout tiles of one pixel tile (they then share its L1 lines)
   int cu_pair;
   float rcp_ow, rcp_ohow; // 1/OW, 1/(OH*OW) for the prologue's index split
-  // Blank-row skipping (opt-in, DV_BLANK_SKIP): blank_row[n] = first output row of
+  // Blank-row skipping (opt-in, DV_BLANK_SKIP; HISTORY.md 7): blank_row[n] = first output row of
   // example n whose receptive field lies entirely in the zero rows below the pile-up.  Such
   // outputs equal the response of the all-blank image at the same position (blank_src: ONE
   // example in the output tensor's geometry), so a block whose pixels all lie there copies
   // instead of multiplying -- bit-identical.  Single-branch launches only; NULL = off.
   const int* blank_row;
   const _Float16* blank_src;
-  // Split weights (model.hip): the packed image holds every K chunk twice, W_hi then
+  // Split weights (model.hip, HISTORY.md 15): the packed image holds every K chunk twice, W_hi then
   // W_lo = fp16(W - W_hi); n_chunks counts both, the pixel operand advances once per pair.
   // split_tiles: the leading cout tiles of the launch that carry such pairs (= n_tiles when every
   // branch is split); the tiles behind them hold plain weights in the first half of their slot
-  // (sibling 1x1 heads of which only some are split).
+  // (sibling 1x1 heads of which only some are split, HISTORY.md 15).
   int split;
   int split_tiles;
-  // Side max-pool (model.hip choose_side_pool): a 3x3 / stride-2 'valid' convolution
+  // Side max-pool (model.hip choose_side_pool, HISTORY.md 4.11): a 3x3 / stride-2 'valid' convolution
   // loads, per 16-channel chunk, exactly the nine pieces of the 3x3 / stride-2 max-pool window of
   // each of its output pixels.  The workgroups of cout tile 0 keep their running maximum and store
   // it -- the sibling MaxPooling2D(3, 2) of the reduction block without its own launch.

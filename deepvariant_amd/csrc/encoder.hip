@@ -550,54 +550,32 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
         const uint32_t cg = __builtin_amdgcn_readlane(cg_v, k);
         const int op = cg & 0xF;
         const int len = cg >> 4;
-        switch (op) {
-          case DV_CIGAR_ALIGNMENT_MATCH:
-          case DV_CIGAR_SEQUENCE_MATCH:
-          case DV_CIGAR_SEQUENCE_MISMATCH:
+        // Branch-free: every operation writes at most ONE run of events -- columns [ev_start, ev_start + ev_count)
+        // receive (ev_code, ri_base + offset in the run):
+        //   M / = / X   the aligned bases:              [ref_i, ref_i + len)   code 1, read_i + d
+        //   I           its anchor (if ref_i > 0):      [ref_i - 1, ref_i)     code 2, read_i
+        //   D           its anchor (if read_i > 0):     [ref_i - 1, ref_i)     code 2, read_i - 1
+        //   N, S, H, P  nothing (count 0)
+        // All of that is wave-uniform scalar arithmetic; a lane spends five vector instructions per column and
+        // operation, without the switch's branches and register copies (a long-read CIGAR has a dozen operations
+        // per read).  Same events in the same order as the reference's walk (pileup_channel_lib.cc:171-261).
+        const bool is_m = op == DV_CIGAR_ALIGNMENT_MATCH || op == DV_CIGAR_SEQUENCE_MATCH ||
+                          op == DV_CIGAR_SEQUENCE_MISMATCH;
+        const bool is_i = op == DV_CIGAR_INSERT, is_d = op == DV_CIGAR_DELETE;
+        const int ev_start = is_m ? ref_i : ref_i - 1;
+        const unsigned ev_count = is_m ? static_cast<unsigned>(len)
+                                       : ((is_i && ref_i > 0) || (is_d && read_i > 0)) ? 1u : 0u;
+        const int ev_code = is_m ? 1 : 2;
+        const int ri_base = is_d ? read_i - 1 : read_i;
 #pragma unroll
-            for (int q = 0; q < kColsPerLane; ++q) {
-              const int d = istart + cb0 + q * 64 + lane - ref_i;
-              if (d >= 0 && d < len) {
-                in.ev[q] = 1;
-                in.ri[q] = read_i + d;
-              }
-            }
-            ref_i += len;
-            read_i += len;
-            break;
-          case DV_CIGAR_INSERT:
-            if (ref_i > 0) {
-#pragma unroll
-              for (int q = 0; q < kColsPerLane; ++q) {
-                if (istart + cb0 + q * 64 + lane == ref_i - 1) {
-                  in.ev[q] = 2;
-                  in.ri[q] = read_i;
-                }
-              }
-            }
-            read_i += len;
-            break;
-          case DV_CIGAR_CLIP_SOFT:
-            read_i += len;
-            break;
-          case DV_CIGAR_DELETE:
-            if (read_i > 0) {
-#pragma unroll
-              for (int q = 0; q < kColsPerLane; ++q) {
-                if (istart + cb0 + q * 64 + lane == ref_i - 1) {
-                  in.ev[q] = 2;
-                  in.ri[q] = read_i - 1;
-                }
-              }
-            }
-            ref_i += len;
-            break;
-          case DV_CIGAR_SKIP:
-            ref_i += len;
-            break;
-          default:
-            break;
+        for (int q = 0; q < kColsPerLane; ++q) {
+          const unsigned d = static_cast<unsigned>(istart + cb0 + q * 64 + lane - ev_start);
+          const bool hit = d < ev_count;
+          in.ev[q] = hit ? ev_code : in.ev[q];
+          in.ri[q] = hit ? ri_base + static_cast<int>(d) : in.ri[q];
         }
+        ref_i += (is_m || is_d || op == DV_CIGAR_SKIP) ? len : 0;
+        read_i += (is_m || is_i || op == DV_CIGAR_CLIP_SOFT) ? len : 0;
       }
     }
     // UNCONDITIONAL loads (columns without an event read the read's first base / the window's
@@ -725,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
 
   // ---- read rows.  A row's pixels hang on a chain of dependent loads (row order -> CIGAR ->
   // bases): ~1.5 us of latency against ~0.3 us of work, which is what bounded this kernel at
-  // 0.28 of the HBM roofline.  The wave therefore runs its rows as a two-stage
+  // 0.28 of the HBM roofline (HISTORY.md 4.1).  The wave therefore runs its rows as a two-stage
   // software pipeline: the NEXT row's walk runs and its byte loads are issued before the
   // CURRENT row's pixels are drawn, so those loads travel under a whole row of work; the CIGAR
   // itself comes from LDS (phase C').  Single-pass images (W <= 256: every BASELINE shape) whose

@@ -14,7 +14,7 @@
 // (scale=False, eps=1e-3, moving statistics) is folded into the fp16 conv
 // weights and an fp32 per-channel shift at load time.
 //
-// Kernels (DESIGN.md 4.2 has the measurements behind each choice)
+// Kernels (HISTORY.md 4.2 has the measurements behind each choice)
 //   conv_mfma_kernel<NB,PT>   implicit-GEMM conv + shift + ReLU on v_mfma_f32_32x32x16_f16:
 //                             D[cout][pixel] = sum_k W[cout][k] X[k][pixel]; a wave owns
 //                             PT*32 pixels x NB*32 couts; weights stream through LDS in
@@ -62,7 +62,7 @@ constexpr int kFirstUnroll = 5;  // conv_first_u8_kernel: chunks of a 3x3 filter
 constexpr int kSlabChunks = 8;   // K chunks (of 16 channels) per weight slab
 // Pixel-operand prefetch depth, in chunks, per tile shape.  Measured on MI355X: 8 or 16
 // instead of 4 changes nothing (+-1 %) for thin, mid or big tiles -- the queue is not what
-// the waves wait for -- so every shape uses 4.
+// the waves wait for (HISTORY.md 7) -- so every shape uses 4.
 constexpr int prefetch_depth(int /*nb*/, int /*pt*/) { return 4; }
 
 // Wave-uniform walk over the K chunks kept in SGPRs and advanced with selects
@@ -256,7 +256,7 @@ template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChu
           bool SPLIT = false, bool SIDE_POOL = false, bool AVG = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
-  constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8)
+  constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8, HISTORY.md 7)
   constexpr int SLAB_HALFS = SLAB * BN * kChunk;
   constexpr int SLAB_PIECES = SLAB_HALFS / 8;            // 16-byte pieces
   constexpr int W_PER_THREAD = SLAB_PIECES / kThreads;   // = 2 * NB with four waves
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
 }
 
 // Resident-weight variant of conv_mfma_kernel for layers whose whole cout tile fits the CU's LDS
-// (K * NB*32 halfs <= ~150 KB: the 3x3 80->192, short-K 1x1 heads).  DESIGN.md 7: halving a
+// (K * NB*32 halfs <= ~150 KB: the 3x3 80->192, short-K 1x1 heads).  HISTORY.md 7: halving a
 // launch's MFMA work and pixel traffic moved it by 10 %, so what a block of the streaming
 // kernel waits for is its weight slabs (global -> registers -> LDS behind a barrier per slab,
 // 138 KB per 256-pixel block on the 3x3 80->192).  Here a PERSISTENT block of eight waves
@@ -1395,7 +1395,7 @@ struct dv_model {
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
-  // opt-in blank-row skipping (DV_BLANK_SKIP=1)
+  // opt-in blank-row skipping (DV_BLANK_SKIP=1; HISTORY.md 7)
   bool blank_skip = false;        // requested and applicable to this model
   bool blank_ready = false;       // the blank responses have been computed (after load_weights)
   int blank_conv4_op = -1;        // op index of the stem's 3x3 80->192
@@ -1693,7 +1693,7 @@ struct dv_model {
     }
   }
 
-  // Split weights.  The fp16 rounding of the BN-folded weights is ~3/4 of the variance
+  // Split weights (HISTORY.md 15).  The fp16 rounding of the BN-folded weights is ~3/4 of the variance
   // of the CNN's error against the fp32 reference (tools/r4_layer_sensitivity.py: a flat budget, no
   // layer above 3.5 %), and it is the half that a kernel can remove without touching its pixel
   // operand.  Selected conv_mfma_kernel launches therefore carry W as W_hi + W_lo (both fp16,
@@ -2089,7 +2089,7 @@ struct dv_model {
 namespace {
 
 // 192-cout tiles (NB = 6), one pixel fragment per wave: the pixel operand -- the texture-
-// addresser path that bounds the other shapes -- is fetched once for all 192
+// addresser path that bounds the other shapes (HISTORY.md 7) -- is fetched once for all 192
 // couts instead of once per 96-cout tile.  Weight slabs of 4 chunks keep two blocks per CU.
 void launch_conv6(const ConvArgs& a, hipStream_t stream) {
   const long rows = a.band ? a.band : 1;
@@ -2153,7 +2153,7 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
       return;
     }
   }
-  // tuning experiments: 4-chunk weight slabs; 8-wave blocks of 512 pixels
+  // tuning experiments (HISTORY.md 7): 4-chunk weight slabs; 8-wave blocks of 512 pixels
   static const bool slab4 = getenv("DV_CONV_SLAB4") != nullptr;
   static const bool w8 = getenv("DV_CONV_W8") != nullptr;
   if constexpr (NB >= 3 && NB <= 4) {
@@ -2241,7 +2241,8 @@ bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
   if (mode == 0 || op.nb != 3 || op.band || op.v2 || op.pool_in || op.split || a.blank_row != nullptr) return false;
   const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
   if (lds > 150 * 1024 || m->n_cus < 8 * a.n_tiles) return false;
-  if (static_cast<long>(a.M) < static_cast<long>(m->n_cus) * 8 * 64 * 4) return false;
+  static const long min_tiles = getenv("DV_RESIDENT_MIN_TILES") ? atol(getenv("DV_RESIDENT_MIN_TILES")) : 4;   // tuning knob
+  if (static_cast<long>(a.M) < static_cast<long>(m->n_cus) * 8 * 64 * min_tiles) return false;
   if (mode >= 2) return true;
   return m->blank_conv4_op >= 0 && &op == &m->ops[m->blank_conv4_op];
 }
@@ -2748,7 +2749,7 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
   if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
   if (int rc = m->d_ext.reserve(sizeof(ExtPtrs))) return rc;
-  // opt-in: skip the stem work that only sees the zero rows below the pile-up;
+  // opt-in: skip the stem work that only sees the zero rows below the pile-up (HISTORY.md 7);
   // needs the uint8 front end, a single-branch 3x3 80->192 and whole dwords per image
   if (getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0 &&
       m->ops[0].first_u8 && m->blank_conv4_op >= 0 && m->ops[m->blank_conv4_op].group_followers == 0 &&

@@ -61,6 +61,15 @@ class InceptionV3(torch.nn.Module):
                                                 flat.size))
     self.flat_weights = flat
 
+  def enable_auto_calibration(self, min_images: int = 64, max_images: int = 256) -> None:
+    """Model preparation inside a run: the FIRST forward that brings at least `min_images` examples calibrates the
+    shifts on up to `max_images` of them (dv_model_calibrate) before it classifies; forwards before that (tiny
+    inputs) run the uncalibrated fp16 model.  What call_variants and make_examples' fused route switch on after
+    loading a checkpoint (`--calibration_examples`, 0 = off): deterministic for a given input, a few hundred
+    milliseconds once per run (profiles/r05_cnn_tail.txt: why)."""
+    self._auto_cal = (int(min_images), int(max_images)) if max_images > 0 else None
+    self.calibrated_on = 0
+
   def calibrate(self, images: torch.Tensor) -> np.ndarray:
     """dv_model_calibrate: moves every layer's fp32 shift by the per-channel mean of the fp16
     pipeline's error on `images` (CUDA uint8 [N,H,W,C], a few hundred examples drawn like the inputs
@@ -113,6 +122,12 @@ class InceptionV3(torch.nn.Module):
                        (tuple(images.shape[1:]), self.input_shape))
     images = images.contiguous()
     n = images.shape[0]
+    auto = getattr(self, '_auto_cal', None)
+    if auto is not None and n >= auto[0] and self.flat_weights is not None:
+      self._auto_cal = None
+      self.calibrated_on = min(n, auto[1])
+      torch.cuda.current_stream(images.device).synchronize()
+      self.calibrate(images[:self.calibrated_on])
     # dv_model_infer replays the forward as a hipGraph keyed by (n, stream) -- the image and
     # output pointers travel through a device-side table, so fresh tensors replay the same
     # graph.  The output lives in a model-owned buffer per batch size; callers get their own

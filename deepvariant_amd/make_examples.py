@@ -149,6 +149,8 @@ def build_arg_parser() -> argparse.ArgumentParser:
   # window realigner, candidate caller); R ranks share one GPU, as N make_examples processes share
   # the reference's call_variants GPU.  world = gpus * ranks_per_gpu, rank r runs on GPU r // R
   ap.add_argument('--ranks_per_gpu', type=int, default=1)
+  # fused route: as call_variants' flag of the same name (examples the fp16 classifier's shifts are calibrated on)
+  ap.add_argument('--calibration_examples', type=int, default=256)
   return ap
 
 
@@ -496,6 +498,9 @@ class RunnerHooks:
     # each own a model, and a 1 kb region rarely yields more than a few dozen examples
     model = InceptionV3(shape, max_batch=512 if args.ranks_per_gpu == 1 else 256, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
+    if getattr(args, 'calibration_examples', 256) > 0:
+      # the first forward of >= 64 examples (the fused route classifies 256 at a time) calibrates the shifts
+      model.enable_auto_calibration(max_images=args.calibration_examples)
     return model
 
 

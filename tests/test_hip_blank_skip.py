@@ -1,4 +1,4 @@
-"""Opt-in blank-row skipping (DV_BLANK_SKIP=1) against the default kernels (GPU).
+"""Opt-in blank-row skipping (DV_BLANK_SKIP=1, HISTORY.md 7) against the default kernels (GPU).
 
 Stem outputs whose receptive field sees only the zero rows below the pile-up are copied from
 the all-blank image's response instead of being computed.  That must be invisible: the stem

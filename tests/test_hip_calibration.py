@@ -122,3 +122,25 @@ def test_calibrate_argument_errors():
   assert rc == _lib.DV_ERR_INVALID_ARGUMENT
   with pytest.raises(ValueError):
     m.calibrate(x.cpu())
+
+
+def test_auto_calibration_is_the_manual_calibration_on_the_first_large_batch():
+  """What call_variants / make_examples switch on (--calibration_examples): forwards of fewer than 64 examples
+  leave the model alone, the first larger one calibrates on its leading 256 and then classifies."""
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  ref = R.make_random_model(7, seed=57)
+  x = _images(shape, 320, seed=818)
+  manual = _model(shape, ref.export_flat(), 320)
+  plain = manual(x).cpu().numpy()
+  manual.calibrate(x[:256])
+  want = manual(x).cpu().numpy()
+  auto = _model(shape, ref.export_flat(), 320)
+  auto.enable_auto_calibration()
+  assert np.array_equal(auto(x[:40]).cpu().numpy(), plain[:40])      # too few: uncalibrated, nothing consumed
+  assert auto.calibrated_on == 0
+  got = auto(x).cpu().numpy()
+  assert auto.calibrated_on == 256
+  assert np.array_equal(got, want)
+  assert np.array_equal(auto(x).cpu().numpy(), want)                 # once per model
+  assert not np.array_equal(want, plain)

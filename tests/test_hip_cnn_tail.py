@@ -7,10 +7,11 @@ TAIL: 65,536 encoder-drawn ILLUMINA30 pileups on weight seeds {101, 202, 303} th
 examples of each long-read shape (100x147x10, 100x199x9).  The fp32 oracle runs on the GPU through torch-ROCm
 (tests/cnn_tail.py) after being checked against its CPU form on 256 of the same images.
 
-What is asserted is what profiles/r05_cnn_tail.txt measured, with the reason in DESIGN.md 15: the 99.9th
-percentile of |dp| stays under 1e-3 and the share of candidates over 1e-3 is bounded; the largest |dp| of a
-65,536 sample is reported and bounded at 2e-3 (fp16 activations put sigma(dp) at ~2e-4: a 4.5-sigma event
-per 65 K draws crosses 1e-3 on some seeds).
+What is asserted is the bar itself, with the product's default model preparation -- plain fp16 weights, shifts
+calibrated (dv_model_calibrate) on 256 OTHER pileups: every one of the 65,536 candidates within 1e-3 on every
+held-out seed (profiles/r05_cnn_tail.txt: max |dp| 8.6e-4 / 2.9e-4 / 7.2e-4, none over; without calibration seed 101
+has 11 candidates over, with the round-4 split weights 1).  Why the calibration works and what is left of the
+fp16 error: HISTORY.md 15 and DESIGN.md 6.
 """
 import numpy as np
 import pytest
@@ -62,9 +63,8 @@ def test_illumina30_tail_on_held_out_weight_seeds(seed):
   s = T.tail_stats(got, want)
   print('seed %d: %s' % (seed, T.fmt(s)))
   assert s['prob_spread'] > 5e-2, s                # the random network is not a constant
-  assert s['p999_abs_dp'] <= 1e-3, s
-  assert s['n_over_tol'] <= N_TAIL // 2000, s       # <= 0.05 % of the candidates beyond 1e-3
-  assert s['max_abs_dp'] <= 2e-3, s
+  assert s['n_over_tol'] == 0, s                   # no candidate of the 65,536 beyond 1e-3
+  assert s['max_abs_dp'] <= 1e-3, s
 
 
 @pytest.mark.parametrize('kind,shape', [('hifi', (100, 147, 10)), ('ont', (100, 199, 9))])
