@@ -21,13 +21,16 @@ from tests import cnn_tail as T   # noqa: E402
 from oracle import inception_ref as R   # noqa: E402
 
 
-def build(setting, weights, cal):
+SHAPES = {'illumina': (100, 221, 7), 'hifi': (100, 147, 10), 'ont': (100, 199, 9)}
+
+
+def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   from deepvariant_amd.inception_v3 import InceptionV3
   env = {'split': {'DV_SPLIT_DEFAULT': '1'}, 'none': {'DV_SPLIT_FROM': '94'}, 'cal': {'DV_SPLIT_FROM': '94'},
          'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'}}[setting]
   os.environ.update(env)
   try:
-    m = InceptionV3((100, 221, 7), max_batch=8192)
+    m = InceptionV3(shape, max_batch=max_batch)
   finally:
     for k in env:
       os.environ.pop(k, None)
@@ -42,27 +45,38 @@ def main():
   ap.add_argument('--n', type=int, default=65536)
   ap.add_argument('--seeds', default='101,202,303')
   ap.add_argument('--settings', default='split,none')
-  ap.add_argument('--ncal', type=int, default=256)
+  ap.add_argument('--ncal', default='256', help='calibration images; a comma list repeats the cal* settings per size')
+  ap.add_argument('--workload', default='illumina', choices=sorted(SHAPES))
   args = ap.parse_args()
+  shape = SHAPES[args.workload]
   t0 = time.time()
-  x = T.illumina_pileups_gpu(args.n, seed=424242)
-  print('# %d ILLUMINA30 pileups drawn by the HIP encoder (%.0f s); HIP CNN vs fp32 oracle (torch-ROCm fp32 on the GPU)'
-        % (args.n, time.time() - t0), flush=True)
+  if args.workload == 'illumina':
+    x = T.illumina_pileups_gpu(args.n, seed=424242)
+  else:
+    x = T.longread_images_gpu(args.workload, args.n)
+  print('# %d %s pileups %s drawn by the HIP encoder (%.0f s); HIP CNN vs fp32 oracle (torch-ROCm fp32 on the GPU)'
+        % (args.n, args.workload, shape, time.time() - t0), flush=True)
+  chunk = min(args.n, 8192)
   for seed in [int(s) for s in args.seeds.split(',')]:
-    ref = R.make_random_model(7, seed=seed)
-    ref_gpu = R.make_random_model(7, seed=seed).cuda()
-    d = T.check_gpu_oracle(ref, ref_gpu, x, n=256, tol=1e-5)
+    ref = R.make_random_model(shape[2], seed=seed)
+    ref_gpu = R.make_random_model(shape[2], seed=seed).cuda()
+    d = T.check_gpu_oracle(ref, ref_gpu, x, n=min(256, args.n), tol=1e-5)
     t1 = time.time()
     want = T.oracle_probs_gpu(ref_gpu, x)
     print('# seed %d: GPU oracle vs CPU oracle on 256 images max |dp| %.2e; oracle over the sample %.0f s' % (
         seed, d, time.time() - t1), flush=True)
-    cal = T.illumina_pileups_gpu(args.ncal, seed=990000 + seed)
     w = ref.export_flat()
     for setting in args.settings.split(','):
-      m = build(setting, w, cal)
-      got = T.hip_probs(m, x, 8192)
-      del m
-      print('seed %d %-10s %s' % (seed, setting, T.fmt(T.tail_stats(got, want))), flush=True)
+      for ncal in ([int(v) for v in args.ncal.split(',')] if setting.startswith('cal') else [0]):
+        cal = None
+        if ncal:
+          cal = (T.illumina_pileups_gpu(ncal, seed=990000 + seed) if args.workload == 'illumina'
+                 else T.longread_images_gpu(args.workload, ncal, seed=4711 + seed))
+        m = build(setting, w, cal, shape, chunk)
+        got = T.hip_probs(m, x, chunk)
+        del m
+        label = setting + ('@%d' % ncal if ncal else '')
+        print('seed %d %-14s %s' % (seed, label, T.fmt(T.tail_stats(got, want))), flush=True)
 
 
 if __name__ == '__main__':
