@@ -2487,7 +2487,13 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       // four pixel fragments per wave: 20 outstanding 12-byte loads per lane (+1.7 % end to end
       // over two on MI355X); DV_FIRST_PT2 restores the smaller tile for tuning.
       static const bool first4 = getenv("DV_FIRST_PT2") == nullptr;
-      if (f.wide) {   // nine one-tap chunks, all requested before the first MFMA
+      // wide inputs (9..16 channels): four fragments per wave as well -- 36 outstanding 12-byte loads per lane,
+      // 236 VGPRs; hifi35 504.2 -> 516.6 K, ont50 369.4 -> 376.6 K candidates/s same box (DV_FIRST_WIDE_PT2 restores <2,9>)
+      static const bool wide4 = getenv("DV_FIRST_WIDE_PT2") == nullptr;
+      if (f.wide && wide4) {
+        hipLaunchKernelGGL((conv_first_u8_kernel<4, 9>), dim3((f.M + 511) / 512), dim3(kConvThreads), 0,
+                           stream, f);
+      } else if (f.wide) {   // nine one-tap chunks, all requested before the first MFMA
         hipLaunchKernelGGL((conv_first_u8_kernel<2, 9>), dim3((f.M + 255) / 256), dim3(kConvThreads), 0,
                            stream, f);
       } else if (first4) {
