@@ -3122,6 +3122,32 @@ int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, con
   return prepare_blank_responses(m);
 }
 
+int dv_model_apply_corrections(dv_model* m, const float* corrections, int64_t n) {
+  if (!m || !corrections) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_apply_corrections: null");
+  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_apply_corrections: load weights first");
+  std::vector<const Op*> by_layer(m->layers.size(), nullptr);
+  for (const Op& op : m->ops) {
+    if (op.type == kOpConv) by_layer[op.layer] = &op;
+  }
+  int64_t want = static_cast<int64_t>(m->h_dense_b.size());
+  for (size_t l = 0; l + 1 < m->layers.size(); ++l) want += by_layer[l]->cout;
+  if (n != want) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_apply_corrections: wrong number of corrections");
+  for (int64_t i = 0; i < n; ++i) {
+    if (!std::isfinite(corrections[i])) return dv::fail(DV_ERR_BAD_INPUT, "dv_model_apply_corrections: non-finite correction");
+  }
+  std::vector<float> shift = m->h_shift, dense_b = m->h_dense_b;
+  int64_t at = 0;
+  for (size_t l = 0; l + 1 < m->layers.size(); ++l) {
+    for (int co = 0; co < by_layer[l]->cout; ++co) shift[by_layer[l]->shift_off + co] -= corrections[at++];
+  }
+  for (size_t k = 0; k < dense_b.size(); ++k) dense_b[k] -= corrections[at++];
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  DV_HIP_CHECK(hipDeviceSynchronize());
+  DV_HIP_CHECK(hipMemcpy(m->d_shift.ptr, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+  DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dense_b.data(), dense_b.size() * 4, hipMemcpyHostToDevice));
+  return prepare_blank_responses(m);
+}
+
 // Testing hook: copies activation buffer `index` (NHWC fp16, first n examples)
 // to host memory; returns its shape.  Buffer 0 is the preprocessed input.
 int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t* h,

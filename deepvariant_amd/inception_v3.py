@@ -9,7 +9,7 @@ genotype probabilities.  PyTorch only owns device memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -61,13 +61,54 @@ class InceptionV3(torch.nn.Module):
                                                 flat.size))
     self.flat_weights = flat
 
-  def enable_auto_calibration(self, min_images: int = 64, max_images: int = 256) -> None:
+  def apply_corrections(self, corrections: np.ndarray) -> None:
+    """dv_model_apply_corrections: the shift corrections another model of the SAME weights measured
+    (what `calibrate` returns)."""
+    corr = np.ascontiguousarray(corrections, dtype=np.float32)
+    _lib.check(_lib.lib().dv_model_apply_corrections(self._handle, corr.ctypes.data, corr.size))
+
+  def _calibrate_or_share(self, images: torch.Tensor, share_key: Optional[str]) -> None:
+    """One calibration per (job, GPU, set of weights): with a `share_key` the first process to get here measures and
+    publishes the corrections in /dev/shm, the others apply them (host ranks sharing a GPU would otherwise repeat the
+    same 0.17 s of device work one after the other)."""
+    if not share_key:
+      self.calibrate(images)
+      return
+    import os
+    import tempfile
+    import time
+    import zlib
+    base = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    stamp = zlib.crc32(np.ascontiguousarray(self.flat_weights[::1021]).tobytes()) & 0xffffffff
+    path = os.path.join(base, 'dvamd-cal-%s-%08x-%dx%dx%d.f32' % ((share_key, stamp) + tuple(self.input_shape)))
+    try:
+      os.close(os.open(path + '.lock', os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+      winner = True
+    except FileExistsError:
+      winner = False
+    if winner:
+      import atexit
+      atexit.register(lambda: [os.path.exists(f) and os.remove(f) for f in (path, path + '.lock')])
+      corr = self.calibrate(images)
+      tmp = '%s.tmp%d' % (path, os.getpid())
+      corr.tofile(tmp)
+      os.replace(tmp, path)
+      return
+    deadline = time.monotonic() + 60.0
+    while not os.path.exists(path) and time.monotonic() < deadline:
+      time.sleep(0.002)
+    if os.path.exists(path):
+      self.apply_corrections(np.fromfile(path, np.float32))
+    else:                      # the publishing process died: measure here after all
+      self.calibrate(images)
+
+  def enable_auto_calibration(self, min_images: int = 64, max_images: int = 256, share_key: Optional[str] = None) -> None:
     """Model preparation inside a run: the FIRST forward that brings at least `min_images` examples calibrates the
     shifts on up to `max_images` of them (dv_model_calibrate) before it classifies; forwards before that (tiny
     inputs) run the uncalibrated fp16 model.  What call_variants and make_examples' fused route switch on after
     loading a checkpoint (`--calibration_examples`, 0 = off): deterministic for a given input, a few hundred
     milliseconds once per run (profiles/r05_cnn_tail.txt: why)."""
-    self._auto_cal = (int(min_images), int(max_images)) if max_images > 0 else None
+    self._auto_cal = (int(min_images), int(max_images), share_key) if max_images > 0 else None
     self.calibrated_on = 0
 
   def calibrate(self, images: torch.Tensor) -> np.ndarray:
@@ -127,7 +168,7 @@ class InceptionV3(torch.nn.Module):
       self._auto_cal = None
       self.calibrated_on = min(n, auto[1])
       torch.cuda.current_stream(images.device).synchronize()
-      self.calibrate(images[:self.calibrated_on])
+      self._calibrate_or_share(images[:self.calibrated_on], auto[2])
     # dv_model_infer replays the forward as a hipGraph keyed by (n, stream) -- the image and
     # output pointers travel through a device-side table, so fresh tensors replay the same
     # graph.  The output lives in a model-owned buffer per batch size; callers get their own

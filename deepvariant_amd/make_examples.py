@@ -499,8 +499,14 @@ class RunnerHooks:
     model = InceptionV3(shape, max_batch=512 if args.ranks_per_gpu == 1 else 256, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
     if getattr(args, 'calibration_examples', 256) > 0:
-      # the first forward of >= 64 examples (the fused route classifies 256 at a time) calibrates the shifts
-      model.enable_auto_calibration(max_images=args.calibration_examples)
+      # the first forward of >= 64 examples (the fused route classifies 256 at a time) calibrates the shifts; host
+      # ranks that share a GPU share ONE measurement (the first rank to get there publishes it, inception_v3.py)
+      import os
+      share = None
+      if getattr(args, 'ranks_per_gpu', 1) > 1:
+        share = 'job%s-%s-gpu%d' % (os.environ.get('MASTER_ADDR', 'local').replace('/', '_'),
+                                    os.environ.get('MASTER_PORT', str(os.getppid())), args.device)
+      model.enable_auto_calibration(max_images=args.calibration_examples, share_key=share)
     return model
 
 

@@ -776,6 +776,13 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n);
 int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images,
                        int n_images, float* corrections, int64_t capacity);
 
+/* Applies shift corrections measured elsewhere (ABI v7): `corrections` in the layout dv_model_calibrate
+ * reports -- cout values per convolution in layer order, then num_classes logit corrections; `n` must be
+ * exactly that many.  Replaces any previous correction (the loaded shifts minus these).  For host
+ * processes that share one set of weights -- the ranks of `make_examples --ranks_per_gpu R`: one of them
+ * calibrates, the others apply its result instead of repeating the measurement on the same GPU. */
+int dv_model_apply_corrections(dv_model* m, const float* corrections, int64_t n);
+
 /* preprocess_images ((x-128)/128, deepvariant/dv_utils.py:343-366) + model
  * forward + softmax (deepvariant/call_variants.py:904-932).
  *   images  device uint8 [n, height, width, channels]

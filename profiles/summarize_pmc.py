@@ -24,9 +24,9 @@ def main(path):
     a = agg[(kn, cn)]
     a[0] += v
     a[1].add(did)
-  print('%-64s %-14s %8s %14s %14s' % ('Kernel', 'Counter', 'Launches', 'Total', 'PerLaunch'))
+  print('%-110s %-14s %8s %14s %14s' % ('Kernel', 'Counter', 'Launches', 'Total', 'PerLaunch'))
   for (kn, cn), (v, ids) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    print('%-64s %-14s %8d %14.4g %14.4g' % (kn[:64], cn, len(ids), v, v / max(len(ids), 1)))
+    print('%-110s %-14s %8d %14.4g %14.4g' % (kn[:110], cn, len(ids), v, v / max(len(ids), 1)))
 
 
 if __name__ == '__main__':

@@ -144,3 +144,31 @@ def test_auto_calibration_is_the_manual_calibration_on_the_first_large_batch():
   assert np.array_equal(got, want)
   assert np.array_equal(auto(x).cpu().numpy(), want)                 # once per model
   assert not np.array_equal(want, plain)
+
+
+def test_applied_corrections_equal_the_calibration_that_measured_them(tmp_path, monkeypatch):
+  """dv_model_apply_corrections, and the sharing protocol of host ranks on one GPU: the first model to reach its
+  first large batch measures and publishes, a second one with the same key applies -- same probabilities."""
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  ref = R.make_random_model(7, seed=58)
+  x = _images(shape, 300, seed=919)
+  a = _model(shape, ref.export_flat(), 300)
+  corr = a.calibrate(x[:256])
+  want = a(x).cpu().numpy()
+  b = _model(shape, ref.export_flat(), 300)
+  plain = b(x).cpu().numpy()
+  b.apply_corrections(corr)
+  assert np.array_equal(b(x).cpu().numpy(), want) and not np.array_equal(plain, want)
+  with pytest.raises(Exception):
+    b.apply_corrections(corr[:-1])
+  key = 'test-%d' % os.getpid()
+  first = _model(shape, ref.export_flat(), 300)
+  first.enable_auto_calibration(share_key=key)
+  second = _model(shape, ref.export_flat(), 300)
+  second.enable_auto_calibration(share_key=key)
+  got1 = first(x).cpu().numpy()                   # measures on x[:256], publishes
+  got2 = second(x[torch.randperm(300, device=x.device)][:280])      # another first batch: applies the published one
+  assert np.array_equal(got1, want)
+  assert np.array_equal(second(x).cpu().numpy(), want)
+  del got2

@@ -28,14 +28,18 @@ d=json.loads(sys.stdin.read()); print('$w $label', round(d['value']), round(d['m
        env ${kvs//,/ } DV_STEM_PROF=1 DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-workloads --calibration-images 0 2>&1 > /dev/null | grep -E "dv-stem-b|stem_b conv" | tail -6 | sed "s/^/$label /" | tee -a $O/stemprof.txt ;;
     trace) DV_OP_TRACE=1 DV_BENCH_NO_PMC=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-workloads > /dev/null 2> $O/op_trace_raw.txt; grep -c dv-op $O/op_trace_raw.txt ;;
     stats) cd /tmp && export TMPDIR=/tmp
-       DV_BENCH_NO_PMC=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-workloads > $R/$O/stats.log 2>&1
+       DV_BENCH_NO_PMC=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-workloads --calibration-images 0 > $R/$O/stats.log 2>&1
        python $R/profiles/summarize_rocpd.py $(find $R/$O/stats -name '*.db' | head -1) > $R/$O/kernel_stats.txt
        rm -rf $R/$O/stats; cd $R; head -20 $O/kernel_stats.txt ;;
     pmc) bash tools/r5_pmc_sq.sh > $O/pmc_sq.log 2>&1; tail -30 $O/pmc_sq.txt ;;
+    wstats) for w in hifi35 ont50; do
+         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_$w -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --calibration-images 0 > $R/$O/stats_$w.log 2>&1
+           python $R/profiles/summarize_rocpd.py $(find $R/$O/stats_$w -name '*.db' | head -1) > $R/$O/kernel_stats_$w.txt; rm -rf $R/$O/stats_$w )
+       done ;;
     workloads) for w in hifi35 ont50; do
          timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; cat $O/bench_$w.json
          DV_OP_TRACE=1 timeout 300 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/op_trace_$w.txt
-         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_$w -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $R/$O/stats_$w.log 2>&1
+         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_$w -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --calibration-images 0 > $R/$O/stats_$w.log 2>&1
            python $R/profiles/summarize_rocpd.py $(find $R/$O/stats_$w -name '*.db' | head -1) > $R/$O/kernel_stats_$w.txt; rm -rf $R/$O/stats_$w )
        done ;;
     ab:*) kv=${step#ab:}; for r in 1 2; do bench_line default; bench_line "$kv" "$kv"; done ;;
