@@ -260,11 +260,11 @@ __global__ __launch_bounds__(kBlock) void encode_items_kernel(EncArgs a) {
   uint32_t* wave_tot = order + kMaxKept;          // [kWaves]
   // per kept read: pixel program = constant bytes + v_perm selectors, 4 channels per dword
   const int pdw = (a.n_channels + 3) >> 2;         // dwords per pixel program entry
-  uint32_t* m_const = wave_tot + 8;                // [kMaxKept][pdw]
-  uint32_t* m_sel_a = m_const + kMaxKept * pdw;    // dynamic bytes {base, qual, diff, 5mC}
-  uint32_t* m_sel_b = m_sel_a + kMaxKept * pdw;    // dynamic byte  {6mA}
+  uint32_t* m_const = wave_tot + 8;                // [kept_cap][pdw] (kept <= max_reads <= kept_cap)
+  uint32_t* m_sel_a = m_const + a.kept_cap * pdw;  // dynamic bytes {base, qual, diff, 5mC}
+  uint32_t* m_sel_b = m_sel_a + a.kept_cap * pdw;  // dynamic byte  {6mA}
   const int cig_cache = a.cig_cache;
-  uint32_t* m_cig = m_sel_b + kMaxKept * pdw;      // [kept_cap][cig_cache]: the first CIGAR words of each kept read
+  uint32_t* m_cig = m_sel_b + a.kept_cap * pdw;    // [kept_cap][cig_cache]: the first CIGAR words of each kept read
   uint8_t* row_bufs = reinterpret_cast<uint8_t*>(m_cig + a.kept_cap * cig_cache);
   // after the sort the key arrays are dead: they become the per-read metadata
   uint32_t* m_c0 = reinterpret_cast<uint32_t*>(key_hap);
@@ -1337,7 +1337,7 @@ int dv_encode_batch(dv_encoder* enc, const dv_batch* b, int out_channels,
     }
   }
   const size_t lds = sizeof(EncConst) + 6 * kMaxKept * 4 + 8 * 4 +
-                     3 * static_cast<size_t>(kMaxKept) * ((a.n_channels + 3) / 4) * 4 +
+                     3 * static_cast<size_t>(a.kept_cap) * ((a.n_channels + 3) / 4) * 4 +
                      static_cast<size_t>(a.kept_cap) * a.cig_cache * 4 +
                      static_cast<size_t>(kWaves) * a.row_buf_bytes;
   {
