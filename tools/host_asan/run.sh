@@ -12,7 +12,7 @@ CLANG=/opt/rocm/lib/llvm/bin/clang++
 mkdir -p "$WORK"
 FLAGS="-std=c++17 -O1 -g -fPIC -fsanitize=$SAN -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/include -I$ROOT/deepvariant_amd/csrc"
 OBJS=""
-for src in bam_reader cram_reader region_packer local_align fast_pass_aligner debruijn_graph direct_phasing aligner_abi region_realigner flow_channels; do
+for src in bam_reader cram_reader region_packer local_align fast_pass_aligner debruijn_graph direct_phasing aligner_abi region_realigner flow_channels sampling; do
   $CLANG $FLAGS -x c++ -c "$ROOT/deepvariant_amd/csrc/$src.cpp" -o "$WORK/$src.o"
   OBJS="$OBJS $WORK/$src.o"
 done
