@@ -147,7 +147,11 @@ def gather_records(records: Sequence[bytes], device=None, group=None,
 
   `failed=True`: this rank could not produce its records.  The first exchange (counts) carries the
   flag, so every rank leaves the collective at once with `PeerFailed` naming the ranks -- instead of the
-  healthy ranks waiting in an all-gather the failed one never joins until the backend's timeout."""
+  healthy ranks waiting in an all-gather the failed one never joins until the backend's timeout.
+
+  Host ranks (`device=None`, gloo) of ONE node move a payload of more than 16 KB per rank through files under
+  /dev/shm instead of the TCP collective (`_gather_records_shm`; DV_NO_SHM_EXCHANGE keeps the collective);
+  DV_DIST_DEBUG prints the seconds each phase took on stderr."""
   import os as _os, sys as _sys, time as _time
   _dbg = _os.environ.get('DV_DIST_DEBUG') is not None
   _t = [_time.perf_counter()]
