@@ -742,31 +742,9 @@ def bam_mode(args, log=sys.stderr):
 
 
 def make_longread_workload(kind, n, seed=None):
-  """(options, packed batch, candidates with alt images, drawn channels, total channels): items 0..n-1 are the
-  reference-aligned pileups (example i at i * H*W*Ct), items n + 2k, n + 2k + 1 the two alt-aligned images of
-  candidate with_alt[k] in scratch space behind the examples."""
-  from deepvariant_amd import packing, synth
-  opts = synth.longread_options(kind)
-  H, W = opts.height, opts.width
-  c_enc = len(packing.channel_enums(opts))
-  Ct = c_enc + 2                                   # + the two alt-aligned diff channels
-  gen = synth.make_longread_batch(n, kind, seed=synth.SEED if seed is None else seed)
-  img_bytes = H * W * Ct
-  batch = packing.PackedBatch(table=gen.table, width=W)
-  batch.ref_windows_list = gen.ref_windows_list
-  off = np.asarray(gen.item_list_off)
-  lr, lc = np.asarray(gen.list_read), np.asarray(gen.list_code)
-  for i in range(n):
-    a, b = off[i], off[i + 1]
-    batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
-                   height=H, out_off=i * img_bytes)
-  with_alt = list(range(0, n, 3))
-  for k, i in enumerate(with_alt):
-    a, b = off[i], off[i + 1]
-    for j in range(2):
-      batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
-                     height=H, out_off=n * img_bytes + (2 * k + j) * img_bytes)
-  return opts, batch, with_alt, c_enc, Ct
+  """deepvariant_amd.synth.make_longread_workload (the product draws its calibration set with it too)."""
+  from deepvariant_amd import synth
+  return synth.make_longread_workload(kind, n, seed=seed)
 
 
 def longread_bench(args, dev, local_rank, emit=True):

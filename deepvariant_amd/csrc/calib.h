@@ -34,6 +34,9 @@ struct CalibOp {
   int shift_relu;             // avg-pool: + shift, ReLU after averaging
   int64_t shift_off;          // where this op's shifts (and corrections) live in the model's shift array; -1 none
   int split;                  // conv: the product multiplies W_hi + W_lo (two fp16 numbers) instead of W_hi
+  int keep_f32;               // E keeps this op's output in fp32: the product stores it wider than fp16 (an fp32 tensor --
+                              // pooled projections' raw outputs, the last block's outputs that feed the global pool -- or
+                              // hi + lo fp16 pieces) or the probe below asks what that would buy
 };
 
 struct CalibBuf {
@@ -48,12 +51,23 @@ struct CalibPlan {
   int64_t dense_off = 0;          // floats into the flat weights: Dense kernel [feat_c][classes], then bias
 };
 
+// Optional probe (dv_model_probe_rounding, a diagnostic): fixed corrections instead of measured ones, the logits of both
+// pipelines, R skipped when only E is wanted.
+struct CalibProbe {
+  const float* corr_in = nullptr;        // same indexing as `shift`; nullptr = measure (the calibration proper)
+  const float* dense_corr_in = nullptr;  // [num_classes], with corr_in
+  float* logits_r = nullptr;             // HOST [n][num_classes], optional
+  float* logits_e = nullptr;             // HOST [n][num_classes], optional (corrections applied, Dense bias included)
+  bool skip_r = false;                   // needs corr_in
+  bool weights_f32 = false;              // E multiplies the fp32 weights (isolates the activation roundings)
+};
+
 // images: DEVICE pointer, uint8 [n][h][w][c] of bufs[0].  shift: the model's host shift array (as uploaded).
 // On success corr (same indexing as shift; zero where no correction applies) and dense_corr[num_classes]
 // hold mean_E - mean_R; the caller subtracts them from the shifts / the Dense bias.
 int run_calibration(const CalibPlan& plan, int device, const float* weights, int64_t n_weights,
                     const std::vector<float>& shift, const uint8_t* images, int n,
-                    std::vector<float>* corr, std::vector<float>* dense_corr);
+                    std::vector<float>* corr, std::vector<float>* dense_corr, const CalibProbe* probe = nullptr);
 
 }  // namespace dv
 

@@ -203,6 +203,7 @@ struct Scratch {
   DeviceBuffer weights, inv, shift, corr, zeros, wq, z, tmp_in, tmp_out, partial, mean[2], logits[2];
   std::vector<DeviceBuffer> act[2];
   ~Scratch() {
+    (void)hipDeviceSynchronize();   // an early error return must not free buffers that queued kernels still use
     for (DeviceBuffer* b : {&weights, &inv, &shift, &corr, &zeros, &wq, &z, &tmp_in, &tmp_out, &partial, &mean[0],
                             &mean[1], &logits[0], &logits[1]}) {
       b->release();
@@ -216,7 +217,10 @@ struct Scratch {
 
 int run_calibration(const CalibPlan& plan, int device, const float* weights, int64_t n_weights,
                     const std::vector<float>& shift, const uint8_t* images, int n, std::vector<float>* corr,
-                    std::vector<float>* dense_corr) {
+                    std::vector<float>* dense_corr, const CalibProbe* probe) {
+  const bool fixed_corr = probe != nullptr && probe->corr_in != nullptr;
+  const bool skip_r = fixed_corr && probe->skip_r;
+  const int first_pipe = skip_r ? 1 : 0;
   if (n < 1 || plan.ops.empty() || plan.bufs.empty() || plan.feat_buf < 0) {
     return fail(DV_ERR_INVALID_ARGUMENT, "calibration: empty plan or batch");
   }
@@ -278,6 +282,7 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
       if (d.c > kZeroFloats) return fail(DV_ERR_INVALID_ARGUMENT, "calibration: tensor wider than the zero row");
       // the two pipelines read the same input image
       if (b == 0 && p == 1) continue;
+      if (b != 0 && p == 0 && skip_r) continue;
       need(s.act[p][b], static_cast<size_t>(n) * d.h * d.w * d.c * 4);
     }
   }
@@ -285,7 +290,11 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
   DV_HIP_CHECK(hipMemcpy(s.weights.ptr, weights, static_cast<size_t>(n_weights) * 4, hipMemcpyHostToDevice));
   DV_HIP_CHECK(hipMemcpy(s.inv.ptr, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
   DV_HIP_CHECK(hipMemcpy(s.shift.ptr, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
-  DV_HIP_CHECK(hipMemset(s.corr.ptr, 0, shift.size() * 4));
+  if (fixed_corr) {
+    DV_HIP_CHECK(hipMemcpy(s.corr.ptr, probe->corr_in, shift.size() * 4, hipMemcpyHostToDevice));
+  } else {
+    DV_HIP_CHECK(hipMemset(s.corr.ptr, 0, shift.size() * 4));
+  }
   DV_HIP_CHECK(hipMemset(s.zeros.ptr, 0, kZeroFloats * 4));
   hipStream_t st = nullptr;
   auto F = [](DeviceBuffer& b) { return static_cast<float*>(b.ptr); };
@@ -306,6 +315,7 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
                        m_total);
   };
   auto take_corr = [&](int64_t shift_off, int c) {
+    if (fixed_corr) return;   // the probe's corrections are already in s.corr
     hipLaunchKernelGGL(mean_difference, dim3((c + 63) / 64), dim3(64), 0, st,
                        static_cast<const double*>(s.mean[1].ptr), static_cast<const double*>(s.mean[0].ptr),
                        F(s.corr) + shift_off, c);
@@ -313,8 +323,9 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
   for (const CalibOp& op : plan.ops) {
     const CalibBuf& ib = plan.bufs[op.in_buf];
     const CalibBuf& ob = plan.bufs[op.out_buf];
-    for (int pipe = 0; pipe < 2; ++pipe) {
+    for (int pipe = first_pipe; pipe < 2; ++pipe) {
       const float* in = act(pipe, op.in_buf);
+      const int round16 = pipe == 1 && !op.keep_f32;
       float* out = act(pipe, op.out_buf);
       if (op.type == 1) {
         const int oh = (ib.h - 3) / 2 + 1, ow = (ib.w - 3) / 2 + 1;
@@ -331,14 +342,14 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
                            ib.c, ib.c);
         const float* cr = nullptr;
         if (op.shift_relu) {
-          channel_mean(pipe, F(s.z), m_total, ib.c);
+          if (!fixed_corr) channel_mean(pipe, F(s.z), m_total, ib.c);
           if (pipe == 1) {
             take_corr(op.shift_off, ib.c);
             cr = F(s.corr) + op.shift_off;
           }
         }
         hipLaunchKernelGGL(finalize, dim3(blocks_for(cnt, 256)), dim3(256), 0, st, F(s.z), cr, out,
-                           static_cast<size_t>(m_total), ib.c, ob.c, op.out_coff, op.shift_relu, pipe);
+                           static_cast<size_t>(m_total), ib.c, ob.c, op.out_coff, op.shift_relu, round16);
         continue;
       }
       // convolution
@@ -368,7 +379,8 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
       if (g.cin > g.c) return fail(DV_ERR_INVALID_ARGUMENT, "calibration: kernel wider than its input tensor");
       const size_t k_total = static_cast<size_t>(op.kh) * op.kw * op.cin;
       hipLaunchKernelGGL(fold_weights, dim3(blocks_for(k_total * op.cout, 256)), dim3(256), 0, st,
-                         F(s.weights) + op.w_off, F(s.inv) + op.shift_off, F(s.wq), k_total, op.cout, pipe,
+                         F(s.weights) + op.w_off, F(s.inv) + op.shift_off, F(s.wq), k_total, op.cout,
+                         pipe == 1 && !(probe != nullptr && probe->weights_f32) ? 1 : 0,
                          op.split);
       const int m_total = n * g.oh * g.ow;
       hipLaunchKernelGGL(conv_direct, dim3((m_total + kPix - 1) / kPix, (op.cout + 63) / 64), dim3(64), 0, st, in,
@@ -376,7 +388,7 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
       const size_t cnt = static_cast<size_t>(m_total) * op.cout;
       const float* cr = nullptr;
       if (!op.raw) {
-        channel_mean(pipe, F(s.z), m_total, op.cout);
+        if (!fixed_corr) channel_mean(pipe, F(s.z), m_total, op.cout);
         if (pipe == 1) {
           take_corr(op.shift_off, op.cout);
           cr = F(s.corr) + op.shift_off;
@@ -384,14 +396,14 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
       }
       if (op.pool_out) {
         hipLaunchKernelGGL(finalize, dim3(blocks_for(cnt, 256)), dim3(256), 0, st, F(s.z), cr, F(s.tmp_out),
-                           static_cast<size_t>(m_total), op.cout, op.cout, 0, !op.raw, pipe);
+                           static_cast<size_t>(m_total), op.cout, op.cout, 0, !op.raw, round16);
         const int ph = (g.oh - 3) / 2 + 1, pw = (g.ow - 3) / 2 + 1;
         const size_t pc = static_cast<size_t>(n) * ph * pw * op.cout;
         hipLaunchKernelGGL(maxpool_direct, dim3(blocks_for(pc, 256)), dim3(256), 0, st, F(s.tmp_out), out, n, g.oh,
                            g.ow, op.cout, op.cout, ph, pw, ob.c, op.out_coff);
       } else {
         hipLaunchKernelGGL(finalize, dim3(blocks_for(cnt, 256)), dim3(256), 0, st, F(s.z), cr, out,
-                           static_cast<size_t>(m_total), op.cout, ob.c, op.out_coff, !op.raw, pipe);
+                           static_cast<size_t>(m_total), op.cout, ob.c, op.out_coff, !op.raw, round16);
       }
     }
     DV_HIP_CHECK(hipGetLastError());
@@ -399,7 +411,7 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
   // head: the mean logit difference goes to the Dense bias
   const CalibBuf& fb = plan.bufs[plan.feat_buf];
   const float* dw = F(s.weights) + plan.dense_off;
-  for (int pipe = 0; pipe < 2; ++pipe) {
+  for (int pipe = first_pipe; pipe < 2; ++pipe) {
     hipLaunchKernelGGL(head_logits, dim3(n), dim3(256), 0, st, act(pipe, plan.feat_buf), dw,
                        dw + static_cast<size_t>(fb.c) * plan.num_classes, F(s.logits[pipe]), fb.h * fb.w, fb.c,
                        plan.num_classes);
@@ -413,7 +425,19 @@ int run_calibration(const CalibPlan& plan, int device, const float* weights, int
   DV_HIP_CHECK(hipMemcpy(me.data(), s.mean[1].ptr, me.size() * 8, hipMemcpyDeviceToHost));
   DV_HIP_CHECK(hipMemcpy(mr.data(), s.mean[0].ptr, mr.size() * 8, hipMemcpyDeviceToHost));
   dense_corr->resize(plan.num_classes);
-  for (int k = 0; k < plan.num_classes; ++k) (*dense_corr)[k] = static_cast<float>(me[k] - mr[k]);
+  for (int k = 0; k < plan.num_classes; ++k) {
+    (*dense_corr)[k] = fixed_corr ? (probe->dense_corr_in ? probe->dense_corr_in[k] : 0.f) : static_cast<float>(me[k] - mr[k]);
+  }
+  if (probe != nullptr) {
+    const size_t cnt = static_cast<size_t>(n) * plan.num_classes;
+    if (probe->logits_r != nullptr && !skip_r) {
+      DV_HIP_CHECK(hipMemcpy(probe->logits_r, s.logits[0].ptr, cnt * 4, hipMemcpyDeviceToHost));
+    }
+    if (probe->logits_e != nullptr) {
+      DV_HIP_CHECK(hipMemcpy(probe->logits_e, s.logits[1].ptr, cnt * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; ++i) probe->logits_e[i] -= (*dense_corr)[i % plan.num_classes];
+    }
+  }
   for (float v : *corr) {
     if (!std::isfinite(v)) return fail(DV_ERR_BAD_INPUT, "calibration produced a non-finite correction");
   }

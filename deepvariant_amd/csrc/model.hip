@@ -3039,15 +3039,9 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
   return prepare_blank_responses(m);
 }
 
-// Shift calibration (include/dvhip.h, csrc/calib.h): the op list as a plan of plain NHWC tensors --
-// fused pools unfolded (pool_in / pool_out), LDS-only tensors given their real size -- run through
-// the two fp32 pipelines; shifts and the Dense bias move by the mean differences.
-int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images, int n_images,
-                       float* corrections, int64_t capacity) {
-  if (!m || !weights || !images) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: null");
-  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: load weights first");
-  if (n_weights != m->n_params) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: wrong number of weights");
-  if (n_images < 1 || n_images > 4096) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: 1..4096 images");
+// The op list as calib.h's plan of plain NHWC tensors: fused pools unfolded (pool_in / pool_out), LDS-only
+// tensors given their real size, and the tensors the product keeps wider than fp16 marked (keep_f32).
+static dv::CalibPlan calib_plan_of(const dv_model* m) {
   dv::CalibPlan plan;
   plan.bufs.resize(m->buffers.size());
   for (size_t b = 0; b < m->buffers.size(); ++b) plan.bufs[b] = {m->buffers[b].h, m->buffers[b].w, m->buffers[b].c};
@@ -3096,6 +3090,19 @@ int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, con
   plan.feat_buf = m->feat_buf;
   plan.num_classes = m->desc.num_classes;
   plan.dense_off = m->layers.back().param_off;
+  return plan;
+}
+
+// Shift calibration (include/dvhip.h, csrc/calib.h): the op list as a plan of plain NHWC tensors --
+// fused pools unfolded (pool_in / pool_out), LDS-only tensors given their real size -- run through
+// the two fp32 pipelines; shifts and the Dense bias move by the mean differences.
+int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images, int n_images,
+                       float* corrections, int64_t capacity) {
+  if (!m || !weights || !images) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: null");
+  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: load weights first");
+  if (n_weights != m->n_params) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: wrong number of weights");
+  if (n_images < 1 || n_images > 4096) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_calibrate: 1..4096 images");
+  const dv::CalibPlan plan = calib_plan_of(m);
   std::vector<float> corr, dense_corr;
   if (int rc = dv::run_calibration(plan, m->device, weights, n_weights, m->h_shift, images, n_images, &corr,
                                    &dense_corr)) {
@@ -3146,6 +3153,75 @@ int dv_model_apply_corrections(dv_model* m, const float* corrections, int64_t n)
   DV_HIP_CHECK(hipMemcpy(m->d_shift.ptr, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
   DV_HIP_CHECK(hipMemcpy(m->d_dense_b.ptr, dense_b.data(), dense_b.size() * 4, hipMemcpyHostToDevice));
   return prepare_blank_responses(m);
+}
+
+// Diagnostic (include/dvhip.h): the calibration's two fp32 pipelines as a probe of WHERE the fp16 error enters.
+int dv_model_num_ops(const dv_model* m) { return m ? static_cast<int>(m->ops.size()) : 0; }
+
+int dv_model_op_label(const dv_model* m, int op_index, char* buf, int capacity) {
+  if (!m || !buf || capacity < 1 || op_index < 0 || op_index >= static_cast<int>(m->ops.size())) {
+    return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_op_label: bad argument");
+  }
+  const Op& op = m->ops[op_index];
+  const char* kind = op.type == kOpConv ? "conv" : op.type == kOpMaxPool ? "maxpool" : "avgpool";
+  snprintf(buf, static_cast<size_t>(capacity), "%s layer=%d k=%dx%d s=%d cin=%d cout=%d out=%dx%d raw=%d in_buf=%d out_buf=%d coff=%d lds_only=%d",
+           kind, op.layer, op.kh, op.kw, op.stride, op.cin, op.cout, op.oh, op.ow, op.raw ? 1 : 0, op.in_buf, op.out_buf,
+           op.out_coff, (op.type == kOpConv && (op.stem_a || op.stem_b)) || (op_index + 1 < static_cast<int>(m->ops.size()) && m->ops[op_index + 1].in_chain && m->ops[op_index + 1].in_buf == op.out_buf) ? 1 : 0);
+  return DV_OK;
+}
+
+int dv_model_probe_rounding(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images, int n_images,
+                            const uint8_t* keep_f32, int flags, const float* corrections, int64_t n_corrections,
+                            float* logits_r, float* logits_e, float* corrections_out) {
+  if (!m || !weights || !images || !logits_e) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: null");
+  if (!m->loaded) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: load weights first");
+  if (n_weights != m->n_params) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: wrong number of weights");
+  if (n_images < 1 || n_images > 4096) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: 1..4096 images");
+  dv::CalibPlan plan = calib_plan_of(m);
+  if (keep_f32 != nullptr) {
+    for (size_t i = 0; i < plan.ops.size(); ++i) plan.ops[i].keep_f32 = keep_f32[i] ? 1 : 0;
+  }
+  std::vector<float> corr_in(m->h_shift.size(), 0.f), dense_in(m->h_dense_b.size(), 0.f);
+  if (corrections != nullptr) {
+    std::vector<const Op*> by_layer(m->layers.size(), nullptr);
+    for (const Op& op : m->ops) {
+      if (op.type == kOpConv) by_layer[op.layer] = &op;
+    }
+    int64_t want = static_cast<int64_t>(dense_in.size());
+    for (size_t l = 0; l + 1 < m->layers.size(); ++l) want += by_layer[l]->cout;
+    if (n_corrections != want) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: wrong number of corrections");
+    int64_t at = 0;
+    for (size_t l = 0; l + 1 < m->layers.size(); ++l) {
+      for (int co = 0; co < by_layer[l]->cout; ++co) corr_in[by_layer[l]->shift_off + co] = corrections[at++];
+    }
+    for (size_t k = 0; k < dense_in.size(); ++k) dense_in[k] = corrections[at++];
+  }
+  const bool measure = (flags & 2) != 0;   // the calibration proper under this plan: corrections measured on these images
+  if (measure && corrections != nullptr) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_probe_rounding: measure or apply");
+  dv::CalibProbe probe;
+  probe.corr_in = measure ? nullptr : corr_in.data();
+  probe.dense_corr_in = measure ? nullptr : dense_in.data();
+  probe.logits_r = logits_r;
+  probe.logits_e = logits_e;
+  probe.skip_r = logits_r == nullptr && !measure;
+  probe.weights_f32 = (flags & 1) != 0;
+  std::vector<float> corr, dense_corr;
+  if (int rc = dv::run_calibration(plan, m->device, weights, n_weights, m->h_shift, images, n_images, &corr, &dense_corr,
+                                   &probe)) {
+    return rc;
+  }
+  if (corrections_out != nullptr) {
+    std::vector<const Op*> by_layer(m->layers.size(), nullptr);
+    for (const Op& op : m->ops) {
+      if (op.type == kOpConv) by_layer[op.layer] = &op;
+    }
+    int64_t at = 0;
+    for (size_t l = 0; l + 1 < m->layers.size(); ++l) {
+      for (int co = 0; co < by_layer[l]->cout; ++co) corrections_out[at++] = corr[by_layer[l]->shift_off + co];
+    }
+    for (float v : dense_corr) corrections_out[at++] = v;
+  }
+  return DV_OK;
 }
 
 // Testing hook: copies activation buffer `index` (NHWC fp16, first n examples)

@@ -344,6 +344,37 @@ def make_longread_batch(n_candidates: int, kind: str = 'hifi', seed: int = SEED,
   return batch
 
 
+def make_longread_workload(kind: str, n: int, seed=None, options=None):
+  """(options, packed batch, candidates with alt images, drawn channels, total channels) of the long-read model
+  inputs (PACBIO 100x147x10, ONT_R104 100x199x9): items 0..n-1 are the reference-aligned pileups (example i at
+  i * H*W*Ct), items n + 2k, n + 2k + 1 the two alt-aligned images of candidate with_alt[k] (every third
+  candidate -- the indel share of the PacBio golden, 131 of 401) in scratch space behind the examples;
+  dv_merge_alt_channels then fills the two trailing diff channels (FillPileupArray's channel mode,
+  deepvariant/pileup_image_native.h:246-271).  bench.py's hifi35 / ont50 step and the calibration set of the
+  long-read shapes (calibration_set.py) are drawn from it."""
+  opts = options or longread_options(kind)
+  H, W = opts.height, opts.width
+  c_enc = len(packing.channel_enums(opts))
+  Ct = c_enc + 2                                   # + the two alt-aligned diff channels
+  gen = make_longread_batch(n, kind, seed=SEED if seed is None else seed, options=opts)
+  img_bytes = H * W * Ct
+  batch = packing.PackedBatch(table=gen.table, width=W)
+  batch.ref_windows_list = gen.ref_windows_list
+  off = np.asarray(gen.item_list_off)
+  lr, lc = np.asarray(gen.list_read), np.asarray(gen.list_code)
+  for i in range(n):
+    a, b = off[i], off[i + 1]
+    batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
+                   height=H, out_off=i * img_bytes)
+  with_alt = list(range(0, n, 3))
+  for k, i in enumerate(with_alt):
+    a, b = off[i], off[i + 1]
+    for j in range(2):
+      batch.add_item(gen.item_variant_start[i], gen.item_image_start[i], gen.item_ref_idx[i], lr[a:b], lc[a:b],
+                     height=H, out_off=n * img_bytes + (2 * k + j) * img_bytes)
+  return opts, batch, with_alt, c_enc, Ct
+
+
 def region_inputs_from_batch(batch: packing.PackedBatch, options):
   """The same synthetic workload in REGION form -- a read table with read names plus
   DeepVariantCall-shaped candidates with `allele_support` read-name lists -- i.e. what

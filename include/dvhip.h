@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 7
+#define DV_ABI_VERSION 8
 #define DV_MAX_CHANNELS 16
 #define DV_READ_AUX_STRIDE 8
 
@@ -782,6 +782,22 @@ int dv_model_calibrate(dv_model* m, const float* weights, int64_t n_weights, con
  * processes that share one set of weights -- the ranks of `make_examples --ranks_per_gpu R`: one of them
  * calibrates, the others apply its result instead of repeating the measurement on the same GPU. */
 int dv_model_apply_corrections(dv_model* m, const float* corrections, int64_t n);
+
+/* Diagnostic (ABI v8): WHERE the fp16 error of the classifier enters.  Runs dv_model_calibrate's two fp32
+ * pipelines (csrc/calib.h: R exact, E with the MFMA kernels' rounding points) on `n_images` device images with FIXED
+ * shift corrections (`corrections` in dv_model_calibrate's layout, or NULL for none) and returns both pipelines'
+ * logits (host, [n_images][num_classes]; logits_r may be NULL: R is skipped).  keep_f32[op] != 0 keeps the output
+ * tensor of graph op `op` (0 .. dv_model_num_ops - 1, dv_model_op_label describes each) in float32 in E -- what
+ * storing that tensor wider than fp16 would buy; NULL = the product's own rounding points.  flags bit 0: E multiplies
+ * the float32 weights (isolates the activation roundings); bit 1: measure the corrections on these images under this
+ * plan (the calibration proper; `corrections` must be NULL) and report them in `corrections_out` (optional, the
+ * layout of dv_model_calibrate).  The model's state is not changed.  tools/r6_tensor_budget.py;
+ * no reference counterpart (deepvariant/call_variants.py:913-918 computes in float32 end to end). */
+int dv_model_num_ops(const dv_model* m);
+int dv_model_op_label(const dv_model* m, int op_index, char* buf, int capacity);
+int dv_model_probe_rounding(dv_model* m, const float* weights, int64_t n_weights, const uint8_t* images,
+                            int n_images, const uint8_t* keep_f32, int flags, const float* corrections,
+                            int64_t n_corrections, float* logits_r, float* logits_e, float* corrections_out);
 
 /* preprocess_images ((x-128)/128, deepvariant/dv_utils.py:343-366) + model
  * forward + softmax (deepvariant/call_variants.py:904-932).

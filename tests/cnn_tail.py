@@ -41,29 +41,9 @@ def illumina_pileups_gpu(n, seed, chunk=8192, device='cuda'):
 def longread_images_gpu(kind, n, seed=None, device='cuda'):
   """n examples of bench.py's hifi35 / ont50 workload ('hifi' -> [n,100,147,10], 'ont' -> [n,100,199,9]):
   HIP encoder + dv_merge_alt_channels, exactly the bench step's tensor."""
-  import ctypes as CT
-  import bench
-  from deepvariant_amd import _lib
-  from deepvariant_amd.device_batch import DeviceBatch
-  from deepvariant_amd.pileup_image_native import _Encoder
-  opts, batch, with_alt, c_enc, ct = bench.make_longread_workload(kind, n, seed=seed)
-  h, w = opts.height, opts.width
-  img_bytes = h * w * ct
-  entries = (_lib.DvAltMergeEntry * max(len(with_alt), 1))()
-  for k, i in enumerate(with_alt):
-    entries[k].example, entries[k].first_row, entries[k].rows = i, 0, h
-    entries[k].scratch_alt1, entries[k].scratch_alt2 = 2 * k, 2 * k + 1
+  from deepvariant_amd import calibration_set
   dev = torch.device(device)
-  dbatch = DeviceBatch(batch, dev)
-  enc = _Encoder(opts, w)
-  flat = torch.zeros(batch.n_items * img_bytes, dtype=torch.uint8, device=dev)
-  rows = torch.empty(batch.n_items, dtype=torch.int32, device=dev)
-  stream = torch.cuda.current_stream(dev)
-  dbatch.encode(enc, ct, flat, rows)
-  _lib.check(_lib.lib().dv_merge_alt_channels(flat.data_ptr(), n * img_bytes, img_bytes, img_bytes, w, ct, c_enc,
-                                              5, entries, len(with_alt), CT.c_void_p(stream.cuda_stream)))
-  torch.cuda.synchronize(dev)
-  return flat[:n * img_bytes].view(n, h, w, ct).clone()
+  return calibration_set.longread_examples(kind, n, seed=seed, device=dev.index or 0)
 
 
 def hip_probs(model, images, chunk):

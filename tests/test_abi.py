@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
   for sym in declared:
     assert hasattr(l, sym), sym
   assert sorted(_lib.ABI_SYMBOLS) == declared
-  assert l.dv_abi_version() == 7   # 4: dv_realign_regions; 5: dv_cram_read_region; 6: base_aux2 + flow-space channels; 7: dv_model_calibrate
+  assert l.dv_abi_version() == 8   # 4: dv_realign_regions; 5: dv_cram_read_region; 6: base_aux2 + flow-space channels; 7: dv_model_calibrate; 8: dv_model_probe_rounding, calibration sets
 
 
 def test_host_helpers_need_no_gpu():
