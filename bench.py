@@ -208,7 +208,7 @@ def run_rank(args, rank, local_rank, world):
   model = InceptionV3((H, W, C), max_batch=min(n_items, 8192),
                       device=local_rank)
   model.init_random(seed=1234)          # same weights on every rank
-  calibration = calibrate_model(model, args, lambda n, seed: illumina_calibration_images(n, seed, opts, enc, C, dev))
+  calibration = calibrate_model(model, args)
   images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)
   rows = torch.empty(n_items, dtype=torch.int32, device=dev)
   ids = (torch.arange(n_items, device=dev, dtype=torch.int64) +
@@ -262,6 +262,25 @@ def run_rank(args, rank, local_rank, world):
   other_ms = lib.dv_profile_ms(2)
   lib.dv_set_profiling(0)
 
+  # ---- the same K steps with blank-row skipping OFF (dv_model_set_blank_skip; identical probabilities, bit for
+  # bit): `value_dense` / `roofline.dense`, so that the headline can be read with and without the data-dependent part
+  thr = model.blank_thresholds(n_items) if n_items <= model.max_batch else None
+  dense = None
+  if thr is not None:
+    model.set_blank_skip(False)
+    elapsed_d, probs_d = timed_steps(step, sync_all, min(args.warmup, 2), args.steps)
+    assert torch.equal(probs_d, probs), 'blank-row skipping changed a probability'
+    lib.dv_set_profiling(1)
+    for _ in range(args.steps):
+      step()
+    sync_all()
+    lib.dv_profile_ms(0)
+    conv_ms_d = lib.dv_profile_ms(1)
+    lib.dv_set_profiling(0)
+    model.set_blank_skip(True)
+    elapsed_d, _ = reduce_elapsed(elapsed_d, n_items, world, dev)
+    dense = (elapsed_d, conv_ms_d)
+
   elapsed, items_per_step = reduce_elapsed(elapsed, n_items, world, dev)
   assert torch.isfinite(probs).all()
   if gathered is not None:   # every rank holds every rank's results
@@ -271,7 +290,9 @@ def run_rank(args, rank, local_rank, world):
   if rank == 0:
     value = items_per_step * args.steps / elapsed
     conv_flops_per_item = 2.0 * model.conv_macs_per_example
-    conv_tflops = (conv_flops_per_item * n_items * args.steps /
+    executed = executed_conv_flops(model, (H, W, C), thr, conv_flops_per_item) if thr is not None else None
+    exec_flops_per_item = executed['executed_flops_per_candidate'] if executed else conv_flops_per_item
+    conv_tflops = (exec_flops_per_item * n_items * args.steps /
                    (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0
     bytes_per_item = algorithmic_bytes_per_item(host_batch, C)
     enc_gbs = (bytes_per_item * n_items * args.steps / (enc_ms * 1e-3) / 1e9
@@ -311,6 +332,11 @@ def run_rank(args, rank, local_rank, world):
             'traffic': conv_traffic,
             'traffic_note': traffic_note,
             'flops_per_candidate': conv_flops_per_item,
+            'executed_flops_per_candidate': exec_flops_per_item,
+            'achieved_note': '`achieved` / `frac` count EXECUTED MFMA FLOPs: the nominal 2 x MACs of the 94 layers minus '
+                             'the output tiles blank-row skipping copied instead of computing (mirrored on the host from '
+                             "the kernels' tile rules and the per-image thresholds of the timed batch); `dense` = the same "
+                             'K steps with the skipping switched off, nominal FLOPs',
             'avg_launch_ms': conv_ms / max(conv_launches, 1),
             'launches': conv_launches,
             'ms_per_step': conv_ms / args.steps,
@@ -333,6 +359,17 @@ def run_rank(args, rank, local_rank, world):
         'other_kernels_ms_per_step': other_ms / args.steps,
     }
     out['calibration'] = calibration
+    if dense is not None:
+      elapsed_d, conv_ms_d = dense
+      dense_tflops = conv_flops_per_item * n_items * args.steps / (conv_ms_d * 1e-3) / 1e12 if conv_ms_d > 0 else 0.0
+      out['value_dense'] = items_per_step * args.steps / elapsed_d
+      out['ms_per_step_dense'] = 1e3 * elapsed_d / args.steps
+      out['roofline']['dense'] = {'achieved': dense_tflops, 'frac': dense_tflops / MFMA_F16_PEAK_TFLOPS,
+                                  'ms_per_step': conv_ms_d / args.steps, 'flops_per_candidate': conv_flops_per_item}
+      out['blank_row_skipping'] = dict(executed, what=(
+          'stem tiles whose receptive field holds only the zero rows below the pile-up are copied from the all-blank '
+          "image's response (bit-identical; include/dvhip.h dv_model_set_blank_skip); `value` is the product's default, "
+          '`value_dense` the same steps with it off'))
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(host_batch, opts, C, args.cpu_sample)
       out['parity'] = parity_sample(region, opts, C, model, images, probs, n=args.parity_sites)
@@ -345,8 +382,9 @@ def run_rank(args, rank, local_rank, world):
         sub = argparse.Namespace(**vars(args))
         sub.workload = w
         full = longread_bench(sub, dev, local_rank, emit=False)
-        out['workloads'][w] = {k: full[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline',
-                                                    'roofline_encoder', 'other_kernels_ms_per_step', 'calibration',
+        out['workloads'][w] = {k: full[k] for k in ('metric', 'value', 'value_dense', 'unit', 'ms_per_step',
+                                                    'ms_per_step_dense', 'config', 'roofline', 'roofline_encoder',
+                                                    'other_kernels_ms_per_step', 'calibration', 'blank_row_skipping',
                                                     'parity') if k in full}
     print(json.dumps(out))
   if world > 1:
@@ -776,7 +814,7 @@ def longread_bench(args, dev, local_rank, emit=True):
   enc = _Encoder(opts, W, device=local_rank)
   model = InceptionV3((H, W, Ct), max_batch=n, device=local_rank)
   model.init_random(seed=1234)
-  calibration = calibrate_model(model, args, lambda m, seed: longread_calibration_images(kind, m, seed, dev))
+  calibration = calibrate_model(model, args)
   flat = torch.zeros(n_images * img_bytes, dtype=torch.uint8, device=dev)
   images = flat[:n * img_bytes].view(n, H, W, Ct)
   rows = torch.empty(n_images, dtype=torch.int32, device=dev)
@@ -805,8 +843,25 @@ def longread_bench(args, dev, local_rank, emit=True):
   other_ms = lib.dv_profile_ms(2)
   lib.dv_set_profiling(0)
   assert torch.isfinite(probs).all()
+  thr = model.blank_thresholds(n)
+  dense = None
+  if thr is not None:      # the same K steps with blank-row skipping off (identical probabilities)
+    model.set_blank_skip(False)
+    elapsed_d, probs_d = timed_steps(step, sync_all, min(args.warmup, 2), args.steps)
+    assert torch.equal(probs_d, probs), 'blank-row skipping changed a probability'
+    lib.dv_set_profiling(1)
+    for _ in range(args.steps):
+      step()
+    sync_all()
+    lib.dv_profile_ms(0)
+    conv_ms_d = lib.dv_profile_ms(1)
+    lib.dv_set_profiling(0)
+    model.set_blank_skip(True)
+    dense = (elapsed_d, conv_ms_d)
   conv_flops = 2.0 * model.conv_macs_per_example
-  conv_tflops = conv_flops * n * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+  executed = executed_conv_flops(model, (H, W, Ct), thr, conv_flops) if thr is not None else None
+  exec_flops = executed['executed_flops_per_candidate'] if executed else conv_flops
+  conv_tflops = exec_flops * n * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
   # algorithmic bytes: every image's packed reads once per alignment drawn + the n example tensors
   t = batch.table
   seq_len = t.read_seq_off[1:].astype(np.int64) - t.read_seq_off[:-1]
@@ -836,6 +891,7 @@ def longread_bench(args, dev, local_rank, emit=True):
                     'the per-layer stem instead of the fused uint8 stem)',
           'bound': 'mfma', 'achieved': conv_tflops, 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
           'frac': conv_tflops / MFMA_F16_PEAK_TFLOPS, 'traffic': None, 'flops_per_candidate': conv_flops,
+          'executed_flops_per_candidate': exec_flops,
           'avg_launch_ms': conv_ms / max(conv_launches, 1), 'launches': conv_launches,
           'ms_per_step': conv_ms / args.steps,
       },
@@ -848,6 +904,14 @@ def longread_bench(args, dev, local_rank, emit=True):
       'other_kernels_ms_per_step': other_ms / args.steps,
   }
   out['calibration'] = calibration
+  if dense is not None:
+    elapsed_d, conv_ms_d = dense
+    dense_tflops = conv_flops * n * args.steps / (conv_ms_d * 1e-3) / 1e12 if conv_ms_d > 0 else 0.0
+    out['value_dense'] = n * args.steps / elapsed_d
+    out['ms_per_step_dense'] = 1e3 * elapsed_d / args.steps
+    out['roofline']['dense'] = {'achieved': dense_tflops, 'frac': dense_tflops / MFMA_F16_PEAK_TFLOPS,
+                                'ms_per_step': conv_ms_d / args.steps, 'flops_per_candidate': conv_flops}
+    out['blank_row_skipping'] = executed
   if not args.no_cpu_baseline:
     out['parity'] = longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs)
     out['parity'].update(cnn_tail_parity(model, Ct, images, probs))
@@ -941,50 +1005,71 @@ def parity_sample(region, opts, C, model, images, probs, n=512):
   }
 
 
-def illumina_calibration_images(n, seed, opts, enc, C, dev):
-  """n ILLUMINA30 pileups drawn by the HIP encoder from ANOTHER synthetic seed than the timed batch."""
-  from deepvariant_amd import synth
-  batch = synth.make_illumina_batch(n, seed=seed, options=opts, multi_allelic=False)
-  img, _ = enc.encode(batch, C)
-  return torch.from_numpy(np.ascontiguousarray(img.reshape(-1, opts.height, opts.width, C)[:n])).to(dev)
+def executed_conv_flops(model, shape, thr, nominal_flops_per_item):
+  """Nominal conv FLOPs minus the output tiles the stem kernels copied (blank-row skipping), mirrored from their
+  tile rules (csrc/stem.hip next_tile: a 7 x 54 conv2 tile / a 6 x 9 pooled tile starting at or below the example's
+  threshold; model.hip conv_pool_resident_kernel: a 30-position fragment walks down to the deepest threshold among
+  its lanes; conv_mfma_kernel: a wave tile inside one example from its threshold row on) and the per-example
+  thresholds of the last forward (dv_model_blank_thresholds).  -> dict for the JSON line."""
+  h, w, c = shape
+  n = thr.shape[1]
+  oh1, ow1 = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+  oh2, ow2 = oh1 - 2, ow1 - 2
+  ph, pw = (oh2 - 3) // 2 + 1, (ow2 - 3) // 2 + 1
+  oh4, ow4 = ph - 2, pw - 2
+  p4 = (oh4 - 3) // 2 + 1
+  t2, t4, t5 = thr[1].astype(np.int64), thr[2].astype(np.int64), thr[4].astype(np.int64)
+  mac1, mac2, mac3 = 9 * c * 32, 9 * 32 * 32, 9 * 32 * 64
+  mac1x1, mac4 = 64 * 80, 9 * 80 * 192
+  skipped = {}
+  if c <= 8:      # fused stem_a: conv2 tiles of 7 rows; conv1 rows that only skipped tiles read
+    rows2 = np.minimum(oh2, 7 * ((np.minimum(t2, oh2) + 6) // 7))
+    rows1 = np.where(rows2 > 0, np.minimum(oh1, rows2 + 2), 0)
+    skipped['stem_a'] = float(((oh2 - rows2) * ow2 * mac2 + (oh1 - rows1) * ow1 * mac1).sum())
+  else:           # per-layer conv2 (conv_mfma_kernel<1,4>: 128-pixel wave tiles of the flattened (example, row, column) index)
+    px = 128
+    first = np.arange(0, n * oh2 * ow2, px, dtype=np.int64)
+    last = np.minimum(first + px, n * oh2 * ow2) - 1
+    ex_f, ex_l = first // (oh2 * ow2), last // (oh2 * ow2)
+    row_f = (first % (oh2 * ow2)) // ow2
+    blank = (ex_f == ex_l) & (row_f >= t2[ex_f])
+    skipped['conv2'] = float(((last - first + 1) * blank).sum() * mac2)
+  rows_p = np.minimum(ph, 6 * ((np.minimum(t4, ph) + 5) // 6))
+  rows3 = np.where(rows_p > 0, np.minimum(oh2, 2 * rows_p + 1), 0)
+  skipped['stem_b'] = float(((oh2 - rows3) * ow2 * mac3 + (ph - rows_p) * pw * mac1x1).sum())
+  pos = n * ow4
+  frag0 = np.arange(0, pos, 30, dtype=np.int64)
+  lanes = np.minimum(frag0[:, None] + np.arange(32)[None, :], pos - 1)
+  s_end = np.minimum(t5[lanes // ow4], p4).max(axis=1)
+  rows4 = np.where(s_end > 0, np.minimum(oh4, 2 * s_end + 1), 0)
+  new_pos = np.minimum(30, pos - frag0)
+  skipped['conv3x3_80_192'] = float(((oh4 - rows4) * new_pos).sum() * mac4)
+  total_skipped = 2.0 * sum(skipped.values()) / n
+  return {
+      'executed_flops_per_candidate': nominal_flops_per_item - total_skipped,
+      'skipped_flops_per_candidate': total_skipped,
+      'skipped_share_of_nominal': total_skipped / nominal_flops_per_item,
+      'skipped_gflop_per_candidate_by_kernel': {k: 2.0 * v / n / 1e9 for k, v in skipped.items()},
+      'mean_rows_used': float(thr[0].mean()),
+  }
 
 
-def longread_calibration_images(kind, n, seed, dev):
-  """n examples of the long-read workload from another seed: encoder + dv_merge_alt_channels, as in the step."""
-  import ctypes as CT
-  from deepvariant_amd import _lib
-  from deepvariant_amd.device_batch import DeviceBatch
-  from deepvariant_amd.pileup_image_native import _Encoder
-  opts, batch, with_alt, c_enc, Ct = make_longread_workload(kind, n, seed=seed)
-  H, W = opts.height, opts.width
-  img_bytes = H * W * Ct
-  entries = (_lib.DvAltMergeEntry * max(len(with_alt), 1))()
-  for k, i in enumerate(with_alt):
-    entries[k].example, entries[k].first_row, entries[k].rows = i, 0, H
-    entries[k].scratch_alt1, entries[k].scratch_alt2 = 2 * k, 2 * k + 1
-  flat = torch.zeros(batch.n_items * img_bytes, dtype=torch.uint8, device=dev)
-  rows = torch.empty(batch.n_items, dtype=torch.int32, device=dev)
-  DeviceBatch(batch, dev).encode(_Encoder(opts, W, device=dev.index or 0), Ct, flat, rows)
-  _lib.check(_lib.lib().dv_merge_alt_channels(flat.data_ptr(), n * img_bytes, img_bytes, img_bytes, W, Ct, c_enc, 5,
-                                              entries, len(with_alt),
-                                              CT.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-  torch.cuda.synchronize(dev)
-  return flat[:n * img_bytes].view(n, H, W, Ct).clone()
-
-
-def calibrate_model(model, args, draw):
-  """dv_model_calibrate on `--calibration-images` examples of another synthetic seed (model preparation, once per
-  set of weights, before the timed region; --calibration-images 0 = the uncalibrated fp16 model)."""
+def calibrate_model(model, args):
+  """What the product does when it loads a checkpoint (InceptionV3.calibrate_for_checkpoint): dv_model_calibrate on
+  the fixed synthetic calibration set of the model's input shape -- other pileups than the timed batch (another
+  seed), the same on every rank; model preparation before the timed region.  --calibration-images 0 = the
+  uncalibrated fp16 model."""
+  from deepvariant_amd import calibration_set
   n = args.calibration_images
   if n <= 0:
     return {'images': 0}
   t0 = time.perf_counter()
-  x = draw(n, 515151)
-  t1 = time.perf_counter()
-  corr = model.calibrate(x)
-  return {'images': n, 'seed': 515151, 'seconds': time.perf_counter() - t1, 'draw_seconds': t1 - t0,
-          'max_abs_shift_correction': float(np.abs(corr).max()),
-          'what': 'per-channel mean of the fp16 pipeline error moved into the fp32 shifts (dv_model_calibrate)'}
+  corr = model.calibrate_for_checkpoint(n)
+  return {'images': n, 'set': 'deepvariant_amd/calibration_set.py v%d, seed %d' % (calibration_set.SET_VERSION,
+                                                                                 calibration_set.SET_SEED),
+          'seconds': time.perf_counter() - t0, 'max_abs_shift_correction': float(np.abs(corr).max()),
+          'what': 'per-channel mean of the fp16 pipeline error moved into the fp32 shifts (dv_model_calibrate), '
+                  'measured on a fixed synthetic set per input shape: a property of the checkpoint, not of the run'}
 
 
 def cnn_tail_parity(model, C, images, probs, check=64):

@@ -43,6 +43,10 @@ def supported(shape: Tuple[int, int, int]) -> bool:
   return 1 <= c <= 10 and w % 2 == 1 and h >= 8
 
 
+_BLOCK = 64              # images are generated in blocks of 64 candidates (seed + block number): draw(shape, n) is a
+                         # prefix of draw(shape, m) for n <= m
+
+
 def draw(shape: Tuple[int, int, int], n: int = DEFAULT_IMAGES, device: int = 0,
          seed: int = SET_SEED) -> Optional[torch.Tensor]:
   """-> CUDA uint8 [n, H, W, C] (the same bytes for the same arguments, always), or None when the shape has no set."""
@@ -51,28 +55,29 @@ def draw(shape: Tuple[int, int, int], n: int = DEFAULT_IMAGES, device: int = 0,
   if not supported((h, w, c)) or n < 1:
     return None
   dev = torch.device('cuda', device)
+  out = torch.empty((n, h, w, c), dtype=torch.uint8, device=dev)
   if c <= 7:
     opts = _illumina_options(h, w, c)
     enc = _Encoder(opts, w, device=device)
-    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=dev)
-    done, k = 0, 0
-    while done < n:                      # multi-allelic sites are off: one pileup per candidate
-      batch = synth.make_illumina_batch(n - done, seed=seed + 7919 * k, options=opts, multi_allelic=False)
+  else:
+    kind = 'ont' if c == 9 else 'hifi'
+    opts = synth.longread_options(kind)
+    opts.height, opts.width = h, w
+    enc = _Encoder(opts, w, device=device) if c == 8 else None
+  for k, done in enumerate(range(0, n, _BLOCK)):
+    m = min(_BLOCK, n - done)
+    if c <= 7:                             # multi-allelic sites are off: one pileup per candidate
+      batch = synth.make_illumina_batch(_BLOCK, seed=seed + 7919 * k, options=opts, multi_allelic=False)
       img, _ = enc.encode(batch, c)
-      m = min(batch.n_items, n - done)
-      out[done:done + m] = torch.from_numpy(np.ascontiguousarray(img.reshape(-1, h, w, c)[:m])).to(dev)
-      done += m
-      k += 1
-    return out
-  kind = 'ont' if c == 9 else 'hifi'
-  opts = synth.longread_options(kind)
-  opts.height, opts.width = h, w
-  if c == 8:                             # the drawn HiFi channels alone
-    enc = _Encoder(opts, w, device=device)
-    batch = synth.make_longread_batch(n, kind, seed=seed, options=opts)
-    img, _ = enc.encode(batch, c)
-    return torch.from_numpy(np.ascontiguousarray(img.reshape(-1, h, w, c)[:n])).to(dev)
-  return longread_examples(kind, n, seed=seed, device=device, options=opts)
+      block = torch.from_numpy(np.ascontiguousarray(img.reshape(-1, h, w, c)[:_BLOCK])).to(dev)
+    elif c == 8:                           # the drawn HiFi channels alone
+      batch = synth.make_longread_batch(_BLOCK, kind, seed=seed + 7919 * k, options=opts)
+      img, _ = enc.encode(batch, c)
+      block = torch.from_numpy(np.ascontiguousarray(img.reshape(-1, h, w, c)[:_BLOCK])).to(dev)
+    else:
+      block = longread_examples(kind, _BLOCK, seed=seed + 7919 * k, device=device, options=opts)
+    out[done:done + m] = block[:m]
+  return out
 
 
 def longread_examples(kind: str, n: int, seed=None, device: int = 0, options=None) -> torch.Tensor:

@@ -220,8 +220,9 @@ def build_arg_parser():
   ap.add_argument('--stream_examples', **boolean)
   ap.add_argument('--allow_empty_examples', **boolean)
   ap.add_argument('--device', type=int, default=0)
-  # not a reference flag: the fp16 classifier's shifts are calibrated (dv_model_calibrate) on the first examples of
-  # the run -- up to this many, at least 64 -- before they are classified; 0 = the uncalibrated fp16 model
+  # not a reference flag: size of the fixed synthetic calibration set the fp16 classifier's shifts are calibrated on
+  # when the checkpoint is loaded (InceptionV3.calibrate_for_checkpoint; a property of the checkpoint and the input
+  # shape, never of the run's examples); 0 = the uncalibrated fp16 model
   ap.add_argument('--calibration_examples', type=int, default=256)
   return ap
 
@@ -310,6 +311,15 @@ def import_keras_checkpoint(prefix: str, in_channels: int, num_classes: int = 3,
   return dst
 
 
+def calibration_cache_prefix(spec: str):
+  """Where a checkpoint's calibration corrections are cached (InceptionV3.calibrate_for_checkpoint): next to the
+  checkpoint files; None for `random:<seed>` weights."""
+  if spec.startswith('random:'):
+    return None
+  prefix = checkpoint_prefix(spec)
+  return prefix if prefix is not None else spec
+
+
 def load_flat_checkpoint(spec: str, model, allow_channel_mismatch: bool = False):
   """--checkpoint: a TensorFlow checkpoint / SavedModel directory of the reference's Keras
   model, `random:<seed>`, or a flat fp32 array in dv_model_load_weights order."""
@@ -341,8 +351,7 @@ def main(argv=None) -> int:
   from deepvariant_amd.inception_v3 import InceptionV3
   model = InceptionV3(tuple(shape), max_batch=min(args.batch_size, 8192), device=args.device)
   load_flat_checkpoint(args.checkpoint, model)
-  if args.calibration_examples > 0:
-    model.enable_auto_calibration(max_images=args.calibration_examples)
+  model.calibrate_for_checkpoint(args.calibration_examples, cache_prefix=calibration_cache_prefix(args.checkpoint))
   n = call_variants(paths, args.outfile, model,
                     batch_size=args.batch_size, max_batches=args.max_batches,
                     writer_shards=max(1, min(args.writer_threads or 1, 16)),

@@ -35,6 +35,9 @@ struct TensorGeom {
 struct ConvBranch {
   const float* shift;     // [Cout (+pad)] folded BN shift, or NULL (raw output)
   _Float16* out;
+  float* out32;           // non-NULL: the output tensor is float32 (same geometry, a piece = 8 floats) -- raw pooled
+                          // projections awaiting their average pool, the last block's outputs awaiting the global pool:
+                          // tensors no MFMA reads are not rounded to fp16 on the way (round 6)
   TensorGeom og;
   int out_goff;           // first destination group of this branch
   int Cout;
@@ -133,172 +136,150 @@ __device__ __forceinline__ void divmod_small(int m, int d, float rcp, int& q, in
 
 // The arithmetic of one average-pool output channel, shared by avgpool3s1_kernel (model.hip) and the
 // pooling epilogue below so that both round alike: three column sums (each top + middle + bottom, zeros
-// outside the map), left to right, times 1 / (cells inside), then shift + ReLU when the pool carries them.
-__device__ __forceinline__ _Float16 avg_finish(float c0, float c1, float c2, float inv, float sh, bool shift_relu) {
+// outside the map) of the float32 raw projection, left to right, times 1 / (cells inside), then shift + ReLU
+// when the pool carries them.
+__device__ __forceinline__ float avg_finish(float c0, float c1, float c2, float inv, float sh, bool shift_relu) {
 #pragma clang fp contract(off)   // never (sum * inv + sh) as one fma in one kernel and two roundings in the other
   const float v = (c0 + c1 + c2) * inv;
-  return static_cast<_Float16>(shift_relu ? fmaxf(v + sh, 0.f) : v);
+  return shift_relu ? fmaxf(v + sh, 0.f) : v;
 }
 
-// Epilogue of one wave tile: shift + ReLU, lanes l / l+32 pair their halves into
-// 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run.
+// The shifts of one 32-cout subtile as this lane needs them, through the SCALAR cache (constant address
+// space, wave-uniform address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue:
+// shv[q][pair] = shifts of couts 8q + 4*hi + {0,1},{2,3}; zeros without a shift array (raw outputs).
+__device__ __forceinline__ void load_shifts(const float* shift, int cbase, int hi, float2_t (&shv)[4][2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+    if (shift != nullptr) {  // uniform; the shift array is padded past Cout
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
+      const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(shift + (cbase + 8 * q)));
+      const f4_t l4 = sp[0], u4 = sp[1];
+      lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
+      up = make_float4(u4[0], u4[1], u4[2], u4[3]);
+    }
+    shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
+    shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
+  }
+}
+
+// One 32-cout subtile of a wave tile -> its branch's tensor: shift + ReLU, then either fp16 -- lanes l / l+32
+// pair their halves into 16-byte pieces (v_permlane32_swap), 32 consecutive pixels = one 512-byte run -- or
+// float32 (ConvBranch::out32: each lane stores its four consecutive couts of every group, 16 bytes).
+template <int PT>
+__device__ __forceinline__ void epilogue_subtile(const float16_t (&acc)[PT], const ConvBranch& b, int cbase,
+                                                 const int (&pn)[PT], const int (&poh)[PT], const int (&pow_)[PT],
+                                                 const bool (&mvalid)[PT], int lane) {
+  const int hi = lane >> 5;
+  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
+  const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+  float2_t shv[4][2];
+  load_shifts(b.shift, cbase, hi, shv);
+  if (b.out32 != nullptr) {   // wave-uniform
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const float16_t a = acc[pt];
+      const unsigned obase = static_cast<unsigned>(
+          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp + pow_[pt] + b.og.halo);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(a[4 * q] + shv[q][0][0], a[4 * q + 1] + shv[q][0][1], a[4 * q + 2] + shv[q][1][0],
+                               a[4 * q + 3] + shv[q][1][1]);
+        if (b.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        const int group = cbase / 8 + q;
+        if (mvalid[pt] && group * 8 < b.Cout) {
+          *reinterpret_cast<float4*>(b.out32 + (static_cast<size_t>(obase) + static_cast<size_t>(group) * gstride) * 8 +
+                                     4 * hi) = v;
+        }
+      }
+    }
+    return;
+  }
+  uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const float16_t a = acc[pt];
+    // piece index of (n, group out_goff, oh, ow) in this branch's output tensor
+    const unsigned obase = static_cast<unsigned>(
+        ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
+        pow_[pt] + b.og.halo);
+    unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
+        half2_t h = __builtin_convertvector(v, half2_t);
+        if (b.relu) h = __builtin_elementwise_max(h, zero2);
+        pk[q][hq] = __builtin_bit_cast(unsigned, h);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
+      // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
+      // group 2t in the low half-wave and of group 2t+1 in the high one.
+      const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+      const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+      const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
+      const int group = cbase / 8 + 2 * t + hi;
+#ifdef DV_ABLATE_EPI    // timing ablation (tools/ablate_conv.sh): store only a value that never occurs
+      if (mvalid[pt] && group * 8 < b.Cout && piece[0] == 0x7e017e01u) {
+#else
+      if (mvalid[pt] && group * 8 < b.Cout) {
+#endif
+        outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+      }
+    }
+  }
+}
+
+// branch of 32-cout subtile `sub` of the launch (wave-uniform; the branch table sits in the kernarg
+// segment and is indexed with scalar loads)
+__device__ __forceinline__ int branch_of(const ConvArgs& p, int sub) {
+  int bi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
+  return bi;
+}
+
+// Epilogue of one wave tile.
 template <int NB, int PT>
 __device__ __forceinline__ void conv_epilogue(const float16_t (&acc)[NB][PT], const ConvArgs& p,
                                               int n_tile, const int (&pn)[PT], const int (&poh)[PT],
                                               const int (&pow_)[PT], const bool (&mvalid)[PT],
                                               int lane) {
-  const int hi = lane >> 5;
-  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    // branch of this 32-cout subtile (wave-uniform; the branch table sits in the kernarg
-    // segment and is indexed with scalar loads)
     const int sub = n_tile * NB + nb;
-    int bi = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
-    const ConvBranch& b = p.br[bi];
+    const ConvBranch& b = p.br[branch_of(p, sub)];
     const int cbase = (sub - b.sub0) * 32;  // first cout of the subtile within its branch
     if (cbase >= b.Cout) continue;           // padding subtile past the last branch
-    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
-    // Shifts come through the SCALAR cache (constant address space, wave-uniform
-    // address -> s_load_dwordx8, lgkmcnt) instead of the vector memory queue.
-    float2_t shv[4][2];  // [q][pair]: shifts of couts nb*32 + 8q + 4*hi + {0,1},{2,3}
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
-      if (b.shift != nullptr) {  // uniform; the shift array is padded past Cout
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
-        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(
-            b.shift + (cbase + 8 * q)));
-        const f4_t l4 = sp[0], u4 = sp[1];
-        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
-        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
-      }
-      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
-      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
-    }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const float16_t a = acc[nb][pt];
-      // piece index of (n, group out_goff, oh, ow) in this branch's output tensor
-      const unsigned obase = static_cast<unsigned>(
-          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
-          pow_[pt] + b.og.halo);
-      unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
-          half2_t h = __builtin_convertvector(v, half2_t);
-          if (b.relu) h = __builtin_elementwise_max(h, zero2);
-          pk[q][hq] = __builtin_bit_cast(unsigned, h);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // v_permlane32_swap(x, y): x' = {x.lo, y.lo}, y' = {x.hi, y.hi}.  With
-        // x = group 2t and y = group 2t+1, {x', y'} is the full 8-cout piece of
-        // group 2t in the low half-wave and of group 2t+1 in the high one.
-        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
-        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
-        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
-        const int group = cbase / 8 + 2 * t + hi;
-#ifdef DV_ABLATE_EPI    // timing ablation (tools/ablate_conv.sh): store only a value that never occurs
-        if (mvalid[pt] && group * 8 < b.Cout && piece[0] == 0x7e017e01u) {
-#else
-        if (mvalid[pt] && group * 8 < b.Cout) {
-#endif
-          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
-        }
-      }
-    }
+    epilogue_subtile<PT>(acc[nb], b, cbase, pn, poh, pow_, mvalid, lane);
   }
 }
 
 // Epilogue of conv_mfma_kernel<..., AVG>: branches without `avgpool` store as conv_epilogue does; the others
-// leave their RAW fp16 outputs in LDS (the weight slabs' space: NB*32 couts x 256 pixel slots x 2 bytes =
-// both slabs exactly), [subtile nb][8-cout group q][pixel slot][8 halfs], and after one barrier every thread
-// averages the 3x3 neighbourhood of ITS pixel slot (the block holds whole maps, ConvArgs::tile_g) for
-// the 4 groups of each pooled subtile: avgpool3s1_kernel's arithmetic (avg_finish), shift, ReLU, one
-// 16-byte store per group into the pooled tensor.  Bit-identical to conv -> avgpool3s1_kernel.
+// leave their RAW float32 outputs in LDS (the weight slabs' space holds two 32-cout subtiles x 256 pixel slots
+// x 4 bytes at a time, so a 128-cout tile is pooled in two halves), [subtile][8-cout group q][pixel slot]
+// [8 floats], and after a barrier every thread averages the 3x3 neighbourhood of ITS pixel slot (the block holds
+// whole maps, ConvArgs::tile_g) for the 4 groups of each pooled subtile: avgpool3s1_kernel's arithmetic
+// (avg_finish), shift, ReLU, one store per group into the pooled tensor.  Bit-identical to
+// conv (float32 raw tensor) -> avgpool3s1_kernel.  Round 6: the raw projection is no longer rounded to fp16
+// before it is averaged (the reference pools in float32; deepvariant/call_variants.py:913-918).
 template <int NB, int PT>
 __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT], const ConvArgs& p, int n_tile,
                                                   int pix_block, const int (&pn)[PT], const int (&poh)[PT],
                                                   const int (&pow_)[PT], const bool (&mvalid)[PT], int lane,
                                                   int wave, _Float16* smem) {
-  static_assert(PT == 2, "256-pixel blocks");
+  static_assert(PT == 2 && NB % 2 == 0, "256-pixel blocks, subtiles pooled in pairs");
   const int hi = lane >> 5;
-  const half2_t zero2 = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)};
-  uint4_t* tile = reinterpret_cast<uint4_t*>(smem);
-  __syncthreads();   // every wave has read its last weight fragment: the slabs become the pooling tile
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int sub = n_tile * NB + nb;
-    int bi = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
-    const ConvBranch& b = p.br[bi];
-    const int cbase = (sub - b.sub0) * 32;
-    if (cbase >= b.Cout) continue;
-    const bool pooled = b.avgpool != 0;   // block-uniform
-    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
-    float2_t shv[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
-      if (b.shift != nullptr && !pooled) {
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        typedef const f4_t __attribute__((address_space(4))) * const_f4_ptr;
-        const_f4_ptr sp = (const_f4_ptr)(reinterpret_cast<uintptr_t>(b.shift + (cbase + 8 * q)));
-        const f4_t l4 = sp[0], u4 = sp[1];
-        lo = make_float4(l4[0], l4[1], l4[2], l4[3]);
-        up = make_float4(u4[0], u4[1], u4[2], u4[3]);
-      }
-      shv[q][0] = hi ? float2_t{up.x, up.y} : float2_t{lo.x, lo.y};
-      shv[q][1] = hi ? float2_t{up.z, up.w} : float2_t{lo.z, lo.w};
-    }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const float16_t a = acc[nb][pt];
-      const unsigned obase = static_cast<unsigned>(
-          ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp + pow_[pt] + b.og.halo);
-      const int slot = (wave * PT + pt) * 32 + (lane & 31);
-      unsigned pk[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-          const float2_t v = float2_t{a[4 * q + 2 * hq], a[4 * q + 2 * hq + 1]} + shv[q][hq];
-          half2_t h = __builtin_convertvector(v, half2_t);
-          if (b.relu && !pooled) h = __builtin_elementwise_max(h, zero2);
-          pk[q][hq] = __builtin_bit_cast(unsigned, h);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const auto d0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
-        const auto d1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
-        const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
-        const int q8 = 2 * t + hi;            // 8-cout group within the subtile
-        const int group = cbase / 8 + q8;
-        if (pooled) {
-          tile[(nb * 4 + q8) * 256 + slot] = piece;   // idle slots too: never read
-        } else if (mvalid[pt] && group * 8 < b.Cout) {
-          outp[obase + static_cast<unsigned>(group) * gstride] = piece;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- pooling pass: thread = pixel slot
-  const int slot = wave * 64 + lane;
+  float* tile = reinterpret_cast<float*>(smem);
+  // the pooling pass's pixel: thread = pixel slot
+  const int my_slot = wave * 64 + lane;
   int il, pix, y, x;
-  divmod_small(slot, p.tile_p, p.rcp_tile_p, il, pix);
+  divmod_small(my_slot, p.tile_p, p.rcp_tile_p, il, pix);
   divmod_small(pix, p.OW, p.rcp_ow, y, x);
   const int n = pix_block * p.tile_g + il;
   const bool live = il < p.tile_g && n < p.N;
@@ -306,54 +287,93 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
   const int map0 = il * p.tile_p;
   const float inv = 1.0f / static_cast<float>(((y > 0) + (y < H - 1) + 1) * ((x > 0) + (x < W - 1) + 1));
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int sub = n_tile * NB + nb;
-    int bi = 0;
+  for (int half = 0; half < NB / 2; ++half) {
+    bool any_pooled = false;   // block-uniform
 #pragma unroll
-    for (int i = 1; i < kMaxBranches; ++i) bi += (i < p.n_branches && sub >= p.br[i].sub0) ? 1 : 0;
-    const ConvBranch& b = p.br[bi];
-    const int cbase = (sub - b.sub0) * 32;
-    if (cbase >= b.Cout || !b.avgpool || !live) continue;
-    const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
-    const unsigned obase = static_cast<unsigned>(
-        ((n * b.og.groups + b.out_goff) * b.og.hp + y + b.og.halo) * b.og.wp + x + b.og.halo);
-    uint4_t* outp = reinterpret_cast<uint4_t*>(b.out);
-    for (int q8 = 0; q8 < 4; ++q8) {
-      const int group = cbase / 8 + q8;
-      if (group * 8 >= b.Cout) break;
-      const half8_t* src = reinterpret_cast<const half8_t*>(tile) + (nb * 4 + q8) * 256 + map0;
-      float col[3][8];
+    for (int nbl = 0; nbl < 2; ++nbl) {
+      const int sub = n_tile * NB + 2 * half + nbl;
+      const ConvBranch& b = p.br[branch_of(p, sub)];
+      const int cbase = (sub - b.sub0) * 32;
+      if (cbase >= b.Cout) continue;
+      if (b.avgpool == 0) {
+        epilogue_subtile<PT>(acc[2 * half + nbl], b, cbase, pn, poh, pow_, mvalid, lane);
+      } else {
+        any_pooled = true;
+      }
+    }
+    if (!any_pooled) continue;
+    __syncthreads();   // every wave has read its last weight fragment / finished the previous half's pooling pass
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x + dx - 1;
-        const bool cx = xx >= 0 && xx < W;
-        half8_t r[3];
+    for (int nbl = 0; nbl < 2; ++nbl) {
+      const int sub = n_tile * NB + 2 * half + nbl;
+      const ConvBranch& b = p.br[branch_of(p, sub)];
+      const int cbase = (sub - b.sub0) * 32;
+      if (cbase >= b.Cout || b.avgpool == 0) continue;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int yy = y + dy - 1;
-          const bool ok = cx && yy >= 0 && yy < H;
-          r[dy] = src[ok ? yy * W + xx : pix];
-          if (!ok) {
+      for (int pt = 0; pt < PT; ++pt) {
+        const float16_t a = acc[2 * half + nbl][pt];
+        const int slot = (wave * PT + pt) * 32 + (lane & 31);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[dy][j] = static_cast<_Float16>(0.f);
+        for (int q = 0; q < 4; ++q) {   // idle slots too: never read
+          *reinterpret_cast<float4*>(tile + ((nbl * 4 + q) * 256 + slot) * 8 + 4 * hi) =
+              make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nbl = 0; nbl < 2; ++nbl) {
+      const int sub = n_tile * NB + 2 * half + nbl;
+      const ConvBranch& b = p.br[branch_of(p, sub)];
+      const int cbase = (sub - b.sub0) * 32;
+      if (cbase >= b.Cout || b.avgpool == 0 || !live) continue;
+      const unsigned gstride = static_cast<unsigned>(b.og.hp * b.og.wp);
+      const unsigned obase = static_cast<unsigned>(
+          ((n * b.og.groups + b.out_goff) * b.og.hp + y + b.og.halo) * b.og.wp + x + b.og.halo);
+      for (int q8 = 0; q8 < 4; ++q8) {
+        const int group = cbase / 8 + q8;
+        if (group * 8 >= b.Cout) break;
+        const float* src = tile + ((nbl * 4 + q8) * 256 + map0) * 8;
+        float col[3][8];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = x + dx - 1;
+          const bool cx = xx >= 0 && xx < W;
+          float r[3][8];
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool ok = cx && yy >= 0 && yy < H;
+            const float4* s4 = reinterpret_cast<const float4*>(src + (ok ? yy * W + xx : pix) * 8);
+            const float4 lo = s4[0], up = s4[1];
+            r[dy][0] = ok ? lo.x : 0.f; r[dy][1] = ok ? lo.y : 0.f; r[dy][2] = ok ? lo.z : 0.f; r[dy][3] = ok ? lo.w : 0.f;
+            r[dy][4] = ok ? up.x : 0.f; r[dy][5] = ok ? up.y : 0.f; r[dy][6] = ok ? up.z : 0.f; r[dy][7] = ok ? up.w : 0.f;
           }
-        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          col[dx][j] = static_cast<float>(r[0][j]) + static_cast<float>(r[1][j]) + static_cast<float>(r[2][j]);
+          for (int j = 0; j < 8; ++j) col[dx][j] = r[0][j] + r[1][j] + r[2][j];
+        }
+        float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (b.shift != nullptr) {
+          const float4 s0 = *reinterpret_cast<const float4*>(b.shift + group * 8);
+          const float4 s1 = *reinterpret_cast<const float4*>(b.shift + group * 8 + 4);
+          sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
+          sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
+        }
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = avg_finish(col[0][j], col[1][j], col[2][j], inv, sh[j], b.shift != nullptr);
+        const size_t at = static_cast<size_t>(obase) + static_cast<size_t>(group) * gstride;
+        if (b.out32 != nullptr) {
+          float4* d = reinterpret_cast<float4*>(b.out32 + at * 8);
+          d[0] = make_float4(o[0], o[1], o[2], o[3]);
+          d[1] = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+          half8_t h;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = static_cast<_Float16>(o[j]);
+          reinterpret_cast<uint4_t*>(b.out)[at] = __builtin_bit_cast(uint4_t, h);
         }
       }
-      float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (b.shift != nullptr) {
-        const float4 s0 = *reinterpret_cast<const float4*>(b.shift + group * 8);
-        const float4 s1 = *reinterpret_cast<const float4*>(b.shift + group * 8 + 4);
-        sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
-        sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
-      }
-      half8_t o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = avg_finish(col[0][j], col[1][j], col[2][j], inv, sh[j], b.shift != nullptr);
-      outp[obase + static_cast<unsigned>(group) * gstride] = __builtin_bit_cast(uint4_t, o);
     }
   }
 }

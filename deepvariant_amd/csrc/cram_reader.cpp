@@ -296,9 +296,15 @@ void rans_decode(const uint8_t* in, size_t n_in, std::vector<uint8_t>* out) {
   const int order = c.u8();
   c.le32();                       // compressed size
   const uint32_t out_size = c.le32();
-  // rANS 4x8 cannot expand by more than its 12-bit frequency resolution allows per symbol: refuse sizes a few
-  // bytes of input could not have produced before allocating them (a 9-byte block may not ask for 4 GiB)
-  if (static_cast<uint64_t>(out_size) > (static_cast<uint64_t>(n_in) + 16) * 4096) bad("rANS block states an impossible size");
+  // Refuse sizes that a few bytes of input could not have produced before allocating them (a 9-byte block may not
+  // ask for 4 GiB).  The real bound of rANS 4x8: frequencies are normalised to 4095 / 4096 at most, so a dominant
+  // symbol costs log2(4096 / 4095) = 3.5e-4 bits -- ~22,700 symbols per payload byte -- and each of the four
+  // states absorbs ~23 K symbols before it emits its first byte (1.5 M constant quality values of a 10 k-read slice
+  // are a 64-byte payload).  32,768 symbols per input byte + 1 Mi covers both; nothing a slice holds nears 1 GiB.
+  if (static_cast<uint64_t>(out_size) > (static_cast<uint64_t>(n_in) + 16) * 32768 + (1u << 20) ||
+      out_size > (1u << 30)) {
+    bad("rANS block states an impossible size");
+  }
   out->assign(out_size, 0);
   if (out_size == 0) return;
   uint8_t* o = out->data();
@@ -392,10 +398,15 @@ void read_block(Cursor& c, Block* b, bool decode = true) {
   c.take(4);  // CRC32
   b->pos = 0;
   if (!decode) return;
-  // gzip / bzip2 / lzma expand by at most ~1000x / ~50000x (run lengths) in theory, real CRAM blocks by < 100x:
-  // a stated raw size beyond 65536x the payload (+ slack for tiny blocks) is refused before it is allocated
-  if (method != 0 && static_cast<uint64_t>(rsize) > (static_cast<uint64_t>(csize) + 64) * 65536) {
-    bad("CRAM block states an impossible uncompressed size");
+  // A stated raw size that the payload could not have produced is refused before it is allocated.  Deflate expands
+  // by at most 1032x; bzip2 (RLE1 + BWT + RLE2) and LZMA reach ~1,000,000x on constant data -- which real CRAM blocks
+  // hold (one quality value, one flag for every read) -- so their bound is 2^21 per payload byte; rANS has its own
+  // check; and no block of a slice nears 1 GiB whatever the codec.
+  if (method != 0) {
+    const uint64_t per_byte = method == 1 ? 1100u : (1u << 21);
+    if (static_cast<uint64_t>(rsize) > (static_cast<uint64_t>(csize) + 64) * per_byte || rsize > (1 << 30)) {
+      bad("CRAM block states an impossible uncompressed size");
+    }
   }
   switch (method) {
     case 0:

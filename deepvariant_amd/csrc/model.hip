@@ -733,9 +733,21 @@ __global__ __launch_bounds__(512, 1) void conv_pool_resident_kernel(ConvArgs p) 
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) carry[nb][q][0] = carry[nb][q][1] = 0u;
-    for (int s = 0; s <= PH; ++s) {
+    // Blank-row skipping (ConvArgs::blank_row = first blank-determined POOLED row per example): the wave walks
+    // down only as far as the deepest pile-up among its (at most two) examples reaches -- pooled rows
+    // 0 .. s_end - 1 -- and copies the rows below from the all-blank image's response (the values the walk would
+    // produce there, bit for bit).  A lane whose own example turns blank earlier computes its blank rows: same bits.
+    int s_end = PH;
+    if (p.blank_row != nullptr) {
+      int mine = valid ? min(p.blank_row[n], PH) : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mine = max(mine, __shfl_xor(mine, off));
+      s_end = __builtin_amdgcn_readfirstlane(mine);
+    }
+    for (int s = 0; s <= s_end; ++s) {
+      if (s_end == 0) break;      // every pooled row of this fragment is blank-determined
       unsigned top[NB][4][2];   // conv row 2s
-      if (s < PH) {
+      if (s < s_end) {
         unsigned base[2] = {base0, base0};
         if (valid) {
           base[0] = base0 + static_cast<unsigned>(2 * s) * row_b;
@@ -799,6 +811,22 @@ __global__ __launch_bounds__(512, 1) void conv_pool_resident_kernel(ConvArgs p) 
           const uint4_t piece = {d0[0], d1[0], d0[1], d1[1]};
           const int group = cbase / 8 + 2 * t + hi;
           if (emits && group * 8 < b.Cout) outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+        }
+      }
+    }
+    if (s_end < PH && emits) {   // the blank-determined pooled rows of this lane's column: copied
+      const uint4_t* src = reinterpret_cast<const uint4_t*>(p.blank_src);
+      const unsigned rel0 = static_cast<unsigned>(b.og.halo * b.og.wp + (col >> 1) + b.og.halo);
+      const unsigned img = static_cast<unsigned>(n * b.og.groups) * gstride;
+      for (int pr = s_end; pr < PH; ++pr) {
+        const unsigned rel = rel0 + static_cast<unsigned>(pr * b.og.wp);
+#pragma unroll
+        for (int j = 0; j < NB * 2; ++j) {   // lanes l / l + 32 take alternate 8-cout groups of this tile
+          const int group = n_tile * NB * 4 + 2 * j + hi;
+          if (group * 8 < b.Cout) {
+            const unsigned at = static_cast<unsigned>(b.out_goff + group) * gstride + rel;
+            outp[img + at] = src[at];
+          }
         }
       }
     }
@@ -1124,7 +1152,7 @@ __global__ void preprocess_kernel(const ExtPtrs* ext, size_t in_off, _Float16* o
 //   conv1 3x3/2 valid: rows 2y..2y+2   -> y >= ceil(r / 2)         (= conv2, 3x3 valid on those)
 //   conv3 3x3 same:    rows y-1..y+1   -> y >= t2 + 1
 //   max-pool 3x3/2:    rows 2y..2y+2   -> y >= ceil(t3 / 2)        (= the 1x1 and the 3x3 valid 80->192)
-// thr[k * stride + n], k = 0: rows used, 1: conv2 output, 2: stem_b output, 3: 3x3 80->192 output.
+// thr[k * stride + n], k = 0: rows used, 1: conv2 output, 2: stem_b output, 3: 3x3 80->192 output, 4: the same, pooled.
 __global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, size_t in_off, int H, int row_bytes,
                                                          int* thr, int stride) {
   __shared__ int last;
@@ -1160,12 +1188,15 @@ __global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, siz
     thr[stride + n] = t2;
     thr[2 * stride + n] = t4;
     thr[3 * stride + n] = t4;
+    thr[4 * stride + n] = (t4 + 1) / 2;   // the 3x3 80->192's output max-pooled (3x3 / 2) inside its producer: rows 2s .. 2s+2
   }
 }
 
 struct PoolArgs {
-  const _Float16* in;
+  const _Float16* in;     // maxpool3s2_kernel: fp16
+  const float* in32;      // avgpool3s1_kernel: the float32 raw projection
   _Float16* out;
+  float* out32;           // avgpool3s1_kernel: non-NULL = the pooled tensor is float32 (the last block's, read by the head)
   TensorGeom ig, og;
   int N, C, OH, OW;
   int out_goff;
@@ -1200,11 +1231,11 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
       best;
 }
 
-// AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.  The input
-// buffer carries a zero halo of >= 1 (build() asks for it), so the taps are unconditional
-// 16-byte loads and only the divisor depends on the position.  One thread produces TWO
-// horizontally adjacent outputs from a 3x4 window (12 loads instead of 18): the three
-// column sums in the middle are shared.
+// AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.  The input is the float32 raw
+// 1x1 projection of a pooled branch (pooled_projection: conv -> pool -> shift -> ReLU); its buffer carries a
+// zero halo of >= 1 (build() asks for it), so the taps are unconditional loads and only the divisor depends on
+// the position.  One thread produces TWO horizontally adjacent outputs from a 3x4 window (12 loads instead of
+// 18): the three column sums in the middle are shared.  Same arithmetic as conv_epilogue_avg (avg_finish).
 __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int cg = p.C / 8;
   const int H = p.ig.h, W = p.ig.w;
@@ -1219,18 +1250,21 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
   const int g = t % cg;
   const int n = t / cg;
   const bool two = ow + 1 < W;
-  const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
-                       ((static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp + oh + p.ig.halo - 1) *
-                           p.ig.wp + ow + p.ig.halo - 1;
+  const float4* src = reinterpret_cast<const float4*>(p.in32) +
+                      (((static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp + oh + p.ig.halo - 1) *
+                           p.ig.wp + ow + p.ig.halo - 1) * 2;
   const int last = two ? 3 : 2;  // never read past the row's halo
   float col[4][8];
 #pragma unroll
   for (int dw = 0; dw < 4; ++dw) {
     const int c = dw < 3 ? dw : last;
-    const half8_t a = src[c], b = src[p.ig.wp + c], d = src[2 * p.ig.wp + c];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      col[dw][j] = static_cast<float>(a[j]) + static_cast<float>(b[j]) + static_cast<float>(d[j]);
+    for (int hf = 0; hf < 2; ++hf) {
+      const float4 a = src[2 * c + hf], b = src[2 * (p.ig.wp + c) + hf], d = src[2 * (2 * p.ig.wp + c) + hf];
+      col[dw][4 * hf + 0] = a.x + b.x + d.x;
+      col[dw][4 * hf + 1] = a.y + b.y + d.y;
+      col[dw][4 * hf + 2] = a.z + b.z + d.z;
+      col[dw][4 * hf + 3] = a.w + b.w + d.w;
     }
   }
   const int rows = (oh > 0) + (oh < H - 1) + 1;
@@ -1241,25 +1275,34 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
     sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
     sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
   }
-  half8_t* dst = reinterpret_cast<half8_t*>(p.out) +
-                 ((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) * p.og.hp + oh +
-                  p.og.halo) * p.og.wp + ow + p.og.halo;
+  const size_t at = ((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) * p.og.hp + oh + p.og.halo) * p.og.wp +
+                    ow + p.og.halo;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (k == 1 && !two) break;
     const int x = ow + k;
     const float inv = 1.0f / static_cast<float>(rows * ((x > 0) + (x < W - 1) + 1));
-    half8_t o;
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       o[j] = avg_finish(col[k][j], col[k + 1][j], col[k + 2][j], inv, sh[j], p.shift != nullptr);
     }
-    dst[k] = o;
+    if (p.out32 != nullptr) {
+      float4* d = reinterpret_cast<float4*>(p.out32 + (at + k) * 8);
+      d[0] = make_float4(o[0], o[1], o[2], o[3]);
+      d[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+      half8_t h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = static_cast<_Float16>(o[j]);
+      reinterpret_cast<half8_t*>(p.out)[at + k] = h;
+    }
   }
 }
 
-// GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.
-__global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const float* w,
+// GlobalAveragePooling2D + Dense(num_classes) + softmax, fp32.  Round 6: the last block's outputs arrive in
+// float32 (BufferDesc::f32) -- the values the convolutions' accumulators held, not an fp16 copy of them.
+__global__ __launch_bounds__(256) void head_kernel(const float* in, const float* w,
                                                    const float* b, const ExtPtrs* ext, size_t probs_off,
                                                    TensorGeom g, int K) {
   float* probs = ext->probs + probs_off;
@@ -1269,17 +1312,17 @@ __global__ __launch_bounds__(256) void head_kernel(const _Float16* in, const flo
   const int C = g.groups * 8;
   const size_t plane = static_cast<size_t>(g.hp) * g.wp * 8;
   float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const _Float16* x = in + static_cast<size_t>(n) * g.groups * plane;
+  const float* x = in + static_cast<size_t>(n) * g.groups * plane;
   const float invP = 1.0f / static_cast<float>(g.h * g.w);
   // one thread per 8-channel group: the map's pixels come in as whole 16-byte pieces
   for (int grp = tid; grp * 8 < C; grp += 256) {
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const half8_t* xg = reinterpret_cast<const half8_t*>(x + static_cast<size_t>(grp) * plane);
+    const float4* xg = reinterpret_cast<const float4*>(x + static_cast<size_t>(grp) * plane);
     for (int y = 0; y < g.h; ++y)
       for (int xx = 0; xx < g.w; ++xx) {
-        const half8_t v = xg[(y + g.halo) * g.wp + xx + g.halo];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += static_cast<float>(v[j]);
+        const float4 lo = xg[((y + g.halo) * g.wp + xx + g.halo) * 2], up = xg[((y + g.halo) * g.wp + xx + g.halo) * 2 + 1];
+        s[0] += lo.x; s[1] += lo.y; s[2] += lo.z; s[3] += lo.w;
+        s[4] += up.x; s[5] += up.y; s[6] += up.z; s[7] += up.w;
       }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1319,11 +1362,14 @@ struct BufferDesc {
   int h, w, c;  // channels = full (concat) width
   int halo = 0; // max padding any consumer needs (zero border kept in HBM)
   int min_examples = 1;  // imgconv tiles read whole groups of images: allocate at least this many
+  bool f32 = false;      // float32 elements (a piece = 8 floats): tensors that no MFMA reads -- the raw 1x1 outputs of
+                         // the pooled projections (input of an average pool) and the last block's outputs (input of the
+                         // global pool) -- keep the accumulators' values instead of an fp16 rounding of them
   TensorGeom geom() const {
     return TensorGeom{h, w, halo, h + 2 * halo, w + 2 * halo, c / 8};
   }
   size_t bytes_per_example() const {
-    return static_cast<size_t>(h + 2 * halo) * (w + 2 * halo) * c * 2;
+    return static_cast<size_t>(h + 2 * halo) * (w + 2 * halo) * c * (f32 ? 4 : 2);
   }
 };
 
@@ -1395,12 +1441,18 @@ struct dv_model {
   size_t packed_halfs = 0, shift_floats = 0, tbl_entries = 0;
   std::vector<dv::DeviceBuffer> dbuf;
   dv::DeviceBuffer d_w, d_shift, d_dense_w, d_dense_b, d_tbl;
-  // opt-in blank-row skipping (DV_BLANK_SKIP=1; HISTORY.md 7)
-  bool blank_skip = false;        // requested and applicable to this model
+  // Blank-row skipping through the stem (round 6: on by default, DV_BLANK_SKIP=0 / dv_model_set_blank_skip turn it
+  // off): tiles of conv2 / stem_b / the 3x3 80->192 whose receptive field holds only the zero rows below
+  // the pile-up are copied from the all-blank image's response instead of computed -- bit-identical.
+  bool blank_skip = false;        // applicable to this model and not switched off by the environment
+  bool blank_enabled = true;      // dv_model_set_blank_skip
   bool blank_ready = false;       // the blank responses have been computed (after load_weights)
   int blank_conv4_op = -1;        // op index of the stem's 3x3 80->192
-  dv::DeviceBuffer d_blank_thr;   // int32 [4][max_batch], blank_rows_kernel
-  dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output for the all-blank image (one example)
+  dv::DeviceBuffer d_blank_thr;   // int32 [5][max_batch], blank_rows_kernel
+  dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output (pooled when its kernel pools) for the all-blank image (one example)
+  dv::DeviceBuffer d_blank_c2;    // conv2's output for the all-blank image
+  dv::DeviceBuffer d_blank_b;     // stem_b's (the 1x1 64->80's) output for the all-blank image
+  bool blank_on() const { return blank_ready && blank_enabled; }
   bool loaded = false;
   std::vector<float> h_shift, h_dense_b;   // as computed by dv_model_load_weights (before any calibration)
   dv::DeviceBuffer d_ext;         // ExtPtrs: the caller's image / probability pointers of the running forward
@@ -1494,6 +1546,7 @@ struct dv_model {
   void pooled_projection(TensorRef x, int cout, int dst_buf, int dst_coff) {
     TensorRef raw = conv(x, cout, 1, 1);
     ops.back().raw = true;                   // no shift, no ReLU in the conv epilogue
+    buffers[raw.buf].f32 = true;             // averaged in float32 (conv_epilogue_avg / avgpool3s1_kernel)
     const size_t shift_off = ops.back().shift_off;
     pool(kOpAvgPool, raw, dst_buf, dst_coff);
     ops.back().shift_off = shift_off;        // applied after the pool
@@ -1597,7 +1650,9 @@ struct dv_model {
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& op = ops[i];
       const int followers = op.type == kOpConv ? op.group_followers : 0;
-      if (op.type == kOpConv && !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b &&
+      bool f32_out = false;   // float32 outputs go through conv_epilogue only
+      for (int gi = 0; gi <= followers; ++gi) f32_out = f32_out || buffers[ops[i + gi].out_buf].f32;
+      if (op.type == kOpConv && !f32_out && !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b &&
           op.chain_len == 0 && !op.in_chain &&
           !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
           dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
@@ -1782,6 +1837,9 @@ struct dv_model {
   void choose_avg_epilogue() {
     if (getenv("DV_NO_AVG_EPI") != nullptr) return;
     const int min_g = getenv("DV_AVG_EPI_MIN_G") ? atoi(getenv("DV_AVG_EPI_MIN_G")) : 1;   // tuning knob: whole maps per block
+    // whole maps must fill this share of the 256 pixel slots (percent).  Round 5: 90 (the ILLUMINA30 maps: 98 / 94 / 100 %);
+    // round 6: 85, which takes in ONT_R104's 10x22 maps (86 %) -- PACBIO's 10x16 (62 %) keeps the separate pool
+    const int min_fill = getenv("DV_AVG_EPI_MIN_FILL") ? atoi(getenv("DV_AVG_EPI_MIN_FILL")) : 85;
     for (size_t i = 0; i < ops.size(); ++i) {
       Op& lead = ops[i];
       if (lead.type != kOpConv) continue;
@@ -1790,7 +1848,7 @@ struct dv_model {
       const bool ok = lead.kh == 1 && lead.kw == 1 && lead.stride == 1 && lead.nb == 4 && !lead.split && !lead.pool_in &&
                       !lead.pool_out && !lead.v2 && !lead.band && lead.chain_len == 0 && !lead.in_chain &&
                       !lead.first_u8 && !lead.stem_a && !lead.stem_b && px >= 5 && px <= 256 &&
-                      (256 / px) * px * 10 >= 256 * 9 && 256 / px >= min_g;
+                      (256 / px) * px * 100 >= 256 * min_fill && 256 / px >= min_g;
       if (ok) {
         for (int gi = 0; gi <= followers; ++gi) {
           Op& c = ops[i + gi];
@@ -1829,8 +1887,8 @@ struct dv_model {
     const int min_len_2d = getenv("DV_CHAIN2D_MIN_LEN") ? atoi(getenv("DV_CHAIN2D_MIN_LEN")) : 2;
     std::vector<int> readers(buffers.size(), 0);
     for (const Op& o : ops) readers[o.in_buf]++;
-    auto plain = [](const Op& o) {
-      return o.type == kOpConv && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
+    auto plain = [&](const Op& o) {
+      return o.type == kOpConv && !buffers[o.out_buf].f32 && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
              o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
              !o.first_u8 && !o.pool_in && !o.pool_out && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
              o.cin == o.cin_real && o.oh == o.ih && o.ow == o.iw;
@@ -1942,11 +2000,9 @@ struct dv_model {
     const int pool2_ih = x.h, pool2_iw = x.w;
     // Round 4: the pool moves into its PRODUCER (conv_pool_resident_kernel): the 21 x 51 x 192 tensor
     // is never written, mixed0's heads read the pooled 10 x 25 x 192 tensor like any other block's.
-    // DV_NO_POOL2_IN_CONV keeps the round-3 arrangement (pool on load in the heads); so does the
-    // opt-in blank-row skipping, which works on the unpooled tensor.
+    // DV_NO_POOL2_IN_CONV keeps the round-3 arrangement (pool on load in the heads).
     const bool pool_in_conv = fuse_pool2 && getenv("DV_NO_POOL2_IN_CONV") == nullptr && ops.back().nb == 3 &&
-                              x.h >= 3 && x.w >= 3 &&
-                              !(getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0);
+                              x.h >= 3 && x.w >= 3;
     if (pool_in_conv) {
       x.h = (x.h - 3) / 2 + 1;
       x.w = (x.w - 3) / 2 + 1;
@@ -2035,6 +2091,7 @@ struct dv_model {
       x = full(out);
     }
     feat_buf = x.buf;
+    buffers[feat_buf].f32 = true;            // the global pool reads float32
     feat_p = x.h * x.w;
     feat_c = x.c;
     group_siblings();
@@ -2287,7 +2344,11 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.tiles_x = (c2.ow + dv::kStemA_TW - 1) / dv::kStemA_TW;
       a.total_tiles = n * a.tiles_y * a.tiles_x;
       a.in_bytes = static_cast<unsigned>(static_cast<size_t>(n) * op.ih * op.iw * op.cin_real);
-      TraceScope tr(stream, "stem_a conv3x3s2 " + std::to_string(op.cin_real) + "->32 + conv3x3 32->32 (fused)",
+      if (m->blank_on()) {
+        a.blank_thr = static_cast<const int*>(m->d_blank_thr.ptr) + 1 * m->desc.max_batch;
+        a.blank_src = static_cast<const _Float16*>(m->d_blank_c2.ptr);
+      }
+      TraceScope tr(stream, std::string(m->blank_on() ? "[blank tiles copied] " : "") + "stem_a conv3x3s2 " + std::to_string(op.cin_real) + "->32 + conv3x3 32->32 (fused)",
                     2.0 * n * (static_cast<double>(op.oh) * op.ow * op.kh * op.kw * op.cin_real * op.cout +
                                static_cast<double>(c2.oh) * c2.ow * 9 * 32 * 32),
                     static_cast<double>(n) * (op.ih * op.iw * op.cin_real + 2.0 * c2.oh * c2.ow * 32));
@@ -2319,7 +2380,11 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.total_tiles = n * a.tiles_y * a.tiles_x;
       a.in_bytes = static_cast<size_t>(n) * ib.bytes_per_example();
       a.in_img_bytes = static_cast<unsigned>(ib.bytes_per_example());
-      TraceScope tr(stream, "stem_b conv3x3 32->64 + maxpool3s2 + conv1x1 64->" + std::to_string(c4.cout) + " (fused)",
+      if (m->blank_on()) {
+        a.blank_thr = static_cast<const int*>(m->d_blank_thr.ptr) + 2 * m->desc.max_batch;
+        a.blank_src = static_cast<const _Float16*>(m->d_blank_b.ptr);
+      }
+      TraceScope tr(stream, std::string(m->blank_on() ? "[blank tiles copied] " : "") + "stem_b conv3x3 32->64 + maxpool3s2 + conv1x1 64->" + std::to_string(c4.cout) + " (fused)",
                     2.0 * n * (static_cast<double>(op.oh) * op.ow * 9 * 32 * 64 +
                                static_cast<double>(c4.oh) * c4.ow * 64 * c4.cout),
                     2.0 * n * (static_cast<double>(op.ih) * op.iw * 32 + static_cast<double>(c4.oh) * c4.ow * c4.cout));
@@ -2549,6 +2614,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                  (bo.out_buf == shifted_buf
                       ? static_cast<size_t>(out_example_off) * bob.bytes_per_example() / 2
                       : 0);
+        br.out32 = bob.f32 ? static_cast<float*>(m->dbuf[bo.out_buf].ptr) : nullptr;   // (never the stem's shifted buffer)
         br.og = bob.geom();
         br.out_goff = bo.out_coff / 8;
         br.Cout = bo.cout;
@@ -2563,6 +2629,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
           br.relu = 1;
           br.out = static_cast<_Float16*>(m->dbuf[pl.out_buf].ptr) +
                    (pl.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * pb.bytes_per_example() / 2 : 0);
+          br.out32 = pb.f32 ? static_cast<float*>(m->dbuf[pl.out_buf].ptr) : nullptr;
           br.og = pb.geom();
           br.out_goff = pl.out_coff / 8;
           a.tile_g = op.avg_tile_g;
@@ -2574,10 +2641,17 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.w = static_cast<const _Float16*>(m->d_w.ptr) + op.w_off;
       const int tiles = (subs + op.nb - 1) / op.nb;
       a.n_tiles = tiles;
-      if (m->blank_ready && m->blank_conv4_op >= 0 && &op == &m->ops[m->blank_conv4_op] &&
+      if (m->blank_on() && m->blank_conv4_op >= 0 && &op == &m->ops[m->blank_conv4_op] &&
           a.n_branches == 1 && !op.band && !op.v2 && !op.pool_in) {
-        a.blank_row = static_cast<const int*>(m->d_blank_thr.ptr) + 3 * m->desc.max_batch;
+        a.blank_row = static_cast<const int*>(m->d_blank_thr.ptr) + (op.pool_out ? 4 : 3) * m->desc.max_batch;
         a.blank_src = static_cast<const _Float16*>(m->d_blank_conv4.ptr);
+        tr_label += " [blank rows copied]";
+      }
+      if (m->blank_on() && oi == 1 && !m->ops[0].stem_a && a.n_branches == 1 && !op.band && !op.v2 && !op.pool_in &&
+          !op.pool_out && !op.split && op.nb <= 4 && m->d_blank_c2.ptr != nullptr) {
+        // inputs of 9..16 channels: conv2 runs per layer (conv_mfma_kernel) and skips like the fused stem_a does
+        a.blank_row = static_cast<const int*>(m->d_blank_thr.ptr) + 1 * m->desc.max_batch;
+        a.blank_src = static_cast<const _Float16*>(m->d_blank_c2.ptr);
         tr_label += " [blank rows copied]";
       }
       oi += op.group_followers;  // the followers ran in this launch
@@ -2663,7 +2737,9 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
     } else {
       PoolArgs p{};
       p.in = static_cast<const _Float16*>(m->dbuf[op.in_buf].ptr);
+      p.in32 = static_cast<const float*>(m->dbuf[op.in_buf].ptr);
       p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
+      p.out32 = ob.f32 ? static_cast<float*>(m->dbuf[op.out_buf].ptr) : nullptr;
       p.ig = m->buffers[op.in_buf].geom();
       p.og = ob.geom();
       p.N = n;
@@ -2682,8 +2758,10 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                     0.0, 2.0 * n * op.cin * (static_cast<double>(op.ih) * op.iw + op.oh * op.ow));
       dv::ProfileScope prof(dv::kProfOther, stream);
       if (op.type == kOpMaxPool) {
+        if (m->buffers[op.in_buf].f32 || ob.f32) return dv::fail(DV_ERR_UNSUPPORTED, "max-pool of a float32 tensor");
         hipLaunchKernelGGL(maxpool3s2_kernel, grid, dim3(256), 0, stream, p);
       } else {
+        if (!m->buffers[op.in_buf].f32) return dv::fail(DV_ERR_UNSUPPORTED, "average pool of an fp16 tensor");
         hipLaunchKernelGGL(avgpool3s1_kernel, grid, dim3(256), 0, stream, p);
       }
     }
@@ -2755,12 +2833,12 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (int rc = m->d_dense_w.reserve(static_cast<size_t>(m->feat_c) * desc->num_classes * 4)) return rc;
   if (int rc = m->d_dense_b.reserve(desc->num_classes * 4)) return rc;
   if (int rc = m->d_ext.reserve(sizeof(ExtPtrs))) return rc;
-  // opt-in: skip the stem work that only sees the zero rows below the pile-up (HISTORY.md 7);
-  // needs the uint8 front end, a single-branch 3x3 80->192 and whole dwords per image
-  if (getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) != 0 &&
+  // Skip the stem work that only sees the zero rows below the pile-up (on unless DV_BLANK_SKIP=0): needs the uint8
+  // front end (the scan reads the caller's image), a single-branch 3x3 80->192 and whole dwords per image
+  if (!(getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) == 0) &&
       m->ops[0].first_u8 && m->blank_conv4_op >= 0 && m->ops[m->blank_conv4_op].group_followers == 0 &&
       (static_cast<size_t>(desc->height) * desc->width * desc->channels) % 4 == 0) {
-    if (int rc = m->d_blank_thr.reserve(static_cast<size_t>(4) * desc->max_batch * sizeof(int))) return rc;
+    if (int rc = m->d_blank_thr.reserve(static_cast<size_t>(5) * desc->max_batch * sizeof(int))) return rc;
     DV_HIP_CHECK(hipMemset(m->d_blank_thr.ptr, 0, m->d_blank_thr.cap));
     m->blank_skip = true;
   }
@@ -2780,6 +2858,8 @@ void dv_model_destroy(dv_model* m) {
   m->d_blank_thr.release();
   m->d_ext.release();
   m->d_blank_conv4.release();
+  m->d_blank_c2.release();
+  m->d_blank_b.release();
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   delete m;
 }
@@ -2841,15 +2921,17 @@ static int prepare_blank_responses(dv_model* m) {
     rc = enqueue_forward(m, 1, nullptr);
   }
   if (rc == DV_OK && hipDeviceSynchronize() != hipSuccess) rc = dv::fail(DV_ERR_HIP, "blank forward failed");
-  if (rc == DV_OK) {
-    const int buf = m->ops[m->blank_conv4_op].out_buf;
+  auto keep = [&](int buf, dv::DeviceBuffer* dst) {
+    if (rc != DV_OK || buf < 0 || m->buffers[buf].h <= 1) return;   // (LDS-only tensors have no buffer)
     const size_t bytes = m->buffers[buf].bytes_per_example();
-    rc = m->d_blank_conv4.reserve(bytes);
-    if (rc == DV_OK && hipMemcpy(m->d_blank_conv4.ptr, m->dbuf[buf].ptr, bytes,
-                                 hipMemcpyDeviceToDevice) != hipSuccess) {
+    rc = dst->reserve(bytes);
+    if (rc == DV_OK && hipMemcpy(dst->ptr, m->dbuf[buf].ptr, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
       rc = dv::fail(DV_ERR_HIP, "copying the blank response");
     }
-  }
+  };
+  keep(m->ops[m->blank_conv4_op].out_buf, &m->d_blank_conv4);
+  keep(m->ops[1].out_buf, &m->d_blank_c2);                               // conv2 (stem_a's output)
+  if (m->ops[2].stem_b) keep(m->ops[3].out_buf, &m->d_blank_b);          // the 1x1 64->80 (stem_b's output)
   zero_img.release();
   probs.release();
   if (rc != DV_OK) return rc;
@@ -3068,6 +3150,7 @@ static dv::CalibPlan calib_plan_of(const dv_model* m) {
       c.raw = op.raw;
       c.shift_off = static_cast<int64_t>(op.shift_off);
       c.split = op.split_rows;
+      c.keep_f32 = m->buffers[op.out_buf].f32 ? 1 : 0;
       if (op.pool_in) {   // op.ih / op.iw: the tensor as stored, before the on-the-fly pool
         plan.bufs[op.in_buf].h = op.ih;
         plan.bufs[op.in_buf].w = op.iw;
@@ -3080,6 +3163,7 @@ static dv::CalibPlan calib_plan_of(const dv_model* m) {
       c.shift_relu = op.pool_shift_relu;
       if (op.pool_shift_relu) c.shift_off = static_cast<int64_t>(op.shift_off);
       c.cout = op.cout;
+      c.keep_f32 = m->buffers[op.out_buf].f32 ? 1 : 0;
     } else {
       c.cout = op.cout;
     }
@@ -3241,9 +3325,16 @@ int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t
   if (host_out) {
     DV_HIP_CHECK(hipSetDevice(m->device));
     DV_HIP_CHECK(hipDeviceSynchronize());
-    DV_HIP_CHECK(hipMemcpy(host_out, m->dbuf[index].ptr,
-                           static_cast<size_t>(n) * b.bytes_per_example(),
-                           hipMemcpyDeviceToHost));
+    if (b.f32) {   // float32 tensors (BufferDesc::f32) leave as the fp16 numbers the hook's contract promises
+      std::vector<float> tmp(static_cast<size_t>(n) * b.bytes_per_example() / 4);
+      DV_HIP_CHECK(hipMemcpy(tmp.data(), m->dbuf[index].ptr, tmp.size() * 4, hipMemcpyDeviceToHost));
+      _Float16* dst = static_cast<_Float16*>(host_out);
+      for (size_t i = 0; i < tmp.size(); ++i) dst[i] = static_cast<_Float16>(tmp[i]);
+    } else {
+      DV_HIP_CHECK(hipMemcpy(host_out, m->dbuf[index].ptr,
+                             static_cast<size_t>(n) * b.bytes_per_example(),
+                             hipMemcpyDeviceToHost));
+    }
   }
   return DV_OK;
 }
@@ -3261,7 +3352,7 @@ static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
     for (int sb0 = 0; sb0 < nb; sb0 += stem_sub_batch()) {
       const int sb = std::min(stem_sub_batch(), nb - sb0);
       const size_t img_off = static_cast<size_t>(done + sb0) * img_bytes;
-      if (m->blank_ready) {
+      if (m->blank_on()) {
         dv::ProfileScope prof(dv::kProfOther, stream);
         hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, ext, img_off, m->desc.height,
                            m->desc.width * m->desc.channels, static_cast<int*>(m->d_blank_thr.ptr),
@@ -3283,7 +3374,7 @@ static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
     {
       dv::ProfileScope prof(dv::kProfOther, stream);
       hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, stream,
-                         static_cast<const _Float16*>(m->dbuf[m->feat_buf].ptr),
+                         static_cast<const float*>(m->dbuf[m->feat_buf].ptr),
                          static_cast<const float*>(m->d_dense_w.ptr),
                          static_cast<const float*>(m->d_dense_b.ptr), ext,
                          static_cast<size_t>(done) * m->desc.num_classes,
@@ -3354,6 +3445,37 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   m->graphs.push_back(e);
   ++m->graph_captures;
   DV_HIP_CHECK(hipGraphLaunch(e.exec, stream));
+  return DV_OK;
+}
+
+// Blank-row skipping on / off at run time (include/dvhip.h): bench.py times the dense path on the same model.
+int dv_model_set_blank_skip(dv_model* m, int enabled) {
+  if (!m) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_set_blank_skip: null");
+  const bool on = enabled != 0;
+  if (on == m->blank_enabled) return DV_OK;
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  for (auto& g : m->graphs) {   // captured with the other setting
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipGraphExecDestroy(g.exec);
+  }
+  m->graphs.clear();
+  m->blank_enabled = on;
+  return DV_OK;
+}
+
+// The thresholds the last forward's scan found for its first `n` examples: out[k * n + i], k = 0 rows used (first
+// all-zero row), 1 conv2 rows, 2 stem_b rows, 3 the 3x3 80->192's rows, 4 its pooled rows.  Returns
+// DV_ERR_UNSUPPORTED when the model does not skip (shape without the uint8 front end, DV_BLANK_SKIP=0, switched off).
+int dv_model_blank_thresholds(dv_model* m, int n, int32_t* out) {
+  if (!m || !out || n < 1 || n > m->desc.max_batch) return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_blank_thresholds: bad argument");
+  if (!m->blank_on()) return dv::fail(DV_ERR_UNSUPPORTED, "dv_model_blank_thresholds: blank-row skipping is off for this model");
+  DV_HIP_CHECK(hipSetDevice(m->device));
+  DV_HIP_CHECK(hipDeviceSynchronize());
+  for (int k = 0; k < 5; ++k) {
+    DV_HIP_CHECK(hipMemcpy(out + static_cast<size_t>(k) * n,
+                           static_cast<const int*>(m->d_blank_thr.ptr) + static_cast<size_t>(k) * m->desc.max_batch,
+                           static_cast<size_t>(n) * sizeof(int), hipMemcpyDeviceToHost));
+  }
   return DV_OK;
 }
 

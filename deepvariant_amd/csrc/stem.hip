@@ -280,7 +280,34 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
       }
     }
   };
-  int t = blockIdx.x;
+  // Blank-row skipping: the tile sequence of this workgroup is walked by next_tile(), which copies the
+  // blank-determined tiles it passes (all 256 threads, global -> global, no LDS, no barrier) and stops at the
+  // next tile that has to be computed.  Everything it decides on is workgroup-uniform.
+  auto copy_blank_tile = [&](int nb_, int yb, int xb) {
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(p.blank_src);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(p.out) + static_cast<size_t>(nb_) * img_out;
+    const int th = min(A_TH, p.OH2 - yb), tw = min(A_TW, p.OW2 - xb);
+    const int per_group = th * tw;
+    for (int e = tid; e < 4 * per_group; e += A_THREADS) {
+      const int g = e / per_group, r = e - g * per_group;
+      const int yy = r / tw, xx = r - yy * tw;
+      const unsigned o = static_cast<unsigned>(g) * gstride +
+                         static_cast<unsigned>((yb + yy + p.og.halo) * p.og.wp + xb + xx + p.og.halo);
+      dst[o] = src[o];
+    }
+  };
+  auto next_tile = [&](int tt) {
+    if (p.blank_thr == nullptr) return tt;
+    while (tt < p.total_tiles) {
+      int nb_, yb, xb;
+      tile_origin(tt, nb_, yb, xb);
+      if (yb < p.blank_thr[nb_]) break;
+      copy_blank_tile(nb_, yb, xb);
+      tt += gridDim.x;
+    }
+    return tt;
+  };
+  int t = next_tile(blockIdx.x);
   int n, y0, x0;
   unsigned origin = 0;
   if (t < p.total_tiles) {
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
     __syncthreads();  // conv1 tile complete; the input patch may be overwritten
 
     // ---- next tile's pixels start their trip now, land after conv2's matrix work ----------
-    const int tn = t + gridDim.x;
+    const int tn = next_tile(t + gridDim.x);
     int nn = 0, yn = 0, xn = 0;
     unsigned origin_n = 0;
     if (tn < p.total_tiles) {
@@ -491,7 +518,35 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     }
   };
 
-  int t = blockIdx.x;
+  // Blank-row skipping (see stem A): next_tile() copies the blank-determined tiles it passes and stops at the next
+  // one that has to be computed.
+  auto copy_blank_tile = [&](int nb_, int pyb, int pxb) {
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(p.blank_src);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(p.out) +
+                   static_cast<size_t>(nb_) * p.og.groups * ogstride;
+    const int th = min(B_PH, p.PH - pyb), tw = min(B_PW, p.PW - pxb);
+    const int per_group = th * tw;
+    const int groups = (p.Cout4 + 7) / 8;
+    for (int e = tid; e < groups * per_group; e += B_THREADS) {
+      const int g = e / per_group, r = e - g * per_group;
+      const int yy = r / tw, xx = r - yy * tw;
+      const unsigned o = static_cast<unsigned>(g) * ogstride +
+                         static_cast<unsigned>((pyb + yy + p.og.halo) * p.og.wp + pxb + xx + p.og.halo);
+      dst[o] = src[o];
+    }
+  };
+  auto next_tile = [&](int tt) {
+    if (p.blank_thr == nullptr) return tt;
+    while (tt < p.total_tiles) {
+      int nb_, pyb, pxb;
+      tile_coords(tt, nb_, pyb, pxb);
+      if (pyb < p.blank_thr[nb_]) break;
+      copy_blank_tile(nb_, pyb, pxb);
+      tt += gridDim.x;
+    }
+    return tt;
+  };
+  int t = next_tile(blockIdx.x);
   int n = 0, py0 = 0, px0 = 0;
   unsigned buf = 0;  // byte offset of the current patch buffer
   if (t < p.total_tiles) {
@@ -511,7 +566,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     tm = now_;                                                \
   }
   while (t < p.total_tiles) {
-    const int tn = t + gridDim.x;
+    const int tn = next_tile(t + gridDim.x);
     int nn = 0, pyn = 0, pxn = 0;
     const bool more = tn < p.total_tiles;
     if (more) tile_coords(tn, nn, pyn, pxn);
@@ -658,6 +713,25 @@ int cu_count(int device) {
 
 }  // namespace
 
+// Blank-row skipping makes a tile's cost depend on its row: workgroup b walks tiles b, b + grid, b + 2 grid, ..., so
+// with grid and the tiles per image sharing a factor it would only ever see some of the tile rows (512 workgroups,
+// 24 tiles per image: three of them) -- and the workgroups that drew the upper rows would finish last.  A grid
+// coprime with the tiles per image gives every workgroup every (row, column) equally often; at most a few workgroups
+// of the persistent grid are given up.
+static int balanced_grid(int grid, int tiles_img, bool skipping) {
+  if (!skipping) return grid;
+  auto gcd = [](int a, int b) {
+    while (b) {
+      const int t = a % b;
+      a = b;
+      b = t;
+    }
+    return a;
+  };
+  while (grid > 1 && gcd(grid, tiles_img) != 1) --grid;
+  return grid;
+}
+
 int stem_a_blocks(int device) { return 2 * cu_count(device); }
 int stem_b_blocks(int device) { return B_BLOCKS_PER_CU * cu_count(device); }
 
@@ -668,7 +742,7 @@ void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  const int grid = std::max(1, std::min(blocks, a.total_tiles));
+  const int grid = balanced_grid(std::max(1, std::min(blocks, a.total_tiles)), a.tiles_y * a.tiles_x, a.blank_thr != nullptr);
   hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, a);
 }
 
@@ -679,7 +753,7 @@ void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  const int grid = std::max(1, std::min(blocks, a.total_tiles));
+  const int grid = balanced_grid(std::max(1, std::min(blocks, a.total_tiles)), a.tiles_y * a.tiles_x, a.blank_thr != nullptr);
   hipLaunchKernelGGL(stem_b_kernel, dim3(grid), dim3(B_THREADS), B_LDS, stream, a);
 }
 

@@ -39,6 +39,12 @@ struct StemAArgs {
   int tiles_y, tiles_x;
   int total_tiles;        // N * tiles_y * tiles_x
   unsigned in_bytes;      // N*H*W*C (< 2^31)
+  // Blank-row skipping (model.hip): blank_thr[n] = first conv2 output row of example n whose receptive
+  // field holds only the zero rows below the pile-up; a tile that starts at or below it equals the all-blank image's
+  // response at the same position (blank_src: ONE example in `og`'s geometry, produced by this kernel) and is copied
+  // instead of loaded and multiplied -- bit-identical.  NULL = off.
+  const int* blank_thr;
+  const _Float16* blank_src;
 };
 
 // ---- stem B: conv 3x3 'same' 32 -> 64, max-pool 3x3/2, conv 1x1 64 -> 80 -----------------
@@ -74,6 +80,10 @@ struct StemBArgs {
   unsigned in_img_bytes;
   // tuning aid (DV_STEM_PROF): per-phase shader-clock sums [block][8], or NULL
   unsigned long long* prof;
+  // Blank-row skipping (see StemAArgs): blank_thr[n] = first POOLED row of example n that is blank-determined
+  // (pooled row py reads conv2 rows 2py-1 .. 2py+3), blank_src = the all-blank image's 1x1 output (one example, `og`)
+  const int* blank_thr;
+  const _Float16* blank_src;
 };
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream);

@@ -72,8 +72,11 @@ _shm_seq = [0]
 
 def _gather_records_shm(records, lengths, sizes, group):
   """The payload of gather_records between host ranks of ONE node: every rank writes its records into a file
-  under /dev/shm, a barrier, every rank reads every file.  Returns None (caller falls back to the collective)
-  unless every rank sees the same boot id and the directory rank 0 made.
+  under /dev/shm, every rank reads every file.  Returns None -- on EVERY rank together, so that the caller's
+  fall-back to the collective is taken by all of them -- unless every rank sees the same boot id, the directory
+  rank 0 made and room for everybody's payload, and every write and every read succeeds: each phase ends in an
+  all_reduce(MIN) of a success flag instead of a bare barrier (a rank that hit ENOSPC must not leave the others
+  waiting for it until the backend's timeout).
 
   Why: gloo's TCP all-gather of a 129 KB payload between 8 ranks sharing one MI355X box took 4.4-5.3 s on its
   first use and 0.85 s afterwards (16 ranks: 16.6 s; a 6 KB message: 1 ms) -- more than the ranks' whole region
@@ -98,33 +101,56 @@ def _gather_records_shm(records, lengths, sizes, group):
       token[0] = ('', '')
   dist.broadcast_object_list(token, src=0, group=group)
   boot0, path = token[0]
+
+  def agreed(ok: bool) -> bool:
+    """True only when EVERY rank says ok: no rank leaves this function on its own."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
   ok = bool(boot) and boot == boot0 and bool(path) and os.path.isdir(path)
-  flags = torch.tensor([1 if ok else 0], dtype=torch.int64)
-  dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
-  if int(flags.item()) != 1:
+  if ok:
+    # everybody's payload must fit: Docker's default /dev/shm is 64 MB, a whole-genome gather is hundreds
+    try:
+      st = os.statvfs(path)
+      need = sum(8 * n + total for n, total in sizes)
+      ok = st.f_bavail * st.f_frsize >= need + (1 << 20)
+    except OSError:
+      ok = False
+  if not agreed(ok):
     if rank == 0 and path:
       shutil.rmtree(path, ignore_errors=True)
     return None
+  out = None
   try:
-    with open(os.path.join(path, '%d.bin' % rank), 'wb') as f:
-      f.write(np.asarray(lengths.numpy(), np.int64).tobytes())
-      f.write(b''.join(records))
-    dist.barrier(group=group)
-    out = []
-    for r in range(world):
-      n, total = sizes[r]
-      with open(os.path.join(path, '%d.bin' % r), 'rb') as f:
-        blob = f.read()
-      if len(blob) != 8 * n + total:
-        raise RuntimeError('record exchange: rank %d wrote %d bytes, %d announced' % (r, len(blob), 8 * n + total))
-      lens = np.frombuffer(blob, np.int64, count=n).tolist()
-      at = 8 * n
-      recs = []
-      for k in lens:
-        recs.append(blob[at:at + k])
-        at += k
-      out.append(recs)
-    dist.barrier(group=group)       # everybody has read: the files may go
+    wrote = True
+    try:
+      with open(os.path.join(path, '%d.bin' % rank), 'wb') as f:
+        f.write(np.asarray(lengths.numpy(), np.int64).tobytes())
+        f.write(b''.join(records))
+    except OSError:                  # ENOSPC after all, a vanished directory: all ranks take the collective together
+      wrote = False
+    if not agreed(wrote):            # (also the barrier: every file is complete before anybody reads)
+      return None
+    got = []
+    try:
+      for r in range(world):
+        n, total = sizes[r]
+        with open(os.path.join(path, '%d.bin' % r), 'rb') as f:
+          blob = f.read()
+        if len(blob) != 8 * n + total:
+          raise OSError('record exchange: rank %d wrote %d bytes, %d announced' % (r, len(blob), 8 * n + total))
+        lens = np.frombuffer(blob, np.int64, count=n).tolist()
+        at = 8 * n
+        recs = []
+        for k in lens:
+          recs.append(blob[at:at + k])
+          at += k
+        got.append(recs)
+    except OSError:
+      got = None
+    if agreed(got is not None):      # everybody has read (or everybody falls back): the files may go
+      out = got
   finally:
     if rank == 0:
       shutil.rmtree(path, ignore_errors=True)

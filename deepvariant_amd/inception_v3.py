@@ -67,49 +67,51 @@ class InceptionV3(torch.nn.Module):
     corr = np.ascontiguousarray(corrections, dtype=np.float32)
     _lib.check(_lib.lib().dv_model_apply_corrections(self._handle, corr.ctypes.data, corr.size))
 
-  def _calibrate_or_share(self, images: torch.Tensor, share_key: Optional[str]) -> None:
-    """One calibration per (job, GPU, set of weights): with a `share_key` the first process to get here measures and
-    publishes the corrections in /dev/shm, the others apply them (host ranks sharing a GPU would otherwise repeat the
-    same 0.17 s of device work one after the other)."""
-    if not share_key:
-      self.calibrate(images)
-      return
-    import os
-    import tempfile
-    import time
-    import zlib
-    base = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
-    stamp = zlib.crc32(np.ascontiguousarray(self.flat_weights[::1021]).tobytes()) & 0xffffffff
-    path = os.path.join(base, 'dvamd-cal-%s-%08x-%dx%dx%d.f32' % ((share_key, stamp) + tuple(self.input_shape)))
-    try:
-      os.close(os.open(path + '.lock', os.O_CREAT | os.O_EXCL | os.O_WRONLY))
-      winner = True
-    except FileExistsError:
-      winner = False
-    if winner:
-      import atexit
-      atexit.register(lambda: [os.path.exists(f) and os.remove(f) for f in (path, path + '.lock')])
-      corr = self.calibrate(images)
-      tmp = '%s.tmp%d' % (path, os.getpid())
-      corr.tofile(tmp)
-      os.replace(tmp, path)
-      return
-    deadline = time.monotonic() + 60.0
-    while not os.path.exists(path) and time.monotonic() < deadline:
-      time.sleep(0.002)
-    if os.path.exists(path):
-      self.apply_corrections(np.fromfile(path, np.float32))
-    else:                      # the publishing process died: measure here after all
-      self.calibrate(images)
+  def calibrate_for_checkpoint(self, n_images: int = 256, cache_prefix: Optional[str] = None) -> Optional[np.ndarray]:
+    """Model preparation, part of LOADING a checkpoint: calibrates the shifts (dv_model_calibrate) on the fixed
+    synthetic calibration set of this input shape (calibration_set.draw: the same images on every rank, in every
+    run), so that the probabilities stay a pure function of (checkpoint, image) -- batch size, example order,
+    `--task` split and rank layout do not enter, as in the reference (deepvariant/call_variants.py:904-932).  What
+    call_variants and make_examples' fused route do after loading weights (`--calibration_examples`, 0 = off).
 
-  def enable_auto_calibration(self, min_images: int = 64, max_images: int = 256, share_key: Optional[str] = None) -> None:
-    """Model preparation inside a run: the FIRST forward that brings at least `min_images` examples calibrates the
-    shifts on up to `max_images` of them (dv_model_calibrate) before it classifies; forwards before that (tiny
-    inputs) run the uncalibrated fp16 model.  What call_variants and make_examples' fused route switch on after
-    loading a checkpoint (`--calibration_examples`, 0 = off): deterministic for a given input, a few hundred
-    milliseconds once per run (profiles/r05_cnn_tail.txt: why)."""
-    self._auto_cal = (int(min_images), int(max_images), share_key) if max_images > 0 else None
-    self.calibrated_on = 0
+    `cache_prefix` (the checkpoint's path): the corrections are kept next to it in a file named by the content
+    hash of the weights, the shape, the set's version and size -- whoever finds the file applies it
+    (dv_model_apply_corrections) instead of measuring again; written atomically, never locked, safe to share
+    between jobs because the name says everything the content depends on.  Returns the corrections, or None when
+    the shape has no calibration set (the model then stays plain fp16 -- on every rank alike)."""
+    from deepvariant_amd import calibration_set
+    import os
+    import zlib
+    if self.flat_weights is None:
+      raise ValueError('calibrate_for_checkpoint() needs load_flat_weights() first')
+    self.calibration = {'images': 0}
+    if n_images <= 0 or not calibration_set.supported(self.input_shape):
+      return None
+    n_corr = sum(co for _, _, _, co, _ in self.layer_table())
+    path = None
+    if cache_prefix:
+      stamp = zlib.crc32(self.flat_weights.tobytes()) & 0xffffffff
+      path = '%s.dvcal-v%d-%08x-%dx%dx%d-n%d.f32' % ((cache_prefix, calibration_set.SET_VERSION, stamp) +
+                                                  tuple(self.input_shape) + (n_images,))
+      try:
+        corr = np.fromfile(path, np.float32)
+        if corr.size == n_corr and np.isfinite(corr).all():
+          self.apply_corrections(corr)
+          self.calibration = {'images': n_images, 'set_version': calibration_set.SET_VERSION, 'cached': True}
+          return corr
+      except OSError:
+        pass
+    images = calibration_set.draw(self.input_shape, n_images, device=self.device_index)
+    corr = self.calibrate(images)
+    self.calibration = {'images': n_images, 'set_version': calibration_set.SET_VERSION, 'cached': False}
+    if path:
+      try:
+        tmp = '%s.tmp%d' % (path, os.getpid())
+        corr.tofile(tmp)
+        os.replace(tmp, path)
+      except OSError:
+        pass                                   # read-only model directory: every process measures for itself
+    return corr
 
   def calibrate(self, images: torch.Tensor) -> np.ndarray:
     """dv_model_calibrate: moves every layer's fp32 shift by the per-channel mean of the fp16
@@ -163,12 +165,6 @@ class InceptionV3(torch.nn.Module):
                        (tuple(images.shape[1:]), self.input_shape))
     images = images.contiguous()
     n = images.shape[0]
-    auto = getattr(self, '_auto_cal', None)
-    if auto is not None and n >= auto[0] and self.flat_weights is not None:
-      self._auto_cal = None
-      self.calibrated_on = min(n, auto[1])
-      torch.cuda.current_stream(images.device).synchronize()
-      self._calibrate_or_share(images[:self.calibrated_on], auto[2])
     # dv_model_infer replays the forward as a hipGraph keyed by (n, stream) -- the image and
     # output pointers travel through a device-side table, so fresh tensors replay the same
     # graph.  The output lives in a model-owned buffer per batch size; callers get their own
@@ -184,6 +180,20 @@ class InceptionV3(torch.nn.Module):
         self._handle, images.data_ptr(), n, out.data_ptr(),
         C.c_void_p(stream)))
     return out.clone()
+
+  def set_blank_skip(self, enabled: bool) -> None:
+    """dv_model_set_blank_skip: False runs the dense stem (same probabilities, bit for bit)."""
+    _lib.check(_lib.lib().dv_model_set_blank_skip(self._handle, 1 if enabled else 0))
+
+  def blank_thresholds(self, n: int) -> Optional[np.ndarray]:
+    """int32 [5, n]: the last forward's per-example thresholds (dv_model_blank_thresholds), or None when the model
+    does not skip."""
+    out = np.zeros((5, n), np.int32)
+    rc = _lib.lib().dv_model_blank_thresholds(self._handle, n, out.ctypes.data)
+    if rc == _lib.DV_ERR_UNSUPPORTED:
+      return None
+    _lib.check(rc)
+    return out
 
   def graph_stats(self) -> Tuple[int, int]:
     """(forwards captured into a new hipGraph, forwards replayed from the cache)."""

@@ -149,7 +149,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
   # window realigner, candidate caller); R ranks share one GPU, as N make_examples processes share
   # the reference's call_variants GPU.  world = gpus * ranks_per_gpu, rank r runs on GPU r // R
   ap.add_argument('--ranks_per_gpu', type=int, default=1)
-  # fused route: as call_variants' flag of the same name (examples the fp16 classifier's shifts are calibrated on)
+  # fused route: as call_variants' flag of the same name (size of the fixed synthetic calibration set)
   ap.add_argument('--calibration_examples', type=int, default=256)
   return ap
 
@@ -498,15 +498,10 @@ class RunnerHooks:
     # each own a model, and a 1 kb region rarely yields more than a few dozen examples
     model = InceptionV3(shape, max_batch=512 if args.ranks_per_gpu == 1 else 256, device=args.device)
     call_variants.load_flat_checkpoint(args.checkpoint, model)
-    if getattr(args, 'calibration_examples', 256) > 0:
-      # the first forward of >= 64 examples (the fused route classifies 256 at a time) calibrates the shifts; host
-      # ranks that share a GPU share ONE measurement (the first rank to get there publishes it, inception_v3.py)
-      import os
-      share = None
-      if getattr(args, 'ranks_per_gpu', 1) > 1:
-        share = 'job%s-%s-gpu%d' % (os.environ.get('MASTER_ADDR', 'local').replace('/', '_'),
-                                    os.environ.get('MASTER_PORT', str(os.getppid())), args.device)
-      model.enable_auto_calibration(max_images=args.calibration_examples, share_key=share)
+    # the shifts are calibrated on the fixed synthetic set of this input shape: the same corrections on every rank
+    # (computed, or read from the cache next to the checkpoint), whatever the rank layout and the regions a rank gets
+    model.calibrate_for_checkpoint(getattr(args, 'calibration_examples', 256),
+                                   cache_prefix=call_variants.calibration_cache_prefix(args.checkpoint))
     return model
 
 

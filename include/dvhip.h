@@ -806,6 +806,20 @@ int dv_model_probe_rounding(dv_model* m, const float* weights, int64_t n_weights
 int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
                    void* stream);
 
+/* Blank-row skipping (ABI v8; on by default for inputs of <= 16 channels).  A pileup image is zero below its last
+ * read row (deepvariant/pileup_image_native.cc:405-447 zero-pads every image to `height` rows; a 30x pile-up fills
+ * ~40 of 100), and the model normalises zero to the constant -1 (deepvariant/dv_utils.py:343-366): every activation of
+ * the stem whose receptive field lies inside those rows equals the all-blank image's response at the same position.
+ * dv_model_infer finds each image's last nonzero row (one scan kernel) and the stem kernels copy such tiles from the
+ * precomputed response instead of multiplying -- bit-identical to the dense path (tests/test_hip_blank_skip.py), so
+ * probabilities are unchanged; only the executed work depends on the images' depth.  `enabled` = 0 runs the dense path
+ * (bench.py reports both); the environment variable DV_BLANK_SKIP=0 does the same for a whole process.
+ * dv_model_blank_thresholds: what the last forward's scan found for its first n examples, out[k * n + i] with
+ * k = 0 first all-zero row, 1..4 the first blank-determined row of conv2 / stem_b / the 3x3 80->192 / its pooled
+ * output (bench.py derives the executed FLOPs from them); DV_ERR_UNSUPPORTED when the model does not skip. */
+int dv_model_set_blank_skip(dv_model* m, int enabled);
+int dv_model_blank_thresholds(dv_model* m, int n, int32_t* out);
+
 /* On a non-default stream the forward is captured once per (n, stream) into a hipGraph and
  * replayed; the image / probability pointers are read from a device-side table, so they may
  * change from call to call without a new capture.  Testing hook: captures and replays so far. */

@@ -1,8 +1,9 @@
 """torch restatement of the product's shift calibration (deepvariant_amd/csrc/calib.hip) -- test infrastructure.
 
 Two walks of the oracle's graph (oracle/inception_ref.py) with the product's rounding points: R in float32 as
-given; E with BN-folded weights rounded to fp16 and every stored activation rounded to fp16 (the pooled
-projections in the product's commuted order: raw 1x1 conv -> round -> average pool -> + shift -> ReLU -> round).
+given; E with BN-folded weights rounded to fp16 and every stored fp16 activation rounded to fp16 (the pooled
+projections in the product's commuted order: raw 1x1 conv, float32 -> average pool -> + shift -> ReLU -> round; the
+last block's outputs stay float32 for the global pool -- round 6, BufferDesc::f32 in csrc/model.hip).
 corr[layer][c] = mean_E(pre-activation) - mean_R(pre-activation), applied in E before the next layer.
 """
 import numpy as np
@@ -27,27 +28,27 @@ class _Walk:
   def _r(self, x):
     return x.half().float() if self.e else x
 
-  def _act(self, i, z):
+  def _act(self, i, z, keep_f32=False):
     self.means[i] = z.double().mean(dim=(0, 2, 3))
     if self.e:
       self.corr[i] = (self.means[i] - self.ref_means[i]).float()
       z = z - self.corr[i][None, :, None, None]
-    return F.relu(self._r(z))
+    return F.relu(z if keep_f32 else self._r(z))
 
-  def conv(self, cb, x):
+  def conv(self, cb, x, keep_f32=False):
     w, shift = _folded(cb)
     if self.e:
       w = w.half().float()
     z = F.conv2d(x, w, None, cb.conv.stride, cb.conv.padding) + shift[None, :, None, None]
-    return self._act(self.index[id(cb)], z)
+    return self._act(self.index[id(cb)], z, keep_f32)
 
-  def pooled_projection(self, cb, x):
+  def pooled_projection(self, cb, x, keep_f32=False):
     w, shift = _folded(cb)
     if self.e:
       w = w.half().float()
-    raw = self._r(F.conv2d(x, w))
+    raw = F.conv2d(x, w)            # float32 in LDS / in a float32 tensor: never rounded
     z = F.avg_pool2d(raw, 3, stride=1, padding=1, count_include_pad=False) + shift[None, :, None, None]
-    return self._act(self.index[id(cb)], z)
+    return self._act(self.index[id(cb)], z, keep_f32)
 
   def seq(self, mods, x):
     for m in mods:
@@ -71,11 +72,12 @@ class _Walk:
                      self.pooled_projection(blk['bp'][0], x)], 1)
     x = torch.cat([self.seq(ref.mixed8['b3'], x), self.seq(ref.mixed8['b7'], x), F.max_pool2d(x, 3, stride=2)], 1)
     for blk in ref.mixed_c:
+      last = blk is ref.mixed_c[-1]       # its outputs feed the global pool in float32
       b3 = c(blk['b3'][0], x)
-      b3 = torch.cat([c(blk['b3'][1], b3), c(blk['b3'][2], b3)], 1)
+      b3 = torch.cat([c(blk['b3'][1], b3, last), c(blk['b3'][2], b3, last)], 1)
       b3d = c(blk['b3d'][1], c(blk['b3d'][0], x))
-      b3d = torch.cat([c(blk['b3d'][2], b3d), c(blk['b3d'][3], b3d)], 1)
-      x = torch.cat([self.seq(blk['b1'], x), b3, b3d, self.pooled_projection(blk['bp'][0], x)], 1)
+      b3d = torch.cat([c(blk['b3d'][2], b3d, last), c(blk['b3d'][3], b3d, last)], 1)
+      x = torch.cat([c(blk['b1'][0], x, last), b3, b3d, self.pooled_projection(blk['bp'][0], x, last)], 1)
     return ref.classification(x.mean(dim=(2, 3)))
 
 

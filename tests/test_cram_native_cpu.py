@@ -491,3 +491,28 @@ def test_index_rows_that_point_outside_the_file_are_refused(files, offset):
     f.write(''.join('\t'.join(r) + '\n' for r in rows))
   with pytest.raises((ValueError, RuntimeError, _lib.DvError)):
     packing.ReadTable.from_cram(bad, ref.get_bases, 'chr20', 10_000_000, 10_100_000)
+
+
+@pytest.mark.parametrize('method', ['rans0', 'rans1', 'bzip2'])
+def test_constant_quality_blocks_expand_by_more_than_a_naive_bound(files, method):
+  """A slice whose qualities are ONE value (binned / unavailable qualities, as real CRAMs hold): rANS 4x8 codes a
+  symbol of frequency 4095 / 4096 in 3.5e-4 bits, so 400,000 quality bytes are a payload of a few dozen bytes --
+  20,000x, beyond the 4096x-per-input-byte guard round 5 had put in front of the allocation."""
+  rng = random.Random(5)
+  contigs = _contigs(rng)
+  ref = contigs[0][1].upper()
+  reads = []
+  for k in range(2000):
+    pos = 1 + (k * 2600) // 2000
+    reads.append(dict(name='q%d' % k, flag=0, ref_id=0, pos=pos, mapq=60, cigar=[('M', 200)],
+                      seq=ref[pos - 1:pos - 1 + 200].replace('N', 'A'), qual=[30] * 200, cf=0x1))
+  methods = {cid: 'gzip' for cid in range(0, 40)}
+  methods[18] = method                      # QS
+  w = cram_writer.CramWriter(contigs, EXTERNAL_CODECS, methods, _rans_encode)
+  w.add_container([(reads, 0)])
+  path = os.path.join(files['tmp'], 'constq_%s.cram' % method)
+  w.finish(path)
+  assert os.path.getsize(path) < 120_000            # 400,000 qualities + 400,000 bases in < 120 KB
+  t = packing.ReadTable.from_cram(path, _fetch(contigs), 'c1', n_threads=2)
+  assert t.n_reads == 2000 and t.quals.size == 400_000 and int(t.quals.min()) == 30 == int(t.quals.max())
+  _same_tables(t, _python_table(path, _fetch(contigs), 'c1'))

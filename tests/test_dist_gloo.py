@@ -126,6 +126,48 @@ def test_gather_records_through_shared_memory_equals_the_collective_world3():
     assert left == []                              # the exchange directory is gone
 
 
+def _shm_write_fails_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=60))
+  import builtins
+  import glob
+  from deepvariant_amd import dist as dvd
+  mine = [bytes([(rank * 37 + i) % 251]) * 120 for i in range(300)]
+  real_open = builtins.open
+  def failing_open(path, mode='r', *a, **k):           # rank 1 cannot write its file (ENOSPC on a 64 MB /dev/shm)
+    if rank == 1 and 'w' in mode and '/dev/shm/dvamd-' in str(path):
+      raise OSError(28, 'No space left on device')
+    return real_open(path, mode, *a, **k)
+  before = set(glob.glob('/dev/shm/dvamd-*'))
+  builtins.open = failing_open
+  try:
+    got = dvd.gather_records(mine)               # every rank falls back to the collective TOGETHER
+  finally:
+    builtins.open = real_open
+  dist.barrier()
+  q.put((rank, [len(x) for x in got], got[rank] == mine, sorted(set(glob.glob('/dev/shm/dvamd-*')) - before)))
+  dist.destroy_process_group()
+
+
+def test_a_rank_that_cannot_write_to_shared_memory_takes_everybody_to_the_collective():
+  """a one-sided failure inside the /dev/shm exchange (ENOSPC) used to leave the other ranks in a
+  barrier until the backend's timeout; every phase now ends in an agreement, and the job completes."""
+  world = 3
+  port = _free_port()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_shm_write_fails_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = sorted(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for _, counts, own, left in results:
+    assert counts == [300, 300, 300] and own and left == []
+
+
 def _failing_worker(rank, world, port, q):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)

@@ -1,10 +1,12 @@
-"""Opt-in blank-row skipping (DV_BLANK_SKIP=1, HISTORY.md 7) against the default kernels (GPU).
+"""Blank-row skipping through the stem (round 6: on by default) against the dense kernels (GPU).
 
-Stem outputs whose receptive field sees only the zero rows below the pile-up are copied from
-the all-blank image's response instead of being computed.  That must be invisible: the stem
-output tensor and the probabilities are compared BIT FOR BIT with the default path on encoded
-pileups of every depth, on images with hand-placed last rows around every threshold parity,
-on all-zero and completely filled images, and with a nonzero byte in the very last row."""
+Tiles of conv2 / stem_b / the 3x3 80->192 whose receptive field sees only the zero rows below the pile-up are copied
+from the all-blank image's response instead of being computed.  That must be invisible: the stem's tensors and the
+probabilities are compared BIT FOR BIT with the dense path (DV_BLANK_SKIP=0, and the run-time switch of one model) on
+encoded pileups of every depth, on images with hand-placed last rows around every threshold parity, on all-zero and
+completely filled images, with a nonzero byte in the very last row, at the long-read shapes (per-layer conv1 / conv2),
+at sizes that do not fill the persistent grids and at the bench's batch size.  Semantics being exploited:
+deepvariant/pileup_image_native.cc:405-447 (images are zero-padded to `height` rows), deepvariant/dv_utils.py:343-366."""
 import os
 
 import numpy as np
@@ -17,8 +19,8 @@ pytestmark = pytest.mark.gpu
 def _model(shape, weights, max_batch, skip):
   from deepvariant_amd.inception_v3 import InceptionV3
   old = os.environ.pop('DV_BLANK_SKIP', None)
-  if skip:
-    os.environ['DV_BLANK_SKIP'] = '1'
+  if not skip:
+    os.environ['DV_BLANK_SKIP'] = '0'
   try:
     m = InceptionV3(shape, max_batch=max_batch)
   finally:
@@ -33,15 +35,14 @@ def _images(shape, n_pileups, seed):
   h, w, c = shape
   rng = np.random.default_rng(seed)
   imgs = []
-  if (h, w) == (100, 221) and c in (6, 7):
-    from deepvariant_amd import synth
-    from deepvariant_amd.pileup_image_native import _Encoder
-    opts = synth.illumina_options(c)
-    batch = synth.make_illumina_batch(n_pileups, seed=seed, options=opts)
-    out, _ = _Encoder(opts, opts.width).encode(batch, c)
-    imgs.extend(out.reshape(-1, h, w, c))
+  if n_pileups:
+    from deepvariant_amd import calibration_set
+    drawn = calibration_set.draw(shape, n_pileups, seed=seed)
+    if drawn is not None:
+      imgs.extend(drawn.cpu().numpy())
   # hand-placed pile-up heights: every row count around the thresholds, 0 and the full image
   for r in list(range(0, 12)) + list(range(30, 60)) + [h - 3, h - 2, h - 1, h]:
+    r = min(r, h)
     im = np.zeros((h, w, c), np.uint8)
     im[:r] = rng.integers(0, 256, (r, w, c), dtype=np.uint8)
     imgs.append(im)
@@ -54,28 +55,66 @@ def _images(shape, n_pileups, seed):
   return np.stack(imgs)
 
 
-@pytest.mark.parametrize('shape', [(100, 221, 7), (100, 221, 6), (100, 147, 8), (76, 199, 4)])
+def _expected_thresholds(x):
+  n, h = x.shape[0], x.shape[1]
+  nz = x.reshape(n, h, -1).any(axis=2)
+  r = np.where(nz.any(axis=1), h - np.argmax(nz[:, ::-1], axis=1), 0)
+  t2 = (r + 1) // 2
+  t4 = (t2 + 2) // 2
+  return np.stack([r, t2, t4, t4, (t4 + 1) // 2]).astype(np.int32)
+
+
+@pytest.mark.parametrize('shape', [(100, 221, 7), (100, 221, 6), (100, 147, 8), (76, 199, 4), (100, 199, 9), (100, 147, 10)])
 def test_blank_skip_is_bit_identical(shape):
   from oracle import inception_ref as R
   ref = R.make_random_model(shape[2], seed=23)
   w = ref.export_flat()
-  x = _images(shape, 300, seed=5)
+  x = _images(shape, 192, seed=5)
   n = x.shape[0]
-  plain = _model(shape, w, n, skip=False)
+  dense = _model(shape, w, n, skip=False)
   skip = _model(shape, w, n, skip=True)
   xd = torch.from_numpy(x).cuda()
-  want = plain(xd).cpu().numpy()
+  want = dense(xd).cpu().numpy()
   got = skip(xd).cpu().numpy()
-  # the stem's last tensor (3x3 80->192 output) is where the copies land.  Round 4: the default path
-  # pools that tensor inside the convolution (10 x 25), the blank-skipping path keeps the unpooled
-  # one (21 x 51) for its copies -- pool it here before comparing (max is exact)
-  idx = -2
-  a, b = skip.debug_tensor(idx, n), plain.debug_tensor(idx, n)
-  if a.shape != b.shape:
-    a = torch.nn.functional.max_pool2d(torch.from_numpy(a.astype(np.float32)).permute(0, 3, 1, 2), 3, 2
-                                       ).permute(0, 2, 3, 1).numpy().astype(np.float16)
-  np.testing.assert_array_equal(a, b)
+  assert dense.blank_thresholds(n) is None
+  thr = skip.blank_thresholds(n)
+  np.testing.assert_array_equal(thr, _expected_thresholds(x))
+  assert (thr[4] < 10).mean() > 0.5                  # the test does skip: most images have blank pooled rows
+  # the stem's tensors, where the copies land: conv2's output (buffer 2 of the fused stem: input image, conv1 (LDS
+  # only), conv2), the 1x1's and the pooled 3x3 80->192's (the stem's output)
+  for idx in (2, 4, -2):
+    np.testing.assert_array_equal(skip.debug_tensor(idx, n), dense.debug_tensor(idx, n), err_msg='buffer %d' % idx)
   np.testing.assert_array_equal(got, want)
-  # a second forward through the captured graph, different images in the same buffer
+  # the run-time switch on ONE model: dense, then skipping again -- the same bits every time
+  skip.set_blank_skip(False)
+  np.testing.assert_array_equal(skip(xd).cpu().numpy(), want)
+  assert skip.blank_thresholds(n) is None
+  skip.set_blank_skip(True)
+  np.testing.assert_array_equal(skip(xd).cpu().numpy(), want)
+  # a second forward through the captured graph, different images in the same buffer; and a small batch that does
+  # not fill the persistent grids
   xd.copy_(torch.from_numpy(x[::-1].copy()).cuda())
-  np.testing.assert_array_equal(skip(xd).cpu().numpy(), plain(xd).cpu().numpy())
+  np.testing.assert_array_equal(skip(xd).cpu().numpy(), dense(xd).cpu().numpy())
+  np.testing.assert_array_equal(skip(xd[:7]).cpu().numpy(), dense(xd[:7]).cpu().numpy())
+  # calibration moves the shifts: the blank responses are recomputed with them
+  from deepvariant_amd import calibration_set
+  if calibration_set.supported(shape):
+    skip.calibrate_for_checkpoint(64)
+    dense.calibrate_for_checkpoint(64)
+    np.testing.assert_array_equal(skip(xd).cpu().numpy(), dense(xd).cpu().numpy())
+
+
+def test_blank_skip_at_the_bench_batch_size():
+  """8,104 ILLUMINA30 pileups per forward (the bench's step): every probability and the stem's output identical."""
+  from tests import cnn_tail as T
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  w = R.make_random_model(7, seed=31).export_flat()
+  x = T.illumina_pileups_gpu(8104, seed=77)
+  skip = _model(shape, w, 8104, skip=True)
+  got = skip(x).cpu().numpy()
+  a = skip.debug_tensor(-2, 64)
+  skip.set_blank_skip(False)
+  want = skip(x).cpu().numpy()
+  np.testing.assert_array_equal(skip.debug_tensor(-2, 64), a)
+  np.testing.assert_array_equal(got, want)

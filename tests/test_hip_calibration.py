@@ -124,31 +124,72 @@ def test_calibrate_argument_errors():
     m.calibrate(x.cpu())
 
 
-def test_auto_calibration_is_the_manual_calibration_on_the_first_large_batch():
-  """What call_variants / make_examples switch on (--calibration_examples): forwards of fewer than 64 examples
-  leave the model alone, the first larger one calibrates on its leading 256 and then classifies."""
+def test_checkpoint_calibration_is_the_manual_calibration_on_the_fixed_set():
+  """What call_variants / make_examples do after loading weights (--calibration_examples): calibrate on
+  calibration_set.draw(shape) -- the same images whenever and wherever it is drawn."""
+  from deepvariant_amd import calibration_set
   from oracle import inception_ref as R
   shape = (100, 221, 7)
   ref = R.make_random_model(7, seed=57)
   x = _images(shape, 320, seed=818)
+  cal = calibration_set.draw(shape, 256)
+  assert cal.shape == (256,) + shape and cal.dtype == torch.uint8
+  assert torch.equal(cal, calibration_set.draw(shape, 256))          # deterministic
+  assert torch.equal(cal[:64], calibration_set.draw(shape, 64))      # and prefix-stable
+  assert not torch.equal(cal[:64].cpu(), x[:64].cpu())
   manual = _model(shape, ref.export_flat(), 320)
   plain = manual(x).cpu().numpy()
-  manual.calibrate(x[:256])
+  manual.calibrate(cal)
   want = manual(x).cpu().numpy()
   auto = _model(shape, ref.export_flat(), 320)
-  auto.enable_auto_calibration()
-  assert np.array_equal(auto(x[:40]).cpu().numpy(), plain[:40])      # too few: uncalibrated, nothing consumed
-  assert auto.calibrated_on == 0
-  got = auto(x).cpu().numpy()
-  assert auto.calibrated_on == 256
-  assert np.array_equal(got, want)
-  assert np.array_equal(auto(x).cpu().numpy(), want)                 # once per model
+  corr = auto.calibrate_for_checkpoint(256)
+  assert auto.calibration == {'images': 256, 'set_version': calibration_set.SET_VERSION, 'cached': False}
+  assert np.array_equal(auto(x).cpu().numpy(), want)
+  assert np.array_equal(auto(x[:40]).cpu().numpy(), want[:40])       # small forwards are calibrated too
   assert not np.array_equal(want, plain)
+  off = _model(shape, ref.export_flat(), 320)
+  assert off.calibrate_for_checkpoint(0) is None
+  assert np.array_equal(off(x).cpu().numpy(), plain)
+  assert corr.size == sum(co for _, _, _, co, _ in auto.layer_table())
+
+
+def test_probabilities_are_a_pure_function_of_checkpoint_and_image():
+  """The reference's call_variants maps (weights, image) -> probabilities (deepvariant/call_variants.py:904-932).
+  The same 512 examples (a) in one batch, (b) shuffled, in batches of 100, (c) split between two models that each
+  loaded and calibrated for themselves: identical bits per example."""
+  from oracle import inception_ref as R
+  shape = (100, 221, 7)
+  flat = R.make_random_model(7, seed=59).export_flat()
+  x = _images(shape, 512, seed=4242)
+  a = _model(shape, flat, 512)
+  a.calibrate_for_checkpoint(256)
+  one = a(x).cpu().numpy()
+  perm = torch.randperm(512, generator=torch.Generator().manual_seed(5)).to(x.device)
+  got = np.zeros_like(one)
+  for i in range(0, 512, 100):
+    idx = perm[i:i + 100]
+    got[idx.cpu().numpy()] = a(x[idx]).cpu().numpy()
+  assert np.array_equal(got, one)
+  b = _model(shape, flat, 256)
+  b.calibrate_for_checkpoint(256)
+  c = _model(shape, flat, 300)
+  c.calibrate_for_checkpoint(256)
+  halves = np.concatenate([b(x[:256]).cpu().numpy(), c(x[256:]).cpu().numpy()])
+  assert np.array_equal(halves, one)
+
+
+@pytest.mark.parametrize('shape', [(100, 199, 9), (100, 147, 10), (100, 147, 8), (100, 221, 6), (75, 75, 4)])
+def test_calibration_set_of_every_supported_shape(shape):
+  from deepvariant_amd import calibration_set
+  x = calibration_set.draw(shape, 48)
+  assert x.shape == (48,) + shape and x.dtype == torch.uint8 and x.is_cuda
+  assert torch.equal(x, calibration_set.draw(shape, 48))
+  assert int((x.reshape(48, -1).max(1).values > 0).sum()) == 48         # every image holds a pile-up
+  assert calibration_set.draw((100, 221, 12), 8) is None                # no set: the model stays plain fp16
 
 
 def test_applied_corrections_equal_the_calibration_that_measured_them(tmp_path, monkeypatch):
-  """dv_model_apply_corrections, and the sharing protocol of host ranks on one GPU: the first model to reach its
-  first large batch measures and publishes, a second one with the same key applies -- same probabilities."""
+  """dv_model_apply_corrections, and the cache of a checkpoint's corrections next to it."""
   from oracle import inception_ref as R
   shape = (100, 221, 7)
   ref = R.make_random_model(7, seed=58)
@@ -162,13 +203,20 @@ def test_applied_corrections_equal_the_calibration_that_measured_them(tmp_path, 
   assert np.array_equal(b(x).cpu().numpy(), want) and not np.array_equal(plain, want)
   with pytest.raises(Exception):
     b.apply_corrections(corr[:-1])
-  key = 'test-%d' % os.getpid()
+  # the cache next to a checkpoint: named by everything the corrections depend on; the second model applies the file
+  prefix = str(tmp_path / 'ckpt.f32')
   first = _model(shape, ref.export_flat(), 300)
-  first.enable_auto_calibration(share_key=key)
+  c1 = first.calibrate_for_checkpoint(128, cache_prefix=prefix)
+  files = [f for f in os.listdir(tmp_path) if '.dvcal-' in f]
+  assert len(files) == 1 and first.calibration['cached'] is False
   second = _model(shape, ref.export_flat(), 300)
-  second.enable_auto_calibration(share_key=key)
-  got1 = first(x).cpu().numpy()                   # measures on x[:256], publishes
-  got2 = second(x[torch.randperm(300, device=x.device)][:280])      # another first batch: applies the published one
-  assert np.array_equal(got1, want)
-  assert np.array_equal(second(x).cpu().numpy(), want)
-  del got2
+  c2 = second.calibrate_for_checkpoint(128, cache_prefix=prefix)
+  assert second.calibration['cached'] is True and np.array_equal(c1, c2)
+  assert np.array_equal(first(x).cpu().numpy(), second(x).cpu().numpy())
+  other = _model(shape, R.make_random_model(7, seed=60).export_flat(), 300)      # other weights: another file
+  other.calibrate_for_checkpoint(128, cache_prefix=prefix)
+  assert other.calibration['cached'] is False and len([f for f in os.listdir(tmp_path) if '.dvcal-' in f]) == 2
+  (tmp_path / files[0]).write_bytes(b'\0' * 10)                                   # a damaged file is measured again
+  third = _model(shape, ref.export_flat(), 300)
+  assert np.array_equal(third.calibrate_for_checkpoint(128, cache_prefix=prefix), c1)
+  assert third.calibration['cached'] is False

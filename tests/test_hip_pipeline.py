@@ -348,13 +348,19 @@ def test_make_examples_two_ranks_sharing_the_gpu(tmp_path):
     assert me.main(common + ['--call_variants_outfile', tasks, '--task', str(task)]) == 0
   ranks = str(tmp_path / 'ranks.cvo.tfrecord@2.gz')
   assert me.main(common + ['--call_variants_outfile', ranks, '--gpus', '1', '--ranks_per_gpu', '2']) == 0
-  total = 0
+  total, both = 0, []
   for r in (0, 1):
     want = list(tfrecord.read_tfrecords(str(tmp_path / ('tasks.cvo.tfrecord-%05d-of-00002.gz' % r))))
     got = list(tfrecord.read_tfrecords(str(tmp_path / ('ranks.cvo.tfrecord-%05d-of-00002.gz' % r))))
     assert got == want and len(got) > 10
     total += len(got)
+    both += got
   assert total == 84
+  # ... and the same records as ONE process writes for the whole region list: a candidate's probabilities do not
+  # depend on the rank layout or on which other examples share its batch (the corrections are the checkpoint's)
+  one = str(tmp_path / 'one.cvo.tfrecord.gz')
+  assert me.main(common + ['--call_variants_outfile', one]) == 0
+  assert sorted(tfrecord.read_tfrecords(one)) == sorted(both)
 
 
 @pytest.mark.timeout(900)
@@ -419,9 +425,10 @@ def test_table_path_writes_what_the_object_path_writes(tmp_path, monkeypatch):
     ex = str(tmp_path / (name + '.examples.tfrecord.gz'))
     cvo = str(tmp_path / (name + '.cvo.tfrecord.gz'))
     assert me.main(common + ['--examples', ex]) == 0
-    # (--calibration_examples 0: the two routes classify in different batch sizes -- 256 at a time against one region
-    # at a time -- so they would calibrate the fp16 model on different first batches, or not at all)
-    assert me.main(common + ['--call_variants_outfile', cvo, '--checkpoint', 'random:7', '--calibration_examples', '0']) == 0
+    # calibration ON (the default): the two routes classify in different batch sizes -- 256 at a time against one
+    # region at a time -- and still agree bit for bit, because the corrections come from the checkpoint's fixed
+    # calibration set, not from the run's first examples
+    assert me.main(common + ['--call_variants_outfile', cvo, '--checkpoint', 'random:7']) == 0
     outs[name] = (list(tfrecord.read_tfrecords(ex)), list(tfrecord.read_tfrecords(cvo)))
   assert outs['tables'][0] == outs['objects'][0] and len(outs['tables'][0]) > 40
   assert outs['tables'][1] == outs['objects'][1] and len(outs['tables'][1]) == len(outs['tables'][0])
