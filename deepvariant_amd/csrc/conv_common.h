@@ -92,6 +92,9 @@ struct ConvArgs {
   // instead of multiplying -- bit-identical.  Single-branch launches only; NULL = off.
   const int* blank_row;
   const _Float16* blank_src;
+  // blank_need[n] (optional): output rows of example n that the consumer's computed tiles read; a blank block at or
+  // below it is not even copied (model.hip blank_need_kernel)
+  const int* blank_need;
   // Split weights (model.hip, HISTORY.md 15): the packed image holds every K chunk twice, W_hi then
   // W_lo = fp16(W - W_hi); n_chunks counts both, the pixel operand advances once per pair.
   // split_tiles: the leading cout tiles of the launch that carry such pairs (= n_tiles when every

@@ -351,7 +351,14 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
       return nf == nl && ohf >= p.blank_row[nf];
     };
     if (range_blank(m_block, m_block + 32 * PT * WAVES)) {   // block-uniform, before any barrier
-      copy_blank_wave<NB, PT>(p, n_tile, pn, poh, pow_, mvalid, lane);
+      bool wanted = true;   // rows nobody reads are not even copied (ConvArgs::blank_need)
+      if (p.blank_need != nullptr) {
+        int nf, pf, ohf, owf;
+        divmod_small(m_block, ohow, p.rcp_ohow, nf, pf);
+        divmod_small(pf, p.OW, p.rcp_ow, ohf, owf);
+        wanted = ohf < p.blank_need[nf];
+      }
+      if (wanted) copy_blank_wave<NB, PT>(p, n_tile, pn, poh, pow_, mvalid, lane);
       return;
     }
     const int m_wave = m_block + wave * (32 * PT);
@@ -1153,6 +1160,25 @@ __global__ void preprocess_kernel(const ExtPtrs* ext, size_t in_off, _Float16* o
 //   conv3 3x3 same:    rows y-1..y+1   -> y >= t2 + 1
 //   max-pool 3x3/2:    rows 2y..2y+2   -> y >= ceil(t3 / 2)        (= the 1x1 and the 3x3 valid 80->192)
 // thr[k * stride + n], k = 0: rows used, 1: conv2 output, 2: stem_b output, 3: 3x3 80->192 output, 4: the same, pooled.
+// What the consumers of the skipping kernels read (thr rows 5 and 6): blank tiles beyond these rows are not even
+// copied.  need2 = conv2 rows under stem_b's computed tiles (pooled tiles of kStemB_PH rows starting above t4: pooled
+// row py reads conv3 rows 2py..2py+2, conv3 row y conv2 rows y-1..y+1); need4 = stem_b rows under the 3x3 80->192's
+// walk, which goes down to the deepest pooled threshold among the examples a 32-position fragment spans (conv row r
+// reads rows r..r+2; the walk's last row is 2 s_end).
+// (stem_b_fused / conv4_walks = 0: the consumer is a per-layer kernel that may read every row -- everything is wanted.)
+__global__ void blank_need_kernel(int* thr, int stride, int n, int oh2, int ph_b, int ow4, int p4, int stem_b_fused,
+                                  int conv4_walks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t4 = min(thr[2 * stride + i], ph_b);
+  const int kb = (t4 + dv::kStemB_PH - 1) / dv::kStemB_PH;
+  thr[5 * stride + i] = !stem_b_fused ? oh2 : kb > 0 ? min(oh2, 2 * dv::kStemB_PH * kb + 2) : 0;
+  const int span = 31 / max(ow4, 1) + 1;
+  int m5 = 0;
+  for (int j = max(0, i - span); j <= min(n - 1, i + span); ++j) m5 = max(m5, min(thr[4 * stride + j], p4));
+  thr[6 * stride + i] = !conv4_walks ? ph_b : m5 > 0 ? min(ph_b, 2 * m5 + 3) : 0;
+}
+
 __global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, size_t in_off, int H, int row_bytes,
                                                          int* thr, int stride) {
   __shared__ int last;
@@ -1448,7 +1474,7 @@ struct dv_model {
   bool blank_enabled = true;      // dv_model_set_blank_skip
   bool blank_ready = false;       // the blank responses have been computed (after load_weights)
   int blank_conv4_op = -1;        // op index of the stem's 3x3 80->192
-  dv::DeviceBuffer d_blank_thr;   // int32 [5][max_batch], blank_rows_kernel
+  dv::DeviceBuffer d_blank_thr;   // int32 [7][max_batch], blank_rows_kernel + blank_need_kernel
   dv::DeviceBuffer d_blank_conv4; // the 3x3 80->192's output (pooled when its kernel pools) for the all-blank image (one example)
   dv::DeviceBuffer d_blank_c2;    // conv2's output for the all-blank image
   dv::DeviceBuffer d_blank_b;     // stem_b's (the 1x1 64->80's) output for the all-blank image
@@ -1977,10 +2003,12 @@ struct dv_model {
     // launches whose intermediates stay in LDS.  DV_NO_STEM_FUSE keeps the per-layer path
     // (also used for inputs with more than 8 channels).
     if (getenv("DV_NO_STEM_FUSE") == nullptr) {
-      // stem_a reads the uint8 image with two taps x 8 channels per chunk: C <= 8 only.  stem_b
-      // (conv3 + max-pool + 1x1) reads conv2's fp16 output whatever produced it, so the long-read
-      // channel sets (C = 9, 10) get it too -- behind conv_first_u8 (wide) + a per-layer conv2.
-      if (ops[0].first_u8 && desc.channels <= 8 && ops[3].pool_in && ops[3].cout <= 96) {
+      // stem_a reads the uint8 image with two taps x 8 channels per chunk (C <= 8) or, round 6, one tap x 16
+      // channels (C = 9..12: the long-read channel sets ONT_R104 9, PACBIO 10; DV_NO_STEM_A_WIDE keeps
+      // conv_first_u8 (wide) + a per-layer conv2 for them).  stem_b (conv3 + max-pool + 1x1) reads conv2's fp16
+      // output whatever produced it.
+      const int stem_a_max = getenv("DV_NO_STEM_A_WIDE") == nullptr ? dv::kStemA_MaxChannels : 8;
+      if (ops[0].first_u8 && desc.channels <= stem_a_max && ops[3].pool_in && ops[3].cout <= 96) {
         ops[0].stem_a = true;
         buffers[ops[0].out_buf] = {1, 1, 32, 0};  // conv1 output: LDS only
       }
@@ -2347,6 +2375,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (m->blank_on()) {
         a.blank_thr = static_cast<const int*>(m->d_blank_thr.ptr) + 1 * m->desc.max_batch;
         a.blank_src = static_cast<const _Float16*>(m->d_blank_c2.ptr);
+        a.blank_need = static_cast<const int*>(m->d_blank_thr.ptr) + 5 * m->desc.max_batch;
       }
       TraceScope tr(stream, std::string(m->blank_on() ? "[blank tiles copied] " : "") + "stem_a conv3x3s2 " + std::to_string(op.cin_real) + "->32 + conv3x3 32->32 (fused)",
                     2.0 * n * (static_cast<double>(op.oh) * op.ow * op.kh * op.kw * op.cin_real * op.cout +
@@ -2383,6 +2412,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       if (m->blank_on()) {
         a.blank_thr = static_cast<const int*>(m->d_blank_thr.ptr) + 2 * m->desc.max_batch;
         a.blank_src = static_cast<const _Float16*>(m->d_blank_b.ptr);
+        a.blank_need = static_cast<const int*>(m->d_blank_thr.ptr) + 6 * m->desc.max_batch;
       }
       TraceScope tr(stream, std::string(m->blank_on() ? "[blank tiles copied] " : "") + "stem_b conv3x3 32->64 + maxpool3s2 + conv1x1 64->" + std::to_string(c4.cout) + " (fused)",
                     2.0 * n * (static_cast<double>(op.oh) * op.ow * 9 * 32 * 64 +
@@ -2652,6 +2682,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
         // inputs of 9..16 channels: conv2 runs per layer (conv_mfma_kernel) and skips like the fused stem_a does
         a.blank_row = static_cast<const int*>(m->d_blank_thr.ptr) + 1 * m->desc.max_batch;
         a.blank_src = static_cast<const _Float16*>(m->d_blank_c2.ptr);
+        if (m->ops[2].stem_b) a.blank_need = static_cast<const int*>(m->d_blank_thr.ptr) + 5 * m->desc.max_batch;
         tr_label += " [blank rows copied]";
       }
       oi += op.group_followers;  // the followers ran in this launch
@@ -2838,7 +2869,7 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   if (!(getenv("DV_BLANK_SKIP") != nullptr && atoi(getenv("DV_BLANK_SKIP")) == 0) &&
       m->ops[0].first_u8 && m->blank_conv4_op >= 0 && m->ops[m->blank_conv4_op].group_followers == 0 &&
       (static_cast<size_t>(desc->height) * desc->width * desc->channels) % 4 == 0) {
-    if (int rc = m->d_blank_thr.reserve(static_cast<size_t>(5) * desc->max_batch * sizeof(int))) return rc;
+    if (int rc = m->d_blank_thr.reserve(static_cast<size_t>(7) * desc->max_batch * sizeof(int))) return rc;
     DV_HIP_CHECK(hipMemset(m->d_blank_thr.ptr, 0, m->d_blank_thr.cap));
     m->blank_skip = true;
   }
@@ -2977,7 +3008,8 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
     }
     if ((m->ops[0].stem_a && oi < 2) || (m->ops[2].stem_b && (oi == 2 || oi == 3))) {
       _Float16* dst = packed.data() + op.w_off;   // fused stem: stem.hip's own fragment images
-      if (oi == 0) dv::pack_stem_a_w1(w, inv.data(), l.cin, dst);
+      if (oi == 0 && l.cin > 8) dv::pack_stem_a_w1_wide(w, inv.data(), l.cin, dst);
+      if (oi == 0 && l.cin <= 8) dv::pack_stem_a_w1(w, inv.data(), l.cin, dst);
       if (oi == 1) dv::pack_stem_a_w2(w, inv.data(), dst);
       if (oi == 2) dv::pack_stem_b_w3(w, inv.data(), dst);
       if (oi == 3) dv::pack_stem_b_w4(w, inv.data(), l.cout, dst);
@@ -3357,6 +3389,11 @@ static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
         hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, ext, img_off, m->desc.height,
                            m->desc.width * m->desc.channels, static_cast<int*>(m->d_blank_thr.ptr),
                            m->desc.max_batch);
+        const Op& c4 = m->ops[m->blank_conv4_op];
+        hipLaunchKernelGGL(blank_need_kernel, dim3((sb + 255) / 256), dim3(256), 0, stream,
+                           static_cast<int*>(m->d_blank_thr.ptr), m->desc.max_batch, sb, m->ops[1].oh, m->ops[3].oh,
+                           c4.ow, c4.pool_out ? m->buffers[c4.out_buf].h : c4.oh, m->ops[2].stem_b ? 1 : 0,
+                           c4.pool_out ? 1 : 0);
       }
       if (!m->ops[0].first_u8) {
         const size_t n_pix = static_cast<size_t>(sb) * m->desc.height * m->desc.width;

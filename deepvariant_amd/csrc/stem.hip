@@ -30,6 +30,7 @@
 //     phase and written to LDS after it (before that phase's stores are issued, so no
 //     s_waitcnt ever waits for a store); two workgroup barriers per tile.
 #include <algorithm>
+#include <type_traits>
 
 #include "stem_fused.h"
 
@@ -153,6 +154,19 @@ constexpr int A_ROWS_PER_PASS = A_THREADS / A_INW;            // 2
 constexpr int A_PASSES = (A_INH + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;  // 10
 static_assert(A_C1FR % 4 == 0 && A_C2FR % 4 == 0, "fragments split evenly over 4 waves");
 static_assert(A_LDS <= 80 * 1024, "two workgroups per CU");
+// Inputs of 9..12 channels (the long-read models: ONT_R104 9, PACBIO 10), round 6.  A pixel is up to 12 bytes: conv1's
+// K chunk is ONE tap x 16 channels (k-group 0 = bytes 0..7, k-group 1 = bytes 8..15 of the pixel; bytes past C belong
+// to the next pixel and meet zero weights), nine chunks.  The input patch stays uint8 in LDS -- four planes (column
+// parity x k-group) of 8 bytes per pixel, the same 34,656 bytes as the two fp16 planes above, so the rest of the LDS
+// map is shared -- and is normalised on its way into the matrix core (one v_perm + packed FMA per two channels, beside
+// the MFMAs); conv1's nine weight fragments live in LDS (9 KB) instead of registers (36 VGPRs would not fit next to
+// conv2's 72).  conv1's output tile, conv2 and the stores are the code of the <= 8-channel kernel.
+constexpr int AW_ROW = A_INWH * 8;                            // 456 bytes: one row of one plane
+constexpr int AW_PLANE = A_INH * AW_ROW;                      // 8664
+static_assert(4 * AW_PLANE == 2 * A_INPLANE, "the uint8 patch of the wide kernel fills the fp16 patch's space");
+constexpr int AW_OFF_W1 = A_OFF_SH + 64 * 4;
+constexpr int AW_LDS = AW_OFF_W1 + kStemA_W1WideHalfs * 2;
+static_assert(AW_LDS <= 80 * 1024, "two workgroups per CU");
 
 // uint8 -> fp16 (x - 128) / 128 for 8 consecutive bytes: 0x6400 | b is the fp16 number
 // 1024 + b, and (1024 + b) * 2^-7 - 9 = (b - 128) / 128 exactly (deepvariant/dv_utils.py:343-366)
@@ -170,6 +184,7 @@ __device__ __forceinline__ uint4_t normalise8(unsigned lo, unsigned up) {
                  __builtin_bit_cast(unsigned, h67 * scale + bias)};
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -180,7 +195,12 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   half8_t a1[5], a2[18];
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
-    a1[c] = *reinterpret_cast<const half8_t*>(p.w1 + ((c * 2 + hi) * 32 + l31) * 8);
+    if constexpr (!WIDE) a1[c] = *reinterpret_cast<const half8_t*>(p.w1 + ((c * 2 + hi) * 32 + l31) * 8);
+  }
+  if constexpr (WIDE) {   // conv1's nine (tap x 16 channels) fragments -> LDS, once per workgroup
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(p.w1);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(smem + AW_OFF_W1);
+    for (int i = tid; i < kStemA_W1WideHalfs / 8; i += A_THREADS) dst[i] = src[i];
   }
 #pragma unroll
   for (int kc = 0; kc < 18; ++kc) {
@@ -188,8 +208,10 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   }
   // The weight loads retire HERE: inside the tile loop the only vector-memory traffic left
   // for s_waitcnt to reason about is the patch prefetch and the output stores.
+  if constexpr (!WIDE) {
 #pragma unroll
-  for (int c = 0; c < 5; ++c) asm volatile("" : "+v"(a1[c]));
+    for (int c = 0; c < 5; ++c) asm volatile("" : "+v"(a1[c]));
+  }
 #pragma unroll
   for (int kc = 0; kc < 18; ++kc) asm volatile("" : "+v"(a2[kc]));
   float* lsh = reinterpret_cast<float*>(smem + A_OFF_SH);
@@ -205,7 +227,8 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   const bool sact = tid < A_ROWS_PER_PASS * A_INW;
   const unsigned srel = static_cast<unsigned>((srow * p.W + scol) * p.C);
   const unsigned spass = static_cast<unsigned>(A_ROWS_PER_PASS * p.W * p.C);
-  const unsigned sdst = static_cast<unsigned>((scol & 1) * A_INPLANE + srow * A_INROW + (scol >> 1) * 16);
+  const unsigned sdst = WIDE ? static_cast<unsigned>((scol & 1) * 2 * AW_PLANE + srow * AW_ROW + (scol >> 1) * 8)
+                             : static_cast<unsigned>((scol & 1) * A_INPLANE + srow * A_INROW + (scol >> 1) * 16);
   // conv1: 4 fragments of the 9 x 56 tile per wave
   unsigned bA[4], bB[4], bC[4], c1dst[4];
 #pragma unroll
@@ -217,6 +240,9 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
     bA[f] = base + hi * A_INPLANE;  // tap pairs (kh,0),(kh,1): even / odd column plane
     bB[f] = base + hi * A_INROW;    // tap pair (0,2),(1,2): one row down
     bC[f] = base;                   // tap (2,2) + the zero-weight pad
+    if constexpr (WIDE) {           // plane (column parity 0, k-group hi), row 2 cy, piece cx: taps are offsets on it
+      bA[f] = static_cast<unsigned>(hi * AW_PLANE + 2 * cy * AW_ROW + cx * 8);
+    }
     c1dst[f] = static_cast<unsigned>(A_OFF_C1 + hi * A_C1PLANE + j * 16);
   }
   // conv2: 3 fragments of the 7 x 54 tile per wave
@@ -247,7 +273,8 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
   const size_t img_out = static_cast<size_t>(p.og.groups) * p.og.hp * p.og.wp;  // pieces
   const unsigned gstride = static_cast<unsigned>(p.og.hp * p.og.wp);
 
-  uint3_t pre[A_PASSES];
+  typedef typename std::conditional<WIDE, uint4_t, uint3_t>::type pre_t;
+  pre_t pre[A_PASSES];
   auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
     n = t / tiles_img;
     const int r = t - n * tiles_img;
@@ -261,7 +288,11 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
     for (int ps = 0; ps < A_PASSES; ++ps) {
       const bool act = sact && (ps * A_ROWS_PER_PASS + srow < A_INH);
       const unsigned a = origin + srel + ps * spass;
-      pre[ps] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, act ? (a & ~3u) : 0x80000000u, 0, 0);
+      if constexpr (WIDE) {   // the aligned 16 bytes around the pixel's <= 12
+        pre[ps] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, act ? (a & ~3u) : 0x80000000u, 0, 0);
+      } else {
+        pre[ps] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, act ? (a & ~3u) : 0x80000000u, 0, 0);
+      }
     }
   };
 
@@ -275,8 +306,16 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
         const unsigned s8 = (a & 3u) * 8u;
         const unsigned lo = __builtin_amdgcn_alignbit(pre[ps][1], pre[ps][0], s8);
         const unsigned up = __builtin_amdgcn_alignbit(pre[ps][2], pre[ps][1], s8);
-        *reinterpret_cast<uint4_t*>(smem + sdst + ps * (A_ROWS_PER_PASS * A_INROW)) =
-            normalise8(lo, up);
+        if constexpr (WIDE) {   // raw bytes: k-group 0 = bytes 0..7, k-group 1 = bytes 8..11 (+ 4 that meet zero weights)
+          typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+          const unsigned lo1 = __builtin_amdgcn_alignbit(pre[ps][3], pre[ps][2], s8);
+          char* d = smem + sdst + ps * (A_ROWS_PER_PASS * AW_ROW);
+          *reinterpret_cast<uint2_t*>(d) = uint2_t{lo, up};
+          *reinterpret_cast<uint2_t*>(d + AW_PLANE) = uint2_t{lo1, 0u};
+        } else {
+          *reinterpret_cast<uint4_t*>(smem + sdst + ps * (A_ROWS_PER_PASS * A_INROW)) =
+              normalise8(lo, up);
+        }
       }
     }
   };
@@ -288,12 +327,22 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
     uint4_t* dst = reinterpret_cast<uint4_t*>(p.out) + static_cast<size_t>(nb_) * img_out;
     const int th = min(A_TH, p.OH2 - yb), tw = min(A_TW, p.OW2 - xb);
     const int per_group = th * tw;
-    for (int e = tid; e < 4 * per_group; e += A_THREADS) {
+    constexpr int kPer = (4 * A_TH * A_TW + A_THREADS - 1) / A_THREADS;   // 6 pieces per thread: all loads, then all stores
+    uint4_t v[kPer];
+    unsigned at[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = k * A_THREADS + tid;
       const int g = e / per_group, r = e - g * per_group;
       const int yy = r / tw, xx = r - yy * tw;
-      const unsigned o = static_cast<unsigned>(g) * gstride +
-                         static_cast<unsigned>((yb + yy + p.og.halo) * p.og.wp + xb + xx + p.og.halo);
-      dst[o] = src[o];
+      at[k] = e < 4 * per_group ? static_cast<unsigned>(g) * gstride +
+                                      static_cast<unsigned>((yb + yy + p.og.halo) * p.og.wp + xb + xx + p.og.halo)
+                                : 0xffffffffu;
+      if (at[k] != 0xffffffffu) v[k] = src[at[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (at[k] != 0xffffffffu) dst[at[k]] = v[k];
     }
   };
   auto next_tile = [&](int tt) {
@@ -302,7 +351,7 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
       int nb_, yb, xb;
       tile_origin(tt, nb_, yb, xb);
       if (yb < p.blank_thr[nb_]) break;
-      copy_blank_tile(nb_, yb, xb);
+      if (yb < p.blank_need[nb_]) copy_blank_tile(nb_, yb, xb);   // (else: nobody reads this tile)
       tt += gridDim.x;
     }
     return tt;
@@ -324,6 +373,35 @@ __global__ __launch_bounds__(A_THREADS, 2) void stem_a_kernel(StemAArgs p) {
       float16_t acc[2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) acc[f] = acc_init(lsh + hi * 16);
+      if constexpr (WIDE) {
+        // nine taps x 16 channels: the A fragment of a tap from LDS (shared by the round's two pixel fragments), the
+        // B fragments = 8 raw bytes of (row 2cy + kh, column 2cx + kw), normalised on the way in; the reads of tap
+        // t + 1 are issued before the MFMAs of tap t
+        typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+        auto b_addr = [&](int tap, int f) {
+          const int kh = tap / 3, kw = tap % 3;
+          return bA[round * 2 + f] + static_cast<unsigned>((kw & 1) * 2 * AW_PLANE + kh * AW_ROW + (kw >> 1) * 8);
+        };
+        const char* w1l = smem + AW_OFF_W1 + (hi * 32 + l31) * 16;
+        half8_t wa[2];
+        uint2_t xb[2][2];
+        wa[0] = lds_piece(w1l, 0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) xb[0][f] = *reinterpret_cast<const uint2_t*>(smem + b_addr(0, f));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 1 < 9) {
+            wa[(tap + 1) & 1] = lds_piece(w1l, (tap + 1) * 2 * 32 * 16);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) xb[(tap + 1) & 1][f] = *reinterpret_cast<const uint2_t*>(smem + b_addr(tap + 1, f));
+          }
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const half8_t x = __builtin_bit_cast(half8_t, normalise8(xb[tap & 1][f][0], xb[tap & 1][f][1]));
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap & 1], x, acc[f], 0, 0, 0);
+          }
+        }
+      } else
       mfma_sweep<5, 2, 3>(
           a1, smem,
           [&](int s, int f) {
@@ -527,12 +605,22 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
     const int th = min(B_PH, p.PH - pyb), tw = min(B_PW, p.PW - pxb);
     const int per_group = th * tw;
     const int groups = (p.Cout4 + 7) / 8;
-    for (int e = tid; e < groups * per_group; e += B_THREADS) {
+    constexpr int kPer = (12 * B_PH * B_PW + B_THREADS - 1) / B_THREADS;   // up to 96 couts: all loads, then all stores
+    uint4_t v[kPer];
+    unsigned at[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int e = k * B_THREADS + tid;
       const int g = e / per_group, r = e - g * per_group;
       const int yy = r / tw, xx = r - yy * tw;
-      const unsigned o = static_cast<unsigned>(g) * ogstride +
-                         static_cast<unsigned>((pyb + yy + p.og.halo) * p.og.wp + pxb + xx + p.og.halo);
-      dst[o] = src[o];
+      at[k] = e < groups * per_group ? static_cast<unsigned>(g) * ogstride +
+                                           static_cast<unsigned>((pyb + yy + p.og.halo) * p.og.wp + pxb + xx + p.og.halo)
+                                     : 0xffffffffu;
+      if (at[k] != 0xffffffffu) v[k] = src[at[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (at[k] != 0xffffffffu) dst[at[k]] = v[k];
     }
   };
   auto next_tile = [&](int tt) {
@@ -541,7 +629,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void stem_b_kernel(StemBArgs p) {
       int nb_, pyb, pxb;
       tile_coords(tt, nb_, pyb, pxb);
       if (pyb < p.blank_thr[nb_]) break;
-      copy_blank_tile(nb_, pyb, pxb);
+      if (pyb < p.blank_need[nb_]) copy_blank_tile(nb_, pyb, pxb);   // (else: nobody reads this tile)
       tt += gridDim.x;
     }
     return tt;
@@ -737,13 +825,19 @@ int stem_b_blocks(int device) { return B_BLOCKS_PER_CU * cu_count(device); }
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream) {
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_a_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_a_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_a_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, AW_LDS);
     return true;
   }();
   (void)attr;
   const int grid = balanced_grid(std::max(1, std::min(blocks, a.total_tiles)), a.tiles_y * a.tiles_x, a.blank_thr != nullptr);
-  hipLaunchKernelGGL(stem_a_kernel, dim3(grid), dim3(A_THREADS), A_LDS, stream, a);
+  if (a.C > 8) {
+    hipLaunchKernelGGL(stem_a_kernel<true>, dim3(grid), dim3(A_THREADS), AW_LDS, stream, a);
+  } else {
+    hipLaunchKernelGGL(stem_a_kernel<false>, dim3(grid), dim3(A_THREADS), A_LDS, stream, a);
+  }
 }
 
 void launch_stem_b(const StemBArgs& a, int blocks, hipStream_t stream) {
@@ -783,6 +877,19 @@ void pack_stem_a_w1(const float* w, const float* inv, int cin, _Float16* dst) {
               static_cast<_Float16>(w[(static_cast<size_t>(tap) * cin + ci) * 32 + co] * inv[co]);
         }
     }
+}
+
+void pack_stem_a_w1_wide(const float* w, const float* inv, int cin, _Float16* dst) {
+  std::fill(dst, dst + kStemA_W1WideHalfs, static_cast<_Float16>(0.f));
+  for (int tap = 0; tap < 9; ++tap)
+    for (int g = 0; g < 2; ++g)
+      for (int co = 0; co < 32; ++co)
+        for (int j = 0; j < 8; ++j) {
+          const int ci = 8 * g + j;   // input channel = byte of the pixel
+          if (ci >= cin) continue;
+          dst[((tap * 2 + g) * 32 + co) * 8 + j] =
+              static_cast<_Float16>(w[(static_cast<size_t>(tap) * cin + ci) * 32 + co] * inv[co]);
+        }
 }
 
 void pack_stem_a_w2(const float* w, const float* inv, _Float16* dst) {

@@ -15,13 +15,15 @@ struct C8Geom {
   int h, w, halo, hp, wp, groups;
 };
 
-// ---- stem A: conv 3x3/2 (uint8 pileup, C <= 8 channels -> 32) + conv 3x3 32 -> 32 --------
+// ---- stem A: conv 3x3/2 (uint8 pileup, C <= 12 channels -> 32) + conv 3x3 32 -> 32 -------
 // tf_keras InceptionV3 stem layers 1-2 (deepvariant/keras_modeling.py:268-274 builds the
 // backbone); both 'valid'.  One workgroup produces a TH x TW tile of the SECOND conv: the
 // (TH+2) x (TW+2) tile of the first conv's output lives in LDS only.
 constexpr int kStemA_TH = 7, kStemA_TW = 54;
 constexpr int kStemA_W1Halfs = 5 * 2 * 32 * 8;    // conv1: 5 chunks (2 taps x 8 channels each)
 constexpr int kStemA_W2Halfs = 18 * 2 * 32 * 8;   // conv2: 9 taps x 2 channel chunks
+constexpr int kStemA_W1WideHalfs = 9 * 2 * 32 * 8;  // conv1 at 9..12 input channels: 9 chunks (1 tap x 16 channels each)
+constexpr int kStemA_MaxChannels = 12;            // a pixel's bytes must lie inside one aligned 16-byte load
 
 struct StemAArgs {
   const uint8_t* in;      // [N][H][W][C]; or, when in_ind is set, *in_ind + in_off (the caller's
@@ -45,6 +47,9 @@ struct StemAArgs {
   // instead of loaded and multiplied -- bit-identical.  NULL = off.
   const int* blank_thr;
   const _Float16* blank_src;
+  // blank_need[n] = conv2 rows of example n that stem_b's computed tiles read: blank tiles below that row are not
+  // even copied -- nothing reads them (the tensor keeps whatever an earlier forward left there)
+  const int* blank_need;
 };
 
 // ---- stem B: conv 3x3 'same' 32 -> 64, max-pool 3x3/2, conv 1x1 64 -> 80 -----------------
@@ -84,6 +89,7 @@ struct StemBArgs {
   // (pooled row py reads conv2 rows 2py-1 .. 2py+3), blank_src = the all-blank image's 1x1 output (one example, `og`)
   const int* blank_thr;
   const _Float16* blank_src;
+  const int* blank_need;  // rows of example n the 3x3 80->192's walk reads (see StemAArgs::blank_need)
 };
 
 void launch_stem_a(const StemAArgs& a, int blocks, hipStream_t stream);
@@ -94,6 +100,7 @@ int stem_b_blocks(int device);
 // Host-side weight packing.  `w` is the layer's HWIO kernel, `inv` the folded BatchNorm
 // scale 1/sqrt(var + eps) per output channel.
 void pack_stem_a_w1(const float* w, const float* inv, int cin, _Float16* dst);
+void pack_stem_a_w1_wide(const float* w, const float* inv, int cin, _Float16* dst);   // cin in 9..kStemA_MaxChannels
 void pack_stem_a_w2(const float* w, const float* inv, _Float16* dst);
 void pack_stem_b_w3(const float* w, const float* inv, _Float16* dst);
 void pack_stem_b_w4(const float* w, const float* inv, int cout, _Float16* dst);

@@ -80,10 +80,10 @@ def test_blank_skip_is_bit_identical(shape):
   thr = skip.blank_thresholds(n)
   np.testing.assert_array_equal(thr, _expected_thresholds(x))
   assert (thr[4] < 10).mean() > 0.5                  # the test does skip: most images have blank pooled rows
-  # the stem's tensors, where the copies land: conv2's output (buffer 2 of the fused stem: input image, conv1 (LDS
-  # only), conv2), the 1x1's and the pooled 3x3 80->192's (the stem's output)
-  for idx in (2, 4, -2):
-    np.testing.assert_array_equal(skip.debug_tensor(idx, n), dense.debug_tensor(idx, n), err_msg='buffer %d' % idx)
+  # the stem's output (the pooled 3x3 80->192), where the last copies land -- every later layer reads all of it.  (The
+  # tensors between the skipping kernels are NOT compared: blank tiles that no computed tile of the consumer reads
+  # are not even copied there, StemAArgs::blank_need.)
+  np.testing.assert_array_equal(skip.debug_tensor(-2, n), dense.debug_tensor(-2, n))
   np.testing.assert_array_equal(got, want)
   # the run-time switch on ONE model: dense, then skipping again -- the same bits every time
   skip.set_blank_skip(False)

@@ -8,7 +8,8 @@ examples of each long-read shape (100x147x10, 100x199x9) on the same held-out se
 (tests/cnn_tail.py) after being checked against its CPU form on 256 of the same images.
 
 What is asserted is the bar itself, with the product's default model preparation -- plain fp16 weights, shifts
-calibrated (dv_model_calibrate) on 256 OTHER pileups: every one of the 65,536 candidates within 1e-3 on every
+calibrated (dv_model_calibrate) on the checkpoint's fixed synthetic set of 256 OTHER pileups
+(InceptionV3.calibrate_for_checkpoint): every one of the 65,536 candidates within 1e-3 on every
 held-out seed (profiles/r05_cnn_tail.txt: max |dp| 8.6e-4 / 2.9e-4 / 7.2e-4, none over; without calibration seed 101
 has 11 candidates over, with the round-4 split weights 1).  Why the calibration works and what is left of the
 fp16 error: HISTORY.md 15 and DESIGN.md 6.
@@ -31,12 +32,13 @@ def _tail_images():
   return _cache['x']
 
 
-def _calibrated_model(shape, weights, max_batch, cal_images):
+def _product_model(shape, weights, max_batch):
+  """The product's model preparation: weights, then the shift calibration on the checkpoint's fixed synthetic set
+  (InceptionV3.calibrate_for_checkpoint -- what call_variants / make_examples do; other pileups than any sample here)."""
   from deepvariant_amd.inception_v3 import InceptionV3
   m = InceptionV3(shape, max_batch=max_batch)
   m.load_flat_weights(weights)
-  if hasattr(m, 'calibrate') and cal_images is not None:
-    m.calibrate(cal_images)
+  m.calibrate_for_checkpoint(256)
   return m
 
 
@@ -57,8 +59,7 @@ def test_illumina30_tail_on_held_out_weight_seeds(seed):
   x = _tail_images()
   ref = R.make_random_model(7, seed=seed)
   want = T.oracle_probs_gpu(R.make_random_model(7, seed=seed).cuda(), x)
-  cal = T.illumina_pileups_gpu(256, seed=990000 + seed)      # calibration batch: other pileups than the sample
-  model = _calibrated_model((100, 221, 7), ref.export_flat(), 8192, cal)
+  model = _product_model((100, 221, 7), ref.export_flat(), 8192)
   got = T.hip_probs(model, x, 8192)
   s = T.tail_stats(got, want)
   print('seed %d: %s' % (seed, T.fmt(s)))
@@ -70,12 +71,12 @@ def test_illumina30_tail_on_held_out_weight_seeds(seed):
 @pytest.mark.parametrize('seed', HELD_OUT_SEEDS)
 @pytest.mark.parametrize('kind,shape', [('hifi', (100, 147, 10)), ('ont', (100, 199, 9))])
 def test_long_read_shapes_on_2048_examples(kind, shape, seed):
-  """The PACBIO / ONT_R104 input shapes on bench.py's hifi35 / ont50 images, held-out weight seeds, product default
-  (calibrated on 256 other images).  These shapes do NOT hold 1e-3 on every seed: profiles/r05_cnn_tail_longread.txt
-  -- sigma(dp) ~ 2.5e-4 after calibration, the largest of 2,048 draws at 0.9-1.4e-3; ont / seed 202 has 10 candidates
-  over the bar (max 1.39e-3), hifi / seed 101 one (1.09e-3).  Asserted: what was measured plus margin, so that a
-  regression shows -- the 99.9th percentile under 1.25e-3, at most 1 % of the candidates over 1e-3, nothing over
-  1.6e-3 -- and the statistics are printed for the record."""
+  """The PACBIO / ONT_R104 input shapes (BASELINE configs[3], configs[4]) on bench.py's hifi35 / ont50 images,
+  held-out weight seeds, the product's default model preparation.  ASSERTED: north_star's bar itself -- no candidate
+  of the 2,048 beyond 1e-3.  A (shape, seed) pair that misses it is reported as XFAIL with its numbers, never as a
+  pass: profiles/r06_cnn_tail_longread.txt and DESIGN.md 6 say which pairs miss and why (sigma(dp) of these deeper
+  pile-ups sits at the floor of fp16 MFMA operands; profiles/r06_tensor_budget_*.txt is the per-tensor table and the
+  cost of going below it).  A hard regression guard stays underneath: p99.9 <= 1.25e-3, <= 1 % over, max <= 1.6e-3."""
   from tests import cnn_tail as T
   from oracle import inception_ref as R
   n = 2048
@@ -85,14 +86,15 @@ def test_long_read_shapes_on_2048_examples(kind, shape, seed):
   ref_gpu = R.make_random_model(shape[2], seed=seed).cuda()
   T.check_gpu_oracle(ref, ref_gpu, x, n=64, tol=5e-6)
   want = T.oracle_probs_gpu(ref_gpu, x)
-  cal = T.longread_images_gpu(kind, 256, seed=4711 + seed)
-  model = _calibrated_model(shape, ref.export_flat(), n, cal)
+  model = _product_model(shape, ref.export_flat(), n)
   got = T.hip_probs(model, x, n)
   s = T.tail_stats(got, want)
   print('%s %s seed %d: %s' % (kind, shape, seed, T.fmt(s)))
   assert s['p999_abs_dp'] <= 1.25e-3, s
   assert s['n_over_tol'] <= n // 100, s
   assert s['max_abs_dp'] <= 1.6e-3, s
+  if s['n_over_tol'] != 0 or s['max_abs_dp'] > 1e-3:
+    pytest.xfail('%s seed %d misses the 1e-3 bar: %s' % (kind, seed, T.fmt(s)))
 
 
 def _longread_images(kind, n):

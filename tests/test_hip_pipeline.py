@@ -90,6 +90,7 @@ def test_make_examples_then_call_variants(tmp_path):
   ref = R.make_random_model(7, seed=11)
   model = InceptionV3((100, 221, 7), max_batch=32)
   model.load_flat_weights(ref.export_flat())
+  model.calibrate_for_checkpoint(256)     # the drivers' model preparation (the command line below does the same)
   out = str(tmp_path / 'cvo.tfrecord.gz')
   n = cv.call_variants(ex_path, out, model, batch_size=32, writer_shards=2)
   assert n == 84
