@@ -232,9 +232,13 @@ def run_rank(args, rank, local_rank, world):
   # (Measured and removed in round 5: the next step's encoder on a second stream, two pileup buffers, so that it
   # runs under this step's classifier -- 444 K against 455 K candidates/s same box: the encoder's waves take
   # issue slots and L2 from the MFMA kernels for longer than its own 0.55 ms.)
+  # The encoder states how many read rows it drew per image (`rows`); with the reference band on top everything below
+  # is zero, which is what the classifier's blank-row skipping needs to know (dv_model_infer_rows: no scan of the images)
+  band = int(opts.reference_band_height)
+
   def local_step():
     dbatch.encode(enc, C, images, rows)
-    return model(images)
+    return model(images, rows_used=rows, rows_add=band)
 
   step, gathered = make_gather_step(local_step, ids, world, dev)
 

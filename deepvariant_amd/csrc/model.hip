@@ -954,11 +954,15 @@ constexpr size_t conv_lds_bytes() {
 struct ExtPtrs {
   const uint8_t* images;
   float* probs;
+  const int32_t* rows_hint;   // dv_model_infer_rows: per image, rows at or below rows_hint[i] + rows_add are all zero
+  int rows_add;
 };
 
-__global__ void set_ext_kernel(ExtPtrs* ext, const uint8_t* images, float* probs) {
+__global__ void set_ext_kernel(ExtPtrs* ext, const uint8_t* images, float* probs, const int32_t* rows_hint, int rows_add) {
   ext->images = images;
   ext->probs = probs;
+  ext->rows_hint = rows_hint;
+  ext->rows_add = rows_add;
 }
 
 __device__ __forceinline__ const uint8_t* ext_images(const ExtPtrs* ext, size_t off) {
@@ -1179,8 +1183,8 @@ __global__ void blank_need_kernel(int* thr, int stride, int n, int oh2, int ph_b
   thr[6 * stride + i] = !conv4_walks ? ph_b : m5 > 0 ? min(ph_b, 2 * m5 + 3) : 0;
 }
 
-__global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, size_t in_off, int H, int row_bytes,
-                                                         int* thr, int stride) {
+__global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, size_t in_off, int n_hint0, int H,
+                                                         int row_bytes, int* thr, int stride) {
   __shared__ int last;
   const uint8_t* images = ext->images + in_off;
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -1190,7 +1194,10 @@ __global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, siz
   if (tid == 0) last = -1;
   __syncthreads();
   constexpr int kPer = 16;   // dwords per thread and trip: 16 KB of the image per barrier
-  for (int hi = n_dw; hi > 0; hi -= 256 * kPer) {
+  // dv_model_infer_rows: the caller (the encoder that drew the images) states the rows used -- no scan
+  const bool hinted = ext->rows_hint != nullptr;   // uniform
+  const int hinted_rows = hinted ? max(0, min(H, ext->rows_hint[n_hint0 + n] + ext->rows_add)) : 0;
+  for (int hi = hinted ? 0 : n_dw; hi > 0; hi -= 256 * kPer) {
     uint32_t v[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {   // all loads in flight before the first compare
@@ -1208,7 +1215,7 @@ __global__ __launch_bounds__(256) void blank_rows_kernel(const ExtPtrs* ext, siz
     if (last >= 0) break;   // uniform: read after the barrier
   }
   if (tid == 0) {
-    const int r = last < 0 ? 0 : last / row_bytes + 1;
+    const int r = hinted ? hinted_rows : last < 0 ? 0 : last / row_bytes + 1;
     const int t2 = (r + 1) / 2, t3 = t2 + 1, t4 = (t3 + 1) / 2;
     thr[n] = r;
     thr[stride + n] = t2;
@@ -2927,8 +2934,10 @@ int dv_model_layer_info(const dv_model* m, int layer, int32_t* kh, int32_t* kw,
 }
 
 static int enqueue_forward(dv_model* m, int n, hipStream_t stream);
-static void set_ext(dv_model* m, const uint8_t* images, float* probs, hipStream_t stream) {
-  hipLaunchKernelGGL(set_ext_kernel, dim3(1), dim3(1), 0, stream, static_cast<ExtPtrs*>(m->d_ext.ptr), images, probs);
+static void set_ext(dv_model* m, const uint8_t* images, float* probs, hipStream_t stream,
+                    const int32_t* rows_hint = nullptr, int rows_add = 0) {
+  hipLaunchKernelGGL(set_ext_kernel, dim3(1), dim3(1), 0, stream, static_cast<ExtPtrs*>(m->d_ext.ptr), images, probs,
+                     rows_hint, rows_add);
 }
 
 // Blank-row skipping: the stem's response to the all-blank (all-zero) image, computed once per
@@ -3386,7 +3395,7 @@ static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
       const size_t img_off = static_cast<size_t>(done + sb0) * img_bytes;
       if (m->blank_on()) {
         dv::ProfileScope prof(dv::kProfOther, stream);
-        hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, ext, img_off, m->desc.height,
+        hipLaunchKernelGGL(blank_rows_kernel, dim3(sb), dim3(256), 0, stream, ext, img_off, done + sb0, m->desc.height,
                            m->desc.width * m->desc.channels, static_cast<int*>(m->d_blank_thr.ptr),
                            m->desc.max_batch);
         const Op& c4 = m->ops[m->blank_conv4_op];
@@ -3422,6 +3431,11 @@ static int enqueue_forward(dv_model* m, int n, hipStream_t stream) {
 }
 
 int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void* stream_v) {
+  return dv_model_infer_rows(m, images, n, probs, nullptr, 0, stream_v);
+}
+
+int dv_model_infer_rows(dv_model* m, const uint8_t* images, int n, float* probs, const int32_t* rows_used, int rows_add,
+                        void* stream_v) {
   if (!m || !images || !probs || n < 0) {
     return dv::fail(DV_ERR_INVALID_ARGUMENT, "dv_model_infer: bad argument");
   }
@@ -3440,7 +3454,7 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs, void
   // a caller that is already capturing this stream gets plain launches (they join ITS graph)
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (stream != nullptr) (void)hipStreamIsCapturing(stream, &capturing);
-  set_ext(m, images, probs, stream);
+  set_ext(m, images, probs, stream, rows_used, rows_add);
   if (no_graph || dv::profiling_enabled() || stream == nullptr ||
       capturing != hipStreamCaptureStatusNone) {
     static std::vector<OpTrace> trace_store;

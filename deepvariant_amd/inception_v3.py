@@ -156,7 +156,10 @@ class InceptionV3(torch.nn.Module):
     return flat
 
   # ---- forward --------------------------------------------------------------
-  def forward(self, images: torch.Tensor) -> torch.Tensor:
+  def forward(self, images: torch.Tensor, rows_used: Optional[torch.Tensor] = None, rows_add: int = 0) -> torch.Tensor:
+    """`rows_used` (CUDA int32 [N], optional; dv_model_infer_rows): the caller's promise that image i is all zero from
+    row rows_used[i] + rows_add on -- the encoder's `rows` output + the reference band height for images it has just
+    drawn; blank-row skipping then needs no scan of the images."""
     if images.dtype != torch.uint8 or not images.is_cuda:
       raise ValueError('images must be a CUDA uint8 tensor [N, H, W, C]')
     if tuple(images.shape[1:]) != self.input_shape:
@@ -176,9 +179,15 @@ class InceptionV3(torch.nn.Module):
       out = torch.empty((n, self.num_classes), dtype=torch.float32, device=images.device)
       self._out_buffers[(n, images.device)] = out
     stream = torch.cuda.current_stream(images.device).cuda_stream
-    _lib.check(_lib.lib().dv_model_infer(
-        self._handle, images.data_ptr(), n, out.data_ptr(),
-        C.c_void_p(stream)))
+    if rows_used is not None:
+      if rows_used.dtype != torch.int32 or not rows_used.is_cuda or rows_used.numel() < n or not rows_used.is_contiguous():
+        raise ValueError('rows_used must be a contiguous CUDA int32 tensor with one entry per image')
+      _lib.check(_lib.lib().dv_model_infer_rows(
+          self._handle, images.data_ptr(), n, out.data_ptr(), rows_used.data_ptr(), int(rows_add), C.c_void_p(stream)))
+    else:
+      _lib.check(_lib.lib().dv_model_infer(
+          self._handle, images.data_ptr(), n, out.data_ptr(),
+          C.c_void_p(stream)))
     return out.clone()
 
   def set_blank_skip(self, enabled: bool) -> None:

@@ -820,6 +820,15 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
 int dv_model_set_blank_skip(dv_model* m, int enabled);
 int dv_model_blank_thresholds(dv_model* m, int n, int32_t* out);
 
+/* dv_model_infer for a caller that KNOWS how many rows of each image are drawn (ABI v8): `rows_used` is a device
+ * array int32[n], and the caller promises that in image i every byte of rows >= rows_used[i] + rows_add is zero --
+ * what dv_encode_batch's `out_rows` (read rows kept) + the reference band height is for the images it has just drawn.
+ * Blank-row skipping then takes its thresholds from the array instead of scanning the images (0.2 ms per 8 K
+ * ILLUMINA30 pileups).  NULL = dv_model_infer.  A wrong promise gives wrong probabilities; callers that read images
+ * from files (call_variants) use dv_model_infer.  The reference has no counterpart. */
+int dv_model_infer_rows(dv_model* m, const uint8_t* images, int n, float* probs, const int32_t* rows_used,
+                        int rows_add, void* stream);
+
 /* On a non-default stream the forward is captured once per (n, stream) into a hipGraph and
  * replayed; the image / probability pointers are read from a device-side table, so they may
  * change from call to call without a new capture.  Testing hook: captures and replays so far. */

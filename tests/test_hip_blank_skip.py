@@ -85,6 +85,12 @@ def test_blank_skip_is_bit_identical(shape):
   # are not even copied there, StemAArgs::blank_need.)
   np.testing.assert_array_equal(skip.debug_tensor(-2, n), dense.debug_tensor(-2, n))
   np.testing.assert_array_equal(got, want)
+  # dv_model_infer_rows: the caller states the rows used (exactly, or generously) instead of the scan
+  exact = torch.from_numpy(thr[0].copy()).cuda()
+  np.testing.assert_array_equal(skip(xd, rows_used=exact).cpu().numpy(), want)
+  np.testing.assert_array_equal(skip.blank_thresholds(n), thr)
+  np.testing.assert_array_equal(skip(xd, rows_used=torch.clamp(exact - 3, min=0), rows_add=5).cpu().numpy(), want)
+  np.testing.assert_array_equal(skip(xd).cpu().numpy(), want)          # and the scan again, through the same graph
   # the run-time switch on ONE model: dense, then skipping again -- the same bits every time
   skip.set_blank_skip(False)
   np.testing.assert_array_equal(skip(xd).cpu().numpy(), want)
