@@ -62,6 +62,11 @@ def parse_args():
                   help='examples (of another synthetic seed) dv_model_calibrate sees before the timed region; 0 = off')
   ap.add_argument('--no-workloads', action='store_true',
                   help='skip the hifi35 / ont50 lines the default 1-GPU run attaches as "workloads"')
+  ap.add_argument('--no-dense', action='store_true',
+                  help='skip the second timing with blank-row skipping off (value_dense): profiler runs use it so that '
+                       'their per-kernel statistics describe one configuration')
+  ap.add_argument('--dense-only', action='store_true',
+                  help='blank-row skipping off for the whole run (profiler runs of the dense configuration)')
   ap.add_argument('--parity-sites', type=int, default=4096,
                   help='sites of the timed batch checked against the oracle after the timed region')
   ap.add_argument('--cpu-sample', type=int, default=0,
@@ -209,6 +214,8 @@ def run_rank(args, rank, local_rank, world):
                       device=local_rank)
   model.init_random(seed=1234)          # same weights on every rank
   calibration = calibrate_model(model, args)
+  if args.dense_only:
+    model.set_blank_skip(False)
   images = torch.empty((n_items, H, W, C), dtype=torch.uint8, device=dev)
   rows = torch.empty(n_items, dtype=torch.int32, device=dev)
   ids = (torch.arange(n_items, device=dev, dtype=torch.int64) +
@@ -270,7 +277,7 @@ def run_rank(args, rank, local_rank, world):
   # bit): `value_dense` / `roofline.dense`, so that the headline can be read with and without the data-dependent part
   thr = model.blank_thresholds(n_items) if n_items <= model.max_batch else None
   dense = None
-  if thr is not None:
+  if thr is not None and not args.no_dense:
     model.set_blank_skip(False)
     elapsed_d, probs_d = timed_steps(step, sync_all, min(args.warmup, 2), args.steps)
     assert torch.equal(probs_d, probs), 'blank-row skipping changed a probability'
@@ -819,6 +826,8 @@ def longread_bench(args, dev, local_rank, emit=True):
   model = InceptionV3((H, W, Ct), max_batch=n, device=local_rank)
   model.init_random(seed=1234)
   calibration = calibrate_model(model, args)
+  if args.dense_only:
+    model.set_blank_skip(False)
   flat = torch.zeros(n_images * img_bytes, dtype=torch.uint8, device=dev)
   images = flat[:n * img_bytes].view(n, H, W, Ct)
   rows = torch.empty(n_images, dtype=torch.int32, device=dev)
@@ -849,7 +858,7 @@ def longread_bench(args, dev, local_rank, emit=True):
   assert torch.isfinite(probs).all()
   thr = model.blank_thresholds(n)
   dense = None
-  if thr is not None:      # the same K steps with blank-row skipping off (identical probabilities)
+  if thr is not None and not args.no_dense:      # the same K steps with blank-row skipping off (identical probabilities)
     model.set_blank_skip(False)
     elapsed_d, probs_d = timed_steps(step, sync_all, min(args.warmup, 2), args.steps)
     assert torch.equal(probs_d, probs), 'blank-row skipping changed a probability'
@@ -1026,7 +1035,7 @@ def executed_conv_flops(model, shape, thr, nominal_flops_per_item):
   mac1, mac2, mac3 = 9 * c * 32, 9 * 32 * 32, 9 * 32 * 64
   mac1x1, mac4 = 64 * 80, 9 * 80 * 192
   skipped = {}
-  if c <= 8:      # fused stem_a: conv2 tiles of 7 rows; conv1 rows that only skipped tiles read
+  if c <= 12 and os.environ.get('DV_NO_STEM_A_WIDE') is None or c <= 8:      # fused stem_a: conv2 tiles of 7 rows; conv1 rows that only skipped tiles read
     rows2 = np.minimum(oh2, 7 * ((np.minimum(t2, oh2) + 6) // 7))
     rows1 = np.where(rows2 > 0, np.minimum(oh1, rows2 + 2), 0)
     skipped['stem_a'] = float(((oh2 - rows2) * ow2 * mac2 + (oh1 - rows1) * ow1 * mac1).sum())
@@ -1110,7 +1119,7 @@ def _pmc_pass(counter, args, timeout_s=300):
   try:
     env = dict(os.environ, TMPDIR='/tmp', DV_BENCH_NO_PMC='1')
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '--', sys.executable,
-           os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-workloads',
+           os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-workloads', '--no-dense',
            '--calibration-images', '0', '--batch', str(args.batch), '--channels', str(args.channels)]
     subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
