@@ -317,8 +317,9 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
         const float16_t a = acc[2 * half + nbl][pt];
         const int slot = (wave * PT + pt) * 32 + (lane & 31);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {   // idle slots too: never read
-          *reinterpret_cast<float4*>(tile + ((nbl * 4 + q) * 256 + slot) * 8 + 4 * hi) =
+        for (int q = 0; q < 4; ++q) {   // idle slots too: never read.  [subtile][group q][half hi][slot][4 floats]: a half-
+          // wave's 16-byte stores are consecutive (the [slot][8 floats] image cost 4-way bank conflicts)
+          reinterpret_cast<float4*>(tile)[((nbl * 4 + q) * 2 + hi) * 256 + slot] =
               make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
         }
       }
@@ -336,7 +337,7 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
       for (int q8 = 0; q8 < 4; ++q8) {
         const int group = cbase / 8 + q8;
         if (group * 8 >= b.Cout) break;
-        const float* src = tile + ((nbl * 4 + q8) * 256 + map0) * 8;
+        const float4* src = reinterpret_cast<const float4*>(tile) + (nbl * 4 + q8) * 2 * 256 + map0;
         float col[3][8];
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -347,8 +348,8 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
           for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
             const bool ok = cx && yy >= 0 && yy < H;
-            const float4* s4 = reinterpret_cast<const float4*>(src + (ok ? yy * W + xx : pix) * 8);
-            const float4 lo = s4[0], up = s4[1];
+            const int at = ok ? yy * W + xx : pix;
+            const float4 lo = src[at], up = src[256 + at];
             r[dy][0] = ok ? lo.x : 0.f; r[dy][1] = ok ? lo.y : 0.f; r[dy][2] = ok ? lo.z : 0.f; r[dy][3] = ok ? lo.w : 0.f;
             r[dy][4] = ok ? up.x : 0.f; r[dy][5] = ok ? up.y : 0.f; r[dy][6] = ok ? up.z : 0.f; r[dy][7] = ok ? up.w : 0.f;
           }

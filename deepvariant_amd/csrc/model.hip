@@ -2233,6 +2233,9 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
     }
     return;
   }
+  // (Round 6, measured and removed: <4,4> -- 128 pixels x 128 couts per wave, 16 accumulators in AGPRs, one workgroup
+  // per CU, half the weight-slab bytes per MFMA: 17x17 heads 455 -> 490 us, 524 -> 568; 35x35 heads 449 -> 528; the
+  // step 465.6 -> 449.1 K candidates/s with the pools unfused on both sides.  profiles/r06_experiments.txt.)
   static const int force_pt = getenv("DV_CONV_PT") ? atoi(getenv("DV_CONV_PT")) : 0;  // tuning knob
   // Four pixel tiles per wave where the accumulators still leave two blocks per CU and
   // K is long enough to amortise the wider prologue: measured -6 % on the 32-cout stem

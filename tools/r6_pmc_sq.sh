@@ -19,5 +19,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
   python $R/profiles/summarize_pmc.py $(find $O/pmc$i -name '*.db' | head -1) >> $O/pmc_sq$SUF.raw 2>&1
   rm -rf $O/pmc$i
 done
-python $R/tools/r5_pmc_table.py $O/pmc_sq$SUF.raw > $O/pmc_sq$SUF.txt
+OT=$O/op_trace_raw.txt; [ "$W" != illumina30 ] && OT=$O/op_trace_$W.txt
+python $R/tools/r6_pmc_table.py $O/pmc_sq$SUF.raw $OT > $O/pmc_sq$SUF.txt
 cat $O/pmc_sq$SUF.txt
