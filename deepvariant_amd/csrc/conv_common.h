@@ -338,23 +338,42 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
         const int group = cbase / 8 + q8;
         if (group * 8 >= b.Cout) break;
         const float4* src = reinterpret_cast<const float4*>(tile) + (nbl * 4 + q8) * 2 * 256 + map0;
-        float col[3][8];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = x + dx - 1;
-          const bool cx = xx >= 0 && xx < W;
+        // Separable: every thread sums ITS column (rows y-1 .. y+1 of column x: three reads) and takes the two
+        // neighbouring columns' sums from lanes -1 / +1 (v_mov_dpp wave_shr / wave_shl: no LDS) -- consecutive slots of a
+        // map are consecutive columns of a row.  The first and last lane of a wave fetch the column their missing
+        // neighbour would have summed themselves (two active lanes: no LDS bandwidth to speak of).  Round 6: a third of
+        // the LDS reads of the nine-point form, whose 72 ds_read_b128 per thread and pooled subtile made the pooling
+        // epilogue LDS-bound (profiles/r06_experiments.txt).  Same sums in the same order as avgpool3s1_kernel.
+        auto column = [&](int xc, bool wanted, float (&v)[8]) {
           float r[3][8];
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
-            const bool ok = cx && yy >= 0 && yy < H;
-            const int at = ok ? yy * W + xx : pix;
-            const float4 lo = src[at], up = src[256 + at];
-            r[dy][0] = ok ? lo.x : 0.f; r[dy][1] = ok ? lo.y : 0.f; r[dy][2] = ok ? lo.z : 0.f; r[dy][3] = ok ? lo.w : 0.f;
-            r[dy][4] = ok ? up.x : 0.f; r[dy][5] = ok ? up.y : 0.f; r[dy][6] = ok ? up.z : 0.f; r[dy][7] = ok ? up.w : 0.f;
+            const bool ok = wanted && yy >= 0 && yy < H;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), up = lo;
+            if (ok) {
+              lo = src[yy * W + xc];
+              up = src[256 + yy * W + xc];
+            }
+            r[dy][0] = lo.x; r[dy][1] = lo.y; r[dy][2] = lo.z; r[dy][3] = lo.w;
+            r[dy][4] = up.x; r[dy][5] = up.y; r[dy][6] = up.z; r[dy][7] = up.w;
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) col[dx][j] = r[0][j] + r[1][j] + r[2][j];
+          for (int j = 0; j < 8; ++j) v[j] = r[0][j] + r[1][j] + r[2][j];
+        };
+        float col[3][8];
+        column(x, true, col[1]);
+        const bool first = lane == 0, last = lane == 63;
+        const int xe = first ? x - 1 : x + 1;
+        float edge[8];
+        column(xe, (first || last) && xe >= 0 && xe < W, edge);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int vi = __builtin_bit_cast(int, col[1][j]);
+          const float from_left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x138, 0xf, 0xf, false));   // wave_shr:1
+          const float from_right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x130, 0xf, 0xf, false));  // wave_shl:1
+          col[0][j] = x == 0 ? 0.f : first ? edge[j] : from_left;
+          col[2][j] = x == W - 1 ? 0.f : last ? edge[j] : from_right;
         }
         float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (b.shift != nullptr) {

@@ -27,7 +27,7 @@ SHAPES = {'illumina': (100, 221, 7), 'hifi': (100, 147, 10), 'ont': (100, 199, 9
 def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   from deepvariant_amd.inception_v3 import InceptionV3
   env = {'split': {'DV_SPLIT_DEFAULT': '1'}, 'none': {'DV_SPLIT_FROM': '94'}, 'cal': {'DV_SPLIT_FROM': '94'},
-         'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'}, 'product': {}}[setting]
+         'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'}}.get(setting, {})
   os.environ.update(env)
   try:
     m = InceptionV3(shape, max_batch=max_batch)
@@ -35,8 +35,8 @@ def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
     for k in env:
       os.environ.pop(k, None)
   m.load_flat_weights(weights)
-  if setting == 'product':          # round 6: the checkpoint's fixed calibration set
-    m.calibrate_for_checkpoint(256)
+  if setting.startswith('product'):          # round 6: the checkpoint's fixed calibration set ('product1024': 1,024 images of it)
+    m.calibrate_for_checkpoint(int(setting[7:] or 256))
   elif setting.startswith('cal'):
     m.calibrate(cal)
   return m
