@@ -396,7 +396,7 @@ def run_rank(args, rank, local_rank, world):
         out['workloads'][w] = {k: full[k] for k in ('metric', 'value', 'value_dense', 'unit', 'ms_per_step',
                                                     'ms_per_step_dense', 'config', 'roofline', 'roofline_encoder',
                                                     'other_kernels_ms_per_step', 'calibration', 'blank_row_skipping',
-                                                    'parity') if k in full}
+                                                    'parity', 'precise', 'fast') if k in full}
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
@@ -923,6 +923,11 @@ def longread_bench(args, dev, local_rank, emit=True):
       'other_kernels_ms_per_step': other_ms / args.steps,
   }
   out['calibration'] = calibration
+  out['precise'] = bool(model.precise)
+  out['config']['classifier_mode'] = (
+      'precise (the default for inputs of more than 8 channels): every fp16 tensor of the 17x17 and 8x8 stages as hi + lo '
+      'pieces, their consumers at twice the K -- what holds 1e-3 on every held-out weight seed; `fast` below = DV_PRECISE=0'
+      if model.precise else 'fast (DV_PRECISE=0): fp16 activations everywhere')
   if dense is not None:
     elapsed_d, conv_ms_d = dense
     dense_tflops = conv_flops * n * args.steps / (conv_ms_d * 1e-3) / 1e12 if conv_ms_d > 0 else 0.0
@@ -934,6 +939,35 @@ def longread_bench(args, dev, local_rank, emit=True):
   if not args.no_cpu_baseline:
     out['parity'] = longread_parity(opts, batch, n, with_alt, Ct, c_enc, model, images, probs)
     out['parity'].update(cnn_tail_parity(model, Ct, images, probs))
+  if model.precise and not args.no_dense:
+    # the same steps in fast mode (DV_PRECISE=0: fp16 activations everywhere) on a second model of the same weights
+    flat_weights = model.flat_weights
+    del model
+    torch.cuda.empty_cache()
+    old = os.environ.get('DV_PRECISE')
+    os.environ['DV_PRECISE'] = '0'
+    try:
+      model = InceptionV3((H, W, Ct), max_batch=n, device=local_rank)
+    finally:
+      if old is None:
+        os.environ.pop('DV_PRECISE', None)
+      else:
+        os.environ['DV_PRECISE'] = old
+    model.load_flat_weights(flat_weights)
+    calibrate_model(model, args)
+    elapsed_f, probs_f = timed_steps(step, sync_all, min(args.warmup, 2), args.steps)
+    lib.dv_set_profiling(1)
+    for _ in range(args.steps):
+      step()
+    sync_all()
+    lib.dv_profile_ms(0)
+    conv_ms_f = lib.dv_profile_ms(1)
+    lib.dv_set_profiling(0)
+    fast = {'value': n * args.steps / elapsed_f, 'ms_per_step': 1e3 * elapsed_f / args.steps,
+            'conv_ms_per_step': conv_ms_f / args.steps}
+    if not args.no_cpu_baseline:
+      fast['parity'] = cnn_tail_parity(model, Ct, images, probs_f)
+    out['fast'] = fast
   if emit:
     print(json.dumps(out))
   return out

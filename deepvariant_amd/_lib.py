@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     'dv_downsample_indices', 'dv_validate_batch', 'dv_query_reads', 'dv_crc32c',
     'dv_model_create', 'dv_model_destroy', 'dv_model_num_params', 'dv_model_conv_macs',
     'dv_model_num_layers', 'dv_model_layer_info', 'dv_model_load_weights', 'dv_model_calibrate', 'dv_model_apply_corrections',
-    'dv_model_num_ops', 'dv_model_op_label', 'dv_model_probe_rounding', 'dv_model_set_blank_skip', 'dv_model_blank_thresholds',
+    'dv_model_num_ops', 'dv_model_op_label', 'dv_model_probe_rounding', 'dv_model_set_blank_skip', 'dv_model_blank_thresholds', 'dv_model_is_precise',
     'dv_model_infer', 'dv_model_infer_rows', 'dv_model_graph_stats', 'dv_model_debug_tensor', 'dv_set_profiling', 'dv_profile_ms',
     'dv_last_profile_count',
     'dv_bam_read_region', 'dv_read_table_fill_batch', 'dv_read_table_name',
@@ -295,6 +295,7 @@ def lib():
     l.dv_model_num_ops.argtypes = [C.c_void_p]
     l.dv_model_infer_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     l.dv_model_set_blank_skip.argtypes = [C.c_void_p, C.c_int]
+    l.dv_model_is_precise.argtypes = [C.c_void_p]
     l.dv_model_blank_thresholds.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     l.dv_model_op_label.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     l.dv_model_probe_rounding.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

@@ -39,6 +39,9 @@ struct ConvBranch {
                           // projections awaiting their average pool, the last block's outputs awaiting the global pool:
                           // tensors no MFMA reads are not rounded to fp16 on the way (round 6)
   TensorGeom og;
+  int lo_groups;          // > 0: the output tensor is WIDE (precise mode, model.hip): channel groups [0, lo_groups) hold
+                          // hi = fp16(x), groups [lo_groups, 2 lo_groups) hold lo = fp16(x - hi) -- the consumer's K runs over
+                          // both with the same weights, i.e. it multiplies 22-bit activations at twice the MFMA count
   int out_goff;           // first destination group of this branch
   int Cout;
   int relu;
@@ -208,6 +211,7 @@ __device__ __forceinline__ void epilogue_subtile(const float16_t (&acc)[PT], con
         ((pn[pt] * b.og.groups + b.out_goff) * b.og.hp + poh[pt] + b.og.halo) * b.og.wp +
         pow_[pt] + b.og.halo);
     unsigned pk[4][2];  // [q][dword]: 4 halfs of group q held by this lane
+    unsigned pl[4][2];  // the same for the lo pieces of a wide output
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -216,6 +220,11 @@ __device__ __forceinline__ void epilogue_subtile(const float16_t (&acc)[PT], con
         half2_t h = __builtin_convertvector(v, half2_t);
         if (b.relu) h = __builtin_elementwise_max(h, zero2);
         pk[q][hq] = __builtin_bit_cast(unsigned, h);
+        if (b.lo_groups > 0) {   // wave-uniform
+          const float2_t x = b.relu ? float2_t{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)} : v;
+          const float2_t r = x - __builtin_convertvector(h, float2_t);
+          pl[q][hq] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2_t));
+        }
       }
     }
 #pragma unroll
@@ -233,6 +242,14 @@ __device__ __forceinline__ void epilogue_subtile(const float16_t (&acc)[PT], con
       if (mvalid[pt] && group * 8 < b.Cout) {
 #endif
         outp[obase + static_cast<unsigned>(group) * gstride] = piece;
+      }
+      if (b.lo_groups > 0) {
+        const auto e0 = __builtin_amdgcn_permlane32_swap(pl[2 * t][0], pl[2 * t + 1][0], false, false);
+        const auto e1 = __builtin_amdgcn_permlane32_swap(pl[2 * t][1], pl[2 * t + 1][1], false, false);
+        const uint4_t lo_piece = {e0[0], e1[0], e0[1], e1[1]};
+        if (mvalid[pt] && group * 8 < b.Cout) {
+          outp[obase + static_cast<unsigned>(group + b.lo_groups) * gstride] = lo_piece;
+        }
       }
     }
   }
@@ -395,6 +412,12 @@ __device__ __forceinline__ void conv_epilogue_avg(const float16_t (&acc)[NB][PT]
 #pragma unroll
           for (int j = 0; j < 8; ++j) h[j] = static_cast<_Float16>(o[j]);
           reinterpret_cast<uint4_t*>(b.out)[at] = __builtin_bit_cast(uint4_t, h);
+          if (b.lo_groups > 0) {
+            half8_t l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l[j] = static_cast<_Float16>(o[j] - static_cast<float>(h[j]));
+            reinterpret_cast<uint4_t*>(b.out)[at + static_cast<size_t>(b.lo_groups) * gstride] = __builtin_bit_cast(uint4_t, l);
+          }
         }
       }
     }

@@ -1230,13 +1230,16 @@ struct PoolArgs {
   const float* in32;      // avgpool3s1_kernel: the float32 raw projection
   _Float16* out;
   float* out32;           // avgpool3s1_kernel: non-NULL = the pooled tensor is float32 (the last block's, read by the head)
+  int lo_in_groups;       // maxpool3s2_kernel: > 0 = the input is wide (hi groups, then lo groups: precise mode)
+  int lo_out_groups;      // > 0 = the output tensor is wide: the lo pieces go lo_out_groups channel groups further
   TensorGeom ig, og;
   int N, C, OH, OW;
   int out_goff;
   const float* shift;  // avgpool only: per-channel shift + ReLU after the average, or NULL
 };
 
-// MaxPooling2D(3, strides=2, 'valid'), C8 layout; one thread = one 16-byte piece.
+// MaxPooling2D(3, strides=2, 'valid'), C8 layout; one thread = one 16-byte piece.  Wide tensors (precise mode): the
+// maximum of hi + lo is the lexicographic maximum of (hi, lo) -- |lo| is at most half an ulp of hi.
 __global__ void maxpool3s2_kernel(PoolArgs p) {
   const int cg = p.C / 8;
   const size_t total = static_cast<size_t>(p.N) * cg * p.OH * p.OW;
@@ -1248,20 +1251,37 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
   t /= p.OH;
   const int g = t % cg;
   const int n = t / cg;
-  const half8_t* src = reinterpret_cast<const half8_t*>(p.in) +
-                       (static_cast<size_t>(n) * p.ig.groups + g) * p.ig.hp * p.ig.wp;
-  half8_t best;
+  const size_t plane = static_cast<size_t>(p.ig.hp) * p.ig.wp;
+  const half8_t* src = reinterpret_cast<const half8_t*>(p.in) + (static_cast<size_t>(n) * p.ig.groups + g) * plane;
+  const half8_t* src_lo = src + static_cast<size_t>(p.lo_in_groups) * plane;
+  half8_t best, best_lo;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) best[j] = static_cast<_Float16>(-65504.f);
+  for (int j = 0; j < 8; ++j) {
+    best[j] = static_cast<_Float16>(-65504.f);
+    best_lo[j] = static_cast<_Float16>(0.f);
+  }
   for (int dh = 0; dh < 3; ++dh)
     for (int dw = 0; dw < 3; ++dw) {
-      const half8_t v = src[(oh * 2 + dh + p.ig.halo) * p.ig.wp + ow * 2 + dw + p.ig.halo];
+      const size_t at = static_cast<size_t>(oh * 2 + dh + p.ig.halo) * p.ig.wp + ow * 2 + dw + p.ig.halo;
+      const half8_t v = src[at];
+      if (p.lo_in_groups > 0) {
+        const half8_t l = src_lo[at];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
+        for (int j = 0; j < 8; ++j) {
+          const bool take = v[j] > best[j] || (v[j] == best[j] && l[j] > best_lo[j]);
+          best[j] = take ? v[j] : best[j];
+          best_lo[j] = take ? l[j] : best_lo[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
+      }
     }
-  reinterpret_cast<half8_t*>(p.out)[((static_cast<size_t>(n) * p.og.groups + p.out_goff + g) *
-                                         p.og.hp + oh + p.og.halo) * p.og.wp + ow + p.og.halo] =
-      best;
+  const size_t oplane = static_cast<size_t>(p.og.hp) * p.og.wp;
+  half8_t* dst = reinterpret_cast<half8_t*>(p.out) + (static_cast<size_t>(n) * p.og.groups + p.out_goff + g) * oplane +
+                 static_cast<size_t>(oh + p.og.halo) * p.og.wp + ow + p.og.halo;
+  *dst = best;
+  if (p.lo_out_groups > 0) dst[static_cast<size_t>(p.lo_out_groups) * oplane] = best_lo;
 }
 
 // AveragePooling2D(3, strides=1, 'same'): divisor = number of valid cells.  The input is the float32 raw
@@ -1329,6 +1349,12 @@ __global__ void avgpool3s1_kernel(PoolArgs p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = static_cast<_Float16>(o[j]);
       reinterpret_cast<half8_t*>(p.out)[at + k] = h;
+      if (p.lo_out_groups > 0) {
+        half8_t l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = static_cast<_Float16>(o[j] - static_cast<float>(h[j]));
+        reinterpret_cast<half8_t*>(p.out)[at + k + static_cast<size_t>(p.lo_out_groups) * p.og.hp * p.og.wp] = l;
+      }
     }
   }
 }
@@ -1398,11 +1424,13 @@ struct BufferDesc {
   bool f32 = false;      // float32 elements (a piece = 8 floats): tensors that no MFMA reads -- the raw 1x1 outputs of
                          // the pooled projections (input of an average pool) and the last block's outputs (input of the
                          // global pool) -- keep the accumulators' values instead of an fp16 rounding of them
+  bool wide = false;     // precise mode (dv_model::precise): the tensor holds c / 8 groups of hi = fp16(x), then c / 8 groups
+                         // of lo = fp16(x - hi); its consumers run their K over both with the same weights
   TensorGeom geom() const {
-    return TensorGeom{h, w, halo, h + 2 * halo, w + 2 * halo, c / 8};
+    return TensorGeom{h, w, halo, h + 2 * halo, w + 2 * halo, (wide ? 2 : 1) * (c / 8)};
   }
   size_t bytes_per_example() const {
-    return static_cast<size_t>(h + 2 * halo) * (w + 2 * halo) * c * (f32 ? 4 : 2);
+    return static_cast<size_t>(h + 2 * halo) * (w + 2 * halo) * c * (f32 ? 4 : wide ? 4 : 2);
   }
 };
 
@@ -1415,7 +1443,8 @@ struct Op {
   // conv
   int layer = -1;
   int kh = 0, kw = 0, stride = 1, pad_h = 0, pad_w = 0;
-  int cin = 0, cin_real = 0, cout = 0;
+  int cin = 0, cin_real = 0, cout = 0;   // cin = K channels of the launch (twice the layer's when the input tensor is wide)
+  bool in_wide = false;          // the input tensor holds hi + lo pieces (BufferDesc::wide): weights duplicated over K
   int ih = 0, iw = 0, oh = 0, ow = 0;
   int nb = 4;
   int n_steps = 0, n_chunks = 0;
@@ -1486,6 +1515,11 @@ struct dv_model {
   dv::DeviceBuffer d_blank_c2;    // conv2's output for the all-blank image
   dv::DeviceBuffer d_blank_b;     // stem_b's (the 1x1 64->80's) output for the all-blank image
   bool blank_on() const { return blank_ready && blank_enabled; }
+  // Precise mode (round 6): every fp16 tensor of the 17x17 and 8x8 stages is stored as hi + lo fp16 pieces
+  // and its consumers multiply both (K doubled, the factorised-7x7 chains run per layer) -- what it takes to hold 1e-3
+  // on every long-read seed, at +45 % of the forward.  Default: on for > 8 input channels (dv_model_create).
+  bool precise = false;
+  bool wide_stage = false;        // build(): buffers created now belong to the wide stages
   bool loaded = false;
   std::vector<float> h_shift, h_dense_b;   // as computed by dv_model_load_weights (before any calibration)
   dv::DeviceBuffer d_ext;         // ExtPtrs: the caller's image / probability pointers of the running forward
@@ -1500,6 +1534,7 @@ struct dv_model {
   // ---- builder ------------------------------------------------------------
   int new_buffer(int h, int w, int c) {
     buffers.push_back({h, w, c, 0});
+    buffers.back().wide = precise && wide_stage;
     return static_cast<int>(buffers.size()) - 1;
   }
   static int pick_nb(int cout) {
@@ -1531,7 +1566,8 @@ struct dv_model {
     op.stride = stride;
     op.pad_h = same ? (kh - 1) / 2 : 0;
     op.pad_w = same ? (kw - 1) / 2 : 0;
-    op.cin = x.c;
+    op.in_wide = buffers[x.buf].wide;
+    op.cin = x.c * (op.in_wide ? 2 : 1);
     op.cin_real = cin_real < 0 ? x.c : cin_real;
     op.cout = cout;
     op.ih = x.h;
@@ -1546,7 +1582,7 @@ struct dv_model {
     op.out_buf = dst_buf;
     op.out_coff = dst_coff;
     op.nb = pick_nb(cout);
-    op.n_chunks = kh * kw * (x.c / kChunk);
+    op.n_chunks = kh * kw * (op.cin / kChunk);
     op.n_steps = (op.n_chunks + kSlabChunks - 1) / kSlabChunks;  // weight slabs
     op.shift_off = shift_floats;
     shift_floats += cout + 128;  // padded: the epilogue reads whole 32-cout tiles
@@ -1580,6 +1616,7 @@ struct dv_model {
     TensorRef raw = conv(x, cout, 1, 1);
     ops.back().raw = true;                   // no shift, no ReLU in the conv epilogue
     buffers[raw.buf].f32 = true;             // averaged in float32 (conv_epilogue_avg / avgpool3s1_kernel)
+    buffers[raw.buf].wide = false;
     const size_t shift_off = ops.back().shift_off;
     pool(kOpAvgPool, raw, dst_buf, dst_coff);
     ops.back().shift_off = shift_off;        // applied after the pool
@@ -2086,6 +2123,7 @@ struct dv_model {
       pool(kOpMaxPool, x, out, 480);
       x = full(out);
     }
+    wide_stage = true;   // precise mode: the tensors created from here on (17x17 and 8x8 stages) are hi + lo
     for (int c7 : {128, 160, 160, 192}) {  // mixed4..7
       const int out = new_buffer(x.h, x.w, 768);
       conv(x, 192, 1, 1, 1, true, out, 0);
@@ -2127,6 +2165,7 @@ struct dv_model {
     }
     feat_buf = x.buf;
     buffers[feat_buf].f32 = true;            // the global pool reads float32
+    buffers[feat_buf].wide = false;
     feat_p = x.h * x.w;
     feat_c = x.c;
     group_siblings();
@@ -2643,7 +2682,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                              std::to_string(op.stride) + " " + std::to_string(op.cin) + "->";
       for (int gi = 0; gi <= op.group_followers; ++gi) {
         const Op& bo = m->ops[oi + gi];
-        tr_flops += 2.0 * n * op.oh * op.ow * op.kh * op.kw * op.cin * bo.cout;
+        tr_flops += 2.0 * n * op.oh * op.ow * op.kh * op.kw * op.cin_real * bo.cout;
         tr_bytes += 2.0 * n * op.oh * op.ow * bo.cout;
         tr_label += (gi ? "+" : "") + std::to_string(bo.cout);
         const BufferDesc& bob = m->buffers[bo.out_buf];
@@ -2656,6 +2695,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                       : 0);
         br.out32 = bob.f32 ? static_cast<float*>(m->dbuf[bo.out_buf].ptr) : nullptr;   // (never the stem's shifted buffer)
         br.og = bob.geom();
+        br.lo_groups = bob.wide ? bob.c / 8 : 0;
         br.out_goff = bo.out_coff / 8;
         br.Cout = bo.cout;
         br.relu = bo.raw ? 0 : 1;
@@ -2671,6 +2711,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
                    (pl.out_buf == shifted_buf ? static_cast<size_t>(out_example_off) * pb.bytes_per_example() / 2 : 0);
           br.out32 = pb.f32 ? static_cast<float*>(m->dbuf[pl.out_buf].ptr) : nullptr;
           br.og = pb.geom();
+          br.lo_groups = pb.wide ? pb.c / 8 : 0;
           br.out_goff = pl.out_coff / 8;
           a.tile_g = op.avg_tile_g;
           a.tile_p = op.oh * op.ow;
@@ -2699,6 +2740,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
                   " tiles" + std::to_string(tiles);
       if (op.pool_in) tr_label += " <- maxpool3s2";
+      if (op.in_wide) tr_label += " [hi+lo input: K x2]";
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
       if (op.split) tr_label += " [split W: " + std::to_string(op.split_tiles) + " of " + std::to_string(tiles) + " tiles]";
@@ -2781,6 +2823,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       p.in32 = static_cast<const float*>(m->dbuf[op.in_buf].ptr);
       p.out = static_cast<_Float16*>(m->dbuf[op.out_buf].ptr) + out_shift_halfs;
       p.out32 = ob.f32 ? static_cast<float*>(m->dbuf[op.out_buf].ptr) : nullptr;
+      p.lo_in_groups = m->buffers[op.in_buf].wide ? m->buffers[op.in_buf].c / 8 : 0;
+      p.lo_out_groups = ob.wide ? ob.c / 8 : 0;
       p.ig = m->buffers[op.in_buf].geom();
       p.og = ob.geom();
       p.N = n;
@@ -2835,6 +2879,10 @@ int dv_model_create(const dv_model_desc* desc, int device, dv_model** out) {
   std::unique_ptr<dv_model> m(new dv_model());
   m->device = device;
   m->desc = *desc;
+  // Precise mode: on by default for inputs of more than 8 channels (the long-read models, whose deeper pile-ups do not
+  // hold 1e-3 on every weight seed with fp16 activations: DESIGN.md 6), off for the short-read shapes; DV_PRECISE=0 / 1
+  // overrides either way.
+  m->precise = getenv("DV_PRECISE") != nullptr ? atoi(getenv("DV_PRECISE")) != 0 : desc->channels > 8;
   m->build();
   m->stem_a_grid = dv::stem_a_blocks(device);
   m->stem_b_grid = dv::stem_b_blocks(device);
@@ -3130,7 +3178,8 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         _Float16* chunk = packed.data() + op.w_off +
                           ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn * kChunk;
         for (int jj = 0; jj < kChunk; ++jj) {
-          const int ci = cc * kChunk + jj;
+          int ci = cc * kChunk + jj;
+          if (op.in_wide) ci = ci >= l.cin ? ci - l.cin : ci;   // the lo half of a wide input meets the same weights
           if (ci >= l.cin) continue;  // padded input channels
           const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co] * inv[co];
           const _Float16 hi = static_cast<_Float16>(v);
@@ -3194,7 +3243,7 @@ static dv::CalibPlan calib_plan_of(const dv_model* m) {
       c.raw = op.raw;
       c.shift_off = static_cast<int64_t>(op.shift_off);
       c.split = op.split_rows;
-      c.keep_f32 = m->buffers[op.out_buf].f32 ? 1 : 0;
+      c.keep_f32 = m->buffers[op.out_buf].f32 || m->buffers[op.out_buf].wide ? 1 : 0;
       if (op.pool_in) {   // op.ih / op.iw: the tensor as stored, before the on-the-fly pool
         plan.bufs[op.in_buf].h = op.ih;
         plan.bufs[op.in_buf].w = op.iw;
@@ -3207,7 +3256,7 @@ static dv::CalibPlan calib_plan_of(const dv_model* m) {
       c.shift_relu = op.pool_shift_relu;
       if (op.pool_shift_relu) c.shift_off = static_cast<int64_t>(op.shift_off);
       c.cout = op.cout;
-      c.keep_f32 = m->buffers[op.out_buf].f32 ? 1 : 0;
+      c.keep_f32 = m->buffers[op.out_buf].f32 || m->buffers[op.out_buf].wide ? 1 : 0;
     } else {
       c.cout = op.cout;
     }
@@ -3374,6 +3423,17 @@ int dv_model_debug_tensor(dv_model* m, int index, int n, void* host_out, int32_t
       DV_HIP_CHECK(hipMemcpy(tmp.data(), m->dbuf[index].ptr, tmp.size() * 4, hipMemcpyDeviceToHost));
       _Float16* dst = static_cast<_Float16*>(host_out);
       for (size_t i = 0; i < tmp.size(); ++i) dst[i] = static_cast<_Float16>(tmp[i]);
+    } else if (b.wide) {   // wide tensors (precise mode) leave as hi + lo, rounded to the fp16 the hook's contract promises
+      const size_t half_halfs = b.bytes_per_example() / 4;   // fp16 numbers of the hi (= of the lo) part of one example
+      std::vector<_Float16> tmp(static_cast<size_t>(n) * half_halfs * 2);
+      DV_HIP_CHECK(hipMemcpy(tmp.data(), m->dbuf[index].ptr, tmp.size() * 2, hipMemcpyDeviceToHost));
+      _Float16* dst = static_cast<_Float16*>(host_out);
+      for (int e = 0; e < n; ++e)
+        for (size_t i = 0; i < half_halfs; ++i) {
+          dst[static_cast<size_t>(e) * half_halfs + i] = static_cast<_Float16>(
+              static_cast<float>(tmp[static_cast<size_t>(e) * 2 * half_halfs + i]) +
+              static_cast<float>(tmp[static_cast<size_t>(e) * 2 * half_halfs + half_halfs + i]));
+        }
     } else {
       DV_HIP_CHECK(hipMemcpy(host_out, m->dbuf[index].ptr,
                              static_cast<size_t>(n) * b.bytes_per_example(),
@@ -3501,6 +3561,9 @@ int dv_model_infer_rows(dv_model* m, const uint8_t* images, int n, float* probs,
   DV_HIP_CHECK(hipGraphLaunch(e.exec, stream));
   return DV_OK;
 }
+
+// 1 when the model runs in precise mode (include/dvhip.h).
+int dv_model_is_precise(const dv_model* m) { return m && m->precise ? 1 : 0; }
 
 // Blank-row skipping on / off at run time (include/dvhip.h): bench.py times the dense path on the same model.
 int dv_model_set_blank_skip(dv_model* m, int enabled) {

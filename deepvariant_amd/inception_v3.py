@@ -33,6 +33,9 @@ class InceptionV3(torch.nn.Module):
     _lib.check(_lib.lib().dv_model_create(C.byref(desc), device,
                                           C.byref(self._handle)))
     self.num_params = int(_lib.lib().dv_model_num_params(self._handle))
+    # precise mode (include/dvhip.h dv_model_is_precise): hi + lo activations through the 17x17 and 8x8 stages; the
+    # default for inputs of more than 8 channels, DV_PRECISE=0 / 1 in the environment overrides at construction
+    self.precise = bool(_lib.lib().dv_model_is_precise(self._handle))
     self.flat_weights = None
     self._out_buffers = {}
 

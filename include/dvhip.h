@@ -818,6 +818,16 @@ int dv_model_infer(dv_model* m, const uint8_t* images, int n, float* probs,
  * k = 0 first all-zero row, 1..4 the first blank-determined row of conv2 / stem_b / the 3x3 80->192 / its pooled
  * output (bench.py derives the executed FLOPs from them); DV_ERR_UNSUPPORTED when the model does not skip. */
 int dv_model_set_blank_skip(dv_model* m, int enabled);
+
+/* Precise mode (ABI v8).  The reference classifies in float32 (deepvariant/call_variants.py:913-918); with fp16 MFMA
+ * operands the zero-mean rounding noise of the stored activations puts sigma(dp) of the long-read models' deeper pile-ups
+ * at ~2.5e-4, and the largest of a few thousand candidates beyond north_star's 1e-3 on some weight seeds.  In precise
+ * mode every fp16 tensor of the 17x17 and 8x8 stages (83 % of that variance; the per-tensor table is
+ * profiles/r06_tensor_budget_*.txt) is stored as hi = fp16(x) and lo = fp16(x - hi), and its consumers run their K over
+ * both with the same weights: 22-bit activations at twice the MFMA count there, +45 % on the forward.  dv_model_create
+ * switches it on for inputs of more than 8 channels (PACBIO, ONT_R104) and off otherwise; the environment variable
+ * DV_PRECISE=0 / 1 read at dv_model_create overrides.  Same ABI, same weights, same outputs to within the tolerance. */
+int dv_model_is_precise(const dv_model* m);
 int dv_model_blank_thresholds(dv_model* m, int n, int32_t* out);
 
 /* dv_model_infer for a caller that KNOWS how many rows of each image are drawn (ABI v8): `rows_used` is a device

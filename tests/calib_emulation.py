@@ -19,8 +19,10 @@ def _folded(cb):
 
 
 class _Walk:
-  def __init__(self, ref, mode_e, ref_means=None):
+  def __init__(self, ref, mode_e, ref_means=None, precise=False):
     self.ref, self.e, self.ref_means = ref, mode_e, ref_means
+    self.precise = precise        # precise mode (> 8 input channels): the 17x17 and 8x8 stages' tensors are hi + lo: not rounded
+    self.wide = False
     self.index = {id(cb): i for i, cb in enumerate(ref.convs)}
     self.means = [None] * len(ref.convs)
     self.corr = [None] * len(ref.convs)
@@ -33,7 +35,7 @@ class _Walk:
     if self.e:
       self.corr[i] = (self.means[i] - self.ref_means[i]).float()
       z = z - self.corr[i][None, :, None, None]
-    return F.relu(z if keep_f32 else self._r(z))
+    return F.relu(z if keep_f32 or self.wide else self._r(z))
 
   def conv(self, cb, x, keep_f32=False):
     w, shift = _folded(cb)
@@ -67,6 +69,7 @@ class _Walk:
       x = torch.cat([self.seq(blk['b1'], x), self.seq(blk['b5'], x), self.seq(blk['b3'], x),
                      self.pooled_projection(blk['bp'][0], x)], 1)
     x = torch.cat([self.seq(ref.mixed3['b3'], x), self.seq(ref.mixed3['b3d'], x), F.max_pool2d(x, 3, stride=2)], 1)
+    self.wide = self.precise
     for blk in ref.mixed_b:
       x = torch.cat([self.seq(blk['b1'], x), self.seq(blk['b7'], x), self.seq(blk['b7d'], x),
                      self.pooled_projection(blk['bp'][0], x)], 1)
@@ -81,12 +84,15 @@ class _Walk:
     return ref.classification(x.mean(dim=(2, 3)))
 
 
-def corrections(ref, images_u8):
-  """-> float32 array: cout corrections per conv layer in layer order, then the 3 logit corrections."""
+def corrections(ref, images_u8, precise=None):
+  """-> float32 array: cout corrections per conv layer in layer order, then the 3 logit corrections.
+  `precise`: the product's precise mode (default: as dv_model_create decides -- more than 8 input channels)."""
+  if precise is None:
+    precise = images_u8.shape[-1] > 8
   with torch.no_grad():
     r = _Walk(ref, False)
     lr = r.logits(images_u8)
-    e = _Walk(ref, True, r.means)
+    e = _Walk(ref, True, r.means, precise=precise)
     le = e.logits(images_u8)
     dl = (le.double().mean(0) - lr.double().mean(0)).float()
   return np.concatenate([c.numpy() for c in e.corr] + [dl.numpy()])

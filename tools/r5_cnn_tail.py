@@ -27,7 +27,8 @@ SHAPES = {'illumina': (100, 221, 7), 'hifi': (100, 147, 10), 'ont': (100, 199, 9
 def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   from deepvariant_amd.inception_v3 import InceptionV3
   env = {'split': {'DV_SPLIT_DEFAULT': '1'}, 'none': {'DV_SPLIT_FROM': '94'}, 'cal': {'DV_SPLIT_FROM': '94'},
-         'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'}}.get(setting, {})
+         'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'},
+         'precise': {'DV_PRECISE': '1'}}.get(setting, {})     # 'precise' (round 6): hi + lo activations through the 17x17 and 8x8 stages
   os.environ.update(env)
   try:
     m = InceptionV3(shape, max_batch=max_batch)
@@ -37,6 +38,8 @@ def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   m.load_flat_weights(weights)
   if setting.startswith('product'):          # round 6: the checkpoint's fixed calibration set ('product1024': 1,024 images of it)
     m.calibrate_for_checkpoint(int(setting[7:] or 256))
+  elif setting == 'precise':
+    m.calibrate_for_checkpoint(256)
   elif setting.startswith('cal'):
     m.calibrate(cal)
   return m
