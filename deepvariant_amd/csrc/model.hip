@@ -1260,23 +1260,32 @@ __global__ void maxpool3s2_kernel(PoolArgs p) {
     best[j] = static_cast<_Float16>(-65504.f);
     best_lo[j] = static_cast<_Float16>(0.f);
   }
-  for (int dh = 0; dh < 3; ++dh)
-    for (int dw = 0; dw < 3; ++dw) {
-      const size_t at = static_cast<size_t>(oh * 2 + dh + p.ig.halo) * p.ig.wp + ow * 2 + dw + p.ig.halo;
-      const half8_t v = src[at];
-      if (p.lo_in_groups > 0) {
-        const half8_t l = src_lo[at];
+  const size_t at0 = static_cast<size_t>(oh * 2 + p.ig.halo) * p.ig.wp + ow * 2 + p.ig.halo;
+  if (p.lo_in_groups > 0) {   // uniform; all eighteen pieces in flight before the first compare
+    half8_t v[9], l[9];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool take = v[j] > best[j] || (v[j] == best[j] && l[j] > best_lo[j]);
-          best[j] = take ? v[j] : best[j];
-          best_lo[j] = take ? l[j] : best_lo[j];
-        }
-      } else {
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const size_t at = at0 + static_cast<size_t>(t9 / 3) * p.ig.wp + t9 % 3;
+      v[t9] = src[at];
+      l[t9] = src_lo[at];
+    }
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool take = v[t9][j] > best[j] || (v[t9][j] == best[j] && l[t9][j] > best_lo[j]);
+        best[j] = take ? v[t9][j] : best[j];
+        best_lo[j] = take ? l[t9][j] : best_lo[j];
+      }
+    }
+  } else {
+    for (int dh = 0; dh < 3; ++dh)
+      for (int dw = 0; dw < 3; ++dw) {
+        const half8_t v = src[at0 + static_cast<size_t>(dh) * p.ig.wp + dw];
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[j] = v[j] > best[j] ? v[j] : best[j];
       }
-    }
+  }
   const size_t oplane = static_cast<size_t>(p.og.hp) * p.og.wp;
   half8_t* dst = reinterpret_cast<half8_t*>(p.out) + (static_cast<size_t>(n) * p.og.groups + p.out_goff + g) * oplane +
                  static_cast<size_t>(oh + p.og.halo) * p.og.wp + ow + p.og.halo;

@@ -2,7 +2,9 @@
 
   python tools/r5_cnn_tail.py --n 65536 --seeds 101,202,303 --settings split,none,cal,cal+m8 > profiles/r05_cnn_tail.txt
 
-settings: 'split' = round-4 default split weights, 'none' = plain fp16 weights, 'cal' = plain fp16 weights + the
+settings (round 6): 'product' = the product's default for the shape (calibrate_for_checkpoint; precise mode for more than 8
+channels), 'fast' = DV_PRECISE=0 + calibration, 'precise' = DV_PRECISE=1 + calibration, 'none' = plain fp16, uncalibrated.
+Older: 'split' = round-4 default split weights, 'none' = plain fp16 weights, 'cal' = plain fp16 weights + the
 calibrated shift correction (dv_model_calibrate), 'cal+split' = both.  Test infrastructure (tests/cnn_tail.py).
 """
 import argparse
@@ -26,7 +28,8 @@ SHAPES = {'illumina': (100, 221, 7), 'hifi': (100, 147, 10), 'ont': (100, 199, 9
 
 def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   from deepvariant_amd.inception_v3 import InceptionV3
-  env = {'split': {'DV_SPLIT_DEFAULT': '1'}, 'none': {'DV_SPLIT_FROM': '94'}, 'cal': {'DV_SPLIT_FROM': '94'},
+  env = {'split': {'DV_SPLIT_DEFAULT': '1'}, 'none': {'DV_SPLIT_FROM': '94', 'DV_PRECISE': '0'}, 'cal': {'DV_SPLIT_FROM': '94'},
+         'fast': {'DV_PRECISE': '0'},      # round 6: fp16 activations everywhere + the checkpoint calibration (the long-read shapes' opt-out)
          'cal+split': {'DV_SPLIT_DEFAULT': '1'}, 'all': {'DV_SPLIT_FROM': '0'},
          'precise': {'DV_PRECISE': '1'}}.get(setting, {})     # 'precise' (round 6): hi + lo activations through the 17x17 and 8x8 stages
   os.environ.update(env)
@@ -38,7 +41,7 @@ def build(setting, weights, cal, shape=(100, 221, 7), max_batch=8192):
   m.load_flat_weights(weights)
   if setting.startswith('product'):          # round 6: the checkpoint's fixed calibration set ('product1024': 1,024 images of it)
     m.calibrate_for_checkpoint(int(setting[7:] or 256))
-  elif setting == 'precise':
+  elif setting in ('precise', 'fast'):
     m.calibrate_for_checkpoint(256)
   elif setting.startswith('cal'):
     m.calibrate(cal)
