@@ -119,6 +119,12 @@ struct ConvArgs {
   // the raw tensor and the avg-pool launch disappear.  grid = ceil(N / tile_g) * n_tiles.
   int tile_g, tile_p;
   float rcp_tile_p;
+  // Wide input (precise mode, model.hip BufferDesc::wide): the input tensor holds Cin / 8 groups of hi = fp16(x) and,
+  // lo_off bytes further in every example, Cin / 8 groups of lo = fp16(x - hi).  Every K chunk is multiplied twice --
+  // the same weight fragments against the hi and the lo pixel fragment (conv_slab_wide) -- so the layer sees 22-bit
+  // activations for twice the MFMAs at unchanged weight traffic.  n_chunks counts the layer's own chunks.
+  int wide_in;
+  unsigned lo_off;
 };
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));

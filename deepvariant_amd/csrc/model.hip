@@ -204,6 +204,50 @@ __device__ __forceinline__ void conv_slab(const ConvArgs& p, const __amdgpu_buff
   }
 }
 
+// conv_slab for a WIDE input (ConvArgs::wide_in): R K-chunks, each multiplied against the hi and then the lo pixel
+// fragment with the same weight fragments.  The prefetch ring of four fragments holds two chunks' (hi, lo) pairs; the
+// fragment consumed is replaced by the same part of the chunk two further on.  R is even (slabs of 8 or 4 chunks), so the
+// ring position is 0 at every call.
+template <int NB, int PT, int R>
+__device__ __forceinline__ void conv_slab_wide(const ConvArgs& p, const __amdgpu_buffer_rsrc_t rsrc,
+                                               const _Float16* wslab, ChunkWalk& walk, const unsigned (&base)[PT],
+                                               uint4_t (&xf)[prefetch_depth(NB, PT)][PT], float16_t (&acc)[NB][PT]) {
+  constexpr int BN = NB * 32;
+  static_assert(prefetch_depth(NB, PT) == 4 && R % 2 == 0, "two (hi, lo) pairs in flight");
+  half8_t wf[2][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wf[0][nb] = *reinterpret_cast<const half8_t*>(wslab + (nb * 32) * 8);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (j + 1 < R) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        wf[(j + 1) & 1][nb] = *reinterpret_cast<const half8_t*>(wslab + (j + 1) * BN * kChunk + (nb * 32) * 8);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int slot = (2 * j + part) & 3;
+      half8_t xh[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) xh[pt] = __builtin_bit_cast(half8_t, xf[slot][pt]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j & 1][nb], xh[pt], acc[nb][pt], 0, 0, 0);
+        }
+      }
+      const unsigned soff = walk.off() + (part ? p.lo_off : 0u);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) xf[slot][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
+      if (part) walk.advance(p);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Blank-row skipping (ConvArgs::blank_row): the wave's PT*32 pixels x NB*32 couts copied from the
 // all-blank image's response instead of computed.  Lanes l / l+32 take alternate 8-cout
 // groups; all loads are issued before the first store.
@@ -253,7 +297,7 @@ __device__ __forceinline__ void copy_blank_wave(const ConvArgs& p, int n_tile, c
 //  * Epilogue: shift + ReLU, lanes l / l+32 pair their halves into 16-byte
 //    pieces, stored as contiguous 512-byte runs (no LDS).
 template <int NB, int PT, int MINB = (NB * PT >= 8 ? 1 : 2), int SLAB = kSlabChunks, int WAVES = 4,
-          bool SPLIT = false, bool SIDE_POOL = false, bool AVG = false>
+          bool SPLIT = false, bool SIDE_POOL = false, bool AVG = false, bool WIDE = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   constexpr int kThreads = WAVES * 64;   // (WAVES = 8: tuning experiment DV_CONV_W8, HISTORY.md 7)
@@ -401,13 +445,13 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
   ChunkWalk walk{0, 0, 0u, 0u};
   DV_LOAD_SLAB(0)
 #pragma unroll
-  for (int d = 0; d < kPrefetch; ++d) {  // chunks 0 .. kPrefetch-1
-    const unsigned soff = walk.off();
+  for (int d = 0; d < kPrefetch; ++d) {  // chunks 0 .. kPrefetch-1 (wide input: the (hi, lo) pairs of chunks 0 and 1)
+    const unsigned soff = walk.off() + (WIDE && (d & 1) ? p.lo_off : 0u);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       xf[d][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base[pt], soff, 0);
     }
-    walk.advance(p);
+    if (!WIDE || (d & 1)) walk.advance(p);
   }
   DV_STORE_SLAB(0)
   __syncthreads();
@@ -451,7 +495,11 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
       // were, drains the whole four-chunk prefetch queue at every slab start.
       const int next = s + 1 < tile_slabs ? s + 1 : s;
       DV_LOAD_SLAB(next)
-      conv_slab<NB, PT, SLAB, 0, S, P>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc, sp);
+      if constexpr (WIDE) {
+        conv_slab_wide<NB, PT, SLAB>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc);
+      } else {
+        conv_slab<NB, PT, SLAB, 0, S, P>(p, rsrc, smem + (s & 1) * SLAB_HALFS + frag_off, walk, base, xf, acc, sp);
+      }
       DV_STORE_SLAB((s + 1) & 1)
       __syncthreads();
     }
@@ -463,9 +511,16 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void conv_mfma_kernel(ConvArgs p)
     // made the register allocator clone the accumulators.)
     if (rem) {
       const _Float16* wslab = smem + (n_full & 1) * SLAB_HALFS + frag_off;
+      if constexpr (WIDE) {
+        conv_slab_wide<NB, PT, 4>(p, rsrc, wslab, walk, base, xf, acc);
+        if constexpr (SLAB > 4) {
+          if (rem > 4) conv_slab_wide<NB, PT, 4>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc);
+        }
+      } else {
       conv_slab<NB, PT, 4, 0, S, P>(p, rsrc, wslab, walk, base, xf, acc, sp);
       if constexpr (SLAB > 4) {
         if (rem > 4) conv_slab<NB, PT, 4, 4, S, P>(p, rsrc, wslab + 4 * BN * kChunk, walk, base, xf, acc, sp);
+      }
       }
     }
   };
@@ -1452,8 +1507,9 @@ struct Op {
   // conv
   int layer = -1;
   int kh = 0, kw = 0, stride = 1, pad_h = 0, pad_w = 0;
-  int cin = 0, cin_real = 0, cout = 0;   // cin = K channels of the launch (twice the layer's when the input tensor is wide)
-  bool in_wide = false;          // the input tensor holds hi + lo pieces (BufferDesc::wide): weights duplicated over K
+  int cin = 0, cin_real = 0, cout = 0;
+  bool in_wide = false;          // the input tensor holds hi + lo pieces (BufferDesc::wide): every K chunk is multiplied
+                                 // against both (ConvArgs::wide_in, conv_slab_wide)
   int ih = 0, iw = 0, oh = 0, ow = 0;
   int nb = 4;
   int n_steps = 0, n_chunks = 0;
@@ -1576,7 +1632,7 @@ struct dv_model {
     op.pad_h = same ? (kh - 1) / 2 : 0;
     op.pad_w = same ? (kw - 1) / 2 : 0;
     op.in_wide = buffers[x.buf].wide;
-    op.cin = x.c * (op.in_wide ? 2 : 1);
+    op.cin = x.c;
     op.cin_real = cin_real < 0 ? x.c : cin_real;
     op.cout = cout;
     op.ih = x.h;
@@ -1731,7 +1787,7 @@ struct dv_model {
       const int followers = op.type == kOpConv ? op.group_followers : 0;
       bool f32_out = false;   // float32 outputs go through conv_epilogue only
       for (int gi = 0; gi <= followers; ++gi) f32_out = f32_out || buffers[ops[i + gi].out_buf].f32;
-      if (op.type == kOpConv && !f32_out && !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b &&
+      if (op.type == kOpConv && !f32_out && !op.in_wide && !buffers[op.out_buf].wide && !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b &&
           op.chain_len == 0 && !op.in_chain &&
           !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) && op.stride == 1 &&
           dv::imgconv_supported(op.kh, op.kw, op.nb) && op.oh * op.ow <= 512) {
@@ -1874,7 +1930,7 @@ struct dv_model {
       const int followers = op.group_followers;
       const bool eligible = !op.first_u8 && !op.pool_in && !op.pool_out && !op.stem_a && !op.stem_b && !op.v2 &&
                             op.chain_len == 0 && !op.in_chain && !(i > 0 && (ops[i - 1].stem_a || ops[i - 1].stem_b)) &&
-                            op.nb <= 4 && static_cast<int>(i) != blank_conv4_op;
+                            op.nb <= 4 && static_cast<int>(i) != blank_conv4_op && !op.in_wide;
       int n_wanted = 0;
       for (int gi = 0; gi <= followers; ++gi) n_wanted += wanted(ops[i + gi]) ? 1 : 0;
       if (eligible && n_wanted > 0) {
@@ -1967,7 +2023,7 @@ struct dv_model {
     std::vector<int> readers(buffers.size(), 0);
     for (const Op& o : ops) readers[o.in_buf]++;
     auto plain = [&](const Op& o) {
-      return o.type == kOpConv && !buffers[o.out_buf].f32 && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
+      return o.type == kOpConv && !buffers[o.out_buf].f32 && !o.in_wide && !buffers[o.out_buf].wide && o.stride == 1 && (o.kh & 1) && (o.kw & 1) && o.kh * o.kw > 1 &&
              o.pad_h == (o.kh - 1) / 2 && o.pad_w == (o.kw - 1) / 2 && o.group_followers == 0 &&
              !o.first_u8 && !o.pool_in && !o.pool_out && !o.raw && !o.stem_a && !o.stem_b && o.cin % kChunk == 0 &&
              o.cin == o.cin_real && o.oh == o.ih && o.ow == o.iw;
@@ -2236,6 +2292,11 @@ void launch_conv6(const ConvArgs& a, hipStream_t stream) {
   const long row_px = a.band ? static_cast<long>(a.N) * a.OW : a.M;
   const long blocks = rows * ((row_px + 127) / 128) * a.n_tiles;
   constexpr size_t lds = static_cast<size_t>(2) * 4 * 192 * kChunk * 2;
+  if (a.wide_in) {
+    hipLaunchKernelGGL((conv_mfma_kernel<6, 1, 2, 4, 4, false, false, false, true>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kConvThreads), lds, stream, a);
+    return;
+  }
   hipLaunchKernelGGL((conv_mfma_kernel<6, 1, 2, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kConvThreads), lds,
                      stream, a);
 }
@@ -2258,6 +2319,26 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
       } else {
         hipLaunchKernelGGL((conv_mfma_kernel<NB, 1, 2, kSlabChunks, 4, false, true>), dim3(static_cast<unsigned>(blocks(128))),
                            dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+      }
+      return;
+    }
+  }
+  if (a.wide_in) {   // precise mode: hi + lo pixel fragments per K chunk (conv_slab_wide); the two usual tile shapes
+    if constexpr (NB >= 2 && NB <= 4) {
+      if constexpr (NB == 4) {
+        if (a.tile_g > 0) {
+          const long tiles = (static_cast<long>(a.N) + a.tile_g - 1) / a.tile_g * n_tiles;
+          hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2, kSlabChunks, 4, false, false, true, true>),
+                             dim3(static_cast<unsigned>(tiles)), dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+          return;
+        }
+      }
+      if (blocks2 >= 512) {
+        hipLaunchKernelGGL((conv_mfma_kernel<NB, 2, 2, kSlabChunks, 4, false, false, false, true>),
+                           dim3(static_cast<unsigned>(blocks2)), dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
+      } else {
+        hipLaunchKernelGGL((conv_mfma_kernel<NB, 1, 2, kSlabChunks, 4, false, false, false, true>),
+                           dim3(static_cast<unsigned>(blocks(128))), dim3(kConvThreads), conv_lds_bytes<NB>(), stream, a);
       }
       return;
     }
@@ -2381,7 +2462,7 @@ void dump_trace(hipStream_t stream) {
 bool resident_ok(const dv_model* m, const Op& op, const ConvArgs& a) {
   const char* env = getenv("DV_RESIDENT");   // read per launch set-up (tests toggle it between models)
   const int mode = env ? atoi(env) : 1;
-  if (mode == 0 || op.nb != 3 || op.band || op.v2 || op.pool_in || op.split || a.blank_row != nullptr) return false;
+  if (mode == 0 || op.nb != 3 || op.band || op.v2 || op.pool_in || op.split || a.blank_row != nullptr || a.wide_in) return false;
   const size_t lds = static_cast<size_t>(a.n_slabs) * kSlabChunks * 3 * 32 * kChunk * 2;
   if (lds > 150 * 1024 || m->n_cus < 8 * a.n_tiles) return false;
   static const long min_tiles = getenv("DV_RESIDENT_MIN_TILES") ? atol(getenv("DV_RESIDENT_MIN_TILES")) : 4;   // tuning knob
@@ -2679,6 +2760,8 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       a.n_slabs = op.n_steps;
       a.split = op.split ? 1 : 0;
       a.split_tiles = op.split_tiles;
+      a.wide_in = op.in_wide ? 1 : 0;
+      a.lo_off = op.in_wide ? static_cast<unsigned>(ib.c / 8) * static_cast<unsigned>(a.ig.hp * a.ig.wp) * 16u : 0u;
       a.in_bytes = static_cast<size_t>(n) * ib.bytes_per_example();
       a.img_bytes = static_cast<unsigned>(ib.bytes_per_example());
       a.rcp_ow = 1.0f / static_cast<float>(op.ow);
@@ -2749,7 +2832,7 @@ int run_ops(dv_model* m, int first, int last, int n, hipStream_t stream,
       tr_label += " @" + std::to_string(op.oh) + "x" + std::to_string(op.ow) + " nb" + std::to_string(op.nb) +
                   " tiles" + std::to_string(tiles);
       if (op.pool_in) tr_label += " <- maxpool3s2";
-      if (op.in_wide) tr_label += " [hi+lo input: K x2]";
+      if (op.in_wide) tr_label += " [hi+lo input: 2 MFMAs per weight fragment]";
       if (op.v2) tr_label += " [imgconv G=" + std::to_string(op.v2_g) + "]";
       if (op.band) tr_label += " [band: " + std::to_string(op.band) + " of " + std::to_string(op.kh) + " tap rows]";
       if (op.split) tr_label += " [split W: " + std::to_string(op.split_tiles) + " of " + std::to_string(tiles) + " tiles]";
@@ -3187,8 +3270,7 @@ int dv_model_load_weights(dv_model* m, const float* weights, int64_t n) {
         _Float16* chunk = packed.data() + op.w_off +
                           ((static_cast<size_t>(t) * op.n_steps + sl) * kSlabChunks + j) * bn * kChunk;
         for (int jj = 0; jj < kChunk; ++jj) {
-          int ci = cc * kChunk + jj;
-          if (op.in_wide) ci = ci >= l.cin ? ci - l.cin : ci;   // the lo half of a wide input meets the same weights
+          const int ci = cc * kChunk + jj;
           if (ci >= l.cin) continue;  // padded input channels
           const float v = w[((static_cast<size_t>(kh) * l.kw + kw) * l.cin + ci) * l.cout + co] * inv[co];
           const _Float16 hi = static_cast<_Float16>(v);
