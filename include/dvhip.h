@@ -824,7 +824,7 @@ int dv_model_set_blank_skip(dv_model* m, int enabled);
  * at ~2.5e-4, and the largest of a few thousand candidates beyond north_star's 1e-3 on some weight seeds.  In precise
  * mode every fp16 tensor of the 17x17 and 8x8 stages (83 % of that variance; the per-tensor table is
  * profiles/r06_tensor_budget_*.txt) is stored as hi = fp16(x) and lo = fp16(x - hi), and its consumers run their K over
- * both with the same weights: 22-bit activations at twice the MFMA count there, +45 % on the forward.  dv_model_create
+ * both with the same weights: 22-bit activations at twice the MFMA count there, +40 % on the forward.  dv_model_create
  * switches it on for inputs of more than 8 channels (PACBIO, ONT_R104) and off otherwise; the environment variable
  * DV_PRECISE=0 / 1 read at dv_model_create overrides.  Same ABI, same weights, same outputs to within the tolerance. */
 int dv_model_is_precise(const dv_model* m);
