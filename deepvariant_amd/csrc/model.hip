@@ -1582,7 +1582,7 @@ struct dv_model {
   bool blank_on() const { return blank_ready && blank_enabled; }
   // Precise mode (round 6): every fp16 tensor of the 17x17 and 8x8 stages is stored as hi + lo fp16 pieces
   // and its consumers multiply both (K doubled, the factorised-7x7 chains run per layer) -- what it takes to hold 1e-3
-  // on every long-read seed, at +45 % of the forward.  Default: on for > 8 input channels (dv_model_create).
+  // on every long-read seed, at about +40 % of the forward.  Default: on for > 8 input channels (dv_model_create).
   bool precise = false;
   bool wide_stage = false;        // build(): buffers created now belong to the wide stages
   bool loaded = false;
