@@ -65,15 +65,22 @@ for k in order:
       ratio(d, 'SQ_ACTIVE_INST_LDS', 'SQ_WAVE_CYCLES'), ratio(d, 'SQ_WAIT_INST_LDS', 'SQ_WAVE_CYCLES'),
       ratio(d, 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'), ta))
 # ---- executed / nominal MFMA FLOPs per kernel family
+def is_avg(k):
+  """conv_mfma_kernel<NB,PT,MINB,SLAB,WAVES,SPLIT,SIDE_POOL,AVG[,WIDE]>: the pooled-heads variant."""
+  m = re.search(r'conv_mfma_kernel<([\d,]+)>', short(k))
+  a = m.group(1).split(',') if m else []
+  return len(a) >= 8 and a[7] == '1'
+
+
 FAMILIES = [   # (kernel-name test, op-trace label test, title)
     (lambda k: 'stem_a_kernel' in k, lambda l: 'stem_a ' in l, 'stem_a'),
     (lambda k: 'stem_b_kernel' in k, lambda l: 'stem_b ' in l, 'stem_b'),
     (lambda k: 'conv_pool_resident' in k, lambda l: '-> maxpool3s2' in l and 'resident' in l, 'conv_pool_resident (3x3 80->192 + pool)'),
     (lambda k: 'chain_kernel' in k, lambda l: l.startswith('chain '), 'chain_kernel (all)'),
     (lambda k: 'imgconv_kernel' in k, lambda l: '[imgconv' in l, 'imgconv_kernel (all)'),
-    (lambda k: 'conv_mfma_kernel' in k and short(k).endswith(',1>'), lambda l: 'avgpool3s1 in the epilogue' in l,
+    (lambda k: 'conv_mfma_kernel' in k and is_avg(k), lambda l: 'avgpool3s1 in the epilogue' in l,
      'conv_mfma<4,2,...,AVG> (pooled heads)'),
-    (lambda k: 'conv_mfma_kernel' in k and not short(k).endswith(',1>') or 'conv_first_u8' in k or 'conv_resident_kernel' in k
+    (lambda k: 'conv_mfma_kernel' in k and not is_avg(k) or 'conv_first_u8' in k or 'conv_resident_kernel' in k
      or 'conv_pool1x1' in k,
      lambda l: l.startswith('conv') and 'avgpool3s1 in the epilogue' not in l and '[imgconv' not in l and
      not ('-> maxpool3s2' in l and 'resident' in l), 'conv_mfma (every other variant) + conv_first_u8'),
